@@ -1,0 +1,179 @@
+/*
+ * hipvol.h — C ABI of libpyslam_hipvol.so, the MI355X-native (gfx950) volumetric fusion library.
+ *
+ * This is the drop-in boundary for pySLAM's dense-mapping hot path.  Each entry point states the
+ * reference interface it replaces (paths relative to the pySLAM tree):
+ *
+ *   VOXEL_GRID mode  == the `volumetric` pybind11 module's VoxelBlockGrid
+ *                       (cpp/volumetric/volumetric_grid_module.h:732-935, voxel_block_grid.h:61-234)
+ *   TSDF mode        == open3d.pipelines.integration.ScalableTSDFVolume as pySLAM drives it
+ *                       (pyslam/dense/volumetric_integrator_tsdf.py:104-108, 215-223, 239-267)
+ *
+ * Conventions
+ *   - plain C types only; all pointers are borrowed for the duration of the call;
+ *   - every function returns HV_OK (0) or a negative hv_status; hv_last_error() gives the message
+ *     of the last failure on the calling thread (mirrors the std::runtime_error text the pybind
+ *     module would raise, e.g. "points must be a contiguous Nx3 array");
+ *   - `loc` says where the *input/output arrays* live: HV_HOST (the library stages them through
+ *     HBM itself) or HV_DEVICE (already resident in HBM on the volume's device; zero-copy);
+ *   - a volume is owned by one host thread at a time (pySLAM runs all volume access on the single
+ *     thread of its VolumetricIntegratorProcess, volumetric_integrator_base.py:789-967);
+ *   - all GPU work is enqueued on the volume's HIP stream; calls that return data to the host
+ *     synchronise that stream, the integrate calls do not.
+ *   - there is NO CPU fallback: hv_create fails if no gfx950 device is usable.
+ */
+#ifndef PYSLAM_HIPVOL_H
+#define PYSLAM_HIPVOL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hv_volume hv_volume;
+
+typedef enum hv_status {
+    HV_OK = 0,
+    HV_ERR_INVALID = -1,   /* bad argument (message mirrors the pybind module's) */
+    HV_ERR_DEVICE = -2,    /* HIP runtime failure / no gfx950 device */
+    HV_ERR_CAPACITY = -3,  /* block pool, hash table or scratch capacity exceeded */
+    HV_ERR_MODE = -4       /* call not valid for this volume's mode */
+} hv_status;
+
+/* Values match pySLAM's VolumetricIntegratorType (pyslam/dense/volumetric_integrator_types.py:8-21). */
+typedef enum hv_mode { HV_MODE_VOXEL_GRID = 0, HV_MODE_TSDF = 3 } hv_mode;
+typedef enum hv_loc { HV_HOST = 0, HV_DEVICE = 1 } hv_loc;
+typedef enum hv_color_dtype { HV_COLOR_NONE = 0, HV_COLOR_U8 = 1, HV_COLOR_F32 = 2 } hv_color_dtype;
+typedef enum hv_depth_dtype { HV_DEPTH_F32 = 0, HV_DEPTH_U16 = 1 } hv_depth_dtype;
+
+typedef struct hv_config {
+    int32_t mode;          /* hv_mode */
+    int32_t device;        /* HIP device ordinal */
+    /* VOXEL_GRID: VoxelBlockGrid(voxel_size: float, block_size=8) — voxel_block_grid.hpp:4-9.
+     * TSDF: ScalableTSDFVolume(voxel_length, sdf_trunc, RGB8, volume_unit_resolution=16,
+     *       depth_sampling_stride=4) — volumetric_integrator_tsdf.py:104-108. */
+    double voxel_size;     /* metres (narrowed to float in VOXEL_GRID mode, as pybind does) */
+    double sdf_trunc;      /* TSDF only */
+    int32_t block_size;    /* voxels per block side: 8 (VOXEL_GRID) / 16 (TSDF unit resolution) */
+    int32_t depth_sampling_stride; /* TSDF only (Open3D default 4) */
+    int64_t max_blocks;    /* block/unit pool capacity (HBM = max_blocks * bytes_per_block) */
+    int64_t max_points;    /* largest point batch / H*W accepted by one integrate call */
+} hv_config;
+
+/* Camera: pinhole intrinsics {fx, fy, cx, cy} as doubles and T_cw (world->camera) as a row-major
+ * 4x4 double — exactly what pySLAM hands over (keyframe.pose(), volumetric_integrator_base.py:116). */
+
+const char *hv_last_error(void);
+int hv_device_count(void);                       /* usable gfx950 devices, or negative hv_status */
+void hv_default_config(int32_t mode, hv_config *cfg);
+
+int hv_create(const hv_config *cfg, hv_volume **out);
+void hv_destroy(hv_volume *v);
+int hv_reset(hv_volume *v);                      /* VoxelBlockGrid.clear()/reset(), ScalableTSDFVolume.reset() */
+int hv_synchronize(hv_volume *v);
+int hv_set_stream(hv_volume *v, void *hip_stream); /* adopt a caller-owned hipStream_t (e.g. a torch stream) */
+void *hv_get_stream(hv_volume *v);
+
+/* ---- common introspection (volumetric_grid_module.h:761-812) ---------------------------------- */
+int hv_num_blocks(hv_volume *v, int64_t *n);     /* num_blocks() / number of TSDF volume units */
+int hv_block_size(hv_volume *v, int32_t *bs);    /* get_block_size() */
+int hv_bytes_per_block(hv_volume *v, int64_t *bytes);
+int hv_dropped_points(hv_volume *v, int64_t *n); /* points/pixels rejected because their block key fell
+                                                    outside the +/-2^20 packed range (never for sane maps) */
+
+/* ---- VOXEL_GRID mode ---------------------------------------------------------------------------
+ * hv_integrate_points == VoxelBlockGrid.integrate(points f32 [N,3], colors u8|f32 [N,3] | None)
+ *   (volumetric_grid_module.h:743-749 -> integrate_raw, voxel_block_grid.hpp:115-136).
+ *   Result is bit-identical to the reference's sequential (point-index-order) accumulation. */
+int hv_integrate_points(hv_volume *v, const float *points, int64_t n, const void *colors,
+                        int32_t color_dtype, int32_t loc);
+
+/* Fused L3 prep + integrate for one posed RGB-D frame: depth2pointcloud (pyslam/utilities/depth.py:
+ * 45-85) + world transform (volumetric_integrator_voxel_grid.py:262-281) + integrate, without the
+ * host round trip.  rgb is H*W*3 u8 (already RGB), depth H*W f32 metres (or u16 * depth_scale^-1).
+ * Pixels with depth <= min_depth or >= max_depth are skipped (depth.py:64). */
+int hv_integrate_rgbd_points(hv_volume *v, const void *depth, int32_t depth_dtype, double depth_scale,
+                             const uint8_t *rgb, int32_t height, int32_t width, const double *intr,
+                             const double *T_cw, double min_depth, double max_depth, int32_t loc);
+
+/* get_voxels(min_count, min_confidence) (voxel_block_grid.hpp:717-819): rows = sum / count.
+ * Pass points == NULL to query *n only.  At most `cap` rows are written; *n is the full count. */
+int hv_get_voxels(hv_volume *v, int32_t min_count, float min_confidence, float *points,
+                  float *colors, int64_t cap, int64_t *n, int32_t loc);
+/* get_voxels_in_bb (voxel_block_grid.hpp:822-1016); bbox = {min x,y,z, max x,y,z}. */
+int hv_get_voxels_in_bb(hv_volume *v, const double *bbox, int32_t min_count, float min_confidence,
+                        float *points, float *colors, int64_t cap, int64_t *n, int32_t loc);
+/* get_voxels_in_camera_frustrum (voxel_block_grid.hpp:1019-1195); CameraFrustrum(fx,fy,cx,cy f32,
+ * width, height, T_cw, depth_max, depth_min) (camera_frustrum.h:37-130). */
+int hv_get_voxels_in_frustum(hv_volume *v, const float *intr_f32, int32_t width, int32_t height,
+                             const double *T_cw, float depth_max, float depth_min, int32_t min_count,
+                             float min_confidence, float *points, float *colors, int64_t cap,
+                             int64_t *n, int32_t loc);
+/* carve(camera_frustrum, depth_image f32 HxW, depth_threshold) (voxel_grid_carving.h:47-79). */
+int hv_carve(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw,
+             float depth_max, float depth_min, const float *depth, float depth_threshold, int32_t loc);
+int hv_remove_low_count_voxels(hv_volume *v, int32_t min_count); /* voxel_block_grid.hpp:625-646 */
+int hv_size(hv_volume *v, int64_t *n);           /* size()/get_total_voxel_count(): voxels with count>0 */
+
+/* Parity/debug export: all blocks sorted by (x,y,z) key.  keys [B,3] i32; hashes [B] u64 =
+ * BlockKeyHash (voxel_hashing.h:106-113); counts [B,bs^3] i32; sums [B,bs^3,6] f32 (position_sum,
+ * color_sum); voxel order inside a block = lx + ly*bs + lz*bs^2 (voxel_block.h:67-70).  Host
+ * pointers; any may be NULL.  *n_blocks receives B. */
+int hv_dump_blocks(hv_volume *v, int32_t *keys, uint64_t *hashes, int32_t *counts, float *sums,
+                   int64_t *n_blocks);
+/* K2 parity probe: key arithmetic of voxel_hashing.h:69-75,139-161 for N f32 points (host arrays). */
+int hv_keys_from_points(hv_volume *v, const float *points, int64_t n, int32_t *voxel_keys,
+                        int32_t *block_keys, int32_t *local_keys, uint64_t *block_hashes);
+
+/* ---- TSDF mode ---------------------------------------------------------------------------------
+ * hv_tsdf_integrate == RGBDImage.create_from_color_and_depth(color, depth, depth_scale,
+ *   depth_trunc, convert_rgb_to_intensity=False) + volume.integrate(rgbd, intrinsic, T_cw)
+ *   (volumetric_integrator_tsdf.py:215-223). */
+int hv_tsdf_integrate(hv_volume *v, const void *depth, int32_t depth_dtype, const uint8_t *rgb,
+                      int32_t height, int32_t width, const double *intr, const double *T_cw,
+                      double depth_scale, double depth_trunc, int32_t loc);
+
+/* Batched replay of F posed frames resident in HBM (rebuild(), volumetric_integrator_base.py:
+ * 1242-1318): identical results to F successive hv_tsdf_integrate calls.  depth: F*H*W, rgb:
+ * F*H*W*3, T_cw: F*16 (host array). */
+int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype, const uint8_t *rgb,
+                            int32_t n_frames, int32_t height, int32_t width, const double *intr,
+                            const double *T_cw, double depth_scale, double depth_trunc, int32_t loc);
+
+/* extract_triangle_mesh() (volumetric_integrator_tsdf.py:239,260).  vertices/vertex_colors f64
+ * [V,3] (colours in [0,1]); triangles i32 [T,3].  NULL arrays = size query.  Host pointers. */
+int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, int64_t cap_vertices,
+                         int32_t *triangles, int64_t cap_triangles, int64_t *n_vertices,
+                         int64_t *n_triangles);
+/* extract_point_cloud() (volumetric_integrator_tsdf.py:246,267): points/colors f64 [N,3]. */
+int hv_tsdf_extract_points(hv_volume *v, double *points, double *colors, int64_t cap, int64_t *n);
+
+/* Parity/debug export, units sorted by (x,y,z) index: keys [U,3] i32; tsdf, weight [U,R^3] f32;
+ * color [U,R^3,3] f64 = running-mean RGB on the 0..255 scale; voxel order = Open3D's IndexOf
+ * x*R^2 + y*R + z.  Host pointers; any may be NULL. */
+int hv_tsdf_dump(hv_volume *v, int32_t *keys, float *tsdf, float *weight, double *color,
+                 int64_t *n_units);
+/* Unit indices touched by the most recent hv_tsdf_integrate, sorted; keys may be NULL. */
+int hv_tsdf_touched(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n);
+
+/* Multi-GPU merge support: export/import additive numerators of the listed units.
+ * keys [K,3] i32 host; payload [K, R^3, 5] f32 = {sum_tsdf_w, weight, sum_r, sum_g, sum_b}; units
+ * absent from the volume export zeros; import REPLACES the unit's state from merged numerators
+ * (allocating the unit if needed).  payload lives at `loc`. */
+int hv_tsdf_export_numerators(hv_volume *v, const int32_t *keys, int64_t k, float *payload, int32_t loc);
+int hv_tsdf_import_numerators(hv_volume *v, const int32_t *keys, int64_t k, const float *payload, int32_t loc);
+/* All allocated unit keys (unsorted) for the key all-gather; keys may be NULL. */
+int hv_tsdf_unit_keys(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n);
+
+/* ---- measurement hooks (bench.py) ---------------------------------------------------------------
+ * When enabled, the dominant kernel of each integrate call is bracketed by HIP events on the
+ * volume's stream; hv_profile_read synchronises and returns the summed device time. */
+int hv_profile_enable(hv_volume *v, int32_t on);
+int hv_profile_read(hv_volume *v, double *kernel_ms_total, int64_t *kernel_launches,
+                    int64_t *units_processed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYSLAM_HIPVOL_H */

@@ -1,0 +1,510 @@
+/*
+ * TEST INFRASTRUCTURE ONLY — CPU restatement ("port") of the TSDF mode of pySLAM's dense path.
+ *
+ * PARITY UNPINNED.  pySLAM's VolumetricIntegratorType.TSDF delegates all arithmetic to the
+ * third-party Open3D library (o3d.pipelines.integration.ScalableTSDFVolume; pinned by the
+ * reference to git 02674268f706be4b004bbbf3d39b95fa9de35f74, scripts/install_open3d_python.sh:118,
+ * or conda open3d 0.19.0, pixi.lock:539).  Open3D is neither vendored under /root/reference nor
+ * installed in this image, and the reference holds no test that pins values at that boundary.
+ * This file restates Open3D's published algorithm (ScalableTSDFVolume / UniformTSDFVolume /
+ * MarchingCubesConst) operation by operation; the hand-derived known-answer tests in
+ * tests/test_tsdf_oracle_kat.py are the only anchor.  Reference call sites (the contract):
+ *   ctor                  pyslam/dense/volumetric_integrator_tsdf.py:104-108
+ *   intrinsic             :112-119
+ *   RGBDImage.create...   :215-221   (depth_scale, depth_trunc, convert_rgb_to_intensity=False)
+ *   integrate(rgbd,K,Tcw) :223
+ *   extract_triangle_mesh :239, :260
+ *   extract_point_cloud   :246, :267
+ *   reset                 :156
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * Compile with -ffp-contract=off: every float/double op below is exactly one IEEE operation, in
+ * the order written (matrix-vector products accumulate left to right: ((m0*x + m1*y) + m2*z) + m3).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mc_tables.h" /* pyslam_amd/csrc/mc_tables.h via -I; validated by tools/gen_mc_tables.py */
+
+typedef struct {
+    float tsdf;      /* TSDFVoxel::tsdf_   = 0 */
+    float weight;    /* TSDFVoxel::weight_ = 0 */
+    double color[3]; /* TSDFVoxel::color_  = 0, running mean of the 0..255 RGB values */
+} to_voxel;
+
+typedef struct {
+    int32_t index[3]; /* VolumeUnit::index_ */
+    to_voxel *voxels; /* res^3, IndexOf(x,y,z) = x*res*res + y*res + z */
+    int64_t touched_frame;
+} to_unit;
+
+typedef struct {
+    double voxel_length, sdf_trunc, unit_length;
+    int res, stride, threads;
+    to_unit *units;
+    int64_t num_units, cap_units;
+    int64_t *table;
+    int64_t table_size;
+    int64_t frame;
+    int64_t *touched; /* indices of units touched by the last integrate(), in touch order */
+    int64_t num_touched, cap_touched;
+} to_volume;
+
+static uint64_t to_mix(int32_t x, int32_t y, int32_t z) {
+    uint64_t h = (uint64_t)(uint32_t)x * 0x9E3779B97F4A7C15ull;
+    h ^= (uint64_t)(uint32_t)y * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+    h ^= (uint64_t)(uint32_t)z * 0x165667B19E3779F9ull + (h << 6) + (h >> 2);
+    return h ^ (h >> 29);
+}
+
+static void to_table_rebuild(to_volume *v, int64_t new_size) {
+    free(v->table);
+    v->table_size = new_size;
+    v->table = (int64_t *)malloc(sizeof(int64_t) * (size_t)new_size);
+    for (int64_t i = 0; i < new_size; ++i) v->table[i] = -1;
+    for (int64_t u = 0; u < v->num_units; ++u) {
+        const int32_t *k = v->units[u].index;
+        uint64_t s = to_mix(k[0], k[1], k[2]) & (uint64_t)(new_size - 1);
+        while (v->table[s] >= 0) s = (s + 1) & (uint64_t)(new_size - 1);
+        v->table[s] = u;
+    }
+}
+
+/* ScalableTSDFVolume(voxel_length, sdf_trunc, RGB8, volume_unit_resolution=16,
+ * depth_sampling_stride=4): volume_unit_length_ = voxel_length * volume_unit_resolution. */
+to_volume *to_create(double voxel_length, double sdf_trunc, int unit_resolution, int stride) {
+    to_volume *v = (to_volume *)calloc(1, sizeof(to_volume));
+    v->voxel_length = voxel_length;
+    v->sdf_trunc = sdf_trunc;
+    v->res = unit_resolution;
+    v->stride = stride;
+    v->unit_length = voxel_length * (double)unit_resolution;
+    v->threads = 1;
+    to_table_rebuild(v, 1024);
+    return v;
+}
+
+void to_set_threads(to_volume *v, int threads) { v->threads = threads < 1 ? 1 : threads; }
+
+void to_reset(to_volume *v) { /* ScalableTSDFVolume::Reset(): volume_units_.clear() */
+    for (int64_t u = 0; u < v->num_units; ++u) free(v->units[u].voxels);
+    v->num_units = 0;
+    v->num_touched = 0;
+    to_table_rebuild(v, 1024);
+}
+
+void to_destroy(to_volume *v) {
+    if (!v) return;
+    to_reset(v);
+    free(v->units);
+    free(v->table);
+    free(v->touched);
+    free(v);
+}
+
+static int64_t to_find(const to_volume *v, int32_t x, int32_t y, int32_t z) {
+    uint64_t s = to_mix(x, y, z) & (uint64_t)(v->table_size - 1);
+    while (v->table[s] >= 0) {
+        const int32_t *k = v->units[v->table[s]].index;
+        if (k[0] == x && k[1] == y && k[2] == z) return v->table[s];
+        s = (s + 1) & (uint64_t)(v->table_size - 1);
+    }
+    return -1;
+}
+
+/* OpenVolumeUnit(index): find or create a zero-initialised unit. */
+static int64_t to_open_unit(to_volume *v, int32_t x, int32_t y, int32_t z) {
+    int64_t u = to_find(v, x, y, z);
+    if (u >= 0) return u;
+    if (v->num_units == v->cap_units) {
+        v->cap_units = v->cap_units ? v->cap_units * 2 : 256;
+        v->units = (to_unit *)realloc(v->units, sizeof(to_unit) * (size_t)v->cap_units);
+    }
+    u = v->num_units++;
+    v->units[u].index[0] = x; v->units[u].index[1] = y; v->units[u].index[2] = z;
+    v->units[u].voxels = (to_voxel *)calloc((size_t)v->res * v->res * v->res, sizeof(to_voxel));
+    v->units[u].touched_frame = -1;
+    if (v->num_units * 2 > v->table_size) {
+        to_table_rebuild(v, v->table_size * 2);
+    } else {
+        uint64_t s = to_mix(x, y, z) & (uint64_t)(v->table_size - 1);
+        while (v->table[s] >= 0) s = (s + 1) & (uint64_t)(v->table_size - 1);
+        v->table[s] = u;
+    }
+    return u;
+}
+
+/* General 4x4 inverse by cofactors (adjugate / determinant), double, row-major.  Stands in for
+ * Eigen's extrinsic.inverse() in CreatePointCloudFromFloatDepthImage. */
+void to_invert4x4(const double *m, double *out) {
+    double inv[16];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    const double inv_det = 1.0 / det;
+    for (int i = 0; i < 16; ++i) out[i] = inv[i] * inv_det;
+}
+
+typedef struct {
+    const float *depth;  /* H*W, metres, after ConvertDepthToFloatImage */
+    const uint8_t *rgb;  /* H*W*3 */
+    int H, W;
+    float fx, fy, cx, cy; /* static_cast<float>(intrinsic...) */
+    float ext[16];        /* extrinsic.cast<float>() row-major */
+    float ext_scaled_col2[3];
+    float voxel_length_f, half_voxel_length_f, sdf_trunc_f, sdf_trunc_inv_f;
+    float safe_width_f, safe_height_f;
+    float ffl_inv[2], fpp[2]; /* CreateDepthToCameraDistanceMultiplierFloatImage operands */
+} to_frame;
+
+/* Image::CreateDepthToCameraDistanceMultiplierFloatImage: sqrtf(xx*xx + yy*yy + 1), with
+ * xx[j] = (j - cx_f) * (1/fx_f), all float. */
+static inline float to_multiplier(const to_frame *f, int u, int v) {
+    const float xx = ((float)u - f->fpp[0]) * f->ffl_inv[0];
+    const float yy = ((float)v - f->fpp[1]) * f->ffl_inv[1];
+    return sqrtf(xx * xx + yy * yy + 1.0f);
+}
+
+/* UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier for one unit. */
+static void to_integrate_unit(const to_volume *vol, to_unit *unit, const to_frame *f) {
+    const int R = vol->res;
+    const double origin[3] = {(double)unit->index[0] * vol->unit_length,
+                              (double)unit->index[1] * vol->unit_length,
+                              (double)unit->index[2] * vol->unit_length};
+    for (int x = 0; x < R; ++x) {
+        for (int y = 0; y < R; ++y) {
+            /* float(half + vl * x + origin) : float product, float sum, then double add, cast */
+            const float p0 = (float)((double)(f->half_voxel_length_f + f->voxel_length_f * (float)x) + origin[0]);
+            const float p1 = (float)((double)(f->half_voxel_length_f + f->voxel_length_f * (float)y) + origin[1]);
+            const float p2 = (float)((double)f->half_voxel_length_f + origin[2]);
+            float pc[3];
+            for (int r = 0; r < 3; ++r) {
+                pc[r] = ((f->ext[r * 4 + 0] * p0 + f->ext[r * 4 + 1] * p1) + f->ext[r * 4 + 2] * p2) + f->ext[r * 4 + 3] * 1.0f;
+            }
+            for (int z = 0; z < R; ++z, pc[0] += f->ext_scaled_col2[0], pc[1] += f->ext_scaled_col2[1], pc[2] += f->ext_scaled_col2[2]) {
+                if (pc[2] <= 0.0f) continue;
+                const float u_f = pc[0] * f->fx / pc[2] + f->cx + 0.5f;
+                const float v_f = pc[1] * f->fy / pc[2] + f->cy + 0.5f;
+                if (!(u_f >= 0.0001f && u_f < f->safe_width_f && v_f >= 0.0001f && v_f < f->safe_height_f)) continue;
+                const int u = (int)u_f;
+                const int v = (int)v_f;
+                const float d = f->depth[(int64_t)v * f->W + u];
+                if (d <= 0.0f) continue;
+                const float sdf = (d - pc[2]) * to_multiplier(f, u, v);
+                if (sdf > -f->sdf_trunc_f) {
+                    float tsdf = sdf * f->sdf_trunc_inv_f;
+                    if (tsdf > 1.0f) tsdf = 1.0f; /* std::min(1.0f, sdf * inv) */
+                    to_voxel *vx = &unit->voxels[(x * R + y) * R + z];
+                    const uint8_t *rgb = f->rgb + ((int64_t)v * f->W + u) * 3;
+                    const double w = (double)vx->weight;
+                    const double wp1 = (double)(vx->weight + 1.0f);
+                    for (int c = 0; c < 3; ++c) vx->color[c] = (vx->color[c] * w + (double)rgb[c]) / wp1;
+                    vx->tsdf = (vx->tsdf * vx->weight + tsdf) / (vx->weight + 1.0f);
+                    vx->weight += 1.0f;
+                }
+            }
+        }
+    }
+}
+
+/* RGBDImage::CreateFromColorAndDepth + ScalableTSDFVolume::Integrate.
+ * depth_kind 0: float32 image, 1: uint16 image (CreateFloatImage casts to float first).
+ * intr = {fx, fy, cx, cy} (double, as PinholeCameraIntrinsic stores them). */
+void to_integrate(to_volume *vol, const void *depth_in, int depth_kind, const uint8_t *rgb, int H,
+                  int W, const double *intr, const double *extrinsic, double depth_scale,
+                  double depth_trunc) {
+    const int64_t npx = (int64_t)H * W;
+    float *depth = (float *)malloc(sizeof(float) * (size_t)npx);
+    /* Image::ConvertDepthToFloatImage: *p /= (float)depth_scale; if (*p >= depth_trunc) *p = 0 */
+    for (int64_t i = 0; i < npx; ++i) {
+        float p = depth_kind == 1 ? (float)((const uint16_t *)depth_in)[i] : ((const float *)depth_in)[i];
+        p /= (float)depth_scale;
+        if ((double)p >= depth_trunc) p = 0.0f;
+        depth[i] = p;
+    }
+
+    to_frame f;
+    f.depth = depth; f.rgb = rgb; f.H = H; f.W = W;
+    f.fx = (float)intr[0]; f.fy = (float)intr[1]; f.cx = (float)intr[2]; f.cy = (float)intr[3];
+    for (int i = 0; i < 16; ++i) f.ext[i] = (float)extrinsic[i];
+    f.voxel_length_f = (float)vol->voxel_length;
+    f.half_voxel_length_f = f.voxel_length_f * 0.5f;
+    f.sdf_trunc_f = (float)vol->sdf_trunc;
+    f.sdf_trunc_inv_f = 1.0f / f.sdf_trunc_f;
+    for (int r = 0; r < 3; ++r) f.ext_scaled_col2[r] = f.ext[r * 4 + 2] * f.voxel_length_f;
+    f.safe_width_f = (float)W - 0.0001f;
+    f.safe_height_f = (float)H - 0.0001f;
+    f.ffl_inv[0] = 1.0f / (float)intr[0]; f.ffl_inv[1] = 1.0f / (float)intr[1];
+    f.fpp[0] = (float)intr[2]; f.fpp[1] = (float)intr[3];
+
+    /* PointCloud::CreateFromDepthImage(depth, intrinsic, extrinsic, 1000, 1000, stride): float
+     * depth image branch -> CreatePointCloudFromFloatDepthImage, double arithmetic. */
+    double pose[16];
+    to_invert4x4(extrinsic, pose);
+    vol->frame += 1;
+    vol->num_touched = 0;
+    for (int i = 0; i < H; i += vol->stride) {
+        for (int j = 0; j < W; j += vol->stride) {
+            const float p = depth[(int64_t)i * W + j];
+            if (!(p > 0)) continue;
+            const double z = (double)p;
+            const double x = ((double)j - intr[2]) * z / intr[0];
+            const double y = ((double)i - intr[3]) * z / intr[1];
+            double pw[3];
+            for (int r = 0; r < 3; ++r)
+                pw[r] = ((pose[r * 4 + 0] * x + pose[r * 4 + 1] * y) + pose[r * 4 + 2] * z) + pose[r * 4 + 3] * 1.0;
+            /* LocateVolumeUnit(point -/+ sdf_trunc): (int)floor(p / volume_unit_length_) */
+            int32_t lo[3], hi[3];
+            for (int r = 0; r < 3; ++r) {
+                lo[r] = (int32_t)floor((pw[r] - vol->sdf_trunc) / vol->unit_length);
+                hi[r] = (int32_t)floor((pw[r] + vol->sdf_trunc) / vol->unit_length);
+            }
+            for (int32_t ux = lo[0]; ux <= hi[0]; ++ux)
+                for (int32_t uy = lo[1]; uy <= hi[1]; ++uy)
+                    for (int32_t uz = lo[2]; uz <= hi[2]; ++uz) {
+                        const int64_t u = to_open_unit(vol, ux, uy, uz);
+                        if (vol->units[u].touched_frame == vol->frame) continue;
+                        vol->units[u].touched_frame = vol->frame;
+                        if (vol->num_touched == vol->cap_touched) {
+                            vol->cap_touched = vol->cap_touched ? vol->cap_touched * 2 : 1024;
+                            vol->touched = (int64_t *)realloc(vol->touched, sizeof(int64_t) * (size_t)vol->cap_touched);
+                        }
+                        vol->touched[vol->num_touched++] = u;
+                    }
+        }
+    }
+    /* each touched unit is integrated exactly once per frame; units are independent */
+#pragma omp parallel for schedule(dynamic, 4) num_threads(vol->threads) if (vol->threads > 1)
+    for (int64_t t = 0; t < vol->num_touched; ++t) {
+        to_integrate_unit(vol, &vol->units[vol->touched[t]], &f);
+    }
+    free(depth);
+}
+
+int64_t to_num_units(const to_volume *v) { return v->num_units; }
+int64_t to_num_touched(const to_volume *v) { return v->num_touched; }
+
+static int to_cmp_key(const int32_t *a, const int32_t *b) {
+    for (int k = 0; k < 3; ++k)
+        if (a[k] != b[k]) return a[k] < b[k] ? -1 : 1;
+    return 0;
+}
+static const to_volume *g_sort_vol;
+static int to_cmp_unit_idx(const void *pa, const void *pb) {
+    return to_cmp_key(g_sort_vol->units[*(const int64_t *)pa].index, g_sort_vol->units[*(const int64_t *)pb].index);
+}
+
+/* Unit keys touched by the last integrate(), sorted by (x,y,z); returns the count. */
+int64_t to_touched_keys(const to_volume *v, int32_t *keys) {
+    int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * (size_t)(v->num_touched ? v->num_touched : 1));
+    memcpy(idx, v->touched, sizeof(int64_t) * (size_t)v->num_touched);
+    g_sort_vol = v;
+    qsort(idx, (size_t)v->num_touched, sizeof(int64_t), to_cmp_unit_idx);
+    for (int64_t t = 0; t < v->num_touched; ++t) memcpy(keys + t * 3, v->units[idx[t]].index, 12);
+    free(idx);
+    return v->num_touched;
+}
+
+/* All units sorted by key.  tsdf/weight: U*res^3 float; color: U*res^3*3 double (0..255 scale);
+ * voxel order = Open3D's IndexOf: x*res^2 + y*res + z.  Null outputs are skipped. */
+int64_t to_dump(const to_volume *v, int32_t *keys, float *tsdf, float *weight, double *color) {
+    const int64_t nu = v->num_units;
+    int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nu ? nu : 1));
+    for (int64_t u = 0; u < nu; ++u) idx[u] = u;
+    g_sort_vol = v;
+    qsort(idx, (size_t)nu, sizeof(int64_t), to_cmp_unit_idx);
+    const int64_t nv = (int64_t)v->res * v->res * v->res;
+    for (int64_t u = 0; u < nu; ++u) {
+        const to_unit *unit = &v->units[idx[u]];
+        if (keys) memcpy(keys + u * 3, unit->index, 12);
+        for (int64_t i = 0; i < nv; ++i) {
+            if (tsdf) tsdf[u * nv + i] = unit->voxels[i].tsdf;
+            if (weight) weight[u * nv + i] = unit->voxels[i].weight;
+            if (color) memcpy(color + (u * nv + i) * 3, unit->voxels[i].color, 24);
+        }
+    }
+    free(idx);
+    return nu;
+}
+
+/* voxel lookup across unit borders; returns 0 and w=f=0 if the neighbour unit does not exist */
+static int to_fetch(const to_volume *v, const to_unit *unit0, int x, int y, int z, float *w, float *f, double *c) {
+    const int R = v->res;
+    const to_unit *unit = unit0;
+    if (x >= R || y >= R || z >= R) {
+        int32_t k[3] = {unit0->index[0], unit0->index[1], unit0->index[2]};
+        if (x >= R) { x -= R; k[0] += 1; }
+        if (y >= R) { y -= R; k[1] += 1; }
+        if (z >= R) { z -= R; k[2] += 1; }
+        const int64_t u = to_find(v, k[0], k[1], k[2]);
+        if (u < 0) { *w = 0.0f; *f = 0.0f; return 0; }
+        unit = &v->units[u];
+    }
+    const to_voxel *vx = &unit->voxels[(x * R + y) * R + z];
+    *w = vx->weight; *f = vx->tsdf;
+    if (c) { c[0] = vx->color[0]; c[1] = vx->color[1]; c[2] = vx->color[2]; }
+    return 1;
+}
+
+/* ---- vertex de-duplication map: (gx, gy, gz, axis) -> vertex index --------------------------- */
+typedef struct { int32_t k[4]; int32_t val; } to_edge_ent;
+typedef struct { to_edge_ent *e; int64_t size, used; } to_edge_map;
+
+static uint64_t to_mix4(const int32_t *k) { return to_mix(k[0], k[1], k[2]) * 4 + (uint64_t)k[3]; }
+static void to_edge_map_init(to_edge_map *m, int64_t size) {
+    m->size = size; m->used = 0;
+    m->e = (to_edge_ent *)malloc(sizeof(to_edge_ent) * (size_t)size);
+    for (int64_t i = 0; i < size; ++i) m->e[i].val = -1;
+}
+static int32_t *to_edge_map_slot(to_edge_map *m, const int32_t *k) {
+    if (m->used * 2 >= m->size) {
+        to_edge_map n;
+        to_edge_map_init(&n, m->size * 2);
+        for (int64_t i = 0; i < m->size; ++i)
+            if (m->e[i].val >= 0) { *to_edge_map_slot(&n, m->e[i].k) = m->e[i].val; }
+        free(m->e);
+        *m = n;
+    }
+    uint64_t s = to_mix4(k) & (uint64_t)(m->size - 1);
+    while (m->e[s].val >= 0) {
+        if (memcmp(m->e[s].k, k, 16) == 0) return &m->e[s].val;
+        s = (s + 1) & (uint64_t)(m->size - 1);
+    }
+    memcpy(m->e[s].k, k, 16);
+    m->used++;
+    return &m->e[s].val; /* caller must set val >= 0 */
+}
+
+/* ScalableTSDFVolume::ExtractTriangleMesh.  vertices / vertex_colors: double [cap_v*3];
+ * triangles: int32 [cap_t*3].  Returns the vertex count, *n_tris the triangle count; arrays are
+ * filled up to their caps (pass nulls/0 to size).  Unit iteration order = insertion order here vs
+ * unordered_map order in Open3D: compare meshes as vertex/triangle sets. */
+int64_t to_extract_mesh(const to_volume *v, double *vertices, double *vertex_colors, int64_t cap_v,
+                        int32_t *triangles, int64_t cap_t, int64_t *n_tris) {
+    const int R = v->res;
+    const double half_voxel_length = v->voxel_length * 0.5;
+    to_edge_map map;
+    to_edge_map_init(&map, 1 << 16);
+    int64_t nv = 0, nt = 0;
+    int edge_to_index[12];
+    for (int64_t ui = 0; ui < v->num_units; ++ui) {
+        const to_unit *unit0 = &v->units[ui];
+        for (int x = 0; x < R; ++x)
+            for (int y = 0; y < R; ++y)
+                for (int z = 0; z < R; ++z) {
+                    int cube_index = 0;
+                    float w[8], f[8];
+                    double c[8][3];
+                    for (int i = 0; i < 8; ++i) {
+                        double craw[3] = {0, 0, 0};
+                        to_fetch(v, unit0, x + hv_mc_shift[i][0], y + hv_mc_shift[i][1], z + hv_mc_shift[i][2], &w[i], &f[i], craw);
+                        if (w[i] == 0.0f) { cube_index = 0; break; }
+                        for (int k = 0; k < 3; ++k) c[i][k] = craw[k] / 255.0; /* color_.cast<double>() / 255.0 */
+                        if (f[i] < 0.0f) cube_index |= (1 << i);
+                    }
+                    if (cube_index == 0 || cube_index == 255) continue;
+                    for (int i = 0; i < 12; ++i) {
+                        if (!(hv_mc_edge_table[cube_index] & (1 << i))) continue;
+                        int32_t edge_index[4];
+                        edge_index[0] = unit0->index[0] * R + x + hv_mc_edge_shift[i][0];
+                        edge_index[1] = unit0->index[1] * R + y + hv_mc_edge_shift[i][1];
+                        edge_index[2] = unit0->index[2] * R + z + hv_mc_edge_shift[i][2];
+                        edge_index[3] = hv_mc_edge_shift[i][3];
+                        int32_t *slot = to_edge_map_slot(&map, edge_index);
+                        if (*slot < 0) {
+                            *slot = (int32_t)nv;
+                            edge_to_index[i] = (int)nv;
+                            double pt[3] = {half_voxel_length + v->voxel_length * (double)edge_index[0],
+                                            half_voxel_length + v->voxel_length * (double)edge_index[1],
+                                            half_voxel_length + v->voxel_length * (double)edge_index[2]};
+                            const int e0 = hv_mc_edge_to_vert[i][0], e1 = hv_mc_edge_to_vert[i][1];
+                            const double f0 = fabs((double)f[e0]);
+                            const double f1 = fabs((double)f[e1]);
+                            pt[edge_index[3]] += f0 * v->voxel_length / (f0 + f1);
+                            if (vertices && nv < cap_v) {
+                                memcpy(vertices + nv * 3, pt, 24);
+                                if (vertex_colors)
+                                    for (int k = 0; k < 3; ++k)
+                                        vertex_colors[nv * 3 + k] = (f1 * c[e0][k] + f0 * c[e1][k]) / (f0 + f1);
+                            }
+                            ++nv;
+                        } else {
+                            edge_to_index[i] = *slot;
+                        }
+                    }
+                    for (int i = 0; hv_mc_tri_table[cube_index][i] != -1; i += 3) {
+                        if (triangles && nt < cap_t) {
+                            triangles[nt * 3 + 0] = edge_to_index[hv_mc_tri_table[cube_index][i]];
+                            triangles[nt * 3 + 1] = edge_to_index[hv_mc_tri_table[cube_index][i + 2]];
+                            triangles[nt * 3 + 2] = edge_to_index[hv_mc_tri_table[cube_index][i + 1]];
+                        }
+                        ++nt;
+                    }
+                }
+    }
+    free(map.e);
+    if (n_tris) *n_tris = nt;
+    return nv;
+}
+
+/* ScalableTSDFVolume::ExtractPointCloud (points + colours; normals are not consumed by pySLAM's
+ * VolumetricIntegrationPointCloud, volumetric_integrator_base.py:159-206, and are not restated). */
+int64_t to_extract_points(const to_volume *v, double *points, double *colors, int64_t cap) {
+    const int R = v->res;
+    const double half_voxel_length = v->voxel_length * 0.5;
+    int64_t n = 0;
+    for (int64_t ui = 0; ui < v->num_units; ++ui) {
+        const to_unit *unit0 = &v->units[ui];
+        for (int x = 0; x < R; ++x)
+            for (int y = 0; y < R; ++y)
+                for (int z = 0; z < R; ++z) {
+                    const to_voxel *v0 = &unit0->voxels[(x * R + y) * R + z];
+                    const float w0 = v0->weight, f0 = v0->tsdf;
+                    const float c0[3] = {(float)v0->color[0], (float)v0->color[1], (float)v0->color[2]};
+                    if (!(w0 != 0.0f && f0 < 0.98f && f0 >= -0.98f)) continue;
+                    const double p0[3] = {
+                        (half_voxel_length + v->voxel_length * (double)x) + (double)unit0->index[0] * v->unit_length,
+                        (half_voxel_length + v->voxel_length * (double)y) + (double)unit0->index[1] * v->unit_length,
+                        (half_voxel_length + v->voxel_length * (double)z) + (double)unit0->index[2] * v->unit_length};
+                    for (int i = 0; i < 3; ++i) {
+                        int idx1[3] = {x, y, z};
+                        idx1[i] += 1;
+                        const double p1i = p0[i] + v->voxel_length;
+                        float w1, f1;
+                        double c1d[3] = {0, 0, 0};
+                        to_fetch(v, unit0, idx1[0], idx1[1], idx1[2], &w1, &f1, c1d);
+                        if (w1 != 0.0f && f1 < 0.98f && f1 >= -0.98f && f0 * f1 < 0) {
+                            const float r0 = fabsf(f0), r1 = fabsf(f1);
+                            if (points && n < cap) {
+                                double p[3] = {p0[0], p0[1], p0[2]};
+                                p[i] = (p0[i] * (double)r1 + p1i * (double)r0) / (double)(r0 + r1);
+                                memcpy(points + n * 3, p, 24);
+                                if (colors)
+                                    for (int k = 0; k < 3; ++k) {
+                                        const float c1 = (float)c1d[k];
+                                        colors[n * 3 + k] = (double)((c0[k] * r1 + c1 * r0) / (r0 + r1) / 255.0f);
+                                    }
+                            }
+                            ++n;
+                        }
+                    }
+                }
+    }
+    return n;
+}

@@ -1,0 +1,488 @@
+/*
+ * TEST INFRASTRUCTURE ONLY — CPU restatement ("port") of pySLAM's cpp/volumetric VOXEL_GRID path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+ * product (pyslam_amd/) never does.  Parity status: PINNED against the real reference — every
+ * entry point below is compared with oracle/_ref/libref_volumetric.so (the unmodified reference
+ * sources compiled by oracle/Makefile) in tests/test_oracle_vs_reference.py, and with the
+ * committed fixtures under tests/golden/ that were generated from that library.
+ *
+ * Single-threaded, point-index-order accumulation == the reference's non-TBB sequential branches.
+ * Compile with -ffp-contract=off (oracle/Makefile): every float op below is one IEEE op.
+ *
+ * Reference citations are relative to /root/reference/cpp/volumetric/.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * Key arithmetic — voxel_hashing.h
+ * ---------------------------------------------------------------------------------------------- */
+
+/* get_voxel_key_inv<float,float>, voxel_hashing.h:69-75: (int32)floor(x * inv_voxel_size), f32. */
+static inline int32_t vo_key_f32(float x, float inv_voxel_size) {
+    return (int32_t)floorf(x * inv_voxel_size);
+}
+/* get_voxel_key_inv<double,double> with the float member promoted, voxel_block_grid.hpp:827-830. */
+static inline int32_t vo_key_f64(double x, float inv_voxel_size) {
+    return (int32_t)floor(x * (double)inv_voxel_size);
+}
+/* floor_div, voxel_hashing.h:139-142 (b > 0). */
+static inline int64_t vo_floor_div(int64_t a, int64_t b) {
+    return (a >= 0) ? (a / b) : ((a - b + 1) / b);
+}
+/* get_block_key, voxel_hashing.h:145-151. */
+static inline int32_t vo_block_of(int32_t v, int bs) { return (int32_t)vo_floor_div(v, bs); }
+/* get_local_voxel_key, voxel_hashing.h:154-161. */
+static inline int32_t vo_local_of(int32_t v, int32_t b, int bs) {
+    return (int32_t)((int64_t)v - (int64_t)b * (int64_t)bs);
+}
+/* BlockKeyHash, voxel_hashing.h:106-113, with libstdc++'s identity std::hash<int32_t> (the int is
+ * converted to size_t, i.e. sign-extended). */
+static inline uint64_t vo_block_hash(int32_t x, int32_t y, int32_t z) {
+    const uint64_t h1 = (uint64_t)(int64_t)x;
+    const uint64_t h2 = (uint64_t)(int64_t)y;
+    const uint64_t h3 = (uint64_t)(int64_t)z;
+    return h1 ^ (h2 << 1) ^ (h3 << 2);
+}
+
+void vo_keys(float voxel_size, int block_size, const float *pts, int64_t n, int32_t *voxel_keys,
+             int32_t *block_keys, int32_t *local_keys, uint64_t *block_hashes) {
+    const float inv = 1.0f / voxel_size; /* voxel_block_grid.hpp:6 */
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t b[3];
+        for (int k = 0; k < 3; ++k) {
+            const int32_t v = vo_key_f32(pts[i * 3 + k], inv);
+            b[k] = vo_block_of(v, block_size);
+            voxel_keys[i * 3 + k] = v;
+            block_keys[i * 3 + k] = b[k];
+            local_keys[i * 3 + k] = vo_local_of(v, b[k], block_size);
+        }
+        block_hashes[i] = vo_block_hash(b[0], b[1], b[2]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Voxel payload (voxel_data.h:118-133) and block container (voxel_block.h:45-89)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct {
+    int32_t count;
+    float position_sum[3];
+    float color_sum[3];
+} vo_voxel; /* 28 bytes, VoxelDataT<float,float> */
+
+typedef struct {
+    int32_t key[3];
+    vo_voxel *data; /* bs^3, index lx + ly*bs + lz*bs^2 (voxel_block.h:67-70) */
+} vo_block;
+
+typedef struct {
+    float voxel_size, inv_voxel_size;
+    int block_size, voxels_per_block;
+    vo_block *blocks; /* insertion order */
+    int64_t num_blocks, cap_blocks;
+    int64_t *table; /* open addressing: index into blocks or -1 */
+    int64_t table_size; /* power of two */
+} vo_grid;
+
+static uint64_t vo_mix(int32_t x, int32_t y, int32_t z) {
+    uint64_t h = (uint64_t)(uint32_t)x * 0x9E3779B97F4A7C15ull;
+    h ^= (uint64_t)(uint32_t)y * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+    h ^= (uint64_t)(uint32_t)z * 0x165667B19E3779F9ull + (h << 6) + (h >> 2);
+    return h ^ (h >> 29);
+}
+
+static void vo_table_rebuild(vo_grid *g, int64_t new_size) {
+    free(g->table);
+    g->table_size = new_size;
+    g->table = (int64_t *)malloc(sizeof(int64_t) * (size_t)new_size);
+    for (int64_t i = 0; i < new_size; ++i) g->table[i] = -1;
+    for (int64_t b = 0; b < g->num_blocks; ++b) {
+        const int32_t *k = g->blocks[b].key;
+        uint64_t s = vo_mix(k[0], k[1], k[2]) & (uint64_t)(new_size - 1);
+        while (g->table[s] >= 0) s = (s + 1) & (uint64_t)(new_size - 1);
+        g->table[s] = b;
+    }
+}
+
+vo_grid *vo_create(float voxel_size, int block_size) {
+    vo_grid *g = (vo_grid *)calloc(1, sizeof(vo_grid));
+    g->voxel_size = voxel_size;
+    g->inv_voxel_size = 1.0f / voxel_size; /* voxel_block_grid.hpp:5-6 */
+    g->block_size = block_size;
+    g->voxels_per_block = block_size * block_size * block_size;
+    vo_table_rebuild(g, 1024);
+    return g;
+}
+
+void vo_clear(vo_grid *g) { /* clear(), voxel_block_grid.hpp:1543 */
+    for (int64_t b = 0; b < g->num_blocks; ++b) free(g->blocks[b].data);
+    g->num_blocks = 0;
+    vo_table_rebuild(g, 1024);
+}
+
+void vo_destroy(vo_grid *g) {
+    if (!g) return;
+    vo_clear(g);
+    free(g->blocks);
+    free(g->table);
+    free(g);
+}
+
+/* blocks_.insert({key, Block(bs)}) — find or create, voxel_block_grid.hpp:481. */
+static vo_block *vo_find_or_create(vo_grid *g, int32_t bx, int32_t by, int32_t bz, int create) {
+    uint64_t s = vo_mix(bx, by, bz) & (uint64_t)(g->table_size - 1);
+    while (g->table[s] >= 0) {
+        vo_block *blk = &g->blocks[g->table[s]];
+        if (blk->key[0] == bx && blk->key[1] == by && blk->key[2] == bz) return blk;
+        s = (s + 1) & (uint64_t)(g->table_size - 1);
+    }
+    if (!create) return NULL;
+    if (g->num_blocks == g->cap_blocks) {
+        g->cap_blocks = g->cap_blocks ? g->cap_blocks * 2 : 256;
+        g->blocks = (vo_block *)realloc(g->blocks, sizeof(vo_block) * (size_t)g->cap_blocks);
+    }
+    vo_block *blk = &g->blocks[g->num_blocks];
+    blk->key[0] = bx; blk->key[1] = by; blk->key[2] = bz;
+    blk->data = (vo_voxel *)calloc((size_t)g->voxels_per_block, sizeof(vo_voxel));
+    g->table[s] = g->num_blocks++;
+    if (g->num_blocks * 2 > g->table_size) {
+        vo_table_rebuild(g, g->table_size * 2);
+        return &g->blocks[g->num_blocks - 1];
+    }
+    return blk;
+}
+
+/* integrate_raw<float, Tcolor> -> (no TBB) integrate_raw_baseline sequential branch
+ * (voxel_block_grid.hpp:221-287) -> update_voxel (:466-497) -> update_voxel_direct (:524-614).
+ * color_kind: 0 none, 1 uint8 (c * (1/255), voxel_data.h:81-85), 2 float32 (plain add). */
+void vo_integrate(vo_grid *g, const float *pts, int64_t n, const void *cols, int color_kind) {
+    const int bs = g->block_size;
+    const float inv_255 = 1.0f / 255.0f; /* voxel_data.h:82 */
+    for (int64_t i = 0; i < n; ++i) {
+        const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+        const int32_t vx = vo_key_f32(x, g->inv_voxel_size);
+        const int32_t vy = vo_key_f32(y, g->inv_voxel_size);
+        const int32_t vz = vo_key_f32(z, g->inv_voxel_size);
+        const int32_t bx = vo_block_of(vx, bs), by = vo_block_of(vy, bs), bz = vo_block_of(vz, bs);
+        const int32_t lx = vo_local_of(vx, bx, bs), ly = vo_local_of(vy, by, bs),
+                      lz = vo_local_of(vz, bz, bs);
+        vo_block *blk = vo_find_or_create(g, bx, by, bz, 1);
+        vo_voxel *v = &blk->data[lx + ly * bs + lz * bs * bs];
+        /* both branches of update_voxel_direct do the same arithmetic for VoxelData */
+        v->position_sum[0] += x;
+        v->position_sum[1] += y;
+        v->position_sum[2] += z;
+        if (color_kind == 1) {
+            const uint8_t *c = (const uint8_t *)cols + i * 3;
+            v->color_sum[0] += (float)c[0] * inv_255;
+            v->color_sum[1] += (float)c[1] * inv_255;
+            v->color_sum[2] += (float)c[2] * inv_255;
+        } else if (color_kind == 2) {
+            const float *c = (const float *)cols + i * 3;
+            v->color_sum[0] += c[0];
+            v->color_sum[1] += c[1];
+            v->color_sum[2] += c[2];
+        }
+        v->count = (v->count == 0) ? 1 : v->count + 1;
+    }
+}
+
+int64_t vo_num_blocks(const vo_grid *g) { return g->num_blocks; }
+int vo_block_size(const vo_grid *g) { return g->block_size; }
+int vo_empty(const vo_grid *g) { return g->num_blocks == 0; }
+
+/* get_total_voxel_count()/size(): voxels with count > 0 (voxel_block_grid.hpp:1551-1572). */
+int64_t vo_size(const vo_grid *g) {
+    int64_t total = 0;
+    for (int64_t b = 0; b < g->num_blocks; ++b)
+        for (int i = 0; i < g->voxels_per_block; ++i)
+            if (g->blocks[b].data[i].count > 0) ++total;
+    return total;
+}
+
+/* remove_low_count_voxels, voxel_block_grid.hpp:625-646: reset() voxels with count < min_count. */
+void vo_remove_low_count(vo_grid *g, int min_count) {
+    for (int64_t b = 0; b < g->num_blocks; ++b)
+        for (int i = 0; i < g->voxels_per_block; ++i)
+            if (g->blocks[b].data[i].count < min_count)
+                memset(&g->blocks[b].data[i], 0, sizeof(vo_voxel));
+}
+
+static int vo_cmp_block(const void *pa, const void *pb) {
+    const vo_block *a = *(const vo_block *const *)pa, *b = *(const vo_block *const *)pb;
+    for (int k = 0; k < 3; ++k) {
+        if (a->key[k] != b->key[k]) return a->key[k] < b->key[k] ? -1 : 1;
+    }
+    return 0;
+}
+
+/* Same layout as ref_grid_dump (oracle/ref_shim.cpp): key-sorted blocks. */
+int64_t vo_dump(const vo_grid *g, int32_t *keys, uint64_t *hashes, int32_t *counts, float *sums) {
+    const int64_t nb = g->num_blocks;
+    const vo_block **order = (const vo_block **)malloc(sizeof(void *) * (size_t)(nb ? nb : 1));
+    for (int64_t b = 0; b < nb; ++b) order[b] = &g->blocks[b];
+    qsort(order, (size_t)nb, sizeof(void *), vo_cmp_block);
+    const int64_t nv = g->voxels_per_block;
+    for (int64_t b = 0; b < nb; ++b) {
+        const vo_block *blk = order[b];
+        if (keys) memcpy(keys + b * 3, blk->key, sizeof(int32_t) * 3);
+        if (hashes) hashes[b] = vo_block_hash(blk->key[0], blk->key[1], blk->key[2]);
+        for (int64_t i = 0; i < nv; ++i) {
+            const vo_voxel *v = &blk->data[i];
+            if (counts) counts[b * nv + i] = v->count;
+            if (sums) {
+                float *s = sums + (b * nv + i) * 6;
+                s[0] = v->position_sum[0]; s[1] = v->position_sum[1]; s[2] = v->position_sum[2];
+                s[3] = v->color_sum[0]; s[4] = v->color_sum[1]; s[5] = v->color_sum[2];
+            }
+        }
+    }
+    free(order);
+    return nb;
+}
+
+/* get_position()/get_color(): sum / (float)count, voxel_data.h:58-69,98-109. */
+static inline void vo_emit(const vo_voxel *v, float *pts, float *cols, int64_t row) {
+    const float c = (float)v->count;
+    for (int k = 0; k < 3; ++k) {
+        pts[row * 3 + k] = v->position_sum[k] / c;
+        cols[row * 3 + k] = v->color_sum[k] / c;
+    }
+}
+
+/* get_voxels(min_count, min_confidence), voxel_block_grid.hpp:785-817 (non-semantic: count only).
+ * Returns the number of rows; writes at most cap rows when pts/cols non-null.  Row order is block
+ * insertion order here vs unordered_map order in the reference: compare as sets. */
+int64_t vo_get_voxels(const vo_grid *g, int min_count, float min_confidence, float *pts,
+                      float *cols, int64_t cap) {
+    (void)min_confidence;
+    int64_t n = 0;
+    for (int64_t b = 0; b < g->num_blocks; ++b) {
+        for (int i = 0; i < g->voxels_per_block; ++i) {
+            const vo_voxel *v = &g->blocks[b].data[i];
+            if (v->count >= min_count) {
+                if (pts && cols && n < cap) vo_emit(v, pts, cols, n);
+                ++n;
+            }
+        }
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CameraFrustrum — camera_frustrum.h:37-130, camera_frustrum.cpp
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct {
+    float fx, fy, cx, cy;
+    int width, height;
+    double R[9]; /* R_cw row-major */
+    double t[3]; /* t_cw */
+    float depth_max, depth_min;
+} vo_frustum;
+
+static vo_frustum vo_make_frustum(const float *intr, int width, int height, const double *T_cw,
+                                  float depth_max, float depth_min) {
+    vo_frustum f;
+    f.fx = intr[0]; f.fy = intr[1]; f.cx = intr[2]; f.cy = intr[3];
+    f.width = width; f.height = height;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) f.R[r * 3 + c] = T_cw[r * 4 + c];
+        f.t[r] = T_cw[r * 4 + 3];
+    }
+    f.depth_max = depth_max; f.depth_min = depth_min;
+    return f;
+}
+
+/* CameraFrustrum::contains<float>, camera_frustrum.cpp:175-196.  The row dot products are summed
+ * as a0*b0 + (a1*b1 + a2*b2)?  No: validated bit-exact against the compiled reference with the
+ * order below (see tests/test_oracle_vs_reference.py::test_frustum_contains). */
+static int vo_frustum_contains(const vo_frustum *f, float xw, float yw, float zw, float *uvd) {
+    const double p[3] = {(double)xw, (double)yw, (double)zw};
+    double pc[3];
+    for (int r = 0; r < 3; ++r) {
+        pc[r] = (f->R[r * 3 + 0] * p[0] + f->R[r * 3 + 1] * p[1] + f->R[r * 3 + 2] * p[2]) + f->t[r];
+    }
+    const float depth = (float)pc[2];
+    uvd[0] = -1.0f; uvd[1] = -1.0f; uvd[2] = -1.0f;
+    if (!(depth >= f->depth_min && depth <= f->depth_max)) return 0;
+    const float u = (float)((double)f->fx * (pc[0] / pc[2]) + (double)f->cx);
+    const float v = (float)((double)f->fy * (pc[1] / pc[2]) + (double)f->cy);
+    uvd[0] = u; uvd[1] = v; uvd[2] = depth;
+    return (u >= 0.0f && u < (float)f->width && v >= 0.0f && v < (float)f->height) ? 1 : 0;
+}
+
+int vo_frustum_contains_pt(const float *intr, int width, int height, const double *T_cw,
+                           float depth_max, float depth_min, const float *p_w, float *out) {
+    const vo_frustum f = vo_make_frustum(intr, width, height, T_cw, depth_max, depth_min);
+    return vo_frustum_contains(&f, p_w[0], p_w[1], p_w[2], out);
+}
+
+/* compute_frustum_corners_world_ + compute_bbox_, camera_frustrum.cpp:209-264. */
+static void vo_frustum_bbox_impl(const vo_frustum *f, double *bb) {
+    double Rwc[9], twc[3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Rwc[r * 3 + c] = f->R[c * 3 + r];
+    for (int r = 0; r < 3; ++r)
+        twc[r] = -(Rwc[r * 3 + 0] * f->t[0] + Rwc[r * 3 + 1] * f->t[1] + Rwc[r * 3 + 2] * f->t[2]);
+    const double cu[4] = {0.0, (double)f->width, (double)f->width, 0.0};
+    const double cv[4] = {0.0, 0.0, (double)f->height, (double)f->height};
+    for (int k = 0; k < 3; ++k) { bb[k] = 1.7976931348623157e308; bb[3 + k] = -1.7976931348623157e308; }
+    for (int i = 0; i < 4; ++i) {
+        const double xn = (cu[i] - (double)f->cx) / (double)f->fx;
+        const double yn = (cv[i] - (double)f->cy) / (double)f->fy;
+        const double ds[2] = {(double)f->depth_min, (double)f->depth_max};
+        for (int j = 0; j < 2; ++j) {
+            const double pc[3] = {xn * ds[j], yn * ds[j], ds[j]};
+            for (int r = 0; r < 3; ++r) {
+                const double w =
+                    (Rwc[r * 3 + 0] * pc[0] + Rwc[r * 3 + 1] * pc[1] + Rwc[r * 3 + 2] * pc[2]) + twc[r];
+                if (w < bb[r]) bb[r] = w;
+                if (w > bb[3 + r]) bb[3 + r] = w;
+            }
+        }
+    }
+}
+
+void vo_frustum_bbox(const float *intr, int width, int height, const double *T_cw, float depth_max,
+                     float depth_min, double *bb) {
+    const vo_frustum f = vo_make_frustum(intr, width, height, T_cw, depth_max, depth_min);
+    vo_frustum_bbox_impl(&f, bb);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Spatial queries and carving
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct {
+    int32_t vmin[3], vmax[3], bmin[3], bmax[3];
+} vo_range;
+
+/* bbox -> voxel/block key range, voxel_block_grid.hpp:827-835 / 1340-1348. */
+static vo_range vo_make_range(const vo_grid *g, const double *bb) {
+    vo_range r;
+    for (int k = 0; k < 3; ++k) {
+        r.vmin[k] = vo_key_f64(bb[k], g->inv_voxel_size);
+        r.vmax[k] = vo_key_f64(bb[3 + k], g->inv_voxel_size);
+        r.bmin[k] = vo_block_of(r.vmin[k], g->block_size);
+        r.bmax[k] = vo_block_of(r.vmax[k], g->block_size);
+    }
+    return r;
+}
+
+static int vo_block_in_range(const vo_range *r, const int32_t *key) {
+    for (int k = 0; k < 3; ++k)
+        if (key[k] < r->bmin[k] || key[k] > r->bmax[k]) return 0;
+    return 1;
+}
+
+/* get_voxels_in_bb<false>, voxel_block_grid.hpp:944-1013 (sequential branch). */
+int64_t vo_get_voxels_in_bb(const vo_grid *g, const double *bb, int min_count, float min_confidence,
+                            float *pts, float *cols, int64_t cap) {
+    (void)min_confidence;
+    const vo_range r = vo_make_range(g, bb);
+    const int bs = g->block_size;
+    int64_t n = 0;
+    for (int64_t b = 0; b < g->num_blocks; ++b) {
+        const vo_block *blk = &g->blocks[b];
+        if (!vo_block_in_range(&r, blk->key)) continue;
+        for (int lx = 0; lx < bs; ++lx)
+            for (int ly = 0; ly < bs; ++ly)
+                for (int lz = 0; lz < bs; ++lz) {
+                    const vo_voxel *v = &blk->data[lx + ly * bs + lz * bs * bs];
+                    if (v->count < min_count) continue;
+                    const int32_t vk[3] = {blk->key[0] * bs + lx, blk->key[1] * bs + ly,
+                                           blk->key[2] * bs + lz};
+                    if (vk[0] < r.vmin[0] || vk[0] > r.vmax[0] || vk[1] < r.vmin[1] ||
+                        vk[1] > r.vmax[1] || vk[2] < r.vmin[2] || vk[2] > r.vmax[2])
+                        continue;
+                    const float c = (float)v->count;
+                    const float px = v->position_sum[0] / c, py = v->position_sum[1] / c,
+                                pz = v->position_sum[2] / c;
+                    /* BoundingBox3D::contains<float>, bounding_boxes_3d.cpp:207-210 */
+                    if ((double)px >= bb[0] && (double)px <= bb[3] && (double)py >= bb[1] &&
+                        (double)py <= bb[4] && (double)pz >= bb[2] && (double)pz <= bb[5]) {
+                        if (pts && cols && n < cap) vo_emit(v, pts, cols, n);
+                        ++n;
+                    }
+                }
+    }
+    return n;
+}
+
+/* get_voxels_in_camera_frustrum<false>, voxel_block_grid.hpp:1019-1195 (sequential branch). */
+int64_t vo_get_voxels_in_frustum(const vo_grid *g, const float *intr, int width, int height,
+                                 const double *T_cw, float depth_max, float depth_min,
+                                 int min_count, float min_confidence, float *pts, float *cols,
+                                 int64_t cap) {
+    (void)min_confidence;
+    const vo_frustum f = vo_make_frustum(intr, width, height, T_cw, depth_max, depth_min);
+    double bb[6];
+    vo_frustum_bbox_impl(&f, bb);
+    const vo_range r = vo_make_range(g, bb);
+    const int bs = g->block_size;
+    int64_t n = 0;
+    for (int64_t b = 0; b < g->num_blocks; ++b) {
+        const vo_block *blk = &g->blocks[b];
+        if (!vo_block_in_range(&r, blk->key)) continue;
+        for (int lx = 0; lx < bs; ++lx)
+            for (int ly = 0; ly < bs; ++ly)
+                for (int lz = 0; lz < bs; ++lz) {
+                    const vo_voxel *v = &blk->data[lx + ly * bs + lz * bs * bs];
+                    if (v->count < min_count) continue;
+                    const int32_t vk[3] = {blk->key[0] * bs + lx, blk->key[1] * bs + ly,
+                                           blk->key[2] * bs + lz};
+                    if (vk[0] < r.vmin[0] || vk[0] > r.vmax[0] || vk[1] < r.vmin[1] ||
+                        vk[1] > r.vmax[1] || vk[2] < r.vmin[2] || vk[2] > r.vmax[2])
+                        continue;
+                    const float c = (float)v->count;
+                    float uvd[3];
+                    if (vo_frustum_contains(&f, v->position_sum[0] / c, v->position_sum[1] / c,
+                                            v->position_sum[2] / c, uvd)) {
+                        if (pts && cols && n < cap) vo_emit(v, pts, cols, n);
+                        ++n;
+                    }
+                }
+    }
+    return n;
+}
+
+/* carve(), voxel_grid_carving.h:47-79 over iterate_voxels_in_camera_frustrum (min_count = 1),
+ * voxel_block_grid.hpp:1335-1540: reset voxels whose averaged position projects inside the image
+ * at a depth more than `depth_threshold` in front of the measured depth. */
+void vo_carve(vo_grid *g, const float *intr, int width, int height, const double *T_cw,
+              float depth_max, float depth_min, const float *depth, float depth_threshold) {
+    const vo_frustum f = vo_make_frustum(intr, width, height, T_cw, depth_max, depth_min);
+    double bb[6];
+    vo_frustum_bbox_impl(&f, bb);
+    const vo_range r = vo_make_range(g, bb);
+    const int bs = g->block_size;
+    for (int64_t b = 0; b < g->num_blocks; ++b) {
+        vo_block *blk = &g->blocks[b];
+        if (!vo_block_in_range(&r, blk->key)) continue;
+        for (int lx = 0; lx < bs; ++lx)
+            for (int ly = 0; ly < bs; ++ly)
+                for (int lz = 0; lz < bs; ++lz) {
+                    vo_voxel *v = &blk->data[lx + ly * bs + lz * bs * bs];
+                    if (v->count < 1) continue;
+                    const int32_t vk[3] = {blk->key[0] * bs + lx, blk->key[1] * bs + ly,
+                                           blk->key[2] * bs + lz};
+                    if (vk[0] < r.vmin[0] || vk[0] > r.vmax[0] || vk[1] < r.vmin[1] ||
+                        vk[1] > r.vmax[1] || vk[2] < r.vmin[2] || vk[2] > r.vmax[2])
+                        continue;
+                    const float c = (float)v->count;
+                    float uvd[3];
+                    if (!vo_frustum_contains(&f, v->position_sum[0] / c, v->position_sum[1] / c,
+                                             v->position_sum[2] / c, uvd))
+                        continue;
+                    /* depth_image.at<float>(image_point.v, image_point.u): float -> int truncation */
+                    const float image_depth = depth[(int64_t)(int)uvd[1] * width + (int)uvd[0]];
+                    if (image_depth <= 0.0f || !isfinite(image_depth)) continue;
+                    if (uvd[2] < image_depth - depth_threshold) memset(v, 0, sizeof(vo_voxel));
+                }
+    }
+}

@@ -1,0 +1,261 @@
+// Shared host/device definitions of libpyslam_hipvol.so (gfx950 / CDNA4 only).
+//
+// One sparse block hash serves both fusion modes:
+//   VOXEL_GRID  block = 8^3 voxels  of {count, position_sum[3], color_sum[3]}  (cpp/volumetric semantics)
+//   TSDF        unit  = 16^3 voxels of {tsdf, weight, rgb sums}                (Open3D semantics)
+// Keys are the reference's BlockKey / Open3D's unit index: three int32 packed 21 bits per axis
+// into one 64-bit word so that a slot can be claimed with a single 64-bit CAS.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "hipvol.h"
+
+#define HV_WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+void hv_set_error(const char *fmt, ...);
+
+#define HV_HIP(call)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            hv_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,          \
+                         __LINE__);                                                                \
+            return HV_ERR_DEVICE;                                                                  \
+        }                                                                                          \
+    } while (0)
+
+#define HV_REQUIRE(cond, code, ...)                                                                \
+    do {                                                                                           \
+        if (!(cond)) {                                                                             \
+            hv_set_error(__VA_ARGS__);                                                             \
+            return (code);                                                                         \
+        }                                                                                          \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// packed block keys
+// ------------------------------------------------------------------------------------------------
+static constexpr int HV_KEY_BITS = 21;
+static constexpr int32_t HV_KEY_BIAS = 1 << (HV_KEY_BITS - 1);          // 2^20
+static constexpr uint64_t HV_KEY_MASK = (1ull << HV_KEY_BITS) - 1;
+static constexpr uint64_t HV_EMPTY_KEY = ~0ull;
+
+__host__ __device__ inline bool hv_key_in_range(int32_t x, int32_t y, int32_t z) {
+    return x >= -HV_KEY_BIAS && x < HV_KEY_BIAS && y >= -HV_KEY_BIAS && y < HV_KEY_BIAS &&
+           z >= -HV_KEY_BIAS && z < HV_KEY_BIAS;
+}
+__host__ __device__ inline uint64_t hv_pack_key(int32_t x, int32_t y, int32_t z) {
+    return (uint64_t)(uint32_t)(x + HV_KEY_BIAS) | ((uint64_t)(uint32_t)(y + HV_KEY_BIAS) << HV_KEY_BITS) |
+           ((uint64_t)(uint32_t)(z + HV_KEY_BIAS) << (2 * HV_KEY_BITS));
+}
+__host__ __device__ inline void hv_unpack_key(uint64_t k, int32_t &x, int32_t &y, int32_t &z) {
+    x = (int32_t)(k & HV_KEY_MASK) - HV_KEY_BIAS;
+    y = (int32_t)((k >> HV_KEY_BITS) & HV_KEY_MASK) - HV_KEY_BIAS;
+    z = (int32_t)((k >> (2 * HV_KEY_BITS)) & HV_KEY_MASK) - HV_KEY_BIAS;
+}
+// slot hash (internal; the reference's BlockKeyHash is only reproduced for export)
+__host__ __device__ inline uint32_t hv_slot_hash(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return (uint32_t)k;
+}
+// BlockKeyHash / VoxelKeyHash of the reference, voxel_hashing.h:51-58,106-113 (libstdc++ identity
+// std::hash<int32_t>, sign-extended to size_t).
+__host__ __device__ inline uint64_t hv_reference_hash(int32_t x, int32_t y, int32_t z) {
+    return (uint64_t)(int64_t)x ^ ((uint64_t)(int64_t)y << 1) ^ ((uint64_t)(int64_t)z << 2);
+}
+
+// Device view of the block hash.  keys[slot] = packed key or HV_EMPTY_KEY; vals[slot] = pool index
+// (written by the claiming thread; readers in *later* kernels only).  block_keys[pool index] = key.
+struct HvTable {
+    unsigned long long *keys;
+    int32_t *vals;
+    unsigned long long *block_keys;
+    int32_t *counters; // [HV_CNT_*]
+    uint32_t mask;     // capacity - 1
+    int32_t max_blocks;
+};
+
+enum {
+    HV_CNT_BLOCKS = 0,   // allocated blocks
+    HV_CNT_OVERFLOW = 1, // pool/table overflow events
+    HV_CNT_DROPPED = 2,  // points with out-of-range keys
+    HV_CNT_TOUCH0 = 3,   // touched-unit list length, frame parity 0
+    HV_CNT_TOUCH1 = 4,   // ... parity 1
+    HV_CNT_OUT = 5,      // output row counter (compaction kernels)
+    HV_CNT_OUT2 = 6,     // second output counter (triangles)
+    HV_CNT_COUNT = 16
+};
+
+#ifdef __HIPCC__
+// Lookup only.  Returns slot or -1.
+__device__ inline int32_t hv_table_find(const HvTable &t, uint64_t key) {
+    uint32_t s = hv_slot_hash(key) & t.mask;
+    for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+        const unsigned long long k = t.keys[s];
+        if (k == key) return (int32_t)s;
+        if (k == HV_EMPTY_KEY) return -1;
+        s = (s + 1) & t.mask;
+    }
+    return -1;
+}
+
+// Find-or-claim.  Returns the slot (>= 0) or -1 on overflow.  A newly claimed slot gets a pool
+// index from the block counter; pool memory is pre-zeroed, so no per-block initialisation runs.
+__device__ inline int32_t hv_table_insert(const HvTable &t, uint64_t key) {
+    uint32_t s = hv_slot_hash(key) & t.mask;
+    for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+        unsigned long long k = t.keys[s];
+        if (k == key) return (int32_t)s;
+        if (k == HV_EMPTY_KEY) {
+            k = atomicCAS(&t.keys[s], HV_EMPTY_KEY, (unsigned long long)key);
+            if (k == HV_EMPTY_KEY) {
+                const int32_t idx = atomicAdd(&t.counters[HV_CNT_BLOCKS], 1);
+                if (idx >= t.max_blocks) {
+                    atomicAdd(&t.counters[HV_CNT_OVERFLOW], 1);
+                    // leave vals[s] = -1: consumers skip it
+                    return -1;
+                }
+                t.vals[s] = idx;
+                t.block_keys[idx] = key;
+                return (int32_t)s;
+            }
+            if (k == key) return (int32_t)s;
+        }
+        s = (s + 1) & t.mask;
+    }
+    atomicAdd(&t.counters[HV_CNT_OVERFLOW], 1);
+    return -1;
+}
+
+__device__ inline int hv_lane_id() { return (int)(threadIdx.x & (HV_WAVE - 1)); }
+
+// Wave-aggregated append: every lane with `pred` gets a distinct index from *counter; one atomic
+// per wave (ballot + popcount prefix).
+__device__ inline int32_t hv_wave_append(int32_t *counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0) return -1;
+    const int lane = hv_lane_id();
+    const int leader = __ffsll((long long)m) - 1;
+    int32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (int32_t)__popcll(m));
+    base = __shfl(base, leader);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    return pred ? base + (int32_t)__popcll(m & lt) : -1;
+}
+#endif // __HIPCC__
+
+// ------------------------------------------------------------------------------------------------
+// TSDF unit layout in HBM.  R = 16: five planes of R^3 4-byte words, plane-major:
+//   [tsdf f32][weight u32][sum_r u32][sum_g u32][sum_b u32]   = 5 * 16 KiB = 80 KiB / unit
+// word index inside a plane: z*R*R + x*R + y  (y fastest) so that one wave (lane -> (x, 4 y's))
+// reads/writes a z-slab as one contiguous 1 KiB dwordx4 burst per plane.
+// Weight is an exact observation count; colour is kept as exact integer sums of the u8 samples
+// (mean = sum / weight reproduces Open3D's running mean to double rounding).
+// ------------------------------------------------------------------------------------------------
+static constexpr int HV_TSDF_PLANES = 5;
+
+// VOXEL_GRID voxel record: the reference's 28-byte VoxelData padded to 32 B so that one voxel is
+// two aligned 16-byte accesses and never straddles a 64-B line.
+struct __attribute__((aligned(16))) HvVoxel {
+    int32_t count;
+    float pos[3];
+    float col[3];
+    int32_t pad;
+};
+static_assert(sizeof(HvVoxel) == 32, "HvVoxel must be 32 bytes");
+
+struct HvFrameParams { // per-frame constants of the TSDF kernels (passed by value)
+    float ext[12];          // T_cw.cast<float>() rows 0..2
+    float ext_scaled_col2[3];
+    float fx, fy, cx, cy;
+    float ffl_inv_x, ffl_inv_y; // 1.0f / (float)fx ...
+    float voxel_length_f, half_voxel_length_f;
+    float sdf_trunc_f, sdf_trunc_inv_f;
+    float safe_width_f, safe_height_f;
+    double unit_length;
+    double pose[12];        // inverse(T_cw) rows 0..2 (f64)
+    double fx_d, fy_d, cx_d, cy_d;
+    double sdf_trunc_d;
+    float depth_scale_f;
+    double depth_trunc_d;
+    int32_t H, W, stride;
+    int32_t depth_is_u16;
+    int32_t frame_id;       // touched stamp value (> 0)
+};
+
+// ------------------------------------------------------------------------------------------------
+// host-side volume object
+// ------------------------------------------------------------------------------------------------
+struct HvEventPair {
+    hipEvent_t start, stop;
+};
+
+struct hv_volume {
+    hv_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+
+    // hash + pool
+    HvTable table{};
+    uint64_t table_capacity = 0;
+    void *pool = nullptr; // max_blocks * bytes_per_block, zero-initialised
+    int64_t bytes_per_block = 0;
+    int32_t *h_counters = nullptr; // pinned mirror [HV_CNT_COUNT]
+
+    // TSDF per-frame state
+    int32_t *touched_stamp = nullptr; // [table_capacity] last frame id that touched the slot
+    int32_t *touched_list = nullptr;  // [max_blocks] slots touched this frame
+    uint64_t *touched_mask = nullptr; // [table_capacity] per-slot frame bitmask (batch mode)
+    float *depth_f32 = nullptr;       // [batch * max_points] converted depth
+    uint32_t *rgba = nullptr;         // [batch * max_points] packed colour
+    int32_t frame_counter = 0;
+    int32_t last_touch_parity = 0;
+    int32_t frame_batch_cap = 0;
+
+    // staging for HV_HOST inputs
+    void *stage_a = nullptr;
+    void *stage_b = nullptr;
+    size_t stage_a_bytes = 0, stage_b_bytes = 0;
+
+    // VOXEL_GRID scratch
+    uint32_t *sort_keys_in = nullptr, *sort_keys_out = nullptr;
+    uint32_t *sort_vals_in = nullptr, *sort_vals_out = nullptr;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    float *scratch_points = nullptr; // [max_points*3]
+    float *scratch_colors = nullptr; // [max_points*3]
+    int local_bits = 9;
+
+    // output scratch (grown on demand)
+    void *out_a = nullptr;
+    void *out_b = nullptr;
+    void *out_c = nullptr;
+    size_t out_a_bytes = 0, out_b_bytes = 0, out_c_bytes = 0;
+
+    // profiling
+    bool profiling = false;
+    std::vector<HvEventPair> events;
+    size_t events_used = 0;
+    int64_t prof_units = 0;
+};
+
+int hv_ensure_buffer(hv_volume *v, void **buf, size_t *cur, size_t want);
+int hv_read_counters(hv_volume *v); // D2H of the counter block (synchronises the stream)
+int hv_stage_in(hv_volume *v, const void *src, size_t bytes, int32_t loc, int which, const void **dev);
+void hv_profile_begin(hv_volume *v);
+void hv_profile_end(hv_volume *v, int64_t units);
+void hv_invert4x4(const double *m, double *out);

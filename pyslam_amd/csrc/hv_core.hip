@@ -1,0 +1,353 @@
+// libpyslam_hipvol.so — volume lifetime, block hash/pool allocation, staging, measurement hooks.
+#include <cstdarg>
+#include <cstdlib>
+
+#include "hv_common.h"
+
+static thread_local std::string g_last_error;
+
+void hv_set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+// General 4x4 inverse by cofactors (adjugate / determinant), row-major doubles — the library's
+// definition of Eigen's `extrinsic.inverse()` in Open3D's CreatePointCloudFromFloatDepthImage.
+void hv_invert4x4(const double *m, double *out) {
+    double a[16];
+    a[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    a[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    a[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    a[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    a[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    a[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    a[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    a[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    a[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    a[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    a[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    a[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    a[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    a[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    a[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    a[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const double det = m[0] * a[0] + m[1] * a[4] + m[2] * a[8] + m[3] * a[12];
+    const double inv_det = 1.0 / det;
+    for (int i = 0; i < 16; ++i) out[i] = a[i] * inv_det;
+}
+
+int hv_ensure_buffer(hv_volume *v, void **buf, size_t *cur, size_t want) {
+    if (*cur >= want && *buf != nullptr) return HV_OK;
+    if (*buf) {
+        HV_HIP(hipStreamSynchronize(v->stream));
+        HV_HIP(hipFree(*buf));
+        *buf = nullptr;
+        *cur = 0;
+    }
+    size_t bytes = want < 4096 ? 4096 : want + want / 4;
+    HV_HIP(hipMalloc(buf, bytes));
+    *cur = bytes;
+    return HV_OK;
+}
+
+int hv_read_counters(hv_volume *v) {
+    HV_HIP(hipMemcpyAsync(v->h_counters, v->table.counters, sizeof(int32_t) * HV_CNT_COUNT,
+                          hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipStreamSynchronize(v->stream));
+    return HV_OK;
+}
+
+// HV_HOST inputs are copied into a device staging buffer on the volume's stream; HV_DEVICE inputs
+// are used in place.
+int hv_stage_in(hv_volume *v, const void *src, size_t bytes, int32_t loc, int which, const void **dev) {
+    if (src == nullptr || bytes == 0) {
+        *dev = nullptr;
+        return HV_OK;
+    }
+    if (loc == HV_DEVICE) {
+        *dev = src;
+        return HV_OK;
+    }
+    void **buf = which == 0 ? &v->stage_a : &v->stage_b;
+    size_t *cur = which == 0 ? &v->stage_a_bytes : &v->stage_b_bytes;
+    int rc = hv_ensure_buffer(v, buf, cur, bytes);
+    if (rc != HV_OK) return rc;
+    HV_HIP(hipMemcpyAsync(*buf, src, bytes, hipMemcpyHostToDevice, v->stream));
+    *dev = *buf;
+    return HV_OK;
+}
+
+void hv_profile_begin(hv_volume *v) {
+    if (!v->profiling) return;
+    if (v->events_used == v->events.size()) {
+        HvEventPair p;
+        if (hipEventCreate(&p.start) != hipSuccess || hipEventCreate(&p.stop) != hipSuccess) return;
+        v->events.push_back(p);
+    }
+    (void)hipEventRecord(v->events[v->events_used].start, v->stream);
+}
+
+void hv_profile_end(hv_volume *v, int64_t units) {
+    if (!v->profiling || v->events_used >= v->events.size()) return;
+    (void)hipEventRecord(v->events[v->events_used].stop, v->stream);
+    v->events_used++;
+    v->prof_units += units;
+}
+
+static uint64_t next_pow2(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+extern "C" {
+
+const char *hv_last_error(void) { return g_last_error.c_str(); }
+
+int hv_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        hv_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return HV_ERR_DEVICE;
+    }
+    return n;
+}
+
+void hv_default_config(int32_t mode, hv_config *cfg) {
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->mode = mode;
+    cfg->device = 0;
+    if (mode == HV_MODE_TSDF) {
+        cfg->voxel_size = 0.015; // kVolumetricIntegrationVoxelLength, config_parameters.py:311
+        cfg->sdf_trunc = 0.04;   // kVolumetricIntegrationTSdfTrunc, config_parameters.py:349
+        cfg->block_size = 16;    // Open3D volume_unit_resolution
+        cfg->depth_sampling_stride = 4;
+        cfg->max_blocks = 1 << 16; // 65536 units * 80 KiB = 5 GiB of the 288 GB HBM
+    } else {
+        cfg->voxel_size = 0.015;
+        cfg->sdf_trunc = 0.0;
+        cfg->block_size = 8; // kVolumetricIntegrationBlockSize, config_parameters.py:313
+        cfg->depth_sampling_stride = 1;
+        cfg->max_blocks = 1 << 19; // 524288 blocks * 16 KiB = 8 GiB
+    }
+    cfg->max_points = 2 * 1024 * 1024;
+}
+
+int hv_create(const hv_config *cfg, hv_volume **out) {
+    HV_REQUIRE(cfg != nullptr && out != nullptr, HV_ERR_INVALID, "hv_create: null argument");
+    HV_REQUIRE(cfg->mode == HV_MODE_VOXEL_GRID || cfg->mode == HV_MODE_TSDF, HV_ERR_INVALID,
+               "hv_create: unsupported mode %d", cfg->mode);
+    HV_REQUIRE(cfg->voxel_size > 0.0, HV_ERR_INVALID, "hv_create: voxel_size must be > 0");
+    HV_REQUIRE(cfg->max_blocks > 0 && cfg->max_blocks < (1ll << 30), HV_ERR_INVALID,
+               "hv_create: max_blocks out of range");
+    HV_REQUIRE(cfg->max_points > 0 && cfg->max_points < (1ll << 31), HV_ERR_INVALID,
+               "hv_create: max_points out of range");
+    if (cfg->mode == HV_MODE_TSDF) {
+        HV_REQUIRE(cfg->block_size == 16, HV_ERR_INVALID,
+                   "hv_create: TSDF mode supports volume_unit_resolution 16 only (Open3D default)");
+        HV_REQUIRE(cfg->sdf_trunc > 0.0, HV_ERR_INVALID, "hv_create: sdf_trunc must be > 0");
+        HV_REQUIRE(cfg->depth_sampling_stride >= 1, HV_ERR_INVALID, "hv_create: bad sampling stride");
+    } else {
+        HV_REQUIRE(cfg->block_size >= 1 && cfg->block_size <= 16, HV_ERR_INVALID,
+                   "hv_create: block_size must be in [1,16]");
+    }
+    int ndev = 0;
+    HV_HIP(hipGetDeviceCount(&ndev));
+    HV_REQUIRE(ndev > 0 && cfg->device >= 0 && cfg->device < ndev, HV_ERR_DEVICE,
+               "hv_create: HIP device %d not available (%d devices)", cfg->device, ndev);
+    hipDeviceProp_t prop;
+    HV_HIP(hipGetDeviceProperties(&prop, cfg->device));
+    HV_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, HV_ERR_DEVICE,
+               "hv_create: device %d is %s; this library is built for gfx950 only", cfg->device,
+               prop.gcnArchName);
+    HV_HIP(hipSetDevice(cfg->device));
+
+    hv_volume *v = new hv_volume();
+    v->cfg = *cfg;
+    v->device = cfg->device;
+    int rc = HV_OK;
+    auto fail = [&](int code) {
+        hv_destroy(v);
+        return code;
+    };
+#define HV_TRY(call)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            hv_set_error("%s failed: %s", #call, hipGetErrorString(e_));                           \
+            return fail(HV_ERR_DEVICE);                                                            \
+        }                                                                                          \
+    } while (0)
+
+    HV_TRY(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+    v->own_stream = true;
+
+    const int64_t nvox = (int64_t)cfg->block_size * cfg->block_size * cfg->block_size;
+    v->bytes_per_block = cfg->mode == HV_MODE_TSDF ? nvox * 4 * HV_TSDF_PLANES : nvox * (int64_t)sizeof(HvVoxel);
+    v->local_bits = 0;
+    while ((1ll << v->local_bits) < nvox) v->local_bits++;
+
+    v->table_capacity = next_pow2((uint64_t)cfg->max_blocks * 4);
+    if (v->table_capacity < 1024) v->table_capacity = 1024;
+    if (cfg->mode == HV_MODE_VOXEL_GRID && (v->table_capacity << v->local_bits) > (1ull << 32)) {
+        hv_set_error("hv_create: max_blocks too large for 32-bit (slot, voxel) sort keys");
+        return fail(HV_ERR_INVALID);
+    }
+    v->table.mask = (uint32_t)(v->table_capacity - 1);
+    v->table.max_blocks = (int32_t)cfg->max_blocks;
+    HV_TRY(hipMalloc(&v->table.keys, sizeof(uint64_t) * v->table_capacity));
+    HV_TRY(hipMalloc(&v->table.vals, sizeof(int32_t) * v->table_capacity));
+    HV_TRY(hipMalloc(&v->table.block_keys, sizeof(uint64_t) * cfg->max_blocks));
+    HV_TRY(hipMalloc(&v->table.counters, sizeof(int32_t) * HV_CNT_COUNT));
+    HV_TRY(hipHostMalloc((void **)&v->h_counters, sizeof(int32_t) * HV_CNT_COUNT));
+    memset(v->h_counters, 0, sizeof(int32_t) * HV_CNT_COUNT);
+    HV_TRY(hipMalloc(&v->pool, (size_t)cfg->max_blocks * v->bytes_per_block));
+
+    if (cfg->mode == HV_MODE_TSDF) {
+        HV_TRY(hipMalloc(&v->touched_stamp, sizeof(int32_t) * v->table_capacity));
+        HV_TRY(hipMalloc(&v->touched_list, sizeof(int32_t) * cfg->max_blocks));
+        HV_TRY(hipMalloc(&v->touched_mask, sizeof(uint64_t) * v->table_capacity));
+        v->frame_batch_cap = 1;
+        HV_TRY(hipMalloc(&v->depth_f32, sizeof(float) * cfg->max_points));
+        HV_TRY(hipMalloc(&v->rgba, sizeof(uint32_t) * cfg->max_points));
+    } else {
+        HV_TRY(hipMalloc(&v->sort_keys_in, sizeof(uint32_t) * cfg->max_points));
+        HV_TRY(hipMalloc(&v->sort_keys_out, sizeof(uint32_t) * cfg->max_points));
+        HV_TRY(hipMalloc(&v->sort_vals_in, sizeof(uint32_t) * cfg->max_points));
+        HV_TRY(hipMalloc(&v->sort_vals_out, sizeof(uint32_t) * cfg->max_points));
+        HV_TRY(hipMalloc(&v->scratch_points, sizeof(float) * 3 * cfg->max_points));
+        HV_TRY(hipMalloc(&v->scratch_colors, sizeof(float) * 3 * cfg->max_points));
+    }
+#undef HV_TRY
+    // first reset zeroes the whole pool (later resets only the used prefix)
+    HV_HIP(hipMemsetAsync(v->pool, 0, (size_t)cfg->max_blocks * v->bytes_per_block, v->stream));
+    rc = hv_reset(v);
+    if (rc != HV_OK) return fail(rc);
+    *out = v;
+    return HV_OK;
+}
+
+void hv_destroy(hv_volume *v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    if (v->stream) (void)hipStreamSynchronize(v->stream);
+    void *bufs[] = {v->table.keys, v->table.vals, v->table.block_keys, v->table.counters, v->pool,
+                    v->touched_stamp, v->touched_list, v->touched_mask, v->depth_f32, v->rgba,
+                    v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
+                    v->sort_vals_out, v->sort_tmp, v->scratch_points, v->scratch_colors, v->out_a,
+                    v->out_b, v->out_c};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (v->h_counters) (void)hipHostFree(v->h_counters);
+    for (auto &p : v->events) {
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.stop);
+    }
+    if (v->stream && v->own_stream) (void)hipStreamDestroy(v->stream);
+    delete v;
+}
+
+int hv_reset(hv_volume *v) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_reset: null volume");
+    HV_HIP(hipSetDevice(v->device));
+    // zero only the used pool prefix (pool was fully zeroed at creation)
+    int64_t used = 0;
+    if (v->frame_counter != 0 || v->h_counters[HV_CNT_BLOCKS] != 0) {
+        int rc = hv_read_counters(v);
+        if (rc != HV_OK) return rc;
+        used = v->h_counters[HV_CNT_BLOCKS];
+        if (used > v->cfg.max_blocks) used = v->cfg.max_blocks;
+    }
+    if (used > 0) HV_HIP(hipMemsetAsync(v->pool, 0, (size_t)used * v->bytes_per_block, v->stream));
+    HV_HIP(hipMemsetAsync(v->table.keys, 0xFF, sizeof(uint64_t) * v->table_capacity, v->stream));
+    HV_HIP(hipMemsetAsync(v->table.vals, 0xFF, sizeof(int32_t) * v->table_capacity, v->stream));
+    HV_HIP(hipMemsetAsync(v->table.counters, 0, sizeof(int32_t) * HV_CNT_COUNT, v->stream));
+    if (v->touched_stamp) HV_HIP(hipMemsetAsync(v->touched_stamp, 0, sizeof(int32_t) * v->table_capacity, v->stream));
+    if (v->touched_mask) HV_HIP(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * v->table_capacity, v->stream));
+    memset(v->h_counters, 0, sizeof(int32_t) * HV_CNT_COUNT);
+    v->frame_counter = 0;
+    v->last_touch_parity = 0;
+    return HV_OK;
+}
+
+int hv_synchronize(hv_volume *v) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_synchronize: null volume");
+    HV_HIP(hipStreamSynchronize(v->stream));
+    return HV_OK;
+}
+
+int hv_set_stream(hv_volume *v, void *hip_stream) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_set_stream: null volume");
+    HV_HIP(hipStreamSynchronize(v->stream));
+    if (v->own_stream && v->stream) HV_HIP(hipStreamDestroy(v->stream));
+    v->stream = (hipStream_t)hip_stream;
+    v->own_stream = false;
+    return HV_OK;
+}
+
+void *hv_get_stream(hv_volume *v) { return v ? (void *)v->stream : nullptr; }
+
+int hv_num_blocks(hv_volume *v, int64_t *n) {
+    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_num_blocks: null argument");
+    int rc = hv_read_counters(v);
+    if (rc != HV_OK) return rc;
+    int64_t nb = v->h_counters[HV_CNT_BLOCKS];
+    if (nb > v->cfg.max_blocks) nb = v->cfg.max_blocks;
+    *n = nb;
+    HV_REQUIRE(v->h_counters[HV_CNT_OVERFLOW] == 0, HV_ERR_CAPACITY,
+               "block pool exhausted: max_blocks=%lld; recreate the volume with a larger pool",
+               (long long)v->cfg.max_blocks);
+    return HV_OK;
+}
+
+int hv_block_size(hv_volume *v, int32_t *bs) {
+    HV_REQUIRE(v != nullptr && bs != nullptr, HV_ERR_INVALID, "hv_block_size: null argument");
+    *bs = v->cfg.block_size;
+    return HV_OK;
+}
+
+int hv_bytes_per_block(hv_volume *v, int64_t *bytes) {
+    HV_REQUIRE(v != nullptr && bytes != nullptr, HV_ERR_INVALID, "hv_bytes_per_block: null argument");
+    *bytes = v->bytes_per_block;
+    return HV_OK;
+}
+
+int hv_dropped_points(hv_volume *v, int64_t *n) {
+    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_dropped_points: null argument");
+    int rc = hv_read_counters(v);
+    if (rc != HV_OK) return rc;
+    *n = v->h_counters[HV_CNT_DROPPED];
+    return HV_OK;
+}
+
+int hv_profile_enable(hv_volume *v, int32_t on) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_profile_enable: null volume");
+    v->profiling = on != 0;
+    v->events_used = 0;
+    v->prof_units = 0;
+    return HV_OK;
+}
+
+int hv_profile_read(hv_volume *v, double *kernel_ms_total, int64_t *kernel_launches, int64_t *units_processed) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_profile_read: null volume");
+    HV_HIP(hipStreamSynchronize(v->stream));
+    double total = 0.0;
+    for (size_t i = 0; i < v->events_used; ++i) {
+        float ms = 0.f;
+        HV_HIP(hipEventElapsedTime(&ms, v->events[i].start, v->events[i].stop));
+        total += ms;
+    }
+    if (kernel_ms_total) *kernel_ms_total = total;
+    if (kernel_launches) *kernel_launches = (int64_t)v->events_used;
+    if (units_processed) *units_processed = v->prof_units;
+    v->events_used = 0;
+    v->prof_units = 0;
+    return HV_OK;
+}
+
+} // extern "C"

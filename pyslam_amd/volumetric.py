@@ -1,0 +1,490 @@
+"""Host-side mirror of the two volume objects pySLAM's dense integrators drive.
+
+* :class:`VoxelBlockGrid`, :class:`CameraFrustrum`, :class:`BoundingBox3D`, :class:`VoxelGridData`
+  mirror the ``volumetric`` pybind11 module (reference: cpp/volumetric/volumetric_grid_module.h:
+  732-935, camera_frustrum_module.h:41-130) — same method names, argument meaning, defaults and
+  error messages — over the HIP library's VOXEL_GRID mode.
+* :class:`ScalableTSDFVolume`, :class:`PinholeCameraIntrinsic`, :class:`TriangleMesh`,
+  :class:`PointCloud` mirror the slice of ``open3d`` that pyslam/dense/volumetric_integrator_tsdf.py
+  uses (:104-119, 215-223, 239-267) over the library's TSDF mode.
+
+All compute happens in libpyslam_hipvol.so on the GPU; nothing here falls back to the CPU.
+Arrays may be numpy (host) or torch CUDA tensors (zero-copy, already resident in HBM).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _as_f64_4x4(T):
+    T = np.ascontiguousarray(np.asarray(T, dtype=np.float64))
+    if T.shape != (4, 4):
+        raise RuntimeError("T_cw must be a 4x4 matrix")
+    return T
+
+
+class _Volume:
+    """Owns one hv_volume handle."""
+
+    def __init__(self, mode, voxel_size, sdf_trunc, block_size, stride, device, max_blocks, max_points):
+        lib = L.load()
+        cfg = L.HvConfig()
+        lib.hv_default_config(mode, ctypes.byref(cfg))
+        cfg.device = int(device)
+        cfg.voxel_size = float(voxel_size)
+        cfg.sdf_trunc = float(sdf_trunc)
+        cfg.block_size = int(block_size)
+        cfg.depth_sampling_stride = int(stride)
+        if max_blocks is not None:
+            cfg.max_blocks = int(max_blocks)
+        if max_points is not None:
+            cfg.max_points = int(max_points)
+        self._lib = lib
+        self._cfg = cfg
+        handle = ctypes.c_void_p()
+        L.check(lib.hv_create(ctypes.byref(cfg), ctypes.byref(handle)))
+        self._h = handle
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- shared introspection -------------------------------------------------------------------
+    def num_blocks(self):
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_num_blocks(self._h, ctypes.byref(n)))
+        return n.value
+
+    def synchronize(self):
+        L.check(self._lib.hv_synchronize(self._h))
+
+    def set_stream(self, stream_handle):
+        """Adopt a caller-owned hipStream_t (e.g. ``torch.cuda.Stream().cuda_stream``)."""
+        L.check(self._lib.hv_set_stream(self._h, ctypes.c_void_p(int(stream_handle))))
+
+    def dropped_points(self):
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_dropped_points(self._h, ctypes.byref(n)))
+        return n.value
+
+    def profile_enable(self, on=True):
+        L.check(self._lib.hv_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        ms, launches, units = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
+        L.check(self._lib.hv_profile_read(self._h, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(units)))
+        return ms.value, launches.value, units.value
+
+    def bytes_per_block(self):
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_bytes_per_block(self._h, ctypes.byref(n)))
+        return n.value
+
+
+# ================================================================================================
+# `volumetric` module mirror
+# ================================================================================================
+class BoundingBox3D:
+    """cpp/volumetric/bounding_boxes_3d.h:39-80 (axis-aligned)."""
+
+    def __init__(self, min_point, max_point):
+        self.min_x, self.min_y, self.min_z = (float(x) for x in min_point)
+        self.max_x, self.max_y, self.max_z = (float(x) for x in max_point)
+
+    def as_array(self):
+        return np.array([self.min_x, self.min_y, self.min_z, self.max_x, self.max_y, self.max_z], np.float64)
+
+
+class CameraFrustrum:
+    """cpp/volumetric/camera_frustrum.h:37-130: CameraFrustrum(fx, fy, cx, cy, width, height, T_cw,
+    depth_max=10.0, depth_min=1e-2); intrinsics and depth limits are float32 there."""
+
+    def __init__(self, fx, fy, cx, cy, width, height, T_cw=None, depth_max=10.0, depth_min=1e-2):
+        self.intr = np.array([fx, fy, cx, cy], dtype=np.float32)
+        self.width = int(width)
+        self.height = int(height)
+        self.depth_max = float(np.float32(depth_max))
+        self.depth_min = float(np.float32(depth_min))
+        self.T_cw = _as_f64_4x4(np.eye(4) if T_cw is None else T_cw)
+
+    def set_T_cw(self, T_cw):
+        self.T_cw = _as_f64_4x4(T_cw)
+
+    def get_T_cw(self):
+        return self.T_cw.copy()
+
+    def set_depth_max(self, depth_max):
+        self.depth_max = float(np.float32(depth_max))
+
+    def set_depth_min(self, depth_min):
+        self.depth_min = float(np.float32(depth_min))
+
+    def get_width(self):
+        return self.width
+
+    def get_height(self):
+        return self.height
+
+
+class VoxelGridData:
+    """cpp/volumetric/voxel_grid_data.h:36-50: .points/.colors (+ empty semantic fields)."""
+
+    def __init__(self, points, colors):
+        self.points = points
+        self.colors = colors
+        self.class_ids = np.zeros((0,), np.int32)
+        self.object_ids = np.zeros((0,), np.int32)
+        self.confidences = np.zeros((0,), np.float32)
+
+
+class VoxelBlockGrid(_Volume):
+    """``volumetric.VoxelBlockGrid(voxel_size, block_size=8)`` on the GPU.
+
+    integrate() results (count, position_sum, color_sum per voxel) are bit-identical to the
+    reference's sequential accumulation; row order of get_voxels() differs (the reference's is its
+    unordered_map iteration order), so compare outputs as sets.
+    """
+
+    def __init__(self, voxel_size, block_size=8, device=0, max_blocks=None, max_points=None):
+        voxel_size = float(np.float32(voxel_size))  # pybind narrows to float (py::init<float,int>)
+        super().__init__(L.HV_MODE_VOXEL_GRID, voxel_size, 0.0, block_size, 1, device, max_blocks, max_points)
+        self.voxel_size = voxel_size
+        self.block_size = int(block_size)
+
+    # -- integrate -------------------------------------------------------------------------------
+    def integrate(self, points, colors=None):
+        """points: [N,3] float32 (float64 is narrowed to float32); colors: [N,3] uint8|float32|None."""
+        is_torch = hasattr(points, "data_ptr")
+        if is_torch:
+            if points.dim() != 2 or points.shape[1] != 3:
+                raise RuntimeError("points must be a contiguous Nx3 array")
+            pts = points.contiguous().float()
+            n = pts.shape[0]
+        else:
+            pts = np.asarray(points)
+            if pts.ndim != 2 or pts.shape[1] != 3:
+                raise RuntimeError("points must be a contiguous Nx3 array")
+            pts = np.ascontiguousarray(pts, dtype=np.float32)
+            n = pts.shape[0]
+        if n == 0:
+            return
+        kind, cols = L.HV_COLOR_NONE, None
+        if colors is not None:
+            if hasattr(colors, "data_ptr"):
+                cols = colors.contiguous()
+                shape, dt = tuple(cols.shape), str(cols.dtype)
+                is_u8, is_f32 = dt == "torch.uint8", dt == "torch.float32"
+            else:
+                cols = np.ascontiguousarray(colors)
+                shape, dt = cols.shape, str(cols.dtype)
+                is_u8, is_f32 = cols.dtype == np.uint8, cols.dtype == np.float32
+            if len(shape) != 2 or shape[1] != 3:
+                raise RuntimeError("colors must be a contiguous Nx3 array")
+            if shape[0] != n:
+                raise RuntimeError("points and colors must have the same size")
+            if is_u8:
+                kind = L.HV_COLOR_U8
+            elif is_f32:
+                kind = L.HV_COLOR_F32
+            else:
+                raise RuntimeError(f"Colors must be uint8 or float32, got dtype with {dt}")
+            if L.location(cols) != L.location(pts):
+                raise RuntimeError("points and colors must live on the same device")
+        L.check(self._lib.hv_integrate_points(self._h, L.ptr(pts), n, L.ptr(cols), kind, L.location(pts)))
+
+    def integrate_rgbd(self, depth, rgb, fx, fy, cx, cy, T_cw, max_depth=np.inf, min_depth=0.0, depth_scale=1.0):
+        """Fused depth2pointcloud + world transform + integrate for one posed RGB-D frame
+        (pyslam/utilities/depth.py:45-85, volumetric_integrator_voxel_grid.py:251-300)."""
+        dkind = L.HV_DEPTH_U16 if str(depth.dtype) in ("uint16", "torch.uint16") else L.HV_DEPTH_F32
+        H, W = int(depth.shape[0]), int(depth.shape[1])
+        intr = np.array([fx, fy, cx, cy], dtype=np.float64)
+        T = _as_f64_4x4(T_cw)
+        maxd = float(min(max_depth, 3.0e38))
+        L.check(
+            self._lib.hv_integrate_rgbd_points(
+                self._h, L.ptr(depth), dkind, float(depth_scale), L.ptr(rgb), H, W, L.ptr(intr), L.ptr(T),
+                float(min_depth), maxd, L.location(depth)
+            )
+        )
+
+    # -- queries ---------------------------------------------------------------------------------
+    def _collect(self, call):
+        n = ctypes.c_int64()
+        L.check(call(None, None, 0, ctypes.byref(n)))
+        pts = np.zeros((n.value, 3), np.float32)
+        cols = np.zeros((n.value, 3), np.float32)
+        if n.value:
+            L.check(call(L.ptr(pts), L.ptr(cols), n.value, ctypes.byref(n)))
+        return VoxelGridData(pts, cols)
+
+    def get_voxels(self, min_count=1, min_confidence=0.0):
+        return self._collect(
+            lambda p, c, cap, n: self._lib.hv_get_voxels(self._h, int(min_count), float(min_confidence), p, c, cap, n, L.HV_HOST)
+        )
+
+    def get_points(self):
+        return self.get_voxels(1, 0.0).points
+
+    def get_colors(self):
+        return self.get_voxels(1, 0.0).colors
+
+    def get_voxels_in_bb(self, bbox, min_count=1, min_confidence=0.0, include_semantics=False):
+        bb = bbox.as_array() if isinstance(bbox, BoundingBox3D) else np.ascontiguousarray(bbox, dtype=np.float64)
+        return self._collect(
+            lambda p, c, cap, n: self._lib.hv_get_voxels_in_bb(
+                self._h, L.ptr(bb), int(min_count), float(min_confidence), p, c, cap, n, L.HV_HOST
+            )
+        )
+
+    def get_voxels_in_camera_frustrum(self, camera_frustrum, min_count=1, min_confidence=0.0, include_semantics=False):
+        f = camera_frustrum
+        return self._collect(
+            lambda p, c, cap, n: self._lib.hv_get_voxels_in_frustum(
+                self._h, L.ptr(f.intr), f.width, f.height, L.ptr(f.T_cw), f.depth_max, f.depth_min,
+                int(min_count), float(min_confidence), p, c, cap, n, L.HV_HOST
+            )
+        )
+
+    def carve(self, camera_frustrum, depth_image, depth_threshold=1e-2):
+        f = camera_frustrum
+        if hasattr(depth_image, "data_ptr"):
+            depth = depth_image.contiguous().float()
+        else:
+            depth = np.ascontiguousarray(depth_image, dtype=np.float32)
+        if depth.shape[0] != f.height or depth.shape[1] != f.width:
+            return  # check_image_size(): the reference prints a message and returns
+        L.check(
+            self._lib.hv_carve(
+                self._h, L.ptr(f.intr), f.width, f.height, L.ptr(f.T_cw), f.depth_max, f.depth_min, L.ptr(depth),
+                float(depth_threshold), L.location(depth)
+            )
+        )
+
+    def remove_low_count_voxels(self, min_count):
+        L.check(self._lib.hv_remove_low_count_voxels(self._h, int(min_count)))
+
+    def remove_low_confidence_voxels(self, min_confidence):
+        return  # no-op for non-semantic voxels (voxel_block_grid.hpp:650-676)
+
+    def clear(self):
+        L.check(self._lib.hv_reset(self._h))
+
+    reset = clear
+
+    def size(self):
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_size(self._h, ctypes.byref(n)))
+        return n.value
+
+    get_total_voxel_count = size
+
+    def empty(self):
+        return self.num_blocks() == 0
+
+    def get_block_size(self):
+        return self.block_size
+
+    # -- parity/debug ----------------------------------------------------------------------------
+    def dump(self):
+        """-> keys [B,3] i32, hashes [B] u64, counts [B,bs^3] i32, sums [B,bs^3,6] f32, key-sorted."""
+        nb = self.num_blocks()
+        nv = self.block_size ** 3
+        keys = np.zeros((nb, 3), np.int32)
+        hashes = np.zeros(nb, np.uint64)
+        counts = np.zeros((nb, nv), np.int32)
+        sums = np.zeros((nb, nv, 6), np.float32)
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_dump_blocks(self._h, L.ptr(keys), L.ptr(hashes), L.ptr(counts), L.ptr(sums), ctypes.byref(n)))
+        return keys, hashes, counts, sums
+
+    def keys_from_points(self, points):
+        pts = np.ascontiguousarray(points, dtype=np.float32)
+        n = pts.shape[0]
+        vk = np.zeros((n, 3), np.int32)
+        bk = np.zeros((n, 3), np.int32)
+        lk = np.zeros((n, 3), np.int32)
+        h = np.zeros(n, np.uint64)
+        L.check(self._lib.hv_keys_from_points(self._h, L.ptr(pts), n, L.ptr(vk), L.ptr(bk), L.ptr(lk), L.ptr(h)))
+        return vk, bk, lk, h
+
+
+class TBBUtils:
+    """`volumetric.TBBUtils` exists only so callers' thread-cap call keeps working; the GPU path has
+    no CPU worker threads (cpp/volumetric/tbb_utils.h:29-58)."""
+
+    @staticmethod
+    def set_max_threads(num_threads):
+        return None
+
+
+# ================================================================================================
+# open3d slice mirror (TSDF)
+# ================================================================================================
+class PinholeCameraIntrinsic:
+    """o3d.camera.PinholeCameraIntrinsic(width, height, fx, fy, cx, cy)."""
+
+    def __init__(self, width, height, fx, fy, cx, cy):
+        self.width = int(width)
+        self.height = int(height)
+        self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+
+    def as_array(self):
+        return np.array([self.fx, self.fy, self.cx, self.cy], dtype=np.float64)
+
+
+class RGBDImage:
+    """o3d.geometry.RGBDImage.create_from_color_and_depth(color, depth, depth_scale, depth_trunc,
+    convert_rgb_to_intensity=False): the scale/trunc conversion itself runs on the GPU inside
+    integrate(); this object only carries the operands."""
+
+    def __init__(self, color, depth, depth_scale=1000.0, depth_trunc=3.0):
+        self.color = color
+        self.depth = depth
+        self.depth_scale = float(depth_scale)
+        self.depth_trunc = float(depth_trunc)
+
+    @staticmethod
+    def create_from_color_and_depth(color, depth, depth_scale=1000.0, depth_trunc=3.0, convert_rgb_to_intensity=True):
+        if convert_rgb_to_intensity:
+            raise RuntimeError("[ScalableTSDFVolume::Integrate] Unsupported image format.")
+        return RGBDImage(color, depth, depth_scale, depth_trunc)
+
+
+class TriangleMesh:
+    def __init__(self, vertices, triangles, vertex_colors):
+        self.vertices = vertices
+        self.triangles = triangles
+        self.vertex_colors = vertex_colors
+        self.vertex_normals = np.zeros((0, 3), np.float64)  # compute_vertex_normals() is not called by pySLAM
+
+
+class PointCloud:
+    def __init__(self, points, colors):
+        self.points = points
+        self.colors = colors
+
+
+class ScalableTSDFVolume(_Volume):
+    """o3d.pipelines.integration.ScalableTSDFVolume(voxel_length, sdf_trunc, color_type=RGB8) on
+    the GPU (volume_unit_resolution=16, depth_sampling_stride=4 as in Open3D)."""
+
+    def __init__(self, voxel_length, sdf_trunc, color_type=None, volume_unit_resolution=16,
+                 depth_sampling_stride=4, device=0, max_blocks=None, max_points=None):
+        super().__init__(L.HV_MODE_TSDF, voxel_length, sdf_trunc, volume_unit_resolution, depth_sampling_stride,
+                         device, max_blocks, max_points)
+        self.voxel_length = float(voxel_length)
+        self.sdf_trunc = float(sdf_trunc)
+        self.res = int(volume_unit_resolution)
+
+    def reset(self):
+        L.check(self._lib.hv_reset(self._h))
+
+    def integrate(self, image, intrinsic, extrinsic):
+        """image: RGBDImage (color HxWx3 uint8 RGB, depth HxW float32|uint16); extrinsic = T_cw."""
+        depth, color = image.depth, image.color
+        dkind = L.HV_DEPTH_U16 if str(depth.dtype) in ("uint16", "torch.uint16") else L.HV_DEPTH_F32
+        if not hasattr(depth, "data_ptr"):
+            depth = np.ascontiguousarray(depth, dtype=np.uint16 if dkind == L.HV_DEPTH_U16 else np.float32)
+            color = np.ascontiguousarray(color, dtype=np.uint8)
+        H, W = int(depth.shape[0]), int(depth.shape[1])
+        if tuple(color.shape) != (H, W, 3) or intrinsic.width != W or intrinsic.height != H:
+            raise RuntimeError("[ScalableTSDFVolume::Integrate] Unsupported image format.")
+        if L.location(depth) != L.location(color):
+            raise RuntimeError("depth and color must live on the same device")
+        intr = intrinsic.as_array()
+        T = _as_f64_4x4(extrinsic)
+        L.check(
+            self._lib.hv_tsdf_integrate(
+                self._h, L.ptr(depth), dkind, L.ptr(color), H, W, L.ptr(intr), L.ptr(T), image.depth_scale,
+                image.depth_trunc, L.location(depth)
+            )
+        )
+
+    def integrate_batch(self, depth, color, intrinsic, extrinsics, depth_scale=1.0, depth_trunc=4.0):
+        """Replay F posed frames ([F,H,W] depth, [F,H,W,3] colour, [F,4,4] T_cw); same result as F
+        integrate() calls (the rebuild() use case, volumetric_integrator_base.py:1242-1318)."""
+        dkind = L.HV_DEPTH_U16 if str(depth.dtype) in ("uint16", "torch.uint16") else L.HV_DEPTH_F32
+        F, H, W = (int(s) for s in depth.shape)
+        T = np.ascontiguousarray(np.asarray(extrinsics, dtype=np.float64).reshape(F, 16))
+        intr = intrinsic.as_array()
+        L.check(
+            self._lib.hv_tsdf_integrate_batch(
+                self._h, L.ptr(depth), dkind, L.ptr(color), F, H, W, L.ptr(intr), L.ptr(T), float(depth_scale),
+                float(depth_trunc), L.location(depth)
+            )
+        )
+
+    def extract_triangle_mesh(self):
+        nv, nt = ctypes.c_int64(), ctypes.c_int64()
+        L.check(self._lib.hv_tsdf_extract_mesh(self._h, None, None, 0, None, 0, ctypes.byref(nv), ctypes.byref(nt)))
+        verts = np.zeros((nv.value, 3), np.float64)
+        cols = np.zeros((nv.value, 3), np.float64)
+        tris = np.zeros((nt.value, 3), np.int32)
+        if nv.value or nt.value:
+            L.check(
+                self._lib.hv_tsdf_extract_mesh(
+                    self._h, L.ptr(verts), L.ptr(cols), nv.value, L.ptr(tris), nt.value, ctypes.byref(nv), ctypes.byref(nt)
+                )
+            )
+        return TriangleMesh(verts, tris, cols)
+
+    def extract_point_cloud(self):
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_tsdf_extract_points(self._h, None, None, 0, ctypes.byref(n)))
+        pts = np.zeros((n.value, 3), np.float64)
+        cols = np.zeros((n.value, 3), np.float64)
+        if n.value:
+            L.check(self._lib.hv_tsdf_extract_points(self._h, L.ptr(pts), L.ptr(cols), n.value, ctypes.byref(n)))
+        return PointCloud(pts, cols)
+
+    # -- parity/debug + multi-GPU ------------------------------------------------------------------
+    def dump(self):
+        """-> keys [U,3], tsdf [U,R^3] f32, weight [U,R^3] f32, color [U,R^3,3] f64 (0..255), key-sorted,
+        voxel order x*R^2 + y*R + z (Open3D IndexOf)."""
+        nu = self.num_blocks()
+        nv = self.res ** 3
+        keys = np.zeros((nu, 3), np.int32)
+        tsdf = np.zeros((nu, nv), np.float32)
+        weight = np.zeros((nu, nv), np.float32)
+        color = np.zeros((nu, nv, 3), np.float64)
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_tsdf_dump(self._h, L.ptr(keys), L.ptr(tsdf), L.ptr(weight), L.ptr(color), ctypes.byref(n)))
+        return keys, tsdf, weight, color
+
+    def touched_keys(self):
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_tsdf_touched(self._h, None, 0, ctypes.byref(n)))
+        keys = np.zeros((n.value, 3), np.int32)
+        if n.value:
+            L.check(self._lib.hv_tsdf_touched(self._h, L.ptr(keys), n.value, ctypes.byref(n)))
+        return keys
+
+    def unit_keys(self):
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_tsdf_unit_keys(self._h, None, 0, ctypes.byref(n)))
+        keys = np.zeros((n.value, 3), np.int32)
+        if n.value:
+            L.check(self._lib.hv_tsdf_unit_keys(self._h, L.ptr(keys), n.value, ctypes.byref(n)))
+        return keys
+
+    def export_numerators(self, keys, out=None):
+        """keys [K,3] int32 -> payload [K, R^3, 5] float32 {sum tsdf*w, w, sum r, sum g, sum b}."""
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        k = keys.shape[0]
+        if out is None:
+            out = np.zeros((k, self.res ** 3, 5), np.float32)
+        L.check(self._lib.hv_tsdf_export_numerators(self._h, L.ptr(keys), k, L.ptr(out), L.location(out)))
+        return out
+
+    def import_numerators(self, keys, payload):
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        L.check(self._lib.hv_tsdf_import_numerators(self._h, L.ptr(keys), keys.shape[0], L.ptr(payload), L.location(payload)))
