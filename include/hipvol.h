@@ -141,6 +141,11 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
                             int32_t n_frames, int32_t height, int32_t width, const double *intr,
                             const double *T_cw, double depth_scale, double depth_trunc, int32_t loc);
 
+/* Multi-GPU image-tile sharding (north-star form): this volume fuses only voxels whose
+ * projection lands in pixel tile [u0,u1) x [v0,v1); units that cannot project into the tile are
+ * allocated (so all GPUs agree on the unit set) but not swept.  All zeros = whole image (default). */
+int hv_tsdf_set_tile(hv_volume *v, int32_t u0, int32_t v0, int32_t u1, int32_t v1);
+
 /* extract_triangle_mesh() (volumetric_integrator_tsdf.py:239,260).  vertices/vertex_colors f64
  * [V,3] (colours in [0,1]); triangles i32 [T,3].  NULL arrays = size query.  Host pointers. */
 int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, int64_t cap_vertices,

@@ -71,7 +71,7 @@ def _load_port():
     L.to_reset.argtypes = [_vp]
     L.to_set_threads.argtypes = [_vp, _i32]
     L.to_integrate.argtypes = [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _f64, _f64]
-    for name in ("to_num_units", "to_num_touched"):
+    for name in ("to_num_units", "to_num_touched", "to_last_updated"):
         getattr(L, name).restype = _i64
         getattr(L, name).argtypes = [_vp]
     L.to_touched_keys.restype = _i64
@@ -321,6 +321,12 @@ class PortTsdf:
 
     def num_units(self):
         return self._lib.to_num_units(self._h)
+
+    def num_touched(self):
+        return self._lib.to_num_touched(self._h)
+
+    def last_updated(self):
+        return self._lib.to_last_updated(self._h)
 
     def touched_keys(self):
         n = self._lib.to_num_touched(self._h)

@@ -50,6 +50,7 @@ typedef struct {
     int64_t frame;
     int64_t *touched; /* indices of units touched by the last integrate(), in touch order */
     int64_t num_touched, cap_touched;
+    int64_t last_updated; /* voxels updated by the last integrate() (roofline accounting) */
 } to_volume;
 
 static uint64_t to_mix(int32_t x, int32_t y, int32_t z) {
@@ -182,8 +183,9 @@ static inline float to_multiplier(const to_frame *f, int u, int v) {
 }
 
 /* UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier for one unit. */
-static void to_integrate_unit(const to_volume *vol, to_unit *unit, const to_frame *f) {
+static int64_t to_integrate_unit(const to_volume *vol, to_unit *unit, const to_frame *f) {
     const int R = vol->res;
+    int64_t updated = 0;
     const double origin[3] = {(double)unit->index[0] * vol->unit_length,
                               (double)unit->index[1] * vol->unit_length,
                               (double)unit->index[2] * vol->unit_length};
@@ -217,10 +219,12 @@ static void to_integrate_unit(const to_volume *vol, to_unit *unit, const to_fram
                     for (int c = 0; c < 3; ++c) vx->color[c] = (vx->color[c] * w + (double)rgb[c]) / wp1;
                     vx->tsdf = (vx->tsdf * vx->weight + tsdf) / (vx->weight + 1.0f);
                     vx->weight += 1.0f;
+                    ++updated;
                 }
             }
         }
     }
+    return updated;
 }
 
 /* RGBDImage::CreateFromColorAndDepth + ScalableTSDFVolume::Integrate.
@@ -290,15 +294,18 @@ void to_integrate(to_volume *vol, const void *depth_in, int depth_kind, const ui
         }
     }
     /* each touched unit is integrated exactly once per frame; units are independent */
-#pragma omp parallel for schedule(dynamic, 4) num_threads(vol->threads) if (vol->threads > 1)
+    int64_t updated = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(vol->threads) if (vol->threads > 1) reduction(+ : updated)
     for (int64_t t = 0; t < vol->num_touched; ++t) {
-        to_integrate_unit(vol, &vol->units[vol->touched[t]], &f);
+        updated += to_integrate_unit(vol, &vol->units[vol->touched[t]], &f);
     }
+    vol->last_updated = updated;
     free(depth);
 }
 
 int64_t to_num_units(const to_volume *v) { return v->num_units; }
 int64_t to_num_touched(const to_volume *v) { return v->num_touched; }
+int64_t to_last_updated(const to_volume *v) { return v->last_updated; }
 
 static int to_cmp_key(const int32_t *a, const int32_t *b) {
     for (int k = 0; k < 3; ++k)

@@ -63,6 +63,7 @@ SIGNATURES = {
     "hv_keys_from_points": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "hv_tsdf_integrate": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_tsdf_integrate_batch": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
+    "hv_tsdf_set_tile": (_i32, [_vp, _i32, _i32, _i32, _i32]),
     "hv_tsdf_extract_mesh": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _pi64, _pi64]),
     "hv_tsdf_extract_points": (_i32, [_vp, _vp, _vp, _i64, _pi64]),
     "hv_tsdf_dump": (_i32, [_vp, _vp, _vp, _vp, _vp, _pi64]),
@@ -93,6 +94,13 @@ def load():
     path = _build.LIB_PATH
     if not os.path.exists(path):
         _build.build(verbose=False)
+    # One HIP runtime per process: PyTorch-ROCm dlopens its bundled libamdhip64/libhsa-runtime64 by
+    # absolute path, so if this library pulled in /opt/rocm's copies first the process would hold
+    # two HSA runtimes and whichever initialises second sees no devices.  Importing torch first
+    # makes our DT_NEEDED libamdhip64.so.7 resolve to the already-loaded runtime, which is also
+    # what lets torch CUDA tensors and torch streams be passed straight into the C ABI.
+    import torch  # noqa: F401
+
     lib = _c.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -194,6 +194,7 @@ struct HvFrameParams { // per-frame constants of the TSDF kernels (passed by val
     int32_t H, W, stride;
     int32_t depth_is_u16;
     int32_t frame_id;       // touched stamp value (> 0)
+    int32_t tile_u0, tile_v0, tile_u1, tile_v1; // image-space tile owned by this GPU: [u0,u1) x [v0,v1)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -220,11 +221,12 @@ struct hv_volume {
     int32_t *touched_stamp = nullptr; // [table_capacity] last frame id that touched the slot
     int32_t *touched_list = nullptr;  // [max_blocks] slots touched this frame
     uint64_t *touched_mask = nullptr; // [table_capacity] per-slot frame bitmask (batch mode)
-    float *depth_f32 = nullptr;       // [batch * max_points] converted depth
-    uint32_t *rgba = nullptr;         // [batch * max_points] packed colour
+    void *frame_px = nullptr;         // [max_points] uint2 {depth f32 bits, packed rgb}: the gather target
+    int debug_variant = 0;            // env HV_TSDF_DEBUG_VARIANT (roofline ablation only)
     int32_t frame_counter = 0;
     int32_t last_touch_parity = 0;
     int32_t frame_batch_cap = 0;
+    int32_t tile[4] = {0, 0, 0, 0}; // u0, v0, u1, v1; all zero = whole image
 
     // staging for HV_HOST inputs
     void *stage_a = nullptr;

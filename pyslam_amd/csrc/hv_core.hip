@@ -213,8 +213,8 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
         HV_TRY(hipMalloc(&v->touched_list, sizeof(int32_t) * cfg->max_blocks));
         HV_TRY(hipMalloc(&v->touched_mask, sizeof(uint64_t) * v->table_capacity));
         v->frame_batch_cap = 1;
-        HV_TRY(hipMalloc(&v->depth_f32, sizeof(float) * cfg->max_points));
-        HV_TRY(hipMalloc(&v->rgba, sizeof(uint32_t) * cfg->max_points));
+        HV_TRY(hipMalloc(&v->frame_px, 8 * (size_t)cfg->max_points));
+        if (const char *dv = getenv("HV_TSDF_DEBUG_VARIANT")) v->debug_variant = atoi(dv);
     } else {
         HV_TRY(hipMalloc(&v->sort_keys_in, sizeof(uint32_t) * cfg->max_points));
         HV_TRY(hipMalloc(&v->sort_keys_out, sizeof(uint32_t) * cfg->max_points));
@@ -237,7 +237,7 @@ void hv_destroy(hv_volume *v) {
     (void)hipSetDevice(v->device);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     void *bufs[] = {v->table.keys, v->table.vals, v->table.block_keys, v->table.counters, v->pool,
-                    v->touched_stamp, v->touched_list, v->touched_mask, v->depth_f32, v->rgba,
+                    v->touched_stamp, v->touched_list, v->touched_mask, v->frame_px,
                     v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                     v->sort_vals_out, v->sort_tmp, v->scratch_points, v->scratch_colors, v->out_a,
                     v->out_b, v->out_c};

@@ -18,6 +18,7 @@
 // voxel written).  No reuse of voxel data -> no LDS staging; depth/colour gathers are served by
 // L1/L2 (one 640x480 frame = 2.4 MB packed, resident in every XCD's 4 MiB L2).
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <numeric>
 
@@ -42,78 +43,130 @@ __device__ __forceinline__ float hv_convert_depth(const HvFrameParams &P, const 
     return p;
 }
 
+// Conservative test: can any voxel centre of unit (ux,uy,uz) project into this GPU's image tile?
+// (Only used to skip units when the frame is tile-sharded across GPUs; with the default whole-image
+// tile every touched unit is kept, exactly as in ScalableTSDFVolume::Integrate.)
+__device__ inline bool hv_unit_hits_tile(const HvFrameParams &P, int32_t ux, int32_t uy, int32_t uz) {
+    if (P.tile_u0 <= 0 && P.tile_v0 <= 0 && P.tile_u1 >= P.W && P.tile_v1 >= P.H) return true;
+    const float len = (float)P.unit_length;
+    const float o[3] = {(float)((double)ux * P.unit_length), (float)((double)uy * P.unit_length),
+                        (float)((double)uz * P.unit_length)};
+    float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
+    for (int c = 0; c < 8; ++c) {
+        const float x = o[0] + ((c & 1) ? len : 0.0f), y = o[1] + ((c & 2) ? len : 0.0f), z = o[2] + ((c & 4) ? len : 0.0f);
+        const float pz = P.ext[8] * x + P.ext[9] * y + P.ext[10] * z + P.ext[11];
+        if (pz <= 1.0e-3f) return true; // straddles the camera plane: keep
+        const float px = P.ext[0] * x + P.ext[1] * y + P.ext[2] * z + P.ext[3];
+        const float py = P.ext[4] * x + P.ext[5] * y + P.ext[6] * z + P.ext[7];
+        const float u = px * P.fx / pz + P.cx + 0.5f, v = py * P.fy / pz + P.cy + 0.5f;
+        umin = fminf(umin, u); umax = fmaxf(umax, u);
+        vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+    }
+    return umax + 2.0f >= (float)P.tile_u0 && umin - 2.0f < (float)P.tile_u1 && vmax + 2.0f >= (float)P.tile_v0 &&
+           vmin - 2.0f < (float)P.tile_v1;
+}
+
 __global__ __launch_bounds__(256) void k_tsdf_prep_touch(HvTable table, int32_t *__restrict__ stamp,
                                                           int32_t *__restrict__ list, int parity,
                                                           const void *__restrict__ depth_raw,
                                                           const uint8_t *__restrict__ rgb,
-                                                          float *__restrict__ depth_out,
-                                                          uint32_t *__restrict__ rgba_out, HvFrameParams P,
+                                                          uint2 *__restrict__ frame_px, HvFrameParams P,
                                                           int n_prep_blocks) {
     const int64_t npx = (int64_t)P.H * P.W;
     if ((int)blockIdx.x < n_prep_blocks) {
+        // prep role: one 8-byte {depth f32, rgb packed} record per pixel so that the per-voxel
+        // gather of the integrate kernel is a single dwordx2 load
         const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (i >= npx) return;
-        depth_out[i] = hv_convert_depth(P, depth_raw, i);
         const uint8_t *c = rgb + i * 3;
-        rgba_out[i] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+        uint2 rec;
+        rec.x = __float_as_uint(hv_convert_depth(P, depth_raw, i));
+        rec.y = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+        frame_px[i] = rec;
         return;
     }
     // ---- touch role: PointCloud::CreateFromDepthImage(stride) + unit enumeration, all f64 ----
     const int ns_w = (P.W + P.stride - 1) / P.stride;
     const int ns_h = (P.H + P.stride - 1) / P.stride;
     const int s = ((int)blockIdx.x - n_prep_blocks) * blockDim.x + threadIdx.x;
-    if (s >= ns_w * ns_h) return;
-    const int i = (s / ns_w) * P.stride;
-    const int j = (s % ns_w) * P.stride;
-    const float p = hv_convert_depth(P, depth_raw, (int64_t)i * P.W + j);
-    if (!(p > 0.0f)) return;
-    const double z = (double)p;
-    const double x = ((double)j - P.cx_d) * z / P.fx_d;
-    const double y = ((double)i - P.cy_d) * z / P.fy_d;
-    int32_t lo[3], hi[3];
+    int32_t lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1}; // empty range for lanes without a valid sample
+    if (s < ns_w * ns_h) {
+        const int i = (s / ns_w) * P.stride;
+        const int j = (s % ns_w) * P.stride;
+        const float p = hv_convert_depth(P, depth_raw, (int64_t)i * P.W + j);
+        if (p > 0.0f) {
+            const double z = (double)p;
+            const double x = ((double)j - P.cx_d) * z / P.fx_d;
+            const double y = ((double)i - P.cy_d) * z / P.fy_d;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const double pw = ((P.pose[r * 4 + 0] * x + P.pose[r * 4 + 1] * y) + P.pose[r * 4 + 2] * z) + P.pose[r * 4 + 3];
-        lo[r] = (int32_t)floor((pw - P.sdf_trunc_d) / P.unit_length);
-        hi[r] = (int32_t)floor((pw + P.sdf_trunc_d) / P.unit_length);
+            for (int r = 0; r < 3; ++r) {
+                const double pw = ((P.pose[r * 4 + 0] * x + P.pose[r * 4 + 1] * y) + P.pose[r * 4 + 2] * z) + P.pose[r * 4 + 3];
+                lo[r] = (int32_t)floor((pw - P.sdf_trunc_d) / P.unit_length);
+                hi[r] = (int32_t)floor((pw + P.sdf_trunc_d) / P.unit_length);
+            }
+        }
     }
-    for (int32_t ux = lo[0]; ux <= hi[0]; ++ux)
-        for (int32_t uy = lo[1]; uy <= hi[1]; ++uy)
-            for (int32_t uz = lo[2]; uz <= hi[2]; ++uz) {
-                if (!hv_key_in_range(ux, uy, uz)) {
-                    atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
-                    continue;
-                }
-                const int32_t slot = hv_table_insert(table, hv_pack_key(ux, uy, uz));
-                if (slot < 0) continue;
-                if (stamp[slot] == P.frame_id) continue; // cheap pre-check (may be stale: exch decides)
+    // Enumerate the lane's units k = 0,1,... ; per k the wave de-duplicates equal keys with
+    // ballots (neighbouring samples hit the same 8 cm units) and only group leaders go to the hash:
+    // ~8x fewer device-scope atomics than one insert per sample.
+    const int nx = hi[0] - lo[0] + 1, ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+    const int count = (nx > 0 && ny > 0 && nz > 0) ? nx * ny * nz : 0;
+    const int lane = hv_lane_id();
+    for (int k = 0; __any(k < count); ++k) {
+        unsigned long long key = HV_EMPTY_KEY;
+        int32_t ux = 0, uy = 0, uz = 0;
+        if (k < count) {
+            ux = lo[0] + k / (ny * nz);
+            uy = lo[1] + (k / nz) % ny;
+            uz = lo[2] + k % nz;
+            if (hv_key_in_range(ux, uy, uz)) {
+                key = hv_pack_key(ux, uy, uz);
+            } else {
+                atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
+            }
+        }
+        bool leader = false;
+        unsigned long long remaining = __ballot(key != HV_EMPTY_KEY);
+        while (remaining) {
+            const int first = __ffsll((long long)remaining) - 1;
+            const unsigned long long fkey = __shfl(key, first);
+            const unsigned long long same = __ballot(key == fkey);
+            if (lane == first) leader = true;
+            remaining &= ~same;
+        }
+        if (leader) {
+            const int32_t slot = hv_table_insert(table, key);
+            if (slot >= 0) {
                 const int32_t old = atomicExch(&stamp[slot], P.frame_id);
-                if (old != P.frame_id) {
+                if (old != P.frame_id && hv_unit_hits_tile(P, ux, uy, uz)) {
                     const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0 + parity], 1);
                     if (at < table.max_blocks) list[at] = slot;
                 }
             }
+        }
+    }
 }
 
 // One voxel update: UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier inner body.
-__device__ __forceinline__ bool hv_tsdf_update(const HvFrameParams &P, const float *__restrict__ depth,
-                                               const uint32_t *__restrict__ rgba, float pc0, float pc1,
-                                               float pc2, float &tsdf, uint32_t &w, uint32_t &sr,
-                                               uint32_t &sg, uint32_t &sb) {
+__device__ __forceinline__ bool hv_tsdf_update(const HvFrameParams &P, const uint2 *__restrict__ frame_px,
+                                               float pc0, float pc1, float pc2, float &tsdf, uint32_t &w,
+                                               uint32_t &sr, uint32_t &sg, uint32_t &sb) {
     if (pc2 <= 0.0f) return false;
     const float u_f = pc0 * P.fx / pc2 + P.cx + 0.5f;
     const float v_f = pc1 * P.fy / pc2 + P.cy + 0.5f;
     if (!(u_f >= 0.0001f && u_f < P.safe_width_f && v_f >= 0.0001f && v_f < P.safe_height_f)) return false;
     const int u = (int)u_f;
     const int v = (int)v_f;
-    const int64_t px = (int64_t)v * P.W + u;
-    const float d = depth[px];
+    // multi-GPU image-tile sharding: a voxel is fused by the GPU that owns the pixel it projects to
+    if (u < P.tile_u0 || u >= P.tile_u1 || v < P.tile_v0 || v >= P.tile_v1) return false;
+    const uint2 rec = frame_px[(int64_t)v * P.W + u];
+    const float d = __uint_as_float(rec.x);
     if (d <= 0.0f) return false;
     const float sdf = (d - pc2) * hv_multiplier(P, u, v);
     if (!(sdf > -P.sdf_trunc_f)) return false;
     float t = sdf * P.sdf_trunc_inv_f;
     if (t > 1.0f) t = 1.0f;
-    const uint32_t c = rgba[px];
+    const uint32_t c = rec.y;
     const float wf = (float)w;
     tsdf = (tsdf * wf + t) / (wf + 1.0f);
     w += 1u;
@@ -123,10 +176,13 @@ __device__ __forceinline__ bool hv_tsdf_update(const HvFrameParams &P, const flo
     return true;
 }
 
+// VARIANT 0: production (all 4 z-slabs prefetched).  3: per-slab loads (A/B of the prefetch).  1: no voxel-plane traffic (math + gathers only).  2: plane traffic only
+// (no projection/gather/update).  1 and 2 exist for the roofline ablation in profiles/ (env
+// HV_TSDF_DEBUG_VARIANT); they do not produce a valid volume.
+template <int VARIANT>
 __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int32_t *__restrict__ list,
                                                          int parity, char *__restrict__ pool,
-                                                         const float *__restrict__ depth,
-                                                         const uint32_t *__restrict__ rgba, HvFrameParams P) {
+                                                         const uint2 *__restrict__ frame_px, HvFrameParams P) {
     int n_touched = table.counters[HV_CNT_TOUCH0 + parity];
     if (n_touched > table.max_blocks) n_touched = table.max_blocks;
     if (blockIdx.x == 0 && threadIdx.x == 0) table.counters[HV_CNT_TOUCH0 + (parity ^ 1)] = 0;
@@ -168,27 +224,59 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int
             }
         }
         char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
+        const int word0 = z0 * RR + x * R + y0;
+        // issue all 4 z-slabs' loads (20 x 1 KiB bursts per wave) before the first use
+        float4 vt[4];
+        uint4 vw[4], vr[4], vg[4], vb[4];
+        if (VARIANT == 3) {
+            // loads issued per z-slab inside the loop below (lower register pressure, 6 waves/SIMD)
+        } else if (VARIANT != 1) {
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz) {
+                const int q = (word0 + zz * RR) >> 2;
+                vt[zz] = ((const float4 *)(unit + 0 * PLANE_BYTES))[q];
+                vw[zz] = ((const uint4 *)(unit + 1 * PLANE_BYTES))[q];
+                vr[zz] = ((const uint4 *)(unit + 2 * PLANE_BYTES))[q];
+                vg[zz] = ((const uint4 *)(unit + 3 * PLANE_BYTES))[q];
+                vb[zz] = ((const uint4 *)(unit + 4 * PLANE_BYTES))[q];
+            }
+        } else {
+#pragma unroll
+            for (int zz = 0; zz < 4; ++zz) {
+                vt[zz] = make_float4(0.f, 0.f, 0.f, 0.f);
+                vw[zz] = vr[zz] = vg[zz] = vb[zz] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
 #pragma unroll
         for (int zz = 0; zz < 4; ++zz) {
-            const int word = (z0 + zz) * RR + x * R + y0;
-            float4 *pt = (float4 *)(unit + 0 * PLANE_BYTES) + (word >> 2);
-            uint4 *pw = (uint4 *)(unit + 1 * PLANE_BYTES) + (word >> 2);
-            uint4 *pr = (uint4 *)(unit + 2 * PLANE_BYTES) + (word >> 2);
-            uint4 *pg = (uint4 *)(unit + 3 * PLANE_BYTES) + (word >> 2);
-            uint4 *pb = (uint4 *)(unit + 4 * PLANE_BYTES) + (word >> 2);
-            float4 vt = *pt;
-            uint4 vw = *pw, vr = *pr, vg = *pg, vb = *pb;
             bool any = false;
-            any |= hv_tsdf_update(P, depth, rgba, pc[0][0], pc[0][1], pc[0][2], vt.x, vw.x, vr.x, vg.x, vb.x);
-            any |= hv_tsdf_update(P, depth, rgba, pc[1][0], pc[1][1], pc[1][2], vt.y, vw.y, vr.y, vg.y, vb.y);
-            any |= hv_tsdf_update(P, depth, rgba, pc[2][0], pc[2][1], pc[2][2], vt.z, vw.z, vr.z, vg.z, vb.z);
-            any |= hv_tsdf_update(P, depth, rgba, pc[3][0], pc[3][1], pc[3][2], vt.w, vw.w, vr.w, vg.w, vb.w);
-            if (any) {
-                *pt = vt;
-                *pw = vw;
-                *pr = vr;
-                *pg = vg;
-                *pb = vb;
+            if (VARIANT == 3) {
+                const int q = (word0 + zz * RR) >> 2;
+                vt[zz] = ((const float4 *)(unit + 0 * PLANE_BYTES))[q];
+                vw[zz] = ((const uint4 *)(unit + 1 * PLANE_BYTES))[q];
+                vr[zz] = ((const uint4 *)(unit + 2 * PLANE_BYTES))[q];
+                vg[zz] = ((const uint4 *)(unit + 3 * PLANE_BYTES))[q];
+                vb[zz] = ((const uint4 *)(unit + 4 * PLANE_BYTES))[q];
+            }
+            if (VARIANT != 2) {
+                any |= hv_tsdf_update(P, frame_px, pc[0][0], pc[0][1], pc[0][2], vt[zz].x, vw[zz].x, vr[zz].x, vg[zz].x, vb[zz].x);
+                any |= hv_tsdf_update(P, frame_px, pc[1][0], pc[1][1], pc[1][2], vt[zz].y, vw[zz].y, vr[zz].y, vg[zz].y, vb[zz].y);
+                any |= hv_tsdf_update(P, frame_px, pc[2][0], pc[2][1], pc[2][2], vt[zz].z, vw[zz].z, vr[zz].z, vg[zz].z, vb[zz].z);
+                any |= hv_tsdf_update(P, frame_px, pc[3][0], pc[3][1], pc[3][2], vt[zz].w, vw[zz].w, vr[zz].w, vg[zz].w, vb[zz].w);
+            } else {
+                vw[zz].x += 1u;
+                any = true;
+            }
+            if (VARIANT == 1) {
+                // keep the math alive without plane traffic
+                if (any && vt[zz].x == 123.456f) ((float *)unit)[0] = vt[zz].y + (float)(vr[zz].x + vg[zz].y + vb[zz].z + vw[zz].w);
+            } else if (any) {
+                const int q = (word0 + zz * RR) >> 2;
+                ((float4 *)(unit + 0 * PLANE_BYTES))[q] = vt[zz];
+                ((uint4 *)(unit + 1 * PLANE_BYTES))[q] = vw[zz];
+                ((uint4 *)(unit + 2 * PLANE_BYTES))[q] = vr[zz];
+                ((uint4 *)(unit + 3 * PLANE_BYTES))[q] = vg[zz];
+                ((uint4 *)(unit + 4 * PLANE_BYTES))[q] = vb[zz];
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -296,6 +384,11 @@ static int make_frame_params(hv_volume *v, int H, int W, const double *intr, con
     P->W = W;
     P->stride = v->cfg.depth_sampling_stride;
     P->depth_is_u16 = depth_dtype == HV_DEPTH_U16;
+    const bool whole = v->tile[0] == 0 && v->tile[1] == 0 && v->tile[2] == 0 && v->tile[3] == 0;
+    P->tile_u0 = whole ? 0 : v->tile[0];
+    P->tile_v0 = whole ? 0 : v->tile[1];
+    P->tile_u1 = whole ? W : v->tile[2];
+    P->tile_v1 = whole ? H : v->tile[3];
     return HV_OK;
 }
 
@@ -314,13 +407,25 @@ static int tsdf_integrate_one(hv_volume *v, const void *d_depth, int depth_dtype
     const int ns = ((W + P.stride - 1) / P.stride) * ((H + P.stride - 1) / P.stride);
     const int n_touch_blocks = (ns + 255) / 256;
     hipLaunchKernelGGL(k_tsdf_prep_touch, dim3(n_prep_blocks + n_touch_blocks), dim3(256), 0, v->stream,
-                       v->table, v->touched_stamp, v->touched_list, parity, d_depth, d_rgb, v->depth_f32,
-                       v->rgba, P, n_prep_blocks);
+                       v->table, v->touched_stamp, v->touched_list, parity, d_depth, d_rgb, (uint2 *)v->frame_px,
+                       P, n_prep_blocks);
     hv_profile_begin(v);
     // grid: enough workgroups to fill 256 CUs x 8 resident 4-wave groups; grid-stride over the
     // device-side touched count (no host round trip between the two launches)
-    hipLaunchKernelGGL(k_tsdf_integrate, dim3(4096), dim3(256), 0, v->stream, v->table, v->touched_list,
-                       parity, (char *)v->pool, v->depth_f32, v->rgba, P);
+    const dim3 grid(4096), block(256);
+    if (v->debug_variant == 1) {
+        hipLaunchKernelGGL(k_tsdf_integrate<1>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
+                           (char *)v->pool, (const uint2 *)v->frame_px, P);
+    } else if (v->debug_variant == 2) {
+        hipLaunchKernelGGL(k_tsdf_integrate<2>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
+                           (char *)v->pool, (const uint2 *)v->frame_px, P);
+    } else if (v->debug_variant == 3) {
+        hipLaunchKernelGGL(k_tsdf_integrate<3>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
+                           (char *)v->pool, (const uint2 *)v->frame_px, P);
+    } else {
+        hipLaunchKernelGGL(k_tsdf_integrate<0>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
+                           (char *)v->pool, (const uint2 *)v->frame_px, P);
+    }
     hv_profile_end(v, 0);
     HV_HIP(hipGetLastError());
     return HV_OK;
@@ -375,6 +480,18 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
                                 depth_scale, depth_trunc);
         if (rc != HV_OK) return rc;
     }
+    return HV_OK;
+}
+
+int hv_tsdf_set_tile(hv_volume *v, int32_t u0, int32_t v0, int32_t u1, int32_t v1) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_tsdf_set_tile: null volume");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_set_tile: volume is not in TSDF mode");
+    HV_REQUIRE((u0 == 0 && v0 == 0 && u1 == 0 && v1 == 0) || (u0 >= 0 && v0 >= 0 && u1 > u0 && v1 > v0), HV_ERR_INVALID,
+               "hv_tsdf_set_tile: empty tile");
+    v->tile[0] = u0;
+    v->tile[1] = v0;
+    v->tile[2] = u1;
+    v->tile[3] = v1;
     return HV_OK;
 }
 

@@ -1,0 +1,107 @@
+"""Multi-GPU TSDF fusion: one process per GPU, frames sharded by image tile, RCCL merge over xGMI.
+
+pySLAM itself has no multi-GPU path (no NCCL/MPI/torch.distributed call anywhere); this
+is new design (north-star form):
+
+* every rank sees every posed frame; rank r fuses only the voxels whose projection falls into its
+  vertical image tile [r*W/N, (r+1)*W/N) (``hv_tsdf_set_tile``): a voxel projects to exactly one
+  pixel, so within a frame the ranks' updates are disjoint and per-frame work divides by N;
+* units are allocated identically on all ranks (the touch pass looks at the whole image), units
+  that cannot project into a rank's tile are not swept there;
+* each rank's volume holds *partial* running means.  ``merge()`` turns them into additive
+  numerators {sum w*tsdf, w, sum r, sum g, sum b}, sum-reduces them to the root rank in ~64 MB
+  buckets (ring collectives over xGMI are per-link bound, ~153 GB/s: a few large messages), imports
+  the merged state on the root and clears the other ranks, which keep fusing deltas — the next
+  merge is again a plain sum.  The only collectives are an all-gather of unit keys (12 B/unit) and
+  the bucketed reduce.
+
+The volume object is duck-typed (unit_keys / export_numerators / import_numerators / reset /
+set_tile) so the collective logic is exercised on CPU with the gloo backend in tests/.
+"""
+import numpy as np
+
+
+def tile_bounds(rank, world_size, width, height):
+    """Vertical strip of rank `rank`: (u0, v0, u1, v1)."""
+    return (rank * width) // world_size, 0, ((rank + 1) * width) // world_size, height
+
+
+def union_keys(key_sets):
+    """Sorted unique [K,3] int32 union of several [n_i,3] key arrays."""
+    allk = np.concatenate([np.asarray(k, dtype=np.int32).reshape(-1, 3) for k in key_sets], axis=0)
+    if allk.shape[0] == 0:
+        return allk
+    return np.unique(allk, axis=0)
+
+
+class TileShardedTSDF:
+    BUCKET_BYTES = 64 << 20
+
+    def __init__(self, voxel_length, sdf_trunc, width, height, device=0, max_blocks=None, rank=0, world_size=1,
+                 process_group=None, volume=None, group=None):
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.width, self.height = int(width), int(height)
+        self.group = group
+        self.distributed = self.world_size > 1
+        if volume is None:
+            from .volumetric import ScalableTSDFVolume
+
+            volume = ScalableTSDFVolume(voxel_length, sdf_trunc, device=device, max_blocks=max_blocks,
+                                        max_points=max(width * height, 1 << 16))
+        self.volume = volume
+        self.tile = tile_bounds(self.rank, self.world_size, self.width, self.height)
+        if self.distributed:
+            self.volume.set_tile(*self.tile)
+
+    # -- fusion ----------------------------------------------------------------------------------
+    def integrate(self, image, intrinsic, extrinsic):
+        self.volume.integrate(image, intrinsic, extrinsic)
+
+    def integrate_batch(self, depth, color, intrinsic, extrinsics, depth_scale=1.0, depth_trunc=4.0):
+        self.volume.integrate_batch(depth, color, intrinsic, extrinsics, depth_scale, depth_trunc)
+
+    # -- merge -----------------------------------------------------------------------------------
+    def _gather_keys(self, keys, dist, torch, dev):
+        n_local = torch.tensor([keys.shape[0]], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(n_local) for _ in range(self.world_size)]
+        dist.all_gather(counts, n_local, group=self.group)
+        counts = [int(c.item()) for c in counts]
+        cap = max(max(counts), 1)
+        buf = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
+        if keys.shape[0]:
+            buf[: keys.shape[0]] = torch.from_numpy(np.ascontiguousarray(keys)).to(dev)
+        gathered = [torch.zeros_like(buf) for _ in range(self.world_size)]
+        dist.all_gather(gathered, buf, group=self.group)
+        return [g[:c].cpu().numpy() for g, c in zip(gathered, counts)]
+
+    def merge(self, root=0):
+        """Sum-reduce all ranks' partial volumes into rank `root`; the other ranks are cleared.
+        Returns the number of merged units."""
+        if not self.distributed:
+            return 0
+        import torch
+        import torch.distributed as dist
+
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+        keys = union_keys(self._gather_keys(self.volume.unit_keys(), dist, torch, dev))
+        k = keys.shape[0]
+        if k == 0:
+            return 0
+        res3 = self.volume.res ** 3
+        units_per_bucket = max(1, self.BUCKET_BYTES // (res3 * 5 * 4))
+        for b0 in range(0, k, units_per_bucket):
+            sub = keys[b0 : b0 + units_per_bucket]
+            # torch.empty: the export kernel (volume's own HIP stream, synchronised on return) writes
+            # every element, so no fill kernel on torch's stream can race with it
+            payload = torch.empty((sub.shape[0], res3, 5), dtype=torch.float32, device=dev)
+            self.volume.export_numerators(sub, out=payload if on_gpu else payload.numpy())
+            dist.reduce(payload, dst=root, op=dist.ReduceOp.SUM, group=self.group)
+            if on_gpu:
+                torch.cuda.current_stream().synchronize()  # RCCL result visible before the import kernel reads it
+            if self.rank == root:
+                self.volume.import_numerators(sub, payload if on_gpu else payload.numpy())
+            del payload
+        if self.rank != root:
+            self.volume.reset()
+        return k

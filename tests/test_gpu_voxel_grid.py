@@ -1,0 +1,228 @@
+"""GPU parity: VOXEL_GRID mode vs the compiled reference (oracle/_ref) / its C restatement.
+
+Bar: block keys, BlockKeyHash, per-voxel count AND the float32 position/colour sums are bit-exact
+(the GPU folds every voxel's points in point-index order, the reference's sequential order)."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import host_prep as hp
+from tests.conftest import sort_rows, synthetic_frames
+
+pytestmark = pytest.mark.gpu
+
+
+def make_oracle(voxel, bs=8):
+    return oracle.RefGrid(voxel, bs) if oracle.ref_available() else oracle.PortGrid(voxel, bs)
+
+
+def assert_same_grid(gpu, cpu):
+    a, b = gpu.dump(), cpu.dump()
+    assert a[0].shape == b[0].shape, (a[0].shape, b[0].shape)
+    np.testing.assert_array_equal(a[0], b[0])  # block keys
+    np.testing.assert_array_equal(a[1], b[1])  # BlockKeyHash
+    np.testing.assert_array_equal(a[2], b[2])  # counts
+    np.testing.assert_array_equal(a[3].view(np.uint32), b[3].view(np.uint32))  # sums, bitwise
+
+
+def adversarial_points(rng, voxel, n):
+    """negative coords, exact voxel multiples, +/-0, denormals, block boundaries."""
+    vs = np.float32(voxel)
+    k = rng.integers(-4000, 4000, size=(n, 3)).astype(np.float32)
+    exact = k * vs
+    nudged = np.nextafter(exact, np.float32(np.inf) * rng.choice([-1, 1], size=(n, 3)).astype(np.float32))
+    special = np.array(
+        [[0.0, -0.0, 1e-45], [-1e-45, 1e-38, -1e-38], [-0.001, 0.5, 1.25], [8 * voxel, -8 * voxel, 16 * voxel],
+         [-vs, vs, -2 * vs]], dtype=np.float32)
+    rand = (rng.random((n, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(40.0)
+    return np.concatenate([exact, nudged, special, rand]).astype(np.float32)
+
+
+@pytest.mark.parametrize("voxel", [0.005, 0.004, 0.002, 0.015, 0.05])
+def test_keys_bit_exact(voxel):
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    rng = np.random.default_rng(1)
+    pts = adversarial_points(rng, voxel, 200_000)
+    g = VoxelBlockGrid(voxel, 8, max_blocks=1 << 12, max_points=1 << 20)
+    got = g.keys_from_points(pts)
+    want = oracle.keys(pts, voxel, 8, "ref" if oracle.ref_available() else "port")
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("color_kind", ["f32", "u8", "none"])
+def test_integrate_points_bit_exact(color_kind):
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    s, frames = synthetic_frames("synthetic_640x480_5mm", 3, 3)
+    gpu = VoxelBlockGrid(0.005, 8, max_blocks=1 << 17, max_points=1 << 20)
+    cpu = make_oracle(0.005)
+    for depth, rgb, T in frames:
+        pts, cols, _ = hp.frame_to_world_f32(depth, rgb, *s.intrinsics, T, 4.0)
+        c = {"f32": cols, "u8": (cols * 255).astype(np.uint8), "none": None}[color_kind]
+        gpu.integrate(pts, c)
+        cpu.integrate(pts, c)
+    assert gpu.dropped_points() == 0
+    assert gpu.num_blocks() == cpu.num_blocks()
+    assert gpu.size() == cpu.size()
+    assert_same_grid(gpu, cpu)
+    # get_voxels as key-sorted sets (H8: the reference's row order is its hash-map order)
+    for min_count in (1, 3):
+        v = gpu.get_voxels(min_count)
+        pa, ca = sort_rows(v.points, v.colors)
+        pb, cb = sort_rows(*cpu.get_voxels(min_count))
+        np.testing.assert_array_equal(pa, pb)
+        np.testing.assert_array_equal(ca, cb)
+
+
+def test_integrate_device_resident_inputs():
+    import torch
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    s, frames = synthetic_frames("tiny_160x120_2cm", 0, 2)
+    gpu = VoxelBlockGrid(0.02, 8, max_blocks=1 << 14, max_points=1 << 18)
+    cpu = make_oracle(0.02)
+    for depth, rgb, T in frames:
+        pts, cols, _ = hp.frame_to_world_f32(depth, rgb, *s.intrinsics, T, 4.0)
+        gpu.integrate(torch.from_numpy(pts).cuda(), torch.from_numpy(cols).cuda())
+        cpu.integrate(pts, cols)
+    assert_same_grid(gpu, cpu)
+
+
+def test_edge_cases_empty_ragged_duplicates():
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    gpu = VoxelBlockGrid(0.05, 8, max_blocks=1 << 10, max_points=1 << 16)
+    cpu = make_oracle(0.05)
+    assert gpu.empty() and gpu.size() == 0 and gpu.num_blocks() == 0
+    gpu.integrate(np.zeros((0, 3), np.float32))  # empty input is a no-op
+    assert gpu.get_voxels().points.shape == (0, 3)
+    one = np.array([[0.01, 0.02, 0.03]], np.float32)
+    many = np.repeat(one, 1000, axis=0)  # 1000 hits of one voxel: long ordered run
+    cols = np.linspace(0, 1, 3000, dtype=np.float32).reshape(1000, 3)
+    for g in (gpu, cpu):
+        g.integrate(one)
+        g.integrate(many, cols)
+    assert_same_grid(gpu, cpu)
+    with pytest.raises(RuntimeError, match="Nx3"):
+        gpu.integrate(np.zeros((4, 2), np.float32))
+    with pytest.raises(RuntimeError, match="same size"):
+        gpu.integrate(np.zeros((4, 3), np.float32), np.zeros((3, 3), np.float32))
+    with pytest.raises(RuntimeError, match="uint8 or float32"):
+        gpu.integrate(np.zeros((4, 3), np.float32), np.zeros((4, 3), np.float64))
+    gpu.clear()
+    cpu.clear()
+    assert gpu.empty() and gpu.num_blocks() == 0
+    gpu.integrate(many[:10], cols[:10])
+    cpu.integrate(many[:10], cols[:10])
+    assert_same_grid(gpu, cpu)
+
+
+def test_block_size_variants():
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    rng = np.random.default_rng(5)
+    pts = ((rng.random((50_000, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(3.0)).astype(np.float32)
+    cols = rng.random((50_000, 3), dtype=np.float32)
+    for bs in (4, 5, 8, 16):
+        gpu = VoxelBlockGrid(0.03, bs, max_blocks=1 << 15, max_points=1 << 17)
+        cpu = make_oracle(0.03, bs)
+        gpu.integrate(pts, cols)
+        cpu.integrate(pts, cols)
+        assert_same_grid(gpu, cpu)
+
+
+def test_fused_rgbd_matches_reference_prep():
+    """hv_integrate_rgbd_points == depth2pointcloud + world transform + integrate (H1): keys/counts
+    must match the oracle fed with the reference-style numpy points; sums to 1e-4 on the averages."""
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    s, frames = synthetic_frames("synthetic_640x480_5mm", 10, 2)
+    gpu = VoxelBlockGrid(0.005, 8, max_blocks=1 << 17, max_points=1 << 20)
+    cpu = make_oracle(0.005)
+    cpu_blas = make_oracle(0.005)
+    for depth, rgb, T in frames:
+        gpu.integrate_rgbd(depth, rgb, *s.intrinsics, T, max_depth=4.0)
+        pts, cols, _ = hp.frame_to_world_f32(depth, rgb, *s.intrinsics, T, 4.0, blas=False)
+        cpu.integrate(pts, cols)
+        pts_b, cols_b, _ = hp.frame_to_world_f32(depth, rgb, *s.intrinsics, T, 4.0, blas=True)
+        cpu_blas.integrate(pts_b, cols_b)
+    assert_same_grid(gpu, cpu)  # same documented operation order -> bit-exact
+    # against the literal numpy `R @ P.T` (BLAS order): report and bound the voxel-boundary ties
+    a, b = gpu.dump(), cpu_blas.dump()
+    if a[0].shape == b[0].shape and np.array_equal(a[0], b[0]):
+        mism = int((a[2] != b[2]).sum())
+    else:
+        mism = -1
+    total = int((b[2] > 0).sum())
+    assert mism == -1 or mism <= max(4, total // 10000), (mism, total)
+
+
+def test_queries_and_carve():
+    from pyslam_amd.volumetric import BoundingBox3D, CameraFrustrum, VoxelBlockGrid
+
+    s, frames = synthetic_frames("synthetic_640x480_5mm", 20, 2)
+    gpu = VoxelBlockGrid(0.005, 8, max_blocks=1 << 17, max_points=1 << 20)
+    cpu = make_oracle(0.005)
+    for depth, rgb, T in frames:
+        pts, cols, _ = hp.frame_to_world_f32(depth, rgb, *s.intrinsics, T, 4.0)
+        gpu.integrate(pts, cols)
+        cpu.integrate(pts, cols)
+    depth, rgb, T = frames[1]
+    intr = np.array(s.intrinsics, np.float32)
+    fr = CameraFrustrum(*s.intrinsics, s.width, s.height, T, depth_max=3.0, depth_min=0.5)
+    v = gpu.get_voxels_in_camera_frustrum(fr, min_count=2)
+    pa, ca = sort_rows(v.points, v.colors)
+    pb, cb = sort_rows(*cpu.get_voxels_in_camera_frustrum(intr, s.width, s.height, T, 3.0, 0.5, 2))
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(ca, cb)
+    bb = [2.0, 1.0, 0.2, 4.0, 3.0, 1.5]
+    v = gpu.get_voxels_in_bb(BoundingBox3D(bb[:3], bb[3:]), min_count=1)
+    pa, ca = sort_rows(v.points, v.colors)
+    pb, cb = sort_rows(*cpu.get_voxels_in_bb(np.array(bb), 1))
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(ca, cb)
+    # carve with a depth image pushed back by 0.5 m on the left half: voxels there are "in front"
+    dc = depth.copy()
+    dc[:, : s.width // 2] += 0.5
+    fr2 = CameraFrustrum(*s.intrinsics, s.width, s.height, T, depth_max=8.0, depth_min=0.01)
+    gpu.carve(fr2, dc, 0.03)
+    cpu.carve(intr, s.width, s.height, T, 8.0, 0.01, dc, 0.03)
+    assert_same_grid(gpu, cpu)
+    gpu.remove_low_count_voxels(2)
+    cpu.remove_low_count_voxels(2)
+    assert_same_grid(gpu, cpu)
+    assert gpu.size() == cpu.size()
+
+
+def test_full_size_properties():
+    """BASELINE full size (640x480 @ 5 mm, 8 frames): size-independent properties."""
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    s, frames = synthetic_frames("synthetic_640x480_5mm", 40, 8)
+    gpu = VoxelBlockGrid(0.005, 8, max_blocks=1 << 18, max_points=1 << 20)
+    total = 0
+    for depth, rgb, T in frames:
+        gpu.integrate_rgbd(depth, rgb, *s.intrinsics, T, max_depth=4.0)
+        total += int(((depth > 0) & (depth < 4.0)).sum())
+    keys, hashes, counts, sums = gpu.dump()
+    assert counts.sum() == total  # every valid pixel lands in exactly one voxel
+    assert len(np.unique(keys, axis=0)) == len(keys)  # block keys unique
+    occ = counts > 0
+    avg = sums[..., :3][occ] / counts[occ][:, None]
+    # averaged position lies inside its voxel: floor(avg / voxel) reproduces the key
+    bs = 8
+    lin = np.nonzero(occ)
+    lx, ly, lz = lin[1] % bs, (lin[1] // bs) % bs, lin[1] // (bs * bs)
+    vox = keys[lin[0]] * bs + np.stack([lx, ly, lz], 1)
+    inv = np.float32(1.0) / np.float32(0.005)
+    got = np.floor(avg.astype(np.float64) * np.float64(inv) + 1e-6 * np.sign(avg)).astype(np.int64)
+    assert (np.abs(got - vox) <= 1).all()
+    col = sums[..., 3:][occ] / counts[occ][:, None]
+    assert (col >= 0).all() and (col <= 1.0 + 1e-6).all()
+    # idempotence of extraction + reset round trip
+    n1 = gpu.size()
+    assert n1 == int(occ.sum()) == gpu.get_voxels(1).points.shape[0]
+    gpu.reset()
+    assert gpu.size() == 0 and gpu.num_blocks() == 0
