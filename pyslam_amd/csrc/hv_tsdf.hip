@@ -28,6 +28,7 @@ static constexpr int R = 16;
 static constexpr int RR = R * R;
 static constexpr int RRR = R * R * R;
 static constexpr int PLANE_BYTES = RRR * 4;
+static constexpr int HV_TOUCH_FAN = 8; // lanes per depth sample in the touch pass
 
 // Image::CreateDepthToCameraDistanceMultiplierFloatImage, evaluated per gather instead of tabulated.
 __device__ __forceinline__ float hv_multiplier(const HvFrameParams &P, int u, int v) {
@@ -86,9 +87,13 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch(HvTable table, int32_t 
         return;
     }
     // ---- touch role: PointCloud::CreateFromDepthImage(stride) + unit enumeration, all f64 ----
+    // HV_TOUCH_FAN lanes per sample: lane (sample, k0) handles the sample's units k0, k0+FAN, ... so
+    // the (usually 8) hash inserts of one sample run in parallel instead of as one latency chain.
     const int ns_w = (P.W + P.stride - 1) / P.stride;
     const int ns_h = (P.H + P.stride - 1) / P.stride;
-    const int s = ((int)blockIdx.x - n_prep_blocks) * blockDim.x + threadIdx.x;
+    const int tid = ((int)blockIdx.x - n_prep_blocks) * blockDim.x + threadIdx.x;
+    const int s = tid / HV_TOUCH_FAN;
+    const int k0 = tid % HV_TOUCH_FAN;
     int32_t lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1}; // empty range for lanes without a valid sample
     if (s < ns_w * ns_h) {
         const int i = (s / ns_w) * P.stride;
@@ -106,13 +111,10 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch(HvTable table, int32_t 
             }
         }
     }
-    // Enumerate the lane's units k = 0,1,... ; per k the wave de-duplicates equal keys with
-    // ballots (neighbouring samples hit the same 8 cm units) and only group leaders go to the hash:
-    // ~8x fewer device-scope atomics than one insert per sample.
     const int nx = hi[0] - lo[0] + 1, ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
     const int count = (nx > 0 && ny > 0 && nz > 0) ? nx * ny * nz : 0;
     const int lane = hv_lane_id();
-    for (int k = 0; __any(k < count); ++k) {
+    for (int k = k0; __any(k < count); k += HV_TOUCH_FAN) {
         unsigned long long key = HV_EMPTY_KEY;
         int32_t ux = 0, uy = 0, uz = 0;
         if (k < count) {
@@ -125,6 +127,8 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch(HvTable table, int32_t 
                 atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
             }
         }
+        // wave-level de-duplication: neighbouring samples hit the same 8 cm units; only one lane
+        // per distinct key goes to the hash (ballot + shuffle, no memory traffic)
         bool leader = false;
         unsigned long long remaining = __ballot(key != HV_EMPTY_KEY);
         while (remaining) {
@@ -137,10 +141,13 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch(HvTable table, int32_t 
         if (leader) {
             const int32_t slot = hv_table_insert(table, key);
             if (slot >= 0) {
-                const int32_t old = atomicExch(&stamp[slot], P.frame_id);
-                if (old != P.frame_id && hv_unit_hits_tile(P, ux, uy, uz)) {
-                    const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0 + parity], 1);
-                    if (at < table.max_blocks) list[at] = slot;
+                // L1-bypassing pre-check: most units were already stamped by another wave this frame
+                if (__hip_atomic_load(&stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.frame_id) {
+                    const int32_t old = atomicExch(&stamp[slot], P.frame_id);
+                    if (old != P.frame_id && hv_unit_hits_tile(P, ux, uy, uz)) {
+                        const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0 + parity], 1);
+                        if (at < table.max_blocks) list[at] = slot;
+                    }
                 }
             }
         }
@@ -176,7 +183,95 @@ __device__ __forceinline__ bool hv_tsdf_update(const HvFrameParams &P, const uin
     return true;
 }
 
-// VARIANT 0: production (all 4 z-slabs prefetched).  3: per-slab loads (A/B of the prefetch).  1: no voxel-plane traffic (math + gathers only).  2: plane traffic only
+// Two-phase form of the same update: hv_tsdf_eval decides whether the voxel is updated and with
+// what (needs only the frame), hv_tsdf_apply folds it into the voxel state.  Splitting them lets the
+// kernel fetch voxel planes only for lanes that really update something.
+__device__ __forceinline__ bool hv_tsdf_eval(const HvFrameParams &P, const uint2 *__restrict__ frame_px, float pc0,
+                                             float pc1, float pc2, float &t, uint32_t &rgb) {
+    if (pc2 <= 0.0f) return false;
+    const float u_f = pc0 * P.fx / pc2 + P.cx + 0.5f;
+    const float v_f = pc1 * P.fy / pc2 + P.cy + 0.5f;
+    if (!(u_f >= 0.0001f && u_f < P.safe_width_f && v_f >= 0.0001f && v_f < P.safe_height_f)) return false;
+    const int u = (int)u_f;
+    const int v = (int)v_f;
+    if (u < P.tile_u0 || u >= P.tile_u1 || v < P.tile_v0 || v >= P.tile_v1) return false;
+    const uint2 rec = frame_px[(int64_t)v * P.W + u];
+    const float d = __uint_as_float(rec.x);
+    if (d <= 0.0f) return false;
+    const float sdf = (d - pc2) * hv_multiplier(P, u, v);
+    if (!(sdf > -P.sdf_trunc_f)) return false;
+    t = sdf * P.sdf_trunc_inv_f;
+    if (t > 1.0f) t = 1.0f;
+    rgb = rec.y;
+    return true;
+}
+
+__device__ __forceinline__ void hv_tsdf_apply(bool valid, float t, uint32_t c, float &tsdf, uint32_t &w, uint32_t &sr,
+                                              uint32_t &sg, uint32_t &sb) {
+    if (!valid) return;
+    const float wf = (float)w;
+    tsdf = (tsdf * wf + t) / (wf + 1.0f);
+    w += 1u;
+    sr += c & 255u;
+    sg += (c >> 8) & 255u;
+    sb += (c >> 16) & 255u;
+}
+
+// ZB z-slabs of one lane (ZB x 4 voxels).  Phase 1 evaluates every voxel (ZB*4 independent 8-byte
+// gathers in flight, no voxel-plane traffic); phase 2 read-modify-writes only the 16-byte pieces
+// that hold an updated voxel.  pc[][] is advanced by ZB z-steps.
+template <int ZB>
+__device__ __forceinline__ void hv_tsdf_slabs(const HvFrameParams &P, const uint2 *__restrict__ frame_px,
+                                              char *__restrict__ unit, int wordb, float (&pc)[4][3], float inc0,
+                                              float inc1, float inc2) {
+    float tv[ZB][4];
+    uint32_t cv[ZB][4];
+    unsigned mask = 0;
+#pragma unroll
+    for (int zz = 0; zz < ZB; ++zz) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            tv[zz][c] = 0.f;
+            cv[zz][c] = 0u;
+            if (hv_tsdf_eval(P, frame_px, pc[c][0], pc[c][1], pc[c][2], tv[zz][c], cv[zz][c])) mask |= 1u << (zz * 4 + c);
+            pc[c][0] += inc0;
+            pc[c][1] += inc1;
+            pc[c][2] += inc2;
+        }
+    }
+    float4 vt[ZB];
+    uint4 vw[ZB], vr[ZB], vg[ZB], vb[ZB];
+#pragma unroll
+    for (int zz = 0; zz < ZB; ++zz) {
+        if ((mask >> (zz * 4)) & 15u) {
+            const int q = (wordb + zz * RR) >> 2;
+            vt[zz] = ((const float4 *)(unit + 0 * PLANE_BYTES))[q];
+            vw[zz] = ((const uint4 *)(unit + 1 * PLANE_BYTES))[q];
+            vr[zz] = ((const uint4 *)(unit + 2 * PLANE_BYTES))[q];
+            vg[zz] = ((const uint4 *)(unit + 3 * PLANE_BYTES))[q];
+            vb[zz] = ((const uint4 *)(unit + 4 * PLANE_BYTES))[q];
+        }
+    }
+#pragma unroll
+    for (int zz = 0; zz < ZB; ++zz) {
+        const unsigned m = (mask >> (zz * 4)) & 15u;
+        if (m) {
+            hv_tsdf_apply(m & 1u, tv[zz][0], cv[zz][0], vt[zz].x, vw[zz].x, vr[zz].x, vg[zz].x, vb[zz].x);
+            hv_tsdf_apply(m & 2u, tv[zz][1], cv[zz][1], vt[zz].y, vw[zz].y, vr[zz].y, vg[zz].y, vb[zz].y);
+            hv_tsdf_apply(m & 4u, tv[zz][2], cv[zz][2], vt[zz].z, vw[zz].z, vr[zz].z, vg[zz].z, vb[zz].z);
+            hv_tsdf_apply(m & 8u, tv[zz][3], cv[zz][3], vt[zz].w, vw[zz].w, vr[zz].w, vg[zz].w, vb[zz].w);
+            const int q = (wordb + zz * RR) >> 2;
+            ((float4 *)(unit + 0 * PLANE_BYTES))[q] = vt[zz];
+            ((uint4 *)(unit + 1 * PLANE_BYTES))[q] = vw[zz];
+            ((uint4 *)(unit + 2 * PLANE_BYTES))[q] = vr[zz];
+            ((uint4 *)(unit + 3 * PLANE_BYTES))[q] = vg[zz];
+            ((uint4 *)(unit + 4 * PLANE_BYTES))[q] = vb[zz];
+        }
+    }
+}
+
+// VARIANT 0: production (evaluate first, then fetch only the pieces that are updated).  6: unconditional
+// prefetch of all 4 z-slabs (round-1 first version).  3: per-slab loads (A/B of the prefetch).  1: no voxel-plane traffic (math + gathers only).  2: plane traffic only
 // (no projection/gather/update).  1 and 2 exist for the roofline ablation in profiles/ (env
 // HV_TSDF_DEBUG_VARIANT); they do not produce a valid volume.
 template <int VARIANT>
@@ -224,6 +319,28 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int
             }
         }
         char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
+        if (VARIANT == 4) { // ablation: the same 80 KiB read+written as one linear 20 KiB run per wave
+            uint4 *lin = (uint4 *)(unit + wave * 20480) + lane;
+            uint4 buf[20];
+#pragma unroll
+            for (int i = 0; i < 20; ++i) buf[i] = lin[i * 64];
+#pragma unroll
+            for (int i = 0; i < 20; ++i) {
+                buf[i].x += 1u;
+                lin[i * 64] = buf[i];
+            }
+            continue;
+        }
+        if (VARIANT == 0 || VARIANT == 5) {
+            // z-slabs evaluated per batch: 2 (107 VGPRs, 4 waves/SIMD) measured 7269 fps vs 6342 for 4
+            // (180 VGPRs, 2 waves/SIMD) on the headline config
+            constexpr int ZB = (VARIANT == 0) ? 2 : 4;
+#pragma unroll
+            for (int zb = 0; zb < 4; zb += ZB) {
+                hv_tsdf_slabs<ZB>(P, frame_px, unit, (z0 + zb) * RR + x * R + y0, pc, inc0, inc1, inc2);
+            }
+            continue;
+        }
         const int word0 = z0 * RR + x * R + y0;
         // issue all 4 z-slabs' loads (20 x 1 KiB bursts per wave) before the first use
         float4 vt[4];
@@ -405,7 +522,7 @@ static int tsdf_integrate_one(hv_volume *v, const void *d_depth, int depth_dtype
     const int64_t npx = (int64_t)H * W;
     const int n_prep_blocks = (int)((npx + 255) / 256);
     const int ns = ((W + P.stride - 1) / P.stride) * ((H + P.stride - 1) / P.stride);
-    const int n_touch_blocks = (ns + 255) / 256;
+    const int n_touch_blocks = (ns * HV_TOUCH_FAN + 255) / 256;
     hipLaunchKernelGGL(k_tsdf_prep_touch, dim3(n_prep_blocks + n_touch_blocks), dim3(256), 0, v->stream,
                        v->table, v->touched_stamp, v->touched_list, parity, d_depth, d_rgb, (uint2 *)v->frame_px,
                        P, n_prep_blocks);
@@ -418,6 +535,15 @@ static int tsdf_integrate_one(hv_volume *v, const void *d_depth, int depth_dtype
                            (char *)v->pool, (const uint2 *)v->frame_px, P);
     } else if (v->debug_variant == 2) {
         hipLaunchKernelGGL(k_tsdf_integrate<2>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
+                           (char *)v->pool, (const uint2 *)v->frame_px, P);
+    } else if (v->debug_variant == 5) {
+        hipLaunchKernelGGL(k_tsdf_integrate<5>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
+                           (char *)v->pool, (const uint2 *)v->frame_px, P);
+    } else if (v->debug_variant == 6) {
+        hipLaunchKernelGGL(k_tsdf_integrate<6>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
+                           (char *)v->pool, (const uint2 *)v->frame_px, P);
+    } else if (v->debug_variant == 4) {
+        hipLaunchKernelGGL(k_tsdf_integrate<4>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
                            (char *)v->pool, (const uint2 *)v->frame_px, P);
     } else if (v->debug_variant == 3) {
         hipLaunchKernelGGL(k_tsdf_integrate<3>, grid, block, 0, v->stream, v->table, v->touched_list, parity,

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the compiled reference (oracle/_ref/libref_volumetric.so).
+
+Run in the dev container (needs /root/reference to build oracle/_ref).  Inputs are regenerated from
+fixed seeds by tests/test_golden.py; only the reference's *outputs* are stored.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from oracle import host_prep as hp  # noqa: E402
+from pyslam_amd.synthetic import SyntheticRGBD  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_points(seed, n, voxel):
+    """Random + adversarial float32 points (shared with tests/test_golden.py)."""
+    rng = np.random.default_rng(seed)
+    vs = np.float32(voxel)
+    k = rng.integers(-300, 300, size=(n, 3)).astype(np.float32)
+    exact = k * vs
+    nudged = np.nextafter(exact, (rng.choice([-1.0, 1.0], size=(n, 3)) * np.inf).astype(np.float32))
+    special = np.array([[0.0, -0.0, 1e-45], [-1e-45, 1e-38, -1e-38], [-0.001, 0.5, 1.25],
+                        [8 * voxel, -8 * voxel, 16 * voxel], [-voxel, voxel, -2 * voxel]], dtype=np.float32)
+    rand = ((rng.random((n, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(6.0)).astype(np.float32)
+    pts = np.concatenate([exact, nudged, special, rand]).astype(np.float32)
+    cols = rng.random((pts.shape[0], 3), dtype=np.float32)
+    return pts, cols
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    assert oracle.ref_available(), "needs the compiled reference"
+    # 1. key arithmetic at the voxel sizes of the BASELINE configs (Appendix D: 0.004/0.002/0.015 have inexact f32 reciprocals)
+    for voxel in (0.005, 0.004, 0.002, 0.015):
+        pts, _ = golden_points(11, 1500, voxel)
+        vk, bk, lk, h = oracle.keys(pts, voxel, 8, "ref")
+        np.savez_compressed(os.path.join(OUT, f"keys_v{int(voxel * 1000):03d}.npz"), voxel_keys=vk, block_keys=bk,
+                            local_keys=lk, hashes=h)
+    # 2. integrate + get_voxels + remove_low_count on random/adversarial points, f32 and u8 colours
+    pts, cols = golden_points(12, 2500, 0.02)
+    g = oracle.RefGrid(0.02, 8)
+    g.integrate(pts, cols)
+    g.integrate(pts[::3], (cols[::3] * 255).astype(np.uint8))
+    g.integrate(pts[::7])
+    keys, hashes, counts, sums = g.dump()
+    occ = counts > 0
+    np.savez_compressed(os.path.join(OUT, "integrate_random.npz"), keys=keys, hashes=hashes, occ_block=np.nonzero(occ)[0].astype(np.int32),
+                        occ_voxel=np.nonzero(occ)[1].astype(np.int16), counts=counts[occ], sums=sums[occ], size=g.size())
+    # 3. a posed synthetic frame through the reference-style host prep, then queries and carving
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    g = oracle.RefGrid(0.02, 8)
+    for i in (0, 1):
+        depth, rgb, T = s[i]
+        p, c, _ = hp.frame_to_world_f32(depth, rgb, *s.intrinsics, T, 4.0)
+        g.integrate(p, c)
+    keys, hashes, counts, sums = g.dump()
+    occ = counts > 0
+    intr = np.array(s.intrinsics, np.float32)
+    depth, rgb, T = s[1]
+    fp, fc = g.get_voxels_in_camera_frustrum(intr, s.width, s.height, T, 3.0, 0.5, 2)
+    bb = np.array([2.0, 1.0, 0.2, 4.0, 3.0, 1.5])
+    bp, bc = g.get_voxels_in_bb(bb, 1)
+    gv, gc = g.get_voxels(3)
+    dc = depth.copy()
+    dc[:, : s.width // 2] += 0.5
+    g.carve(intr, s.width, s.height, T, 8.0, 0.01, dc, 0.03)
+    keys2, _, counts2, _ = g.dump()
+
+    def srt(a, b):
+        i = np.lexsort(a.T[::-1])
+        return a[i], b[i]
+
+    fp, fc = srt(fp, fc)
+    bp, bc = srt(bp, bc)
+    gv, gc = srt(gv, gc)
+    np.savez_compressed(os.path.join(OUT, "frame_tiny.npz"), keys=keys, hashes=hashes, occ_block=np.nonzero(occ)[0].astype(np.int32),
+                        occ_voxel=np.nonzero(occ)[1].astype(np.int16), counts=counts[occ], sums=sums[occ],
+                        frustum_points=fp, frustum_colors=fc, bb_points=bp, bb_colors=bc, voxels3_points=gv, voxels3_colors=gc,
+                        carved_total=int(counts2.sum()), carved_occupied=int((counts2 > 0).sum()))
+    # 4. CameraFrustrum::contains on a point grid
+    rng = np.random.default_rng(13)
+    P = (rng.random((400, 3)) * np.array([6, 4, 3])).astype(np.float32)
+    res = [oracle.frustum_contains(intr, s.width, s.height, T, 8.0, 0.01, p, "ref") for p in P]
+    np.savez_compressed(os.path.join(OUT, "frustum_contains.npz"), inside=np.array([r[0] for r in res]),
+                        uvd=np.stack([r[1] for r in res]), bbox=oracle.frustum_bbox(intr, s.width, s.height, T, 8.0, 0.01, "ref"))
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
