@@ -97,6 +97,12 @@ int hv_integrate_rgbd_points(hv_volume *v, const void *depth, int32_t depth_dtyp
                              const uint8_t *rgb, int32_t height, int32_t width, const double *intr,
                              const double *T_cw, double min_depth, double max_depth, int32_t loc);
 
+/* filter_shadow_points(depth, delta_depth=None, delta_x=2, delta_y=2, fill_value=-1)
+ * (pyslam/utilities/depth.py:103-146): MAD-thresholded depth-discontinuity filter, bit-identical to
+ * the numpy reference for float32 depth.  Works on any volume (uses its stream and scratch). */
+int hv_filter_shadow_points(hv_volume *v, const float *depth, int32_t height, int32_t width, int32_t delta_x,
+                            int32_t delta_y, float fill_value, float *out, int32_t loc);
+
 /* get_voxels(min_count, min_confidence) (voxel_block_grid.hpp:717-819): rows = sum / count.
  * Pass points == NULL to query *n only.  At most `cap` rows are written; *n is the full count. */
 int hv_get_voxels(hv_volume *v, int32_t min_count, float min_confidence, float *points,

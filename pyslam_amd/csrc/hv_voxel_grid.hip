@@ -277,6 +277,53 @@ __global__ __launch_bounds__(256) void k_vg_probe_keys(const float *__restrict__
     hashes[i] = hv_reference_hash(k.b[0], k.b[1], k.b[2]);
 }
 
+
+// ---- filter_shadow_points (pyslam/utilities/depth.py:103-146) -----------------------------------
+// |d(r,c) - d(r-dy,c)| and |d(r,c) - d(r,c-dx)|; threshold = 3 * 1.4826 * median(positive deltas)
+// (float32 arithmetic, as numpy evaluates it for a float32 image); both endpoints of a large jump
+// are replaced by fill_value.  The global median is a device radix sort of the positive deltas'
+// bit patterns (order-preserving for positive floats) + a read of the middle element(s).
+__global__ __launch_bounds__(256) void k_shadow_deltas(const float *__restrict__ depth, int H, int W, int dx, int dy,
+                                                        uint32_t *__restrict__ keys, int32_t *__restrict__ n_pos) {
+    const int64_t n_y = dy > 0 ? (int64_t)(H - dy) * W : 0;
+    const int64_t n_x = dx > 0 ? (int64_t)H * (W - dx) : 0;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool pos = false;
+    if (i < n_y + n_x) {
+        float d;
+        if (i < n_y) {
+            const int64_t r = i / W + dy, c = i % W;
+            d = fabsf(depth[r * W + c] - depth[(r - dy) * W + c]);
+        } else {
+            const int64_t j = i - n_y;
+            const int64_t r = j / (W - dx), c = j % (W - dx) + dx;
+            d = fabsf(depth[r * W + c] - depth[r * W + c - dx]);
+        }
+        pos = d > 0.0f; // NaN compares false, like numpy's `delta_values > 0`
+        keys[i] = pos ? __float_as_uint(d) : 0xFFFFFFFFu;
+    }
+    const unsigned long long m = __ballot(pos);
+    if (m && hv_lane_id() == 0) atomicAdd(n_pos, (int32_t)__popcll(m));
+}
+
+__global__ __launch_bounds__(256) void k_shadow_mask(const float *__restrict__ depth, int H, int W, int dx, int dy,
+                                                      float thr, float fill, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)H * W) return;
+    const int r = (int)(i / W), c = (int)(i % W);
+    const float d = depth[i];
+    bool m = false;
+    if (dy > 0) {
+        if (r >= dy) m |= fabsf(d - depth[i - (int64_t)dy * W]) > thr;
+        if (r + dy < H) m |= fabsf(depth[i + (int64_t)dy * W] - d) > thr;
+    }
+    if (dx > 0) {
+        if (c >= dx) m |= fabsf(d - depth[i - dx]) > thr;
+        if (c + dx < W) m |= fabsf(depth[i + dx] - d) > thr;
+    }
+    out[i] = m ? fill : d;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -489,6 +536,60 @@ int hv_integrate_rgbd_points(hv_volume *v, const void *depth, int32_t depth_dtyp
     hipLaunchKernelGGL(k_vg_unproject, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream, d_depth,
                        (const uint8_t *)d_rgb, U, v->scratch_points, v->scratch_colors, v->sort_keys_out);
     return integrate_device_points(v, v->scratch_points, npx, v->scratch_colors, HV_COLOR_F32, v->sort_keys_out);
+}
+
+
+int hv_filter_shadow_points(hv_volume *v, const float *depth, int32_t height, int32_t width, int32_t delta_x,
+                            int32_t delta_y, float fill_value, float *out, int32_t loc) {
+    HV_REQUIRE(v != nullptr && depth != nullptr && out != nullptr, HV_ERR_INVALID, "hv_filter_shadow_points: null argument");
+    HV_REQUIRE(height > 0 && width > 0 && delta_x >= 0 && delta_y >= 0 && delta_x < width && delta_y < height,
+               HV_ERR_INVALID, "hv_filter_shadow_points: bad image size or deltas");
+    HV_HIP(hipSetDevice(v->device));
+    const int64_t npx = (int64_t)height * width;
+    const int64_t n_y = delta_y > 0 ? (int64_t)(height - delta_y) * width : 0;
+    const int64_t n_x = delta_x > 0 ? (int64_t)height * (width - delta_x) : 0;
+    const int64_t n = n_y + n_x;
+    const void *d_depth = nullptr;
+    int rc = hv_stage_in(v, depth, sizeof(float) * npx, loc, 0, &d_depth);
+    if (rc != HV_OK) return rc;
+    // scratch: [keys_in n][keys_out n][out npx]
+    rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, sizeof(uint32_t) * 2 * (size_t)std::max<int64_t>(n, 1) + sizeof(float) * npx);
+    if (rc != HV_OK) return rc;
+    uint32_t *keys_in = (uint32_t *)v->out_c, *keys_out = keys_in + std::max<int64_t>(n, 1);
+    float *d_out = loc == HV_DEVICE ? out : (float *)(keys_out + std::max<int64_t>(n, 1));
+    float thr = NAN; // np.median of an empty array -> nan -> nothing is masked
+    if (n > 0) {
+        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
+        hipLaunchKernelGGL(k_shadow_deltas, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream,
+                           (const float *)d_depth, height, width, delta_x, delta_y, keys_in, &v->table.counters[HV_CNT_OUT]);
+        size_t tmp = 0;
+        HV_HIP(rocprim::radix_sort_keys(nullptr, tmp, keys_in, keys_out, (size_t)n, 0, 32, v->stream));
+        rc = hv_ensure_buffer(v, &v->sort_tmp, &v->sort_tmp_bytes, tmp);
+        if (rc != HV_OK) return rc;
+        tmp = v->sort_tmp_bytes;
+        HV_HIP(rocprim::radix_sort_keys(v->sort_tmp, tmp, keys_in, keys_out, (size_t)n, 0, 32, v->stream));
+        rc = hv_read_counters(v);
+        if (rc != HV_OK) return rc;
+        const int64_t np_ = v->h_counters[HV_CNT_OUT];
+        if (np_ > 0) {
+            uint32_t mid[2] = {0, 0};
+            const int64_t lo = (np_ - 1) / 2, hi = np_ / 2; // equal for odd counts
+            HV_HIP(hipMemcpy(&mid[0], keys_out + lo, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            HV_HIP(hipMemcpy(&mid[1], keys_out + hi, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            float a, b;
+            memcpy(&a, &mid[0], 4);
+            memcpy(&b, &mid[1], 4);
+            const float mad = lo == hi ? a : (a + b) * 0.5f; // np.median -> np.mean of the two middle float32
+            const float sigma = 1.4826f * mad;
+            thr = 3.0f * sigma;
+        }
+    }
+    hipLaunchKernelGGL(k_shadow_mask, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream,
+                       (const float *)d_depth, height, width, delta_x, delta_y, thr, fill_value, d_out);
+    HV_HIP(hipGetLastError());
+    if (loc == HV_HOST) HV_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * npx, hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipStreamSynchronize(v->stream));
+    return HV_OK;
 }
 
 int hv_get_voxels(hv_volume *v, int32_t min_count, float min_confidence, float *points, float *colors,

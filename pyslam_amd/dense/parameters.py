@@ -1,0 +1,62 @@
+"""The dense-mapping knobs of pyslam/config_parameters.py:286-380, same names and defaults.
+
+When real pySLAM is importable its Parameters class is used instead (see get_parameters()), so a
+user's edits to config_parameters.py keep working."""
+
+
+class Parameters:
+    kDenseMappingDtypeVertices = "float32"
+    kDenseMappingDtypeColors = "float32"
+    kDenseMappingDtypeDepth = "float32"
+    kDenseMappingDtypeSemantics = "int32"
+    kDenseMappingDtypeObjectIds = "int32"
+    kDenseMappingDtypeTriangles = "uint32"
+
+    kDoVolumetricIntegration = False
+    kVolumetricIntegrationType = "VOXEL_GRID"
+    kVolumetricIntegrationVoxelLength = 0.015  # [m]
+    kVolumetricIntegrationUseVoxelBlocks = True
+    kVolumetricIntegrationBlockSize = 8
+    kVolumetricIntegrationTBBThreads = 2  # no meaning on the GPU path; kept for API parity
+    kVolumetricIntegrationFpsThrottleEnabled = True
+    kVolumetricIntegrationFpsThrottleMinQueueSize = 10
+    kVolumetricIntegrationFpsMaxThreshold = 10.0
+    kVolumetricIntegrationFpsThrottleBaseDelay = 0.01
+    kVolumetricIntegrationFpsThrottleScale = 0.1
+    kVolumetricIntegrationVoxelGridMinCount = 3
+    kVolumetricIntegrationVoxelGridMinConfidence = 0.6
+    kVolumetricIntegrationVoxelGridUseCarving = False
+    kVolumetricIntegrationVoxelGridCarvingDepthMin = 1e-2
+    kVolumetricIntegrationVoxelGridCarvingDepthMaxIndoor = 8.0
+    kVolumetricIntegrationVoxelGridCarvingDepthMaxOutdoor = 15.0
+    kVolumetricIntegrationVoxelGridCarvingDepthThreshold = 3e-2
+    kVolumetricIntegrationVoxelGridShadowPointsFilter = True
+    kVolumetricIntegrationTsdfExtractMesh = True
+    kVolumetricIntegrationTSdfTrunc = 0.04
+    kVolumetricIntegrationTsdfDepthTruncIndoor = 4.0
+    kVolumetricIntegrationTsdfDepthTruncOutdoor = 10.0
+    kVolumetricIntegrationMinNumLBATimes = 1
+    kVolumetricIntegrationOutputTimeInterval = 1.0
+    kVolumetricIntegrationUseDepthEstimator = False
+    kMultiprocessingProcessJoinDefaultTimeout = 5.0
+    kLoopDetectingTimeoutPopKeyframe = 0.5
+
+    # GPU-path additions (no reference counterpart)
+    kVolumetricIntegrationHipDevice = 0
+    kVolumetricIntegrationHipMaxBlocks = None  # None: library default pool size
+
+
+def get_parameters():
+    try:  # real pySLAM present: honour its (possibly edited) constants, add ours
+        from pyslam.config_parameters import Parameters as P  # type: ignore
+
+        for k, v in vars(Parameters).items():
+            if k.startswith("k") and not hasattr(P, k):
+                setattr(P, k, v)
+        return P
+    except Exception:
+        return Parameters
+
+
+def static_fields_to_dict(cls):
+    return {k: v for k, v in vars(cls).items() if k.startswith("k")}

@@ -1,0 +1,536 @@
+"""Mirror of pyslam/dense/volumetric_integrator_base.py: task/queue protocol, worker process loop,
+keyframe gating, output wrappers (reference lines cited per item).
+
+Differences that are deliberate (MI355X-first):
+* the worker is always a *spawned* process (the reference already spawns for TSDF, base.py:348-362)
+  and owns the HIP context; the volume stays resident in HBM for the life of the worker;
+* queues are plain multiprocessing queues of the spawn context instead of Manager proxies (one
+  pickle instead of two per frame); the names q_in / q_out / q_management and their semantics
+  (push-to-front for regular tasks, RESET on q_management) are unchanged;
+* undistortion (cv2.remap, base.py:1017-1043) is not part of this round's scope:
+  cameras with non-zero distortion are rejected loudly instead of being silently mis-fused.
+"""
+import multiprocessing as std_mp
+import os
+import signal
+import threading
+import time
+import traceback
+from collections import deque
+from enum import Enum
+
+import numpy as np
+
+from .parameters import get_parameters, static_fields_to_dict
+from .ply_io import write_ply_mesh, write_ply_points
+
+Parameters = get_parameters()
+
+kVerbose = False
+kVolumetricIntegratorProcessName = "VolumetricIntegratorProcess"  # base.py:88
+kLogFile = "logs/volumetric_integrator.log"  # base.py:462
+
+
+class VolumetricIntegrationTaskType(Enum):  # base.py:91-97
+    NONE = 0
+    INTEGRATE = 1
+    SAVE = 2
+    LOAD = 3
+    RESET = 4
+    UPDATE_OUTPUT = 5
+
+
+class VolumetricIntegrationKeyframeData:  # base.py:101-137
+    """Picklable snapshot of the keyframe fields the dense path consumes."""
+
+    def __init__(self, keyframe, img=None, img_right=None, depth=None, semantic_img=None, semantic_instances_img=None):
+        self.id = keyframe.id if keyframe is not None else -1
+        self.kid = keyframe.kid if keyframe is not None else -1
+        self.img_id = keyframe.img_id if keyframe is not None else -1
+        self.timestamp = keyframe.timestamp if keyframe is not None else -1
+        self.pose = keyframe.pose() if keyframe is not None else None  # Tcw
+        self.camera = keyframe.camera if keyframe is not None else None
+        self.img = img if img is not None else (keyframe.img if keyframe is not None else None)
+        self.img_right = img_right if img_right is not None else (getattr(keyframe, "img_right", None) if keyframe is not None else None)
+        self.depth = depth if depth is not None else (keyframe.depth_img if keyframe is not None else None)
+        self.semantic_img = semantic_img if semantic_img is not None else (getattr(keyframe, "semantic_img", None) if keyframe is not None else None)
+        self.semantic_instances_img = (
+            semantic_instances_img if semantic_instances_img is not None
+            else (getattr(keyframe, "semantic_instances_img", None) if keyframe is not None else None)
+        )
+
+
+class VolumetricIntegrationTask:  # base.py:140-156
+    def __init__(self, keyframe=None, img=None, img_right=None, depth=None, semantic_img=None,
+                 task_type=VolumetricIntegrationTaskType.NONE, load_save_path=None):
+        self.task_type = task_type
+        self.keyframe_data = VolumetricIntegrationKeyframeData(keyframe, img, img_right, depth, semantic_img)
+        self.load_save_path = load_save_path
+
+
+class VolumetricIntegrationPointCloud:  # base.py:159-206
+    def __init__(self, point_cloud=None, points=None, colors=None, semantics=None, object_ids=None,
+                 semantic_colors=None, object_colors=None):
+        if point_cloud is not None:
+            self.points = np.asarray(point_cloud.points)
+            self.colors = np.asarray(point_cloud.colors)
+            self.semantics = self.object_ids = self.semantic_colors = self.object_colors = None
+        else:
+            self.points = np.asarray(points) if points is not None else None
+            self.colors = np.asarray(colors) if colors is not None else None
+            self.semantics = np.asarray(semantics) if semantics is not None else None
+            self.object_ids = np.asarray(object_ids) if object_ids is not None else None
+            self.semantic_colors = np.asarray(semantic_colors) if semantic_colors is not None else None
+            self.object_colors = np.asarray(object_colors) if object_colors is not None else None
+
+    def to_o3d(self):
+        import open3d as o3d
+
+        pc = o3d.geometry.PointCloud()
+        pc.points = o3d.utility.Vector3dVector(self.points)
+        pc.colors = o3d.utility.Vector3dVector(self.colors)
+        return pc
+
+
+class VolumetricIntegrationMesh:  # base.py:209-226
+    def __init__(self, mesh):
+        self.vertices = np.asarray(mesh.vertices)
+        self.triangles = np.asarray(mesh.triangles)
+        self.vertex_colors = np.asarray(mesh.vertex_colors)
+        self.vertex_normals = np.asarray(mesh.vertex_normals)
+
+    def to_o3d(self):
+        import open3d as o3d
+
+        mesh = o3d.geometry.TriangleMesh()
+        mesh.vertices = o3d.utility.Vector3dVector(self.vertices)
+        mesh.triangles = o3d.utility.Vector3iVector(self.triangles)
+        mesh.vertex_colors = o3d.utility.Vector3dVector(self.vertex_colors)
+        mesh.vertex_normals = o3d.utility.Vector3dVector(self.vertex_normals)
+        return mesh
+
+
+class VolumetricIntegrationOutput:  # base.py:308-322
+    def __init__(self, task_type, id=-1, point_cloud=None, mesh=None, objects=None):
+        self.task_type = task_type
+        self.id = id
+        self.point_cloud = point_cloud
+        self.mesh = mesh
+        self.objects = objects
+        self.timestamp = time.perf_counter()
+
+
+def push_to_front(queue, item):
+    """pyslam/utilities/data_management.py:94-114: drain, then refill with `item` first."""
+    items = [item]
+    while True:
+        try:
+            items.append(queue.get(block=False))
+        except Exception:
+            break
+    for i in items:
+        try:
+            queue.put(i, block=False)
+        except Exception:
+            try:
+                queue.put(i, timeout=1.0)
+            except Exception:
+                pass
+
+
+def empty_queue(queue):
+    try:
+        while True:
+            queue.get(block=False)
+    except Exception:
+        pass
+
+
+class TimerFps:
+    """pyslam/utilities/timer.py:75-94: moving average over the last 10 intervals."""
+
+    def __init__(self, name="", average_width=10):
+        self.name = name
+        self.times = deque(maxlen=average_width)
+        self.last = None
+        self.last_elapsed = 0.0
+
+    def start(self):
+        self.last = time.perf_counter()
+
+    def refresh(self):
+        now = time.perf_counter()
+        if self.last is not None:
+            self.last_elapsed = now - self.last
+            self.times.append(self.last_elapsed)
+        self.last = now
+
+    def get_fps(self):
+        if not self.times:
+            return 0.0
+        mean = sum(self.times) / len(self.times)
+        return 1.0 / mean if mean > 0 else 0.0
+
+
+class _RepeatingTimer:
+    """SimpleTaskTimer(interval, callback, single_shot=False) of pyslam/utilities/timer.py."""
+
+    def __init__(self, interval, callback, name="timer"):
+        self.interval, self.callback, self.name = interval, callback, name
+        self._stop = threading.Event()
+        self._thread = None
+
+    def start(self):
+        self._thread = threading.Thread(target=self._loop, name=self.name, daemon=True)
+        self._thread.start()
+
+    def _loop(self):
+        while not self._stop.wait(self.interval):
+            try:
+                self.callback()
+            except Exception:
+                traceback.print_exc()
+
+    def stop(self):
+        self._stop.set()
+
+
+class VolumetricIntegratorBase:
+    """pyslam/dense/volumetric_integrator_base.py:328-1394 (public protocol)."""
+
+    print = staticmethod(lambda *a, **k: print(*a, **k) if kVerbose else None)
+
+    def __init__(self, camera, environment_type, sensor_type, volumetric_integrator_type, viewer_queue=None, **kwargs):
+        self.volumetric_integrator_type = volumetric_integrator_type
+        self.constructor_kwargs = kwargs
+        self.mp = std_mp.get_context("spawn")  # base.py:348-362: spawn is required once a GPU context is involved
+        mp = self.mp
+        self.camera = camera
+        self.environment_type = environment_type
+        self.sensor_type = sensor_type
+        self.viewer_queue = viewer_queue
+
+        self.keyframe_queue_timer = _RepeatingTimer(0.5, self.flush_keyframe_queue, "KeyframeQueueTimer")  # base.py:369-374
+        self.keyframe_queue_lock = threading.Lock()
+        self.keyframe_queue = deque()
+
+        self.volume = None
+        self.time_volumetric_integration = mp.Value("d", 0.0)  # base.py:383
+        self.last_input_task = None
+        self.last_output = None
+        self.last_integrated_id = -1
+
+        self.reset_mutex = mp.Lock()
+        self.reset_requested = mp.Value("i", -1)
+        self.load_request_completed = mp.Value("i", -1)
+        self.load_request_condition = mp.Condition()
+        self.save_request_completed = mp.Value("i", -1)
+        self.save_request_condition = mp.Condition()
+
+        self.q_in = mp.Queue()          # regular tasks (integrate, update output, save)
+        self.q_out = mp.Queue()         # outputs (visualise, save)
+        self.q_management = mp.Queue()  # management tasks (reset / rebuild)
+        self.parameters_dict = static_fields_to_dict(Parameters)  # snapshot for the child, base.py:412-416
+        self.q_in_condition = mp.Condition()
+        self.q_out_condition = mp.Condition()
+        self.is_running = mp.Value("i", 0)
+        self.is_looping = mp.Value("i", 0)
+        self.process = None
+        self.start()
+
+    def is_ready(self):  # base.py:451
+        return self.is_running.value == 1 and self.is_looping.value == 1
+
+    # -- pickling for the spawned child (base.py:495-526): drop what must not cross --------------
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ("keyframe_queue_timer", "keyframe_queue_lock", "keyframe_queue", "process", "mp", "volume"):
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.volume = None
+
+    def start(self):  # base.py:536-568
+        self.is_running.value = 1
+        self.process = self.mp.Process(
+            target=self.run,
+            args=(self.camera, self.environment_type, self.sensor_type, self.viewer_queue, self.q_in, self.q_in_condition,
+                  self.q_out, self.q_out_condition, self.q_management, self.is_running, self.is_looping, self.reset_mutex,
+                  self.reset_requested, self.load_request_completed, self.load_request_condition,
+                  self.save_request_completed, self.save_request_condition, self.time_volumetric_integration,
+                  self.parameters_dict, self.constructor_kwargs),
+            name=kVolumetricIntegratorProcessName,
+        )
+        self.process.daemon = True
+        self.process.start()
+        self.keyframe_queue_timer.start()
+
+    def _stop_volume_integrator_implementation(self):  # base.py:571
+        pass
+
+    # -- caller-side API --------------------------------------------------------------------------
+    def save(self, path):  # base.py:574-593
+        if self.save_request_completed.value == 0:
+            return
+        filepath = path + "/dense_map.ply"
+        task = VolumetricIntegrationTask(task_type=VolumetricIntegrationTaskType.SAVE, load_save_path=filepath)
+        self.save_request_completed.value = 0
+        self.add_task(task, front=True)
+        with self.save_request_condition:
+            while self.save_request_completed.value == 0 and self.is_running.value == 1:
+                self.save_request_condition.wait(timeout=1.0)
+
+    def load(self, path):  # base.py:595-604: a stub in the reference too
+        return None
+
+    def request_reset(self):  # base.py:606-631
+        with self.reset_mutex:
+            if self.reset_requested.value == 1:
+                return
+            self.reset_requested.value = 1
+        while self.is_running.value == 1:
+            with self.reset_mutex:
+                with self.q_in_condition:
+                    self.q_in_condition.notify_all()
+                if self.reset_requested.value == 0:
+                    break
+            time.sleep(0.1)
+        with self.keyframe_queue_lock:
+            self.keyframe_queue.clear()
+
+    def quit(self):  # base.py:652-700
+        if self.is_running.value != 1:
+            return
+        self.is_running.value = 0
+        self.keyframe_queue_timer.stop()
+        with self.q_in_condition:
+            self.q_in.put(None)
+            self.q_in_condition.notify_all()
+        with self.q_out_condition:
+            self.q_out_condition.notify_all()
+        self.process.join(timeout=2 * Parameters.kMultiprocessingProcessJoinDefaultTimeout)
+        if self.process.is_alive():
+            self.process.terminate()
+
+    def flush_keyframe_queue(self):  # base.py:1120-1188
+        with self.keyframe_queue_lock:
+            if len(self.keyframe_queue) == 0:
+                return
+            max_checks = len(self.keyframe_queue)
+            processed = 0
+            while len(self.keyframe_queue) > 0:
+                kf = self.keyframe_queue[0]
+                wait_for_semantics = bool(getattr(kf, "wait_for_semantics", False)) and not kf.is_semantics_available()
+                if kf.lba_count >= Parameters.kVolumetricIntegrationMinNumLBATimes and not wait_for_semantics:
+                    self.keyframe_queue.popleft()
+                    processed += 1
+                    self.add_task(VolumetricIntegrationTask(kf, task_type=VolumetricIntegrationTaskType.INTEGRATE))
+                else:
+                    if len(self.keyframe_queue) <= 1:
+                        break
+                    self.keyframe_queue.rotate(-1)
+                    processed += 1
+                if processed >= max_checks:
+                    break
+
+    def add_keyframe(self, keyframe, img, img_right, depth, print=print):  # base.py:1191-1214
+        if (depth is None or depth.size == 0) and not Parameters.kVolumetricIntegrationUseDepthEstimator:
+            return
+        with self.keyframe_queue_lock:
+            self.keyframe_queue.append(keyframe)
+        self.flush_keyframe_queue()
+
+    def add_task(self, task, front=True):  # base.py:1216-1232
+        if self.is_running.value == 1:
+            with self.q_in_condition:
+                if front:
+                    push_to_front(self.q_in, task)
+                else:
+                    self.q_in.put(task, timeout=1.0)
+                self.q_in_condition.notify_all()
+
+    def add_update_output_task(self):  # base.py:1234-1240
+        if self.is_running.value == 1:
+            with self.q_in_condition:
+                self.q_in.put(VolumetricIntegrationTask(task_type=VolumetricIntegrationTaskType.UPDATE_OUTPUT))
+                self.q_in_condition.notify_all()
+
+    def rebuild(self, map):  # base.py:1242-1318
+        if self.is_running.value != 1:
+            return
+        with self.q_in_condition:
+            empty_queue(self.q_in)
+        with self.q_in_condition:
+            self.q_management.put(VolumetricIntegrationTask(task_type=VolumetricIntegrationTaskType.RESET), timeout=1.0)
+            self.q_in_condition.notify_all()
+        wait_start = time.time()
+        while self.is_running.value == 1 and not self.q_management.empty():
+            if time.time() - wait_start > 5.0:
+                break
+            time.sleep(0.05)
+        with self.q_out_condition:
+            empty_queue(self.q_out)
+            self.q_out.put(VolumetricIntegrationOutput(VolumetricIntegrationTaskType.RESET))
+            self.q_out_condition.notify_all()
+        with self.keyframe_queue_lock:
+            self.keyframe_queue.clear()
+            for kf in map.keyframes:
+                if not kf.is_bad() and kf.lba_count >= Parameters.kVolumetricIntegrationMinNumLBATimes:
+                    if kf.depth_img is None:
+                        continue
+                    self.keyframe_queue.append(kf)
+        self.flush_keyframe_queue()
+
+    def pop_output(self, timeout=Parameters.kLoopDetectingTimeoutPopKeyframe):  # base.py:1320-1342
+        if self.is_running.value == 0:
+            return None
+        with self.q_out_condition:
+            while self.q_out.empty() and self.is_running.value == 1:
+                if not self.q_out_condition.wait(timeout=timeout):
+                    break
+        if self.q_out.empty():
+            return None
+        try:
+            return self.q_out.get(timeout=timeout)
+        except Exception:
+            return None
+
+    def draw_output(self, output):  # base.py:1344: forwards to pySLAM's viewer when it exists
+        if self.viewer_queue is not None and output is not None:
+            self.viewer_queue.put(output)
+
+    # -- worker side ------------------------------------------------------------------------------
+    def init(self, camera, environment_type, sensor_type, parameters_dict, constructor_kwargs):  # base.py:703-786
+        for k, v in (parameters_dict or {}).items():  # the snapshot taken in the parent wins
+            setattr(Parameters, k, v)
+        self.camera = camera
+        self.environment_type = environment_type
+        self.sensor_type = sensor_type
+        self.depth_factor = 1.0  # base.py:713: the factor is already folded into the keyframe depth
+        self.last_output = None
+        self.last_integrated_id = -1
+        D = np.asarray(getattr(camera, "D", np.zeros(5)), dtype=np.float64).ravel()
+        if np.linalg.norm(D) > 1e-10:
+            raise NotImplementedError(
+                "camera has lens distortion: undistort/rectify (cv2.remap, base.py:1017-1043) is outside this "
+                "round's scope (SURVEY 8f N1); feed rectified images"
+            )
+        self.dtype_vertices = np.dtype(Parameters.kDenseMappingDtypeVertices)
+        self.dtype_colors = np.dtype(Parameters.kDenseMappingDtypeColors)
+        self.dtype_depths = np.dtype(Parameters.kDenseMappingDtypeDepth)
+
+    def get_camera_intrinsics_for_depth(self):
+        return self.camera.fx, self.camera.fy, self.camera.cx, self.camera.cy
+
+    def estimate_depth_if_needed_and_rectify(self, keyframe_data):  # base.py:969-1062 (no estimator, no remap)
+        color, depth = keyframe_data.img, keyframe_data.depth
+        if depth is None or depth.size == 0:
+            return None, None, None, None, None
+        if depth.dtype != np.float32:
+            factor = getattr(self.camera, "depth_factor", 1.0) if getattr(self, "use_cpp_core", False) else 1.0
+            depth = depth.astype(np.float32) * np.float32(factor) if factor != 1.0 else depth.astype(np.float32)
+            keyframe_data.depth = depth
+        color_rgb = np.ascontiguousarray(color[..., ::-1])  # cv2.COLOR_BGR2RGB, base.py:1054
+        return color_rgb, depth, None, keyframe_data.semantic_img, keyframe_data.semantic_instances_img
+
+    def volume_integration(self, *args, **kwargs):  # base.py:1100-1117
+        raise NotImplementedError
+
+    def reset_if_requested(self, reset_mutex, reset_requested, q_in, q_in_condition, q_out, q_out_condition):  # base.py:633-650
+        with reset_mutex:
+            if reset_requested.value == 1:
+                with q_in_condition:
+                    empty_queue(q_in)
+                    q_in_condition.notify_all()
+                with q_out_condition:
+                    empty_queue(q_out)
+                    q_out_condition.notify_all()
+                try:
+                    self.volume.reset()
+                except Exception:
+                    traceback.print_exc()
+                reset_requested.value = 0
+
+    def run(self, camera, environment_type, sensor_type, viewer_queue, q_in, q_in_condition, q_out, q_out_condition,
+            q_management, is_running, is_looping, reset_mutex, reset_requested, load_request_completed,
+            load_request_condition, save_request_completed, save_request_condition, time_volumetric_integration,
+            parameters_dict, constructor_kwargs):  # base.py:789-967
+        is_running.value = 1
+
+        def signal_handler(signum, frame):
+            is_running.value = 0
+            with q_in_condition:
+                q_in_condition.notify_all()
+
+        try:
+            signal.signal(signal.SIGTERM, signal_handler)
+            signal.signal(signal.SIGINT, signal_handler)
+        except ValueError:
+            pass
+        try:
+            self.init(camera, environment_type, sensor_type, parameters_dict, constructor_kwargs)
+        except Exception:
+            traceback.print_exc()
+            is_running.value = 0
+            return
+        is_looping.value = 1
+        timer_fps = TimerFps("VolumetricIntegratorBase")
+        timer_fps.start()
+        while is_running.value == 1:
+            try:
+                has_management_task = not q_management.empty()
+                has_regular_task = not q_in.empty()
+                with q_in_condition:
+                    while (not has_management_task and not has_regular_task and is_running.value == 1
+                           and reset_requested.value != 1):
+                        q_in_condition.wait(timeout=1.0)
+                        has_management_task = not q_management.empty()
+                        has_regular_task = not q_in.empty()
+                if is_running.value == 0:
+                    break
+                if has_regular_task or has_management_task:
+                    q_in_size = q_in.qsize()
+                    self.volume_integration(q_in, q_out, q_out_condition, q_management, viewer_queue, is_running,
+                                            load_request_completed, load_request_condition, save_request_completed,
+                                            save_request_condition, time_volumetric_integration)
+                    timer_fps.refresh()
+                    fps = timer_fps.get_fps()
+                    if (Parameters.kVolumetricIntegrationFpsThrottleEnabled
+                            and q_in_size > Parameters.kVolumetricIntegrationFpsThrottleMinQueueSize
+                            and fps > Parameters.kVolumetricIntegrationFpsMaxThreshold > 0):  # base.py:923-938
+                        time.sleep(Parameters.kVolumetricIntegrationFpsThrottleBaseDelay
+                                   + (fps - Parameters.kVolumetricIntegrationFpsMaxThreshold) * Parameters.kVolumetricIntegrationFpsThrottleScale)
+                else:
+                    time.sleep(0.1)
+                self.reset_if_requested(reset_mutex, reset_requested, q_in, q_in_condition, q_out, q_out_condition)
+            except Exception:
+                traceback.print_exc()  # base.py:952-954: log and keep going
+        is_looping.value = 0
+        self._stop_volume_integrator_implementation()
+        empty_queue(q_in)
+        empty_queue(q_out)
+
+    # -- shared tail of every volume_integration(): publish or acknowledge ------------------------
+    def _publish(self, last_output, q_out, q_out_condition, is_running, save_request_completed, save_request_condition):
+        if is_running.value == 1 and last_output is not None:
+            if last_output.task_type in (VolumetricIntegrationTaskType.INTEGRATE, VolumetricIntegrationTaskType.UPDATE_OUTPUT):
+                with q_out_condition:
+                    last_output.timestamp = time.perf_counter()
+                    q_out.put(last_output)
+                    q_out_condition.notify_all()
+            elif last_output.task_type == VolumetricIntegrationTaskType.SAVE:
+                with save_request_condition:
+                    save_request_completed.value = 1
+                    save_request_condition.notify_all()
+
+    @staticmethod
+    def _save_mesh(path, mesh):
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        write_ply_mesh(path, mesh.vertices, mesh.triangles, mesh.vertex_colors)
+
+    @staticmethod
+    def _save_points(path, points, colors):
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        write_ply_points(path, points, colors)

@@ -1,0 +1,122 @@
+"""Mirror of pyslam/dense/volumetric_integrator_voxel_grid.py over the HIP library's VOXEL_GRID
+mode.  The L3 host prep of the reference (depth2pointcloud + world transform in numpy,
+voxel_grid.py:251-281) runs fused on the GPU (VoxelBlockGrid.integrate_rgbd)."""
+import time
+import traceback
+
+import numpy as np
+
+from .parameters import get_parameters
+from .volumetric_integrator_base import (
+    TimerFps,
+    VolumetricIntegrationOutput,
+    VolumetricIntegrationPointCloud,
+    VolumetricIntegrationTaskType,
+    VolumetricIntegratorBase,
+)
+from .volumetric_integrator_types import DatasetEnvironmentType
+
+Parameters = get_parameters()
+
+
+def _default_voxel_grid(voxel_size, block_size, device, max_blocks, max_points):
+    from ..volumetric import VoxelBlockGrid
+
+    return VoxelBlockGrid(voxel_size=voxel_size, block_size=block_size, device=device, max_blocks=max_blocks,
+                          max_points=max_points)
+
+
+class VolumetricIntegratorVoxelGrid(VolumetricIntegratorBase):
+    def init(self, camera, environment_type, sensor_type, parameters_dict, constructor_kwargs):  # voxel_grid.py:91-138
+        VolumetricIntegratorBase.init(self, camera, environment_type, sensor_type, parameters_dict, constructor_kwargs)
+        from ..volumetric import CameraFrustrum
+
+        indoor = getattr(environment_type, "name", str(environment_type)) == DatasetEnvironmentType.INDOOR.name
+        self.volumetric_integration_depth_trunc = (
+            Parameters.kVolumetricIntegrationTsdfDepthTruncIndoor if indoor else Parameters.kVolumetricIntegrationTsdfDepthTruncOutdoor
+        )
+        if not constructor_kwargs.get("use_voxel_blocks", True):
+            raise NotImplementedError("the direct voxel hash (VoxelGrid) is not part of the GPU path; use voxel blocks")
+        factory = constructor_kwargs.get("volume_factory", _default_voxel_grid)
+        self.volume = factory(Parameters.kVolumetricIntegrationVoxelLength, Parameters.kVolumetricIntegrationBlockSize,
+                              Parameters.kVolumetricIntegrationHipDevice, Parameters.kVolumetricIntegrationHipMaxBlocks,
+                              max(camera.width * camera.height, 1 << 16))
+        carving_depth_max = (Parameters.kVolumetricIntegrationVoxelGridCarvingDepthMaxIndoor if indoor
+                             else Parameters.kVolumetricIntegrationVoxelGridCarvingDepthMaxOutdoor)
+        fx, fy, cx, cy = self.get_camera_intrinsics_for_depth()
+        self.camera_frustrum = CameraFrustrum(fx, fy, cx, cy, camera.width, camera.height, np.eye(4),
+                                              depth_max=carving_depth_max,
+                                              depth_min=Parameters.kVolumetricIntegrationVoxelGridCarvingDepthMin)
+
+    def _get_output_cloud(self):
+        data = self.volume.get_voxels(min_count=Parameters.kVolumetricIntegrationVoxelGridMinCount,
+                                      min_confidence=Parameters.kVolumetricIntegrationVoxelGridMinConfidence)
+        points = np.ascontiguousarray(data.points, dtype=self.dtype_vertices)
+        colors = np.ascontiguousarray(data.colors, dtype=self.dtype_colors)
+        return points, colors
+
+    def volume_integration(self, q_in, q_out, q_out_condition, q_management, viewer_queue, is_running,
+                           load_request_completed, load_request_condition, save_request_completed,
+                           save_request_condition, time_volumetric_integration):  # voxel_grid.py:140-404
+        last_output = None
+        do_output = False
+        timer = TimerFps("VolumetricIntegratorVoxelGrid")
+        timer.start()
+        try:
+            if is_running.value == 1:
+                self.last_management_task = None
+                try:
+                    self.last_management_task = q_management.get_nowait()
+                except Exception:
+                    pass
+                if (self.last_management_task is not None
+                        and self.last_management_task.task_type == VolumetricIntegrationTaskType.RESET):
+                    self.volume.reset()
+                try:
+                    self.last_input_task = q_in.get(timeout=0.5)
+                except Exception:
+                    return
+                if self.last_input_task is None:
+                    is_running.value = 0
+                else:
+                    ttype = self.last_input_task.task_type
+                    if ttype == VolumetricIntegrationTaskType.INTEGRATE:
+                        keyframe_data = self.last_input_task.keyframe_data
+                        keyframe_data.semantic_img = None
+                        keyframe_data.semantic_instances_img = None
+                        color, depth, _, _, _ = self.estimate_depth_if_needed_and_rectify(keyframe_data)
+                        if depth is not None:
+                            pose = keyframe_data.pose  # Tcw
+                            depth_filtered = depth
+                            if Parameters.kVolumetricIntegrationVoxelGridShadowPointsFilter:
+                                depth_filtered = self.volume.filter_shadow_points(depth)  # depth.py:103-146 on the GPU
+                            fx, fy, cx, cy = self.get_camera_intrinsics_for_depth()
+                            if Parameters.kVolumetricIntegrationVoxelGridUseCarving:
+                                self.camera_frustrum.set_T_cw(pose)
+                                self.volume.carve(self.camera_frustrum, np.ascontiguousarray(depth, dtype=self.dtype_depths),
+                                                  Parameters.kVolumetricIntegrationVoxelGridCarvingDepthThreshold)
+                            # depth2pointcloud + world transform + integrate, fused on the GPU
+                            self.volume.integrate_rgbd(depth_filtered, color, fx, fy, cx, cy, pose,
+                                                       max_depth=self.volumetric_integration_depth_trunc)
+                            self.last_integrated_id = keyframe_data.id
+                            do_output = True
+                            if self.last_output is not None:
+                                if time.perf_counter() - self.last_output.timestamp < Parameters.kVolumetricIntegrationOutputTimeInterval:
+                                    do_output = False
+                    elif ttype == VolumetricIntegrationTaskType.SAVE:
+                        points, colors = self._get_output_cloud()
+                        if len(points) > 0:
+                            self._save_points(self.last_input_task.load_save_path, points, colors)
+                        last_output = VolumetricIntegrationOutput(ttype)
+                    elif ttype == VolumetricIntegrationTaskType.UPDATE_OUTPUT:
+                        do_output = True
+                    if do_output:
+                        points, colors = self._get_output_cloud()
+                        pc_out = VolumetricIntegrationPointCloud(points=points, colors=colors)
+                        last_output = VolumetricIntegrationOutput(ttype, self.last_integrated_id, pc_out, None)
+                        self.last_output = last_output
+                    self._publish(last_output, q_out, q_out_condition, is_running, save_request_completed, save_request_condition)
+        except Exception:
+            traceback.print_exc()
+        timer.refresh()
+        time_volumetric_integration.value = timer.last_elapsed

@@ -84,6 +84,21 @@ class _Volume:
         L.check(self._lib.hv_profile_read(self._h, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(units)))
         return ms.value, launches.value, units.value
 
+    def filter_shadow_points(self, depth, delta_x=2, delta_y=2, fill_value=-1.0):
+        """pyslam.utilities.depth.filter_shadow_points(depth, delta_depth=None, ...) on the GPU."""
+        if hasattr(depth, "data_ptr"):
+            import torch
+
+            d = depth.contiguous().float()
+            out = torch.empty_like(d)
+        else:
+            d = np.ascontiguousarray(depth, dtype=np.float32)
+            out = np.empty_like(d)
+        H, W = int(d.shape[0]), int(d.shape[1])
+        L.check(self._lib.hv_filter_shadow_points(self._h, L.ptr(d), H, W, int(delta_x), int(delta_y), float(fill_value),
+                                                  L.ptr(out), L.location(d)))
+        return out
+
     def bytes_per_block(self):
         n = ctypes.c_int64()
         L.check(self._lib.hv_bytes_per_block(self._h, ctypes.byref(n)))

@@ -1,0 +1,112 @@
+"""CPU: the drop-in front (pyslam_amd.dense) speaks the reference's task/queue protocol —
+factory, add_keyframe gating, UPDATE_OUTPUT, pop_output, save(dense_map.ply), rebuild, reset, quit
+(volumetric_integrator_base.py:451-1342).  The worker process runs oracle-backed stand-in volumes
+(injected through the constructor kwargs); the GPU tests run the same flow on the real volumes."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from pyslam_amd.dense import (
+    VolumetricIntegrationTaskType,
+    VolumetricIntegratorType,
+    volumetric_integrator_factory,
+)
+from pyslam_amd.dense.parameters import Parameters
+from pyslam_amd.dense.ply_io import read_ply
+from pyslam_amd.dense.volumetric_integrator_types import DatasetEnvironmentType, SensorType
+from pyslam_amd.synthetic import SyntheticRGBD
+from tests import dense_helpers as dh
+
+
+def wait_until(cond, timeout=30.0):
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        if cond():
+            return True
+        time.sleep(0.05)
+    return False
+
+
+@pytest.fixture
+def small_params():
+    old = (Parameters.kVolumetricIntegrationVoxelLength, Parameters.kVolumetricIntegrationTSdfTrunc,
+           Parameters.kVolumetricIntegrationOutputTimeInterval, Parameters.kVolumetricIntegrationMinNumLBATimes)
+    Parameters.kVolumetricIntegrationVoxelLength = 0.04
+    Parameters.kVolumetricIntegrationTSdfTrunc = 0.12
+    Parameters.kVolumetricIntegrationOutputTimeInterval = 0.0
+    Parameters.kVolumetricIntegrationMinNumLBATimes = 1
+    yield
+    (Parameters.kVolumetricIntegrationVoxelLength, Parameters.kVolumetricIntegrationTSdfTrunc,
+     Parameters.kVolumetricIntegrationOutputTimeInterval, Parameters.kVolumetricIntegrationMinNumLBATimes) = old
+
+
+def test_types_and_factory_errors():
+    assert VolumetricIntegratorType.from_string("TSDF") is VolumetricIntegratorType.TSDF
+    assert [t.value for t in VolumetricIntegratorType] == [0, 1, 2, 3, 4]
+    with pytest.raises(ValueError):
+        VolumetricIntegratorType.from_string("NOPE")
+    assert [t.name for t in VolumetricIntegrationTaskType] == ["NONE", "INTEGRATE", "SAVE", "LOAD", "RESET", "UPDATE_OUTPUT"]
+
+
+@pytest.mark.parametrize("kind", ["TSDF", "VOXEL_GRID"])
+def test_protocol_end_to_end(kind, small_params, tmp_path):
+    s = SyntheticRGBD("tiny_160x120_2cm", noise=False)
+    cam = dh.FakeCamera(s)
+    factory = dh.oracle_tsdf_factory if kind == "TSDF" else dh.oracle_grid_factory
+    integ = volumetric_integrator_factory(VolumetricIntegratorType.from_string(kind), cam, DatasetEnvironmentType.INDOOR,
+                                          SensorType.RGBD, volume_factory=factory)
+    try:
+        assert wait_until(integ.is_ready), "worker did not start"
+        kfs = [dh.FakeKeyFrame(i, s, cam) for i in range(3)]
+        held = dh.FakeKeyFrame(3, s, cam, lba_count=0)  # gated until local BA has touched it (base.py:1153-1157)
+        for kf in kfs + [held]:
+            integ.add_keyframe(kf, kf.img, None, kf.depth_img)
+        outs = []
+        assert wait_until(lambda: (outs.append(integ.pop_output(timeout=0.2)) or True) and sum(o is not None for o in outs) >= 3)
+        outs = [o for o in outs if o is not None]
+        assert {o.id for o in outs} <= {0, 1, 2}
+        assert all(o.task_type == VolumetricIntegrationTaskType.INTEGRATE for o in outs)
+        assert len(integ.keyframe_queue) == 1  # the gated keyframe is still waiting
+        held.lba_count = 1
+        assert wait_until(lambda: len(integ.keyframe_queue) == 0, 5.0)  # 0.5 s timer re-flushes (base.py:369-374)
+        assert wait_until(lambda: (o := integ.pop_output(timeout=0.2)) is not None and o.id == 3)
+        integ.add_update_output_task()
+        o = None
+        assert wait_until(lambda: (o := integ.pop_output(timeout=0.2)) is not None and o.task_type == VolumetricIntegrationTaskType.UPDATE_OUTPUT)
+        assert integ.time_volumetric_integration.value > 0.0
+        # save() blocks until dense_map.ply is on disk (base.py:574-593)
+        integ.save(str(tmp_path))
+        pts, cols, faces = read_ply(str(tmp_path / "dense_map.ply"))
+        assert len(pts) > 100 and cols is not None
+        if kind == "TSDF":
+            assert faces is not None and faces.max() < len(pts)
+        # rebuild(): RESET output first, then every good keyframe is replayed (base.py:1242-1318)
+        while integ.pop_output(timeout=0.05) is not None:
+            pass
+        integ.rebuild(dh.FakeMap(kfs))
+        seen = []
+        assert wait_until(lambda: (seen.append(integ.pop_output(timeout=0.2)) or True)
+                          and sum(1 for x in seen if x is not None and x.task_type == VolumetricIntegrationTaskType.INTEGRATE) >= 1, 20.0)
+        assert any(x is not None and x.task_type == VolumetricIntegrationTaskType.RESET for x in seen)
+        integ.request_reset()
+        assert integ.reset_requested.value == 0
+    finally:
+        integ.quit()
+    assert not integ.process.is_alive()
+    assert integ.pop_output() is None  # after quit: None, not an exception
+
+
+def test_outputs_have_reference_fields(small_params):
+    from pyslam_amd.dense import VolumetricIntegrationMesh, VolumetricIntegrationOutput, VolumetricIntegrationPointCloud
+
+    pc = VolumetricIntegrationPointCloud(points=np.zeros((2, 3)), colors=np.ones((2, 3)))
+    for f in ("points", "colors", "semantics", "object_ids", "semantic_colors", "object_colors"):
+        assert hasattr(pc, f)
+    mesh = VolumetricIntegrationMesh(dh.OracleTsdfVolume(0.04, 0.12).extract_triangle_mesh())
+    for f in ("vertices", "triangles", "vertex_colors", "vertex_normals"):
+        assert hasattr(mesh, f)
+    out = VolumetricIntegrationOutput(VolumetricIntegrationTaskType.INTEGRATE, 7, pc, mesh)
+    assert (out.task_type, out.id, out.point_cloud, out.mesh, out.objects) == (VolumetricIntegrationTaskType.INTEGRATE, 7, pc, mesh, None)
+    assert out.timestamp > 0

@@ -1,0 +1,116 @@
+"""GPU: the drop-in front on the real HIP volumes, and the GPU shadow-point filter."""
+import time
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import host_prep as hp
+from tests import dense_helpers as dh
+from tests.conftest import sort_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def wait_until(cond, timeout=60.0):
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        if cond():
+            return True
+        time.sleep(0.02)
+    return False
+
+
+@pytest.mark.parametrize("config", ["tiny_160x120_2cm", "synthetic_640x480_5mm"])
+def test_shadow_filter_bit_exact(config):
+    import torch
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    s = SyntheticRGBD(config)
+    g = VoxelBlockGrid(0.02, 8, max_blocks=1 << 10, max_points=1 << 20)
+    for i in (0, 13):
+        depth = s[i][0]
+        want = hp.filter_shadow_points(depth)
+        got = g.filter_shadow_points(depth)
+        np.testing.assert_array_equal(got, want)
+        assert (want == -1).sum() > 0  # the filter really removes discontinuity pixels
+        got_dev = g.filter_shadow_points(torch.from_numpy(depth).cuda()).cpu().numpy()
+        np.testing.assert_array_equal(got_dev, want)
+    flat = np.full((48, 64), 1.5, np.float32)  # no positive delta: median of nothing -> nothing masked
+    np.testing.assert_array_equal(g.filter_shadow_points(flat), hp.filter_shadow_points(flat))
+
+
+def _params(voxel, trunc):
+    from pyslam_amd.dense.parameters import Parameters
+
+    Parameters.kVolumetricIntegrationVoxelLength = voxel
+    Parameters.kVolumetricIntegrationTSdfTrunc = trunc
+    Parameters.kVolumetricIntegrationOutputTimeInterval = 0.0
+    Parameters.kVolumetricIntegrationHipMaxBlocks = 1 << 13
+    return Parameters
+
+
+def test_voxel_grid_integrator_matches_reference_flow():
+    from pyslam_amd.dense import VolumetricIntegratorType, volumetric_integrator_factory
+    from pyslam_amd.dense.volumetric_integrator_types import DatasetEnvironmentType, SensorType
+    from pyslam_amd.synthetic import SyntheticRGBD
+
+    P = _params(0.02, 0.08)
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    cam = dh.FakeCamera(s)
+    integ = volumetric_integrator_factory(VolumetricIntegratorType.VOXEL_GRID, cam, DatasetEnvironmentType.INDOOR, SensorType.RGBD)
+    ref = oracle.RefGrid(0.02, 8) if oracle.ref_available() else oracle.PortGrid(0.02, 8)
+    try:
+        assert wait_until(integ.is_ready), "worker did not start"
+        last = None
+        for i in range(3):
+            kf = dh.FakeKeyFrame(i, s, cam)
+            integ.add_keyframe(kf, kf.img, None, kf.depth_img)
+            out = []
+            assert wait_until(lambda: (out.append(integ.pop_output(timeout=0.2)) or True) and out[-1] is not None)
+            last = out[-1]
+            depth, rgb, T = s[i]
+            pts, cols, _ = hp.frame_to_world_f32(hp.filter_shadow_points(depth), rgb, *s.intrinsics, T, 4.0)
+            ref.integrate(pts, cols)
+        pa, ca = sort_rows(last.point_cloud.points, last.point_cloud.colors)
+        pb, cb = sort_rows(*ref.get_voxels(P.kVolumetricIntegrationVoxelGridMinCount))
+        np.testing.assert_array_equal(pa, pb)
+        np.testing.assert_array_equal(ca, cb)
+        assert last.point_cloud.points.dtype == np.float32
+    finally:
+        integ.quit()
+
+
+def test_tsdf_integrator_end_to_end(tmp_path):
+    from pyslam_amd.dense import VolumetricIntegrationTaskType, VolumetricIntegratorType, volumetric_integrator_factory
+    from pyslam_amd.dense.ply_io import read_ply
+    from pyslam_amd.dense.volumetric_integrator_types import DatasetEnvironmentType, SensorType
+    from pyslam_amd.synthetic import SyntheticRGBD
+
+    _params(0.02, 0.08)
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    cam = dh.FakeCamera(s)
+    integ = volumetric_integrator_factory(VolumetricIntegratorType.TSDF, cam, DatasetEnvironmentType.INDOOR, SensorType.RGBD)
+    cpu = oracle.PortTsdf(0.02, 0.08)
+    K = np.array(s.intrinsics)
+    try:
+        assert wait_until(integ.is_ready), "worker did not start"
+        last = None
+        for i in range(3):
+            kf = dh.FakeKeyFrame(i, s, cam)
+            integ.add_keyframe(kf, kf.img, None, kf.depth_img)
+            out = []
+            assert wait_until(lambda: (out.append(integ.pop_output(timeout=0.2)) or True) and out[-1] is not None)
+            last = out[-1]
+            depth, rgb, T = s[i]
+            cpu.integrate(depth, rgb, K, T, 1.0, 4.0)
+        v, t, c = cpu.extract_triangle_mesh()
+        assert last.task_type == VolumetricIntegrationTaskType.INTEGRATE and last.id == 2
+        assert last.mesh.vertices.shape == v.shape and last.mesh.triangles.shape == t.shape
+        np.testing.assert_allclose(np.sort(last.mesh.vertices, axis=0), np.sort(v, axis=0), atol=1e-9)
+        integ.save(str(tmp_path))
+        pts, cols, faces = read_ply(str(tmp_path / "dense_map.ply"))
+        assert pts.shape == v.shape and faces.shape == t.shape
+    finally:
+        integ.quit()
