@@ -82,13 +82,19 @@ def cpu_baseline_and_counts(s, depth, rgb, T, budget_s, threads):
     vol.integrate(depth[0], rgb[0], K, T[0], 1.0, DEPTH_TRUNC)
     touched, updated, times = [], [], []
     t_begin = time.perf_counter()
-    for i in range(len(depth)):
+    i = 0
+    # replay the batch (as the GPU steps do) until the CPU budget is spent; per-frame counts of the
+    # first pass over the batch feed the roofline figure
+    while True:
+        j = i % len(depth)
         t0 = time.perf_counter()
-        vol.integrate(depth[i], rgb[i], K, T[i], 1.0, DEPTH_TRUNC)
+        vol.integrate(depth[j], rgb[j], K, T[j], 1.0, DEPTH_TRUNC)
         times.append(time.perf_counter() - t0)
-        touched.append(vol.num_touched())
-        updated.append(vol.last_updated())
-        if time.perf_counter() - t_begin > budget_s and i >= 3:
+        if i < len(depth):
+            touched.append(vol.num_touched())
+            updated.append(vol.last_updated())
+        i += 1
+        if time.perf_counter() - t_begin > budget_s and i >= min(4, len(depth)):
             break
     n = len(times)
     return {

@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int
                                                          const uint2 *__restrict__ frame_px, HvFrameParams P) {
     int n_touched = table.counters[HV_CNT_TOUCH0 + parity];
     if (n_touched > table.max_blocks) n_touched = table.max_blocks;
+    // the next frame's touch pass appends to the other parity's counter: zero it here (stream order)
     if (blockIdx.x == 0 && threadIdx.x == 0) table.counters[HV_CNT_TOUCH0 + (parity ^ 1)] = 0;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -509,52 +510,67 @@ static int make_frame_params(hv_volume *v, int H, int W, const double *intr, con
     return HV_OK;
 }
 
+// Per-frame scratch (single-buffered: the two halves of a frame run back to back on one stream).
+// Measured alternative, rejected: prep+touch of frame f+1 on a second stream overlapping the sweep of
+// frame f (double-buffered scratch, event hand-offs) ran 6955 vs 7280 frames/s - the cross-stream
+// waits and the contention on the sweep cost more than the 16 us they hide.
+static inline uint2 *frame_px_of(hv_volume *v, int) { return (uint2 *)v->frame_px; }
+static inline int32_t *touched_list_of(hv_volume *v, int) { return v->touched_list; }
+
+// First half of a frame: convert/pack the frame, claim and list the touched units.  (This parity's
+// touched counter was zeroed by the previous frame's sweep kernel.)
+static int tsdf_launch_touch(hv_volume *v, hipStream_t s, const HvFrameParams &P, int parity, const void *d_depth,
+                             const uint8_t *d_rgb) {
+    const int64_t npx = (int64_t)P.H * P.W;
+    const int n_prep_blocks = (int)((npx + 255) / 256);
+    const int ns = ((P.W + P.stride - 1) / P.stride) * ((P.H + P.stride - 1) / P.stride);
+    const int n_touch_blocks = (ns * HV_TOUCH_FAN + 255) / 256;
+    hipLaunchKernelGGL(k_tsdf_prep_touch, dim3(n_prep_blocks + n_touch_blocks), dim3(256), 0, s, v->table,
+                       v->touched_stamp, touched_list_of(v, parity), parity, d_depth, d_rgb, frame_px_of(v, parity), P,
+                       n_prep_blocks);
+    return HV_OK;
+}
+
+// Second half on the volume's stream: sweep the touched units.  Grid: enough workgroups to fill
+// 256 CUs; grid-stride over the device-side touched count (no host round trip between launches).
+static int tsdf_launch_integrate(hv_volume *v, const HvFrameParams &P, int parity) {
+    const dim3 grid(4096), block(256);
+    const int32_t *list = touched_list_of(v, parity);
+    const uint2 *px = frame_px_of(v, parity);
+    char *pool = (char *)v->pool;
+    hv_profile_begin(v);
+    switch (v->debug_variant) {
+    case 1: hipLaunchKernelGGL(k_tsdf_integrate<1>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
+    case 2: hipLaunchKernelGGL(k_tsdf_integrate<2>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
+    case 3: hipLaunchKernelGGL(k_tsdf_integrate<3>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
+    case 4: hipLaunchKernelGGL(k_tsdf_integrate<4>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
+    case 5: hipLaunchKernelGGL(k_tsdf_integrate<5>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
+    case 6: hipLaunchKernelGGL(k_tsdf_integrate<6>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
+    default: hipLaunchKernelGGL(k_tsdf_integrate<0>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
+    }
+    hv_profile_end(v, 0);
+    HV_HIP(hipGetLastError());
+    return HV_OK;
+}
+
+static void tsdf_next_frame(hv_volume *v, HvFrameParams &P, int &parity) {
+    v->frame_counter += 1;
+    P.frame_id = v->frame_counter;
+    parity = v->frame_counter & 1;
+    v->last_touch_parity = parity;
+}
+
+// Online path: both halves back to back on the volume's stream.
 static int tsdf_integrate_one(hv_volume *v, const void *d_depth, int depth_dtype, const uint8_t *d_rgb,
                               int H, int W, const double *intr, const double *T_cw, double depth_scale,
                               double depth_trunc) {
     HvFrameParams P;
     make_frame_params(v, H, W, intr, T_cw, depth_scale, depth_trunc, depth_dtype, &P);
-    v->frame_counter += 1;
-    P.frame_id = v->frame_counter;
-    const int parity = v->frame_counter & 1;
-    v->last_touch_parity = parity;
-
-    const int64_t npx = (int64_t)H * W;
-    const int n_prep_blocks = (int)((npx + 255) / 256);
-    const int ns = ((W + P.stride - 1) / P.stride) * ((H + P.stride - 1) / P.stride);
-    const int n_touch_blocks = (ns * HV_TOUCH_FAN + 255) / 256;
-    hipLaunchKernelGGL(k_tsdf_prep_touch, dim3(n_prep_blocks + n_touch_blocks), dim3(256), 0, v->stream,
-                       v->table, v->touched_stamp, v->touched_list, parity, d_depth, d_rgb, (uint2 *)v->frame_px,
-                       P, n_prep_blocks);
-    hv_profile_begin(v);
-    // grid: enough workgroups to fill 256 CUs x 8 resident 4-wave groups; grid-stride over the
-    // device-side touched count (no host round trip between the two launches)
-    const dim3 grid(4096), block(256);
-    if (v->debug_variant == 1) {
-        hipLaunchKernelGGL(k_tsdf_integrate<1>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
-                           (char *)v->pool, (const uint2 *)v->frame_px, P);
-    } else if (v->debug_variant == 2) {
-        hipLaunchKernelGGL(k_tsdf_integrate<2>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
-                           (char *)v->pool, (const uint2 *)v->frame_px, P);
-    } else if (v->debug_variant == 5) {
-        hipLaunchKernelGGL(k_tsdf_integrate<5>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
-                           (char *)v->pool, (const uint2 *)v->frame_px, P);
-    } else if (v->debug_variant == 6) {
-        hipLaunchKernelGGL(k_tsdf_integrate<6>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
-                           (char *)v->pool, (const uint2 *)v->frame_px, P);
-    } else if (v->debug_variant == 4) {
-        hipLaunchKernelGGL(k_tsdf_integrate<4>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
-                           (char *)v->pool, (const uint2 *)v->frame_px, P);
-    } else if (v->debug_variant == 3) {
-        hipLaunchKernelGGL(k_tsdf_integrate<3>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
-                           (char *)v->pool, (const uint2 *)v->frame_px, P);
-    } else {
-        hipLaunchKernelGGL(k_tsdf_integrate<0>, grid, block, 0, v->stream, v->table, v->touched_list, parity,
-                           (char *)v->pool, (const uint2 *)v->frame_px, P);
-    }
-    hv_profile_end(v, 0);
-    HV_HIP(hipGetLastError());
-    return HV_OK;
+    int parity = 0;
+    tsdf_next_frame(v, P, parity);
+    int rc = tsdf_launch_touch(v, v->stream, P, parity, d_depth, d_rgb);
+    if (rc != HV_OK) return rc;
+    return tsdf_launch_integrate(v, P, parity);
 }
 
 static int check_tsdf_args(hv_volume *v, const void *depth, const uint8_t *rgb, int H, int W,
@@ -679,7 +695,7 @@ int hv_tsdf_touched(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n) {
     *n = nt;
     if (keys == nullptr || nt == 0) return HV_OK;
     std::vector<int32_t> slots((size_t)nt);
-    HV_HIP(hipMemcpy(slots.data(), v->touched_list, sizeof(int32_t) * nt, hipMemcpyDeviceToHost));
+    HV_HIP(hipMemcpy(slots.data(), touched_list_of(v, v->last_touch_parity), sizeof(int32_t) * nt, hipMemcpyDeviceToHost));
     std::vector<uint64_t> tkeys((size_t)v->table_capacity);
     HV_HIP(hipMemcpy(tkeys.data(), v->table.keys, sizeof(uint64_t) * v->table_capacity, hipMemcpyDeviceToHost));
     std::vector<std::array<int32_t, 3>> out((size_t)nt);
