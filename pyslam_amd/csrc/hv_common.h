@@ -226,6 +226,9 @@ struct hv_volume {
     int32_t frame_counter = 0;
     int32_t last_touch_parity = 0;
     int32_t frame_batch_cap = 0;
+    void *batch_buf = nullptr;        // multi-frame sweep scratch: B frame records + B HvFrameParams
+    size_t batch_buf_bytes = 0;
+    std::vector<HvFrameParams> host_params; // host copy (kept alive across the async H2D)
     int32_t tile[4] = {0, 0, 0, 0}; // u0, v0, u1, v1; all zero = whole image
 
     // staging for HV_HOST inputs

@@ -406,6 +406,209 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int
     }
 }
 
+// ================================================================================================
+// Multi-frame sweep (hv_tsdf_integrate_batch; the rebuild()/offline-replay use case,
+// volumetric_integrator_base.py:1242-1318).  B <= 64 posed frames are resident in HBM:
+//   k_tsdf_prep_touch_batch  one launch for all B frames (grid.y = frame): packs every frame and ORs
+//                            bit f into the 64-bit frame mask of each unit frame f touches; the first
+//                            toucher of a unit in the batch appends it to the union list
+//   k_tsdf_integrate_batch   one 4-wave workgroup per union unit: the lane's 16 voxels are loaded
+//                            ONCE, then for every frame bit in ascending (= chronological) order the
+//                            voxels are evaluated and updated in registers, then stored once.
+// Identical results to B successive hv_tsdf_integrate calls: a unit is updated by frame f iff frame
+// f touched it, and its frames are applied in order.  Plane traffic per frame drops by ~B x (the
+// union of 32 consecutive frames' units is ~1.6x one frame's); what remains is the per-voxel math
+// and the 8-byte frame gathers.
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, int32_t *__restrict__ stamp,
+                                                                unsigned long long *__restrict__ frame_mask,
+                                                                int32_t *__restrict__ list, int batch_stamp,
+                                                                const char *__restrict__ depth_raw, int64_t depth_stride,
+                                                                const uint8_t *__restrict__ rgb,
+                                                                uint2 *__restrict__ frame_px,
+                                                                const HvFrameParams *__restrict__ Ps, int n_prep_blocks) {
+    const int f = blockIdx.y;
+    const HvFrameParams &P = Ps[f];
+    const int64_t npx = (int64_t)P.H * P.W;
+    const void *depth_f = depth_raw + (int64_t)f * depth_stride;
+    const uint8_t *rgb_f = rgb + (int64_t)f * npx * 3;
+    if ((int)blockIdx.x < n_prep_blocks) {
+        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= npx) return;
+        const uint8_t *c = rgb_f + i * 3;
+        uint2 rec;
+        rec.x = __float_as_uint(hv_convert_depth(P, depth_f, i));
+        rec.y = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+        frame_px[(int64_t)f * npx + i] = rec;
+        return;
+    }
+    const int ns_w = (P.W + P.stride - 1) / P.stride;
+    const int ns_h = (P.H + P.stride - 1) / P.stride;
+    const int tid = ((int)blockIdx.x - n_prep_blocks) * blockDim.x + threadIdx.x;
+    const int s = tid / HV_TOUCH_FAN;
+    const int k0 = tid % HV_TOUCH_FAN;
+    int32_t lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1};
+    if (s < ns_w * ns_h) {
+        const int i = (s / ns_w) * P.stride;
+        const int j = (s % ns_w) * P.stride;
+        const float p = hv_convert_depth(P, depth_f, (int64_t)i * P.W + j);
+        if (p > 0.0f) {
+            const double z = (double)p;
+            const double x = ((double)j - P.cx_d) * z / P.fx_d;
+            const double y = ((double)i - P.cy_d) * z / P.fy_d;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double pw = ((P.pose[r * 4 + 0] * x + P.pose[r * 4 + 1] * y) + P.pose[r * 4 + 2] * z) + P.pose[r * 4 + 3];
+                lo[r] = (int32_t)floor((pw - P.sdf_trunc_d) / P.unit_length);
+                hi[r] = (int32_t)floor((pw + P.sdf_trunc_d) / P.unit_length);
+            }
+        }
+    }
+    const int nx = hi[0] - lo[0] + 1, ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+    const int count = (nx > 0 && ny > 0 && nz > 0) ? nx * ny * nz : 0;
+    const int lane = hv_lane_id();
+    const unsigned long long fbit = 1ull << f;
+    for (int k = k0; __any(k < count); k += HV_TOUCH_FAN) {
+        unsigned long long key = HV_EMPTY_KEY;
+        int32_t ux = 0, uy = 0, uz = 0;
+        if (k < count) {
+            ux = lo[0] + k / (ny * nz);
+            uy = lo[1] + (k / nz) % ny;
+            uz = lo[2] + k % nz;
+            if (hv_key_in_range(ux, uy, uz)) {
+                key = hv_pack_key(ux, uy, uz);
+            } else {
+                atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
+            }
+        }
+        bool leader = false;
+        unsigned long long remaining = __ballot(key != HV_EMPTY_KEY);
+        while (remaining) {
+            const int first = __ffsll((long long)remaining) - 1;
+            const unsigned long long fkey = __shfl(key, first);
+            const unsigned long long same = __ballot(key == fkey);
+            if (lane == first) leader = true;
+            remaining &= ~same;
+        }
+        if (leader) {
+            const int32_t slot = hv_table_insert(table, key);
+            if (slot >= 0) {
+                const bool hits = hv_unit_hits_tile(P, ux, uy, uz);
+                // frame bit (skip the atomic when another wave of this frame already set it)
+                if (hits && !(__hip_atomic_load(&frame_mask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & fbit))
+                    atomicOr(&frame_mask[slot], fbit);
+                if (__hip_atomic_load(&stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != batch_stamp) {
+                    const int32_t old = atomicExch(&stamp[slot], batch_stamp);
+                    if (old != batch_stamp) {
+                        const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0], 1);
+                        if (at < table.max_blocks) list[at] = slot;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ZPW = z-slabs per wave: the workgroup has 16/ZPW waves; fewer slabs per wave = fewer state registers
+// = more resident waves to hide the frame-gather latency.
+template <int ZPW>
+__global__ __launch_bounds__(64 * 16 / ZPW) void k_tsdf_integrate_batch(HvTable table, const int32_t *__restrict__ list,
+                                                               unsigned long long *__restrict__ frame_mask,
+                                                               char *__restrict__ pool, const uint2 *__restrict__ frame_px,
+                                                               const HvFrameParams *__restrict__ Ps) {
+    int n_units = table.counters[HV_CNT_TOUCH0];
+    if (n_units > table.max_blocks) n_units = table.max_blocks;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int x = lane >> 2;
+    const int y0 = (lane & 3) << 2;
+    const int z0 = wave * ZPW;
+    for (int t = blockIdx.x; t < n_units; t += gridDim.x) {
+        const int32_t slot = list[t];
+        const int32_t idx = table.vals[slot];
+        unsigned long long mask = frame_mask[slot];
+        __syncthreads(); // every wave has read the mask before one of them clears it
+        if (threadIdx.x == 0) frame_mask[slot] = 0ull; // clean for the next batch
+        if (idx < 0 || mask == 0ull) continue;
+        int32_t ux, uy, uz;
+        hv_unpack_key(table.keys[slot], ux, uy, uz);
+        char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
+        const int wordb = z0 * RR + x * R + y0;
+        float4 vt[ZPW];
+        uint4 vw[ZPW], vr[ZPW], vg[ZPW], vb[ZPW];
+#pragma unroll
+        for (int zz = 0; zz < ZPW; ++zz) {
+            const int q = (wordb + zz * RR) >> 2;
+            vt[zz] = ((const float4 *)(unit + 0 * PLANE_BYTES))[q];
+            vw[zz] = ((const uint4 *)(unit + 1 * PLANE_BYTES))[q];
+            vr[zz] = ((const uint4 *)(unit + 2 * PLANE_BYTES))[q];
+            vg[zz] = ((const uint4 *)(unit + 3 * PLANE_BYTES))[q];
+            vb[zz] = ((const uint4 *)(unit + 4 * PLANE_BYTES))[q];
+        }
+        unsigned dirty = 0; // bit zz: slab zz holds an updated voxel of this lane
+        while (mask) {
+            const int f = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const HvFrameParams &P = Ps[f];
+            const uint2 *px = frame_px + (int64_t)f * P.H * P.W;
+            const float inc0 = P.ext_scaled_col2[0], inc1 = P.ext_scaled_col2[1], inc2 = P.ext_scaled_col2[2];
+            const double o0 = (double)ux * P.unit_length;
+            const double o1 = (double)uy * P.unit_length;
+            const double o2 = (double)uz * P.unit_length;
+            const float p0 = (float)((double)(P.half_voxel_length_f + P.voxel_length_f * (float)x) + o0);
+            const float p2 = (float)((double)P.half_voxel_length_f + o2);
+            float pc[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float p1 = (float)((double)(P.half_voxel_length_f + P.voxel_length_f * (float)(y0 + c)) + o1);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    pc[c][r] = ((P.ext[r * 4 + 0] * p0 + P.ext[r * 4 + 1] * p1) + P.ext[r * 4 + 2] * p2) + P.ext[r * 4 + 3];
+                }
+            }
+            for (int s = 0; s < z0; ++s) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    pc[c][0] += inc0;
+                    pc[c][1] += inc1;
+                    pc[c][2] += inc2;
+                }
+            }
+#pragma unroll
+            for (int zz = 0; zz < ZPW; ++zz) {
+                float tv[4];
+                uint32_t cv[4];
+                unsigned m = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    tv[c] = 0.f;
+                    cv[c] = 0u;
+                    if (hv_tsdf_eval(P, px, pc[c][0], pc[c][1], pc[c][2], tv[c], cv[c])) m |= 1u << c;
+                    pc[c][0] += inc0;
+                    pc[c][1] += inc1;
+                    pc[c][2] += inc2;
+                }
+                hv_tsdf_apply(m & 1u, tv[0], cv[0], vt[zz].x, vw[zz].x, vr[zz].x, vg[zz].x, vb[zz].x);
+                hv_tsdf_apply(m & 2u, tv[1], cv[1], vt[zz].y, vw[zz].y, vr[zz].y, vg[zz].y, vb[zz].y);
+                hv_tsdf_apply(m & 4u, tv[2], cv[2], vt[zz].z, vw[zz].z, vr[zz].z, vg[zz].z, vb[zz].z);
+                hv_tsdf_apply(m & 8u, tv[3], cv[3], vt[zz].w, vw[zz].w, vr[zz].w, vg[zz].w, vb[zz].w);
+                if (m) dirty |= 1u << zz;
+            }
+        }
+#pragma unroll
+        for (int zz = 0; zz < ZPW; ++zz) {
+            if (dirty & (1u << zz)) {
+                const int q = (wordb + zz * RR) >> 2;
+                ((float4 *)(unit + 0 * PLANE_BYTES))[q] = vt[zz];
+                ((uint4 *)(unit + 1 * PLANE_BYTES))[q] = vw[zz];
+                ((uint4 *)(unit + 2 * PLANE_BYTES))[q] = vr[zz];
+                ((uint4 *)(unit + 3 * PLANE_BYTES))[q] = vg[zz];
+                ((uint4 *)(unit + 4 * PLANE_BYTES))[q] = vb[zz];
+            }
+        }
+    }
+}
+
 // ---- numerators export / import (multi-GPU merge) ----------------------------------------------
 __global__ void k_tsdf_export(HvTable table, const char *__restrict__ pool, const int32_t *__restrict__ keys,
                               int64_t k, float *__restrict__ payload) {
@@ -616,11 +819,64 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
     if (rc != HV_OK) return rc;
     rc = hv_stage_in(v, rgb, npx * 3 * n_frames, loc, 1, &d_rgb);
     if (rc != HV_OK) return rc;
-    for (int f = 0; f < n_frames; ++f) {
-        rc = tsdf_integrate_one(v, (const char *)d_depth + npx * dsz * f, depth_dtype,
-                                (const uint8_t *)d_rgb + npx * 3 * f, height, width, intr, T_cw + 16 * f,
-                                depth_scale, depth_trunc);
+    if (v->debug_variant != 0 || n_frames == 1) { // ablation variants / trivial batch: frame by frame
+        for (int f = 0; f < n_frames; ++f) {
+            rc = tsdf_integrate_one(v, (const char *)d_depth + npx * dsz * f, depth_dtype,
+                                    (const uint8_t *)d_rgb + npx * 3 * f, height, width, intr, T_cw + 16 * f,
+                                    depth_scale, depth_trunc);
+            if (rc != HV_OK) return rc;
+        }
+        return HV_OK;
+    }
+    // multi-frame sweeps of up to 64 frames (one bit per frame in the per-unit mask)
+    HV_HIP(hipStreamSynchronize(v->stream)); // a previous call's async H2D of host_params has finished
+    const int BMAX = 64;
+    std::vector<HvFrameParams> &params = v->host_params;
+    for (int f0 = 0; f0 < n_frames; f0 += BMAX) {
+        const int B = std::min(BMAX, n_frames - f0);
+        params.resize((size_t)B);
+        for (int f = 0; f < B; ++f) {
+            make_frame_params(v, height, width, intr, T_cw + 16 * (size_t)(f0 + f), depth_scale, depth_trunc, depth_dtype,
+                              &params[f]);
+            v->frame_counter += 1;
+            params[f].frame_id = v->frame_counter;
+        }
+        const int batch_stamp = v->frame_counter;
+        v->last_touch_parity = 0;
+        // scratch: [B frame records of npx uint2][B HvFrameParams]
+        const size_t px_bytes = sizeof(uint2) * npx * (size_t)B;
+        rc = hv_ensure_buffer(v, &v->batch_buf, &v->batch_buf_bytes, px_bytes + sizeof(HvFrameParams) * (size_t)B + 256);
         if (rc != HV_OK) return rc;
+        uint2 *d_px = (uint2 *)v->batch_buf;
+        HvFrameParams *d_params = (HvFrameParams *)((char *)v->batch_buf + ((px_bytes + 255) & ~(size_t)255));
+        HV_HIP(hipMemcpyAsync(d_params, params.data(), sizeof(HvFrameParams) * (size_t)B, hipMemcpyHostToDevice, v->stream));
+        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, sizeof(int32_t), v->stream));
+        const int n_prep_blocks = (int)((npx + 255) / 256);
+        const int stride = v->cfg.depth_sampling_stride;
+        const int ns = ((width + stride - 1) / stride) * ((height + stride - 1) / stride);
+        const int n_touch_blocks = (ns * HV_TOUCH_FAN + 255) / 256;
+        hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3(n_prep_blocks + n_touch_blocks, B), dim3(256), 0, v->stream,
+                           v->table, v->touched_stamp, (unsigned long long *)v->touched_mask, v->touched_list, batch_stamp,
+                           (const char *)d_depth + npx * dsz * (size_t)f0, (int64_t)(npx * dsz),
+                           (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks);
+        hv_profile_begin(v);
+        static const int zpw = getenv("HV_TSDF_BATCH_ZPW") ? atoi(getenv("HV_TSDF_BATCH_ZPW")) : 2;
+        if (zpw == 4) {
+            hipLaunchKernelGGL(k_tsdf_integrate_batch<4>, dim3(4096), dim3(256), 0, v->stream, v->table, v->touched_list,
+                               (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
+        } else if (zpw == 1) {
+            hipLaunchKernelGGL(k_tsdf_integrate_batch<1>, dim3(4096), dim3(1024), 0, v->stream, v->table, v->touched_list,
+                               (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
+        } else {
+            hipLaunchKernelGGL(k_tsdf_integrate_batch<2>, dim3(4096), dim3(512), 0, v->stream, v->table, v->touched_list,
+                               (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
+        }
+        hv_profile_end(v, B);
+        HV_HIP(hipGetLastError());
+        // leave both per-frame parity counters clean for a following hv_tsdf_integrate
+        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
+        // host_params is reused by the next sub-batch / call: the H2D copy above must have consumed it
+        if (f0 + BMAX < n_frames) HV_HIP(hipStreamSynchronize(v->stream));
     }
     return HV_OK;
 }
