@@ -7,10 +7,10 @@ For N > 1 the driver launches it with torch.distributed.run (one rank per GPU, R
 Workload (BASELINE.json configs[1]): synthetic 640x480 RGB-D stream, 5 mm voxels, sdf_trunc 0.04 m,
 depth_trunc 4 m, Open3D ScalableTSDFVolume semantics.  A *step* fuses one batch of
 ``--frames-per-step`` consecutive posed frames that are already resident in HBM; value = frames/s
-of the whole job.  N > 1: every frame is split into N vertical image tiles (north-star form,
-SURVEY §8e); rank r fuses only the voxels that project into its tile, and the partial volumes are
-merged once inside the timed region by a sum-reduce of additive numerators (RCCL) — "strong"
-scaling: total work is fixed.
+of the whole job.  N > 1 ("strong" scaling: total work is fixed): every rank sees every frame;
+default --sharding owner: a unit is fused and stored by GPU hash(unit index) % N (SURVEY §8e "zero
+reduce" form: bit-identical to one GPU, no collective while fusing; units all ranks processed = the
+whole frame); --sharding tile: north-star image tiles + one RCCL numerator sum-reduce (timed).
 
 Extra objects on the JSON line:
   roofline     dominant kernel (k_tsdf_integrate): algorithmic bytes per launch (oracle counts:
@@ -35,6 +35,12 @@ SDF_TRUNC = 0.04
 DEPTH_TRUNC = 4.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_VOXEL = 20   # {f32 tsdf, u32 weight, 3 x u32 colour sums}
+# HBM bytes per launch from the PMC passes committed under profiles/r01/pmc_fetch_write_summary.txt
+# (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this script at N=1, headline config;
+# 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, as MI355X_MICROARCH.md prescribes for gfx950).  They are
+# recorded measurements, not live ones: null when the configuration differs.
+PMC_TRAFFIC_BYTES = {"k_tsdf_integrate": int((2 * 136.3e3 + 209.8e3) * 1024),
+                     "k_tsdf_integrate_batch": int((2 * 550.1e3 + 373.2e3) * 1024)}
 
 
 def load_frames(config, n_frames, start=0):
@@ -117,6 +123,12 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--all-on-device0", action="store_true",
+                    help="testing only: every rank uses GPU 0 (multi-rank code path on a 1-GPU box, with --backend gloo)")
+    ap.add_argument("--sharding", choices=["owner", "tile"], default="owner",
+                    help="N > 1: owner = unit-ownership sharding, no collective while fusing (default); "
+                         "tile = image tiles + RCCL numerator sum-reduce at the end")
     ap.add_argument("--mode", choices=["batch", "online"], default="batch",
                     help="batch: one multi-frame sweep per step (replay/rebuild path); online: one integrate() per frame")
     args = ap.parse_args()
@@ -128,15 +140,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback exists)")
+    if args.all_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
-    from pyslam_amd.distributed import TileShardedTSDF
+    from pyslam_amd.distributed import ShardedTSDF
     from pyslam_amd.volumetric import PinholeCameraIntrinsic
 
     B = args.frames_per_step
@@ -145,8 +162,8 @@ def main():
     depth_d = torch.from_numpy(depth_h).cuda()
     rgb_d = torch.from_numpy(rgb_h).cuda()
 
-    fuser = TileShardedTSDF(VOXEL, SDF_TRUNC, s.width, s.height, device=local_rank, max_blocks=1 << 15,
-                            rank=rank, world_size=world, process_group=dist)
+    fuser = ShardedTSDF(VOXEL, SDF_TRUNC, s.width, s.height, device=local_rank, max_blocks=1 << 15,
+                        rank=rank, world_size=world, sharding=args.sharding)
     vol = fuser.volume
 
     from pyslam_amd.volumetric import RGBDImage
@@ -171,14 +188,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1:
-        fuser.merge()  # one consistent volume at the end of the job, inside the timed region
+    if world > 1 and args.sharding == "tile":
+        fuser.merge()  # tile sharding leaves partial means: one merge makes the volume consistent (timed)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches, _ = vol.profile_read()
     vol.profile_enable(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -226,6 +243,9 @@ def main():
                 "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(avg_s * 1e6, 2),
                 "launches": int(launches_), "frames_per_launch": round(frames_per_launch, 2),
             }
+            if args.config == "synthetic_640x480_5mm" and world == 1 and frames_per_launch in (1.0, 32.0):
+                r["traffic"] = PMC_TRAFFIC_BYTES[r["kernel"]]
+                r["traffic_source"] = "profiles/r01/pmc_fetch_write_summary.txt (recorded rocprofv3 --pmc passes)"
             if frames_per_launch > 1:
                 r["note"] = ("multi-frame sweep: each unit slab is read and written once per launch and reused in "
                              "registers across the launch's frames, so HBM traffic (see profiles/) is far below the "
@@ -253,7 +273,10 @@ def main():
                             f"depth_trunc 4 m), {B} posed frames per step resident in HBM, Open3D ScalableTSDFVolume semantics",
                 "frames_per_step": B,
                 "mode": "multi-frame sweep (hv_tsdf_integrate_batch)" if args.mode == "batch" else "one hv_tsdf_integrate per frame",
-                "sharding": "single spatial tile" if world == 1 else f"{world} vertical image tiles + numerator sum-reduce merge",
+                "sharding": "single spatial tile" if world == 1 else (
+                    f"unit ownership: unit -> GPU hash(index) % {world}; every GPU sees every frame, fuses and stores only its "
+                    f"units; no collective while fusing" if args.sharding == "owner"
+                    else f"{world} vertical image tiles + RCCL numerator sum-reduce merge (timed)"),
                 "units_allocated": int(vol.num_blocks()),
             },
             "roofline": roofline,

@@ -152,6 +152,12 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
  * allocated (so all GPUs agree on the unit set) but not swept.  All zeros = whole image (default). */
 int hv_tsdf_set_tile(hv_volume *v, int32_t u0, int32_t v0, int32_t u1, int32_t v1);
 
+/* Multi-GPU unit-ownership sharding (SURVEY §8e "zero reduce" form): every GPU sees every frame but
+ * claims, stores and fuses only the units with owner(unit index) == rank (a fixed hash of the
+ * index modulo world_size).  Per-frame work and HBM footprint divide by world_size, results are
+ * bit-identical to a single GPU, and no collective is needed while fusing.  (1 GPU: rank 0 of 1.) */
+int hv_tsdf_set_owner(hv_volume *v, int32_t rank, int32_t world_size);
+
 /* extract_triangle_mesh() (volumetric_integrator_tsdf.py:239,260).  vertices/vertex_colors f64
  * [V,3] (colours in [0,1]); triangles i32 [T,3].  NULL arrays = size query.  Host pointers. */
 int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, int64_t cap_vertices,

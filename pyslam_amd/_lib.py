@@ -65,6 +65,7 @@ SIGNATURES = {
     "hv_tsdf_integrate": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_tsdf_integrate_batch": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_tsdf_set_tile": (_i32, [_vp, _i32, _i32, _i32, _i32]),
+    "hv_tsdf_set_owner": (_i32, [_vp, _i32, _i32]),
     "hv_tsdf_extract_mesh": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _pi64, _pi64]),
     "hv_tsdf_extract_points": (_i32, [_vp, _vp, _vp, _i64, _pi64]),
     "hv_tsdf_dump": (_i32, [_vp, _vp, _vp, _vp, _vp, _pi64]),

@@ -71,6 +71,13 @@ __host__ __device__ inline uint32_t hv_slot_hash(uint64_t k) {
     k ^= k >> 33;
     return (uint32_t)k;
 }
+// Owner rank of a unit for multi-GPU unit-ownership sharding (decorrelated from the slot hash).
+__host__ __device__ inline int32_t hv_owner_of(uint64_t k, int32_t world) {
+    k ^= k >> 29;
+    k *= 0x9E3779B97F4A7C15ull;
+    k ^= k >> 32;
+    return (int32_t)((k >> 7) % (uint64_t)world);
+}
 // BlockKeyHash / VoxelKeyHash of the reference, voxel_hashing.h:51-58,106-113 (libstdc++ identity
 // std::hash<int32_t>, sign-extended to size_t).
 __host__ __device__ inline uint64_t hv_reference_hash(int32_t x, int32_t y, int32_t z) {
@@ -195,6 +202,7 @@ struct HvFrameParams { // per-frame constants of the TSDF kernels (passed by val
     int32_t depth_is_u16;
     int32_t frame_id;       // touched stamp value (> 0)
     int32_t tile_u0, tile_v0, tile_u1, tile_v1; // image-space tile owned by this GPU: [u0,u1) x [v0,v1)
+    int32_t owner_rank, owner_world;            // unit ownership sharding: this GPU fuses units with owner(key) == rank
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -230,6 +238,7 @@ struct hv_volume {
     size_t batch_buf_bytes = 0;
     std::vector<HvFrameParams> host_params; // host copy (kept alive across the async H2D)
     int32_t tile[4] = {0, 0, 0, 0}; // u0, v0, u1, v1; all zero = whole image
+    int32_t owner_rank = 0, owner_world = 1; // hv_tsdf_set_owner
 
     // staging for HV_HOST inputs
     void *stage_a = nullptr;

@@ -123,6 +123,8 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch(HvTable table, int32_t 
             uz = lo[2] + k % nz;
             if (hv_key_in_range(ux, uy, uz)) {
                 key = hv_pack_key(ux, uy, uz);
+                // unit-ownership sharding: another GPU fuses (and stores) this unit
+                if (P.owner_world > 1 && hv_owner_of(key, P.owner_world) != P.owner_rank) key = HV_EMPTY_KEY;
             } else {
                 atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
             }
@@ -477,6 +479,8 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
             uz = lo[2] + k % nz;
             if (hv_key_in_range(ux, uy, uz)) {
                 key = hv_pack_key(ux, uy, uz);
+                // unit-ownership sharding: another GPU fuses (and stores) this unit
+                if (P.owner_world > 1 && hv_owner_of(key, P.owner_world) != P.owner_rank) key = HV_EMPTY_KEY;
             } else {
                 atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
             }
@@ -710,6 +714,8 @@ static int make_frame_params(hv_volume *v, int H, int W, const double *intr, con
     P->tile_v0 = whole ? 0 : v->tile[1];
     P->tile_u1 = whole ? W : v->tile[2];
     P->tile_v1 = whole ? H : v->tile[3];
+    P->owner_rank = v->owner_rank;
+    P->owner_world = v->owner_world;
     return HV_OK;
 }
 
@@ -890,6 +896,15 @@ int hv_tsdf_set_tile(hv_volume *v, int32_t u0, int32_t v0, int32_t u1, int32_t v
     v->tile[1] = v0;
     v->tile[2] = u1;
     v->tile[3] = v1;
+    return HV_OK;
+}
+
+int hv_tsdf_set_owner(hv_volume *v, int32_t rank, int32_t world_size) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_tsdf_set_owner: null volume");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_set_owner: volume is not in TSDF mode");
+    HV_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, HV_ERR_INVALID, "hv_tsdf_set_owner: bad rank/world");
+    v->owner_rank = rank;
+    v->owner_world = world_size;
     return HV_OK;
 }
 

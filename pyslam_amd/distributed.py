@@ -1,22 +1,27 @@
-"""Multi-GPU TSDF fusion: one process per GPU, frames sharded by image tile, RCCL merge over xGMI.
+"""Multi-GPU TSDF fusion: one process per GPU over torch.distributed (backend "nccl" = RCCL on ROCm).
 
 pySLAM itself has no multi-GPU path (no NCCL/MPI/torch.distributed call anywhere); this
-is new design (north-star form):
+is new design.  Every rank sees every posed frame (a 640x480 frame is 2 MB: replicating
+it is free next to the ~0.5 GB of voxel traffic it causes).  Two ways to split the work:
 
-* every rank sees every posed frame; rank r fuses only the voxels whose projection falls into its
-  vertical image tile [r*W/N, (r+1)*W/N) (``hv_tsdf_set_tile``): a voxel projects to exactly one
-  pixel, so within a frame the ranks' updates are disjoint and per-frame work divides by N;
-* units are allocated identically on all ranks (the touch pass looks at the whole image), units
-  that cannot project into a rank's tile are not swept there;
-* each rank's volume holds *partial* running means.  ``merge()`` turns them into additive
-  numerators {sum w*tsdf, w, sum r, sum g, sum b}, sum-reduces them to the root rank in ~64 MB
-  buckets (ring collectives over xGMI are per-link bound, ~153 GB/s: a few large messages), imports
-  the merged state on the root and clears the other ranks, which keep fusing deltas — the next
-  merge is again a plain sum.  The only collectives are an all-gather of unit keys (12 B/unit) and
-  the bucketed reduce.
+``sharding="owner"`` (default, "zero reduce" form) — a unit belongs to rank ``hash(unit index) % N``
+    (``hv_tsdf_set_owner``).  A rank claims, stores and sweeps only its own units: per-frame work
+    and HBM footprint divide by N, the fused volume is *bit-identical* to a single GPU's and is
+    simply distributed over the ranks — no collective while fusing.  ``gather_to_root()`` collects
+    it on one rank when a mesh is wanted.
 
-The volume object is duck-typed (unit_keys / export_numerators / import_numerators / reset /
-set_tile) so the collective logic is exercised on CPU with the gloo backend in tests/.
+``sharding="tile"`` (north-star form) — rank r fuses only the voxels whose projection falls into its
+    vertical image tile (``hv_tsdf_set_tile``); all ranks allocate all touched units, units that
+    cannot project into a rank's tile are not swept.  Each rank then holds *partial* running means
+    which ``merge()`` turns into additive numerators {sum w*tsdf, w, sum r, sum g, sum b} and
+    sum-reduces to the root in ~64 MB buckets (ring collectives over xGMI are per-link bound,
+    ~153 GB/s: few, large messages); the root imports the merged state, the other ranks are cleared
+    and keep fusing deltas, so the next merge is again a plain sum.
+
+Collectives used: an all-gather of unit keys (12 B/unit) and the bucketed sum-reduce — only inside
+merge()/gather_to_root(), never per frame.  The volume object is duck-typed (unit_keys /
+export_numerators / import_numerators / reset / set_tile / set_owner) so the collective logic is
+exercised on CPU with the gloo backend in tests/.
 """
 import numpy as np
 
@@ -34,14 +39,16 @@ def union_keys(key_sets):
     return np.unique(allk, axis=0)
 
 
-class TileShardedTSDF:
+class ShardedTSDF:
     BUCKET_BYTES = 64 << 20
 
     def __init__(self, voxel_length, sdf_trunc, width, height, device=0, max_blocks=None, rank=0, world_size=1,
-                 process_group=None, volume=None, group=None):
+                 process_group=None, volume=None, group=None, sharding="owner"):
+        assert sharding in ("owner", "tile")
         self.rank, self.world_size = int(rank), int(world_size)
         self.width, self.height = int(width), int(height)
         self.group = group
+        self.sharding = sharding
         self.distributed = self.world_size > 1
         if volume is None:
             from .volumetric import ScalableTSDFVolume
@@ -51,7 +58,10 @@ class TileShardedTSDF:
         self.volume = volume
         self.tile = tile_bounds(self.rank, self.world_size, self.width, self.height)
         if self.distributed:
-            self.volume.set_tile(*self.tile)
+            if sharding == "tile":
+                self.volume.set_tile(*self.tile)
+            else:
+                self.volume.set_owner(self.rank, self.world_size)
 
     # -- fusion ----------------------------------------------------------------------------------
     def integrate(self, image, intrinsic, extrinsic):
@@ -75,8 +85,9 @@ class TileShardedTSDF:
         return [g[:c].cpu().numpy() for g, c in zip(gathered, counts)]
 
     def merge(self, root=0):
-        """Sum-reduce all ranks' partial volumes into rank `root`; the other ranks are cleared.
-        Returns the number of merged units."""
+        """Sum-reduce all ranks' volumes into rank `root`; the other ranks are cleared.
+        tile sharding: merges partial running means; owner sharding: the sum of disjoint unit sets,
+        i.e. a gather.  Returns the number of units on the root afterwards."""
         if not self.distributed:
             return 0
         import torch
@@ -100,8 +111,20 @@ class TileShardedTSDF:
             if on_gpu:
                 torch.cuda.current_stream().synchronize()  # RCCL result visible before the import kernel reads it
             if self.rank == root:
+                # (owner sharding: the root now also *stores* foreign units; it keeps fusing only its own,
+                # the cleared ranks keep fusing theirs, and a later gather sums the deltas onto these)
                 self.volume.import_numerators(sub, payload if on_gpu else payload.numpy())
             del payload
         if self.rank != root:
             self.volume.reset()
         return k
+
+    gather_to_root = merge
+
+
+class TileShardedTSDF(ShardedTSDF):
+    """North-star form: image-tile sharding + numerator sum-reduce."""
+
+    def __init__(self, *args, **kwargs):
+        kwargs.setdefault("sharding", "tile")
+        super().__init__(*args, **kwargs)

@@ -27,6 +27,9 @@ class OracleBackedVolume:
     def set_tile(self, *a):
         pass
 
+    def set_owner(self, *a):
+        pass
+
     def integrate(self, depth, rgb, K, T):
         self.vol.integrate(depth, rgb, K, T, 1.0, 4.0)
 
