@@ -42,7 +42,7 @@ typedef enum hv_status {
 } hv_status;
 
 /* Values match pySLAM's VolumetricIntegratorType (pyslam/dense/volumetric_integrator_types.py:8-21). */
-typedef enum hv_mode { HV_MODE_VOXEL_GRID = 0, HV_MODE_TSDF = 3 } hv_mode;
+typedef enum hv_mode { HV_MODE_VOXEL_GRID = 0, HV_MODE_VOXEL_SEMANTIC_GRID = 1, HV_MODE_TSDF = 3 } hv_mode;
 typedef enum hv_loc { HV_HOST = 0, HV_DEVICE = 1 } hv_loc;
 typedef enum hv_color_dtype { HV_COLOR_NONE = 0, HV_COLOR_U8 = 1, HV_COLOR_F32 = 2 } hv_color_dtype;
 typedef enum hv_depth_dtype { HV_DEPTH_F32 = 0, HV_DEPTH_U16 = 1 } hv_depth_dtype;
@@ -131,6 +131,28 @@ int hv_dump_blocks(hv_volume *v, int32_t *keys, uint64_t *hashes, int32_t *count
 /* K2 parity probe: key arithmetic of voxel_hashing.h:69-75,139-161 for N f32 points (host arrays). */
 int hv_keys_from_points(hv_volume *v, const float *points, int64_t n, int32_t *voxel_keys,
                         int32_t *block_keys, int32_t *local_keys, uint64_t *block_hashes);
+
+/* ---- VOXEL_SEMANTIC_GRID mode: voting semantic payload (VoxelSemanticData, voxel_data_semantic.h:106-202)
+ * hv_integrate_points_semantic == VoxelBlockSemanticGrid.integrate(points f32|f64 [N,3], colors u8|f32,
+ *   class_ids i32 [N] | None, instance_ids i32 [N] | None, depths f32 [N] | None)
+ *   (volumetric_grid_module.h:131-467 -> integrate_raw -> update_voxel_direct, voxel_block_grid.hpp:524-614).
+ *   point_dtype: 0 float32, 1 float64 (keys follow get_voxel_key_inv<Tpos,Tpos>).  Labels, confidence
+ *   counters, counts and float64 position sums are bit-identical to the reference's sequential order.
+ *   Not provided: segment operations, instance->object association, the probabilistic payload. */
+int hv_integrate_points_semantic(hv_volume *v, const void *points, int32_t point_dtype, int64_t n, const void *colors,
+                                 int32_t color_dtype, const int32_t *class_ids, const int32_t *instance_ids,
+                                 const float *depths, int32_t loc);
+/* get_voxels(min_count, min_confidence) for semantic voxels: rows with count >= min_count and
+ * confidence >= min_confidence; points f64 [M,3], colors f32 [M,3], class_ids/object_ids i32 [M],
+ * confidences f32 [M] (host).  points == NULL: size query. */
+int hv_get_voxels_semantic(hv_volume *v, int32_t min_count, float min_confidence, double *points, float *colors,
+                           int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap, int64_t *n);
+/* set_depth_threshold(): observations with depth >= threshold do not vote (voxel_data_semantic.h:107,168-198). */
+int hv_set_depth_threshold(hv_volume *v, float depth_threshold);
+/* Parity/debug export, key-sorted: keys [B,3]; ints [B,bs^3,4] {count, object_id, class_id, confidence_counter};
+ * pos_sums [B,bs^3,3] f64; col_sums [B,bs^3,3] f32. */
+int hv_dump_blocks_semantic(hv_volume *v, int32_t *keys, int32_t *ints, double *pos_sums, float *col_sums,
+                            int64_t *n_blocks);
 
 /* ---- TSDF mode ---------------------------------------------------------------------------------
  * hv_tsdf_integrate == RGBDImage.create_from_color_and_depth(color, depth, depth_scale,

@@ -224,3 +224,106 @@ void ref_keys(float voxel_size, int block_size, const float *pts, int64_t n, int
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Semantic voting payload: VoxelBlockGridT<VoxelSemanticData> (voxel_data_semantic.h:106-202), the
+// container part of VoxelBlockSemanticGrid (segment / object-association methods are not wrapped).
+// ------------------------------------------------------------------------------------------------
+#include "voxel_data_semantic.h"
+
+namespace {
+using SemGridBase = volumetric::VoxelBlockGridT<volumetric::VoxelSemanticData>;
+class DumpableSemGrid : public SemGridBase {
+  public:
+    using SemGridBase::SemGridBase;
+    const auto &blocks() const { return blocks_; }
+};
+
+template <typename Tpos, typename Tcolor>
+void sem_integrate(DumpableSemGrid *g, const Tpos *pts, size_t n, const Tcolor *cols, const int *cls, const int *inst,
+                   const float *depths) {
+    if (inst != nullptr && depths != nullptr) {
+        g->integrate_raw<Tpos, Tcolor, int, int, float>(pts, n, cols, cls, inst, depths);
+    } else if (inst != nullptr) {
+        g->integrate_raw<Tpos, Tcolor, int, int>(pts, n, cols, cls, inst);
+    } else if (depths != nullptr) {
+        g->integrate_raw<Tpos, Tcolor, std::nullptr_t, int, float>(pts, n, cols, cls, nullptr, depths);
+    } else {
+        g->integrate_raw<Tpos, Tcolor, std::nullptr_t, int>(pts, n, cols, cls);
+    }
+}
+} // namespace
+
+extern "C" {
+
+void *ref_sgrid_create(float voxel_size, int block_size) { return new DumpableSemGrid(voxel_size, block_size); }
+void ref_sgrid_destroy(void *g) { delete static_cast<DumpableSemGrid *>(g); }
+void ref_sgrid_clear(void *g) { static_cast<DumpableSemGrid *>(g)->clear(); }
+int64_t ref_sgrid_num_blocks(void *g) { return (int64_t) static_cast<DumpableSemGrid *>(g)->num_blocks(); }
+void ref_sgrid_set_depth_threshold(float thr) { volumetric::VoxelSemanticData::kDepthThreshold = thr; }
+
+// pos_kind: 0 float32, 1 float64; color_kind: 1 uint8, 2 float32 (colours are required with semantics)
+void ref_sgrid_integrate(void *gv, const void *pts, int pos_kind, int64_t n, const void *cols, int color_kind,
+                         const int32_t *class_ids, const int32_t *instance_ids, const float *depths) {
+    auto *g = static_cast<DumpableSemGrid *>(gv);
+    const size_t nn = static_cast<size_t>(n);
+    if (pos_kind == 0 && color_kind == 1)
+        sem_integrate<float, uint8_t>(g, (const float *)pts, nn, (const uint8_t *)cols, class_ids, instance_ids, depths);
+    else if (pos_kind == 0)
+        sem_integrate<float, float>(g, (const float *)pts, nn, (const float *)cols, class_ids, instance_ids, depths);
+    else if (color_kind == 1)
+        sem_integrate<double, uint8_t>(g, (const double *)pts, nn, (const uint8_t *)cols, class_ids, instance_ids, depths);
+    else
+        sem_integrate<double, float>(g, (const double *)pts, nn, (const float *)cols, class_ids, instance_ids, depths);
+}
+
+// key-sorted dump: keys [B,3]; ints [B,bs^3,4] = {count, object_id, class_id, confidence_counter};
+// pos_sums [B,bs^3,3] f64; col_sums [B,bs^3,3] f32
+int64_t ref_sgrid_dump(void *gv, int32_t *keys, int32_t *ints, double *pos_sums, float *col_sums) {
+    auto *g = static_cast<DumpableSemGrid *>(gv);
+    std::vector<const std::pair<const BlockKey, DumpableSemGrid::Block> *> order;
+    for (const auto &kv : g->blocks()) order.push_back(&kv);
+    std::sort(order.begin(), order.end(), [](auto *a, auto *b) {
+        const auto &ka = a->first;
+        const auto &kb = b->first;
+        if (ka.x != kb.x) return ka.x < kb.x;
+        if (ka.y != kb.y) return ka.y < kb.y;
+        return ka.z < kb.z;
+    });
+    const int bs = g->get_block_size();
+    const size_t nv = size_t(bs) * bs * bs;
+    for (size_t b = 0; b < order.size(); ++b) {
+        const auto &key = order[b]->first;
+        const auto &blk = order[b]->second;
+        if (keys) { keys[b * 3] = key.x; keys[b * 3 + 1] = key.y; keys[b * 3 + 2] = key.z; }
+        for (size_t i = 0; i < nv; ++i) {
+            const auto &v = blk.data[i];
+            if (ints) {
+                int32_t *d = ints + (b * nv + i) * 4;
+                d[0] = v.count; d[1] = v.get_object_id(); d[2] = v.get_class_id(); d[3] = v.get_confidence_counter();
+            }
+            if (pos_sums) for (int k = 0; k < 3; ++k) pos_sums[(b * nv + i) * 3 + k] = v.position_sum[k];
+            if (col_sums) for (int k = 0; k < 3; ++k) col_sums[(b * nv + i) * 3 + k] = v.color_sum[k];
+        }
+    }
+    return (int64_t)order.size();
+}
+
+int64_t ref_sgrid_get_voxels(void *gv, int min_count, float min_confidence, double *pts, float *cols, int32_t *class_ids,
+                             int32_t *object_ids, float *confidences, int64_t cap) {
+    auto *g = static_cast<DumpableSemGrid *>(gv);
+    const auto vg = g->get_voxels(min_count, min_confidence);
+    const int64_t n = (int64_t)vg.points.size();
+    if (pts != nullptr) {
+        const int64_t m = std::min(n, cap);
+        for (int64_t i = 0; i < m; ++i) {
+            for (int k = 0; k < 3; ++k) { pts[i * 3 + k] = vg.points[i][k]; cols[i * 3 + k] = vg.colors[i][k]; }
+            class_ids[i] = vg.class_ids[i];
+            object_ids[i] = vg.object_ids[i];
+            confidences[i] = vg.confidences[i];
+        }
+    }
+    return n;
+}
+
+} // extern "C"

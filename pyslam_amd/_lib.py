@@ -17,6 +17,7 @@ _pi32 = _c.POINTER(_c.c_int32)
 
 HV_OK = 0
 HV_MODE_VOXEL_GRID = 0
+HV_MODE_VOXEL_SEMANTIC_GRID = 1
 HV_MODE_TSDF = 3
 HV_HOST, HV_DEVICE = 0, 1
 HV_COLOR_NONE, HV_COLOR_U8, HV_COLOR_F32 = 0, 1, 2
@@ -62,6 +63,10 @@ SIGNATURES = {
     "hv_size": (_i32, [_vp, _pi64]),
     "hv_dump_blocks": (_i32, [_vp, _vp, _vp, _vp, _vp, _pi64]),
     "hv_keys_from_points": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "hv_integrate_points_semantic": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _i32]),
+    "hv_get_voxels_semantic": (_i32, [_vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _pi64]),
+    "hv_set_depth_threshold": (_i32, [_vp, _f32]),
+    "hv_dump_blocks_semantic": (_i32, [_vp, _vp, _vp, _vp, _vp, _pi64]),
     "hv_tsdf_integrate": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_tsdf_integrate_batch": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_tsdf_set_tile": (_i32, [_vp, _i32, _i32, _i32, _i32]),

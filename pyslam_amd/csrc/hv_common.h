@@ -239,6 +239,7 @@ struct hv_volume {
     std::vector<HvFrameParams> host_params; // host copy (kept alive across the async H2D)
     int32_t tile[4] = {0, 0, 0, 0}; // u0, v0, u1, v1; all zero = whole image
     int32_t owner_rank = 0, owner_world = 1; // hv_tsdf_set_owner
+    float sem_depth_threshold = 10.0f;       // VoxelSemanticDataT::kDepthThreshold (hv_set_depth_threshold)
 
     // staging for HV_HOST inputs
     void *stage_a = nullptr;

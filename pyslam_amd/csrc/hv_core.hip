@@ -140,7 +140,7 @@ void hv_default_config(int32_t mode, hv_config *cfg) {
 
 int hv_create(const hv_config *cfg, hv_volume **out) {
     HV_REQUIRE(cfg != nullptr && out != nullptr, HV_ERR_INVALID, "hv_create: null argument");
-    HV_REQUIRE(cfg->mode == HV_MODE_VOXEL_GRID || cfg->mode == HV_MODE_TSDF, HV_ERR_INVALID,
+    HV_REQUIRE(cfg->mode == HV_MODE_VOXEL_GRID || cfg->mode == HV_MODE_VOXEL_SEMANTIC_GRID || cfg->mode == HV_MODE_TSDF, HV_ERR_INVALID,
                "hv_create: unsupported mode %d", cfg->mode);
     HV_REQUIRE(cfg->voxel_size > 0.0, HV_ERR_INVALID, "hv_create: voxel_size must be > 0");
     HV_REQUIRE(cfg->max_blocks > 0 && cfg->max_blocks < (1ll << 30), HV_ERR_INVALID,
@@ -188,13 +188,14 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
     v->own_stream = true;
 
     const int64_t nvox = (int64_t)cfg->block_size * cfg->block_size * cfg->block_size;
-    v->bytes_per_block = cfg->mode == HV_MODE_TSDF ? nvox * 4 * HV_TSDF_PLANES : nvox * (int64_t)sizeof(HvVoxel);
+    v->bytes_per_block = cfg->mode == HV_MODE_TSDF ? nvox * 4 * HV_TSDF_PLANES
+                         : cfg->mode == HV_MODE_VOXEL_SEMANTIC_GRID ? nvox * 64 /* HvSemVoxel */ : nvox * (int64_t)sizeof(HvVoxel);
     v->local_bits = 0;
     while ((1ll << v->local_bits) < nvox) v->local_bits++;
 
     v->table_capacity = next_pow2((uint64_t)cfg->max_blocks * 4);
     if (v->table_capacity < 1024) v->table_capacity = 1024;
-    if (cfg->mode == HV_MODE_VOXEL_GRID && (v->table_capacity << v->local_bits) > (1ull << 32)) {
+    if (cfg->mode != HV_MODE_TSDF && (v->table_capacity << v->local_bits) >= (1ull << 32)) {
         hv_set_error("hv_create: max_blocks too large for 32-bit (slot, voxel) sort keys");
         return fail(HV_ERR_INVALID);
     }

@@ -1,0 +1,373 @@
+// libpyslam_hipvol.so — VOXEL_SEMANTIC_GRID fusion: the *voting* semantic voxel payload of pySLAM's
+// cpp/volumetric (VoxelSemanticData = VoxelSemanticDataT<double,float>, voxel_data_semantic.h:106-202)
+// on the block hash, for gfx950.
+//
+// Label fusion is order dependent (a conflicting observation decrements the confidence counter and
+// may switch the label, voxel_data_semantic.h:175-191), so — exactly as for the plain grid — points
+// are grouped per voxel with a *stable* device radix sort and the head thread of every voxel run
+// folds its points in point-index order: labels, confidence counters, counts and the float64
+// position sums come out bit-identical to the reference's sequential branch.
+//
+// Record (64 B, two per 128-B line): {count, object_id+1, class_id+1, confidence_counter,
+// position_sum f64[3], color_sum f32[3], pad}.  Ids are stored +1 so that the all-zero pool means
+// "object -1 / class -1" (the reference's reset state) without per-block initialisation.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <numeric>
+
+#include "hv_common.h"
+#include <rocprim/device/device_radix_sort.hpp>
+
+static constexpr uint32_t HV_SORT_SENTINEL = 0xFFFFFFFFu;
+
+struct __attribute__((aligned(16))) HvSemVoxel {
+    int32_t count;
+    int32_t obj1; // object_id + 1
+    int32_t cls1; // class_id + 1
+    int32_t counter;
+    double pos[3];
+    float col[3];
+    float pad[3];
+};
+static_assert(sizeof(HvSemVoxel) == 64, "HvSemVoxel must be 64 bytes");
+
+struct HvSemParams {
+    float inv_voxel_size;
+    int32_t bs, nvox, local_bits;
+    float depth_threshold;
+};
+
+__host__ __device__ static inline int32_t sem_floor_div(int32_t a, int32_t b) {
+    const int64_t aa = a, bb = b;
+    return (int32_t)((aa >= 0) ? (aa / bb) : ((aa - bb + 1) / bb));
+}
+
+// get_voxel_key_inv<Tpos,Tpos>(x, inv_voxel_size_) as update_voxel calls it (voxel_block_grid.hpp:473):
+// float points -> float product; double points -> double product with the float member promoted.
+__device__ __forceinline__ int32_t sem_voxel_coord(float x, float inv) { return (int32_t)floorf(x * inv); }
+__device__ __forceinline__ int32_t sem_voxel_coord(double x, float inv) { return (int32_t)floor(x * (double)inv); }
+
+template <typename PT>
+__global__ __launch_bounds__(256) void k_sem_keys(HvTable table, const PT *__restrict__ pts, int64_t n, HvSemParams G,
+                                                   uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vals_out[i] = (uint32_t)i;
+    const PT p[3] = {pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]};
+    uint32_t key = HV_SORT_SENTINEL;
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) ok = ok && isfinite((double)p[a]) && fabs((double)p[a] * (double)G.inv_voxel_size) < 1.0e9;
+    if (ok) {
+        int32_t b[3], l[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int32_t v = sem_voxel_coord(p[a], G.inv_voxel_size);
+            b[a] = sem_floor_div(v, G.bs);
+            l[a] = (int32_t)((int64_t)v - (int64_t)b[a] * G.bs);
+        }
+        if (hv_key_in_range(b[0], b[1], b[2])) {
+            const int32_t slot = hv_table_insert(table, hv_pack_key(b[0], b[1], b[2]));
+            if (slot >= 0) key = ((uint32_t)slot << G.local_bits) | (uint32_t)(l[0] + l[1] * G.bs + l[2] * G.bs * G.bs);
+        }
+    }
+    if (key == HV_SORT_SENTINEL) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
+    keys_out[i] = key;
+}
+
+// update_voxel_direct (voxel_block_grid.hpp:524-614) for a SemanticVoxelWithDepth payload, folded over
+// one voxel's run in point-index order.
+template <typename PT, int COLOR_KIND>
+__global__ __launch_bounds__(256) void k_sem_reduce(HvTable table, HvSemVoxel *__restrict__ pool,
+                                                     const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                     int64_t n, HvSemParams G, const PT *__restrict__ pts,
+                                                     const void *__restrict__ cols, const int32_t *__restrict__ class_ids,
+                                                     const int32_t *__restrict__ instance_ids,
+                                                     const float *__restrict__ depths) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t key = keys[i];
+    if (key == HV_SORT_SENTINEL) return;
+    if (i > 0 && keys[i - 1] == key) return;
+    const int32_t idx = table.vals[(int32_t)(key >> G.local_bits)];
+    if (idx < 0) return;
+    HvSemVoxel *vx = pool + (int64_t)idx * G.nvox + (key & ((1u << G.local_bits) - 1u));
+    HvSemVoxel acc = *vx;
+    const float inv_255 = 1.0f / 255.0f;
+    int64_t j = i;
+    do {
+        const int64_t p = vals[j];
+        acc.pos[0] += (double)pts[p * 3 + 0];
+        acc.pos[1] += (double)pts[p * 3 + 1];
+        acc.pos[2] += (double)pts[p * 3 + 2];
+        if (COLOR_KIND == HV_COLOR_U8) {
+            const uint8_t *c = (const uint8_t *)cols + p * 3;
+            acc.col[0] += (float)c[0] * inv_255;
+            acc.col[1] += (float)c[1] * inv_255;
+            acc.col[2] += (float)c[2] * inv_255;
+        } else if (COLOR_KIND == HV_COLOR_F32) {
+            const float *c = (const float *)cols + p * 3;
+            acc.col[0] += c[0];
+            acc.col[1] += c[1];
+            acc.col[2] += c[2];
+        }
+        if (class_ids != nullptr) {
+            const int32_t obj1 = (instance_ids ? instance_ids[p] : 0) + 1;
+            const int32_t cls1 = class_ids[p] + 1;
+            const bool gate = depths ? (depths[p] < G.depth_threshold) : true; // *_with_depth, voxel_data_semantic.h:168-198
+            if (acc.count == 0) {
+                if (gate) { // initialize_semantics
+                    acc.obj1 = obj1;
+                    acc.cls1 = cls1;
+                    acc.counter = 1;
+                }
+            } else if (gate) { // update_semantics
+                if (acc.obj1 == obj1 && acc.cls1 == cls1) {
+                    acc.counter++;
+                } else {
+                    acc.counter--;
+                    if (acc.counter <= 0) {
+                        acc.obj1 = obj1;
+                        acc.cls1 = cls1;
+                        acc.counter = 1;
+                    }
+                }
+            }
+        }
+        acc.count = acc.count == 0 ? 1 : acc.count + 1;
+        ++j;
+    } while (j < n && keys[j] == key);
+    *vx = acc;
+}
+
+// get_confidence(), voxel_data_semantic.h:116-133
+__device__ __forceinline__ float sem_confidence(const HvSemVoxel &v) {
+    if (v.count == 0) return 0.0f;
+    const float r = (float)v.counter / (float)v.count;
+    return r < 1.0f ? r : 1.0f;
+}
+
+// get_voxels(min_count, min_confidence), voxel_block_grid.hpp:785-817 (semantic branch)
+__global__ __launch_bounds__(256) void k_sem_collect(HvTable table, const HvSemVoxel *__restrict__ pool, int64_t n_voxels,
+                                                      int min_count, float min_confidence, double *__restrict__ out_pts,
+                                                      float *__restrict__ out_cols, int32_t *__restrict__ out_cls,
+                                                      int32_t *__restrict__ out_obj, float *__restrict__ out_conf, int64_t cap) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool pred = false;
+    HvSemVoxel v;
+    v.count = 0;
+    float conf = 0.f;
+    if (gid < n_voxels) {
+        v = pool[gid];
+        conf = sem_confidence(v);
+        pred = v.count >= min_count && conf >= min_confidence;
+    }
+    const int32_t at = hv_wave_append(&table.counters[HV_CNT_OUT], pred);
+    if (pred && at < cap && out_pts != nullptr) {
+        const double c = (double)v.count;
+        const float cf = (float)v.count;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            out_pts[(int64_t)at * 3 + k] = v.pos[k] / c;
+            out_cols[(int64_t)at * 3 + k] = v.col[k] / cf;
+        }
+        out_cls[at] = v.cls1 - 1;
+        out_obj[at] = v.obj1 - 1;
+        out_conf[at] = conf;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static HvSemParams sem_params(const hv_volume *v) {
+    HvSemParams G;
+    G.inv_voxel_size = 1.0f / (float)v->cfg.voxel_size;
+    G.bs = v->cfg.block_size;
+    G.nvox = G.bs * G.bs * G.bs;
+    G.local_bits = v->local_bits;
+    G.depth_threshold = v->sem_depth_threshold;
+    return G;
+}
+
+static int sem_sort_bits(const hv_volume *v) {
+    int slot_bits = 0;
+    while ((1ull << slot_bits) < v->table_capacity) slot_bits++;
+    return std::min(32, slot_bits + v->local_bits + 1);
+}
+
+template <typename PT>
+static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d_cols, int color_kind,
+                         const int32_t *d_cls, const int32_t *d_inst, const float *d_depths) {
+    const HvSemParams G = sem_params(v);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    size_t bytes = 0;
+    HV_HIP(rocprim::radix_sort_pairs(nullptr, bytes, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in, v->sort_vals_out,
+                                     (size_t)n, 0, sem_sort_bits(v), v->stream));
+    int rc = hv_ensure_buffer(v, &v->sort_tmp, &v->sort_tmp_bytes, bytes);
+    if (rc != HV_OK) return rc;
+    hipLaunchKernelGGL(k_sem_keys<PT>, dim3(blocks), dim3(256), 0, v->stream, v->table, d_pts, n, G, v->sort_keys_in,
+                       v->sort_vals_in);
+    bytes = v->sort_tmp_bytes;
+    HV_HIP(rocprim::radix_sort_pairs(v->sort_tmp, bytes, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
+                                     v->sort_vals_out, (size_t)n, 0, sem_sort_bits(v), v->stream));
+    HvSemVoxel *pool = (HvSemVoxel *)v->pool;
+    if (color_kind == HV_COLOR_U8) {
+        hipLaunchKernelGGL((k_sem_reduce<PT, HV_COLOR_U8>), dim3(blocks), dim3(256), 0, v->stream, v->table, pool,
+                           v->sort_keys_out, v->sort_vals_out, n, G, d_pts, d_cols, d_cls, d_inst, d_depths);
+    } else if (color_kind == HV_COLOR_F32) {
+        hipLaunchKernelGGL((k_sem_reduce<PT, HV_COLOR_F32>), dim3(blocks), dim3(256), 0, v->stream, v->table, pool,
+                           v->sort_keys_out, v->sort_vals_out, n, G, d_pts, d_cols, d_cls, d_inst, d_depths);
+    } else {
+        hipLaunchKernelGGL((k_sem_reduce<PT, HV_COLOR_NONE>), dim3(blocks), dim3(256), 0, v->stream, v->table, pool,
+                           v->sort_keys_out, v->sort_vals_out, n, G, d_pts, d_cols, d_cls, d_inst, d_depths);
+    }
+    HV_HIP(hipGetLastError());
+    v->frame_counter += 1;
+    return HV_OK;
+}
+
+// stage a host array into a dedicated slice of the volume's scratch (5 inputs -> one growing buffer)
+static int sem_stage(hv_volume *v, const void *src, size_t bytes, int32_t loc, char *&cursor, const void **dev) {
+    if (src == nullptr) {
+        *dev = nullptr;
+        return HV_OK;
+    }
+    if (loc == HV_DEVICE) {
+        *dev = src;
+        return HV_OK;
+    }
+    HV_HIP(hipMemcpyAsync(cursor, src, bytes, hipMemcpyHostToDevice, v->stream));
+    *dev = cursor;
+    cursor += (bytes + 255) & ~(size_t)255;
+    return HV_OK;
+}
+
+extern "C" {
+
+int hv_set_depth_threshold(hv_volume *v, float depth_threshold) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_set_depth_threshold: null volume");
+    v->sem_depth_threshold = depth_threshold;
+    return HV_OK;
+}
+
+int hv_integrate_points_semantic(hv_volume *v, const void *points, int32_t point_dtype, int64_t n, const void *colors,
+                                 int32_t color_dtype, const int32_t *class_ids, const int32_t *instance_ids,
+                                 const float *depths, int32_t loc) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_integrate_points_semantic: null volume");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID, HV_ERR_MODE,
+               "hv_integrate_points_semantic: volume is not in VOXEL_SEMANTIC_GRID mode");
+    if (n == 0) return HV_OK;
+    HV_REQUIRE(points != nullptr && n > 0, HV_ERR_INVALID, "points must be a contiguous Nx3 array");
+    HV_REQUIRE(point_dtype == 0 || point_dtype == 1, HV_ERR_INVALID, "points must be float32 or float64");
+    HV_REQUIRE(color_dtype == HV_COLOR_NONE || color_dtype == HV_COLOR_U8 || color_dtype == HV_COLOR_F32, HV_ERR_INVALID,
+               "Colors must be uint8 or float32");
+    HV_REQUIRE(color_dtype == HV_COLOR_NONE || colors != nullptr, HV_ERR_INVALID, "points and colors must have the same size");
+    HV_REQUIRE(class_ids != nullptr || instance_ids == nullptr, HV_ERR_INVALID,
+               "instance_ids but no class_ids is not supported"); // voxel_block_grid.hpp:57-59
+    HV_REQUIRE(n <= v->cfg.max_points, HV_ERR_CAPACITY, "hv_integrate_points_semantic: %lld points exceed max_points=%lld",
+               (long long)n, (long long)v->cfg.max_points);
+    HV_HIP(hipSetDevice(v->device));
+    const size_t psz = point_dtype == 1 ? 8 : 4;
+    const size_t need = 3 * psz * n + 12 * (size_t)n + 3 * 4 * (size_t)n + 5 * 256;
+    if (loc == HV_HOST) {
+        int rc = hv_ensure_buffer(v, &v->stage_a, &v->stage_a_bytes, need);
+        if (rc != HV_OK) return rc;
+    }
+    char *cursor = (char *)v->stage_a;
+    const void *d_pts, *d_cols, *d_cls, *d_inst, *d_dep;
+    int rc = sem_stage(v, points, 3 * psz * n, loc, cursor, &d_pts);
+    if (rc == HV_OK) rc = sem_stage(v, color_dtype == HV_COLOR_NONE ? nullptr : colors, (color_dtype == HV_COLOR_U8 ? 3 : 12) * (size_t)n, loc, cursor, &d_cols);
+    if (rc == HV_OK) rc = sem_stage(v, class_ids, 4 * (size_t)n, loc, cursor, &d_cls);
+    if (rc == HV_OK) rc = sem_stage(v, instance_ids, 4 * (size_t)n, loc, cursor, &d_inst);
+    if (rc == HV_OK) rc = sem_stage(v, depths, 4 * (size_t)n, loc, cursor, &d_dep);
+    if (rc != HV_OK) return rc;
+    if (point_dtype == 1)
+        return sem_integrate<double>(v, (const double *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
+                                     (const int32_t *)d_inst, (const float *)d_dep);
+    return sem_integrate<float>(v, (const float *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
+                                (const int32_t *)d_inst, (const float *)d_dep);
+}
+
+int hv_get_voxels_semantic(hv_volume *v, int32_t min_count, float min_confidence, double *points, float *colors,
+                           int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap, int64_t *n) {
+    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_get_voxels_semantic: null argument");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID, HV_ERR_MODE,
+               "hv_get_voxels_semantic: volume is not in VOXEL_SEMANTIC_GRID mode");
+    HV_HIP(hipSetDevice(v->device));
+    int64_t nb = 0;
+    int rc = hv_num_blocks(v, &nb);
+    if (rc != HV_OK) return rc;
+    *n = 0;
+    if (nb == 0) return HV_OK;
+    const int64_t total = nb * sem_params(v).nvox;
+    const bool want = points && colors && class_ids && object_ids && confidences && cap > 0;
+    double *d_pts = nullptr;
+    float *d_cols = nullptr, *d_conf = nullptr;
+    int32_t *d_cls = nullptr, *d_obj = nullptr;
+    if (want) {
+        rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, (size_t)cap * (24 + 12 + 4 + 4 + 4) + 1024);
+        if (rc != HV_OK) return rc;
+        d_pts = (double *)v->out_a;
+        d_cols = (float *)(d_pts + 3 * cap);
+        d_cls = (int32_t *)(d_cols + 3 * cap);
+        d_obj = d_cls + cap;
+        d_conf = (float *)(d_obj + cap);
+    }
+    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
+    hipLaunchKernelGGL(k_sem_collect, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, v->table,
+                       (const HvSemVoxel *)v->pool, total, min_count, min_confidence, d_pts, d_cols, d_cls, d_obj, d_conf,
+                       want ? cap : 0);
+    HV_HIP(hipGetLastError());
+    rc = hv_read_counters(v);
+    if (rc != HV_OK) return rc;
+    *n = v->h_counters[HV_CNT_OUT];
+    if (want) {
+        const int64_t m = std::min(*n, cap);
+        if (m > 0) {
+            HV_HIP(hipMemcpyAsync(points, d_pts, 24 * m, hipMemcpyDeviceToHost, v->stream));
+            HV_HIP(hipMemcpyAsync(colors, d_cols, 12 * m, hipMemcpyDeviceToHost, v->stream));
+            HV_HIP(hipMemcpyAsync(class_ids, d_cls, 4 * m, hipMemcpyDeviceToHost, v->stream));
+            HV_HIP(hipMemcpyAsync(object_ids, d_obj, 4 * m, hipMemcpyDeviceToHost, v->stream));
+            HV_HIP(hipMemcpyAsync(confidences, d_conf, 4 * m, hipMemcpyDeviceToHost, v->stream));
+            HV_HIP(hipStreamSynchronize(v->stream));
+        }
+    }
+    return HV_OK;
+}
+
+int hv_dump_blocks_semantic(hv_volume *v, int32_t *keys, int32_t *ints, double *pos_sums, float *col_sums,
+                            int64_t *n_blocks) {
+    HV_REQUIRE(v != nullptr && n_blocks != nullptr, HV_ERR_INVALID, "hv_dump_blocks_semantic: null argument");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID, HV_ERR_MODE, "hv_dump_blocks_semantic: wrong mode");
+    int64_t nb = 0;
+    int rc = hv_num_blocks(v, &nb);
+    if (rc != HV_OK) return rc;
+    *n_blocks = nb;
+    if (nb == 0 || (!keys && !ints && !pos_sums && !col_sums)) return HV_OK;
+    const int nvox = sem_params(v).nvox;
+    std::vector<uint64_t> bkeys((size_t)nb);
+    HV_HIP(hipMemcpy(bkeys.data(), v->table.block_keys, sizeof(uint64_t) * nb, hipMemcpyDeviceToHost));
+    std::vector<std::array<int32_t, 3>> xyz((size_t)nb);
+    for (int64_t i = 0; i < nb; ++i) hv_unpack_key(bkeys[i], xyz[i][0], xyz[i][1], xyz[i][2]);
+    std::vector<int64_t> order((size_t)nb);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return xyz[a] < xyz[b]; });
+    std::vector<HvSemVoxel> host((size_t)nb * nvox);
+    HV_HIP(hipMemcpy(host.data(), v->pool, sizeof(HvSemVoxel) * host.size(), hipMemcpyDeviceToHost));
+    for (int64_t o = 0; o < nb; ++o) {
+        const int64_t i = order[o];
+        if (keys) memcpy(keys + o * 3, xyz[i].data(), 12);
+        for (int l = 0; l < nvox; ++l) {
+            const HvSemVoxel &x = host[(size_t)i * nvox + l];
+            if (ints) {
+                int32_t *d = ints + ((size_t)o * nvox + l) * 4;
+                d[0] = x.count; d[1] = x.obj1 - 1; d[2] = x.cls1 - 1; d[3] = x.counter;
+            }
+            if (pos_sums) memcpy(pos_sums + ((size_t)o * nvox + l) * 3, x.pos, 24);
+            if (col_sums) memcpy(col_sums + ((size_t)o * nvox + l) * 3, x.col, 12);
+        }
+    }
+    return HV_OK;
+}
+
+} // extern "C"
