@@ -208,6 +208,42 @@ __device__ __forceinline__ bool hv_tsdf_eval(const HvFrameParams &P, const uint2
     return true;
 }
 
+// Image patch of one unit staged in LDS: pixels [u0, u0+pw) x [v0, v0+ph) of the frame records.
+struct HvPatch {
+    const uint2 *lds; // nullptr: no patch (footprint too large / behind the camera) -> gather from global
+    int u0, v0, pw, ph;
+};
+
+// Same as hv_tsdf_eval, but the 8-byte frame record comes from the unit's LDS patch when the pixel
+// lies inside it (always, when a patch exists: the patch is the bounding box of the unit's
+// projection, padded), else from global memory.  Bit-identical results by construction.
+__device__ __forceinline__ bool hv_tsdf_eval_patch(const HvFrameParams &P, const uint2 *__restrict__ frame_px,
+                                                   const HvPatch &patch, float pc0, float pc1, float pc2, float &t,
+                                                   uint32_t &rgb) {
+    if (pc2 <= 0.0f) return false;
+    const float u_f = pc0 * P.fx / pc2 + P.cx + 0.5f;
+    const float v_f = pc1 * P.fy / pc2 + P.cy + 0.5f;
+    if (!(u_f >= 0.0001f && u_f < P.safe_width_f && v_f >= 0.0001f && v_f < P.safe_height_f)) return false;
+    const int u = (int)u_f;
+    const int v = (int)v_f;
+    if (u < P.tile_u0 || u >= P.tile_u1 || v < P.tile_v0 || v >= P.tile_v1) return false;
+    const int du = u - patch.u0, dv = v - patch.v0;
+    uint2 rec;
+    if (patch.lds != nullptr && du >= 0 && du < patch.pw && dv >= 0 && dv < patch.ph) {
+        rec = patch.lds[dv * patch.pw + du];
+    } else {
+        rec = frame_px[(int64_t)v * P.W + u];
+    }
+    const float d = __uint_as_float(rec.x);
+    if (d <= 0.0f) return false;
+    const float sdf = (d - pc2) * hv_multiplier(P, u, v);
+    if (!(sdf > -P.sdf_trunc_f)) return false;
+    t = sdf * P.sdf_trunc_inv_f;
+    if (t > 1.0f) t = 1.0f;
+    rgb = rec.y;
+    return true;
+}
+
 __device__ __forceinline__ void hv_tsdf_apply(bool valid, float t, uint32_t c, float &tsdf, uint32_t &w, uint32_t &sr,
                                               uint32_t &sg, uint32_t &sb) {
     if (!valid) return;
@@ -613,6 +649,175 @@ __global__ __launch_bounds__(64 * 16 / ZPW) void k_tsdf_integrate_batch(HvTable 
     }
 }
 
+// Multi-frame sweep with the unit's image footprint staged in LDS.  In the sweep above every voxel
+// evaluation is an 8-byte gather through the vector L1 (64 lanes -> 20-40 distinct lines per
+// instruction); the sweep is bound by that gather path plus VALU, not by HBM.  Here the workgroup
+// first projects the unit's 8 corners for every frame of its mask (512 threads = 64 frames x 8
+// corners, one pass), then per frame loads the padded bounding rectangle of the projection (a few
+// KB, coalesced row segments, served by L2) into LDS once and the 4096 voxel evaluations read LDS
+// instead.  Pixels outside the patch (or frames whose footprint does not fit / crosses the camera
+// plane) fall back to the global gather, so results are bit-identical.
+static constexpr int HV_PATCH_MAX_PX = 2304; // 18 KiB of LDS: e.g. 48 x 48 pixels
+
+__global__ __launch_bounds__(512, 4) void k_tsdf_integrate_batch_lds(HvTable table, const int32_t *__restrict__ list,
+                                                                   unsigned long long *__restrict__ frame_mask,
+                                                                   char *__restrict__ pool,
+                                                                   const uint2 *__restrict__ frame_px,
+                                                                   const HvFrameParams *__restrict__ Ps) {
+    constexpr int ZPW = 2;
+    __shared__ uint2 s_px[HV_PATCH_MAX_PX];
+    __shared__ int s_rect[64][4]; // per frame bit: u0, v0, pw, ph (pw == 0: no patch)
+    int n_units = table.counters[HV_CNT_TOUCH0];
+    if (n_units > table.max_blocks) n_units = table.max_blocks;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int x = lane >> 2;
+    const int y0 = (lane & 3) << 2;
+    const int z0 = wave * ZPW;
+    for (int t = blockIdx.x; t < n_units; t += gridDim.x) {
+        const int32_t slot = list[t];
+        const int32_t idx = table.vals[slot];
+        unsigned long long mask = frame_mask[slot];
+        __syncthreads(); // every wave has read the mask (and finished with s_rect/s_px of the previous unit)
+        if (tid == 0) frame_mask[slot] = 0ull;
+        if (idx < 0 || mask == 0ull) continue;
+        int32_t ux, uy, uz;
+        hv_unpack_key(table.keys[slot], ux, uy, uz);
+        {   // footprint rectangles: thread -> (frame f = tid / 8, corner = tid % 8)
+            const int f = tid >> 3, corner = tid & 7;
+            float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
+            bool behind = false;
+            if (mask & (1ull << f)) {
+                const HvFrameParams &P = Ps[f];
+                const float len = (float)P.unit_length;
+                const float cx = (float)((double)ux * P.unit_length) + ((corner & 1) ? len : 0.0f);
+                const float cy = (float)((double)uy * P.unit_length) + ((corner & 2) ? len : 0.0f);
+                const float cz = (float)((double)uz * P.unit_length) + ((corner & 4) ? len : 0.0f);
+                const float pz = P.ext[8] * cx + P.ext[9] * cy + P.ext[10] * cz + P.ext[11];
+                if (pz <= 1.0e-3f) {
+                    behind = true;
+                } else {
+                    const float pxc = P.ext[0] * cx + P.ext[1] * cy + P.ext[2] * cz + P.ext[3];
+                    const float pyc = P.ext[4] * cx + P.ext[5] * cy + P.ext[6] * cz + P.ext[7];
+                    umin = umax = pxc * P.fx / pz + P.cx + 0.5f;
+                    vmin = vmax = pyc * P.fy / pz + P.cy + 0.5f;
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { // reduce over the 8 corner lanes of this frame
+                umin = fminf(umin, __shfl_xor(umin, o));
+                umax = fmaxf(umax, __shfl_xor(umax, o));
+                vmin = fminf(vmin, __shfl_xor(vmin, o));
+                vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+                behind = behind || (__shfl_xor((int)behind, o) != 0);
+            }
+            if (corner == 0) {
+                int u0 = 0, v0 = 0, pw = 0, ph = 0;
+                if ((mask & (1ull << f)) && !behind) {
+                    const HvFrameParams &P = Ps[f];
+                    const int a0 = max(0, (int)floorf(umin) - 1), a1 = min(P.W, (int)floorf(umax) + 2);
+                    const int b0 = max(0, (int)floorf(vmin) - 1), b1 = min(P.H, (int)floorf(vmax) + 2);
+                    if (a1 > a0 && b1 > b0 && (a1 - a0) * (b1 - b0) <= HV_PATCH_MAX_PX) {
+                        u0 = a0; v0 = b0; pw = a1 - a0; ph = b1 - b0;
+                    }
+                }
+                s_rect[f][0] = u0; s_rect[f][1] = v0; s_rect[f][2] = pw; s_rect[f][3] = ph;
+            }
+        }
+        char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
+        const int wordb = z0 * RR + x * R + y0;
+        float4 vt[ZPW];
+        uint4 vw[ZPW], vr[ZPW], vg[ZPW], vb[ZPW];
+#pragma unroll
+        for (int zz = 0; zz < ZPW; ++zz) {
+            const int q = (wordb + zz * RR) >> 2;
+            vt[zz] = ((const float4 *)(unit + 0 * PLANE_BYTES))[q];
+            vw[zz] = ((const uint4 *)(unit + 1 * PLANE_BYTES))[q];
+            vr[zz] = ((const uint4 *)(unit + 2 * PLANE_BYTES))[q];
+            vg[zz] = ((const uint4 *)(unit + 3 * PLANE_BYTES))[q];
+            vb[zz] = ((const uint4 *)(unit + 4 * PLANE_BYTES))[q];
+        }
+        __syncthreads(); // s_rect complete
+        unsigned dirty = 0;
+        while (mask) {
+            const int f = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const HvFrameParams &P = Ps[f];
+            const uint2 *px = frame_px + (int64_t)f * P.H * P.W;
+            HvPatch patch;
+            patch.u0 = s_rect[f][0];
+            patch.v0 = s_rect[f][1];
+            patch.pw = s_rect[f][2];
+            patch.ph = s_rect[f][3];
+            patch.lds = patch.pw > 0 ? s_px : nullptr;
+            if (patch.pw > 0) { // stage the footprint: coalesced row segments
+                const int npx_patch = patch.pw * patch.ph;
+                for (int i = tid; i < npx_patch; i += 512) {
+                    const int r = i / patch.pw, c = i - r * patch.pw;
+                    s_px[i] = px[(int64_t)(patch.v0 + r) * P.W + patch.u0 + c];
+                }
+            }
+            __syncthreads(); // patch visible
+            const float inc0 = P.ext_scaled_col2[0], inc1 = P.ext_scaled_col2[1], inc2 = P.ext_scaled_col2[2];
+            const double o0 = (double)ux * P.unit_length;
+            const double o1 = (double)uy * P.unit_length;
+            const double o2 = (double)uz * P.unit_length;
+            const float p0 = (float)((double)(P.half_voxel_length_f + P.voxel_length_f * (float)x) + o0);
+            const float p2 = (float)((double)P.half_voxel_length_f + o2);
+            float pc[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float p1 = (float)((double)(P.half_voxel_length_f + P.voxel_length_f * (float)(y0 + c)) + o1);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    pc[c][r] = ((P.ext[r * 4 + 0] * p0 + P.ext[r * 4 + 1] * p1) + P.ext[r * 4 + 2] * p2) + P.ext[r * 4 + 3];
+                }
+            }
+            for (int s = 0; s < z0; ++s) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    pc[c][0] += inc0;
+                    pc[c][1] += inc1;
+                    pc[c][2] += inc2;
+                }
+            }
+#pragma unroll
+            for (int zz = 0; zz < ZPW; ++zz) {
+                float tv[4];
+                uint32_t cv[4];
+                unsigned m = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    tv[c] = 0.f;
+                    cv[c] = 0u;
+                    if (hv_tsdf_eval_patch(P, px, patch, pc[c][0], pc[c][1], pc[c][2], tv[c], cv[c])) m |= 1u << c;
+                    pc[c][0] += inc0;
+                    pc[c][1] += inc1;
+                    pc[c][2] += inc2;
+                }
+                hv_tsdf_apply(m & 1u, tv[0], cv[0], vt[zz].x, vw[zz].x, vr[zz].x, vg[zz].x, vb[zz].x);
+                hv_tsdf_apply(m & 2u, tv[1], cv[1], vt[zz].y, vw[zz].y, vr[zz].y, vg[zz].y, vb[zz].y);
+                hv_tsdf_apply(m & 4u, tv[2], cv[2], vt[zz].z, vw[zz].z, vr[zz].z, vg[zz].z, vb[zz].z);
+                hv_tsdf_apply(m & 8u, tv[3], cv[3], vt[zz].w, vw[zz].w, vr[zz].w, vg[zz].w, vb[zz].w);
+                if (m) dirty |= 1u << zz;
+            }
+            __syncthreads(); // all reads of s_px done before the next frame's patch overwrites it
+        }
+#pragma unroll
+        for (int zz = 0; zz < ZPW; ++zz) {
+            if (dirty & (1u << zz)) {
+                const int q = (wordb + zz * RR) >> 2;
+                ((float4 *)(unit + 0 * PLANE_BYTES))[q] = vt[zz];
+                ((uint4 *)(unit + 1 * PLANE_BYTES))[q] = vw[zz];
+                ((uint4 *)(unit + 2 * PLANE_BYTES))[q] = vr[zz];
+                ((uint4 *)(unit + 3 * PLANE_BYTES))[q] = vg[zz];
+                ((uint4 *)(unit + 4 * PLANE_BYTES))[q] = vb[zz];
+            }
+        }
+    }
+}
+
 // ---- numerators export / import (multi-GPU merge) ----------------------------------------------
 __global__ void k_tsdf_export(HvTable table, const char *__restrict__ pool, const int32_t *__restrict__ keys,
                               int64_t k, float *__restrict__ payload) {
@@ -867,7 +1072,16 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
                            (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks);
         hv_profile_begin(v);
         static const int zpw = getenv("HV_TSDF_BATCH_ZPW") ? atoi(getenv("HV_TSDF_BATCH_ZPW")) : 2;
-        if (zpw == 4) {
+        // LDS footprint staging is OFF by default.  Measured on the headline config (frames/s): plain
+        // sweep 13.9k; LDS variant 7.4k at 140 VGPRs (one 8-wave workgroup per CU: the load -> barrier ->
+        // evaluate phases of a unit cannot overlap another workgroup's) and 12.2k when forced to 128 VGPRs
+        // (two workgroups per CU, 24 B/lane scratch).  The two barriers per (unit, frame) still cost more
+        // than the L1 gathers they replace; a double-buffered asynchronous patch load is the next step.
+        static const int use_lds = getenv("HV_TSDF_BATCH_LDS") ? atoi(getenv("HV_TSDF_BATCH_LDS")) : 0;
+        if (use_lds && zpw == 2) {
+            hipLaunchKernelGGL(k_tsdf_integrate_batch_lds, dim3(4096), dim3(512), 0, v->stream, v->table, v->touched_list,
+                               (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
+        } else if (zpw == 4) {
             hipLaunchKernelGGL(k_tsdf_integrate_batch<4>, dim3(4096), dim3(256), 0, v->stream, v->table, v->touched_list,
                                (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
         } else if (zpw == 1) {
