@@ -12,6 +12,7 @@ from .volumetric_integrator_base import (
     VolumetricIntegrationPointCloud,
     VolumetricIntegrationTaskType,
     VolumetricIntegratorBase,
+    push_to_front,
 )
 from .volumetric_integrator_types import DatasetEnvironmentType
 
@@ -69,14 +70,38 @@ class VolumetricIntegratorTsdf(VolumetricIntegratorBase):
                 else:
                     ttype = self.last_input_task.task_type
                     if ttype == VolumetricIntegrationTaskType.INTEGRATE:
-                        keyframe_data = self.last_input_task.keyframe_data
-                        color, depth, _, _, _ = self.estimate_depth_if_needed_and_rectify(keyframe_data)
-                        if depth is not None:
-                            rgbd = RGBDImage.create_from_color_and_depth(
-                                color, depth, depth_scale=self.depth_factor,
-                                depth_trunc=self.volumetric_integration_depth_trunc, convert_rgb_to_intensity=False)
-                            self.volume.integrate(rgbd, self.o3d_camera, keyframe_data.pose)  # pose = Tcw
-                            self.last_integrated_id = keyframe_data.id
+                        # Backlog (offline reconstruction, rebuild() after loop closure): drain the queued
+                        # INTEGRATE tasks and fuse them with one multi-frame sweep (hv_tsdf_integrate_batch);
+                        # same result as fusing them one by one in this order.
+                        tasks = [self.last_input_task]
+                        while len(tasks) < 64:
+                            try:
+                                nxt = q_in.get_nowait()
+                            except Exception:
+                                break
+                            if nxt is not None and nxt.task_type == VolumetricIntegrationTaskType.INTEGRATE:
+                                tasks.append(nxt)
+                            else:
+                                push_to_front(q_in, nxt)  # not ours: put it back where it was
+                                break
+                        frames = []
+                        for task in tasks:
+                            color, depth, _, _, _ = self.estimate_depth_if_needed_and_rectify(task.keyframe_data)
+                            if depth is not None:
+                                frames.append((color, depth, task.keyframe_data.pose, task.keyframe_data.id))
+                        if len(frames) > 1 and hasattr(self.volume, "integrate_batch") and len({f[1].shape for f in frames}) == 1:
+                            self.volume.integrate_batch(np.stack([f[1] for f in frames]), np.stack([f[0] for f in frames]),
+                                                        self.o3d_camera, np.stack([f[2] for f in frames]),
+                                                        depth_scale=self.depth_factor,
+                                                        depth_trunc=self.volumetric_integration_depth_trunc)
+                        else:
+                            for color, depth, pose, _ in frames:
+                                rgbd = RGBDImage.create_from_color_and_depth(
+                                    color, depth, depth_scale=self.depth_factor,
+                                    depth_trunc=self.volumetric_integration_depth_trunc, convert_rgb_to_intensity=False)
+                                self.volume.integrate(rgbd, self.o3d_camera, pose)  # pose = Tcw
+                        if frames:
+                            self.last_integrated_id = frames[-1][3]
                             do_output = True
                             if self.last_output is not None:
                                 if time.perf_counter() - self.last_output.timestamp < Parameters.kVolumetricIntegrationOutputTimeInterval:

@@ -63,10 +63,15 @@ def test_protocol_end_to_end(kind, small_params, tmp_path):
         held = dh.FakeKeyFrame(3, s, cam, lba_count=0)  # gated until local BA has touched it (base.py:1153-1157)
         for kf in kfs + [held]:
             integ.add_keyframe(kf, kf.img, None, kf.depth_img)
+        # one output per integrate call; queued keyframes may be fused by one multi-frame sweep (TSDF), so
+        # between 1 and 3 outputs arrive for the 3 released keyframes
         outs = []
-        assert wait_until(lambda: (outs.append(integ.pop_output(timeout=0.2)) or True) and sum(o is not None for o in outs) >= 3)
+        assert wait_until(lambda: (outs.append(integ.pop_output(timeout=0.2)) or True) and any(o is not None for o in outs))
+        time.sleep(1.0)
+        while (o := integ.pop_output(timeout=0.1)) is not None:
+            outs.append(o)
         outs = [o for o in outs if o is not None]
-        assert {o.id for o in outs} <= {0, 1, 2}
+        assert 1 <= len(outs) <= 3 and {o.id for o in outs} <= {0, 1, 2}
         assert all(o.task_type == VolumetricIntegrationTaskType.INTEGRATE for o in outs)
         assert len(integ.keyframe_queue) == 1  # the gated keyframe is still waiting
         held.lba_count = 1
