@@ -97,6 +97,12 @@ int hv_integrate_rgbd_points(hv_volume *v, const void *depth, int32_t depth_dtyp
                              const uint8_t *rgb, int32_t height, int32_t width, const double *intr,
                              const double *T_cw, double min_depth, double max_depth, int32_t loc);
 
+/* cv2.remap(src, map_x, map_y, INTER_LINEAR | INTER_NEAREST, BORDER_CONSTANT 0) as pySLAM's undistortion
+ * uses it (volumetric_integrator_base.py:1017-1043).  src_kind 0: uint8 (channels interleaved), 1: float32,
+ * 2: int32 (nearest only); maps float32 [H,W]; all arrays live at `loc`.  OpenCV semantics restated, unpinned. */
+int hv_remap(hv_volume *v, const void *src, int32_t src_kind, int32_t channels, int32_t height, int32_t width,
+             const float *map_x, const float *map_y, int32_t linear, void *dst, int32_t loc);
+
 /* filter_shadow_points(depth, delta_depth=None, delta_x=2, delta_y=2, fill_value=-1)
  * (pyslam/utilities/depth.py:103-146): MAD-thresholded depth-discontinuity filter, bit-identical to
  * the numpy reference for float32 depth.  Works on any volume (uses its stream and scratch). */

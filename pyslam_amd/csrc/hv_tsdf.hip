@@ -370,10 +370,10 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int
             }
             continue;
         }
-        if (VARIANT == 0 || VARIANT == 5) {
+        if (VARIANT == 0 || VARIANT == 5 || VARIANT == 7) {
             // z-slabs evaluated per batch: 2 (107 VGPRs, 4 waves/SIMD) measured 7269 fps vs 6342 for 4
             // (180 VGPRs, 2 waves/SIMD) on the headline config
-            constexpr int ZB = (VARIANT == 0) ? 2 : 4;
+            constexpr int ZB = (VARIANT == 0) ? 2 : (VARIANT == 7 ? 1 : 4);
 #pragma unroll
             for (int zb = 0; zb < 4; zb += ZB) {
                 hv_tsdf_slabs<ZB>(P, frame_px, unit, (z0 + zb) * RR + x * R + y0, pc, inc0, inc1, inc2);
@@ -948,7 +948,8 @@ static int tsdf_launch_touch(hv_volume *v, hipStream_t s, const HvFrameParams &P
 // Second half on the volume's stream: sweep the touched units.  Grid: enough workgroups to fill
 // 256 CUs; grid-stride over the device-side touched count (no host round trip between launches).
 static int tsdf_launch_integrate(hv_volume *v, const HvFrameParams &P, int parity) {
-    const dim3 grid(4096), block(256);
+    static const int grid_blocks = getenv("HV_TSDF_GRID") ? atoi(getenv("HV_TSDF_GRID")) : 4096;
+    const dim3 grid(grid_blocks), block(256);
     const int32_t *list = touched_list_of(v, parity);
     const uint2 *px = frame_px_of(v, parity);
     char *pool = (char *)v->pool;
@@ -960,6 +961,7 @@ static int tsdf_launch_integrate(hv_volume *v, const HvFrameParams &P, int parit
     case 4: hipLaunchKernelGGL(k_tsdf_integrate<4>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
     case 5: hipLaunchKernelGGL(k_tsdf_integrate<5>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
     case 6: hipLaunchKernelGGL(k_tsdf_integrate<6>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
+    case 7: hipLaunchKernelGGL(k_tsdf_integrate<7>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
     default: hipLaunchKernelGGL(k_tsdf_integrate<0>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
     }
     hv_profile_end(v, 0);

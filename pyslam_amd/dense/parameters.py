@@ -12,6 +12,9 @@ class Parameters:
     kDenseMappingDtypeObjectIds = "int32"
     kDenseMappingDtypeTriangles = "uint32"
 
+    kDepthImageUndistortionUseOptimalNewCameraMatrixWithAlphaScale = True  # config_parameters.py:282-285
+    kDepthImageUndistortionOptimalNewCameraMatrixWithAlphaScaleValue = 0.7
+
     kDoVolumetricIntegration = False
     kVolumetricIntegrationType = "VOXEL_GRID"
     kVolumetricIntegrationVoxelLength = 0.015  # [m]

@@ -7,8 +7,9 @@ Differences that are deliberate (MI355X-first):
 * queues are plain multiprocessing queues of the spawn context instead of Manager proxies (one
   pickle instead of two per frame); the names q_in / q_out / q_management and their semantics
   (push-to-front for regular tasks, RESET on q_management) are unchanged;
-* undistortion (cv2.remap, base.py:1017-1043) is not part of this round's scope:
-  cameras with non-zero distortion are rejected loudly instead of being silently mis-fused.
+* undistortion: the maps are computed by a restatement of OpenCV's getOptimalNewCameraMatrix /
+  initUndistortRectifyMap (pyslam_amd/prep.py) and cv2.remap runs on the GPU (hv_remap); cv2 is not
+  available here, so parity with OpenCV at that step is unpinned (validated geometrically).
 """
 import multiprocessing as std_mp
 import os
@@ -411,18 +412,28 @@ class VolumetricIntegratorBase:
         self.depth_factor = 1.0  # base.py:713: the factor is already folded into the keyframe depth
         self.last_output = None
         self.last_integrated_id = -1
+        # maps to undistort colour / depth / label images (base.py:758-786); the remaps themselves run on
+        # the GPU (hv_remap).  OpenCV's getOptimalNewCameraMatrix / initUndistortRectifyMap are restated
+        # in pyslam_amd/prep.py (cv2 is not a dependency of this package).
         D = np.asarray(getattr(camera, "D", np.zeros(5)), dtype=np.float64).ravel()
+        K = np.array([[camera.fx, 0.0, camera.cx], [0.0, camera.fy, camera.cy], [0.0, 0.0, 1.0]])
+        self.new_K, self.calib_map1, self.calib_map2 = K, None, None
         if np.linalg.norm(D) > 1e-10:
-            raise NotImplementedError(
-                "camera has lens distortion: undistort/rectify (cv2.remap, base.py:1017-1043) is outside this "
-                "round's scope (SURVEY 8f N1); feed rectified images"
-            )
+            from ..prep import get_optimal_new_camera_matrix, init_undistort_rectify_map
+
+            if getattr(Parameters, "kDepthImageUndistortionUseOptimalNewCameraMatrixWithAlphaScale", True):
+                alpha = getattr(Parameters, "kDepthImageUndistortionOptimalNewCameraMatrixWithAlphaScaleValue", 0.7)
+                self.new_K, _ = get_optimal_new_camera_matrix(K, D, (camera.width, camera.height), alpha,
+                                                              (camera.width, camera.height))
+            self.calib_map1, self.calib_map2 = init_undistort_rectify_map(K, D, self.new_K, (camera.width, camera.height))
+        self.rectified_fx, self.rectified_fy = float(self.new_K[0, 0]), float(self.new_K[1, 1])
+        self.rectified_cx, self.rectified_cy = float(self.new_K[0, 2]), float(self.new_K[1, 2])
         self.dtype_vertices = np.dtype(Parameters.kDenseMappingDtypeVertices)
         self.dtype_colors = np.dtype(Parameters.kDenseMappingDtypeColors)
         self.dtype_depths = np.dtype(Parameters.kDenseMappingDtypeDepth)
 
     def get_camera_intrinsics_for_depth(self):
-        return self.camera.fx, self.camera.fy, self.camera.cx, self.camera.cy
+        return self.rectified_fx, self.rectified_fy, self.rectified_cx, self.rectified_cy
 
     def estimate_depth_if_needed_and_rectify(self, keyframe_data):  # base.py:969-1062 (no estimator, no remap)
         color, depth = keyframe_data.img, keyframe_data.depth
@@ -432,8 +443,17 @@ class VolumetricIntegratorBase:
             factor = getattr(self.camera, "depth_factor", 1.0) if getattr(self, "use_cpp_core", False) else 1.0
             depth = depth.astype(np.float32) * np.float32(factor) if factor != 1.0 else depth.astype(np.float32)
             keyframe_data.depth = depth
+        semantic, instances = keyframe_data.semantic_img, keyframe_data.semantic_instances_img
+        if self.calib_map1 is not None:  # base.py:1017-1043: colour bilinear, depth and labels nearest
+            m1, m2 = self.calib_map1, self.calib_map2
+            color = self.volume.remap(np.ascontiguousarray(color), m1, m2, linear=True)
+            depth = self.volume.remap(depth, m1, m2, linear=False)
+            if semantic is not None:
+                semantic = self.volume.remap(np.ascontiguousarray(semantic, dtype=np.int32), m1, m2, linear=False)
+            if instances is not None:
+                instances = self.volume.remap(np.ascontiguousarray(instances, dtype=np.int32), m1, m2, linear=False)
         color_rgb = np.ascontiguousarray(color[..., ::-1])  # cv2.COLOR_BGR2RGB, base.py:1054
-        return color_rgb, depth, None, keyframe_data.semantic_img, keyframe_data.semantic_instances_img
+        return color_rgb, depth, None, semantic, instances
 
     def volume_integration(self, *args, **kwargs):  # base.py:1100-1117
         raise NotImplementedError

@@ -99,6 +99,20 @@ class _Volume:
                                                   L.ptr(out), L.location(d)))
         return out
 
+    def remap(self, img, map_x, map_y, linear=False):
+        """cv2.remap(img, map_x, map_y, INTER_LINEAR if linear else INTER_NEAREST) on the GPU (host arrays)."""
+        img = np.ascontiguousarray(img)
+        kind = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.int32): 2}.get(img.dtype)
+        if kind is None:
+            raise RuntimeError(f"remap: unsupported image dtype {img.dtype}")
+        H, W = img.shape[:2]
+        C = 1 if img.ndim == 2 else img.shape[2]
+        mx = np.ascontiguousarray(map_x, dtype=np.float32)
+        my = np.ascontiguousarray(map_y, dtype=np.float32)
+        out = np.empty_like(img)
+        L.check(self._lib.hv_remap(self._h, L.ptr(img), kind, C, H, W, L.ptr(mx), L.ptr(my), 1 if linear else 0, L.ptr(out), L.HV_HOST))
+        return out
+
     def bytes_per_block(self):
         n = ctypes.c_int64()
         L.check(self._lib.hv_bytes_per_block(self._h, ctypes.byref(n)))

@@ -1,0 +1,73 @@
+"""Undistortion.  CPU: the map restatement is self-consistent (distort o undistort = id,
+zero distortion -> identity maps, alpha interpolation bounds).  GPU: remapping a *distorted* analytic
+rendering with the maps reproduces the ideal pinhole rendering with the new camera matrix — the
+geometric property cv2.initUndistortRectifyMap + cv2.remap exist to deliver (cv2 itself is absent)."""
+import numpy as np
+import pytest
+
+from pyslam_amd import prep
+
+# TUM1-like intrinsics and distortion (settings/TUM1.yaml:27-36)
+K = np.array([[517.306408, 0, 318.643040], [0, 516.469215, 255.313989], [0, 0, 1.0]])
+D = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314])
+W, H = 640, 480
+
+
+def test_distort_undistort_roundtrip():
+    rng = np.random.default_rng(0)
+    x, y = (rng.random(1000) - 0.5) * 0.9, (rng.random(1000) - 0.5) * 0.7
+    xd, yd = prep.distort_normalized(x, y, D)
+    u, v = K[0, 0] * xd + K[0, 2], K[1, 1] * yd + K[1, 2]
+    xr, yr = prep.undistort_points_normalized(u, v, K, D, iters=30)
+    assert np.abs(xr - x).max() < 1e-6 and np.abs(yr - y).max() < 1e-6
+    x5, y5 = prep.undistort_points_normalized(u, v, K, D)  # OpenCV's 5 iterations: close, not exact
+    assert np.abs(x5 - x).max() < 5e-3
+
+
+def test_zero_distortion_gives_identity_maps():
+    mx, my = prep.init_undistort_rectify_map(K, np.zeros(5), K, (W, H))
+    uu, vv = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    assert np.abs(mx - uu).max() < 1e-3 and np.abs(my - vv).max() < 1e-3
+
+
+def test_optimal_new_camera_matrix_alpha_range():
+    k0, _ = prep.get_optimal_new_camera_matrix(K, D, (W, H), 0.0, (W, H))
+    k1, _ = prep.get_optimal_new_camera_matrix(K, D, (W, H), 1.0, (W, H))
+    k7, _ = prep.get_optimal_new_camera_matrix(K, D, (W, H), 0.7, (W, H))
+    assert k0[0, 0] > k1[0, 0] and k0[1, 1] > k1[1, 1]  # alpha=0 zooms in (valid pixels only), alpha=1 keeps all
+    np.testing.assert_allclose(k7, 0.3 * k0 + 0.7 * k1, atol=1e-9)
+    mx, my = prep.init_undistort_rectify_map(K, D, k0, (W, H))
+    assert mx.min() >= -1.0 and mx.max() <= W and my.min() >= -1.0 and my.max() <= H  # alpha=0: all sources inside
+
+
+def _render(Kmat, dist):
+    """Analytic scene: depth of a slanted plane + colour stripes, through a (possibly distorted) camera."""
+    uu, vv = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    if dist is None:
+        x, y = (uu - Kmat[0, 2]) / Kmat[0, 0], (vv - Kmat[1, 2]) / Kmat[1, 1]
+    else:
+        x, y = prep.undistort_points_normalized(uu, vv, Kmat, dist, iters=30)
+    depth = 2.0 / (1.0 + 0.3 * x - 0.2 * y)  # plane n.p = 2 with n = (0.3, -0.2, 1)
+    rgb = np.stack([127 + 100 * np.sin(6 * x), 127 + 100 * np.cos(5 * y), 127 + 100 * np.sin(4 * (x + y))], -1)
+    return depth.astype(np.float32), np.clip(np.rint(rgb), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.gpu
+def test_gpu_remap_undistorts_analytic_scene():
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    vol = VoxelBlockGrid(0.05, 8, max_blocks=1 << 10, max_points=1 << 20)
+    und = prep.Undistorter(vol, K, D, W, H, use_optimal_new_K=True, alpha=0.7)
+    depth_d, rgb_d = _render(K, D)                 # what the distorted sensor sees
+    depth_i, rgb_i = _render(und.new_K, None)      # ideal pinhole view with the new camera matrix
+    depth_u, rgb_u = und.depth(depth_d), und.color(rgb_d)
+    inside = (und.map_x > 1) & (und.map_x < W - 2) & (und.map_y > 1) & (und.map_y < H - 2)
+    assert inside.mean() > 0.6
+    assert np.abs(depth_u - depth_i)[inside].max() < 5e-3       # nearest sampling of a smooth depth field
+    assert np.abs(rgb_u.astype(int) - rgb_i.astype(int))[inside].max() <= 6  # bilinear colour, 8-bit rounding
+    assert (depth_u[~((und.map_x >= -0.5) & (und.map_x < W - 0.5) & (und.map_y >= -0.5) & (und.map_y < H - 0.5))] == 0).all()
+    lab = (np.arange(H * W, dtype=np.int32).reshape(H, W) % 41)
+    lab_u = und.labels(lab)
+    sx, sy = np.rint(und.map_x).astype(int), np.rint(und.map_y).astype(int)
+    ok = (sx >= 0) & (sx < W) & (sy >= 0) & (sy < H)
+    np.testing.assert_array_equal(lab_u[ok], lab[sy[ok], sx[ok]])  # exact nearest-neighbour lookup
