@@ -54,8 +54,9 @@ def load_frames(config, n_frames, start=0):
         return s, z["depth"], z["rgb"], z["T"]
     depth, rgb, T = s.batch(start, n_frames)
     try:
-        np.savez(cache + ".tmp.npz", depth=depth, rgb=rgb, T=T)
-        os.replace(cache + ".tmp.npz", cache)
+        tmp = f"{cache}.{os.getpid()}.tmp.npz"  # per-process name: N ranks may generate concurrently
+        np.savez(tmp, depth=depth, rgb=rgb, T=T)
+        os.replace(tmp, cache)
     except OSError:
         pass
     return s, depth, rgb, T
@@ -225,7 +226,10 @@ def main():
         cpu = None
         cores = args.cpu_threads
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline_and_counts(s, depth_h, rgb_h, T_h, args.cpu_budget_s, args.cpu_threads)
+            # the timed CPU baseline belongs to the N=1 line only; at N>1 a 4-frame oracle pass still
+            # provides the touched/updated counts the roofline figure needs
+            budget = args.cpu_budget_s if world == 1 else 0.0
+            cpu = cpu_baseline_and_counts(s, depth_h, rgb_h, T_h, budget, args.cpu_threads if world == 1 else 8)
             cores = cpu["threads"]
 
         def roofline_of(kernel_ms_, launches_, frames_):
@@ -280,13 +284,13 @@ def main():
                 "units_allocated": int(vol.num_blocks()),
             },
             "roofline": roofline,
-            "cpu_baseline": None if cpu is None else {
+            "cpu_baseline": None if (cpu is None or world > 1) else {
                 "value": round(cpu["fps"], 3), "unit": "frames/s", "cores": cores, "kind": "port",
                 "sample": f"{cpu['frames']} frames of the same stream ({cpu['seconds']:.1f} s), oracle/tsdf_oracle.c "
                           f"(Open3D-semantics restatement; open3d itself is not installed), OpenMP over touched units",
             },
         }
-        if cpu is not None:
+        if cpu is not None and world == 1:
             out["speedup_vs_cpu"] = round(fps / cpu["fps"], 1)
         if other is not None:
             out["online_mode"] = {
