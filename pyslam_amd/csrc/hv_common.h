@@ -236,7 +236,10 @@ struct hv_volume {
     int32_t frame_batch_cap = 0;
     void *batch_buf = nullptr;        // multi-frame sweep scratch: B frame records + B HvFrameParams
     size_t batch_buf_bytes = 0;
-    std::vector<HvFrameParams> host_params; // host copy (kept alive across the async H2D)
+    // pinned ring of per-batch HvFrameParams (async H2D without a host sync per call)
+    void *pinned_params[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t params_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int params_idx = 0;
     int32_t tile[4] = {0, 0, 0, 0}; // u0, v0, u1, v1; all zero = whole image
     int32_t owner_rank = 0, owner_world = 1; // hv_tsdf_set_owner
     float sem_depth_threshold = 10.0f;       // VoxelSemanticDataT::kDepthThreshold (hv_set_depth_threshold)

@@ -245,6 +245,10 @@ void hv_destroy(hv_volume *v) {
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (v->h_counters) (void)hipHostFree(v->h_counters);
+    for (int i = 0; i < 4; ++i) {
+        if (v->pinned_params[i]) (void)hipHostFree(v->pinned_params[i]);
+        if (v->params_ev[i]) (void)hipEventDestroy(v->params_ev[i]);
+    }
     for (auto &p : v->events) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);

@@ -1042,12 +1042,21 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         return HV_OK;
     }
     // multi-frame sweeps of up to 64 frames (one bit per frame in the per-unit mask)
-    HV_HIP(hipStreamSynchronize(v->stream)); // a previous call's async H2D of host_params has finished
     const int BMAX = 64;
-    std::vector<HvFrameParams> &params = v->host_params;
     for (int f0 = 0; f0 < n_frames; f0 += BMAX) {
         const int B = std::min(BMAX, n_frames - f0);
-        params.resize((size_t)B);
+        // per-frame constants go through a ring of 4 pinned host buffers: the H2D copy is truly
+        // asynchronous and a slot is only rewritten after the copy that last used it has completed,
+        // so consecutive calls queue up on the stream without a host synchronisation
+        const int ri = v->params_idx;
+        v->params_idx = (ri + 1) & 3;
+        if (v->pinned_params[ri] == nullptr) {
+            HV_HIP(hipHostMalloc(&v->pinned_params[ri], sizeof(HvFrameParams) * BMAX));
+            HV_HIP(hipEventCreateWithFlags(&v->params_ev[ri], hipEventDisableTiming));
+        } else {
+            HV_HIP(hipEventSynchronize(v->params_ev[ri]));
+        }
+        HvFrameParams *params = (HvFrameParams *)v->pinned_params[ri];
         for (int f = 0; f < B; ++f) {
             make_frame_params(v, height, width, intr, T_cw + 16 * (size_t)(f0 + f), depth_scale, depth_trunc, depth_dtype,
                               &params[f]);
@@ -1062,7 +1071,8 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         if (rc != HV_OK) return rc;
         uint2 *d_px = (uint2 *)v->batch_buf;
         HvFrameParams *d_params = (HvFrameParams *)((char *)v->batch_buf + ((px_bytes + 255) & ~(size_t)255));
-        HV_HIP(hipMemcpyAsync(d_params, params.data(), sizeof(HvFrameParams) * (size_t)B, hipMemcpyHostToDevice, v->stream));
+        HV_HIP(hipMemcpyAsync(d_params, params, sizeof(HvFrameParams) * (size_t)B, hipMemcpyHostToDevice, v->stream));
+        HV_HIP(hipEventRecord(v->params_ev[ri], v->stream));
         HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, sizeof(int32_t), v->stream));
         const int n_prep_blocks = (int)((npx + 255) / 256);
         const int stride = v->cfg.depth_sampling_stride;
@@ -1097,8 +1107,6 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         HV_HIP(hipGetLastError());
         // leave both per-frame parity counters clean for a following hv_tsdf_integrate
         HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
-        // host_params is reused by the next sub-batch / call: the H2D copy above must have consumed it
-        if (f0 + BMAX < n_frames) HV_HIP(hipStreamSynchronize(v->stream));
     }
     return HV_OK;
 }
