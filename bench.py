@@ -12,12 +12,18 @@ default --sharding owner: a unit is fused and stored by GPU hash(unit index) % N
 reduce" form: bit-identical to one GPU, no collective while fusing; units all ranks processed = the
 whole frame); --sharding tile: north-star image tiles + one RCCL numerator sum-reduce (timed).
 
+Launch modes: --mode batch (default) fuses the step's frames with one multi-frame sweep
+(hv_tsdf_integrate_batch, the rebuild()/offline-replay path); --mode online calls hv_tsdf_integrate
+once per frame (pySLAM's live flow).  Both produce identical volumes.
+
 Extra objects on the JSON line:
-  roofline     dominant kernel (k_tsdf_integrate): algorithmic bytes per launch (oracle counts:
-               U_touched*4096*20 B read + N_updated*20 B written) / mean launch
-               duration from HIP events on the kernel's stream, vs the 8 TB/s HBM3E peak.
+  roofline     dominant kernel of the timed region: algorithmic bytes per launch = the oracle's
+               per-frame figure (U_touched*4096*20 B read + N_updated*20 B written) x the
+               frames one launch processes / mean launch duration from HIP events on the kernel's
+               stream, vs the 8 TB/s HBM3E peak; `traffic` = recorded PMC bytes (profiles/r01).
+  online_mode  (N=1, batch mode) a short second pass in online mode: frames/s + that kernel's roofline.
   cpu_baseline oracle/tsdf_oracle.c (Open3D-semantics restatement, kind "port") timed on the host
-               cores on a bounded sample of the same frames.
+               cores on a bounded sample of the same frames (N=1 only).
 """
 import argparse
 import json

@@ -228,12 +228,11 @@ struct hv_volume {
     // TSDF per-frame state
     int32_t *touched_stamp = nullptr; // [table_capacity] last frame id that touched the slot
     int32_t *touched_list = nullptr;  // [max_blocks] slots touched this frame
-    uint64_t *touched_mask = nullptr; // [table_capacity] per-slot frame bitmask (batch mode)
+    uint64_t *touched_mask = nullptr; // [table_capacity] per-slot frame bitmask of the multi-frame sweep
     void *frame_px = nullptr;         // [max_points] uint2 {depth f32 bits, packed rgb}: the gather target
     int debug_variant = 0;            // env HV_TSDF_DEBUG_VARIANT (roofline ablation only)
     int32_t frame_counter = 0;
     int32_t last_touch_parity = 0;
-    int32_t frame_batch_cap = 0;
     void *batch_buf = nullptr;        // multi-frame sweep scratch: B frame records + B HvFrameParams
     size_t batch_buf_bytes = 0;
     // pinned ring of per-batch HvFrameParams (async H2D without a host sync per call)

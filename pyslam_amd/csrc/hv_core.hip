@@ -213,7 +213,6 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
         HV_TRY(hipMalloc(&v->touched_stamp, sizeof(int32_t) * v->table_capacity));
         HV_TRY(hipMalloc(&v->touched_list, sizeof(int32_t) * cfg->max_blocks));
         HV_TRY(hipMalloc(&v->touched_mask, sizeof(uint64_t) * v->table_capacity));
-        v->frame_batch_cap = 1;
         HV_TRY(hipMalloc(&v->frame_px, 8 * (size_t)cfg->max_points));
         if (const char *dv = getenv("HV_TSDF_DEBUG_VARIANT")) v->debug_variant = atoi(dv);
     } else {

@@ -1,22 +1,26 @@
 // libpyslam_hipvol.so — TSDF fusion kernels (Open3D ScalableTSDFVolume semantics) for gfx950.
 //
-// Per frame (reference call site pyslam/dense/volumetric_integrator_tsdf.py:215-223):
+// Online path, per frame (reference call site pyslam/dense/volumetric_integrator_tsdf.py:215-223):
 //   k_tsdf_prep_touch   one launch, two block roles:
 //       prep  blocks: depth -> float metres with depth_scale/depth_trunc applied
-//                     (Image::ConvertDepthToFloatImage), RGB u8x3 -> one packed dword per pixel;
+//                     (Image::ConvertDepthToFloatImage), RGB u8x3 packed: one 8-byte
+//                     {depth, rgb} record per pixel (the sweep's per-voxel gather);
 //       touch blocks: every `stride`-th pixel is back-projected in f64 and the volume units within
 //                     +/- sdf_trunc are claimed in the block hash (ScalableTSDFVolume::Integrate
-//                     front half); first toucher of a unit this frame appends it to the touched list.
+//                     front half), de-duplicated per wave; the first toucher of a unit this frame
+//                     appends it to the touched list.
 //   k_tsdf_integrate    one workgroup (4 waves) per touched unit; wave w owns z in [4w, 4w+4); lane
 //                       (x, 4 y's).  Each z-slab of each plane is one contiguous 1 KiB dwordx4
 //                       burst per wave.  Arithmetic follows UniformTSDFVolume::
 //                       IntegrateWithDepthToCameraDistanceMultiplier operation by operation
 //                       (compiled with -ffp-contract=off; IEEE div/sqrt) so tsdf and weight are
 //                       bit-identical to the CPU restatement in oracle/tsdf_oracle.c.
-//
-// HBM-bound: algorithmic bytes per touched unit = 4096 voxels * 20 B read (+ 20 B per updated
-// voxel written).  No reuse of voxel data -> no LDS staging; depth/colour gathers are served by
-// L1/L2 (one 640x480 frame = 2.4 MB packed, resident in every XCD's 4 MiB L2).
+//   HBM-bound: algorithmic bytes per touched unit = 4096 voxels * 20 B read (+ 20 B per updated
+//   voxel written); no reuse of voxel data within a frame.  Frame gathers are served by L1/L2 (a
+//   640x480 frame = 2.4 MB packed, resident in every XCD's 4 MiB L2).
+// Multi-frame sweep (hv_tsdf_integrate_batch): k_tsdf_prep_touch_batch + k_tsdf_integrate_batch further
+// down — unit slabs are reused in registers across up to 64 frames.
+// Multi-GPU hooks: image-tile restriction (hv_tsdf_set_tile) and unit ownership (hv_tsdf_set_owner).
 #include <algorithm>
 #include <array>
 #include <cmath>
