@@ -42,7 +42,12 @@ typedef enum hv_status {
 } hv_status;
 
 /* Values match pySLAM's VolumetricIntegratorType (pyslam/dense/volumetric_integrator_types.py:8-21). */
-typedef enum hv_mode { HV_MODE_VOXEL_GRID = 0, HV_MODE_VOXEL_SEMANTIC_GRID = 1, HV_MODE_TSDF = 3 } hv_mode;
+typedef enum hv_mode {
+    HV_MODE_VOXEL_GRID = 0,
+    HV_MODE_VOXEL_SEMANTIC_GRID = 1,               /* voting payload */
+    HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID = 2, /* log-probability payload */
+    HV_MODE_TSDF = 3
+} hv_mode;
 typedef enum hv_loc { HV_HOST = 0, HV_DEVICE = 1 } hv_loc;
 typedef enum hv_color_dtype { HV_COLOR_NONE = 0, HV_COLOR_U8 = 1, HV_COLOR_F32 = 2 } hv_color_dtype;
 typedef enum hv_depth_dtype { HV_DEPTH_F32 = 0, HV_DEPTH_U16 = 1 } hv_depth_dtype;
@@ -122,7 +127,8 @@ int hv_get_voxels_in_frustum(hv_volume *v, const float *intr_f32, int32_t width,
                              const double *T_cw, float depth_max, float depth_min, int32_t min_count,
                              float min_confidence, float *points, float *colors, int64_t cap,
                              int64_t *n, int32_t loc);
-/* carve(camera_frustrum, depth_image f32 HxW, depth_threshold) (voxel_grid_carving.h:47-79). */
+/* carve(camera_frustrum, depth_image f32 HxW, depth_threshold) (voxel_grid_carving.h:47-79); VOXEL_GRID and both
+ * semantic modes. */
 int hv_carve(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw,
              float depth_max, float depth_min, const float *depth, float depth_threshold, int32_t loc);
 int hv_remove_low_count_voxels(hv_volume *v, int32_t min_count); /* voxel_block_grid.hpp:625-646 */
@@ -138,13 +144,20 @@ int hv_dump_blocks(hv_volume *v, int32_t *keys, uint64_t *hashes, int32_t *count
 int hv_keys_from_points(hv_volume *v, const float *points, int64_t n, int32_t *voxel_keys,
                         int32_t *block_keys, int32_t *local_keys, uint64_t *block_hashes);
 
-/* ---- VOXEL_SEMANTIC_GRID mode: voting semantic payload (VoxelSemanticData, voxel_data_semantic.h:106-202)
- * hv_integrate_points_semantic == VoxelBlockSemanticGrid.integrate(points f32|f64 [N,3], colors u8|f32,
- *   class_ids i32 [N] | None, instance_ids i32 [N] | None, depths f32 [N] | None)
+/* ---- semantic block grids ------------------------------------------------------------------------
+ * HV_MODE_VOXEL_SEMANTIC_GRID               == volumetric.VoxelBlockSemanticGrid (voting payload,
+ *                                              VoxelSemanticData, voxel_data_semantic.h:106-202)
+ * HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID == volumetric.VoxelBlockSemanticProbabilisticGrid (log-probability
+ *                                              payload, VoxelSemanticDataProbabilistic, voxel_data_semantic.h:249-672)
+ * (bindings: cpp/volumetric/volumetric_grid_module.h:939-1033; class: voxel_block_semantic_grid.h:57-121).
+ *
+ * hv_integrate_points_semantic == .integrate(points f32|f64 [N,3], colors u8|f32, class_ids i32 [N] | None,
+ *   instance_ids i32 [N] | None, depths f32 [N] | None)
  *   (volumetric_grid_module.h:131-467 -> integrate_raw -> update_voxel_direct, voxel_block_grid.hpp:524-614).
  *   point_dtype: 0 float32, 1 float64 (keys follow get_voxel_key_inv<Tpos,Tpos>).  Labels, confidence
- *   counters, counts and float64 position sums are bit-identical to the reference's sequential order.
- *   Not provided: segment operations, instance->object association, the probabilistic payload. */
+ *   counters / log-probabilities, counts and float64 position sums are bit-identical to the reference's
+ *   sequential (point-index) order.  The probabilistic payload keeps at most 7 distinct (object, class) labels per
+ *   voxel; further labels are dropped and counted (hv_label_overflows). */
 int hv_integrate_points_semantic(hv_volume *v, const void *points, int32_t point_dtype, int64_t n, const void *colors,
                                  int32_t color_dtype, const int32_t *class_ids, const int32_t *instance_ids,
                                  const float *depths, int32_t loc);
@@ -153,12 +166,54 @@ int hv_integrate_points_semantic(hv_volume *v, const void *points, int32_t point
  * confidences f32 [M] (host).  points == NULL: size query. */
 int hv_get_voxels_semantic(hv_volume *v, int32_t min_count, float min_confidence, double *points, float *colors,
                            int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap, int64_t *n);
-/* set_depth_threshold(): observations with depth >= threshold do not vote (voxel_data_semantic.h:107,168-198). */
+/* set_depth_threshold() (voxel_block_semantic_grid.hpp:24-30): voting: observations with depth >= threshold do
+ * not vote (voxel_data_semantic.h:168-198); probabilistic: beyond it the evidence decays (:337-352).  Defaults
+ * 10 m / 5 m.  The reference keeps these as process-wide statics; here they are per volume. */
 int hv_set_depth_threshold(hv_volume *v, float depth_threshold);
+/* set_depth_decay_rate() (voxel_block_semantic_grid.hpp:32-37), probabilistic payload; default 0.07 1/m. */
+int hv_set_depth_decay_rate(hv_volume *v, float depth_decay_rate);
+int hv_label_overflows(hv_volume *v, int64_t *n);
+/* assign_object_ids_to_instance_ids(camera_frustrum, class_ids_image i32 HxW, semantic_instances_image i32 HxW,
+ * depth_image f32 HxW | NULL, depth_threshold, do_carving, min_vote_ratio, min_votes)
+ * (voxel_semantic_data_association.h:70-373).  Returns the instance -> object map sorted by instance id in
+ * map_inst / map_obj (host, at most cap entries; *n_map = full size).  Mutates the volume (carving, object ids of
+ * voxels that had none) exactly once per call: there is no size-query mode, pass cap >= the number of distinct
+ * instance ids in the image.  New object ids come from a process-wide counter (hv_peek/set_next_object_id). */
+int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw,
+                                         float depth_max, float depth_min, const int32_t *class_ids_image,
+                                         const int32_t *instance_ids_image, const float *depth_image, float depth_threshold,
+                                         int32_t do_carving, float min_vote_ratio, int32_t min_votes, int32_t *map_inst,
+                                         int32_t *map_obj, int64_t cap, int64_t *n_map, int32_t loc);
+int32_t hv_peek_next_object_id(void); /* VoxelSemanticSharedData::next_object_id, voxel_semantic_shared_data.h:26-34 */
+void hv_set_next_object_id(int32_t id);
+/* remap_instance_ids(instance_ids i32 HxW, map) (image_utils.h:69-163): ids absent from the map (or an empty map)
+ * become -1. */
+int hv_remap_instance_ids(hv_volume *v, const int32_t *instance_ids, int32_t height, int32_t width, const int32_t *map_inst,
+                          const int32_t *map_obj, int64_t n_map, int32_t *out, int32_t loc);
+/* get_object_segments(min_count, min_confidence) (voxel_block_semantic_grid.hpp:217-267): voxels with
+ * count > min_count (strict, as the reference), confidence >= min_confidence and object id >= 0, grouped by object
+ * id.  _compute runs the query and caches the result on the host; _fetch copies it out: points f64 [R,3] and
+ * colors f32 [R,3] grouped by ascending object id, row_object_ids i32 [R]; per object: object_ids i32 [O,3] =
+ * {object_id, class_id, n_points}, confidences f32 [O,2] = {min, max}, obbs f64 [O,10] = {center xyz, quaternion
+ * wxyz, size xyz} = OrientedBoundingBox3D::compute_from_points(PCA) (bounding_boxes_3d.cpp:373-553).  Any pointer
+ * may be NULL. */
+int hv_object_segments_compute(hv_volume *v, int32_t min_count, float min_confidence, int64_t *n_rows, int64_t *n_objects);
+int hv_object_segments_fetch(hv_volume *v, double *points, float *colors, int32_t *row_object_ids, int32_t *object_ids,
+                             float *confidences, double *obbs);
+int hv_compute_obb_pca(const double *points, int64_t n, double *obb);
+/* merge_segments / remove_segment / remove_low_confidence_segments (voxel_block_semantic_grid.hpp:119-196) and
+ * remove_low_confidence_voxels (voxel_block_grid.hpp:650-676; a no-op on non-semantic volumes). */
+int hv_merge_segments(hv_volume *v, int32_t instance_id1, int32_t instance_id2);
+int hv_remove_segment(hv_volume *v, int32_t object_id);
+int hv_remove_low_confidence_segments(hv_volume *v, int32_t min_confidence);
+int hv_remove_low_confidence_voxels(hv_volume *v, float min_confidence);
 /* Parity/debug export, key-sorted: keys [B,3]; ints [B,bs^3,4] {count, object_id, class_id, confidence_counter};
- * pos_sums [B,bs^3,3] f64; col_sums [B,bs^3,3] f32. */
+ * pos_sums [B,bs^3,3] f64; col_sums [B,bs^3,3] f32.  The second form adds conf [B,bs^3] f32 and, for the
+ * probabilistic payload, label_counts [B,bs^3], labels [B,bs^3,7,2] {object, class} and log_probs [B,bs^3,7]. */
 int hv_dump_blocks_semantic(hv_volume *v, int32_t *keys, int32_t *ints, double *pos_sums, float *col_sums,
                             int64_t *n_blocks);
+int hv_dump_blocks_semantic2(hv_volume *v, int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums,
+                             int32_t *label_counts, int32_t *labels, float *log_probs, int64_t *n_blocks);
 
 /* ---- TSDF mode ---------------------------------------------------------------------------------
  * hv_tsdf_integrate == RGBDImage.create_from_color_and_depth(color, depth, depth_scale,

@@ -18,6 +18,7 @@ _pi32 = _c.POINTER(_c.c_int32)
 HV_OK = 0
 HV_MODE_VOXEL_GRID = 0
 HV_MODE_VOXEL_SEMANTIC_GRID = 1
+HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID = 2
 HV_MODE_TSDF = 3
 HV_HOST, HV_DEVICE = 0, 1
 HV_COLOR_NONE, HV_COLOR_U8, HV_COLOR_F32 = 0, 1, 2
@@ -68,6 +69,21 @@ SIGNATURES = {
     "hv_get_voxels_semantic": (_i32, [_vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _pi64]),
     "hv_set_depth_threshold": (_i32, [_vp, _f32]),
     "hv_dump_blocks_semantic": (_i32, [_vp, _vp, _vp, _vp, _vp, _pi64]),
+    "hv_dump_blocks_semantic2": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi64]),
+    "hv_set_depth_decay_rate": (_i32, [_vp, _f32]),
+    "hv_label_overflows": (_i32, [_vp, _pi64]),
+    "hv_assign_object_ids_to_instance_ids": (_i32, [_vp, _vp, _i32, _i32, _vp, _f32, _f32, _vp, _vp, _vp, _f32, _i32, _f32, _i32,
+                                                    _vp, _vp, _i64, _pi64, _i32]),
+    "hv_peek_next_object_id": (_i32, []),
+    "hv_set_next_object_id": (None, [_i32]),
+    "hv_remap_instance_ids": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _i32]),
+    "hv_object_segments_compute": (_i32, [_vp, _i32, _f32, _pi64, _pi64]),
+    "hv_object_segments_fetch": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hv_compute_obb_pca": (_i32, [_vp, _i64, _vp]),
+    "hv_merge_segments": (_i32, [_vp, _i32, _i32]),
+    "hv_remove_segment": (_i32, [_vp, _i32]),
+    "hv_remove_low_confidence_segments": (_i32, [_vp, _i32]),
+    "hv_remove_low_confidence_voxels": (_i32, [_vp, _f32]),
     "hv_tsdf_integrate": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_tsdf_integrate_batch": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_tsdf_set_tile": (_i32, [_vp, _i32, _i32, _i32, _i32]),

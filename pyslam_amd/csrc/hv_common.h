@@ -103,6 +103,8 @@ enum {
     HV_CNT_TOUCH1 = 4,   // ... parity 1
     HV_CNT_OUT = 5,      // output row counter (compaction kernels)
     HV_CNT_OUT2 = 6,     // second output counter (triangles)
+    HV_CNT_LABEL_OVERFLOW = 7, // probabilistic payload: label observations dropped (voxel already holds HV_PROB_K labels)
+    HV_CNT_AUX = 8,      // scratch counter (association pending list)
     HV_CNT_COUNT = 16
 };
 
@@ -242,6 +244,10 @@ struct hv_volume {
     int32_t tile[4] = {0, 0, 0, 0}; // u0, v0, u1, v1; all zero = whole image
     int32_t owner_rank = 0, owner_world = 1; // hv_tsdf_set_owner
     float sem_depth_threshold = 10.0f;       // VoxelSemanticDataT::kDepthThreshold (hv_set_depth_threshold)
+    float sem_depth_decay_rate = 0.07f;      // VoxelSemanticDataProbabilisticT::kDepthDecayRate (hv_set_depth_decay_rate)
+    void *assoc_buf = nullptr;               // association vote table + pending list (hv_semantic_ops.hip)
+    size_t assoc_buf_bytes = 0;
+    void *segments_cache = nullptr;          // host-side result of hv_object_segments_compute (HvSegmentsCache*)
 
     // staging for HV_HOST inputs
     void *stage_a = nullptr;
@@ -276,3 +282,4 @@ int hv_stage_in(hv_volume *v, const void *src, size_t bytes, int32_t loc, int wh
 void hv_profile_begin(hv_volume *v);
 void hv_profile_end(hv_volume *v, int64_t units);
 void hv_invert4x4(const double *m, double *out);
+void hv_segments_cache_free(void *cache); // hv_semantic_ops.hip

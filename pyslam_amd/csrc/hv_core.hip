@@ -140,7 +140,7 @@ void hv_default_config(int32_t mode, hv_config *cfg) {
 
 int hv_create(const hv_config *cfg, hv_volume **out) {
     HV_REQUIRE(cfg != nullptr && out != nullptr, HV_ERR_INVALID, "hv_create: null argument");
-    HV_REQUIRE(cfg->mode == HV_MODE_VOXEL_GRID || cfg->mode == HV_MODE_VOXEL_SEMANTIC_GRID || cfg->mode == HV_MODE_TSDF, HV_ERR_INVALID,
+    HV_REQUIRE(cfg->mode == HV_MODE_VOXEL_GRID || cfg->mode == HV_MODE_VOXEL_SEMANTIC_GRID || cfg->mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID || cfg->mode == HV_MODE_TSDF, HV_ERR_INVALID,
                "hv_create: unsupported mode %d", cfg->mode);
     HV_REQUIRE(cfg->voxel_size > 0.0, HV_ERR_INVALID, "hv_create: voxel_size must be > 0");
     HV_REQUIRE(cfg->max_blocks > 0 && cfg->max_blocks < (1ll << 30), HV_ERR_INVALID,
@@ -189,7 +189,9 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
 
     const int64_t nvox = (int64_t)cfg->block_size * cfg->block_size * cfg->block_size;
     v->bytes_per_block = cfg->mode == HV_MODE_TSDF ? nvox * 4 * HV_TSDF_PLANES
-                         : cfg->mode == HV_MODE_VOXEL_SEMANTIC_GRID ? nvox * 64 /* HvSemVoxel */ : nvox * (int64_t)sizeof(HvVoxel);
+                         : cfg->mode == HV_MODE_VOXEL_SEMANTIC_GRID ? nvox * 64 /* HvSemVoxel */
+                         : cfg->mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID ? nvox * 128 /* HvProbVoxel */ : nvox * (int64_t)sizeof(HvVoxel);
+    if (cfg->mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID) v->sem_depth_threshold = 5.0f; // voxel_data_semantic.h:251-254
     v->local_bits = 0;
     while ((1ll << v->local_bits) < nvox) v->local_bits++;
 
@@ -240,10 +242,11 @@ void hv_destroy(hv_volume *v) {
                     v->touched_stamp, v->touched_list, v->touched_mask, v->frame_px,
                     v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                     v->sort_vals_out, v->sort_tmp, v->scratch_points, v->scratch_colors, v->out_a,
-                    v->out_b, v->out_c, v->batch_buf};
+                    v->out_b, v->out_c, v->batch_buf, v->assoc_buf};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (v->h_counters) (void)hipHostFree(v->h_counters);
+    hv_segments_cache_free(v->segments_cache);
     for (int i = 0; i < 4; ++i) {
         if (v->pinned_params[i]) (void)hipHostFree(v->pinned_params[i]);
         if (v->params_ev[i]) (void)hipEventDestroy(v->params_ev[i]);

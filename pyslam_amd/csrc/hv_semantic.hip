@@ -1,42 +1,28 @@
-// libpyslam_hipvol.so — VOXEL_SEMANTIC_GRID fusion: the *voting* semantic voxel payload of pySLAM's
-// cpp/volumetric (VoxelSemanticData = VoxelSemanticDataT<double,float>, voxel_data_semantic.h:106-202)
-// on the block hash, for gfx950.
+// libpyslam_hipvol.so — semantic block grids of pySLAM's cpp/volumetric on the GPU block hash (gfx950):
+//   VOXEL_SEMANTIC_GRID                = VoxelBlockSemanticGrid              (voting payload,
+//                                        VoxelSemanticData, voxel_data_semantic.h:106-202)
+//   VOXEL_SEMANTIC_PROBABILISTIC_GRID  = VoxelBlockSemanticProbabilisticGrid (log-probability payload,
+//                                        VoxelSemanticDataProbabilistic, voxel_data_semantic.h:249-672)
 //
-// Label fusion is order dependent (a conflicting observation decrements the confidence counter and
-// may switch the label, voxel_data_semantic.h:175-191), so — exactly as for the plain grid — points
+// Label fusion is order dependent in both payloads (voting: a conflicting observation decrements the
+// confidence counter and may switch the label, :175-191; probabilistic: float log-evidence sums and
+// the incremental arg-max with its tie rules, :358-417), so — exactly as for the plain grid — points
 // are grouped per voxel with a *stable* device radix sort and the head thread of every voxel run
-// folds its points in point-index order: labels, confidence counters, counts and the float64
+// folds its points in point-index order: labels, counters / log-probabilities, counts and the float64
 // position sums come out bit-identical to the reference's sequential branch.
 //
-// Record (64 B, two per 128-B line): {count, object_id+1, class_id+1, confidence_counter,
-// position_sum f64[3], color_sum f32[3], pad}.  Ids are stored +1 so that the all-zero pool means
-// "object -1 / class -1" (the reference's reset state) without per-block initialisation.
+// Records: voting 64 B {count, object_id+1, class_id+1, confidence_counter, position_sum f64[3],
+// color_sum f32[3], pad}; probabilistic 128 B with 7 inline label slots (hv_semantic.h).
 #include <algorithm>
 #include <array>
 #include <cmath>
 #include <numeric>
 
 #include "hv_common.h"
+#include "hv_semantic.h"
 #include <rocprim/device/device_radix_sort.hpp>
 
 static constexpr uint32_t HV_SORT_SENTINEL = 0xFFFFFFFFu;
-
-struct __attribute__((aligned(16))) HvSemVoxel {
-    int32_t count;
-    int32_t obj1; // object_id + 1
-    int32_t cls1; // class_id + 1
-    int32_t counter;
-    double pos[3];
-    float col[3];
-    float pad[3];
-};
-static_assert(sizeof(HvSemVoxel) == 64, "HvSemVoxel must be 64 bytes");
-
-struct HvSemParams {
-    float inv_voxel_size;
-    int32_t bs, nvox, local_bits;
-    float depth_threshold;
-};
 
 __host__ __device__ static inline int32_t sem_floor_div(int32_t a, int32_t b) {
     const int64_t aa = a, bb = b;
@@ -77,9 +63,9 @@ __global__ __launch_bounds__(256) void k_sem_keys(HvTable table, const PT *__res
 }
 
 // update_voxel_direct (voxel_block_grid.hpp:524-614) for a SemanticVoxelWithDepth payload, folded over
-// one voxel's run in point-index order.
-template <typename PT, int COLOR_KIND>
-__global__ __launch_bounds__(256) void k_sem_reduce(HvTable table, HvSemVoxel *__restrict__ pool,
+// one voxel's run in point-index order.  VOX = HvSemVoxel (voting) or HvProbVoxel (probabilistic).
+template <typename VOX, typename PT, int COLOR_KIND>
+__global__ __launch_bounds__(256) void k_sem_reduce(HvTable table, VOX *__restrict__ pool,
                                                      const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                      int64_t n, HvSemParams G, const PT *__restrict__ pts,
                                                      const void *__restrict__ cols, const int32_t *__restrict__ class_ids,
@@ -92,110 +78,108 @@ __global__ __launch_bounds__(256) void k_sem_reduce(HvTable table, HvSemVoxel *_
     if (i > 0 && keys[i - 1] == key) return;
     const int32_t idx = table.vals[(int32_t)(key >> G.local_bits)];
     if (idx < 0) return;
-    HvSemVoxel *vx = pool + (int64_t)idx * G.nvox + (key & ((1u << G.local_bits) - 1u));
-    HvSemVoxel acc = *vx;
+    VOX *vx = pool + (int64_t)idx * G.nvox + (key & ((1u << G.local_bits) - 1u));
+    int32_t count = vx->count;
+    double pos[3] = {vx->pos[0], vx->pos[1], vx->pos[2]};
+    float col[3] = {vx->col[0], vx->col[1], vx->col[2]};
     const float inv_255 = 1.0f / 255.0f;
     int64_t j = i;
     do {
         const int64_t p = vals[j];
-        acc.pos[0] += (double)pts[p * 3 + 0];
-        acc.pos[1] += (double)pts[p * 3 + 1];
-        acc.pos[2] += (double)pts[p * 3 + 2];
+        pos[0] += (double)pts[p * 3 + 0];
+        pos[1] += (double)pts[p * 3 + 1];
+        pos[2] += (double)pts[p * 3 + 2];
         if (COLOR_KIND == HV_COLOR_U8) {
             const uint8_t *c = (const uint8_t *)cols + p * 3;
-            acc.col[0] += (float)c[0] * inv_255;
-            acc.col[1] += (float)c[1] * inv_255;
-            acc.col[2] += (float)c[2] * inv_255;
+            col[0] += (float)c[0] * inv_255;
+            col[1] += (float)c[1] * inv_255;
+            col[2] += (float)c[2] * inv_255;
         } else if (COLOR_KIND == HV_COLOR_F32) {
             const float *c = (const float *)cols + p * 3;
-            acc.col[0] += c[0];
-            acc.col[1] += c[1];
-            acc.col[2] += c[2];
+            col[0] += c[0];
+            col[1] += c[1];
+            col[2] += c[2];
         }
         if (class_ids != nullptr) {
-            const int32_t obj1 = (instance_ids ? instance_ids[p] : 0) + 1;
-            const int32_t cls1 = class_ids[p] + 1;
-            const bool gate = depths ? (depths[p] < G.depth_threshold) : true; // *_with_depth, voxel_data_semantic.h:168-198
-            if (acc.count == 0) {
-                if (gate) { // initialize_semantics
-                    acc.obj1 = obj1;
-                    acc.cls1 = cls1;
-                    acc.counter = 1;
-                }
-            } else if (gate) { // update_semantics
-                if (acc.obj1 == obj1 && acc.cls1 == cls1) {
-                    acc.counter++;
-                } else {
-                    acc.counter--;
-                    if (acc.counter <= 0) {
-                        acc.obj1 = obj1;
-                        acc.cls1 = cls1;
-                        acc.counter = 1;
+            const int32_t obj = instance_ids ? instance_ids[p] : 0;
+            const int32_t cls = class_ids[p];
+            if constexpr (sizeof(VOX) == sizeof(HvSemVoxel)) {
+                HvSemVoxel *sv = (HvSemVoxel *)vx;
+                const bool gate = depths ? (depths[p] < G.depth_threshold) : true; // *_with_depth, voxel_data_semantic.h:168-198
+                if (count == 0) {
+                    if (gate) { // initialize_semantics
+                        sv->obj1 = obj + 1;
+                        sv->cls1 = cls + 1;
+                        sv->counter = 1;
+                    }
+                } else if (gate) { // update_semantics
+                    if (sv->obj1 == obj + 1 && sv->cls1 == cls + 1) {
+                        sv->counter++;
+                    } else {
+                        sv->counter--;
+                        if (sv->counter <= 0) {
+                            sv->obj1 = obj + 1;
+                            sv->cls1 = cls + 1;
+                            sv->counter = 1;
+                        }
                     }
                 }
+            } else {
+                const float lp = prob_observation_log_prob(depths != nullptr, depths ? depths[p] : 0.0f, G);
+                if (!prob_fold((HvProbVoxel *)vx, count == 0, obj, cls, lp)) atomicAdd(&table.counters[HV_CNT_LABEL_OVERFLOW], 1);
             }
         }
-        acc.count = acc.count == 0 ? 1 : acc.count + 1;
+        count = count == 0 ? 1 : count + 1;
         ++j;
     } while (j < n && keys[j] == key);
-    *vx = acc;
-}
-
-// get_confidence(), voxel_data_semantic.h:116-133
-__device__ __forceinline__ float sem_confidence(const HvSemVoxel &v) {
-    if (v.count == 0) return 0.0f;
-    const float r = (float)v.counter / (float)v.count;
-    return r < 1.0f ? r : 1.0f;
+    vx->count = count;
+    vx->pos[0] = pos[0];
+    vx->pos[1] = pos[1];
+    vx->pos[2] = pos[2];
+    vx->col[0] = col[0];
+    vx->col[1] = col[1];
+    vx->col[2] = col[2];
 }
 
 // get_voxels(min_count, min_confidence), voxel_block_grid.hpp:785-817 (semantic branch)
-__global__ __launch_bounds__(256) void k_sem_collect(HvTable table, const HvSemVoxel *__restrict__ pool, int64_t n_voxels,
+template <typename VOX>
+__global__ __launch_bounds__(256) void k_sem_collect(HvTable table, const VOX *__restrict__ pool, int64_t n_voxels,
                                                       int min_count, float min_confidence, double *__restrict__ out_pts,
                                                       float *__restrict__ out_cols, int32_t *__restrict__ out_cls,
                                                       int32_t *__restrict__ out_obj, float *__restrict__ out_conf, int64_t cap) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool pred = false;
-    HvSemVoxel v;
-    v.count = 0;
     float conf = 0.f;
+    const VOX *v = pool + (gid < n_voxels ? gid : 0);
+    int32_t count = 0;
     if (gid < n_voxels) {
-        v = pool[gid];
+        count = v->count;
         conf = sem_confidence(v);
-        pred = v.count >= min_count && conf >= min_confidence;
+        pred = count >= min_count && conf >= min_confidence;
     }
     const int32_t at = hv_wave_append(&table.counters[HV_CNT_OUT], pred);
     if (pred && at < cap && out_pts != nullptr) {
-        const double c = (double)v.count;
-        const float cf = (float)v.count;
+        const double c = (double)count;
+        const float cf = (float)count;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            out_pts[(int64_t)at * 3 + k] = v.pos[k] / c;
-            out_cols[(int64_t)at * 3 + k] = v.col[k] / cf;
+            out_pts[(int64_t)at * 3 + k] = v->pos[k] / c;
+            out_cols[(int64_t)at * 3 + k] = v->col[k] / cf;
         }
-        out_cls[at] = v.cls1 - 1;
-        out_obj[at] = v.obj1 - 1;
+        out_cls[at] = sem_class_id(v);
+        out_obj[at] = sem_object_id(v);
         out_conf[at] = conf;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-static HvSemParams sem_params(const hv_volume *v) {
-    HvSemParams G;
-    G.inv_voxel_size = 1.0f / (float)v->cfg.voxel_size;
-    G.bs = v->cfg.block_size;
-    G.nvox = G.bs * G.bs * G.bs;
-    G.local_bits = v->local_bits;
-    G.depth_threshold = v->sem_depth_threshold;
-    return G;
-}
-
 static int sem_sort_bits(const hv_volume *v) {
     int slot_bits = 0;
     while ((1ull << slot_bits) < v->table_capacity) slot_bits++;
     return std::min(32, slot_bits + v->local_bits + 1);
 }
 
-template <typename PT>
+template <typename VOX, typename PT>
 static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d_cols, int color_kind,
                          const int32_t *d_cls, const int32_t *d_inst, const float *d_depths) {
     const HvSemParams G = sem_params(v);
@@ -210,15 +194,15 @@ static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d
     bytes = v->sort_tmp_bytes;
     HV_HIP(rocprim::radix_sort_pairs(v->sort_tmp, bytes, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                                      v->sort_vals_out, (size_t)n, 0, sem_sort_bits(v), v->stream));
-    HvSemVoxel *pool = (HvSemVoxel *)v->pool;
+    VOX *pool = (VOX *)v->pool;
     if (color_kind == HV_COLOR_U8) {
-        hipLaunchKernelGGL((k_sem_reduce<PT, HV_COLOR_U8>), dim3(blocks), dim3(256), 0, v->stream, v->table, pool,
+        hipLaunchKernelGGL((k_sem_reduce<VOX, PT, HV_COLOR_U8>), dim3(blocks), dim3(256), 0, v->stream, v->table, pool,
                            v->sort_keys_out, v->sort_vals_out, n, G, d_pts, d_cols, d_cls, d_inst, d_depths);
     } else if (color_kind == HV_COLOR_F32) {
-        hipLaunchKernelGGL((k_sem_reduce<PT, HV_COLOR_F32>), dim3(blocks), dim3(256), 0, v->stream, v->table, pool,
+        hipLaunchKernelGGL((k_sem_reduce<VOX, PT, HV_COLOR_F32>), dim3(blocks), dim3(256), 0, v->stream, v->table, pool,
                            v->sort_keys_out, v->sort_vals_out, n, G, d_pts, d_cols, d_cls, d_inst, d_depths);
     } else {
-        hipLaunchKernelGGL((k_sem_reduce<PT, HV_COLOR_NONE>), dim3(blocks), dim3(256), 0, v->stream, v->table, pool,
+        hipLaunchKernelGGL((k_sem_reduce<VOX, PT, HV_COLOR_NONE>), dim3(blocks), dim3(256), 0, v->stream, v->table, pool,
                            v->sort_keys_out, v->sort_vals_out, n, G, d_pts, d_cols, d_cls, d_inst, d_depths);
     }
     HV_HIP(hipGetLastError());
@@ -242,6 +226,45 @@ static int sem_stage(hv_volume *v, const void *src, size_t bytes, int32_t loc, c
     return HV_OK;
 }
 
+template <typename VOX>
+static int sem_dump(hv_volume *v, int64_t nb, const std::vector<int64_t> &order, const std::vector<std::array<int32_t, 3>> &xyz,
+                    int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums, int32_t *label_counts,
+                    int32_t *labels, float *log_probs) {
+    const int nvox = sem_params(v).nvox;
+    std::vector<VOX> host((size_t)nb * nvox);
+    HV_HIP(hipMemcpy(host.data(), v->pool, sizeof(VOX) * host.size(), hipMemcpyDeviceToHost));
+    for (int64_t o = 0; o < nb; ++o) {
+        const int64_t i = order[o];
+        if (keys) memcpy(keys + o * 3, xyz[i].data(), 12);
+        for (int l = 0; l < nvox; ++l) {
+            const VOX *x = &host[(size_t)i * nvox + l];
+            const size_t at = (size_t)o * nvox + l;
+            if (ints) {
+                int32_t *d = ints + at * 4;
+                d[0] = x->count; d[1] = sem_object_id(x); d[2] = sem_class_id(x); d[3] = sem_confidence_counter(x);
+            }
+            if (conf) conf[at] = sem_confidence(x);
+            if (pos_sums) memcpy(pos_sums + at * 3, x->pos, 24);
+            if (col_sums) memcpy(col_sums + at * 3, x->col, 12);
+            if constexpr (sizeof(VOX) == sizeof(HvProbVoxel)) {
+                const HvProbVoxel *p = (const HvProbVoxel *)x;
+                const int nlab = prob_nlab(p->meta);
+                if (label_counts) label_counts[at] = nlab;
+                for (int k = 0; k < HV_PROB_K; ++k) {
+                    if (labels) {
+                        labels[(at * HV_PROB_K + k) * 2 + 0] = k < nlab ? p->obj[k] : -1;
+                        labels[(at * HV_PROB_K + k) * 2 + 1] = k < nlab ? p->cls[k] : -1;
+                    }
+                    if (log_probs) log_probs[at * HV_PROB_K + k] = k < nlab ? p->logp[k] : 0.0f;
+                }
+            } else if (label_counts) {
+                label_counts[at] = 0;
+            }
+        }
+    }
+    return HV_OK;
+}
+
 extern "C" {
 
 int hv_set_depth_threshold(hv_volume *v, float depth_threshold) {
@@ -250,12 +273,25 @@ int hv_set_depth_threshold(hv_volume *v, float depth_threshold) {
     return HV_OK;
 }
 
+int hv_set_depth_decay_rate(hv_volume *v, float depth_decay_rate) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_set_depth_decay_rate: null volume");
+    v->sem_depth_decay_rate = depth_decay_rate;
+    return HV_OK;
+}
+
+int hv_label_overflows(hv_volume *v, int64_t *n) {
+    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_label_overflows: null argument");
+    int rc = hv_read_counters(v);
+    if (rc != HV_OK) return rc;
+    *n = v->h_counters[HV_CNT_LABEL_OVERFLOW];
+    return HV_OK;
+}
+
 int hv_integrate_points_semantic(hv_volume *v, const void *points, int32_t point_dtype, int64_t n, const void *colors,
                                  int32_t color_dtype, const int32_t *class_ids, const int32_t *instance_ids,
                                  const float *depths, int32_t loc) {
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_integrate_points_semantic: null volume");
-    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID, HV_ERR_MODE,
-               "hv_integrate_points_semantic: volume is not in VOXEL_SEMANTIC_GRID mode");
+    HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_integrate_points_semantic: volume is not a semantic grid");
     if (n == 0) return HV_OK;
     HV_REQUIRE(points != nullptr && n > 0, HV_ERR_INVALID, "points must be a contiguous Nx3 array");
     HV_REQUIRE(point_dtype == 0 || point_dtype == 1, HV_ERR_INVALID, "points must be float32 or float64");
@@ -281,18 +317,25 @@ int hv_integrate_points_semantic(hv_volume *v, const void *points, int32_t point
     if (rc == HV_OK) rc = sem_stage(v, instance_ids, 4 * (size_t)n, loc, cursor, &d_inst);
     if (rc == HV_OK) rc = sem_stage(v, depths, 4 * (size_t)n, loc, cursor, &d_dep);
     if (rc != HV_OK) return rc;
-    if (point_dtype == 1)
-        return sem_integrate<double>(v, (const double *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
-                                     (const int32_t *)d_inst, (const float *)d_dep);
-    return sem_integrate<float>(v, (const float *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
-                                (const int32_t *)d_inst, (const float *)d_dep);
+    const bool prob = v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID;
+    if (point_dtype == 1) {
+        if (prob)
+            return sem_integrate<HvProbVoxel, double>(v, (const double *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
+                                                      (const int32_t *)d_inst, (const float *)d_dep);
+        return sem_integrate<HvSemVoxel, double>(v, (const double *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
+                                                 (const int32_t *)d_inst, (const float *)d_dep);
+    }
+    if (prob)
+        return sem_integrate<HvProbVoxel, float>(v, (const float *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
+                                                 (const int32_t *)d_inst, (const float *)d_dep);
+    return sem_integrate<HvSemVoxel, float>(v, (const float *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
+                                            (const int32_t *)d_inst, (const float *)d_dep);
 }
 
 int hv_get_voxels_semantic(hv_volume *v, int32_t min_count, float min_confidence, double *points, float *colors,
                            int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap, int64_t *n) {
     HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_get_voxels_semantic: null argument");
-    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID, HV_ERR_MODE,
-               "hv_get_voxels_semantic: volume is not in VOXEL_SEMANTIC_GRID mode");
+    HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_get_voxels_semantic: volume is not a semantic grid");
     HV_HIP(hipSetDevice(v->device));
     int64_t nb = 0;
     int rc = hv_num_blocks(v, &nb);
@@ -314,9 +357,13 @@ int hv_get_voxels_semantic(hv_volume *v, int32_t min_count, float min_confidence
         d_conf = (float *)(d_obj + cap);
     }
     HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
-    hipLaunchKernelGGL(k_sem_collect, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, v->table,
-                       (const HvSemVoxel *)v->pool, total, min_count, min_confidence, d_pts, d_cols, d_cls, d_obj, d_conf,
-                       want ? cap : 0);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID)
+        hipLaunchKernelGGL(k_sem_collect<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvProbVoxel *)v->pool,
+                           total, min_count, min_confidence, d_pts, d_cols, d_cls, d_obj, d_conf, want ? cap : 0);
+    else
+        hipLaunchKernelGGL(k_sem_collect<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvSemVoxel *)v->pool,
+                           total, min_count, min_confidence, d_pts, d_cols, d_cls, d_obj, d_conf, want ? cap : 0);
     HV_HIP(hipGetLastError());
     rc = hv_read_counters(v);
     if (rc != HV_OK) return rc;
@@ -335,16 +382,15 @@ int hv_get_voxels_semantic(hv_volume *v, int32_t min_count, float min_confidence
     return HV_OK;
 }
 
-int hv_dump_blocks_semantic(hv_volume *v, int32_t *keys, int32_t *ints, double *pos_sums, float *col_sums,
-                            int64_t *n_blocks) {
+int hv_dump_blocks_semantic2(hv_volume *v, int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums,
+                             int32_t *label_counts, int32_t *labels, float *log_probs, int64_t *n_blocks) {
     HV_REQUIRE(v != nullptr && n_blocks != nullptr, HV_ERR_INVALID, "hv_dump_blocks_semantic: null argument");
-    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID, HV_ERR_MODE, "hv_dump_blocks_semantic: wrong mode");
+    HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_dump_blocks_semantic: wrong mode");
     int64_t nb = 0;
     int rc = hv_num_blocks(v, &nb);
     if (rc != HV_OK) return rc;
     *n_blocks = nb;
-    if (nb == 0 || (!keys && !ints && !pos_sums && !col_sums)) return HV_OK;
-    const int nvox = sem_params(v).nvox;
+    if (nb == 0 || (!keys && !ints && !conf && !pos_sums && !col_sums && !label_counts && !labels && !log_probs)) return HV_OK;
     std::vector<uint64_t> bkeys((size_t)nb);
     HV_HIP(hipMemcpy(bkeys.data(), v->table.block_keys, sizeof(uint64_t) * nb, hipMemcpyDeviceToHost));
     std::vector<std::array<int32_t, 3>> xyz((size_t)nb);
@@ -352,22 +398,14 @@ int hv_dump_blocks_semantic(hv_volume *v, int32_t *keys, int32_t *ints, double *
     std::vector<int64_t> order((size_t)nb);
     std::iota(order.begin(), order.end(), 0);
     std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return xyz[a] < xyz[b]; });
-    std::vector<HvSemVoxel> host((size_t)nb * nvox);
-    HV_HIP(hipMemcpy(host.data(), v->pool, sizeof(HvSemVoxel) * host.size(), hipMemcpyDeviceToHost));
-    for (int64_t o = 0; o < nb; ++o) {
-        const int64_t i = order[o];
-        if (keys) memcpy(keys + o * 3, xyz[i].data(), 12);
-        for (int l = 0; l < nvox; ++l) {
-            const HvSemVoxel &x = host[(size_t)i * nvox + l];
-            if (ints) {
-                int32_t *d = ints + ((size_t)o * nvox + l) * 4;
-                d[0] = x.count; d[1] = x.obj1 - 1; d[2] = x.cls1 - 1; d[3] = x.counter;
-            }
-            if (pos_sums) memcpy(pos_sums + ((size_t)o * nvox + l) * 3, x.pos, 24);
-            if (col_sums) memcpy(col_sums + ((size_t)o * nvox + l) * 3, x.col, 12);
-        }
-    }
-    return HV_OK;
+    if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID)
+        return sem_dump<HvProbVoxel>(v, nb, order, xyz, keys, ints, conf, pos_sums, col_sums, label_counts, labels, log_probs);
+    return sem_dump<HvSemVoxel>(v, nb, order, xyz, keys, ints, conf, pos_sums, col_sums, label_counts, labels, log_probs);
+}
+
+int hv_dump_blocks_semantic(hv_volume *v, int32_t *keys, int32_t *ints, double *pos_sums, float *col_sums,
+                            int64_t *n_blocks) {
+    return hv_dump_blocks_semantic2(v, keys, ints, nullptr, pos_sums, col_sums, nullptr, nullptr, nullptr, n_blocks);
 }
 
 } // extern "C"

@@ -1,0 +1,888 @@
+// libpyslam_hipvol.so — operations of pySLAM's semantic block grids beyond integrate / get_voxels
+// (both payloads, gfx950):
+//   carve                                voxel_grid_carving.h:47-79 via iterate_voxels_in_camera_frustrum
+//                                        (voxel_block_grid.hpp:1335-1540)
+//   assign_object_ids_to_instance_ids    voxel_semantic_data_association.h:70-373
+//   remap_instance_ids                   image_utils.h:69-163
+//   get_object_segments (+ PCA OBB)      voxel_block_semantic_grid.hpp:217-267, bounding_boxes_3d.cpp:373-553
+//   merge_segments / remove_segment / remove_low_confidence_segments   voxel_block_semantic_grid.hpp:119-196
+//   remove_low_count_voxels / remove_low_confidence_voxels / size      voxel_block_grid.hpp:625-676, 1557-1572
+//
+// Association on the GPU: one thread per allocated voxel tests the frustum and the class / depth
+// gates, then votes (instance_id, object_id) into a small device hash with wave-aggregated atomics
+// (ballot + shuffle: one atomic per distinct pair per wave); voxels without an object id are appended
+// to a pending list (wave-ballot compaction).  The few distinct pairs go to the host, which applies
+// the reference's winner / min_votes / min_vote_ratio rules verbatim and hands the final
+// instance -> object table back for the pending voxels.  New object ids come from a process-wide
+// counter like the reference's (voxel_semantic_shared_data.h:26-34); they are assigned in ascending
+// instance-id order (the reference assigns them in its hash-map iteration order: same set of new
+// ids, possibly permuted between the instances that need one in the same call).
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <map>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "hv_common.h"
+#include "hv_query.h"
+#include "hv_semantic.h"
+#include <rocprim/device/device_radix_sort.hpp>
+
+static constexpr int32_t HV_OBJ_PENDING = INT32_MIN;  // vote cast by a voxel that waits for a new object id
+static constexpr int32_t HV_OBJ_SEEN = INT32_MIN + 1; // "this instance id occurs in the image" marker
+static constexpr uint32_t HV_VOTE_CAP = 1u << 16;     // vote-table slots (distinct (instance, object) pairs per frame)
+static constexpr uint64_t HV_VOTE_EMPTY = ~0ull;
+
+static std::atomic<int32_t> g_next_object_id{1}; // VoxelSemanticSharedData::next_object_id
+
+template <typename VOX> __device__ __forceinline__ void sem_reset(VOX *v) {
+    uint4 *q = (uint4 *)v;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(VOX) / 16); ++i) q[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// The visit predicate of iterate_voxels_in_camera_frustrum (min_count = 1, min_confidence = 0).
+template <typename VOX>
+__device__ __forceinline__ bool sem_visit(const HvQuery &Q, const HvTable &table, const VOX *v, int64_t b, int l,
+                                          const HvSemParams &G, float *uvd) {
+    const int32_t count = v->count;
+    if (count < 1) return false;
+    if (!(sem_confidence(v) >= 0.0f)) return false;
+    int32_t bk[3];
+    hv_unpack_key(table.block_keys[b], bk[0], bk[1], bk[2]);
+    const int32_t lc[3] = {l % G.bs, (l / G.bs) % G.bs, l / (G.bs * G.bs)};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (bk[a] < Q.bmin[a] || bk[a] > Q.bmax[a]) return false;
+        const int32_t vk = bk[a] * G.bs + lc[a];
+        if (vk < Q.vmin[a] || vk > Q.vmax[a]) return false;
+    }
+    const double c = (double)count;
+    return hv_frustum_contains_d(Q, v->pos[0] / c, v->pos[1] / c, v->pos[2] / c, uvd);
+}
+
+template <typename VOX>
+__global__ __launch_bounds__(256) void k_sem_carve(HvTable table, VOX *__restrict__ pool, int64_t n_blocks, HvSemParams G,
+                                                    HvQuery Q, const float *__restrict__ depth) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_blocks * G.nvox) return;
+    VOX *v = pool + gid;
+    float uvd[3];
+    if (!sem_visit(Q, table, v, gid / G.nvox, (int)(gid % G.nvox), G, uvd)) return;
+    const float image_depth = depth[(int64_t)(int)uvd[1] * Q.width + (int)uvd[0]];
+    if (image_depth <= 0.0f || !isfinite(image_depth)) return;
+    if (uvd[2] < image_depth - Q.carve_threshold) sem_reset(v);
+}
+
+// ---- association -------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t vote_key(int32_t inst, int32_t obj) {
+    return ((uint64_t)(uint32_t)inst << 32) | (uint64_t)(uint32_t)obj;
+}
+
+__device__ inline void vote_add(unsigned long long *__restrict__ vkeys, int32_t *__restrict__ vcounts, int32_t *overflow,
+                                uint64_t key, int32_t n) {
+    uint32_t s = hv_slot_hash(key) & (HV_VOTE_CAP - 1);
+    for (uint32_t probe = 0; probe < HV_VOTE_CAP; ++probe) {
+        unsigned long long k = vkeys[s];
+        if (k == HV_VOTE_EMPTY) {
+            k = atomicCAS(&vkeys[s], HV_VOTE_EMPTY, (unsigned long long)key);
+            if (k == HV_VOTE_EMPTY) k = key;
+        }
+        if (k == key) {
+            atomicAdd(&vcounts[s], n);
+            return;
+        }
+        s = (s + 1) & (HV_VOTE_CAP - 1);
+    }
+    atomicAdd(overflow, 1);
+}
+
+// every lane with key != EMPTY votes once; one atomic per distinct key per wave
+__device__ __forceinline__ void vote_wave(unsigned long long *__restrict__ vkeys, int32_t *__restrict__ vcounts,
+                                          int32_t *overflow, uint64_t key) {
+    const int lane = hv_lane_id();
+    unsigned long long remaining = __ballot(key != HV_VOTE_EMPTY);
+    while (remaining) {
+        const int first = __ffsll((long long)remaining) - 1;
+        const unsigned long long fkey = __shfl((unsigned long long)key, first);
+        const unsigned long long same = __ballot(key == fkey);
+        if (lane == first) vote_add(vkeys, vcounts, overflow, fkey, (int32_t)__popcll(same));
+        remaining &= ~same;
+    }
+}
+
+struct HvAssocParams {
+    int32_t use_depth, do_carving;
+    float depth_threshold;
+    int32_t pending_cap;
+};
+
+// process_point, voxel_semantic_data_association.h:190-246
+template <typename VOX>
+__global__ __launch_bounds__(256) void k_sem_assoc_vote(HvTable table, VOX *__restrict__ pool, int64_t n_blocks,
+                                                         HvSemParams G, HvQuery Q, const int32_t *__restrict__ cls_img,
+                                                         const int32_t *__restrict__ inst_img,
+                                                         const float *__restrict__ depth, HvAssocParams A,
+                                                         unsigned long long *__restrict__ vkeys,
+                                                         int32_t *__restrict__ vcounts, int2 *__restrict__ pending) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t key = HV_VOTE_EMPTY;
+    bool is_pending = false;
+    int32_t inst = -1;
+    if (gid < n_blocks * G.nvox) {
+        VOX *v = pool + gid;
+        float uvd[3];
+        if (sem_visit(Q, table, v, gid / G.nvox, (int)(gid % G.nvox), G, uvd)) {
+            const int64_t px = (int64_t)(int)uvd[1] * Q.width + (int)uvd[0];
+            const int32_t image_class = cls_img[px];
+            const int32_t point_class = sem_class_id(v);
+            inst = inst_img[px];
+            bool go = image_class >= 0 && point_class >= 0 && point_class == image_class && inst >= 0;
+            if (go && A.use_depth) {
+                const float image_depth = depth[px];
+                if (image_depth <= 0.0f || !isfinite(image_depth)) {
+                    go = false;
+                } else if (A.do_carving && uvd[2] < image_depth - A.depth_threshold) {
+                    sem_reset(v);
+                    go = false;
+                } else if (uvd[2] > image_depth + A.depth_threshold) {
+                    go = false;
+                }
+            }
+            if (go) {
+                int32_t obj = sem_object_id(v);
+                if (obj < 0) {
+                    if (inst == 0) {
+                        obj = 0;
+                        sem_set_object_id(v, 0);
+                    } else {
+                        obj = HV_OBJ_PENDING;
+                        is_pending = true;
+                    }
+                }
+                key = vote_key(inst, obj);
+            }
+        }
+    }
+    vote_wave(vkeys, vcounts, &table.counters[HV_CNT_OUT2], key);
+    const int32_t at = hv_wave_append(&table.counters[HV_CNT_AUX], is_pending);
+    if (is_pending && at < A.pending_cap) pending[at] = make_int2((int32_t)gid, inst);
+}
+
+// the image scan of voxel_semantic_data_association.h:316-331: every instance id with a valid class
+__global__ __launch_bounds__(256) void k_sem_assoc_image(HvTable table, const int32_t *__restrict__ cls_img,
+                                                          const int32_t *__restrict__ inst_img, int64_t n_px,
+                                                          unsigned long long *__restrict__ vkeys,
+                                                          int32_t *__restrict__ vcounts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t key = HV_VOTE_EMPTY;
+    if (i < n_px) {
+        const int32_t inst = inst_img[i];
+        if (inst >= 0 && cls_img[i] >= 0) key = vote_key(inst, HV_OBJ_SEEN);
+    }
+    vote_wave(vkeys, vcounts, &table.counters[HV_CNT_OUT2], key);
+}
+
+__global__ __launch_bounds__(256) void k_sem_assoc_compact(HvTable table, const unsigned long long *__restrict__ vkeys,
+                                                            const int32_t *__restrict__ vcounts,
+                                                            unsigned long long *__restrict__ out_keys,
+                                                            int32_t *__restrict__ out_counts) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool pred = s < HV_VOTE_CAP && vkeys[s] != HV_VOTE_EMPTY;
+    const int32_t at = hv_wave_append(&table.counters[HV_CNT_OUT], pred);
+    if (pred) {
+        out_keys[at] = vkeys[s];
+        out_counts[at] = vcounts[s];
+    }
+}
+
+__device__ __forceinline__ int32_t map_lookup(const int32_t *__restrict__ map_inst, const int32_t *__restrict__ map_obj,
+                                              int32_t n_map, int32_t inst, int32_t missing) {
+    int lo = 0, hi = n_map - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int32_t k = map_inst[mid];
+        if (k == inst) return map_obj[mid];
+        if (k < inst) lo = mid + 1;
+        else hi = mid - 1;
+    }
+    return missing;
+}
+
+// deferred set_object_id of the voxels that waited for the vote, voxel_semantic_data_association.h:344-361
+template <typename VOX>
+__global__ __launch_bounds__(256) void k_sem_assoc_apply(VOX *__restrict__ pool, const int2 *__restrict__ pending,
+                                                          int32_t n_pending, const int32_t *__restrict__ map_inst,
+                                                          const int32_t *__restrict__ map_obj, int32_t n_map) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pending) return;
+    const int2 p = pending[i];
+    const int32_t final_id = map_lookup(map_inst, map_obj, n_map, p.y, -1);
+    if (final_id >= 0) sem_set_object_id(pool + p.x, final_id);
+}
+
+__global__ __launch_bounds__(256) void k_remap_instance_ids(const int32_t *__restrict__ in, int64_t n,
+                                                             const int32_t *__restrict__ map_inst,
+                                                             const int32_t *__restrict__ map_obj, int32_t n_map,
+                                                             int32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = n_map > 0 ? map_lookup(map_inst, map_obj, n_map, in[i], -1) : -1;
+}
+
+// ---- segments ------------------------------------------------------------------------------------
+template <typename VOX>
+__global__ __launch_bounds__(256) void k_seg_collect(HvTable table, const VOX *__restrict__ pool, int64_t n_voxels,
+                                                      int min_count, float min_confidence,
+                                                      unsigned long long *__restrict__ out_keys, int64_t cap) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool pred = false;
+    int32_t obj = -1;
+    if (gid < n_voxels) {
+        const VOX *v = pool + gid;
+        // NB: strict '>' on the count, voxel_block_semantic_grid.hpp:224
+        if (v->count > min_count && sem_confidence(v) >= min_confidence) {
+            obj = sem_object_id(v);
+            pred = obj >= 0;
+        }
+    }
+    const int32_t at = hv_wave_append(&table.counters[HV_CNT_OUT], pred);
+    if (pred && at < cap && out_keys != nullptr) out_keys[at] = ((unsigned long long)(uint32_t)obj << 32) | (unsigned long long)(uint32_t)gid;
+}
+
+template <typename VOX>
+__global__ __launch_bounds__(256) void k_seg_rows(const VOX *__restrict__ pool, const unsigned long long *__restrict__ keys,
+                                                   int64_t n, double *__restrict__ out_pts, float *__restrict__ out_cols,
+                                                   int32_t *__restrict__ out_obj, int32_t *__restrict__ out_cls,
+                                                   float *__restrict__ out_conf) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    const VOX *v = pool + (uint32_t)(k & 0xffffffffull);
+    const double c = (double)v->count;
+    const float cf = (float)v->count;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        out_pts[i * 3 + a] = v->pos[a] / c;
+        out_cols[i * 3 + a] = v->col[a] / cf;
+    }
+    out_obj[i] = (int32_t)(k >> 32);
+    out_cls[i] = sem_class_id(v);
+    out_conf[i] = sem_confidence(v);
+}
+
+// op 0 merge_segments(a <- b), 1 remove_segment(a), 2 remove_low_confidence_segments(int a),
+// 3 remove_low_count_voxels(a), 4 remove_low_confidence_voxels(fa)
+template <typename VOX>
+__global__ __launch_bounds__(256) void k_sem_segment_op(VOX *__restrict__ pool, int64_t n_voxels, int op, int32_t a, int32_t b,
+                                                         float fa) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_voxels) return;
+    VOX *v = pool + gid;
+    if (op == 0) {
+        if (sem_object_id(v) == b) sem_set_object_id(v, a);
+    } else if (op == 1) {
+        if (sem_object_id(v) == a) sem_reset(v);
+    } else if (op == 2) {
+        if (sem_confidence(v) < (float)a) sem_reset(v);
+    } else if (op == 3) {
+        if (v->count < a) sem_reset(v);
+    } else if (op == 4) {
+        if (sem_confidence(v) < fa) sem_reset(v);
+    }
+}
+
+template <typename VOX>
+__global__ __launch_bounds__(256) void k_sem_count_nonempty(HvTable table, const VOX *__restrict__ pool, int64_t n_voxels) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool pred = gid < n_voxels && pool[gid].count > 0;
+    (void)hv_wave_append(&table.counters[HV_CNT_OUT], pred);
+}
+
+// ---- host: PCA oriented bounding box, bounding_boxes_3d.cpp:373-553 ------------------------------
+namespace {
+
+struct Vec3 {
+    double v[3];
+};
+
+void jacobi_eigen3(const double A[9], double evals[3], double evecs[9]) {
+    double a[3][3], q[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) a[r][c] = A[r * 3 + c];
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int r = p + 1; r < 3; ++r) {
+                if (a[p][r] == 0.0) continue;
+                const double theta = (a[r][r] - a[p][p]) / (2.0 * a[p][r]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = a[k][p], akr = a[k][r];
+                    a[k][p] = c * akp - s * akr;
+                    a[k][r] = s * akp + c * akr;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = a[p][k], ark = a[r][k];
+                    a[p][k] = c * apk - s * ark;
+                    a[r][k] = s * apk + c * ark;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double qkp = q[k][p], qkr = q[k][r];
+                    q[k][p] = c * qkp - s * qkr;
+                    q[k][r] = s * qkp + c * qkr;
+                }
+            }
+    }
+    for (int i = 0; i < 3; ++i) {
+        evals[i] = a[i][i];
+        for (int k = 0; k < 3; ++k) evecs[k * 3 + i] = q[k][i]; // column i = eigenvector i
+    }
+}
+
+// Eigen::Quaterniond(R) (rotation matrix -> quaternion), output {w, x, y, z}
+void quat_from_matrix(const double R[9], double q[4]) {
+    auto m = [&](int r, int c) { return R[r * 3 + c]; };
+    double t = m(0, 0) + m(1, 1) + m(2, 2);
+    if (t > 0.0) {
+        t = std::sqrt(t + 1.0);
+        q[0] = 0.5 * t;
+        t = 0.5 / t;
+        q[1] = (m(2, 1) - m(1, 2)) * t;
+        q[2] = (m(0, 2) - m(2, 0)) * t;
+        q[3] = (m(1, 0) - m(0, 1)) * t;
+    } else {
+        int i = 0;
+        if (m(1, 1) > m(0, 0)) i = 1;
+        if (m(2, 2) > m(i, i)) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0);
+        q[1 + i] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m(k, j) - m(j, k)) * t;
+        q[1 + j] = (m(j, i) + m(i, j)) * t;
+        q[1 + k] = (m(k, i) + m(i, k)) * t;
+    }
+}
+
+void cross3(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+double norm3(const double a[3]) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+
+// extents of the points in frame (c, R): fills center / size / quaternion of obb
+void obb_from_frame(const double *pts, int64_t n, const double c[3], double R[9], double *obb) {
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n; ++i) {
+        const double d[3] = {pts[i * 3] - c[0], pts[i * 3 + 1] - c[1], pts[i * 3 + 2] - c[2]};
+        for (int a = 0; a < 3; ++a) {
+            const double l = R[0 * 3 + a] * d[0] + R[1 * 3 + a] * d[1] + R[2 * 3 + a] * d[2]; // R^T d
+            mn[a] = std::min(mn[a], l);
+            mx[a] = std::max(mx[a], l);
+        }
+    }
+    double cl[3];
+    for (int a = 0; a < 3; ++a) {
+        obb[7 + a] = 2.0 * (0.5 * (mx[a] - mn[a]));
+        cl[a] = 0.5 * (mx[a] + mn[a]);
+    }
+    for (int r = 0; r < 3; ++r) obb[r] = c[r] + (R[r * 3 + 0] * cl[0] + R[r * 3 + 1] * cl[1] + R[r * 3 + 2] * cl[2]);
+    quat_from_matrix(R, obb + 3);
+}
+
+// compute_obb_pca_3d; obb = {center xyz, quaternion wxyz, size xyz}
+void compute_obb_pca(const double *pts, int64_t n, double *obb) {
+    for (int i = 0; i < 10; ++i) obb[i] = 0.0;
+    obb[3] = 1.0;
+    if (n == 0) return;
+    if (n == 1) {
+        obb[0] = pts[0]; obb[1] = pts[1]; obb[2] = pts[2];
+        return;
+    }
+    if (n == 2) {
+        double c[3], diff[3];
+        for (int a = 0; a < 3; ++a) {
+            c[a] = 0.5 * (pts[a] + pts[3 + a]);
+            diff[a] = pts[3 + a] - pts[a];
+        }
+        const double dn = norm3(diff);
+        if (dn < 1e-10) {
+            obb[0] = c[0]; obb[1] = c[1]; obb[2] = c[2];
+            return;
+        }
+        double a1[3] = {diff[0] / dn, diff[1] / dn, diff[2] / dn}, a2[3], a3[3];
+        const double ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0};
+        cross3(std::fabs(a1[0]) < 0.9 ? ex : ey, a1, a2);
+        double nn = norm3(a2);
+        for (int a = 0; a < 3; ++a) a2[a] /= nn;
+        cross3(a1, a2, a3);
+        nn = norm3(a3);
+        for (int a = 0; a < 3; ++a) a3[a] /= nn;
+        double R[9];
+        for (int r = 0; r < 3; ++r) { R[r * 3 + 0] = a1[r]; R[r * 3 + 1] = a2[r]; R[r * 3 + 2] = a3[r]; }
+        double c01[3];
+        cross3(a1, a2, c01);
+        if (c01[0] * a3[0] + c01[1] * a3[1] + c01[2] * a3[2] < 0.0)
+            for (int r = 0; r < 3; ++r) R[r * 3 + 2] = -R[r * 3 + 2];
+        obb_from_frame(pts, n, c, R, obb);
+        return;
+    }
+    // centroid and covariance in one pass (Welford)
+    double centroid[3] = {0, 0, 0}, cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t k = 0; k < n; ++k) {
+        double delta[3], delta2[3];
+        for (int a = 0; a < 3; ++a) delta[a] = pts[k * 3 + a] - centroid[a];
+        for (int a = 0; a < 3; ++a) centroid[a] += delta[a] / (double)(k + 1);
+        for (int a = 0; a < 3; ++a) delta2[a] = pts[k * 3 + a] - centroid[a];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) cov[r * 3 + c] += delta[r] * delta2[c];
+    }
+    for (int i = 0; i < 9; ++i) cov[i] /= (double)n;
+    // SelfAdjointEigenSolver reads the lower triangle: symmetrise from it
+    double sym[9] = {cov[0], cov[3], cov[6], cov[3], cov[4], cov[7], cov[6], cov[7], cov[8]};
+    double evals[3], evecs[9];
+    jacobi_eigen3(sym, evals, evecs);
+    // SelfAdjointEigenSolver returns ascending eigenvalues; the reference then sorts descending with a
+    // swap sort over {0,1,2}
+    int asc[3] = {0, 1, 2};
+    std::sort(asc, asc + 3, [&](int x, int y) { return evals[x] < evals[y]; });
+    double ev[3] = {evals[asc[0]], evals[asc[1]], evals[asc[2]]};
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (ev[order[j]] > ev[order[i]]) std::swap(order[i], order[j]);
+    double R[9];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) R[r * 3 + c] = evecs[r * 3 + asc[order[c]]];
+    const double c0[3] = {R[0], R[3], R[6]}, c1[3] = {R[1], R[4], R[7]}, c2[3] = {R[2], R[5], R[8]};
+    double cr[3];
+    cross3(c0, c1, cr);
+    if (cr[0] * c2[0] + cr[1] * c2[1] + cr[2] * c2[2] < 0.0)
+        for (int r = 0; r < 3; ++r) R[r * 3 + 2] = -R[r * 3 + 2];
+    obb_from_frame(pts, n, centroid, R, obb);
+}
+
+struct HvSegmentsCache {
+    std::vector<double> pts;
+    std::vector<float> cols;
+    std::vector<int32_t> row_obj;
+    std::vector<int32_t> ids;  // per object {object_id, class_id, n_points}
+    std::vector<float> conf;   // per object {min, max}
+    std::vector<double> obb;   // per object {center xyz, quaternion wxyz, size xyz}
+};
+
+template <typename VOX> int sem_launch_segment_op(hv_volume *v, int op, int32_t a, int32_t b, float fa) {
+    HV_HIP(hipSetDevice(v->device));
+    int64_t nb = 0;
+    int rc = hv_num_blocks(v, &nb);
+    if (rc != HV_OK) return rc;
+    if (nb == 0) return HV_OK;
+    const int64_t total = nb * sem_params(v).nvox;
+    hipLaunchKernelGGL(k_sem_segment_op<VOX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, (VOX *)v->pool,
+                       total, op, a, b, fa);
+    HV_HIP(hipGetLastError());
+    return HV_OK;
+}
+
+bool is_prob(const hv_volume *v) { return v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID; }
+
+} // namespace
+
+void hv_segments_cache_free(void *cache) { delete static_cast<HvSegmentsCache *>(cache); }
+
+int hv_sem_carve(hv_volume *v, const HvQuery &Q, const float *d_depth, int64_t nb) {
+    const HvSemParams G = sem_params(v);
+    const int64_t total = nb * G.nvox;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (is_prob(v))
+        hipLaunchKernelGGL(k_sem_carve<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, nb, G, Q, d_depth);
+    else
+        hipLaunchKernelGGL(k_sem_carve<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, nb, G, Q, d_depth);
+    HV_HIP(hipGetLastError());
+    return HV_OK;
+}
+
+int hv_sem_segment_op(hv_volume *v, int op, int32_t a, int32_t b, float fa) {
+    return is_prob(v) ? sem_launch_segment_op<HvProbVoxel>(v, op, a, b, fa) : sem_launch_segment_op<HvSemVoxel>(v, op, a, b, fa);
+}
+
+int hv_sem_size(hv_volume *v, int64_t *n) {
+    HV_HIP(hipSetDevice(v->device));
+    int64_t nb = 0;
+    int rc = hv_num_blocks(v, &nb);
+    if (rc != HV_OK) return rc;
+    *n = 0;
+    if (nb == 0) return HV_OK;
+    const int64_t total = nb * sem_params(v).nvox;
+    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (is_prob(v))
+        hipLaunchKernelGGL(k_sem_count_nonempty<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvProbVoxel *)v->pool, total);
+    else
+        hipLaunchKernelGGL(k_sem_count_nonempty<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvSemVoxel *)v->pool, total);
+    HV_HIP(hipGetLastError());
+    rc = hv_read_counters(v);
+    if (rc != HV_OK) return rc;
+    *n = v->h_counters[HV_CNT_OUT];
+    return HV_OK;
+}
+
+extern "C" {
+
+int32_t hv_peek_next_object_id(void) { return g_next_object_id.load(); }
+void hv_set_next_object_id(int32_t id) { g_next_object_id.store(id); }
+
+int hv_merge_segments(hv_volume *v, int32_t instance_id1, int32_t instance_id2) {
+    HV_REQUIRE(v != nullptr && hv_is_semantic(v), HV_ERR_MODE, "hv_merge_segments: not a semantic grid");
+    return hv_sem_segment_op(v, 0, instance_id1, instance_id2, 0.f);
+}
+int hv_remove_segment(hv_volume *v, int32_t object_id) {
+    HV_REQUIRE(v != nullptr && hv_is_semantic(v), HV_ERR_MODE, "hv_remove_segment: not a semantic grid");
+    return hv_sem_segment_op(v, 1, object_id, 0, 0.f);
+}
+int hv_remove_low_confidence_segments(hv_volume *v, int32_t min_confidence) {
+    HV_REQUIRE(v != nullptr && hv_is_semantic(v), HV_ERR_MODE, "hv_remove_low_confidence_segments: not a semantic grid");
+    return hv_sem_segment_op(v, 2, min_confidence, 0, 0.f);
+}
+int hv_remove_low_confidence_voxels(hv_volume *v, float min_confidence) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_remove_low_confidence_voxels: null volume");
+    if (!hv_is_semantic(v)) return HV_OK; // no-op for non-semantic payloads, voxel_block_grid.hpp:650-676
+    return hv_sem_segment_op(v, 4, 0, 0, min_confidence);
+}
+
+int hv_remap_instance_ids(hv_volume *v, const int32_t *instance_ids, int32_t height, int32_t width, const int32_t *map_inst,
+                          const int32_t *map_obj, int64_t n_map, int32_t *out, int32_t loc) {
+    HV_REQUIRE(v != nullptr && instance_ids != nullptr && out != nullptr, HV_ERR_INVALID, "hv_remap_instance_ids: null argument");
+    HV_REQUIRE(n_map == 0 || (map_inst != nullptr && map_obj != nullptr), HV_ERR_INVALID, "hv_remap_instance_ids: null map");
+    HV_HIP(hipSetDevice(v->device));
+    const int64_t n = (int64_t)height * width;
+    if (n == 0) return HV_OK;
+    // sort the map by instance id on the host (tiny), upload next to the image
+    std::vector<std::pair<int32_t, int32_t>> m((size_t)n_map);
+    for (int64_t i = 0; i < n_map; ++i) m[i] = {map_inst[i], map_obj[i]};
+    std::sort(m.begin(), m.end());
+    std::vector<int32_t> flat((size_t)n_map * 2);
+    for (int64_t i = 0; i < n_map; ++i) { flat[i] = m[i].first; flat[n_map + i] = m[i].second; }
+    const size_t img_bytes = sizeof(int32_t) * (size_t)n;
+    const size_t map_bytes = sizeof(int32_t) * 2 * (size_t)n_map;
+    int rc = hv_ensure_buffer(v, &v->stage_b, &v->stage_b_bytes, 2 * img_bytes + map_bytes + 512);
+    if (rc != HV_OK) return rc;
+    char *base = (char *)v->stage_b;
+    int32_t *d_map = (int32_t *)base;
+    const int32_t *d_in = instance_ids;
+    int32_t *d_out = out;
+    char *cursor = base + ((map_bytes + 255) & ~(size_t)255);
+    if (n_map > 0) HV_HIP(hipMemcpyAsync(d_map, flat.data(), map_bytes, hipMemcpyHostToDevice, v->stream));
+    if (loc == HV_HOST) {
+        HV_HIP(hipMemcpyAsync(cursor, instance_ids, img_bytes, hipMemcpyHostToDevice, v->stream));
+        d_in = (const int32_t *)cursor;
+        d_out = (int32_t *)(cursor + img_bytes);
+    }
+    hipLaunchKernelGGL(k_remap_instance_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, d_in, n, d_map,
+                       d_map + n_map, (int32_t)n_map, d_out);
+    HV_HIP(hipGetLastError());
+    if (loc == HV_HOST) HV_HIP(hipMemcpyAsync(out, d_out, img_bytes, hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipStreamSynchronize(v->stream)); // `flat` is host memory
+    return HV_OK;
+}
+
+int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw,
+                                         float depth_max, float depth_min, const int32_t *class_ids_image,
+                                         const int32_t *instance_ids_image, const float *depth_image, float depth_threshold,
+                                         int32_t do_carving, float min_vote_ratio, int32_t min_votes, int32_t *map_inst,
+                                         int32_t *map_obj, int64_t cap, int64_t *n_map, int32_t loc) {
+    HV_REQUIRE(v != nullptr && intr_f32 != nullptr && T_cw != nullptr && n_map != nullptr, HV_ERR_INVALID,
+               "hv_assign_object_ids_to_instance_ids: null argument");
+    HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_assign_object_ids_to_instance_ids: not a semantic grid");
+    *n_map = 0;
+    // "class IDs or semantic instances image is empty": the reference returns an empty map
+    if (class_ids_image == nullptr || instance_ids_image == nullptr || width <= 0 || height <= 0) return HV_OK;
+    HV_HIP(hipSetDevice(v->device));
+    int64_t nb = 0;
+    int rc = hv_num_blocks(v, &nb);
+    if (rc != HV_OK) return rc;
+    const HvSemParams G = sem_params(v);
+    const int64_t n_px = (int64_t)width * height;
+    const int64_t total = nb * G.nvox;
+    const int64_t pending_cap = std::max<int64_t>(1, std::min<int64_t>(total, 8 * (int64_t)v->cfg.max_points));
+
+    // device scratch: [vote keys][vote counts][compact keys][compact counts][pending][final map]
+    const size_t off_counts = sizeof(uint64_t) * HV_VOTE_CAP;
+    const size_t off_ckeys = off_counts + sizeof(int32_t) * HV_VOTE_CAP;
+    const size_t off_ccounts = off_ckeys + sizeof(uint64_t) * HV_VOTE_CAP;
+    const size_t off_pending = off_ccounts + sizeof(int32_t) * HV_VOTE_CAP;
+    const size_t off_map = off_pending + sizeof(int2) * (size_t)pending_cap;
+    const size_t scratch_bytes = off_map + sizeof(int32_t) * 2 * HV_VOTE_CAP;
+    rc = hv_ensure_buffer(v, &v->assoc_buf, &v->assoc_buf_bytes, scratch_bytes);
+    if (rc != HV_OK) return rc;
+    char *sb = (char *)v->assoc_buf;
+    unsigned long long *vkeys = (unsigned long long *)sb;
+    int32_t *vcounts = (int32_t *)(sb + off_counts);
+    unsigned long long *ckeys = (unsigned long long *)(sb + off_ckeys);
+    int32_t *ccounts = (int32_t *)(sb + off_ccounts);
+    int2 *pending = (int2 *)(sb + off_pending);
+    int32_t *d_map = (int32_t *)(sb + off_map);
+
+    // images: three planes staged back to back when they come from the host
+    const int32_t *d_cls = class_ids_image, *d_inst = instance_ids_image;
+    const float *d_depth = depth_image;
+    if (loc == HV_HOST) {
+        const size_t plane = (sizeof(int32_t) * (size_t)n_px + 255) & ~(size_t)255;
+        rc = hv_ensure_buffer(v, &v->stage_b, &v->stage_b_bytes, 3 * plane);
+        if (rc != HV_OK) return rc;
+        char *st = (char *)v->stage_b;
+        HV_HIP(hipMemcpyAsync(st, class_ids_image, sizeof(int32_t) * n_px, hipMemcpyHostToDevice, v->stream));
+        HV_HIP(hipMemcpyAsync(st + plane, instance_ids_image, sizeof(int32_t) * n_px, hipMemcpyHostToDevice, v->stream));
+        d_cls = (const int32_t *)st;
+        d_inst = (const int32_t *)(st + plane);
+        if (depth_image != nullptr) {
+            HV_HIP(hipMemcpyAsync(st + 2 * plane, depth_image, sizeof(float) * n_px, hipMemcpyHostToDevice, v->stream));
+            d_depth = (const float *)(st + 2 * plane);
+        }
+    }
+
+    HV_HIP(hipMemsetAsync(vkeys, 0xFF, sizeof(uint64_t) * HV_VOTE_CAP, v->stream));
+    HV_HIP(hipMemsetAsync(vcounts, 0, sizeof(int32_t) * HV_VOTE_CAP, v->stream));
+    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t) * 2, v->stream)); // OUT, OUT2
+    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_AUX], 0, sizeof(int32_t), v->stream));
+
+    HvAssocParams A;
+    A.use_depth = depth_image != nullptr ? 1 : 0;
+    A.do_carving = (do_carving && A.use_depth) ? 1 : 0;
+    A.depth_threshold = depth_threshold;
+    A.pending_cap = (int32_t)std::min<int64_t>(pending_cap, INT32_MAX);
+    const bool prob = is_prob(v);
+    if (nb > 0) {
+        HvQuery Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.kind = 2;
+        Q.min_count = 1;
+        fill_frustum_query(Q, v, intr_f32, width, height, T_cw, depth_max, depth_min);
+        HvGridParams GP;
+        GP.inv_voxel_size = G.inv_voxel_size;
+        GP.bs = G.bs;
+        GP.nvox = G.nvox;
+        GP.local_bits = G.local_bits;
+        fill_key_range(Q, GP);
+        const dim3 grid((unsigned)((total + 255) / 256));
+        if (prob)
+            hipLaunchKernelGGL(k_sem_assoc_vote<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, nb, G,
+                               Q, d_cls, d_inst, d_depth, A, vkeys, vcounts, pending);
+        else
+            hipLaunchKernelGGL(k_sem_assoc_vote<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, nb, G, Q,
+                               d_cls, d_inst, d_depth, A, vkeys, vcounts, pending);
+    }
+    hipLaunchKernelGGL(k_sem_assoc_image, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, v->stream, v->table, d_cls, d_inst,
+                       n_px, vkeys, vcounts);
+    hipLaunchKernelGGL(k_sem_assoc_compact, dim3(HV_VOTE_CAP / 256), dim3(256), 0, v->stream, v->table, vkeys, vcounts, ckeys,
+                       ccounts);
+    HV_HIP(hipGetLastError());
+    rc = hv_read_counters(v);
+    if (rc != HV_OK) return rc;
+    HV_REQUIRE(v->h_counters[HV_CNT_OUT2] == 0, HV_ERR_CAPACITY,
+               "hv_assign_object_ids_to_instance_ids: more than %u distinct (instance, object) pairs", HV_VOTE_CAP);
+    const int32_t n_pairs = v->h_counters[HV_CNT_OUT];
+    const int32_t n_pending = v->h_counters[HV_CNT_AUX];
+    HV_REQUIRE(n_pending <= A.pending_cap, HV_ERR_CAPACITY, "hv_assign_object_ids_to_instance_ids: pending list overflow (%d)",
+               n_pending);
+    std::vector<uint64_t> hk((size_t)n_pairs);
+    std::vector<int32_t> hc((size_t)n_pairs);
+    if (n_pairs > 0) {
+        HV_HIP(hipMemcpyAsync(hk.data(), ckeys, sizeof(uint64_t) * n_pairs, hipMemcpyDeviceToHost, v->stream));
+        HV_HIP(hipMemcpyAsync(hc.data(), ccounts, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, v->stream));
+        HV_HIP(hipStreamSynchronize(v->stream));
+    }
+
+    // ---- host: the reference's voting rules, voxel_semantic_data_association.h:268-361 ----
+    std::map<int32_t, std::map<int32_t, int32_t>> votes; // instance -> (object -> count), objects ascending like std::map
+    std::map<int32_t, int32_t> pending_votes;            // instance -> votes of voxels waiting for a new object id
+    std::vector<int32_t> seen;
+    for (int32_t i = 0; i < n_pairs; ++i) {
+        const int32_t inst = (int32_t)(uint32_t)(hk[i] >> 32);
+        const int32_t obj = (int32_t)(uint32_t)(hk[i] & 0xffffffffull);
+        if (obj == HV_OBJ_SEEN) seen.push_back(inst);
+        else if (obj == HV_OBJ_PENDING) pending_votes[inst] += hc[i];
+        else votes[inst][obj] += hc[i];
+    }
+    for (const auto &[inst, cnt] : pending_votes) { // ascending instance id
+        const int32_t new_id = g_next_object_id.fetch_add(1);
+        votes[inst][new_id] += cnt;
+    }
+    std::map<int32_t, int32_t> result;
+    for (const auto &[inst, object_votes] : votes) {
+        int max_votes = 0, winning = -1, total_votes = 0;
+        for (const auto &[obj, cnt] : object_votes) {
+            total_votes += cnt;
+            if (cnt > max_votes) {
+                max_votes = cnt;
+                winning = obj;
+            }
+        }
+        if (total_votes < min_votes) {
+            result[inst] = -1;
+            continue;
+        }
+        const float ratio = (float)max_votes / (float)total_votes;
+        result[inst] = ratio < min_vote_ratio ? -1 : winning;
+    }
+    for (const int32_t inst : seen) {
+        if (inst == 0) result[0] = 0;
+        else if (result.find(inst) == result.end()) result[inst] = -1;
+    }
+
+    // ---- deferred assignments ----
+    if (n_pending > 0 && !result.empty()) {
+        std::vector<int32_t> flat(result.size() * 2);
+        size_t i = 0;
+        for (const auto &[inst, obj] : result) {
+            flat[i] = inst;
+            flat[result.size() + i] = obj;
+            ++i;
+        }
+        HV_REQUIRE(result.size() <= HV_VOTE_CAP, HV_ERR_CAPACITY, "hv_assign_object_ids_to_instance_ids: map too large");
+        HV_HIP(hipMemcpyAsync(d_map, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice, v->stream));
+        const dim3 grid((unsigned)((n_pending + 255) / 256));
+        if (prob)
+            hipLaunchKernelGGL(k_sem_assoc_apply<HvProbVoxel>, grid, dim3(256), 0, v->stream, (HvProbVoxel *)v->pool, pending, n_pending,
+                               d_map, d_map + result.size(), (int32_t)result.size());
+        else
+            hipLaunchKernelGGL(k_sem_assoc_apply<HvSemVoxel>, grid, dim3(256), 0, v->stream, (HvSemVoxel *)v->pool, pending, n_pending,
+                               d_map, d_map + result.size(), (int32_t)result.size());
+        HV_HIP(hipGetLastError());
+        HV_HIP(hipStreamSynchronize(v->stream)); // `flat` is host memory
+    }
+    *n_map = (int64_t)result.size();
+    if (map_inst != nullptr && map_obj != nullptr) {
+        int64_t i = 0;
+        for (const auto &[inst, obj] : result) {
+            if (i >= cap) break;
+            map_inst[i] = inst;
+            map_obj[i] = obj;
+            ++i;
+        }
+    }
+    return HV_OK;
+}
+
+int hv_object_segments_compute(hv_volume *v, int32_t min_count, float min_confidence, int64_t *n_rows, int64_t *n_objects) {
+    HV_REQUIRE(v != nullptr && n_rows != nullptr && n_objects != nullptr, HV_ERR_INVALID, "hv_object_segments_compute: null argument");
+    HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_object_segments_compute: not a semantic grid");
+    HV_HIP(hipSetDevice(v->device));
+    if (v->segments_cache == nullptr) v->segments_cache = new HvSegmentsCache();
+    HvSegmentsCache &C = *static_cast<HvSegmentsCache *>(v->segments_cache);
+    C = HvSegmentsCache();
+    *n_rows = 0;
+    *n_objects = 0;
+    int64_t nb = 0;
+    int rc = hv_num_blocks(v, &nb);
+    if (rc != HV_OK) return rc;
+    if (nb == 0) return HV_OK;
+    const bool prob = is_prob(v);
+    const int64_t total = nb * sem_params(v).nvox;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    // pass 1: count; pass 2: emit (object id, voxel index) keys
+    int64_t m = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        unsigned long long *d_keys = nullptr;
+        if (pass == 1) {
+            rc = hv_ensure_buffer(v, &v->out_b, &v->out_b_bytes, sizeof(uint64_t) * 2 * (size_t)m + 256);
+            if (rc != HV_OK) return rc;
+            d_keys = (unsigned long long *)v->out_b;
+        }
+        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
+        if (prob)
+            hipLaunchKernelGGL(k_seg_collect<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvProbVoxel *)v->pool, total,
+                               min_count, min_confidence, d_keys, m);
+        else
+            hipLaunchKernelGGL(k_seg_collect<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvSemVoxel *)v->pool, total,
+                               min_count, min_confidence, d_keys, m);
+        HV_HIP(hipGetLastError());
+        rc = hv_read_counters(v);
+        if (rc != HV_OK) return rc;
+        m = v->h_counters[HV_CNT_OUT];
+        if (m == 0) return HV_OK;
+    }
+    unsigned long long *d_keys = (unsigned long long *)v->out_b, *d_sorted = d_keys + m;
+    size_t tmp_bytes = 0;
+    HV_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys, d_sorted, (size_t)m, 0, 64, v->stream));
+    rc = hv_ensure_buffer(v, &v->sort_tmp, &v->sort_tmp_bytes, tmp_bytes);
+    if (rc != HV_OK) return rc;
+    tmp_bytes = v->sort_tmp_bytes;
+    HV_HIP(rocprim::radix_sort_keys(v->sort_tmp, tmp_bytes, d_keys, d_sorted, (size_t)m, 0, 64, v->stream));
+    rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, (size_t)m * (24 + 12 + 4 + 4 + 4) + 1024);
+    if (rc != HV_OK) return rc;
+    double *d_pts = (double *)v->out_a;
+    float *d_cols = (float *)(d_pts + 3 * m);
+    int32_t *d_obj = (int32_t *)(d_cols + 3 * m);
+    int32_t *d_cls = d_obj + m;
+    float *d_conf = (float *)(d_cls + m);
+    const dim3 rgrid((unsigned)((m + 255) / 256));
+    if (prob)
+        hipLaunchKernelGGL(k_seg_rows<HvProbVoxel>, rgrid, dim3(256), 0, v->stream, (const HvProbVoxel *)v->pool, d_sorted, m, d_pts,
+                           d_cols, d_obj, d_cls, d_conf);
+    else
+        hipLaunchKernelGGL(k_seg_rows<HvSemVoxel>, rgrid, dim3(256), 0, v->stream, (const HvSemVoxel *)v->pool, d_sorted, m, d_pts,
+                           d_cols, d_obj, d_cls, d_conf);
+    HV_HIP(hipGetLastError());
+    C.pts.resize((size_t)m * 3);
+    C.cols.resize((size_t)m * 3);
+    C.row_obj.resize((size_t)m);
+    std::vector<int32_t> cls((size_t)m);
+    std::vector<float> conf((size_t)m);
+    HV_HIP(hipMemcpyAsync(C.pts.data(), d_pts, 24 * m, hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipMemcpyAsync(C.cols.data(), d_cols, 12 * m, hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipMemcpyAsync(C.row_obj.data(), d_obj, 4 * m, hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipMemcpyAsync(cls.data(), d_cls, 4 * m, hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipMemcpyAsync(conf.data(), d_conf, 4 * m, hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipStreamSynchronize(v->stream));
+    // rows are grouped by object id (ascending): per-object summary + PCA box on the host
+    for (int64_t i = 0; i < m;) {
+        int64_t j = i;
+        float cmin = conf[i], cmax = conf[i];
+        while (j < m && C.row_obj[j] == C.row_obj[i]) {
+            cmin = std::min(cmin, conf[j]);
+            cmax = std::max(cmax, conf[j]);
+            ++j;
+        }
+        C.ids.push_back(C.row_obj[i]);
+        C.ids.push_back(cls[i]); // class of the object's first voxel (the reference: first in *its* iteration order)
+        C.ids.push_back((int32_t)(j - i));
+        C.conf.push_back(cmin);
+        C.conf.push_back(cmax);
+        C.obb.resize(C.obb.size() + 10);
+        compute_obb_pca(C.pts.data() + i * 3, j - i, C.obb.data() + C.obb.size() - 10);
+        i = j;
+    }
+    *n_rows = m;
+    *n_objects = (int64_t)C.ids.size() / 3;
+    return HV_OK;
+}
+
+int hv_object_segments_fetch(hv_volume *v, double *points, float *colors, int32_t *row_object_ids, int32_t *object_ids,
+                             float *confidences, double *obbs) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_object_segments_fetch: null volume");
+    HV_REQUIRE(v->segments_cache != nullptr, HV_ERR_INVALID, "hv_object_segments_fetch: call hv_object_segments_compute first");
+    const HvSegmentsCache &C = *static_cast<HvSegmentsCache *>(v->segments_cache);
+    if (points) memcpy(points, C.pts.data(), sizeof(double) * C.pts.size());
+    if (colors) memcpy(colors, C.cols.data(), sizeof(float) * C.cols.size());
+    if (row_object_ids) memcpy(row_object_ids, C.row_obj.data(), sizeof(int32_t) * C.row_obj.size());
+    if (object_ids) memcpy(object_ids, C.ids.data(), sizeof(int32_t) * C.ids.size());
+    if (confidences) memcpy(confidences, C.conf.data(), sizeof(float) * C.conf.size());
+    if (obbs) memcpy(obbs, C.obb.data(), sizeof(double) * C.obb.size());
+    return HV_OK;
+}
+
+// OrientedBoundingBox3D::compute_from_points(points, PCA) for callers that hold their own point sets
+int hv_compute_obb_pca(const double *points, int64_t n, double *obb) {
+    HV_REQUIRE(obb != nullptr && (n == 0 || points != nullptr), HV_ERR_INVALID, "hv_compute_obb_pca: null argument");
+    compute_obb_pca(points, n, obb);
+    return HV_OK;
+}
+
+} // extern "C"

@@ -19,22 +19,10 @@
 #include <numeric>
 
 #include "hv_common.h"
+#include "hv_query.h"
 #include <rocprim/device/device_radix_sort.hpp>
 
 static constexpr uint32_t HV_SORT_SENTINEL = 0xFFFFFFFFu;
-
-struct HvGridParams {
-    float inv_voxel_size; // 1.0f / voxel_size  (voxel_block_grid.hpp:6)
-    int32_t bs;           // block_size
-    int32_t nvox;         // bs^3
-    int32_t local_bits;
-};
-
-// floor_div, voxel_hashing.h:139-142
-__host__ __device__ inline int32_t hv_floor_div(int32_t a, int32_t b) {
-    const int64_t aa = a, bb = b;
-    return (int32_t)((aa >= 0) ? (aa / bb) : ((aa - bb + 1) / bb));
-}
 
 struct HvPointKey {
     int32_t v[3], b[3], l[3];
@@ -154,35 +142,6 @@ __global__ __launch_bounds__(256) void k_vg_unproject(const void *__restrict__ d
     const uint8_t *c = rgb + i * 3;
 #pragma unroll
     for (int k = 0; k < 3; ++k) cols_out[i * 3 + k] = (float)((double)c[k] / 255.0);
-}
-
-// ---- scans over all allocated voxels -----------------------------------------------------------
-struct HvQuery {
-    int32_t kind; // 0: all, 1: bbox, 2: frustum, 3: carve
-    int32_t min_count;
-    int32_t vmin[3], vmax[3], bmin[3], bmax[3];
-    double bb[6];
-    // frustum (CameraFrustrum, camera_frustrum.h:108-121)
-    float fx, fy, cx, cy, depth_max, depth_min;
-    int32_t width, height;
-    double R[9], t[3];
-    float carve_threshold;
-};
-
-// CameraFrustrum::contains<float>, camera_frustrum.cpp:175-196
-__device__ __forceinline__ bool hv_frustum_contains(const HvQuery &Q, float xw, float yw, float zw, float *uvd) {
-    const double p0 = (double)xw, p1 = (double)yw, p2 = (double)zw;
-    double pc[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) pc[r] = (Q.R[r * 3 + 0] * p0 + Q.R[r * 3 + 1] * p1 + Q.R[r * 3 + 2] * p2) + Q.t[r];
-    const float depth = (float)pc[2];
-    if (!(depth >= Q.depth_min && depth <= Q.depth_max)) return false;
-    const float u = (float)((double)Q.fx * (pc[0] / pc[2]) + (double)Q.cx);
-    const float v = (float)((double)Q.fy * (pc[1] / pc[2]) + (double)Q.cy);
-    uvd[0] = u;
-    uvd[1] = v;
-    uvd[2] = depth;
-    return u >= 0.0f && u < (float)Q.width && v >= 0.0f && v < (float)Q.height;
 }
 
 // Shared predicate of get_voxels / get_voxels_in_bb / get_voxels_in_camera_frustrum / carve.
@@ -377,58 +336,6 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
     HV_HIP(hipGetLastError());
     v->frame_counter += 1;
     return HV_OK;
-}
-
-static void fill_frustum_query(HvQuery &Q, const hv_volume *v, const float *intr, int width, int height,
-                               const double *T_cw, float depth_max, float depth_min) {
-    Q.fx = intr[0];
-    Q.fy = intr[1];
-    Q.cx = intr[2];
-    Q.cy = intr[3];
-    Q.width = width;
-    Q.height = height;
-    Q.depth_max = depth_max;
-    Q.depth_min = depth_min;
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) Q.R[r * 3 + c] = T_cw[r * 4 + c];
-        Q.t[r] = T_cw[r * 4 + 3];
-    }
-    // compute_frustum_corners_world_ + compute_bbox_, camera_frustrum.cpp:209-264
-    double Rwc[9], twc[3];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) Rwc[r * 3 + c] = Q.R[c * 3 + r];
-    for (int r = 0; r < 3; ++r) twc[r] = -(Rwc[r * 3 + 0] * Q.t[0] + Rwc[r * 3 + 1] * Q.t[1] + Rwc[r * 3 + 2] * Q.t[2]);
-    const double cu[4] = {0.0, (double)width, (double)width, 0.0};
-    const double cv[4] = {0.0, 0.0, (double)height, (double)height};
-    for (int k = 0; k < 3; ++k) {
-        Q.bb[k] = 1.7976931348623157e308;
-        Q.bb[3 + k] = -1.7976931348623157e308;
-    }
-    for (int i = 0; i < 4; ++i) {
-        const double xn = (cu[i] - (double)Q.cx) / (double)Q.fx;
-        const double yn = (cv[i] - (double)Q.cy) / (double)Q.fy;
-        const double ds[2] = {(double)depth_min, (double)depth_max};
-        for (int j = 0; j < 2; ++j) {
-            const double pc[3] = {xn * ds[j], yn * ds[j], ds[j]};
-            for (int r = 0; r < 3; ++r) {
-                const double w = (Rwc[r * 3 + 0] * pc[0] + Rwc[r * 3 + 1] * pc[1] + Rwc[r * 3 + 2] * pc[2]) + twc[r];
-                if (w < Q.bb[r]) Q.bb[r] = w;
-                if (w > Q.bb[3 + r]) Q.bb[3 + r] = w;
-            }
-        }
-    }
-    (void)v;
-}
-
-// bbox -> voxel/block key range, voxel_block_grid.hpp:827-835: get_voxel_key_inv<double,double>
-// with the float inv_voxel_size_ promoted to double.
-static void fill_key_range(HvQuery &Q, const HvGridParams &G) {
-    for (int k = 0; k < 3; ++k) {
-        Q.vmin[k] = (int32_t)std::floor(Q.bb[k] * (double)G.inv_voxel_size);
-        Q.vmax[k] = (int32_t)std::floor(Q.bb[3 + k] * (double)G.inv_voxel_size);
-        Q.bmin[k] = hv_floor_div(Q.vmin[k], G.bs);
-        Q.bmax[k] = hv_floor_div(Q.vmax[k], G.bs);
-    }
 }
 
 static int run_collect(hv_volume *v, const HvQuery &Q, float *points, float *colors, int64_t cap, int64_t *n,
@@ -634,7 +541,8 @@ int hv_get_voxels_in_frustum(hv_volume *v, const float *intr_f32, int32_t width,
 int hv_carve(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw, float depth_max,
              float depth_min, const float *depth, float depth_threshold, int32_t loc) {
     HV_REQUIRE(v != nullptr && intr_f32 != nullptr && T_cw != nullptr, HV_ERR_INVALID, "hv_carve: null argument");
-    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_GRID, HV_ERR_MODE, "hv_carve: volume is not in VOXEL_GRID mode");
+    const bool semantic = v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID || v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID;
+    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_GRID || semantic, HV_ERR_MODE, "hv_carve: volume is not a voxel grid");
     if (depth == nullptr || width <= 0 || height <= 0) return HV_OK; // "Depth image is empty": reference returns
     HV_HIP(hipSetDevice(v->device));
     int64_t nb = 0;
@@ -652,6 +560,7 @@ int hv_carve(hv_volume *v, const float *intr_f32, int32_t width, int32_t height,
     fill_frustum_query(Q, v, intr_f32, width, height, T_cw, depth_max, depth_min);
     const HvGridParams G = grid_params(v);
     fill_key_range(Q, G);
+    if (semantic) return hv_sem_carve(v, Q, (const float *)d_depth, nb);
     const int64_t total = nb * G.nvox;
     hipLaunchKernelGGL(k_vg_carve, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, v->table,
                        (HvVoxel *)v->pool, nb, G, Q, (const float *)d_depth);
@@ -661,7 +570,9 @@ int hv_carve(hv_volume *v, const float *intr_f32, int32_t width, int32_t height,
 
 int hv_remove_low_count_voxels(hv_volume *v, int32_t min_count) {
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_remove_low_count_voxels: null volume");
-    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_GRID, HV_ERR_MODE, "hv_remove_low_count_voxels: not a VOXEL_GRID volume");
+    if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID || v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID)
+        return hv_sem_segment_op(v, 3, min_count, 0, 0.f);
+    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_GRID, HV_ERR_MODE, "hv_remove_low_count_voxels: not a voxel grid");
     HV_HIP(hipSetDevice(v->device));
     int64_t nb = 0;
     int rc = hv_num_blocks(v, &nb);
@@ -676,6 +587,7 @@ int hv_remove_low_count_voxels(hv_volume *v, int32_t min_count) {
 
 int hv_size(hv_volume *v, int64_t *n) {
     HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_size: null argument");
+    if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID || v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID) return hv_sem_size(v, n);
     return hv_get_voxels(v, 1, 0.0f, nullptr, nullptr, 0, n, HV_HOST);
 }
 

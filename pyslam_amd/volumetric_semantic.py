@@ -1,10 +1,16 @@
-"""`volumetric.VoxelBlockSemanticGrid` (voting payload) on the GPU: mirror of the semantic block grid
-binding (cpp/volumetric/volumetric_grid_module.h:939-1033; payload voxel_data_semantic.h:106-202).
+"""The semantic block grids of pySLAM's ``volumetric`` module on the GPU (bindings:
+cpp/volumetric/volumetric_grid_module.h:939-1033; class cpp/volumetric/voxel_block_semantic_grid.h:57-121):
 
-Provided: integrate(points, colors, class_ids, instance_ids, depths), get_voxels(min_count,
-min_confidence) with class_ids / object_ids / confidences, set_depth_threshold, clear/reset, num_blocks.
-Not provided (SURVEY 8a V17/V18 remainder): segment operations, instance->object association, the
-probabilistic payload."""
+* ``VoxelBlockSemanticGrid``              — voting payload (voxel_data_semantic.h:106-202)
+* ``VoxelBlockSemanticProbabilisticGrid`` — log-probability payload (voxel_data_semantic.h:249-672)
+
+Methods: integrate(points, colors, class_ids, instance_ids, depths), get_voxels(min_count, min_confidence),
+carve, assign_object_ids_to_instance_ids, get_object_segments, merge_segments, remove_segment,
+remove_low_confidence_segments, remove_low_count_voxels, remove_low_confidence_voxels, get_ids,
+set_depth_threshold, set_depth_decay_rate, clear/reset, size, num_blocks; module-level
+``remap_instance_ids`` (image_utils.h:69-163) and the ``ObjectData`` / ``ObjectDataGroup`` /
+``OrientedBoundingBox3D`` result types (voxel_grid_data.h:58-99, bounding_boxes_3d.h:82-131).
+Not provided: integrate_segment, get_class_segments, the *2 payload variants (voxel_data_semantic2.h)."""
 import ctypes
 
 import numpy as np
@@ -13,14 +19,113 @@ from . import _lib as L
 from .volumetric import VoxelGridData, _Volume
 
 
-class VoxelBlockSemanticGrid(_Volume):
-    def __init__(self, voxel_size, block_size=8, device=0, max_blocks=None, max_points=None):
+class OrientedBoundingBox3D:
+    """bounding_boxes_3d.h:82-131: center (3,), orientation quaternion (w, x, y, z), size (3,)."""
+
+    def __init__(self, center=(0.0, 0.0, 0.0), orientation=(1.0, 0.0, 0.0, 0.0), size=(0.0, 0.0, 0.0)):
+        self.center = np.asarray(center, np.float64).copy()
+        self.orientation = np.asarray(orientation, np.float64).copy()
+        self.size = np.asarray(size, np.float64).copy()
+
+    def get_rotation_matrix(self):
+        w, x, y, z = self.orientation / np.linalg.norm(self.orientation)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def get_matrix(self):
+        M = np.eye(4)
+        M[:3, :3] = self.get_rotation_matrix()
+        M[:3, 3] = self.center
+        return M
+
+    def get_volume(self):
+        return float(np.prod(self.size))
+
+    def get_corners(self):
+        """bounding_boxes_3d.cpp:287-318 (same corner order)."""
+        R, h = self.get_rotation_matrix(), self.size / 2.0
+        signs = [(1, 1, -1), (-1, 1, -1), (-1, -1, -1), (1, -1, -1), (1, 1, 1), (-1, 1, 1), (-1, -1, 1), (1, -1, 1)]
+        return np.array([self.center + R @ (h * np.array(s, np.float64)) for s in signs])
+
+    @staticmethod
+    def compute_from_points(points):
+        """OrientedBoundingBox3D::compute_from_points(points, PCA), bounding_boxes_3d.cpp:373-553."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        obb = np.zeros(10, np.float64)
+        L.check(L.load().hv_compute_obb_pca(L.ptr(pts), pts.shape[0], L.ptr(obb)))
+        return OrientedBoundingBox3D(obb[0:3], obb[3:7], obb[7:10])
+
+
+class ObjectData:
+    """voxel_grid_data.h:58-75."""
+
+    def __init__(self, points, colors, object_id, class_id, confidence_min, confidence_max, oriented_bounding_box):
+        self.points, self.colors = points, colors
+        self.object_id, self.class_id = int(object_id), int(class_id)
+        self.confidence_min, self.confidence_max = float(confidence_min), float(confidence_max)
+        self.oriented_bounding_box = oriented_bounding_box
+
+
+class ObjectDataGroup:
+    """voxel_grid_data.h:83-93: object_vector + the redundant class_ids / object_ids lists."""
+
+    def __init__(self, object_vector):
+        self.object_vector = list(object_vector)
+        self.class_ids = np.array([o.class_id for o in self.object_vector], np.int32)
+        self.object_ids = np.array([o.object_id for o in self.object_vector], np.int32)
+
+
+def _i32_image(img, name):
+    a = np.ascontiguousarray(img)
+    if a.ndim != 2:
+        raise RuntimeError(f"{name} must be single-channel")
+    return np.ascontiguousarray(a, dtype=np.int32)  # convert_image_type_if_needed(..., CV_32S)
+
+
+def remap_instance_ids(instance_ids, instance_id_to_object_id, volume=None):
+    """volumetric.remap_instance_ids(image int32 HxW, map) (image_utils.h:69-163, binding image_utils_module.h):
+    ids absent from the map (or an empty map) become -1.  Runs on the GPU of ``volume`` (any volume)."""
+    img = np.ascontiguousarray(instance_ids)
+    if img.size == 0:
+        return img
+    if img.ndim != 2:
+        raise RuntimeError("Instance ids must be single-channel")
+    if img.dtype != np.int32:
+        raise RuntimeError("Instance ids must be int32")
+    if volume is None:
+        volume = _scratch_volume()
+    keys = np.fromiter(instance_id_to_object_id.keys(), np.int32, len(instance_id_to_object_id))
+    vals = np.fromiter(instance_id_to_object_id.values(), np.int32, len(instance_id_to_object_id))
+    out = np.empty_like(img)
+    L.check(volume._lib.hv_remap_instance_ids(volume._h, L.ptr(img), img.shape[0], img.shape[1], L.ptr(keys), L.ptr(vals),
+                                              len(keys), L.ptr(out), L.HV_HOST))
+    return out
+
+
+_scratch = None
+
+
+def _scratch_volume():
+    global _scratch
+    if _scratch is None:
+        _scratch = VoxelBlockSemanticGrid(0.05, 8, max_blocks=64, max_points=1 << 12)
+    return _scratch
+
+
+class _SemanticGridBase(_Volume):
+    _MODE = None
+
+    def __init__(self, voxel_size=0.05, block_size=8, device=0, max_blocks=None, max_points=None):
         voxel_size = float(np.float32(voxel_size))
-        super().__init__(L.HV_MODE_VOXEL_SEMANTIC_GRID, voxel_size, 0.0, block_size, 1, device, max_blocks, max_points)
+        super().__init__(self._MODE, voxel_size, 0.0, block_size, 1, device, max_blocks, max_points)
         self.voxel_size, self.block_size = voxel_size, int(block_size)
 
     def set_depth_threshold(self, depth_threshold):
         L.check(self._lib.hv_set_depth_threshold(self._h, float(depth_threshold)))
+
+    def set_depth_decay_rate(self, depth_decay_rate):
+        L.check(self._lib.hv_set_depth_decay_rate(self._h, float(depth_decay_rate)))
 
     def integrate(self, points, colors=None, class_ids=None, instance_ids=None, depths=None):
         pts = np.asarray(points)
@@ -78,10 +183,100 @@ class VoxelBlockSemanticGrid(_Volume):
                                                      L.ptr(out.confidences), m, ctypes.byref(n)))
         return out
 
+    def get_points(self):
+        return self.get_voxels(1, -1.0).points
+
+    def get_colors(self):
+        return self.get_voxels(1, -1.0).colors
+
+    def get_ids(self):
+        """-> (class_ids, object_ids) of every voxel with count > 0 (voxel_block_semantic_grid.hpp:198-213)."""
+        vg = self.get_voxels(1, -1.0)
+        return vg.class_ids, vg.object_ids
+
+    def carve(self, camera_frustrum, depth_image, depth_threshold=1e-2):
+        f = camera_frustrum
+        depth = np.ascontiguousarray(depth_image, dtype=np.float32)
+        if depth.size == 0 or depth.shape[0] != f.height or depth.shape[1] != f.width:
+            return  # "Depth image is empty" / check_image_size(): the reference prints a message and returns
+        L.check(self._lib.hv_carve(self._h, L.ptr(f.intr), f.width, f.height, L.ptr(f.T_cw), f.depth_max, f.depth_min, L.ptr(depth),
+                                   float(depth_threshold), L.HV_HOST))
+
+    def assign_object_ids_to_instance_ids(self, camera_frustrum, class_ids_image, semantic_instances_image, depth_image=None,
+                                          depth_threshold=0.1, do_carving=False, min_vote_ratio=0.5, min_votes=3):
+        """-> dict instance_id -> object_id (voxel_semantic_data_association.h:70-373)."""
+        f = camera_frustrum
+        if class_ids_image is None or semantic_instances_image is None:
+            return {}
+        cls, inst = np.asarray(class_ids_image), np.asarray(semantic_instances_image)
+        if cls.size == 0 or inst.size == 0:
+            return {}
+        cls, inst = _i32_image(cls, "Class ids"), _i32_image(inst, "Instance ids")
+        if inst.shape != (f.height, f.width) or cls.shape != (f.height, f.width):
+            return {}  # check_image_size(): message + empty map
+        depth = None
+        if depth_image is not None and np.asarray(depth_image).size > 0:
+            depth = np.ascontiguousarray(depth_image, dtype=np.float32)
+            if depth.shape != (f.height, f.width):
+                depth = None  # use_depth_filter = false
+        cap = 1 << 16
+        mi, mo = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_assign_object_ids_to_instance_ids(
+            self._h, L.ptr(f.intr), f.width, f.height, L.ptr(f.T_cw), f.depth_max, f.depth_min, L.ptr(cls), L.ptr(inst), L.ptr(depth),
+            float(depth_threshold), int(bool(do_carving)), float(min_vote_ratio), int(min_votes), L.ptr(mi), L.ptr(mo), cap,
+            ctypes.byref(n), L.HV_HOST))
+        m = min(n.value, cap)
+        return {int(k): int(v) for k, v in zip(mi[:m], mo[:m])}
+
+    def get_object_segments(self, min_count=1, min_confidence=0.0):
+        """-> ObjectDataGroup (voxel_block_semantic_grid.hpp:217-267); objects in ascending object-id order."""
+        nr, no = ctypes.c_int64(), ctypes.c_int64()
+        L.check(self._lib.hv_object_segments_compute(self._h, int(min_count), float(min_confidence), ctypes.byref(nr), ctypes.byref(no)))
+        R, O = nr.value, no.value
+        pts, cols = np.zeros((R, 3), np.float64), np.zeros((R, 3), np.float32)
+        ids, conf, obb = np.zeros((O, 3), np.int32), np.zeros((O, 2), np.float32), np.zeros((O, 10), np.float64)
+        if R:
+            L.check(self._lib.hv_object_segments_fetch(self._h, L.ptr(pts), L.ptr(cols), None, L.ptr(ids), L.ptr(conf), L.ptr(obb)))
+        objs, at = [], 0
+        for o in range(O):
+            k = int(ids[o, 2])
+            objs.append(ObjectData(pts[at:at + k], cols[at:at + k], ids[o, 0], ids[o, 1], conf[o, 0], conf[o, 1],
+                                   OrientedBoundingBox3D(obb[o, 0:3], obb[o, 3:7], obb[o, 7:10])))
+            at += k
+        return ObjectDataGroup(objs)
+
+    def merge_segments(self, instance_id1, instance_id2):
+        L.check(self._lib.hv_merge_segments(self._h, int(instance_id1), int(instance_id2)))
+
+    def remove_segment(self, object_id):
+        L.check(self._lib.hv_remove_segment(self._h, int(object_id)))
+
+    def remove_low_confidence_segments(self, min_confidence):
+        L.check(self._lib.hv_remove_low_confidence_segments(self._h, int(min_confidence)))
+
+    def remove_low_count_voxels(self, min_count):
+        L.check(self._lib.hv_remove_low_count_voxels(self._h, int(min_count)))
+
+    def remove_low_confidence_voxels(self, min_confidence):
+        L.check(self._lib.hv_remove_low_confidence_voxels(self._h, float(min_confidence)))
+
+    def label_overflows(self):
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_label_overflows(self._h, ctypes.byref(n)))
+        return n.value
+
     def clear(self):
         L.check(self._lib.hv_reset(self._h))
 
     reset = clear
+
+    def size(self):
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_size(self._h, ctypes.byref(n)))
+        return n.value
+
+    get_total_voxel_count = size
 
     def empty(self):
         return self.num_blocks() == 0
@@ -89,12 +284,39 @@ class VoxelBlockSemanticGrid(_Volume):
     def get_block_size(self):
         return self.block_size
 
+    # -- parity/debug ----------------------------------------------------------------------------
     def dump(self):
+        """-> keys [B,3], ints [B,bs^3,4] {count, object_id, class_id, confidence_counter}, pos_sums f64, col_sums f32."""
+        return self.dump2()[:4]
+
+    def dump2(self):
+        """dump() + conf [B,bs^3] f32, label_counts [B,bs^3], labels [B,bs^3,7,2], log_probs [B,bs^3,7]."""
         nb, nv = self.num_blocks(), self.block_size ** 3
         keys = np.zeros((nb, 3), np.int32)
         ints = np.zeros((nb, nv, 4), np.int32)
+        conf = np.zeros((nb, nv), np.float32)
         pos = np.zeros((nb, nv, 3), np.float64)
         col = np.zeros((nb, nv, 3), np.float32)
+        nlab = np.zeros((nb, nv), np.int32)
+        labels = np.zeros((nb, nv, 7, 2), np.int32)
+        logp = np.zeros((nb, nv, 7), np.float32)
         n = ctypes.c_int64()
-        L.check(self._lib.hv_dump_blocks_semantic(self._h, L.ptr(keys), L.ptr(ints), L.ptr(pos), L.ptr(col), ctypes.byref(n)))
-        return keys, ints, pos, col
+        L.check(self._lib.hv_dump_blocks_semantic2(self._h, L.ptr(keys), L.ptr(ints), L.ptr(conf), L.ptr(pos), L.ptr(col), L.ptr(nlab),
+                                                   L.ptr(labels), L.ptr(logp), ctypes.byref(n)))
+        return keys, ints, pos, col, conf, nlab, labels, logp
+
+
+class VoxelBlockSemanticGrid(_SemanticGridBase):
+    _MODE = L.HV_MODE_VOXEL_SEMANTIC_GRID
+
+
+class VoxelBlockSemanticProbabilisticGrid(_SemanticGridBase):
+    _MODE = L.HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID
+
+
+def get_next_object_id_peek():
+    return L.load().hv_peek_next_object_id()
+
+
+def set_next_object_id(value):
+    L.load().hv_set_next_object_id(int(value))
