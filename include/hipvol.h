@@ -161,6 +161,14 @@ int hv_keys_from_points(hv_volume *v, const float *points, int64_t n, int32_t *v
 int hv_integrate_points_semantic(hv_volume *v, const void *points, int32_t point_dtype, int64_t n, const void *colors,
                                  int32_t color_dtype, const int32_t *class_ids, const int32_t *instance_ids,
                                  const float *depths, int32_t loc);
+/* Fused L3 prep + integrate for one posed RGB-D frame with label images (the per-keyframe body of
+ * VolumetricIntegratorVoxelSemanticGrid, pyslam/dense/volumetric_integrator_voxel_semantic_grid.py:402-461):
+ * depth2pointcloud(depth, rgb, ..., semantic_image, object_ids_image) + world transform + float32 casts +
+ * integrate(points, colors, class_ids, instance_ids, depths = camera z when use_depths).  depth f32 metres HxW, rgb
+ * u8 HxWx3, label images i32 HxW or NULL. */
+int hv_integrate_rgbd_semantic(hv_volume *v, const float *depth, const uint8_t *rgb, const int32_t *class_ids_image,
+                               const int32_t *object_ids_image, int32_t height, int32_t width, const double *intr,
+                               const double *T_cw, double min_depth, double max_depth, int32_t use_depths, int32_t loc);
 /* get_voxels(min_count, min_confidence) for semantic voxels: rows with count >= min_count and
  * confidence >= min_confidence; points f64 [M,3], colors f32 [M,3], class_ids/object_ids i32 [M],
  * confidences f32 [M] (host).  points == NULL: size query. */

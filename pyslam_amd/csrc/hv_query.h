@@ -108,3 +108,6 @@ static inline void fill_key_range(HvQuery &Q, const HvGridParams &G) {
 int hv_sem_carve(hv_volume *v, const HvQuery &Q, const float *d_depth, int64_t n_blocks);
 int hv_sem_segment_op(hv_volume *v, int op, int32_t a, int32_t b, float fa);
 int hv_sem_size(hv_volume *v, int64_t *n);
+int hv_unproject_frame(hv_volume *v, const void *depth, int32_t depth_dtype, double depth_scale, const uint8_t *rgb,
+                       int32_t height, int32_t width, const double *intr, const double *T_cw, double min_depth,
+                       double max_depth, int32_t loc, const void **d_depth_out); // hv_voxel_grid.hip

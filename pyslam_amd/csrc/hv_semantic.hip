@@ -19,6 +19,7 @@
 #include <numeric>
 
 #include "hv_common.h"
+#include "hv_query.h"
 #include "hv_semantic.h"
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -36,10 +37,15 @@ __device__ __forceinline__ int32_t sem_voxel_coord(double x, float inv) { return
 
 template <typename PT>
 __global__ __launch_bounds__(256) void k_sem_keys(HvTable table, const PT *__restrict__ pts, int64_t n, HvSemParams G,
-                                                   uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+                                                   uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                   const uint32_t *__restrict__ valid_mask_keys) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     vals_out[i] = (uint32_t)i;
+    if (valid_mask_keys != nullptr && valid_mask_keys[i] == HV_SORT_SENTINEL) { // pixel rejected by the unprojection
+        keys_out[i] = HV_SORT_SENTINEL;
+        return;
+    }
     const PT p[3] = {pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]};
     uint32_t key = HV_SORT_SENTINEL;
     bool ok = true;
@@ -181,7 +187,8 @@ static int sem_sort_bits(const hv_volume *v) {
 
 template <typename VOX, typename PT>
 static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d_cols, int color_kind,
-                         const int32_t *d_cls, const int32_t *d_inst, const float *d_depths) {
+                         const int32_t *d_cls, const int32_t *d_inst, const float *d_depths,
+                         const uint32_t *valid_mask_keys = nullptr) {
     const HvSemParams G = sem_params(v);
     const unsigned blocks = (unsigned)((n + 255) / 256);
     size_t bytes = 0;
@@ -190,7 +197,7 @@ static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d
     int rc = hv_ensure_buffer(v, &v->sort_tmp, &v->sort_tmp_bytes, bytes);
     if (rc != HV_OK) return rc;
     hipLaunchKernelGGL(k_sem_keys<PT>, dim3(blocks), dim3(256), 0, v->stream, v->table, d_pts, n, G, v->sort_keys_in,
-                       v->sort_vals_in);
+                       v->sort_vals_in, valid_mask_keys);
     bytes = v->sort_tmp_bytes;
     HV_HIP(rocprim::radix_sort_pairs(v->sort_tmp, bytes, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                                      v->sort_vals_out, (size_t)n, 0, sem_sort_bits(v), v->stream));
@@ -330,6 +337,44 @@ int hv_integrate_points_semantic(hv_volume *v, const void *points, int32_t point
                                                  (const int32_t *)d_inst, (const float *)d_dep);
     return sem_integrate<HvSemVoxel, float>(v, (const float *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
                                             (const int32_t *)d_inst, (const float *)d_dep);
+}
+
+int hv_integrate_rgbd_semantic(hv_volume *v, const float *depth, const uint8_t *rgb, const int32_t *class_ids_image,
+                               const int32_t *object_ids_image, int32_t height, int32_t width, const double *intr,
+                               const double *T_cw, double min_depth, double max_depth, int32_t use_depths, int32_t loc) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_integrate_rgbd_semantic: null volume");
+    HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_integrate_rgbd_semantic: volume is not a semantic grid");
+    HV_REQUIRE(depth != nullptr && rgb != nullptr && intr != nullptr && T_cw != nullptr && height > 0 && width > 0,
+               HV_ERR_INVALID, "hv_integrate_rgbd_semantic: null or empty input");
+    HV_REQUIRE(class_ids_image != nullptr || object_ids_image == nullptr, HV_ERR_INVALID,
+               "instance_ids but no class_ids is not supported");
+    const int64_t npx = (int64_t)height * width;
+    HV_REQUIRE(npx <= v->cfg.max_points, HV_ERR_CAPACITY, "hv_integrate_rgbd_semantic: image exceeds max_points");
+    HV_HIP(hipSetDevice(v->device));
+    const void *d_depth = nullptr;
+    int rc = hv_unproject_frame(v, depth, HV_DEPTH_F32, 1.0, rgb, height, width, intr, T_cw, min_depth, max_depth, loc, &d_depth);
+    if (rc != HV_OK) return rc;
+    // label planes: staged behind each other in the output scratch when they come from the host
+    const int32_t *d_cls = class_ids_image, *d_obj = object_ids_image;
+    if (loc == HV_HOST && class_ids_image != nullptr) {
+        const size_t plane = (sizeof(int32_t) * (size_t)npx + 255) & ~(size_t)255;
+        rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, 2 * plane);
+        if (rc != HV_OK) return rc;
+        char *st = (char *)v->out_c;
+        HV_HIP(hipMemcpyAsync(st, class_ids_image, sizeof(int32_t) * npx, hipMemcpyHostToDevice, v->stream));
+        d_cls = (const int32_t *)st;
+        if (object_ids_image != nullptr) {
+            HV_HIP(hipMemcpyAsync(st + plane, object_ids_image, sizeof(int32_t) * npx, hipMemcpyHostToDevice, v->stream));
+            d_obj = (const int32_t *)(st + plane);
+        }
+    }
+    // depths = camera z of the point = the pixel's depth (…voxel_semantic_grid.py:418-424)
+    const float *d_depths = use_depths ? (const float *)d_depth : nullptr;
+    if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID)
+        return sem_integrate<HvProbVoxel, float>(v, v->scratch_points, npx, v->scratch_colors, HV_COLOR_F32, d_cls, d_obj, d_depths,
+                                                 v->sort_keys_out);
+    return sem_integrate<HvSemVoxel, float>(v, v->scratch_points, npx, v->scratch_colors, HV_COLOR_F32, d_cls, d_obj, d_depths,
+                                            v->sort_keys_out);
 }
 
 int hv_get_voxels_semantic(hv_volume *v, int32_t min_count, float min_confidence, double *points, float *colors,

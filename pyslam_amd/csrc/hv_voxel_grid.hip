@@ -408,16 +408,15 @@ int hv_integrate_points(hv_volume *v, const float *points, int64_t n, const void
     return integrate_device_points(v, (const float *)d_pts, n, d_cols, color_dtype, nullptr);
 }
 
-int hv_integrate_rgbd_points(hv_volume *v, const void *depth, int32_t depth_dtype, double depth_scale,
-                             const uint8_t *rgb, int32_t height, int32_t width, const double *intr,
-                             const double *T_cw, double min_depth, double max_depth, int32_t loc) {
-    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_integrate_rgbd_points: null volume");
-    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_GRID, HV_ERR_MODE, "hv_integrate_rgbd_points: volume is not in VOXEL_GRID mode");
-    HV_REQUIRE(depth != nullptr && rgb != nullptr && intr != nullptr && T_cw != nullptr && height > 0 && width > 0,
-               HV_ERR_INVALID, "hv_integrate_rgbd_points: null or empty input");
+} // extern "C" (reopened below)
+
+// Shared front half of the fused RGB-D entry points: stages the frame, runs k_vg_unproject into
+// v->scratch_points / v->scratch_colors (float32) with the per-pixel validity flags in v->sort_keys_out.
+// d_depth_out receives the device address of the (staged) depth image.
+int hv_unproject_frame(hv_volume *v, const void *depth, int32_t depth_dtype, double depth_scale, const uint8_t *rgb,
+                       int32_t height, int32_t width, const double *intr, const double *T_cw, double min_depth,
+                       double max_depth, int32_t loc, const void **d_depth_out) {
     const int64_t npx = (int64_t)height * width;
-    HV_REQUIRE(npx <= v->cfg.max_points, HV_ERR_CAPACITY, "hv_integrate_rgbd_points: image exceeds max_points");
-    HV_HIP(hipSetDevice(v->device));
     const void *d_depth = nullptr, *d_rgb = nullptr;
     int rc = hv_stage_in(v, depth, (size_t)npx * (depth_dtype == HV_DEPTH_U16 ? 2 : 4), loc, 0, &d_depth);
     if (rc != HV_OK) return rc;
@@ -442,9 +441,27 @@ int hv_integrate_rgbd_points(hv_volume *v, const void *depth, int32_t depth_dtyp
     // the unprojection's validity flags go straight into the sort-key input buffer
     hipLaunchKernelGGL(k_vg_unproject, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream, d_depth,
                        (const uint8_t *)d_rgb, U, v->scratch_points, v->scratch_colors, v->sort_keys_out);
+    HV_HIP(hipGetLastError());
+    if (d_depth_out) *d_depth_out = d_depth;
+    return HV_OK;
+}
+
+extern "C" int hv_integrate_rgbd_points(hv_volume *v, const void *depth, int32_t depth_dtype, double depth_scale,
+                             const uint8_t *rgb, int32_t height, int32_t width, const double *intr,
+                             const double *T_cw, double min_depth, double max_depth, int32_t loc) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_integrate_rgbd_points: null volume");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_GRID, HV_ERR_MODE, "hv_integrate_rgbd_points: volume is not in VOXEL_GRID mode");
+    HV_REQUIRE(depth != nullptr && rgb != nullptr && intr != nullptr && T_cw != nullptr && height > 0 && width > 0,
+               HV_ERR_INVALID, "hv_integrate_rgbd_points: null or empty input");
+    const int64_t npx = (int64_t)height * width;
+    HV_REQUIRE(npx <= v->cfg.max_points, HV_ERR_CAPACITY, "hv_integrate_rgbd_points: image exceeds max_points");
+    HV_HIP(hipSetDevice(v->device));
+    int rc = hv_unproject_frame(v, depth, depth_dtype, depth_scale, rgb, height, width, intr, T_cw, min_depth, max_depth, loc, nullptr);
+    if (rc != HV_OK) return rc;
     return integrate_device_points(v, v->scratch_points, npx, v->scratch_colors, HV_COLOR_F32, v->sort_keys_out);
 }
 
+extern "C" {
 
 int hv_filter_shadow_points(hv_volume *v, const float *depth, int32_t height, int32_t width, int32_t delta_x,
                             int32_t delta_y, float fill_value, float *out, int32_t loc) {

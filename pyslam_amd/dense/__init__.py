@@ -17,3 +17,8 @@ from .volumetric_integrator_base import (  # noqa: F401
 from .volumetric_integrator_factory import volumetric_integrator_factory  # noqa: F401
 from .volumetric_integrator_tsdf import VolumetricIntegratorTsdf  # noqa: F401
 from .volumetric_integrator_voxel_grid import VolumetricIntegratorVoxelGrid  # noqa: F401
+from .volumetric_integrator_voxel_semantic_grid import (  # noqa: F401
+    VolumetricIntegrationObject,
+    VolumetricIntegrationObjectList,
+    VolumetricIntegratorVoxelSemanticGrid,
+)

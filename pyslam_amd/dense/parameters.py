@@ -41,6 +41,16 @@ class Parameters:
     kVolumetricIntegrationMinNumLBATimes = 1
     kVolumetricIntegrationOutputTimeInterval = 1.0
     kVolumetricIntegrationUseDepthEstimator = False
+    # semantic integration, config_parameters.py:364-380
+    kVolumetricSemanticProbabilisticIntegrationUseDepth = True
+    kVolumetricSemanticProbabilisticIntegrationDepthThresholdIndoor = 5.0
+    kVolumetricSemanticProbabilisticIntegrationDepthThresholdOutdoor = 10.0
+    kVolumetricSemanticProbabilisticIntegrationDepthDecayRateIndoor = 0.1
+    kVolumetricSemanticProbabilisticIntegrationDepthDecayRateOutdoor = 0.05
+    kVolumetricSemanticIntegrationUseInstanceIds = True
+    kVolumetricSemanticIntegrationMinVoteRatio = 0.5
+    kVolumetricSemanticIntegrationMinVotes = 3
+    kDoSparseSemanticMappingAndSegmentation = False
     kMultiprocessingProcessJoinDefaultTimeout = 5.0
     kLoopDetectingTimeoutPopKeyframe = 0.5
 

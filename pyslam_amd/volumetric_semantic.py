@@ -169,6 +169,26 @@ class _SemanticGridBase(_Volume):
         L.check(self._lib.hv_integrate_points_semantic(self._h, L.ptr(pts), pdt, n, L.ptr(cols), kind, L.ptr(cls), L.ptr(inst),
                                                        L.ptr(dep), L.HV_HOST))
 
+    def integrate_rgbd(self, depth, rgb, fx, fy, cx, cy, T_cw, class_ids_image=None, object_ids_image=None, max_depth=np.inf,
+                       min_depth=0.0, use_depths=True):
+        """Fused per-keyframe prep + integrate (hv_integrate_rgbd_semantic): depth f32 [H,W] metres, rgb u8 [H,W,3]
+        (already RGB), label images i32 [H,W] or None, T_cw world->camera."""
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        H, W = depth.shape
+        if rgb.shape[:2] != (H, W):
+            raise RuntimeError("depth and colour image sizes differ")
+        cls = None if class_ids_image is None else np.ascontiguousarray(class_ids_image, dtype=np.int32)
+        obj = None if object_ids_image is None else np.ascontiguousarray(object_ids_image, dtype=np.int32)
+        for a, name in ((cls, "class_ids"), (obj, "object_ids")):
+            if a is not None and a.shape != (H, W):
+                raise RuntimeError(f"depth and {name} image sizes differ")
+        intr = np.array([fx, fy, cx, cy], np.float64)
+        T = np.ascontiguousarray(T_cw, dtype=np.float64)
+        big = float(np.finfo(np.float32).max)
+        L.check(self._lib.hv_integrate_rgbd_semantic(self._h, L.ptr(depth), L.ptr(rgb), L.ptr(cls), L.ptr(obj), H, W, L.ptr(intr), L.ptr(T),
+                                                     float(min_depth), float(min(max_depth, big)), int(bool(use_depths)), L.HV_HOST))
+
     def get_voxels(self, min_count=1, min_confidence=0.0):
         n = ctypes.c_int64()
         L.check(self._lib.hv_get_voxels_semantic(self._h, int(min_count), float(min_confidence), None, None, None, None, None, 0,
@@ -228,6 +248,9 @@ class _SemanticGridBase(_Volume):
             ctypes.byref(n), L.HV_HOST))
         m = min(n.value, cap)
         return {int(k): int(v) for k, v in zip(mi[:m], mo[:m])}
+
+    def remap_instance_ids(self, instance_ids, instance_id_to_object_id):
+        return remap_instance_ids(instance_ids, instance_id_to_object_id, volume=self)
 
     def get_object_segments(self, min_count=1, min_confidence=0.0):
         """-> ObjectDataGroup (voxel_block_semantic_grid.hpp:217-267); objects in ascending object-id order."""

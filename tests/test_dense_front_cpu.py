@@ -115,3 +115,68 @@ def test_outputs_have_reference_fields(small_params):
     out = VolumetricIntegrationOutput(VolumetricIntegrationTaskType.INTEGRATE, 7, pc, mesh)
     assert (out.task_type, out.id, out.point_cloud, out.mesh, out.objects) == (VolumetricIntegrationTaskType.INTEGRATE, 7, pc, mesh, None)
     assert out.timestamp > 0
+
+
+@pytest.mark.parametrize("kind", ["VOXEL_SEMANTIC_GRID", "VOXEL_SEMANTIC_PROBABILISTIC_GRID"])
+def test_semantic_protocol_end_to_end(kind, small_params, tmp_path):
+    """The semantic integrators behind the same protocol: labelled keyframes in, object lists / labelled point
+    clouds out (volumetric_integrator_voxel_semantic_grid.py:208-748), on the compiled-reference stand-in."""
+    import oracle
+
+    if not oracle.ref_available():
+        pytest.skip("compiled reference not available")
+    from pyslam_amd.dense import VolumetricIntegrationObjectList
+    from tests.semantic_helpers import CFG
+
+    old = (Parameters.kVolumetricIntegrationVoxelGridMinCount, Parameters.kVolumetricIntegrationVoxelGridMinConfidence)
+    Parameters.kVolumetricIntegrationVoxelGridMinCount, Parameters.kVolumetricIntegrationVoxelGridMinConfidence = 1, 0.0
+    s = SyntheticRGBD(dict(CFG, width=160, height=120, fx=131.25, fy=131.25, cx=79.5, cy=59.5), noise=False)
+    cam = dh.FakeCamera(s)
+    integ = volumetric_integrator_factory(VolumetricIntegratorType.from_string(kind), cam, DatasetEnvironmentType.INDOOR,
+                                          SensorType.RGBD, volume_factory=dh.oracle_semantic_factory)
+    try:
+        assert wait_until(integ.is_ready), "worker did not start"
+        outs = []
+        for i in (0, 6, 12):
+            kf = dh.FakeKeyFrame(i, s, cam, semantic=True)
+            integ.add_keyframe(kf, kf.img, None, kf.depth_img)
+            got = []
+            assert wait_until(lambda: (got.append(integ.pop_output(timeout=0.2)) or True) and got[-1] is not None)
+            outs.append(got[-1])
+        last = outs[-1]
+        assert last.task_type == VolumetricIntegrationTaskType.INTEGRATE and last.id == 12
+        assert isinstance(last.objects, VolumetricIntegrationObjectList) and last.point_cloud is None
+        assert last.objects.num_objects == len(last.objects.object_list) >= 1
+        o = last.objects.object_list[0]
+        assert o.points.dtype == np.float32 and o.oriented_bounding_box.box_matrix.shape == (4, 4)
+        assert last.objects.object_colors.shape == (last.objects.num_objects, 3)
+        integ.save(str(tmp_path))
+        pts, cols, faces = read_ply(str(tmp_path / "dense_map.ply"))
+        assert len(pts) > 100 and faces is None
+    finally:
+        integ.quit()
+        Parameters.kVolumetricIntegrationVoxelGridMinCount, Parameters.kVolumetricIntegrationVoxelGridMinConfidence = old
+
+
+def test_semantic_point_cloud_output_without_instances(small_params):
+    """No instance ids -> one labelled point cloud (reference :588-690), in-process on the stand-in volume."""
+    import oracle
+
+    if not oracle.ref_available():
+        pytest.skip("compiled reference not available")
+    from pyslam_amd.dense.volumetric_integrator_voxel_semantic_grid import VolumetricIntegratorVoxelSemanticGrid
+    from tests.semantic_helpers import CFG, semantic_frame
+
+    s = SyntheticRGBD(dict(CFG, width=160, height=120, fx=131.25, fy=131.25, cx=79.5, cy=59.5), noise=False)
+    cam = dh.FakeCamera(s)
+    integ = VolumetricIntegratorVoxelSemanticGrid.__new__(VolumetricIntegratorVoxelSemanticGrid)
+    integ.init(cam, DatasetEnvironmentType.INDOOR, SensorType.RGBD, {}, dict(volume_factory=dh.oracle_semantic_factory))
+    depth, rgb, T, cls_img, _ = semantic_frame(s, 0)
+    integ.integrate_keyframe(rgb, depth, T, cls_img, None)
+    integ.last_integrated_id = 0
+    out = integ.make_output(VolumetricIntegrationTaskType.INTEGRATE)
+    assert out.objects is None and out.point_cloud is not None
+    pc = out.point_cloud
+    assert pc.points.dtype == np.float32 and pc.semantics.dtype == np.int32 and len(pc.points) == len(pc.semantics) > 0
+    assert pc.semantic_colors.shape == pc.points.shape and pc.object_colors.shape == pc.points.shape
+    assert set(np.unique(pc.object_ids)) <= {0}  # no instance image: default object id 0

@@ -114,3 +114,83 @@ def test_tsdf_integrator_end_to_end(tmp_path):
         assert pts.shape == v.shape and faces.shape == t.shape
     finally:
         integ.quit()
+
+
+@pytest.mark.parametrize("probabilistic", [False, True])
+def test_semantic_integrator_matches_reference_flow(probabilistic):
+    """VolumetricIntegratorVoxelSemanticGrid on the real GPU volume vs the same integrator class driving the
+    compiled reference through the stand-in volume: identical labelled voxels after 3 keyframes."""
+    if not oracle.ref_available():
+        pytest.skip("compiled reference not available")
+    from pyslam_amd.dense.parameters import Parameters
+    from pyslam_amd.dense.volumetric_integrator_types import DatasetEnvironmentType, SensorType
+    from pyslam_amd.dense.volumetric_integrator_voxel_semantic_grid import VolumetricIntegratorVoxelSemanticGrid
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric_semantic import set_next_object_id
+    from oracle.semantic import RefSemGrid2
+    from tests.semantic_helpers import CFG, relabel, semantic_frame
+    from tests.test_semantic_oracle import srt
+
+    P = _params(0.02, 0.08)
+    old = (P.kVolumetricIntegrationVoxelGridMinCount, P.kVolumetricIntegrationVoxelGridMinConfidence, P.kVolumetricIntegrationVoxelGridUseCarving)
+    P.kVolumetricIntegrationVoxelGridMinCount, P.kVolumetricIntegrationVoxelGridMinConfidence = 1, 0.0
+    P.kVolumetricIntegrationVoxelGridUseCarving = True
+    try:
+        s = SyntheticRGBD(CFG, noise=True)
+        cam = dh.FakeCamera(s)
+        kw = dict(use_semantic_probabilistic=probabilistic)
+        gpu = VolumetricIntegratorVoxelSemanticGrid.__new__(VolumetricIntegratorVoxelSemanticGrid)
+        gpu.init(cam, DatasetEnvironmentType.INDOOR, SensorType.RGBD, {}, dict(kw))
+        ref = VolumetricIntegratorVoxelSemanticGrid.__new__(VolumetricIntegratorVoxelSemanticGrid)
+        ref.init(cam, DatasetEnvironmentType.INDOOR, SensorType.RGBD, {}, dict(kw, volume_factory=dh.oracle_semantic_factory))
+        set_next_object_id(1)
+        ref.volume.grid.set_next_object_id(1)
+        for i in (0, 6, 12):
+            depth, rgb, T, cls_img, inst_img = semantic_frame(s, i)
+            for integ in (gpu, ref):
+                integ.integrate_keyframe(rgb, depth, T, cls_img, inst_img)
+        a = gpu.volume.get_voxels(1, 0.0)
+        b = ref.volume.get_voxels(1, 0.0)
+        ga = srt((a.points, a.colors, a.class_ids, a.object_ids, a.confidences))
+        gb = srt((b.points, b.colors, b.class_ids, b.object_ids, b.confidences))
+        assert len(ga[0]) == len(gb[0]) > 1000
+        np.testing.assert_array_equal(ga[0], gb[0])
+        np.testing.assert_array_equal(ga[1], gb[1])
+        np.testing.assert_array_equal(ga[2], gb[2])
+        # new object ids may be permuted between instances created in the same call: compare as a partition
+        pairs = set(zip(ga[3].tolist(), gb[3].tolist()))
+        assert len({p[0] for p in pairs}) == len(pairs) == len({p[1] for p in pairs})
+        np.testing.assert_allclose(ga[4], gb[4], rtol=0, atol=0 if not probabilistic else 2e-6)
+        out = gpu.make_output("INTEGRATE")
+        assert out.objects is not None and out.objects.num_objects >= 1
+    finally:
+        (P.kVolumetricIntegrationVoxelGridMinCount, P.kVolumetricIntegrationVoxelGridMinConfidence, P.kVolumetricIntegrationVoxelGridUseCarving) = old
+        RefSemGrid2(0, 0.05).set_depth_threshold(10.0)
+        g = RefSemGrid2(1, 0.05)
+        g.set_depth_threshold(5.0)
+        g.set_depth_decay_rate(0.07)
+
+
+def test_semantic_integrator_worker_process():
+    from pyslam_amd.dense import VolumetricIntegrationObjectList, VolumetricIntegratorType, volumetric_integrator_factory
+    from pyslam_amd.dense.volumetric_integrator_types import DatasetEnvironmentType, SensorType
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from tests.semantic_helpers import CFG
+
+    _params(0.02, 0.08)
+    s = SyntheticRGBD(CFG, noise=False)
+    cam = dh.FakeCamera(s)
+    integ = volumetric_integrator_factory(VolumetricIntegratorType.VOXEL_SEMANTIC_PROBABILISTIC_GRID, cam, DatasetEnvironmentType.INDOOR,
+                                          SensorType.RGBD)
+    try:
+        assert wait_until(integ.is_ready), "worker did not start"
+        last = None
+        for i in (0, 6, 12):
+            kf = dh.FakeKeyFrame(i, s, cam, semantic=True)
+            integ.add_keyframe(kf, kf.img, None, kf.depth_img)
+            out = []
+            assert wait_until(lambda: (out.append(integ.pop_output(timeout=0.2)) or True) and out[-1] is not None)
+            last = out[-1]
+        assert last.id == 12 and isinstance(last.objects, VolumetricIntegrationObjectList)
+    finally:
+        integ.quit()
