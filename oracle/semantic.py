@@ -278,6 +278,33 @@ class RefSemGrid2(_Sem2Base):
         super().__init__(ref_lib(), "ref_sem2_", kind, voxel_size, block_size)
 
 
+class PortSemGrid2(_Sem2Base):
+    """oracle/semantic2_oracle.c: the C restatement of the same two grids."""
+
+    def __init__(self, kind, voxel_size, block_size=8):
+        super().__init__(port_lib(), "so2_", kind, voxel_size, block_size)
+
+
+def port_remap_instance_ids(inst_img, mapping):
+    lib = port_lib()
+    lib.so2_remap_instance_ids.argtypes = [_vp, _i32, _i32, _vp, _vp, _i64, _vp]
+    img = np.ascontiguousarray(inst_img, dtype=np.int32)
+    keys = np.fromiter(mapping.keys(), np.int32, len(mapping))
+    vals = np.fromiter(mapping.values(), np.int32, len(mapping))
+    out = np.empty_like(img)
+    lib.so2_remap_instance_ids(_ptr(img), img.shape[0], img.shape[1], _ptr(keys), _ptr(vals), len(keys), _ptr(out))
+    return out
+
+
+def port_compute_obb_pca(points):
+    lib = port_lib()
+    lib.so2_compute_obb_pca.argtypes = [_vp, _i64, _vp]
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    obb = np.zeros(10, np.float64)
+    lib.so2_compute_obb_pca(_ptr(pts), pts.shape[0], _ptr(obb))
+    return obb
+
+
 def ref_remap_instance_ids(inst_img, mapping):
     lib = ref_lib()
     lib.ref_remap_instance_ids.argtypes = [_vp, _i32, _i32, _vp, _vp, _i64, _vp]

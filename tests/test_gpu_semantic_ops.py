@@ -228,3 +228,34 @@ def test_obb_pca_degenerate_cases():
     local = (P - b.center) @ Rm
     assert (np.abs(local) <= b.size / 2 + 1e-9).all()
     assert np.isclose(np.linalg.det(Rm), 1.0) and C.shape == (8, 3)
+
+
+class _GpuKatGrid:
+    def __init__(self, kind, voxel):
+        self.g = gpu_grid(kind, voxel, max_blocks=1 << 8, max_points=1 << 12)
+
+    def integrate(self, *a):
+        self.g.integrate(*a)
+
+    def get_voxels(self, mc, mconf):
+        v = self.g.get_voxels(mc, mconf)
+        return v.points, v.colors, v.class_ids, v.object_ids, v.confidences
+
+
+def test_reference_kats_on_gpu_both_payloads():
+    """cpp/test_volumetric_voxel_semantic.py replayed on the GPU grids."""
+    from tests.semantic_kats import run_reference_kats
+
+    run_reference_kats(_GpuKatGrid)
+
+
+@pytest.mark.parametrize("kind,name", [(VOTE, "vote"), (PROB, "prob")])
+def test_flow_matches_committed_golden(kind, name):
+    """The pySLAM semantic flow on the GPU against the fixture generated from the compiled reference."""
+    from pyslam_amd.volumetric_semantic import remap_instance_ids
+    from tests.semantic_flow import FLOW_CFG, GpuAsSem2, run_flow
+    from tests.test_semantic2_oracle import check_flow_against_golden
+
+    g = gpu_grid(kind, FLOW_CFG["voxel"])
+    r = run_flow(GpuAsSem2(g), lambda img, m: remap_instance_ids(img, m, volume=g), kind)
+    check_flow_against_golden(r, name, 0.0 if kind == VOTE else 2e-6)

@@ -89,6 +89,17 @@ def main():
     res = [oracle.frustum_contains(intr, s.width, s.height, T, 8.0, 0.01, p, "ref") for p in P]
     np.savez_compressed(os.path.join(OUT, "frustum_contains.npz"), inside=np.array([r[0] for r in res]),
                         uvd=np.stack([r[1] for r in res]), bbox=oracle.frustum_bbox(intr, s.width, s.height, T, 8.0, 0.01, "ref"))
+    # 5. the full semantic grids (voting + probabilistic) through pySLAM's per-frame semantic flow
+    from oracle.semantic import RefSemGrid2, ref_remap_instance_ids
+    from tests.semantic_flow import FLOW_CFG, run_flow
+
+    for kind, name in ((0, "vote"), (1, "prob")):
+        g = RefSemGrid2(kind, FLOW_CFG["voxel"], 8)
+        r = run_flow(g, ref_remap_instance_ids, kind)
+        r["map_keys"] = np.array([",".join(map(str, k)) for k in r["map_keys"]])
+        r["map_valid"] = np.array([",".join(map(str, k)) for k in r["map_valid"]])
+        np.savez_compressed(os.path.join(OUT, f"semantic_flow_{name}.npz"), **r)
+    RefSemGrid2(0, 0.05).set_depth_threshold(10.0)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
