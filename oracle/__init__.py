@@ -367,3 +367,41 @@ def invert4x4(T):
     out = np.zeros((4, 4), np.float64)
     port_lib().to_invert4x4(_ptr(T), _ptr(out))
     return out
+
+
+class RefVoxelGrid:
+    """The compiled reference's direct voxel hash, volumetric::VoxelGrid (cpp/volumetric/voxel_grid.h)."""
+
+    def __init__(self, voxel_size):
+        L = ref_lib()
+        L.ref_vgrid_create.restype = _vp
+        L.ref_vgrid_create.argtypes = [_f64]
+        L.ref_vgrid_destroy.argtypes = [_vp]
+        L.ref_vgrid_size.restype = _i64
+        L.ref_vgrid_size.argtypes = [_vp]
+        L.ref_vgrid_integrate.argtypes = [_vp, _vp, _i64, _vp, _i32]
+        L.ref_vgrid_get_voxels.restype = _i64
+        L.ref_vgrid_get_voxels.argtypes = [_vp, _i32, _f32, _vp, _vp, _i64]
+        self._lib = L
+        self._h = L.ref_vgrid_create(float(voxel_size))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.ref_vgrid_destroy(self._h)
+            self._h = None
+
+    def integrate(self, points, colors=None):
+        points = np.ascontiguousarray(points, dtype=np.float32)
+        kind, cols = _color_kind(colors)
+        self._lib.ref_vgrid_integrate(self._h, _ptr(points), points.shape[0], _ptr(cols), kind)
+
+    def size(self):
+        return self._lib.ref_vgrid_size(self._h)
+
+    def get_voxels(self, min_count=1, min_confidence=0.0):
+        n = self._lib.ref_vgrid_get_voxels(self._h, int(min_count), float(min_confidence), None, None, 0)
+        pts = np.zeros((n, 3), np.float32)
+        cols = np.zeros((n, 3), np.float32)
+        if n:
+            self._lib.ref_vgrid_get_voxels(self._h, int(min_count), float(min_confidence), _ptr(pts), _ptr(cols), n)
+        return pts, cols

@@ -282,3 +282,33 @@ void ref_remap_instance_ids(const int32_t *inst_img, int height, int width, cons
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// The non-default direct voxel hash: VoxelGrid = VoxelGridT<VoxelData> (cpp/volumetric/voxel_grid.h:83-245).
+// float32 points + float32 colours take the reference's SIMD path (voxel_grid_simd.hpp), uint8 colours or
+// float64 points the scalar one (voxel_grid.hpp:136-175).
+// ------------------------------------------------------------------------------------------------
+#include "voxel_grid.h"
+
+extern "C" {
+
+void *ref_vgrid_create(double voxel_size) { return new volumetric::VoxelGrid(voxel_size); }
+void ref_vgrid_destroy(void *g) { delete static_cast<volumetric::VoxelGrid *>(g); }
+int64_t ref_vgrid_size(void *g) { return (int64_t) static_cast<volumetric::VoxelGrid *>(g)->size(); }
+// color_kind: 0 none, 1 uint8, 2 float32
+void ref_vgrid_integrate(void *gv, const float *pts, int64_t n, const void *cols, int color_kind) {
+    auto *g = static_cast<volumetric::VoxelGrid *>(gv);
+    if (color_kind == 0) g->integrate_raw<float>(pts, (size_t)n);
+    else if (color_kind == 1) g->integrate_raw<float, uint8_t>(pts, (size_t)n, static_cast<const uint8_t *>(cols));
+    else g->integrate_raw<float, float>(pts, (size_t)n, static_cast<const float *>(cols));
+}
+int64_t ref_vgrid_get_voxels(void *gv, int min_count, float min_confidence, float *pts, float *cols, int64_t cap) {
+    const auto vg = static_cast<volumetric::VoxelGrid *>(gv)->get_voxels(min_count, min_confidence);
+    const int64_t n = (int64_t)vg.points.size();
+    if (pts != nullptr)
+        for (int64_t i = 0; i < std::min(n, cap); ++i)
+            for (int k = 0; k < 3; ++k) { pts[i * 3 + k] = vg.points[i][k]; cols[i * 3 + k] = vg.colors[i][k]; }
+    return n;
+}
+
+} // extern "C"

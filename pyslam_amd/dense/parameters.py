@@ -41,6 +41,8 @@ class Parameters:
     kVolumetricIntegrationMinNumLBATimes = 1
     kVolumetricIntegrationOutputTimeInterval = 1.0
     kVolumetricIntegrationUseDepthEstimator = False
+    kVolumetricIntegrationDepthEstimatorType = "DEPTH_RAFT_STEREO"
+    kVolumetricIntegrationDepthEstimationFilterShadowPoints = True
     # semantic integration, config_parameters.py:364-380
     kVolumetricSemanticProbabilisticIntegrationUseDepth = True
     kVolumetricSemanticProbabilisticIntegrationDepthThresholdIndoor = 5.0

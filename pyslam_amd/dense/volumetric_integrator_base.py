@@ -431,15 +431,45 @@ class VolumetricIntegratorBase:
         self.dtype_vertices = np.dtype(Parameters.kDenseMappingDtypeVertices)
         self.dtype_colors = np.dtype(Parameters.kDenseMappingDtypeColors)
         self.dtype_depths = np.dtype(Parameters.kDenseMappingDtypeDepth)
+        # depth estimator for keyframes without depth (stereo back-end), base.py:719-756.  The factory is injected
+        # (constructor kwarg `depth_estimator_factory(camera) -> object with infer(img, img_right)`), or taken from
+        # real pySLAM when it is importable; see pyslam_amd/depth_estimation.py for the device-resident wrapper.
+        self.depth_estimator = None
+        self.img_id_to_depth = {}
+        if getattr(Parameters, "kVolumetricIntegrationUseDepthEstimator", False):
+            make = constructor_kwargs.get("depth_estimator_factory")
+            if make is not None:
+                self.depth_estimator = make(camera)
+            else:
+                try:
+                    from pyslam.depth_estimation.depth_estimator_factory import DepthEstimatorType, depth_estimator_factory  # type: ignore
+
+                    self.depth_estimator = depth_estimator_factory(
+                        depth_estimator_type=DepthEstimatorType.from_string(Parameters.kVolumetricIntegrationDepthEstimatorType),
+                        camera=camera)
+                except Exception:
+                    self.depth_estimator = None
 
     def get_camera_intrinsics_for_depth(self):
         return self.rectified_fx, self.rectified_fy, self.rectified_cx, self.rectified_cy
 
-    def estimate_depth_if_needed_and_rectify(self, keyframe_data):  # base.py:969-1062 (no estimator, no remap)
+    def estimate_depth_if_needed_and_rectify(self, keyframe_data):  # base.py:969-1062
+        """-> (color RGB, depth f32 metres, pts3d, semantic, instances).  With a depth estimator (base.py:981-1004;
+        SURVEY 8f N3) the depth may be a torch CUDA tensor that never visits the host: the shadow-point filter,
+        the remap and the fusion all take device pointers."""
         color, depth = keyframe_data.img, keyframe_data.depth
-        if depth is None or depth.size == 0:
-            return None, None, None, None, None
-        if depth.dtype != np.float32:
+        pts3d = None
+        if depth is None or getattr(depth, "size", 1) == 0:
+            if self.depth_estimator is None:
+                return None, None, None, None, None  # skip this keyframe
+            if keyframe_data.id in self.img_id_to_depth:
+                depth = self.img_id_to_depth[keyframe_data.id]
+            else:
+                depth, pts3d = self.depth_estimator.infer(color, keyframe_data.img_right)
+                if getattr(Parameters, "kVolumetricIntegrationDepthEstimationFilterShadowPoints", True):
+                    depth = self.volume.filter_shadow_points(depth)
+        is_dev = hasattr(depth, "data_ptr")
+        if not is_dev and depth.dtype != np.float32:
             factor = getattr(self.camera, "depth_factor", 1.0) if getattr(self, "use_cpp_core", False) else 1.0
             depth = depth.astype(np.float32) * np.float32(factor) if factor != 1.0 else depth.astype(np.float32)
             keyframe_data.depth = depth
@@ -452,8 +482,14 @@ class VolumetricIntegratorBase:
                 semantic = self.volume.remap(np.ascontiguousarray(semantic, dtype=np.int32), m1, m2, linear=False)
             if instances is not None:
                 instances = self.volume.remap(np.ascontiguousarray(instances, dtype=np.int32), m1, m2, linear=False)
+        if self.depth_estimator is not None and keyframe_data.id not in self.img_id_to_depth:
+            self.img_id_to_depth[keyframe_data.id] = depth  # base.py:1050-1052
         color_rgb = np.ascontiguousarray(color[..., ::-1])  # cv2.COLOR_BGR2RGB, base.py:1054
-        return color_rgb, depth, None, semantic, instances
+        if is_dev:  # the fused calls want colour and depth in the same place
+            import torch
+
+            color_rgb = torch.from_numpy(color_rgb).to(depth.device)
+        return color_rgb, depth, pts3d, semantic, instances
 
     def volume_integration(self, *args, **kwargs):  # base.py:1100-1117
         raise NotImplementedError

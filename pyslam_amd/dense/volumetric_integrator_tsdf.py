@@ -89,7 +89,9 @@ class VolumetricIntegratorTsdf(VolumetricIntegratorBase):
                             color, depth, _, _, _ = self.estimate_depth_if_needed_and_rectify(task.keyframe_data)
                             if depth is not None:
                                 frames.append((color, depth, task.keyframe_data.pose, task.keyframe_data.id))
-                        if len(frames) > 1 and hasattr(self.volume, "integrate_batch") and len({f[1].shape for f in frames}) == 1:
+                        on_host = all(isinstance(f[1], np.ndarray) for f in frames)  # estimator depth may live in HBM
+                        if (on_host and len(frames) > 1 and hasattr(self.volume, "integrate_batch")
+                                and len({f[1].shape for f in frames}) == 1):
                             self.volume.integrate_batch(np.stack([f[1] for f in frames]), np.stack([f[0] for f in frames]),
                                                         self.o3d_camera, np.stack([f[2] for f in frames]),
                                                         depth_scale=self.depth_factor,

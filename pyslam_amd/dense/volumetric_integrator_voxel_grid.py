@@ -35,8 +35,8 @@ class VolumetricIntegratorVoxelGrid(VolumetricIntegratorBase):
         self.volumetric_integration_depth_trunc = (
             Parameters.kVolumetricIntegrationTsdfDepthTruncIndoor if indoor else Parameters.kVolumetricIntegrationTsdfDepthTruncOutdoor
         )
-        if not constructor_kwargs.get("use_voxel_blocks", True):
-            raise NotImplementedError("the direct voxel hash (VoxelGrid) is not part of the GPU path; use voxel blocks")
+        # use_voxel_blocks=False selects the reference's direct voxel hash (VoxelGrid): same observable results,
+        # and on the GPU the same block hash underneath (pyslam_amd.volumetric.VoxelGrid)
         factory = constructor_kwargs.get("volume_factory", _default_voxel_grid)
         self.volume = factory(Parameters.kVolumetricIntegrationVoxelLength, Parameters.kVolumetricIntegrationBlockSize,
                               Parameters.kVolumetricIntegrationHipDevice, Parameters.kVolumetricIntegrationHipMaxBlocks,

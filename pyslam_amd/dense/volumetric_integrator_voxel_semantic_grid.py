@@ -97,8 +97,8 @@ class VolumetricIntegratorVoxelSemanticGrid(VolumetricIntegratorBase):
         self.volumetric_integration_depth_trunc = (
             Parameters.kVolumetricIntegrationTsdfDepthTruncIndoor if indoor else Parameters.kVolumetricIntegrationTsdfDepthTruncOutdoor
         )
-        if not constructor_kwargs.get("use_voxel_blocks", True):
-            raise NotImplementedError("the direct voxel hash (VoxelSemanticGrid) is not part of the GPU path; use voxel blocks")
+        # use_voxel_blocks=False (the reference's direct hash VoxelSemanticGrid): same payloads and observable
+        # results; on the GPU it is the same block hash underneath
         probabilistic = bool(constructor_kwargs.get("use_semantic_probabilistic", False))
         factory = constructor_kwargs.get("volume_factory", _default_semantic_grid)
         self.volume = factory(probabilistic, Parameters.kVolumetricIntegrationVoxelLength, Parameters.kVolumetricIntegrationBlockSize,

@@ -100,7 +100,29 @@ class _Volume:
         return out
 
     def remap(self, img, map_x, map_y, linear=False):
-        """cv2.remap(img, map_x, map_y, INTER_LINEAR if linear else INTER_NEAREST) on the GPU (host arrays)."""
+        """cv2.remap(img, map_x, map_y, INTER_LINEAR if linear else INTER_NEAREST) on the GPU.  Host arrays, or a
+        torch CUDA tensor (the maps are then uploaded once and cached): the image never leaves the device."""
+        if hasattr(img, "data_ptr") and img.is_cuda:
+            import torch
+
+            src = img.contiguous()
+            kind = {torch.uint8: 0, torch.float32: 1, torch.int32: 2}.get(src.dtype)
+            if kind is None:
+                raise RuntimeError(f"remap: unsupported image dtype {src.dtype}")
+            key = (id(map_x), id(map_y))
+            if getattr(self, "_dev_maps_key", None) != key:
+                self._dev_maps = (torch.from_numpy(np.ascontiguousarray(map_x, dtype=np.float32)).to(src.device),
+                                  torch.from_numpy(np.ascontiguousarray(map_y, dtype=np.float32)).to(src.device))
+                self._dev_maps_key = key
+            mx, my = self._dev_maps
+            H, W = int(src.shape[0]), int(src.shape[1])
+            C = 1 if src.dim() == 2 else int(src.shape[2])
+            out = torch.empty_like(src)
+            torch.cuda.current_stream(src.device).synchronize()  # producers ran on torch's stream, hv_remap on the volume's
+            L.check(self._lib.hv_remap(self._h, L.ptr(src), kind, C, H, W, L.ptr(mx), L.ptr(my), 1 if linear else 0, L.ptr(out),
+                                       L.HV_DEVICE))
+            self.synchronize()
+            return out
         img = np.ascontiguousarray(img)
         kind = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.int32): 2}.get(img.dtype)
         if kind is None:
@@ -344,6 +366,24 @@ class VoxelBlockGrid(_Volume):
         h = np.zeros(n, np.uint64)
         L.check(self._lib.hv_keys_from_points(self._h, L.ptr(pts), n, L.ptr(vk), L.ptr(bk), L.ptr(lk), L.ptr(h)))
         return vk, bk, lk, h
+
+
+class VoxelGrid(VoxelBlockGrid):
+    """``volumetric.VoxelGrid(voxel_size)`` — the reference's *direct* voxel hash (cpp/volumetric/voxel_grid.h:83-245;
+    selected only with kVolumetricIntegrationUseVoxelBlocks=False).  Its observable results (per-voxel sums in
+    point-index order, get_voxels / queries / carve) are those of the block grid, so on the GPU it is the block hash
+    behind the direct grid's constructor.  Two reference quirks of this non-default path: uint8 colours are dropped
+    by its scalar branch (HasColors = is_same<Tc, float>, voxel_grid.hpp:493-498) — mirrored here; with float32
+    points + float32 colours an AVX2/SSE build accumulates batches of 4 in double (voxel_grid_simd.hpp) — not
+    mirrored (the non-SIMD build, which is what the oracle compiles, matches bit for bit)."""
+
+    def __init__(self, voxel_size=0.05, device=0, max_blocks=None, max_points=None):
+        super().__init__(voxel_size, 8, device=device, max_blocks=max_blocks, max_points=max_points)
+
+    def integrate(self, points, colors=None):
+        if colors is not None and getattr(colors, "dtype", None) == np.uint8:
+            colors = None
+        return super().integrate(points, colors)
 
 
 class TBBUtils:

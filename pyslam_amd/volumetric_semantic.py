@@ -337,6 +337,21 @@ class VoxelBlockSemanticProbabilisticGrid(_SemanticGridBase):
     _MODE = L.HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID
 
 
+class VoxelSemanticGrid(VoxelBlockSemanticGrid):
+    """``volumetric.VoxelSemanticGrid(voxel_size)``: the direct-hash variant of the voting grid
+    (cpp/volumetric/voxel_semantic_grid.h); same payload and observable results as the block grid."""
+
+    def __init__(self, voxel_size=0.05, device=0, max_blocks=None, max_points=None):
+        super().__init__(voxel_size, 8, device=device, max_blocks=max_blocks, max_points=max_points)
+
+
+class VoxelSemanticGridProbabilistic(VoxelBlockSemanticProbabilisticGrid):
+    """``volumetric.VoxelSemanticGridProbabilistic(voxel_size)`` (direct-hash variant, same payload)."""
+
+    def __init__(self, voxel_size=0.05, device=0, max_blocks=None, max_points=None):
+        super().__init__(voxel_size, 8, device=device, max_blocks=max_blocks, max_points=max_points)
+
+
 def get_next_object_id_peek():
     return L.load().hv_peek_next_object_id()
 

@@ -194,3 +194,53 @@ def test_semantic_integrator_worker_process():
         assert last.id == 12 and isinstance(last.objects, VolumetricIntegrationObjectList)
     finally:
         integ.quit()
+
+
+def test_depth_estimator_handoff_stays_on_device():
+    """N3: a stereo keyframe without depth -> torch stereo network -> depth as a CUDA tensor -> shadow filter -> TSDF
+    fusion, no host round trip; identical volume to the same depth taken through numpy."""
+    import torch
+    from pyslam_amd.dense.parameters import Parameters
+    from pyslam_amd.dense.volumetric_integrator_base import VolumetricIntegrationKeyframeData
+    from pyslam_amd.dense.volumetric_integrator_tsdf import VolumetricIntegratorTsdf
+    from pyslam_amd.dense.volumetric_integrator_types import DatasetEnvironmentType, SensorType
+    from pyslam_amd.depth_estimation import DepthEstimatorStereoTorch, make_stub_stereo_net
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import RGBDImage
+
+    _params(0.02, 0.08)
+    old = Parameters.kVolumetricIntegrationUseDepthEstimator
+    Parameters.kVolumetricIntegrationUseDepthEstimator = True
+    try:
+        s = SyntheticRGBD("tiny_160x120_2cm")
+        cam = dh.FakeCamera(s)
+        cam.bf = 40.0
+        net = make_stub_stereo_net()
+        made = []
+
+        def factory(camera, keep=True):
+            made.append(DepthEstimatorStereoTorch(net, camera, "cuda", keep_on_device=keep))
+            return made[-1]
+
+        dev = VolumetricIntegratorTsdf.__new__(VolumetricIntegratorTsdf)
+        dev.init(cam, DatasetEnvironmentType.INDOOR, SensorType.STEREO, {}, dict(depth_estimator_factory=factory))
+        host = VolumetricIntegratorTsdf.__new__(VolumetricIntegratorTsdf)
+        host.init(cam, DatasetEnvironmentType.INDOOR, SensorType.STEREO, {}, dict(depth_estimator_factory=lambda c: factory(c, False)))
+        for i in range(3):
+            kf = dh.FakeKeyFrame(i, s, cam)
+            kf.depth_img = None
+            kf.img_right = np.ascontiguousarray(np.roll(kf.img, 3, axis=1))
+            for integ in (dev, host):
+                kd = VolumetricIntegrationKeyframeData(kf, kf.img, kf.img_right, None)
+                color, depth, _, _, _ = integ.estimate_depth_if_needed_and_rectify(kd)
+                assert (hasattr(depth, "is_cuda") and depth.is_cuda) == (integ is dev)
+                if integ is dev:
+                    assert isinstance(color, torch.Tensor) and color.is_cuda
+                rgbd = RGBDImage.create_from_color_and_depth(color, depth, depth_scale=1.0, depth_trunc=4.0, convert_rgb_to_intensity=False)
+                integ.volume.integrate(rgbd, integ.o3d_camera, kd.pose)
+                assert kd.id in integ.img_id_to_depth  # cached like the reference (base.py:1050-1052)
+        for a, b in zip(dev.volume.dump(), host.volume.dump()):
+            np.testing.assert_array_equal(a, b)
+        assert dev.volume.num_blocks() > 10
+    finally:
+        Parameters.kVolumetricIntegrationUseDepthEstimator = old

@@ -226,3 +226,24 @@ def test_full_size_properties():
     assert n1 == int(occ.sum()) == gpu.get_voxels(1).points.shape[0]
     gpu.reset()
     assert gpu.size() == 0 and gpu.num_blocks() == 0
+
+
+@pytest.mark.skipif(not oracle.ref_available(), reason="compiled reference not available")
+def test_direct_voxel_grid_alias_matches_reference_voxelgrid():
+    """V16: volumetric.VoxelGrid (the non-default direct voxel hash) — same rows as the compiled reference's
+    VoxelGrid, including its dropped-uint8-colours quirk."""
+    from pyslam_amd.volumetric import VoxelGrid
+
+    rng = np.random.default_rng(5)
+    pts = ((rng.random((120000, 3)) - 0.5) * 3).astype(np.float32)
+    for cols in (rng.random((120000, 3)).astype(np.float32), rng.integers(0, 255, (120000, 3)).astype(np.uint8), None):
+        gpu, ref = VoxelGrid(0.05, max_blocks=1 << 13, max_points=1 << 18), oracle.RefVoxelGrid(0.05)
+        for g in (gpu, ref):
+            g.integrate(pts, cols)
+            g.integrate(pts[::2] * 0.5, cols[::2] if cols is not None else None)
+        v = gpu.get_voxels(2)
+        pa, ca = sort_rows(v.points, v.colors)
+        pb, cb = sort_rows(*ref.get_voxels(2))
+        np.testing.assert_array_equal(pa, pb)
+        np.testing.assert_array_equal(ca, cb)
+        assert gpu.size() == ref.size()
