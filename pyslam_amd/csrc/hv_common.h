@@ -235,6 +235,7 @@ struct hv_volume {
     int debug_variant = 0;            // env HV_TSDF_DEBUG_VARIANT (roofline ablation only)
     int32_t frame_counter = 0;
     int32_t last_touch_parity = 0;
+    bool touch_counters_clean = true; // both touched-list counters are zero (false after an online frame)
     void *batch_buf = nullptr;        // multi-frame sweep scratch: B frame records + B HvFrameParams
     size_t batch_buf_bytes = 0;
     // pinned ring of per-batch HvFrameParams (async H2D without a host sync per call)

@@ -279,6 +279,7 @@ int hv_reset(hv_volume *v) {
     memset(v->h_counters, 0, sizeof(int32_t) * HV_CNT_COUNT);
     v->frame_counter = 0;
     v->last_touch_parity = 0;
+    v->touch_counters_clean = true;
     return HV_OK;
 }
 

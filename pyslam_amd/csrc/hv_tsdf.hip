@@ -475,13 +475,40 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
     const void *depth_f = depth_raw + (int64_t)f * depth_stride;
     const uint8_t *rgb_f = rgb + (int64_t)f * npx * 3;
     if ((int)blockIdx.x < n_prep_blocks) {
-        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (i >= npx) return;
-        const uint8_t *c = rgb_f + i * 3;
-        uint2 rec;
-        rec.x = __float_as_uint(hv_convert_depth(P, depth_f, i));
-        rec.y = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
-        frame_px[(int64_t)f * npx + i] = rec;
+        // pack role: 4 pixels per thread — one 16-byte depth load (8 for uint16), three dwords of RGB, two 16-byte
+        // record stores; every wave access is a contiguous burst (prep blocks cover 1024 pixels each)
+        const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+        if (i0 >= npx) return;
+        uint2 *dst = frame_px + (int64_t)f * npx + i0;
+        if (i0 + 4 <= npx && (npx & 3) == 0) {
+            const uint32_t *c4 = (const uint32_t *)(rgb_f + i0 * 3); // i0 % 4 == 0 -> 12-byte multiple: dword aligned
+            const uint32_t w0 = c4[0], w1 = c4[1], w2 = c4[2];
+            const uint32_t col[4] = {w0 & 0xffffffu, (w0 >> 24) | ((w1 & 0xffffu) << 8), (w1 >> 16) | ((w2 & 0xffu) << 16), w2 >> 8};
+            float d[4];
+            if (P.depth_is_u16) {
+                const uint2 raw = *(const uint2 *)((const uint16_t *)depth_f + i0);
+                d[0] = (float)(raw.x & 0xffffu); d[1] = (float)(raw.x >> 16);
+                d[2] = (float)(raw.y & 0xffffu); d[3] = (float)(raw.y >> 16);
+            } else {
+                const float4 raw = *(const float4 *)((const float *)depth_f + i0);
+                d[0] = raw.x; d[1] = raw.y; d[2] = raw.z; d[3] = raw.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { // hv_convert_depth
+                d[k] = d[k] / P.depth_scale_f;
+                if ((double)d[k] >= P.depth_trunc_d) d[k] = 0.0f;
+            }
+            ((uint4 *)dst)[0] = make_uint4(__float_as_uint(d[0]), col[0], __float_as_uint(d[1]), col[1]);
+            ((uint4 *)dst)[1] = make_uint4(__float_as_uint(d[2]), col[2], __float_as_uint(d[3]), col[3]);
+        } else {
+            for (int64_t i = i0; i < npx && i < i0 + 4; ++i) {
+                const uint8_t *c = rgb_f + i * 3;
+                uint2 rec;
+                rec.x = __float_as_uint(hv_convert_depth(P, depth_f, i));
+                rec.y = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+                frame_px[(int64_t)f * npx + i] = rec;
+            }
+        }
         return;
     }
     const int ns_w = (P.W + P.stride - 1) / P.stride;
@@ -553,26 +580,29 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
     }
 }
 
-// ZPW = z-slabs per wave: the workgroup has 16/ZPW waves; fewer slabs per wave = fewer state registers
-// = more resident waves to hide the frame-gather latency.
-template <int ZPW>
-__global__ __launch_bounds__(64 * 16 / ZPW) void k_tsdf_integrate_batch(HvTable table, const int32_t *__restrict__ list,
-                                                               unsigned long long *__restrict__ frame_mask,
+// ZPW = z-slabs per wave, SPLIT = workgroups per unit: a workgroup has 16 / (ZPW * SPLIT) waves and sweeps the
+// z range [part * 16 / SPLIT, (part + 1) * 16 / SPLIT) of its unit.  Fewer slabs per wave = fewer state registers =
+// more resident waves to hide the frame-gather latency; SPLIT > 1 halves the longest work item (a unit seen by all
+// frames of the batch is otherwise one ~250 us workgroup, which bounds the sweep when a GPU owns few units:
+// multi-GPU ownership sharding) and evens out the tail.  Work items are independent: the unit's frame mask is
+// only read here and cleared afterwards by k_tsdf_batch_finish.
+template <int ZPW, int SPLIT>
+__global__ __launch_bounds__(64 * 16 / (ZPW * SPLIT)) void k_tsdf_integrate_batch(HvTable table, const int32_t *__restrict__ list,
+                                                               const unsigned long long *__restrict__ frame_mask,
                                                                char *__restrict__ pool, const uint2 *__restrict__ frame_px,
-                                                               const HvFrameParams *__restrict__ Ps) {
-    int n_units = table.counters[HV_CNT_TOUCH0];
+                                                               const HvFrameParams *__restrict__ Ps, int parity) {
+    int n_units = table.counters[HV_CNT_TOUCH0 + parity];
     if (n_units > table.max_blocks) n_units = table.max_blocks;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int x = lane >> 2;
     const int y0 = (lane & 3) << 2;
-    const int z0 = wave * ZPW;
-    for (int t = blockIdx.x; t < n_units; t += gridDim.x) {
+    for (int item = blockIdx.x; item < n_units * SPLIT; item += gridDim.x) {
+        const int t = item / SPLIT;
+        const int z0 = (item % SPLIT) * (16 / SPLIT) + wave * ZPW;
         const int32_t slot = list[t];
         const int32_t idx = table.vals[slot];
         unsigned long long mask = frame_mask[slot];
-        __syncthreads(); // every wave has read the mask before one of them clears it
-        if (threadIdx.x == 0) frame_mask[slot] = 0ull; // clean for the next batch
         if (idx < 0 || mask == 0ull) continue;
         int32_t ux, uy, uz;
         hv_unpack_key(table.keys[slot], ux, uy, uz);
@@ -653,6 +683,20 @@ __global__ __launch_bounds__(64 * 16 / ZPW) void k_tsdf_integrate_batch(HvTable 
     }
 }
 
+// After the sweep (one workgroup): clear the frame masks of the batch's units and zero both touched-list counters, so
+// that the next batch / online frame starts clean without a memset launch per counter.
+__global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const int32_t *__restrict__ list,
+                                                             unsigned long long *__restrict__ frame_mask, int parity) {
+    int n_units = table.counters[HV_CNT_TOUCH0 + parity];
+    if (n_units > table.max_blocks) n_units = table.max_blocks;
+    __syncthreads(); // every thread holds n_units before the counters are reset
+    for (int t = threadIdx.x; t < n_units; t += blockDim.x) frame_mask[list[t]] = 0ull;
+    if (threadIdx.x == 0) {
+        table.counters[HV_CNT_TOUCH0] = 0;
+        table.counters[HV_CNT_TOUCH1] = 0;
+    }
+}
+
 // Multi-frame sweep with the unit's image footprint staged in LDS.  In the sweep above every voxel
 // evaluation is an 8-byte gather through the vector L1 (64 lanes -> 20-40 distinct lines per
 // instruction); the sweep is bound by that gather path plus VALU, not by HBM.  Here the workgroup
@@ -683,8 +727,7 @@ __global__ __launch_bounds__(512, 4) void k_tsdf_integrate_batch_lds(HvTable tab
         const int32_t slot = list[t];
         const int32_t idx = table.vals[slot];
         unsigned long long mask = frame_mask[slot];
-        __syncthreads(); // every wave has read the mask (and finished with s_rect/s_px of the previous unit)
-        if (tid == 0) frame_mask[slot] = 0ull;
+        __syncthreads(); // every wave has finished with s_rect/s_px of the previous unit
         if (idx < 0 || mask == 0ull) continue;
         int32_t ux, uy, uz;
         hv_unpack_key(table.keys[slot], ux, uy, uz);
@@ -978,6 +1021,7 @@ static void tsdf_next_frame(hv_volume *v, HvFrameParams &P, int &parity) {
     P.frame_id = v->frame_counter;
     parity = v->frame_counter & 1;
     v->last_touch_parity = parity;
+    v->touch_counters_clean = false; // this parity's counter keeps the frame's touched count until the next frame's sweep
 }
 
 // Online path: both halves back to back on the volume's stream.
@@ -1077,8 +1121,11 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         HvFrameParams *d_params = (HvFrameParams *)((char *)v->batch_buf + ((px_bytes + 255) & ~(size_t)255));
         HV_HIP(hipMemcpyAsync(d_params, params, sizeof(HvFrameParams) * (size_t)B, hipMemcpyHostToDevice, v->stream));
         HV_HIP(hipEventRecord(v->params_ev[ri], v->stream));
-        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, sizeof(int32_t), v->stream));
-        const int n_prep_blocks = (int)((npx + 255) / 256);
+        // the touched-list counters are zero after hv_reset and k_tsdf_batch_finish; an online frame leaves its own
+        // parity's count behind
+        if (!v->touch_counters_clean) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
+        v->touch_counters_clean = true;
+        const int n_prep_blocks = (int)((npx + 1023) / 1024); // 4 pixels per thread
         const int stride = v->cfg.depth_sampling_stride;
         const int ns = ((width + stride - 1) / stride) * ((height + stride - 1) / stride);
         const int n_touch_blocks = (ns * HV_TOUCH_FAN + 255) / 256;
@@ -1088,29 +1135,32 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
                            (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks);
         hv_profile_begin(v);
         static const int zpw = getenv("HV_TSDF_BATCH_ZPW") ? atoi(getenv("HV_TSDF_BATCH_ZPW")) : 2;
+        static const int split = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : 2;
         // LDS footprint staging is OFF by default.  Measured on the headline config (frames/s): plain
         // sweep 13.9k; LDS variant 7.4k at 140 VGPRs (one 8-wave workgroup per CU: the load -> barrier ->
         // evaluate phases of a unit cannot overlap another workgroup's) and 12.2k when forced to 128 VGPRs
         // (two workgroups per CU, 24 B/lane scratch).  The two barriers per (unit, frame) still cost more
         // than the L1 gathers they replace; a double-buffered asynchronous patch load is the next step.
         static const int use_lds = getenv("HV_TSDF_BATCH_LDS") ? atoi(getenv("HV_TSDF_BATCH_LDS")) : 0;
+        const unsigned long long *d_mask = (const unsigned long long *)v->touched_mask;
+#define HV_LAUNCH_SWEEP(Z, S)                                                                                          \
+    hipLaunchKernelGGL((k_tsdf_integrate_batch<Z, S>), dim3(8192), dim3(64 * 16 / (Z * S)), 0, v->stream, v->table,      \
+                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0)
         if (use_lds && zpw == 2) {
             hipLaunchKernelGGL(k_tsdf_integrate_batch_lds, dim3(4096), dim3(512), 0, v->stream, v->table, v->touched_list,
                                (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
         } else if (zpw == 4) {
-            hipLaunchKernelGGL(k_tsdf_integrate_batch<4>, dim3(4096), dim3(256), 0, v->stream, v->table, v->touched_list,
-                               (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
+            if (split == 1) HV_LAUNCH_SWEEP(4, 1); else HV_LAUNCH_SWEEP(4, 2);
         } else if (zpw == 1) {
-            hipLaunchKernelGGL(k_tsdf_integrate_batch<1>, dim3(4096), dim3(1024), 0, v->stream, v->table, v->touched_list,
-                               (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
+            if (split == 1) HV_LAUNCH_SWEEP(1, 1); else if (split == 2) HV_LAUNCH_SWEEP(1, 2); else HV_LAUNCH_SWEEP(1, 4);
         } else {
-            hipLaunchKernelGGL(k_tsdf_integrate_batch<2>, dim3(4096), dim3(512), 0, v->stream, v->table, v->touched_list,
-                               (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
+            if (split == 1) HV_LAUNCH_SWEEP(2, 1); else if (split == 4) HV_LAUNCH_SWEEP(2, 4); else if (split == 8) HV_LAUNCH_SWEEP(2, 8); else HV_LAUNCH_SWEEP(2, 2);
         }
+#undef HV_LAUNCH_SWEEP
         hv_profile_end(v, B);
+        hipLaunchKernelGGL(k_tsdf_batch_finish, dim3(1), dim3(1024), 0, v->stream, v->table, v->touched_list,
+                           (unsigned long long *)v->touched_mask, 0);
         HV_HIP(hipGetLastError());
-        // leave both per-frame parity counters clean for a following hv_tsdf_integrate
-        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
     }
     return HV_OK;
 }
