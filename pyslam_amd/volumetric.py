@@ -471,6 +471,10 @@ class ScalableTSDFVolume(_Volume):
             raise RuntimeError("depth and color must live on the same device")
         intr = intrinsic.as_array()
         T = _as_f64_4x4(extrinsic)
+        # the kernels gather from the caller's planes asynchronously on the volume's stream: keep device inputs
+        # alive until the next call (by then the stream has consumed them or they are still referenced here)
+        self._inflight = (getattr(self, "_inflight_prev", None), depth, color)
+        self._inflight_prev = (depth, color)
         L.check(
             self._lib.hv_tsdf_integrate(
                 self._h, L.ptr(depth), dkind, L.ptr(color), H, W, L.ptr(intr), L.ptr(T), image.depth_scale,
@@ -485,6 +489,8 @@ class ScalableTSDFVolume(_Volume):
         F, H, W = (int(s) for s in depth.shape)
         T = np.ascontiguousarray(np.asarray(extrinsics, dtype=np.float64).reshape(F, 16))
         intr = intrinsic.as_array()
+        self._inflight = (getattr(self, "_inflight_prev", None), depth, color)
+        self._inflight_prev = (depth, color)
         L.check(
             self._lib.hv_tsdf_integrate_batch(
                 self._h, L.ptr(depth), dkind, L.ptr(color), F, H, W, L.ptr(intr), L.ptr(T), float(depth_scale),
