@@ -123,8 +123,8 @@ def cpu_baseline_and_counts(s, depth, rgb, T, budget_s, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-step", type=int, default=32)
     ap.add_argument("--config", default="synthetic_640x480_5mm")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)

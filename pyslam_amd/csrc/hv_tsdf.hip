@@ -192,11 +192,39 @@ __device__ __forceinline__ bool hv_tsdf_update(const HvFrameParams &P, const uin
 // Two-phase form of the same update: hv_tsdf_eval decides whether the voxel is updated and with
 // what (needs only the frame), hv_tsdf_apply folds it into the voxel state.  Splitting them lets the
 // kernel fetch voxel planes only for lanes that really update something.
+// a0 / b and a1 / b, both correctly rounded (bit-identical to the IEEE divisions the reference performs), sharing one
+// refined reciprocal: v_rcp_f32 + one Newton step, then the quotient / residual / correction chain the compiler itself
+// emits for an f32 division, minus v_div_scale / v_div_fixup, which are no-ops while the operands stay clear of the
+// overflow / denormal bands.  Verified exhaustively-at-random on gfx950: 0 mismatches in 1.4e11 divisions with
+// operands in 2^-60 .. 2^60 (tools/divtest.hip); callers guarantee b >= 2^-20 and |a| < 2^60.
+__device__ __forceinline__ void hv_div2(float a0, float a1, float b, float &q0, float &q1) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = fmaf(-b, r, 1.0f);
+    r = fmaf(e, r, r);
+    float q = a0 * r;
+    float rem = fmaf(-b, q, a0);
+    q = fmaf(rem, r, q);
+    rem = fmaf(-b, q, a0);
+    q0 = fmaf(rem, r, q);
+    q = a1 * r;
+    rem = fmaf(-b, q, a1);
+    q = fmaf(rem, r, q);
+    rem = fmaf(-b, q, a1);
+    q1 = fmaf(rem, r, q);
+}
+
 __device__ __forceinline__ bool hv_tsdf_eval(const HvFrameParams &P, const uint2 *__restrict__ frame_px, float pc0,
                                              float pc1, float pc2, float &t, uint32_t &rgb) {
     if (pc2 <= 0.0f) return false;
-    const float u_f = pc0 * P.fx / pc2 + P.cx + 0.5f;
-    const float v_f = pc1 * P.fy / pc2 + P.cy + 0.5f;
+    float q0, q1;
+    if (pc2 >= 0x1p-20f) { // always, for voxels a camera can resolve
+        hv_div2(pc0 * P.fx, pc1 * P.fy, pc2, q0, q1);
+    } else {
+        q0 = pc0 * P.fx / pc2;
+        q1 = pc1 * P.fy / pc2;
+    }
+    const float u_f = q0 + P.cx + 0.5f;
+    const float v_f = q1 + P.cy + 0.5f;
     if (!(u_f >= 0.0001f && u_f < P.safe_width_f && v_f >= 0.0001f && v_f < P.safe_height_f)) return false;
     const int u = (int)u_f;
     const int v = (int)v_f;
@@ -683,6 +711,100 @@ __global__ __launch_bounds__(64 * 16 / (ZPW * SPLIT)) void k_tsdf_integrate_batc
     }
 }
 
+// Column mapping of the same sweep: lane -> one (x, y) column of the unit, wave -> 64 consecutive columns (4 x-values:
+// word index z*256 + cg*64 + lane, so every plane access of a wave is one contiguous 256-byte dword burst) and ZH
+// consecutive z.  Compared with the slab mapping above (lane -> 4 y's of one x, 2 z-slabs per wave) a lane projects ONE
+// column per frame instead of four and replays at most 16 - ZH steps of the reference's z-walk instead of up to 14
+// steps on four columns: fewer VALU instructions per voxel (the sweep is VALU-bound: 85 % VALU busy).
+// A unit = 4 column groups x (16 / ZH) z ranges = 64 / ZH wave tasks, SPLIT workgroups per unit.
+template <int ZH, int SPLIT>
+__global__ __launch_bounds__(64 * (64 / ZH) / SPLIT) void k_tsdf_integrate_batch_col(
+    HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
+    char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int parity) {
+    constexpr int TASKS = 64 / ZH;          // wave tasks per unit
+    constexpr int WAVES = TASKS / SPLIT;    // waves per workgroup
+    int n_units = table.counters[HV_CNT_TOUCH0 + parity];
+    if (n_units > table.max_blocks) n_units = table.max_blocks;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    for (int item = blockIdx.x; item < n_units * SPLIT; item += gridDim.x) {
+        const int t = item / SPLIT;
+        const int task = (item % SPLIT) * WAVES + wave;
+        const int cg = task & 3;            // column group: x in [4 cg, 4 cg + 4)
+        const int z0 = (task >> 2) * ZH;
+        const int x = cg * 4 + (lane >> 4);
+        const int y = lane & 15;
+        const int32_t slot = list[t];
+        const int32_t idx = table.vals[slot];
+        unsigned long long mask = frame_mask[slot];
+        if (idx < 0 || mask == 0ull) continue;
+        int32_t ux, uy, uz;
+        hv_unpack_key(table.keys[slot], ux, uy, uz);
+        char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
+        const int wordb = z0 * RR + cg * 64 + lane;
+        float vt[ZH];
+        uint32_t vw[ZH], vr[ZH], vg[ZH], vb[ZH];
+#pragma unroll
+        for (int zz = 0; zz < ZH; ++zz) {
+            const int q = wordb + zz * RR;
+            vt[zz] = ((const float *)(unit + 0 * PLANE_BYTES))[q];
+            vw[zz] = ((const uint32_t *)(unit + 1 * PLANE_BYTES))[q];
+            vr[zz] = ((const uint32_t *)(unit + 2 * PLANE_BYTES))[q];
+            vg[zz] = ((const uint32_t *)(unit + 3 * PLANE_BYTES))[q];
+            vb[zz] = ((const uint32_t *)(unit + 4 * PLANE_BYTES))[q];
+        }
+        unsigned dirty = 0;
+        // the voxel centre of (x, y, z = 0) does not depend on the frame (voxel / unit length are the volume's)
+        float p0, p1, p2;
+        {
+            const HvFrameParams &P = Ps[__ffsll((long long)mask) - 1];
+            const double o0 = (double)ux * P.unit_length;
+            const double o1 = (double)uy * P.unit_length;
+            const double o2 = (double)uz * P.unit_length;
+            p0 = (float)((double)(P.half_voxel_length_f + P.voxel_length_f * (float)x) + o0);
+            p1 = (float)((double)(P.half_voxel_length_f + P.voxel_length_f * (float)y) + o1);
+            p2 = (float)((double)P.half_voxel_length_f + o2);
+        }
+        while (mask) {
+            const int f = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const HvFrameParams &P = Ps[f];
+            const uint2 *px = frame_px + (int64_t)f * P.H * P.W;
+            const float inc0 = P.ext_scaled_col2[0], inc1 = P.ext_scaled_col2[1], inc2 = P.ext_scaled_col2[2];
+            float pc0 = ((P.ext[0] * p0 + P.ext[1] * p1) + P.ext[2] * p2) + P.ext[3];
+            float pc1 = ((P.ext[4] * p0 + P.ext[5] * p1) + P.ext[6] * p2) + P.ext[7];
+            float pc2 = ((P.ext[8] * p0 + P.ext[9] * p1) + P.ext[10] * p2) + P.ext[11];
+            for (int s = 0; s < z0; ++s) { // the reference's repeated float additions along z, replayed
+                pc0 += inc0;
+                pc1 += inc1;
+                pc2 += inc2;
+            }
+#pragma unroll
+            for (int zz = 0; zz < ZH; ++zz) {
+                float tv = 0.f;
+                uint32_t cv = 0u;
+                const bool ok = hv_tsdf_eval(P, px, pc0, pc1, pc2, tv, cv);
+                pc0 += inc0;
+                pc1 += inc1;
+                pc2 += inc2;
+                hv_tsdf_apply(ok, tv, cv, vt[zz], vw[zz], vr[zz], vg[zz], vb[zz]);
+                if (ok) dirty |= 1u << zz;
+            }
+        }
+#pragma unroll
+        for (int zz = 0; zz < ZH; ++zz) {
+            if (dirty & (1u << zz)) {
+                const int q = wordb + zz * RR;
+                ((float *)(unit + 0 * PLANE_BYTES))[q] = vt[zz];
+                ((uint32_t *)(unit + 1 * PLANE_BYTES))[q] = vw[zz];
+                ((uint32_t *)(unit + 2 * PLANE_BYTES))[q] = vr[zz];
+                ((uint32_t *)(unit + 3 * PLANE_BYTES))[q] = vg[zz];
+                ((uint32_t *)(unit + 4 * PLANE_BYTES))[q] = vb[zz];
+            }
+        }
+    }
+}
+
 // After the sweep (one workgroup): clear the frame masks of the batch's units and zero both touched-list counters, so
 // that the next batch / online frame starts clean without a memset launch per counter.
 __global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const int32_t *__restrict__ list,
@@ -1135,7 +1257,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
                            (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks);
         hv_profile_begin(v);
         static const int zpw = getenv("HV_TSDF_BATCH_ZPW") ? atoi(getenv("HV_TSDF_BATCH_ZPW")) : 2;
-        static const int split = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : 2;
+        static const int split = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : 4;
         // LDS footprint staging is OFF by default.  Measured on the headline config (frames/s): plain
         // sweep 13.9k; LDS variant 7.4k at 140 VGPRs (one 8-wave workgroup per CU: the load -> barrier ->
         // evaluate phases of a unit cannot overlap another workgroup's) and 12.2k when forced to 128 VGPRs
@@ -1146,9 +1268,21 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
 #define HV_LAUNCH_SWEEP(Z, S)                                                                                          \
     hipLaunchKernelGGL((k_tsdf_integrate_batch<Z, S>), dim3(8192), dim3(64 * 16 / (Z * S)), 0, v->stream, v->table,      \
                        v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0)
+        static const int layout_col = getenv("HV_TSDF_BATCH_COL") ? atoi(getenv("HV_TSDF_BATCH_COL")) : 4; // ZH of the column mapping (default), 0 = slab mapping
+#define HV_LAUNCH_COL(Z, S)                                                                                            \
+    hipLaunchKernelGGL((k_tsdf_integrate_batch_col<Z, S>), dim3(8192), dim3(64 * (64 / Z) / S), 0, v->stream, v->table,   \
+                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0)
         if (use_lds && zpw == 2) {
             hipLaunchKernelGGL(k_tsdf_integrate_batch_lds, dim3(4096), dim3(512), 0, v->stream, v->table, v->touched_list,
                                (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
+        } else if (layout_col == 8) {
+            if (split == 1) HV_LAUNCH_COL(8, 1); else if (split == 4) HV_LAUNCH_COL(8, 4); else if (split == 8) HV_LAUNCH_COL(8, 8); else HV_LAUNCH_COL(8, 2);
+        } else if (layout_col == 16) {
+            if (split == 1) HV_LAUNCH_COL(16, 1); else if (split == 4) HV_LAUNCH_COL(16, 4); else HV_LAUNCH_COL(16, 2);
+        } else if (layout_col == 4) {
+            if (split == 1) HV_LAUNCH_COL(4, 1); else if (split == 4) HV_LAUNCH_COL(4, 4); else if (split == 8) HV_LAUNCH_COL(4, 8); else if (split == 16) HV_LAUNCH_COL(4, 16); else HV_LAUNCH_COL(4, 2);
+        } else if (layout_col == 2) {
+            if (split == 4) HV_LAUNCH_COL(2, 4); else if (split == 8) HV_LAUNCH_COL(2, 8); else if (split == 16) HV_LAUNCH_COL(2, 16); else HV_LAUNCH_COL(2, 2);
         } else if (zpw == 4) {
             if (split == 1) HV_LAUNCH_SWEEP(4, 1); else HV_LAUNCH_SWEEP(4, 2);
         } else if (zpw == 1) {
@@ -1157,6 +1291,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
             if (split == 1) HV_LAUNCH_SWEEP(2, 1); else if (split == 4) HV_LAUNCH_SWEEP(2, 4); else if (split == 8) HV_LAUNCH_SWEEP(2, 8); else HV_LAUNCH_SWEEP(2, 2);
         }
 #undef HV_LAUNCH_SWEEP
+#undef HV_LAUNCH_COL
         hv_profile_end(v, B);
         hipLaunchKernelGGL(k_tsdf_batch_finish, dim3(1), dim3(1024), 0, v->stream, v->table, v->touched_list,
                            (unsigned long long *)v->touched_mask, 0);
