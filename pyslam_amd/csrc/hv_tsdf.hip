@@ -812,7 +812,19 @@ __global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const
     int n_units = table.counters[HV_CNT_TOUCH0 + parity];
     if (n_units > table.max_blocks) n_units = table.max_blocks;
     __syncthreads(); // every thread holds n_units before the counters are reset
-    for (int t = threadIdx.x; t < n_units; t += blockDim.x) frame_mask[list[t]] = 0ull;
+    // 8 independent list loads in flight per thread, then the 8 stores: two memory latencies per 8192 units instead
+    // of two per 1024
+    for (int base = 0; base < n_units; base += 8 * (int)blockDim.x) {
+        int32_t slot[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = base + k * (int)blockDim.x + (int)threadIdx.x;
+            slot[k] = t < n_units ? list[t] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (slot[k] >= 0) frame_mask[slot[k]] = 0ull;
+    }
     if (threadIdx.x == 0) {
         table.counters[HV_CNT_TOUCH0] = 0;
         table.counters[HV_CNT_TOUCH1] = 0;
