@@ -174,6 +174,15 @@ int hv_integrate_rgbd_semantic(hv_volume *v, const float *depth, const uint8_t *
  * confidences f32 [M] (host).  points == NULL: size query. */
 int hv_get_voxels_semantic(hv_volume *v, int32_t min_count, float min_confidence, double *points, float *colors,
                            int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap, int64_t *n);
+/* get_voxels_in_bb / get_voxels_in_camera_frustrum for semantic voxels (voxel_block_grid.hpp:822-1016, 1019-1195; the
+ * label / confidence outputs are what IncludeSemantics=true adds).  Same output conventions as hv_get_voxels_semantic. */
+int hv_get_voxels_semantic_in_bb(hv_volume *v, const double *bbox, int32_t min_count, float min_confidence, double *points,
+                                 float *colors, int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap,
+                                 int64_t *n);
+int hv_get_voxels_semantic_in_frustum(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw,
+                                      float depth_max, float depth_min, int32_t min_count, float min_confidence, double *points,
+                                      float *colors, int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap,
+                                      int64_t *n);
 /* set_depth_threshold() (voxel_block_semantic_grid.hpp:24-30): voting: observations with depth >= threshold do
  * not vote (voxel_data_semantic.h:168-198); probabilistic: beyond it the evidence decays (:337-352).  Defaults
  * 10 m / 5 m.  The reference keeps these as process-wide statics; here they are per volume. */

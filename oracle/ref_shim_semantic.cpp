@@ -312,3 +312,57 @@ int64_t ref_vgrid_get_voxels(void *gv, int min_count, float min_confidence, floa
 }
 
 } // extern "C"
+
+// ---- spatial queries with semantics, integrate_segment, get_class_segments ------------------------------------
+namespace {
+template <typename VG>
+int64_t copy_sem(const VG &vg, double *pts, float *cols, int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap) {
+    const int64_t n = (int64_t)vg.points.size();
+    if (pts != nullptr) {
+        for (int64_t i = 0; i < std::min(n, cap); ++i) {
+            for (int k = 0; k < 3; ++k) { pts[i * 3 + k] = vg.points[i][k]; cols[i * 3 + k] = vg.colors[i][k]; }
+            class_ids[i] = vg.class_ids[i];
+            object_ids[i] = vg.object_ids[i];
+            confidences[i] = vg.confidences[i];
+        }
+    }
+    return n;
+}
+template <typename G>
+int64_t class_segments_g(const G *g, int min_count, float min_confidence, int32_t *ids, float *conf, int64_t cap) {
+    const auto group = g->get_class_segments(min_count, min_confidence);
+    std::vector<std::shared_ptr<volumetric::ClassData>> cs(group->class_vector.begin(), group->class_vector.end());
+    std::sort(cs.begin(), cs.end(), [](const auto &a, const auto &b) { return a->class_id < b->class_id; });
+    for (size_t i = 0; i < cs.size() && (int64_t)i < cap; ++i) {
+        if (ids) { ids[i * 2] = cs[i]->class_id; ids[i * 2 + 1] = (int32_t)cs[i]->points.size(); }
+        if (conf) { conf[i * 2] = cs[i]->confidence_min; conf[i * 2 + 1] = cs[i]->confidence_max; }
+    }
+    return (int64_t)cs.size();
+}
+} // namespace
+
+extern "C" {
+
+int64_t ref_sem2_get_voxels_in_bb(void *h, const double *bb, int min_count, float min_confidence, double *pts, float *cols,
+                                  int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap) {
+    volumetric::BoundingBox3D bbox(bb[0], bb[1], bb[2], bb[3], bb[4], bb[5]);
+    if (H(h)->kind == 0) return copy_sem(H(h)->vote->get_voxels_in_bb<true>(bbox, min_count, min_confidence), pts, cols, class_ids, object_ids, confidences, cap);
+    return copy_sem(H(h)->prob->get_voxels_in_bb<true>(bbox, min_count, min_confidence), pts, cols, class_ids, object_ids, confidences, cap);
+}
+int64_t ref_sem2_get_voxels_in_frustum(void *h, const float *intr, int width, int height, const double *T_cw, float depth_max,
+                                       float depth_min, int min_count, float min_confidence, double *pts, float *cols,
+                                       int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap) {
+    const CameraFrustrum fr = make_frustum(intr, width, height, T_cw, depth_max, depth_min);
+    if (H(h)->kind == 0) return copy_sem(H(h)->vote->get_voxels_in_camera_frustrum<true>(fr, min_count, min_confidence), pts, cols, class_ids, object_ids, confidences, cap);
+    return copy_sem(H(h)->prob->get_voxels_in_camera_frustrum<true>(fr, min_count, min_confidence), pts, cols, class_ids, object_ids, confidences, cap);
+}
+void ref_sem2_integrate_segment(void *h, const double *pts, int64_t n, const float *cols, int object_id, int class_id) {
+    if (H(h)->kind == 0) H(h)->vote->integrate_segment_raw<double, float, int, int>(pts, (size_t)n, cols, class_id, object_id);
+    else H(h)->prob->integrate_segment_raw<double, float, int, int>(pts, (size_t)n, cols, class_id, object_id);
+}
+int64_t ref_sem2_get_class_segments(void *h, int min_count, float min_confidence, int32_t *ids, float *conf, int64_t cap) {
+    return DISPATCH(h, class_segments_g(H(h)->vote, min_count, min_confidence, ids, conf, cap),
+                    class_segments_g(H(h)->prob, min_count, min_confidence, ids, conf, cap));
+}
+
+} // extern "C"

@@ -314,3 +314,58 @@ def ref_remap_instance_ids(inst_img, mapping):
     out = np.empty_like(img)
     lib.ref_remap_instance_ids(_ptr(img), img.shape[0], img.shape[1], _ptr(keys), _ptr(vals), len(keys), _ptr(out))
     return out
+
+
+def _bind_queries(lib):
+    lib.ref_sem2_get_voxels_in_bb.restype = _i64
+    lib.ref_sem2_get_voxels_in_bb.argtypes = [_vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i64]
+    lib.ref_sem2_get_voxels_in_frustum.restype = _i64
+    lib.ref_sem2_get_voxels_in_frustum.argtypes = [_vp, _vp, _i32, _i32, _vp, _f32, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i64]
+    lib.ref_sem2_integrate_segment.argtypes = [_vp, _vp, _i64, _vp, _i32, _i32]
+    lib.ref_sem2_get_class_segments.restype = _i64
+    lib.ref_sem2_get_class_segments.argtypes = [_vp, _i32, _f32, _vp, _vp, _i64]
+
+
+def _rows(fn):
+    n = fn(None, None, None, None, None, 0)
+    pts, cols = np.zeros((n, 3), np.float64), np.zeros((n, 3), np.float32)
+    cls, obj, conf = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+    if n:
+        fn(_ptr(pts), _ptr(cols), _ptr(cls), _ptr(obj), _ptr(conf), n)
+    return pts, cols, cls, obj, conf
+
+
+def ref_get_voxels_in_bb(grid, bb, min_count=1, min_confidence=0.0):
+    """RefSemGrid2.get_voxels_in_bb<IncludeSemantics=true>."""
+    lib = ref_lib()
+    _bind_queries(lib)
+    bb = np.ascontiguousarray(bb, dtype=np.float64)
+    return _rows(lambda *a: lib.ref_sem2_get_voxels_in_bb(grid._h, _ptr(bb), int(min_count), float(min_confidence), *a))
+
+
+def ref_get_voxels_in_frustum(grid, intr, width, height, T_cw, depth_max, depth_min, min_count=1, min_confidence=0.0):
+    lib = ref_lib()
+    _bind_queries(lib)
+    intr = np.ascontiguousarray(intr, dtype=np.float32)
+    T = np.ascontiguousarray(T_cw, dtype=np.float64)
+    return _rows(lambda *a: lib.ref_sem2_get_voxels_in_frustum(grid._h, _ptr(intr), width, height, _ptr(T), depth_max, depth_min,
+                                                               int(min_count), float(min_confidence), *a))
+
+
+def ref_integrate_segment(grid, points, colors, object_id, class_id):
+    lib = ref_lib()
+    _bind_queries(lib)
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    cols = np.ascontiguousarray(colors, dtype=np.float32)
+    lib.ref_sem2_integrate_segment(grid._h, _ptr(pts), pts.shape[0], _ptr(cols), int(object_id), int(class_id))
+
+
+def ref_get_class_segments(grid, min_count=1, min_confidence=0.0):
+    """-> ids [C,2] {class_id, n_points}, conf [C,2] {min, max}, ascending class id."""
+    lib = ref_lib()
+    _bind_queries(lib)
+    n = lib.ref_sem2_get_class_segments(grid._h, int(min_count), float(min_confidence), None, None, 0)
+    ids, conf = np.zeros((n, 2), np.int32), np.zeros((n, 2), np.float32)
+    if n:
+        lib.ref_sem2_get_class_segments(grid._h, int(min_count), float(min_confidence), _ptr(ids), _ptr(conf), n)
+    return ids, conf

@@ -67,6 +67,8 @@ SIGNATURES = {
     "hv_keys_from_points": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "hv_integrate_points_semantic": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp, _i32]),
     "hv_get_voxels_semantic": (_i32, [_vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _pi64]),
+    "hv_get_voxels_semantic_in_bb": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _pi64]),
+    "hv_get_voxels_semantic_in_frustum": (_i32, [_vp, _vp, _i32, _i32, _vp, _f32, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _pi64]),
     "hv_set_depth_threshold": (_i32, [_vp, _f32]),
     "hv_dump_blocks_semantic": (_i32, [_vp, _vp, _vp, _vp, _vp, _pi64]),
     "hv_dump_blocks_semantic2": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi64]),

@@ -147,12 +147,14 @@ __global__ __launch_bounds__(256) void k_sem_reduce(HvTable table, VOX *__restri
     vx->col[2] = col[2];
 }
 
-// get_voxels(min_count, min_confidence), voxel_block_grid.hpp:785-817 (semantic branch)
+// get_voxels(min_count, min_confidence) (voxel_block_grid.hpp:785-817, semantic branch) and, with Q.kind 1 / 2,
+// get_voxels_in_bb (:944-1013) / get_voxels_in_camera_frustrum (:1019-1195) for semantic voxels.
 template <typename VOX>
 __global__ __launch_bounds__(256) void k_sem_collect(HvTable table, const VOX *__restrict__ pool, int64_t n_voxels,
-                                                      int min_count, float min_confidence, double *__restrict__ out_pts,
-                                                      float *__restrict__ out_cols, int32_t *__restrict__ out_cls,
-                                                      int32_t *__restrict__ out_obj, float *__restrict__ out_conf, int64_t cap) {
+                                                      HvSemParams G, HvQuery Q, int min_count, float min_confidence,
+                                                      double *__restrict__ out_pts, float *__restrict__ out_cols,
+                                                      int32_t *__restrict__ out_cls, int32_t *__restrict__ out_obj,
+                                                      float *__restrict__ out_conf, int64_t cap) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool pred = false;
     float conf = 0.f;
@@ -162,6 +164,27 @@ __global__ __launch_bounds__(256) void k_sem_collect(HvTable table, const VOX *_
         count = v->count;
         conf = sem_confidence(v);
         pred = count >= min_count && conf >= min_confidence;
+        if (pred && Q.kind != 0) {
+            int32_t bk[3];
+            hv_unpack_key(table.block_keys[gid / G.nvox], bk[0], bk[1], bk[2]);
+            const int l = (int)(gid % G.nvox);
+            const int32_t lc[3] = {l % G.bs, (l / G.bs) % G.bs, l / (G.bs * G.bs)};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int32_t vk = bk[a] * G.bs + lc[a];
+                if (bk[a] < Q.bmin[a] || bk[a] > Q.bmax[a] || vk < Q.vmin[a] || vk > Q.vmax[a]) pred = false;
+            }
+            if (pred) {
+                const double c = (double)count;
+                const double p0 = v->pos[0] / c, p1 = v->pos[1] / c, p2 = v->pos[2] / c;
+                if (Q.kind == 1) { // BoundingBox3D::contains, bounding_boxes_3d.cpp:207-210
+                    pred = p0 >= Q.bb[0] && p0 <= Q.bb[3] && p1 >= Q.bb[1] && p1 <= Q.bb[4] && p2 >= Q.bb[2] && p2 <= Q.bb[5];
+                } else {
+                    float uvd[3];
+                    pred = hv_frustum_contains_d(Q, p0, p1, p2, uvd);
+                }
+            }
+        }
     }
     const int32_t at = hv_wave_append(&table.counters[HV_CNT_OUT], pred);
     if (pred && at < cap && out_pts != nullptr) {
@@ -267,6 +290,56 @@ static int sem_dump(hv_volume *v, int64_t nb, const std::vector<int64_t> &order,
             } else if (label_counts) {
                 label_counts[at] = 0;
             }
+        }
+    }
+    return HV_OK;
+}
+
+static int sem_run_collect(hv_volume *v, const HvQuery &Q, int32_t min_count, float min_confidence, double *points, float *colors,
+                           int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap, int64_t *n) {
+    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_get_voxels_semantic: null argument");
+    HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_get_voxels_semantic: volume is not a semantic grid");
+    HV_HIP(hipSetDevice(v->device));
+    int64_t nb = 0;
+    int rc = hv_num_blocks(v, &nb);
+    if (rc != HV_OK) return rc;
+    *n = 0;
+    if (nb == 0) return HV_OK;
+    const int64_t total = nb * sem_params(v).nvox;
+    const bool want = points && colors && class_ids && object_ids && confidences && cap > 0;
+    double *d_pts = nullptr;
+    float *d_cols = nullptr, *d_conf = nullptr;
+    int32_t *d_cls = nullptr, *d_obj = nullptr;
+    if (want) {
+        rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, (size_t)cap * (24 + 12 + 4 + 4 + 4) + 1024);
+        if (rc != HV_OK) return rc;
+        d_pts = (double *)v->out_a;
+        d_cols = (float *)(d_pts + 3 * cap);
+        d_cls = (int32_t *)(d_cols + 3 * cap);
+        d_obj = d_cls + cap;
+        d_conf = (float *)(d_obj + cap);
+    }
+    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID)
+        hipLaunchKernelGGL(k_sem_collect<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvProbVoxel *)v->pool,
+                           total, sem_params(v), Q, min_count, min_confidence, d_pts, d_cols, d_cls, d_obj, d_conf, want ? cap : 0);
+    else
+        hipLaunchKernelGGL(k_sem_collect<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvSemVoxel *)v->pool,
+                           total, sem_params(v), Q, min_count, min_confidence, d_pts, d_cols, d_cls, d_obj, d_conf, want ? cap : 0);
+    HV_HIP(hipGetLastError());
+    rc = hv_read_counters(v);
+    if (rc != HV_OK) return rc;
+    *n = v->h_counters[HV_CNT_OUT];
+    if (want) {
+        const int64_t m = std::min(*n, cap);
+        if (m > 0) {
+            HV_HIP(hipMemcpyAsync(points, d_pts, 24 * m, hipMemcpyDeviceToHost, v->stream));
+            HV_HIP(hipMemcpyAsync(colors, d_cols, 12 * m, hipMemcpyDeviceToHost, v->stream));
+            HV_HIP(hipMemcpyAsync(class_ids, d_cls, 4 * m, hipMemcpyDeviceToHost, v->stream));
+            HV_HIP(hipMemcpyAsync(object_ids, d_obj, 4 * m, hipMemcpyDeviceToHost, v->stream));
+            HV_HIP(hipMemcpyAsync(confidences, d_conf, 4 * m, hipMemcpyDeviceToHost, v->stream));
+            HV_HIP(hipStreamSynchronize(v->stream));
         }
     }
     return HV_OK;
@@ -379,52 +452,38 @@ int hv_integrate_rgbd_semantic(hv_volume *v, const float *depth, const uint8_t *
 
 int hv_get_voxels_semantic(hv_volume *v, int32_t min_count, float min_confidence, double *points, float *colors,
                            int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap, int64_t *n) {
-    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_get_voxels_semantic: null argument");
-    HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_get_voxels_semantic: volume is not a semantic grid");
-    HV_HIP(hipSetDevice(v->device));
-    int64_t nb = 0;
-    int rc = hv_num_blocks(v, &nb);
-    if (rc != HV_OK) return rc;
-    *n = 0;
-    if (nb == 0) return HV_OK;
-    const int64_t total = nb * sem_params(v).nvox;
-    const bool want = points && colors && class_ids && object_ids && confidences && cap > 0;
-    double *d_pts = nullptr;
-    float *d_cols = nullptr, *d_conf = nullptr;
-    int32_t *d_cls = nullptr, *d_obj = nullptr;
-    if (want) {
-        rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, (size_t)cap * (24 + 12 + 4 + 4 + 4) + 1024);
-        if (rc != HV_OK) return rc;
-        d_pts = (double *)v->out_a;
-        d_cols = (float *)(d_pts + 3 * cap);
-        d_cls = (int32_t *)(d_cols + 3 * cap);
-        d_obj = d_cls + cap;
-        d_conf = (float *)(d_obj + cap);
-    }
-    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
-    const dim3 grid((unsigned)((total + 255) / 256));
-    if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID)
-        hipLaunchKernelGGL(k_sem_collect<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvProbVoxel *)v->pool,
-                           total, min_count, min_confidence, d_pts, d_cols, d_cls, d_obj, d_conf, want ? cap : 0);
-    else
-        hipLaunchKernelGGL(k_sem_collect<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvSemVoxel *)v->pool,
-                           total, min_count, min_confidence, d_pts, d_cols, d_cls, d_obj, d_conf, want ? cap : 0);
-    HV_HIP(hipGetLastError());
-    rc = hv_read_counters(v);
-    if (rc != HV_OK) return rc;
-    *n = v->h_counters[HV_CNT_OUT];
-    if (want) {
-        const int64_t m = std::min(*n, cap);
-        if (m > 0) {
-            HV_HIP(hipMemcpyAsync(points, d_pts, 24 * m, hipMemcpyDeviceToHost, v->stream));
-            HV_HIP(hipMemcpyAsync(colors, d_cols, 12 * m, hipMemcpyDeviceToHost, v->stream));
-            HV_HIP(hipMemcpyAsync(class_ids, d_cls, 4 * m, hipMemcpyDeviceToHost, v->stream));
-            HV_HIP(hipMemcpyAsync(object_ids, d_obj, 4 * m, hipMemcpyDeviceToHost, v->stream));
-            HV_HIP(hipMemcpyAsync(confidences, d_conf, 4 * m, hipMemcpyDeviceToHost, v->stream));
-            HV_HIP(hipStreamSynchronize(v->stream));
-        }
-    }
-    return HV_OK;
+    HvQuery Q;
+    memset(&Q, 0, sizeof(Q));
+    return sem_run_collect(v, Q, min_count, min_confidence, points, colors, class_ids, object_ids, confidences, cap, n);
+}
+
+int hv_get_voxels_semantic_in_bb(hv_volume *v, const double *bbox, int32_t min_count, float min_confidence, double *points,
+                                 float *colors, int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap,
+                                 int64_t *n) {
+    HV_REQUIRE(v != nullptr && bbox != nullptr, HV_ERR_INVALID, "hv_get_voxels_semantic_in_bb: null argument");
+    HvQuery Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.kind = 1;
+    for (int k = 0; k < 6; ++k) Q.bb[k] = bbox[k];
+    const HvSemParams G = sem_params(v);
+    HvGridParams GP{G.inv_voxel_size, G.bs, G.nvox, G.local_bits};
+    fill_key_range(Q, GP);
+    return sem_run_collect(v, Q, min_count, min_confidence, points, colors, class_ids, object_ids, confidences, cap, n);
+}
+
+int hv_get_voxels_semantic_in_frustum(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw,
+                                      float depth_max, float depth_min, int32_t min_count, float min_confidence, double *points,
+                                      float *colors, int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap,
+                                      int64_t *n) {
+    HV_REQUIRE(v != nullptr && intr_f32 != nullptr && T_cw != nullptr, HV_ERR_INVALID, "hv_get_voxels_semantic_in_frustum: null argument");
+    HvQuery Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.kind = 2;
+    fill_frustum_query(Q, v, intr_f32, width, height, T_cw, depth_max, depth_min);
+    const HvSemParams G = sem_params(v);
+    HvGridParams GP{G.inv_voxel_size, G.bs, G.nvox, G.local_bits};
+    fill_key_range(Q, GP);
+    return sem_run_collect(v, Q, min_count, min_confidence, points, colors, class_ids, object_ids, confidences, cap, n);
 }
 
 int hv_dump_blocks_semantic2(hv_volume *v, int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums,

@@ -10,7 +10,8 @@ remove_low_confidence_segments, remove_low_count_voxels, remove_low_confidence_v
 set_depth_threshold, set_depth_decay_rate, clear/reset, size, num_blocks; module-level
 ``remap_instance_ids`` (image_utils.h:69-163) and the ``ObjectData`` / ``ObjectDataGroup`` /
 ``OrientedBoundingBox3D`` result types (voxel_grid_data.h:58-99, bounding_boxes_3d.h:82-131).
-Not provided: integrate_segment, get_class_segments, the *2 payload variants (voxel_data_semantic2.h)."""
+Also: get_voxels_in_bb / get_voxels_in_camera_frustrum (include_semantics), integrate_segment, get_class_segments.
+Not provided: the *2 payload variants (voxel_data_semantic2.h)."""
 import ctypes
 
 import numpy as np
@@ -65,6 +66,14 @@ class ObjectData:
         self.object_id, self.class_id = int(object_id), int(class_id)
         self.confidence_min, self.confidence_max = float(confidence_min), float(confidence_max)
         self.oriented_bounding_box = oriented_bounding_box
+
+
+class ClassData:
+    """voxel_grid_data.h:107-120."""
+
+    def __init__(self, points, colors, class_id, confidence_min, confidence_max):
+        self.points, self.colors, self.class_id = points, colors, int(class_id)
+        self.confidence_min, self.confidence_max = float(confidence_min), float(confidence_max)
 
 
 class ObjectDataGroup:
@@ -201,6 +210,55 @@ class _SemanticGridBase(_Volume):
             L.check(self._lib.hv_get_voxels_semantic(self._h, int(min_count), float(min_confidence), L.ptr(out.points),
                                                      L.ptr(out.colors), L.ptr(out.class_ids), L.ptr(out.object_ids),
                                                      L.ptr(out.confidences), m, ctypes.byref(n)))
+        return out
+
+    def _query(self, call):
+        n = ctypes.c_int64()
+        L.check(call(None, None, None, None, None, 0, ctypes.byref(n)))
+        m = n.value
+        out = VoxelGridData(np.zeros((m, 3), np.float64), np.zeros((m, 3), np.float32))
+        out.class_ids, out.object_ids = np.zeros(m, np.int32), np.zeros(m, np.int32)
+        out.confidences = np.zeros(m, np.float32)
+        if m:
+            L.check(call(L.ptr(out.points), L.ptr(out.colors), L.ptr(out.class_ids), L.ptr(out.object_ids), L.ptr(out.confidences), m,
+                         ctypes.byref(n)))
+        return out
+
+    @staticmethod
+    def _strip_semantics(out, include_semantics):
+        if not include_semantics:  # IncludeSemantics=false: only points / colours are filled (voxel_block_grid.hpp:1004-1010)
+            out.class_ids, out.object_ids = np.zeros(0, np.int32), np.zeros(0, np.int32)
+            out.confidences = np.zeros(0, np.float32)
+        return out
+
+    def get_voxels_in_bb(self, bbox, min_count=1, min_confidence=0.0, include_semantics=False):
+        bb = bbox.as_array() if hasattr(bbox, "as_array") else np.ascontiguousarray(bbox, dtype=np.float64)
+        out = self._query(lambda *a: self._lib.hv_get_voxels_semantic_in_bb(self._h, L.ptr(bb), int(min_count), float(min_confidence), *a))
+        return self._strip_semantics(out, include_semantics)
+
+    def get_voxels_in_camera_frustrum(self, camera_frustrum, min_count=1, min_confidence=0.0, include_semantics=False):
+        f = camera_frustrum
+        out = self._query(lambda *a: self._lib.hv_get_voxels_semantic_in_frustum(
+            self._h, L.ptr(f.intr), f.width, f.height, L.ptr(f.T_cw), f.depth_max, f.depth_min, int(min_count), float(min_confidence), *a))
+        return self._strip_semantics(out, include_semantics)
+
+    def integrate_segment(self, points, colors, object_id, class_id):
+        """integrate_segment(points, colors, object_id, class_id) (voxel_block_semantic_grid.hpp:39-96): every point
+        carries the same ids; nothing happens for negative ids."""
+        if object_id < 0 or class_id < 0:
+            return
+        n = np.asarray(points).shape[0]
+        self.integrate(points, colors, np.full(n, class_id, np.int32), np.full(n, object_id, np.int32))
+
+    def get_class_segments(self, min_count=1, min_confidence=0.0):
+        """-> list of ClassData-like objects (voxel_block_semantic_grid.hpp:269-313): voxels with count > min_count,
+        confidence >= min_confidence and class id >= 0 grouped by class (ascending)."""
+        v = self.get_voxels(int(min_count) + 1, min_confidence)  # strict '>' on the count, like get_object_segments
+        keep = v.class_ids >= 0
+        out = []
+        for c in np.unique(v.class_ids[keep]):
+            m = keep & (v.class_ids == c)
+            out.append(ClassData(v.points[m], v.colors[m], int(c), float(v.confidences[m].min()), float(v.confidences[m].max())))
         return out
 
     def get_points(self):

@@ -259,3 +259,49 @@ def test_flow_matches_committed_golden(kind, name):
     g = gpu_grid(kind, FLOW_CFG["voxel"])
     r = run_flow(GpuAsSem2(g), lambda img, m: remap_instance_ids(img, m, volume=g), kind)
     check_flow_against_golden(r, name, 0.0 if kind == VOTE else 2e-6)
+
+
+@pytest.mark.parametrize("kind", [VOTE, PROB])
+def test_semantic_queries_segments_by_class_and_integrate_segment(kind):
+    """get_voxels_in_bb / get_voxels_in_camera_frustrum with semantics, get_class_segments, integrate_segment
+    against the compiled reference."""
+    from oracle.semantic import ref_get_class_segments, ref_get_voxels_in_bb, ref_get_voxels_in_frustum, ref_integrate_segment
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import BoundingBox3D, CameraFrustrum
+
+    s = SyntheticRGBD(CFG, noise=True, invalid_frac=0.02)
+    intr = s.intrinsics
+    gpu, ref = gpu_grid(kind, CFG["voxel"]), RefSemGrid2(kind, CFG["voxel"])
+    for i in (0, 6):
+        depth, rgb, T, cls_img, inst_img = semantic_frame(s, i)
+        pts, cols, cls, obj, depths = frame_points(depth, rgb, T, cls_img, inst_img, intr, 4.0)
+        for g in (gpu, ref):
+            g.integrate(pts, cols, cls, obj, depths)
+    seg_pts = np.random.default_rng(4).uniform([2.0, 1.0, 0.5], [2.3, 1.3, 0.8], (5000, 3))
+    seg_cols = np.full((5000, 3), 0.25, np.float32)
+    gpu.integrate_segment(seg_pts, seg_cols, 77, 5)
+    ref_integrate_segment(ref, seg_pts, seg_cols, 77, 5)
+    gpu.integrate_segment(seg_pts, seg_cols, -1, 5)  # negative ids: ignored
+    ref_integrate_segment(ref, seg_pts, seg_cols, -1, 5)
+    assert_state_equal(gpu, ref, kind)
+    tol = 0 if kind == VOTE else 2e-6
+
+    def same(v, r):
+        a = srt((v.points, v.colors, v.class_ids, v.object_ids, v.confidences))
+        b = srt(r)
+        assert len(a[0]) == len(b[0]) > 0
+        for x, y in zip(a[:4], b[:4]):
+            np.testing.assert_array_equal(x, y)
+        np.testing.assert_allclose(a[4], b[4], rtol=0, atol=tol)
+
+    bb = np.array([1.5, 0.5, 0.2, 4.0, 3.0, 1.8])
+    same(gpu.get_voxels_in_bb(BoundingBox3D(bb[:3], bb[3:]), 2, 0.0, include_semantics=True), ref_get_voxels_in_bb(ref, bb, 2, 0.0))
+    T = s[6][2]
+    fr = CameraFrustrum(*intr, s.width, s.height, T, depth_max=3.0, depth_min=0.5)
+    same(gpu.get_voxels_in_camera_frustrum(fr, 1, 0.0, include_semantics=True),
+         ref_get_voxels_in_frustum(ref, fr.intr, s.width, s.height, T, fr.depth_max, fr.depth_min, 1, 0.0))
+    assert len(gpu.get_voxels_in_bb(BoundingBox3D(bb[:3], bb[3:]), 2, 0.0).class_ids) == 0  # include_semantics=False
+    ids, conf = ref_get_class_segments(ref, 1, 0.0)
+    got = gpu.get_class_segments(1, 0.0)
+    assert [(c.class_id, len(c.points)) for c in got] == [tuple(r) for r in ids.tolist()]
+    np.testing.assert_allclose([[c.confidence_min, c.confidence_max] for c in got], conf, rtol=0, atol=tol)

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Secondary benchmark (BASELINE config 5 shape): keyframes/s of pySLAM's per-keyframe semantic flow
+(shadow filter -> assign_object_ids_to_instance_ids -> remap_instance_ids -> depth2pointcloud with labels + world
+transform -> integrate, volumetric_integrator_voxel_semantic_grid.py:322-461) on one MI355X for both semantic payloads,
+next to the *compiled reference* (oracle/_ref: unmodified cpp/volumetric sources, sequential non-TBB branch, 1 core)
+running the same flow with numpy host prep.  Also times get_voxels and get_object_segments.  One JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--voxel", type=float, default=0.01)
+    args = ap.parse_args()
+
+    import oracle
+    from oracle import host_prep as hp
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import CameraFrustrum
+    from pyslam_amd.volumetric_semantic import (VoxelBlockSemanticGrid, VoxelBlockSemanticProbabilisticGrid,
+                                                remap_instance_ids, set_next_object_id)
+    from tests.semantic_helpers import frame_points, semantic_frame
+
+    s = SyntheticRGBD("synthetic_640x480_5mm")
+    intr = s.intrinsics
+    frames = [semantic_frame(s, 3 * i, shuffle=i) for i in range(args.frames)]
+    out = {"metric": "keyframes/sec, semantic flow (640x480, assign+remap+integrate, cpp/volumetric semantics)", "unit": "keyframes/s",
+           "n_gpus": 1, "voxel": args.voxel, "frames": args.frames}
+    for name, cls, kind in (("voting", VoxelBlockSemanticGrid, 0), ("probabilistic", VoxelBlockSemanticProbabilisticGrid, 1)):
+        g = cls(args.voxel, 8, max_blocks=1 << 17, max_points=1 << 20)
+        fr = CameraFrustrum(*intr, s.width, s.height, np.eye(4), depth_max=8.0, depth_min=0.01)
+        set_next_object_id(1)
+
+        def run(frames_):
+            for depth, rgb, T, cls_img, inst_img in frames_:
+                d = g.filter_shadow_points(depth)
+                fr.set_T_cw(T)
+                m = g.assign_object_ids_to_instance_ids(fr, cls_img, inst_img, d, depth_threshold=0.03, do_carving=False,
+                                                        min_vote_ratio=0.5, min_votes=3)
+                obj = remap_instance_ids(inst_img, m, volume=g)
+                g.integrate_rgbd(d, rgb, *intr, T, class_ids_image=cls_img, object_ids_image=obj, max_depth=4.0, use_depths=True)
+
+        run(frames[:2])
+        g.synchronize()
+        t0 = time.perf_counter()
+        run(frames[2:])
+        g.synchronize()
+        fps = (len(frames) - 2) / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        v = g.get_voxels(3, 0.6)
+        t_get = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        segs = g.get_object_segments(3, 0.6)
+        t_seg = time.perf_counter() - t0
+        res = {"value": round(fps, 1), "get_voxels_ms": round(t_get * 1e3, 2), "voxels_out": int(len(v.points)),
+               "get_object_segments_ms": round(t_seg * 1e3, 2), "objects": len(segs.object_vector), "blocks": int(g.num_blocks()),
+               "label_overflows": g.label_overflows()}
+        if oracle.ref_available():
+            from oracle.semantic import RefSemGrid2, ref_remap_instance_ids
+
+            r = RefSemGrid2(kind, args.voxel, 8)
+            r.set_next_object_id(1)
+            intr32 = np.array(intr, np.float32)
+
+            def run_ref(frames_):
+                for depth, rgb, T, cls_img, inst_img in frames_:
+                    d = hp.filter_shadow_points(depth)
+                    m = r.assign_object_ids_to_instance_ids(intr32, s.width, s.height, T, 8.0, 0.01, cls_img, inst_img, d, 0.03, False, 0.5, 3)
+                    obj = ref_remap_instance_ids(inst_img, m)
+                    pts, cols, cls, ob, depths = frame_points(d, rgb, T, cls_img, obj, intr, 4.0)
+                    r.integrate(pts.astype(np.float32), cols, cls, ob, depths)
+
+            run_ref(frames[:1])
+            t0 = time.perf_counter()
+            run_ref(frames[1:1 + args.cpu_frames])
+            dt = time.perf_counter() - t0
+            res["cpu_reference"] = {"value": round(args.cpu_frames / dt, 3), "unit": "keyframes/s", "cores": 1, "kind": "reference",
+                                    "sample": f"{args.cpu_frames} keyframes, same flow: numpy shadow filter / depth2pointcloud + compiled "
+                                              f"cpp/volumetric (sequential non-TBB branch)"}
+            res["speedup_vs_cpu_reference"] = round(fps / res["cpu_reference"]["value"], 1)
+        out[name] = res
+        del g
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
