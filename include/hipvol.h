@@ -83,6 +83,11 @@ void *hv_get_stream(hv_volume *v);
 /* ---- common introspection (volumetric_grid_module.h:761-812) ---------------------------------- */
 int hv_num_blocks(hv_volume *v, int64_t *n);     /* num_blocks() / number of TSDF volume units */
 int hv_block_size(hv_volume *v, int32_t *bs);    /* get_block_size() */
+/* Grow the block pool + hash to new_max_blocks, keeping the contents (no-op when not larger).  The library also
+ * doubles the pool by itself whenever a data-returning call finds it more than half full and the larger pool fits
+ * into free HBM (HV_AUTO_GROW=0 disables this); the reference's containers grow without bound, so must the map. */
+int hv_reserve_blocks(hv_volume *v, int64_t new_max_blocks);
+int hv_max_blocks(hv_volume *v, int64_t *n);
 int hv_bytes_per_block(hv_volume *v, int64_t *bytes);
 int hv_dropped_points(hv_volume *v, int64_t *n); /* points/pixels rejected because their block key fell
                                                     outside the +/-2^20 packed range (never for sane maps) */

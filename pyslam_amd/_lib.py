@@ -51,6 +51,8 @@ SIGNATURES = {
     "hv_get_stream": (_vp, [_vp]),
     "hv_num_blocks": (_i32, [_vp, _pi64]),
     "hv_block_size": (_i32, [_vp, _pi32]),
+    "hv_reserve_blocks": (_i32, [_vp, _i64]),
+    "hv_max_blocks": (_i32, [_vp, _pi64]),
     "hv_bytes_per_block": (_i32, [_vp, _pi64]),
     "hv_dropped_points": (_i32, [_vp, _pi64]),
     "hv_integrate_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32]),

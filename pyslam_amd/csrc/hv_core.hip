@@ -2,6 +2,8 @@
 #include <cstdarg>
 #include <cstdlib>
 
+#include <algorithm>
+
 #include "hv_common.h"
 
 static thread_local std::string g_last_error;
@@ -300,6 +302,94 @@ int hv_set_stream(hv_volume *v, void *hip_stream) {
 
 void *hv_get_stream(hv_volume *v) { return v ? (void *)v->stream : nullptr; }
 
+// Re-insert the allocated blocks' keys into a fresh (larger) table: vals[slot] = pool index.
+__global__ void k_rehash(HvTable t, const unsigned long long *__restrict__ block_keys, int32_t n) {
+    const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const unsigned long long key = block_keys[idx];
+    uint32_t s = hv_slot_hash(key) & t.mask;
+    for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+        if (atomicCAS(&t.keys[s], HV_EMPTY_KEY, key) == HV_EMPTY_KEY) {
+            t.vals[s] = idx;
+            return;
+        }
+        s = (s + 1) & t.mask;
+    }
+}
+
+// Grow the block pool and the hash to `new_max_blocks` (>= the current capacity), keeping every block: the pool is
+// copied (block indices persist), the table is rebuilt at 4x the new capacity.  Synchronises the stream.
+int hv_reserve_blocks(hv_volume *v, int64_t new_max_blocks) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_reserve_blocks: null volume");
+    if (new_max_blocks <= v->cfg.max_blocks) return HV_OK;
+    HV_REQUIRE(new_max_blocks < (1ll << 30), HV_ERR_INVALID, "hv_reserve_blocks: max_blocks out of range");
+    const uint64_t new_cap = next_pow2((uint64_t)new_max_blocks * 4);
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF || (new_cap << v->local_bits) < (1ull << 32), HV_ERR_CAPACITY,
+               "hv_reserve_blocks: %lld blocks are too many for 32-bit (slot, voxel) sort keys", (long long)new_max_blocks);
+    HV_HIP(hipSetDevice(v->device));
+    HV_HIP(hipStreamSynchronize(v->stream));
+    int rc = hv_read_counters(v);
+    if (rc != HV_OK) return rc;
+    const int64_t used = std::min<int64_t>(v->h_counters[HV_CNT_BLOCKS], v->cfg.max_blocks);
+    size_t free_b = 0, total_b = 0;
+    HV_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = (size_t)new_max_blocks * v->bytes_per_block + new_cap * 24 + (size_t)new_max_blocks * 16;
+    HV_REQUIRE(need < free_b, HV_ERR_CAPACITY, "hv_reserve_blocks: %.1f GiB needed, %.1f GiB of HBM free", need / 1073741824.0,
+               free_b / 1073741824.0);
+    void *pool = nullptr;
+    unsigned long long *keys = nullptr, *block_keys = nullptr;
+    int32_t *vals = nullptr;
+    HV_HIP(hipMalloc(&pool, (size_t)new_max_blocks * v->bytes_per_block));
+    HV_HIP(hipMalloc((void **)&keys, sizeof(uint64_t) * new_cap));
+    HV_HIP(hipMalloc((void **)&vals, sizeof(int32_t) * new_cap));
+    HV_HIP(hipMalloc((void **)&block_keys, sizeof(uint64_t) * new_max_blocks));
+    HV_HIP(hipMemcpyAsync(pool, v->pool, (size_t)used * v->bytes_per_block, hipMemcpyDeviceToDevice, v->stream));
+    HV_HIP(hipMemsetAsync((char *)pool + (size_t)used * v->bytes_per_block, 0, (size_t)(new_max_blocks - used) * v->bytes_per_block,
+                          v->stream));
+    HV_HIP(hipMemcpyAsync(block_keys, v->table.block_keys, sizeof(uint64_t) * used, hipMemcpyDeviceToDevice, v->stream));
+    HV_HIP(hipMemsetAsync(keys, 0xFF, sizeof(uint64_t) * new_cap, v->stream));
+    HV_HIP(hipMemsetAsync(vals, 0xFF, sizeof(int32_t) * new_cap, v->stream));
+    HvTable nt = v->table;
+    nt.keys = keys;
+    nt.vals = vals;
+    nt.block_keys = block_keys;
+    nt.mask = (uint32_t)(new_cap - 1);
+    nt.max_blocks = (int32_t)new_max_blocks;
+    if (used > 0) hipLaunchKernelGGL(k_rehash, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, v->stream, nt, block_keys, (int32_t)used);
+    HV_HIP(hipGetLastError());
+    if (v->cfg.mode == HV_MODE_TSDF) { // per-slot frame stamps / masks and the touched list follow the table
+        int32_t *stamp = nullptr, *list = nullptr;
+        uint64_t *mask = nullptr;
+        HV_HIP(hipMalloc((void **)&stamp, sizeof(int32_t) * new_cap));
+        HV_HIP(hipMalloc((void **)&list, sizeof(int32_t) * new_max_blocks));
+        HV_HIP(hipMalloc((void **)&mask, sizeof(uint64_t) * new_cap));
+        HV_HIP(hipMemsetAsync(stamp, 0, sizeof(int32_t) * new_cap, v->stream));
+        HV_HIP(hipMemsetAsync(mask, 0, sizeof(uint64_t) * new_cap, v->stream));
+        HV_HIP(hipStreamSynchronize(v->stream));
+        (void)hipFree(v->touched_stamp);
+        (void)hipFree(v->touched_list);
+        (void)hipFree(v->touched_mask);
+        v->touched_stamp = stamp;
+        v->touched_list = list;
+        v->touched_mask = mask;
+        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream)); // lists are void now
+        v->touch_counters_clean = true;
+    }
+    HV_HIP(hipStreamSynchronize(v->stream));
+    (void)hipFree(v->pool);
+    (void)hipFree(v->table.keys);
+    (void)hipFree(v->table.vals);
+    (void)hipFree(v->table.block_keys);
+    v->pool = pool;
+    v->table = nt;
+    v->table_capacity = new_cap;
+    v->cfg.max_blocks = new_max_blocks;
+    return HV_OK;
+}
+
+// Every call that returns data to the host passes through here (one counter read-back): the natural place to grow
+// the pool before it runs out.  Policy: when more than half of the blocks are in use, double the capacity (while the
+// doubled pool fits in 60 % of the free HBM and the sort keys).  HV_AUTO_GROW=0 disables it.
 int hv_num_blocks(hv_volume *v, int64_t *n) {
     HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_num_blocks: null argument");
     int rc = hv_read_counters(v);
@@ -308,8 +398,26 @@ int hv_num_blocks(hv_volume *v, int64_t *n) {
     if (nb > v->cfg.max_blocks) nb = v->cfg.max_blocks;
     *n = nb;
     HV_REQUIRE(v->h_counters[HV_CNT_OVERFLOW] == 0, HV_ERR_CAPACITY,
-               "block pool exhausted: max_blocks=%lld; recreate the volume with a larger pool",
+               "block pool exhausted: max_blocks=%lld; recreate the volume with a larger pool (or call hv_reserve_blocks "
+               "earlier: blocks that did not fit were dropped)",
                (long long)v->cfg.max_blocks);
+    static const bool auto_grow = !(getenv("HV_AUTO_GROW") && atoi(getenv("HV_AUTO_GROW")) == 0);
+    if (auto_grow && nb * 2 > v->cfg.max_blocks) {
+        const int64_t want = v->cfg.max_blocks * 2;
+        size_t free_b = 0, total_b = 0;
+        const bool fits_keys = v->cfg.mode == HV_MODE_TSDF || (next_pow2((uint64_t)want * 4) << v->local_bits) < (1ull << 32);
+        if (fits_keys && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+            (double)want * (double)v->bytes_per_block < 0.6 * (double)free_b) {
+            rc = hv_reserve_blocks(v, want);
+            if (rc != HV_OK) return rc;
+        }
+    }
+    return HV_OK;
+}
+
+int hv_max_blocks(hv_volume *v, int64_t *n) {
+    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_max_blocks: null argument");
+    *n = v->cfg.max_blocks;
     return HV_OK;
 }
 

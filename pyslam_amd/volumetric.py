@@ -64,6 +64,15 @@ class _Volume:
         L.check(self._lib.hv_num_blocks(self._h, ctypes.byref(n)))
         return n.value
 
+    def max_blocks(self):
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_max_blocks(self._h, ctypes.byref(n)))
+        return n.value
+
+    def reserve_blocks(self, new_max_blocks):
+        """Grow the block pool / hash, keeping the contents (also happens automatically when more than half full)."""
+        L.check(self._lib.hv_reserve_blocks(self._h, int(new_max_blocks)))
+
     def synchronize(self):
         L.check(self._lib.hv_synchronize(self._h))
 
