@@ -204,6 +204,7 @@ struct HvFrameParams { // per-frame constants of the TSDF kernels (passed by val
     int32_t depth_is_u16;
     int32_t frame_id;       // touched stamp value (> 0)
     int32_t tile_u0, tile_v0, tile_u1, tile_v1; // image-space tile owned by this GPU: [u0,u1) x [v0,v1)
+    int32_t tiled;                              // 0: the tile is the whole image (the per-voxel tile test is skipped)
     int32_t owner_rank, owner_world;            // unit ownership sharding: this GPU fuses units with owner(key) == rank
 };
 

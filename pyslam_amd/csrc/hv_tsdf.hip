@@ -171,7 +171,7 @@ __device__ __forceinline__ bool hv_tsdf_update(const HvFrameParams &P, const uin
     const int u = (int)u_f;
     const int v = (int)v_f;
     // multi-GPU image-tile sharding: a voxel is fused by the GPU that owns the pixel it projects to
-    if (u < P.tile_u0 || u >= P.tile_u1 || v < P.tile_v0 || v >= P.tile_v1) return false;
+    if (P.tiled && (u < P.tile_u0 || u >= P.tile_u1 || v < P.tile_v0 || v >= P.tile_v1)) return false;
     const uint2 rec = frame_px[(int64_t)v * P.W + u];
     const float d = __uint_as_float(rec.x);
     if (d <= 0.0f) return false;
@@ -228,7 +228,7 @@ __device__ __forceinline__ bool hv_tsdf_eval(const HvFrameParams &P, const uint2
     if (!(u_f >= 0.0001f && u_f < P.safe_width_f && v_f >= 0.0001f && v_f < P.safe_height_f)) return false;
     const int u = (int)u_f;
     const int v = (int)v_f;
-    if (u < P.tile_u0 || u >= P.tile_u1 || v < P.tile_v0 || v >= P.tile_v1) return false;
+    if (P.tiled && (u < P.tile_u0 || u >= P.tile_u1 || v < P.tile_v0 || v >= P.tile_v1)) return false;
     const uint2 rec = frame_px[(int64_t)v * P.W + u];
     const float d = __uint_as_float(rec.x);
     if (d <= 0.0f) return false;
@@ -258,7 +258,7 @@ __device__ __forceinline__ bool hv_tsdf_eval_patch(const HvFrameParams &P, const
     if (!(u_f >= 0.0001f && u_f < P.safe_width_f && v_f >= 0.0001f && v_f < P.safe_height_f)) return false;
     const int u = (int)u_f;
     const int v = (int)v_f;
-    if (u < P.tile_u0 || u >= P.tile_u1 || v < P.tile_v0 || v >= P.tile_v1) return false;
+    if (P.tiled && (u < P.tile_u0 || u >= P.tile_u1 || v < P.tile_v0 || v >= P.tile_v1)) return false;
     const int du = u - patch.u0, dv = v - patch.v0;
     uint2 rec;
     if (patch.lds != nullptr && du >= 0 && du < patch.pw && dv >= 0 && dv < patch.ph) {
@@ -276,11 +276,26 @@ __device__ __forceinline__ bool hv_tsdf_eval_patch(const HvFrameParams &P, const
     return true;
 }
 
+// a / b correctly rounded for operands clear of the overflow / denormal bands (same chain as hv_div2).
+__device__ __forceinline__ float hv_div1(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = fmaf(-b, r, 1.0f);
+    r = fmaf(e, r, r);
+    float q = a * r;
+    float rem = fmaf(-b, q, a);
+    q = fmaf(rem, r, q);
+    rem = fmaf(-b, q, a);
+    return fmaf(rem, r, q);
+}
+
 __device__ __forceinline__ void hv_tsdf_apply(bool valid, float t, uint32_t c, float &tsdf, uint32_t &w, uint32_t &sr,
                                               uint32_t &sg, uint32_t &sb) {
     if (!valid) return;
     const float wf = (float)w;
-    tsdf = (tsdf * wf + t) / (wf + 1.0f);
+    // |tsdf * wf + t| <= 2^24 + 1 and 1 <= wf + 1 <= 2^24 for w < 2^24: inside hv_div1's verified band; beyond
+    // (a voxel observed 16.7 M times) fall back to the plain division
+    const float num = tsdf * wf + t;
+    tsdf = (w < (1u << 24)) ? hv_div1(num, wf + 1.0f) : num / (wf + 1.0f);
     w += 1u;
     sr += c & 255u;
     sg += (c >> 8) & 255u;
@@ -1100,6 +1115,7 @@ static int make_frame_params(hv_volume *v, int H, int W, const double *intr, con
     P->tile_v0 = whole ? 0 : v->tile[1];
     P->tile_u1 = whole ? W : v->tile[2];
     P->tile_v1 = whole ? H : v->tile[3];
+    P->tiled = whole ? 0 : 1;
     P->owner_rank = v->owner_rank;
     P->owner_world = v->owner_world;
     return HV_OK;
