@@ -107,6 +107,12 @@ int hv_integrate_rgbd_points(hv_volume *v, const void *depth, int32_t depth_dtyp
                              const uint8_t *rgb, int32_t height, int32_t width, const double *intr,
                              const double *T_cw, double min_depth, double max_depth, int32_t loc);
 
+/* Batched replay of F posed frames (rebuild(), offline reconstruction): depth F*H*W, rgb F*H*W*3, T_cw F*16 (host).
+ * Bit-identical to F hv_integrate_rgbd_points calls; one sort + reduce per chunk of max_points / (H*W) frames. */
+int hv_integrate_rgbd_points_batch(hv_volume *v, const void *depth, int32_t depth_dtype, double depth_scale,
+                                   const uint8_t *rgb, int32_t n_frames, int32_t height, int32_t width, const double *intr,
+                                   const double *T_cw, double min_depth, double max_depth, int32_t loc);
+
 /* cv2.remap(src, map_x, map_y, INTER_LINEAR | INTER_NEAREST, BORDER_CONSTANT 0) as pySLAM's undistortion
  * uses it (volumetric_integrator_base.py:1017-1043).  src_kind 0: uint8 (channels interleaved), 1: float32,
  * 2: int32 (nearest only); maps float32 [H,W]; all arrays live at `loc`.  OpenCV semantics restated, unpinned. */

@@ -57,6 +57,7 @@ SIGNATURES = {
     "hv_dropped_points": (_i32, [_vp, _pi64]),
     "hv_integrate_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32]),
     "hv_integrate_rgbd_points": (_i32, [_vp, _vp, _i32, _f64, _vp, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
+    "hv_integrate_rgbd_points_batch": (_i32, [_vp, _vp, _i32, _f64, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_remap": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32]),
     "hv_filter_shadow_points": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _i32]),
     "hv_get_voxels": (_i32, [_vp, _i32, _f32, _vp, _vp, _i64, _pi64, _i32]),

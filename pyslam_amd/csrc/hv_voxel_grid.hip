@@ -413,15 +413,11 @@ int hv_integrate_points(hv_volume *v, const float *points, int64_t n, const void
 // Shared front half of the fused RGB-D entry points: stages the frame, runs k_vg_unproject into
 // v->scratch_points / v->scratch_colors (float32) with the per-pixel validity flags in v->sort_keys_out.
 // d_depth_out receives the device address of the (staged) depth image.
-int hv_unproject_frame(hv_volume *v, const void *depth, int32_t depth_dtype, double depth_scale, const uint8_t *rgb,
-                       int32_t height, int32_t width, const double *intr, const double *T_cw, double min_depth,
-                       double max_depth, int32_t loc, const void **d_depth_out) {
+// k_vg_unproject of one frame already in HBM into slice [out_offset, out_offset + H*W) of the scratch arrays.
+static int unproject_device(hv_volume *v, const void *d_depth, int32_t depth_dtype, double depth_scale, const uint8_t *d_rgb,
+                            int32_t height, int32_t width, const double *intr, const double *T_cw, double min_depth,
+                            double max_depth, int64_t out_offset) {
     const int64_t npx = (int64_t)height * width;
-    const void *d_depth = nullptr, *d_rgb = nullptr;
-    int rc = hv_stage_in(v, depth, (size_t)npx * (depth_dtype == HV_DEPTH_U16 ? 2 : 4), loc, 0, &d_depth);
-    if (rc != HV_OK) return rc;
-    rc = hv_stage_in(v, rgb, (size_t)npx * 3, loc, 1, &d_rgb);
-    if (rc != HV_OK) return rc;
     HvUnprojectParams U;
     U.cx = intr[2];
     U.cy = intr[3];
@@ -439,10 +435,59 @@ int hv_unproject_frame(hv_volume *v, const void *depth, int32_t depth_dtype, dou
     U.W = width;
     U.depth_is_u16 = depth_dtype == HV_DEPTH_U16;
     // the unprojection's validity flags go straight into the sort-key input buffer
-    hipLaunchKernelGGL(k_vg_unproject, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream, d_depth,
-                       (const uint8_t *)d_rgb, U, v->scratch_points, v->scratch_colors, v->sort_keys_out);
+    hipLaunchKernelGGL(k_vg_unproject, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream, d_depth, d_rgb, U,
+                       v->scratch_points + 3 * out_offset, v->scratch_colors + 3 * out_offset, v->sort_keys_out + out_offset);
     HV_HIP(hipGetLastError());
+    return HV_OK;
+}
+
+int hv_unproject_frame(hv_volume *v, const void *depth, int32_t depth_dtype, double depth_scale, const uint8_t *rgb,
+                       int32_t height, int32_t width, const double *intr, const double *T_cw, double min_depth,
+                       double max_depth, int32_t loc, const void **d_depth_out) {
+    const int64_t npx = (int64_t)height * width;
+    const void *d_depth = nullptr, *d_rgb = nullptr;
+    int rc = hv_stage_in(v, depth, (size_t)npx * (depth_dtype == HV_DEPTH_U16 ? 2 : 4), loc, 0, &d_depth);
+    if (rc != HV_OK) return rc;
+    rc = hv_stage_in(v, rgb, (size_t)npx * 3, loc, 1, &d_rgb);
+    if (rc != HV_OK) return rc;
     if (d_depth_out) *d_depth_out = d_depth;
+    return unproject_device(v, d_depth, depth_dtype, depth_scale, (const uint8_t *)d_rgb, height, width, intr, T_cw, min_depth,
+                            max_depth, 0);
+}
+
+// Batched replay (rebuild() / offline reconstruction): F posed frames are unprojected into one point array and fused
+// with ONE sort + reduce per chunk of max_points / (H*W) frames.  A voxel's points are still folded in global point
+// index order = frame order, then pixel order, so the result is bit-identical to F hv_integrate_rgbd_points calls;
+// the device-wide radix sort (18 small launches: the per-frame cost of this path) is paid once per chunk.
+extern "C" int hv_integrate_rgbd_points_batch(hv_volume *v, const void *depth, int32_t depth_dtype, double depth_scale,
+                                              const uint8_t *rgb, int32_t n_frames, int32_t height, int32_t width,
+                                              const double *intr, const double *T_cw, double min_depth, double max_depth,
+                                              int32_t loc) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_integrate_rgbd_points_batch: null volume");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_GRID, HV_ERR_MODE, "hv_integrate_rgbd_points_batch: volume is not in VOXEL_GRID mode");
+    HV_REQUIRE(depth != nullptr && rgb != nullptr && intr != nullptr && T_cw != nullptr && height > 0 && width > 0 && n_frames > 0,
+               HV_ERR_INVALID, "hv_integrate_rgbd_points_batch: null or empty input");
+    const int64_t npx = (int64_t)height * width;
+    HV_REQUIRE(npx <= v->cfg.max_points, HV_ERR_CAPACITY, "hv_integrate_rgbd_points_batch: image exceeds max_points");
+    HV_HIP(hipSetDevice(v->device));
+    const size_t dsz = depth_dtype == HV_DEPTH_U16 ? 2 : 4;
+    const void *d_depth = nullptr, *d_rgb = nullptr;
+    int rc = hv_stage_in(v, depth, (size_t)npx * dsz * n_frames, loc, 0, &d_depth);
+    if (rc != HV_OK) return rc;
+    rc = hv_stage_in(v, rgb, (size_t)npx * 3 * n_frames, loc, 1, &d_rgb);
+    if (rc != HV_OK) return rc;
+    const int per_chunk = (int)std::max<int64_t>(1, v->cfg.max_points / npx);
+    for (int f0 = 0; f0 < n_frames; f0 += per_chunk) {
+        const int nf = std::min(per_chunk, n_frames - f0);
+        for (int f = 0; f < nf; ++f) {
+            rc = unproject_device(v, (const char *)d_depth + npx * dsz * (size_t)(f0 + f), depth_dtype, depth_scale,
+                                  (const uint8_t *)d_rgb + npx * 3 * (size_t)(f0 + f), height, width, intr,
+                                  T_cw + 16 * (size_t)(f0 + f), min_depth, max_depth, (int64_t)f * npx);
+            if (rc != HV_OK) return rc;
+        }
+        rc = integrate_device_points(v, v->scratch_points, (int64_t)nf * npx, v->scratch_colors, HV_COLOR_F32, v->sort_keys_out);
+        if (rc != HV_OK) return rc;
+    }
     return HV_OK;
 }
 

@@ -13,6 +13,7 @@ from .volumetric_integrator_base import (
     VolumetricIntegrationPointCloud,
     VolumetricIntegrationTaskType,
     VolumetricIntegratorBase,
+    push_to_front,
 )
 from .volumetric_integrator_types import DatasetEnvironmentType
 
@@ -40,7 +41,7 @@ class VolumetricIntegratorVoxelGrid(VolumetricIntegratorBase):
         factory = constructor_kwargs.get("volume_factory", _default_voxel_grid)
         self.volume = factory(Parameters.kVolumetricIntegrationVoxelLength, Parameters.kVolumetricIntegrationBlockSize,
                               Parameters.kVolumetricIntegrationHipDevice, Parameters.kVolumetricIntegrationHipMaxBlocks,
-                              max(camera.width * camera.height, 1 << 16))
+                              16 * max(camera.width * camera.height, 1 << 12))  # room for 16-frame batched replay
         carving_depth_max = (Parameters.kVolumetricIntegrationVoxelGridCarvingDepthMaxIndoor if indoor
                              else Parameters.kVolumetricIntegrationVoxelGridCarvingDepthMaxOutdoor)
         fx, fy, cx, cy = self.get_camera_intrinsics_for_depth()
@@ -81,24 +82,50 @@ class VolumetricIntegratorVoxelGrid(VolumetricIntegratorBase):
                 else:
                     ttype = self.last_input_task.task_type
                     if ttype == VolumetricIntegrationTaskType.INTEGRATE:
-                        keyframe_data = self.last_input_task.keyframe_data
-                        keyframe_data.semantic_img = None
-                        keyframe_data.semantic_instances_img = None
-                        color, depth, _, _, _ = self.estimate_depth_if_needed_and_rectify(keyframe_data)
-                        if depth is not None:
-                            pose = keyframe_data.pose  # Tcw
+                        # Backlog (offline reconstruction, rebuild() after loop closure): drain the queued INTEGRATE tasks and
+                        # fuse them with one batched call (one device sort per chunk of frames, hv_integrate_rgbd_points_batch);
+                        # bit-identical to fusing them one by one in this order.  Carving needs the per-frame interleaving.
+                        tasks = [self.last_input_task]
+                        can_batch = (not Parameters.kVolumetricIntegrationVoxelGridUseCarving) and hasattr(self.volume, "integrate_rgbd_batch")
+                        while can_batch and len(tasks) < 16:
+                            try:
+                                nxt = q_in.get_nowait()
+                            except Exception:
+                                break
+                            if nxt is not None and nxt.task_type == VolumetricIntegrationTaskType.INTEGRATE:
+                                tasks.append(nxt)
+                            else:
+                                push_to_front(q_in, nxt)  # not ours: put it back where it was
+                                break
+                        frames = []
+                        for task in tasks:
+                            keyframe_data = task.keyframe_data
+                            keyframe_data.semantic_img = None
+                            keyframe_data.semantic_instances_img = None
+                            color, depth, _, _, _ = self.estimate_depth_if_needed_and_rectify(keyframe_data)
+                            if depth is None:
+                                continue
                             depth_filtered = depth
                             if Parameters.kVolumetricIntegrationVoxelGridShadowPointsFilter:
                                 depth_filtered = self.volume.filter_shadow_points(depth)  # depth.py:103-146 on the GPU
-                            fx, fy, cx, cy = self.get_camera_intrinsics_for_depth()
-                            if Parameters.kVolumetricIntegrationVoxelGridUseCarving:
-                                self.camera_frustrum.set_T_cw(pose)
-                                self.volume.carve(self.camera_frustrum, np.ascontiguousarray(depth, dtype=self.dtype_depths),
-                                                  Parameters.kVolumetricIntegrationVoxelGridCarvingDepthThreshold)
-                            # depth2pointcloud + world transform + integrate, fused on the GPU
-                            self.volume.integrate_rgbd(depth_filtered, color, fx, fy, cx, cy, pose,
-                                                       max_depth=self.volumetric_integration_depth_trunc)
-                            self.last_integrated_id = keyframe_data.id
+                            frames.append((color, depth, depth_filtered, keyframe_data.pose, keyframe_data.id))
+                        fx, fy, cx, cy = self.get_camera_intrinsics_for_depth()
+                        on_host = all(isinstance(f[2], np.ndarray) for f in frames)
+                        if len(frames) > 1 and on_host and len({f[2].shape for f in frames}) == 1:
+                            self.volume.integrate_rgbd_batch(np.stack([f[2] for f in frames]), np.stack([f[0] for f in frames]), fx, fy, cx, cy,
+                                                             np.stack([f[3] for f in frames]),
+                                                             max_depth=self.volumetric_integration_depth_trunc)
+                        else:
+                            for color, depth, depth_filtered, pose, _ in frames:
+                                if Parameters.kVolumetricIntegrationVoxelGridUseCarving:
+                                    self.camera_frustrum.set_T_cw(pose)
+                                    self.volume.carve(self.camera_frustrum, np.ascontiguousarray(depth, dtype=self.dtype_depths),
+                                                      Parameters.kVolumetricIntegrationVoxelGridCarvingDepthThreshold)
+                                # depth2pointcloud + world transform + integrate, fused on the GPU
+                                self.volume.integrate_rgbd(depth_filtered, color, fx, fy, cx, cy, pose,
+                                                           max_depth=self.volumetric_integration_depth_trunc)
+                        if frames:
+                            self.last_integrated_id = frames[-1][4]
                             do_output = True
                             if self.last_output is not None:
                                 if time.perf_counter() - self.last_output.timestamp < Parameters.kVolumetricIntegrationOutputTimeInterval:

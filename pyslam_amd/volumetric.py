@@ -276,6 +276,20 @@ class VoxelBlockGrid(_Volume):
             )
         )
 
+    def integrate_rgbd_batch(self, depth, rgb, fx, fy, cx, cy, T_cw, max_depth=np.inf, min_depth=0.0, depth_scale=1.0):
+        """Replay F posed frames ([F,H,W] depth, [F,H,W,3] rgb, [F,4,4] T_cw): bit-identical to F integrate_rgbd()
+        calls, with one device sort per max_points / (H*W) frames (create the grid with a large max_points)."""
+        dkind = L.HV_DEPTH_U16 if str(depth.dtype) in ("uint16", "torch.uint16") else L.HV_DEPTH_F32
+        F, H, W = (int(x) for x in depth.shape)
+        if not hasattr(depth, "data_ptr"):
+            depth = np.ascontiguousarray(depth)
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        intr = np.array([fx, fy, cx, cy], dtype=np.float64)
+        T = np.ascontiguousarray(np.asarray(T_cw, dtype=np.float64).reshape(F, 16))
+        L.check(self._lib.hv_integrate_rgbd_points_batch(self._h, L.ptr(depth), dkind, float(depth_scale), L.ptr(rgb), F, H, W,
+                                                         L.ptr(intr), L.ptr(T), float(min_depth), float(min(max_depth, 3.0e38)),
+                                                         L.location(depth)))
+
     # -- queries ---------------------------------------------------------------------------------
     def _collect(self, call):
         n = ctypes.c_int64()

@@ -90,6 +90,10 @@ class OracleVoxelGrid:
         p, c, _ = host_prep.frame_to_world_f32(depth, rgb, fx, fy, cx, cy, T_cw, max_depth, min_depth)
         self.grid.integrate(p, c)
 
+    def integrate_rgbd_batch(self, depth, rgb, fx, fy, cx, cy, T_cw, max_depth=np.inf, min_depth=0.0):
+        for f in range(len(depth)):
+            self.integrate_rgbd(depth[f], rgb[f], fx, fy, cx, cy, T_cw[f], max_depth, min_depth)
+
     def carve(self, *a):
         pass
 

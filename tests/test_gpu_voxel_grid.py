@@ -247,3 +247,23 @@ def test_direct_voxel_grid_alias_matches_reference_voxelgrid():
         np.testing.assert_array_equal(pa, pb)
         np.testing.assert_array_equal(ca, cb)
         assert gpu.size() == ref.size()
+
+
+def test_batched_replay_is_bit_identical_to_per_frame():
+    """hv_integrate_rgbd_points_batch: one sort per chunk of frames, same per-voxel fold order."""
+    import torch
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    depth, rgb, T = s.batch(0, 7)
+    npx = s.width * s.height
+    one = VoxelBlockGrid(0.02, 8, max_blocks=1 << 13, max_points=npx)
+    for f in range(7):
+        one.integrate_rgbd(depth[f], rgb[f], *s.intrinsics, T[f], max_depth=4.0)
+    for max_points, dev in ((3 * npx, False), (8 * npx, True)):  # chunks of 3 frames / one chunk; host and device inputs
+        g = VoxelBlockGrid(0.02, 8, max_blocks=1 << 13, max_points=max_points)
+        d, c = (torch.from_numpy(depth).cuda(), torch.from_numpy(rgb).cuda()) if dev else (depth, rgb)
+        g.integrate_rgbd_batch(d, c, *s.intrinsics, T, max_depth=4.0)
+        for a, b in zip(g.dump(), one.dump()):
+            np.testing.assert_array_equal(a, b)
