@@ -1145,7 +1145,7 @@ static int tsdf_launch_touch(hv_volume *v, hipStream_t s, const HvFrameParams &P
 // Second half on the volume's stream: sweep the touched units.  Grid: enough workgroups to fill
 // 256 CUs; grid-stride over the device-side touched count (no host round trip between launches).
 static int tsdf_launch_integrate(hv_volume *v, const HvFrameParams &P, int parity) {
-    static const int grid_blocks = getenv("HV_TSDF_GRID") ? atoi(getenv("HV_TSDF_GRID")) : 4096;
+    static const int grid_blocks = getenv("HV_TSDF_GRID") ? atoi(getenv("HV_TSDF_GRID")) : 8192; // > touched units of a frame: no second pass per block
     const dim3 grid(grid_blocks), block(256);
     const int32_t *list = touched_list_of(v, parity);
     const uint2 *px = frame_px_of(v, parity);
