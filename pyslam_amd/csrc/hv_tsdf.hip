@@ -302,6 +302,67 @@ __device__ __forceinline__ void hv_tsdf_apply(bool valid, float t, uint32_t c, f
     sb += (c >> 16) & 255u;
 }
 
+// ---- Predicated ("fast") forms for the multi-frame sweep -------------------------------------------------------------
+// Same arithmetic, no divergent control flow: every lane runs the whole chain and a single predicate selects the
+// result, so the compiler can interleave the ZH voxels of a lane (ZH gathers in flight) and does not spend VALU slots on
+// re-materialising phi values.  The two rare regimes the short division / square-root chains do not cover are excluded
+// by wave-uniform tests in the caller, which then runs the general code above: a voxel column that comes within 1 mm of
+// the camera plane (hv_div2 wants pc2 >= 2^-20 when pc2 > 0) and voxels observed more than 2^24 - 64 times.
+
+// sqrtf(x), correctly rounded, for x >= 2^-96 (here: x >= 1): v_sqrt_f32 (1 ulp) + the compiler's own neighbour test,
+// minus the denormal pre-scaling and the zero / infinity class fix-up it has to add for arbitrary operands.
+__device__ __forceinline__ float hv_sqrt_ge1(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u);
+    const float su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float vp = fmaf(-sd, s, x);
+    const float vs = fmaf(-su, s, x);
+    float r = (vp <= 0.0f) ? sd : s;
+    r = (vs > 0.0f) ? su : r;
+    return r;
+}
+
+__device__ __forceinline__ bool hv_tsdf_eval_fast(const HvFrameParams &P, const uint2 *__restrict__ frame_px, float pc0,
+                                                  float pc1, float pc2, float &t, uint32_t &rgb) {
+    float q0, q1;
+    // (image-tile sharding, P.tiled, is left to the general path)
+    hv_div2(pc0 * P.fx, pc1 * P.fy, pc2, q0, q1); // pc2 <= 0: inf / NaN / a mirrored pixel, rejected by `front`
+    const float u_f = q0 + P.cx + 0.5f;
+    const float v_f = q1 + P.cy + 0.5f;
+    // u_f in [0.0001, safe_width) as ONE unsigned compare: for non-negative floats the bit patterns order like the
+    // values, and a negative / NaN operand has a pattern above every finite positive one
+    const uint32_t lo = __float_as_uint(0.0001f);
+    const bool in_u = (__float_as_uint(u_f) - lo) < (__float_as_uint(P.safe_width_f) - lo);
+    const bool in_v = (__float_as_uint(v_f) - lo) < (__float_as_uint(P.safe_height_f) - lo);
+    bool ok = (int)(pc2 > 0.0f) & (int)in_u & (int)in_v;
+    const int u = (int)u_f; // saturating conversions: garbage lanes stay defined
+    const int v = (int)v_f;
+    const uint32_t off = ok ? (uint32_t)v * (uint32_t)P.W + (uint32_t)u : 0u;
+    const uint2 rec = frame_px[off];
+    const float d = __uint_as_float(rec.x);
+    const float xx = ((float)u - P.cx) * P.ffl_inv_x;
+    const float yy = ((float)v - P.cy) * P.ffl_inv_y;
+    const float sdf = (d - pc2) * hv_sqrt_ge1(xx * xx + yy * yy + 1.0f);
+    ok = (int)ok & (int)(d > 0.0f) & (int)(sdf > -P.sdf_trunc_f);
+    t = fminf(sdf * P.sdf_trunc_inv_f, 1.0f); // == `if (t > 1) t = 1` for the non-NaN t of an accepted voxel
+    rgb = rec.y;
+    return ok;
+}
+
+// Running mean with the weight carried as a float (exact below 2^24): no int->float conversion and one add less per
+// update; the caller converts back once per unit.
+__device__ __forceinline__ void hv_tsdf_apply_fast(bool ok, float t, uint32_t rgb, float &tsdf, float &wf, uint32_t &sr,
+                                                   uint32_t &sg, uint32_t &sb) {
+    const float wf1 = wf + 1.0f;
+    const float nt = hv_div1(tsdf * wf + t, wf1);
+    tsdf = ok ? nt : tsdf;
+    wf = ok ? wf1 : wf;
+    const uint32_t c = ok ? rgb : 0u;
+    sr += c & 255u;
+    sg += (c >> 8) & 255u;
+    sb += (c >> 16) & 255u;
+}
+
 // ZB z-slabs of one lane (ZB x 4 voxels).  Phase 1 evaluates every voxel (ZB*4 independent 8-byte
 // gathers in flight, no voxel-plane traffic); phase 2 read-modify-writes only the 16-byte pieces
 // that hold an updated voxel.  pc[][] is advanced by ZB z-steps.
@@ -735,12 +796,13 @@ __global__ __launch_bounds__(64 * 16 / (ZPW * SPLIT)) void k_tsdf_integrate_batc
 template <int ZH, int SPLIT>
 __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT) void k_tsdf_integrate_batch_col(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
-    char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int parity) {
+    char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int parity,
+    int general) {
     constexpr int TASKS = 64 / ZH;          // wave tasks per unit
     constexpr int WAVES = TASKS / SPLIT;    // waves per workgroup
     int n_units = table.counters[HV_CNT_TOUCH0 + parity];
     if (n_units > table.max_blocks) n_units = table.max_blocks;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: keeps the z-walk replay loop scalar
     const int lane = threadIdx.x & 63;
     for (int item = blockIdx.x; item < n_units * SPLIT; item += gridDim.x) {
         const int t = item / SPLIT;
@@ -768,9 +830,9 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT) void k_tsdf_integrate_batch
             vg[zz] = ((const uint32_t *)(unit + 3 * PLANE_BYTES))[q];
             vb[zz] = ((const uint32_t *)(unit + 4 * PLANE_BYTES))[q];
         }
-        unsigned dirty = 0;
         // the voxel centre of (x, y, z = 0) does not depend on the frame (voxel / unit length are the volume's)
         float p0, p1, p2;
+        bool tiled;
         {
             const HvFrameParams &P = Ps[__ffsll((long long)mask) - 1];
             const double o0 = (double)ux * P.unit_length;
@@ -779,31 +841,91 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT) void k_tsdf_integrate_batch
             p0 = (float)((double)(P.half_voxel_length_f + P.voxel_length_f * (float)x) + o0);
             p1 = (float)((double)(P.half_voxel_length_f + P.voxel_length_f * (float)y) + o1);
             p2 = (float)((double)P.half_voxel_length_f + o2);
+            tiled = P.tiled != 0; // image-tile sharding is a property of the volume: the same for every frame
         }
-        while (mask) {
-            const int f = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const HvFrameParams &P = Ps[f];
-            const uint2 *px = frame_px + (int64_t)f * P.H * P.W;
-            const float inc0 = P.ext_scaled_col2[0], inc1 = P.ext_scaled_col2[1], inc2 = P.ext_scaled_col2[2];
-            float pc0 = ((P.ext[0] * p0 + P.ext[1] * p1) + P.ext[2] * p2) + P.ext[3];
-            float pc1 = ((P.ext[4] * p0 + P.ext[5] * p1) + P.ext[6] * p2) + P.ext[7];
-            float pc2 = ((P.ext[8] * p0 + P.ext[9] * p1) + P.ext[10] * p2) + P.ext[11];
-            for (int s = 0; s < z0; ++s) { // the reference's repeated float additions along z, replayed
-                pc0 += inc0;
-                pc1 += inc1;
-                pc2 += inc2;
+        bool heavy = false; // a voxel near 2^24 observations: float weights would stop being exact
+#pragma unroll
+        for (int zz = 0; zz < ZH; ++zz) heavy |= vw[zz] >= (1u << 24) - 64u;
+        unsigned dirty = 0;
+        if (general || tiled || __any(heavy)) {
+            while (mask) {
+                const int f = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const HvFrameParams &P = Ps[f];
+                const uint2 *px = frame_px + (int64_t)f * P.H * P.W;
+                const float inc0 = P.ext_scaled_col2[0], inc1 = P.ext_scaled_col2[1], inc2 = P.ext_scaled_col2[2];
+                float pc0 = ((P.ext[0] * p0 + P.ext[1] * p1) + P.ext[2] * p2) + P.ext[3];
+                float pc1 = ((P.ext[4] * p0 + P.ext[5] * p1) + P.ext[6] * p2) + P.ext[7];
+                float pc2 = ((P.ext[8] * p0 + P.ext[9] * p1) + P.ext[10] * p2) + P.ext[11];
+                for (int s = 0; s < z0; ++s) { // the reference's repeated float additions along z, replayed
+                    pc0 += inc0;
+                    pc1 += inc1;
+                    pc2 += inc2;
+                }
+#pragma unroll
+                for (int zz = 0; zz < ZH; ++zz) {
+                    float tv = 0.f;
+                    uint32_t cv = 0u;
+                    const bool ok = hv_tsdf_eval(P, px, pc0, pc1, pc2, tv, cv);
+                    pc0 += inc0;
+                    pc1 += inc1;
+                    pc2 += inc2;
+                    hv_tsdf_apply(ok, tv, cv, vt[zz], vw[zz], vr[zz], vg[zz], vb[zz]);
+                    if (ok) dirty |= 1u << zz;
+                }
+            }
+        } else {
+            float wf[ZH];
+#pragma unroll
+            for (int zz = 0; zz < ZH; ++zz) wf[zz] = (float)vw[zz];
+            while (mask) {
+                const int f = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const HvFrameParams &P = Ps[f];
+                const uint2 *px = frame_px + (int64_t)f * P.H * P.W;
+                const float inc0 = P.ext_scaled_col2[0], inc1 = P.ext_scaled_col2[1], inc2 = P.ext_scaled_col2[2];
+                float pc0 = ((P.ext[0] * p0 + P.ext[1] * p1) + P.ext[2] * p2) + P.ext[3];
+                float pc1 = ((P.ext[4] * p0 + P.ext[5] * p1) + P.ext[6] * p2) + P.ext[7];
+                float pc2 = ((P.ext[8] * p0 + P.ext[9] * p1) + P.ext[10] * p2) + P.ext[11];
+                for (int s = 0; s < z0; ++s) {
+                    pc0 += inc0;
+                    pc1 += inc1;
+                    pc2 += inc2;
+                }
+                // does this column come within 1 mm of the camera plane on its ZH steps?  (pc2 is monotone along z up to
+                // rounding that is orders of magnitude below the margin)
+                const float pc2_end = pc2 + (float)ZH * inc2;
+                const bool near_plane = (int)(fminf(pc2, pc2_end) < 0x1p-10f) & (int)(fmaxf(pc2, pc2_end) > -0x1p-10f);
+                float tv[ZH];
+                uint32_t cv[ZH];
+                bool ok[ZH];
+                if (__any(near_plane)) {
+#pragma unroll
+                    for (int zz = 0; zz < ZH; ++zz) {
+                        tv[zz] = 0.f;
+                        cv[zz] = 0u;
+                        ok[zz] = hv_tsdf_eval(P, px, pc0, pc1, pc2, tv[zz], cv[zz]);
+                        pc0 += inc0;
+                        pc1 += inc1;
+                        pc2 += inc2;
+                    }
+                } else {
+#pragma unroll
+                    for (int zz = 0; zz < ZH; ++zz) {
+                        ok[zz] = hv_tsdf_eval_fast(P, px, pc0, pc1, pc2, tv[zz], cv[zz]);
+                        pc0 += inc0;
+                        pc1 += inc1;
+                        pc2 += inc2;
+                    }
+                }
+#pragma unroll
+                for (int zz = 0; zz < ZH; ++zz) hv_tsdf_apply_fast(ok[zz], tv[zz], cv[zz], vt[zz], wf[zz], vr[zz], vg[zz], vb[zz]);
             }
 #pragma unroll
             for (int zz = 0; zz < ZH; ++zz) {
-                float tv = 0.f;
-                uint32_t cv = 0u;
-                const bool ok = hv_tsdf_eval(P, px, pc0, pc1, pc2, tv, cv);
-                pc0 += inc0;
-                pc1 += inc1;
-                pc2 += inc2;
-                hv_tsdf_apply(ok, tv, cv, vt[zz], vw[zz], vr[zz], vg[zz], vb[zz]);
-                if (ok) dirty |= 1u << zz;
+                const uint32_t nw = (uint32_t)wf[zz];
+                if (nw != vw[zz]) dirty |= 1u << zz;
+                vw[zz] = nw;
             }
         }
 #pragma unroll
@@ -1297,9 +1419,11 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
     hipLaunchKernelGGL((k_tsdf_integrate_batch<Z, S>), dim3(8192), dim3(64 * 16 / (Z * S)), 0, v->stream, v->table,      \
                        v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0)
         static const int layout_col = getenv("HV_TSDF_BATCH_COL") ? atoi(getenv("HV_TSDF_BATCH_COL")) : 4; // ZH of the column mapping (default), 0 = slab mapping
+        // 1: run the general (branching) evaluation everywhere instead of the predicated one (A/B and parity tests)
+        static const int general = getenv("HV_TSDF_BATCH_GENERAL") ? atoi(getenv("HV_TSDF_BATCH_GENERAL")) : 0;
 #define HV_LAUNCH_COL(Z, S)                                                                                            \
     hipLaunchKernelGGL((k_tsdf_integrate_batch_col<Z, S>), dim3(8192), dim3(64 * (64 / Z) / S), 0, v->stream, v->table,   \
-                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0)
+                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0, general)
         if (use_lds && zpw == 2) {
             hipLaunchKernelGGL(k_tsdf_integrate_batch_lds, dim3(4096), dim3(512), 0, v->stream, v->table, v->touched_list,
                                (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
