@@ -239,6 +239,10 @@ struct hv_volume {
     bool touch_counters_clean = true; // both touched-list counters are zero (false after an online frame)
     void *batch_buf = nullptr;        // multi-frame sweep scratch: B frame records + B HvFrameParams
     size_t batch_buf_bytes = 0;
+    float *mult_table = nullptr;      // per-pixel depth-to-distance multiplier of the current intrinsics (multi-frame sweep)
+    size_t mult_table_bytes = 0;
+    float mult_key[4] = {0.f, 0.f, 0.f, 0.f}; // cx, cy, 1/fx, 1/fy the table was built for
+    int32_t mult_W = 0, mult_H = 0;
     // pinned ring of per-batch HvFrameParams (async H2D without a host sync per call)
     void *pinned_params[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t params_ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 
 #include "hv_common.h"
@@ -39,6 +40,15 @@ __device__ __forceinline__ float hv_multiplier(const HvFrameParams &P, int u, in
     const float xx = ((float)u - P.cx) * P.ffl_inv_x;
     const float yy = ((float)v - P.cy) * P.ffl_inv_y;
     return sqrtf(xx * xx + yy * yy + 1.0f);
+}
+
+// The depth-to-camera-distance multiplier depends on the pixel and the intrinsics only: one table per (intrinsics,
+// image size), rebuilt when they change, lets the multi-frame sweep replace ~20 VALU instructions (two conversions, the
+// normalisation, a correctly rounded sqrt) per voxel visit by a 4-byte gather at the pixel index it already has.
+__global__ __launch_bounds__(256) void k_tsdf_multiplier_table(HvFrameParams P, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.H * P.W) return;
+    out[i] = hv_multiplier(P, i % P.W, i / P.W);
 }
 
 __device__ __forceinline__ float hv_convert_depth(const HvFrameParams &P, const void *depth_raw, int64_t i) {
@@ -305,9 +315,9 @@ __device__ __forceinline__ void hv_tsdf_apply(bool valid, float t, uint32_t c, f
 // ---- Predicated ("fast") forms for the multi-frame sweep -------------------------------------------------------------
 // Same arithmetic, no divergent control flow: every lane runs the whole chain and a single predicate selects the
 // result, so the compiler can interleave the ZH voxels of a lane (ZH gathers in flight) and does not spend VALU slots on
-// re-materialising phi values.  The two rare regimes the short division / square-root chains do not cover are excluded
-// by wave-uniform tests in the caller, which then runs the general code above: a voxel column that comes within 1 mm of
-// the camera plane (hv_div2 wants pc2 >= 2^-20 when pc2 > 0) and voxels observed more than 2^24 - 64 times.
+// re-materialising phi values.  The two rare regimes the short division chains do not cover are picked out by
+// wave-uniform tests in the caller, which then runs the EXACT forms: a voxel column that comes within 1 mm of the camera
+// plane (hv_div2 wants pc2 >= 2^-20 when pc2 > 0) and voxels observed more than 2^24 - 64 times (integer weights).
 
 // sqrtf(x), correctly rounded, for x >= 2^-96 (here: x >= 1): v_sqrt_f32 (1 ulp) + the compiler's own neighbour test,
 // minus the denormal pre-scaling and the zero / infinity class fix-up it has to add for arbitrary operands.
@@ -322,11 +332,22 @@ __device__ __forceinline__ float hv_sqrt_ge1(float x) {
     return r;
 }
 
-__device__ __forceinline__ bool hv_tsdf_eval_fast(const HvFrameParams &P, const uint2 *__restrict__ frame_px, float pc0,
-                                                  float pc1, float pc2, float &t, uint32_t &rgb) {
+// EXACT = false: operands inside hv_div2's band (the caller's wave-uniform test), whole-image frames.
+// EXACT = true: any operands (IEEE division where pc2 < 2^-20) and the image-tile test of the tile-sharded mode.
+// MT: take the multiplier from the per-pixel table instead of computing it.
+template <bool EXACT, bool MT>
+__device__ __forceinline__ bool hv_tsdf_eval_fast(const HvFrameParams &P, const uint2 *__restrict__ frame_px,
+                                                  const float *__restrict__ mult, float pc0, float pc1, float pc2,
+                                                  float &t, uint32_t &rgb) {
+    const float a0 = pc0 * P.fx, a1 = pc1 * P.fy;
     float q0, q1;
-    // (image-tile sharding, P.tiled, is left to the general path)
-    hv_div2(pc0 * P.fx, pc1 * P.fy, pc2, q0, q1); // pc2 <= 0: inf / NaN / a mirrored pixel, rejected by `front`
+    hv_div2(a0, a1, pc2, q0, q1); // pc2 <= 0: inf / NaN / a mirrored pixel, rejected by the pc2 > 0 term below
+    if (EXACT) {
+        const bool tiny = !(pc2 >= 0x1p-20f);
+        const float e0 = a0 / pc2, e1 = a1 / pc2;
+        q0 = tiny ? e0 : q0;
+        q1 = tiny ? e1 : q1;
+    }
     const float u_f = q0 + P.cx + 0.5f;
     const float v_f = q1 + P.cy + 0.5f;
     // u_f in [0.0001, safe_width) as ONE unsigned compare: for non-negative floats the bit patterns order like the
@@ -337,12 +358,23 @@ __device__ __forceinline__ bool hv_tsdf_eval_fast(const HvFrameParams &P, const 
     bool ok = (int)(pc2 > 0.0f) & (int)in_u & (int)in_v;
     const int u = (int)u_f; // saturating conversions: garbage lanes stay defined
     const int v = (int)v_f;
+    if (EXACT && P.tiled) {
+        const bool in_tile_u = (int)(u >= P.tile_u0) & (int)(u < P.tile_u1);
+        const bool in_tile_v = (int)(v >= P.tile_v0) & (int)(v < P.tile_v1);
+        ok = (int)ok & (int)in_tile_u & (int)in_tile_v;
+    }
     const uint32_t off = ok ? (uint32_t)v * (uint32_t)P.W + (uint32_t)u : 0u;
     const uint2 rec = frame_px[off];
     const float d = __uint_as_float(rec.x);
-    const float xx = ((float)u - P.cx) * P.ffl_inv_x;
-    const float yy = ((float)v - P.cy) * P.ffl_inv_y;
-    const float sdf = (d - pc2) * hv_sqrt_ge1(xx * xx + yy * yy + 1.0f);
+    float m;
+    if (MT) {
+        m = mult[off];
+    } else {
+        const float xx = ((float)u - P.cx) * P.ffl_inv_x;
+        const float yy = ((float)v - P.cy) * P.ffl_inv_y;
+        m = hv_sqrt_ge1(xx * xx + yy * yy + 1.0f);
+    }
+    const float sdf = (d - pc2) * m;
     ok = (int)ok & (int)(d > 0.0f) & (int)(sdf > -P.sdf_trunc_f);
     t = fminf(sdf * P.sdf_trunc_inv_f, 1.0f); // == `if (t > 1) t = 1` for the non-NaN t of an accepted voxel
     rgb = rec.y;
@@ -793,11 +825,12 @@ __global__ __launch_bounds__(64 * 16 / (ZPW * SPLIT)) void k_tsdf_integrate_batc
 // column per frame instead of four and replays at most 16 - ZH steps of the reference's z-walk instead of up to 14
 // steps on four columns: fewer VALU instructions per voxel (the sweep is VALU-bound: 85 % VALU busy).
 // A unit = 4 column groups x (16 / ZH) z ranges = 64 / ZH wave tasks, SPLIT workgroups per unit.
-template <int ZH, int SPLIT>
+template <int ZH, int SPLIT, bool MT>
 __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT) void k_tsdf_integrate_batch_col(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
     char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int parity,
-    int general) {
+    int general, const float *__restrict__ mult) {
+    constexpr int G = ZH < 4 ? ZH : 4; // voxels of a lane evaluated together (G gathers in flight), then folded
     constexpr int TASKS = 64 / ZH;          // wave tasks per unit
     constexpr int WAVES = TASKS / SPLIT;    // waves per workgroup
     int n_units = table.counters[HV_CNT_TOUCH0 + parity];
@@ -847,7 +880,7 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT) void k_tsdf_integrate_batch
 #pragma unroll
         for (int zz = 0; zz < ZH; ++zz) heavy |= vw[zz] >= (1u << 24) - 64u;
         unsigned dirty = 0;
-        if (general || tiled || __any(heavy)) {
+        if (general || __any(heavy)) {
             while (mask) {
                 const int f = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
@@ -864,9 +897,9 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT) void k_tsdf_integrate_batch
                 }
 #pragma unroll
                 for (int zz = 0; zz < ZH; ++zz) {
-                    float tv = 0.f;
-                    uint32_t cv = 0u;
-                    const bool ok = hv_tsdf_eval(P, px, pc0, pc1, pc2, tv, cv);
+                    float tv;
+                    uint32_t cv;
+                    const bool ok = hv_tsdf_eval_fast<true, MT>(P, px, mult, pc0, pc1, pc2, tv, cv);
                     pc0 += inc0;
                     pc1 += inc1;
                     pc2 += inc2;
@@ -896,30 +929,36 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT) void k_tsdf_integrate_batch
                 // rounding that is orders of magnitude below the margin)
                 const float pc2_end = pc2 + (float)ZH * inc2;
                 const bool near_plane = (int)(fminf(pc2, pc2_end) < 0x1p-10f) & (int)(fmaxf(pc2, pc2_end) > -0x1p-10f);
-                float tv[ZH];
-                uint32_t cv[ZH];
-                bool ok[ZH];
-                if (__any(near_plane)) {
+                if (tiled || __any(near_plane)) {
 #pragma unroll
                     for (int zz = 0; zz < ZH; ++zz) {
-                        tv[zz] = 0.f;
-                        cv[zz] = 0u;
-                        ok[zz] = hv_tsdf_eval(P, px, pc0, pc1, pc2, tv[zz], cv[zz]);
+                        float tv;
+                        uint32_t cv;
+                        const bool ok = hv_tsdf_eval_fast<true, MT>(P, px, mult, pc0, pc1, pc2, tv, cv);
                         pc0 += inc0;
                         pc1 += inc1;
                         pc2 += inc2;
+                        hv_tsdf_apply_fast(ok, tv, cv, vt[zz], wf[zz], vr[zz], vg[zz], vb[zz]);
                     }
                 } else {
+                    // G voxels evaluated together (G gathers in flight), then folded
 #pragma unroll
-                    for (int zz = 0; zz < ZH; ++zz) {
-                        ok[zz] = hv_tsdf_eval_fast(P, px, pc0, pc1, pc2, tv[zz], cv[zz]);
-                        pc0 += inc0;
-                        pc1 += inc1;
-                        pc2 += inc2;
+                    for (int zg = 0; zg < ZH; zg += G) {
+                        float tv[G];
+                        uint32_t cv[G];
+                        bool ok[G];
+#pragma unroll
+                        for (int k = 0; k < G; ++k) {
+                            ok[k] = hv_tsdf_eval_fast<false, MT>(P, px, mult, pc0, pc1, pc2, tv[k], cv[k]);
+                            pc0 += inc0;
+                            pc1 += inc1;
+                            pc2 += inc2;
+                        }
+#pragma unroll
+                        for (int k = 0; k < G; ++k)
+                            hv_tsdf_apply_fast(ok[k], tv[k], cv[k], vt[zg + k], wf[zg + k], vr[zg + k], vg[zg + k], vb[zg + k]);
                     }
                 }
-#pragma unroll
-                for (int zz = 0; zz < ZH; ++zz) hv_tsdf_apply_fast(ok[zz], tv[zz], cv[zz], vt[zz], wf[zz], vr[zz], vg[zz], vb[zz]);
             }
 #pragma unroll
             for (int zz = 0; zz < ZH; ++zz) {
@@ -1309,6 +1348,25 @@ static int tsdf_integrate_one(hv_volume *v, const void *d_depth, int depth_dtype
     return tsdf_launch_integrate(v, P, parity);
 }
 
+// (Re)build the per-pixel multiplier table when the intrinsics or the image size changed (stream-ordered).
+static int tsdf_multiplier_table(hv_volume *v, const HvFrameParams &P) {
+    const float key[4] = {P.cx, P.cy, P.ffl_inv_x, P.ffl_inv_y};
+    if (v->mult_table != nullptr && v->mult_W == P.W && v->mult_H == P.H && memcmp(key, v->mult_key, sizeof(key)) == 0)
+        return HV_OK;
+    const size_t npx = (size_t)P.W * P.H;
+    void *buf = v->mult_table;
+    int rc = hv_ensure_buffer(v, &buf, &v->mult_table_bytes, npx * sizeof(float));
+    if (rc != HV_OK) return rc;
+    v->mult_table = (float *)buf;
+    hipLaunchKernelGGL(k_tsdf_multiplier_table, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream, P,
+                       v->mult_table);
+    HV_HIP(hipGetLastError());
+    memcpy(v->mult_key, key, sizeof(key));
+    v->mult_W = P.W;
+    v->mult_H = P.H;
+    return HV_OK;
+}
+
 static int check_tsdf_args(hv_volume *v, const void *depth, const uint8_t *rgb, int H, int W,
                            const double *intr, const double *T_cw, int frames) {
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_tsdf_integrate: null volume");
@@ -1421,10 +1479,26 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         static const int layout_col = getenv("HV_TSDF_BATCH_COL") ? atoi(getenv("HV_TSDF_BATCH_COL")) : 4; // ZH of the column mapping (default), 0 = slab mapping
         // 1: run the general (branching) evaluation everywhere instead of the predicated one (A/B and parity tests)
         static const int general = getenv("HV_TSDF_BATCH_GENERAL") ? atoi(getenv("HV_TSDF_BATCH_GENERAL")) : 0;
+        // per-pixel multiplier table (HV_TSDF_BATCH_MULT=0: compute it per voxel visit instead)
+        static const int use_mult = getenv("HV_TSDF_BATCH_MULT") ? atoi(getenv("HV_TSDF_BATCH_MULT")) : 1;
+        const float *d_mult = nullptr;
+        if (use_mult) {
+            rc = tsdf_multiplier_table(v, params[0]);
+            if (rc != HV_OK) return rc;
+            d_mult = v->mult_table;
+        }
 #define HV_LAUNCH_COL(Z, S)                                                                                            \
-    hipLaunchKernelGGL((k_tsdf_integrate_batch_col<Z, S>), dim3(8192), dim3(64 * (64 / Z) / S), 0, v->stream, v->table,   \
-                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0, general)
-        if (use_lds && zpw == 2) {
+    do {                                                                                                               \
+        if (d_mult)                                                                                                    \
+            hipLaunchKernelGGL((k_tsdf_integrate_batch_col<Z, S, true>), dim3(8192), dim3(64 * (64 / Z) / S), 0, v->stream, \
+                               v->table, v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0, general, d_mult);   \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_tsdf_integrate_batch_col<Z, S, false>), dim3(8192), dim3(64 * (64 / Z) / S), 0,         \
+                               v->stream, v->table, v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0, general, \
+                               d_mult);                                                                                \
+    } while (0)
+        if (false) {
+        } else if (use_lds && zpw == 2) {
             hipLaunchKernelGGL(k_tsdf_integrate_batch_lds, dim3(4096), dim3(512), 0, v->stream, v->table, v->touched_list,
                                (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
         } else if (layout_col == 8) {

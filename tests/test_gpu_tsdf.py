@@ -212,3 +212,57 @@ def test_reset_and_reuse():
     assert gpu.num_blocks() == 0
     integrate_both(gpu, cpu, s, frames[::-1])
     assert_same_volume(gpu, cpu)
+
+
+def test_sweep_camera_inside_touched_units():
+    """Depth samples a few centimetres from the camera: touched units straddle the camera plane, so voxel columns cross
+    pc2 = 0 and the multi-frame sweep has to leave its short division chain (EXACT evaluation).  Online and batch forms
+    against the oracle, bit-exact."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    s, frames = synthetic_frames("tiny_160x120_2cm", 0, 6)
+    rng = np.random.default_rng(5)
+    near = []
+    for i, (depth, rgb, T) in enumerate(frames):
+        d = (0.03 + 0.25 * rng.random(depth.shape)).astype(np.float32)
+        d[rng.random(depth.shape) < 0.1] = 0.0
+        near.append((d, rgb, T))
+    gpu, cpu = make_pair(0.01, 0.04, max_blocks=1 << 14)
+    integrate_both(gpu, cpu, s, near)
+    assert_same_volume(gpu, cpu)
+    b = ScalableTSDFVolume(0.01, 0.04, max_blocks=1 << 14)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    b.integrate_batch(np.stack([f[0] for f in near]), np.stack([f[1] for f in near]), K, np.stack([f[2] for f in near]),
+                      depth_scale=1.0, depth_trunc=4.0)
+    assert_same_volume(b, cpu)
+
+
+@pytest.mark.parametrize("w0", [(1 << 24) - 70, (1 << 24) - 3])
+def test_sweep_weights_near_2_pow_24(w0):
+    """Voxels observed ~16.7 M times: the sweep's float-weight running mean stops being exact at 2^24, so it must switch to
+    the integer-weight form (first across the 2^24 - 64 guard, then across 2^24 itself).  Batch == online, bit-exact."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    s, frames = synthetic_frames("tiny_160x120_2cm", 0, 16)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    seed, _ = make_pair(0.02, 0.08, max_blocks=1 << 13)
+    integrate_both(seed, oracle.PortTsdf(0.02, 0.08), s, frames)
+    keys = seed.unit_keys()
+    payload = np.zeros((len(keys), 16 ** 3, 5), np.float32)
+    payload[..., 1] = float(w0)
+    payload[..., 0] = 0.25 * float(w0)
+    payload[..., 2:] = 64.0 * float(w0)
+    a = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 13)
+    b = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 13)
+    a.import_numerators(keys, payload)
+    b.import_numerators(keys, payload)
+    depth = np.stack([f[0] for f in frames])
+    rgb = np.stack([f[1] for f in frames])
+    T = np.stack([f[2] for f in frames])
+    for lo in (0, 8):
+        a.integrate_batch(depth[lo:lo + 8], rgb[lo:lo + 8], K, T[lo:lo + 8], depth_scale=1.0, depth_trunc=4.0)
+    integrate_both(b, oracle.PortTsdf(0.02, 0.08), s, frames)
+    da, db = a.dump(), b.dump()
+    assert int(da[2].max()) > w0 + 4  # weights really moved past the guard
+    for x, y in zip(da, db):
+        np.testing.assert_array_equal(x, y)
