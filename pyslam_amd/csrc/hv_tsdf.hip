@@ -398,23 +398,61 @@ __device__ __forceinline__ void hv_tsdf_apply_fast(bool ok, float t, uint32_t rg
 // ZB z-slabs of one lane (ZB x 4 voxels).  Phase 1 evaluates every voxel (ZB*4 independent 8-byte
 // gathers in flight, no voxel-plane traffic); phase 2 read-modify-writes only the 16-byte pieces
 // that hold an updated voxel.  pc[][] is advanced by ZB z-steps.
-template <int ZB>
+// EVAL 0: branching evaluation (hv_tsdf_eval); 1: predicated (all ZB*4 gathers really in flight together); 2: predicated
+// with the per-pixel multiplier table.
+template <int ZB, int EVAL>
 __device__ __forceinline__ void hv_tsdf_slabs(const HvFrameParams &P, const uint2 *__restrict__ frame_px,
-                                              char *__restrict__ unit, int wordb, float (&pc)[4][3], float inc0,
-                                              float inc1, float inc2) {
+                                              const float *__restrict__ mult, char *__restrict__ unit, int wordb,
+                                              float (&pc)[4][3], float inc0, float inc1, float inc2) {
     float tv[ZB][4];
     uint32_t cv[ZB][4];
     unsigned mask = 0;
+    if (EVAL == 0) {
 #pragma unroll
-    for (int zz = 0; zz < ZB; ++zz) {
+        for (int zz = 0; zz < ZB; ++zz) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                tv[zz][c] = 0.f;
+                cv[zz][c] = 0u;
+                if (hv_tsdf_eval(P, frame_px, pc[c][0], pc[c][1], pc[c][2], tv[zz][c], cv[zz][c])) mask |= 1u << (zz * 4 + c);
+                pc[c][0] += inc0;
+                pc[c][1] += inc1;
+                pc[c][2] += inc2;
+            }
+        }
+    } else {
+        // wave-uniform choice of the division form: columns that come within 1 mm of the camera plane on these ZB steps
+        // (and tile-sharded frames) take the EXACT form
+        bool near_plane = false;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            tv[zz][c] = 0.f;
-            cv[zz][c] = 0u;
-            if (hv_tsdf_eval(P, frame_px, pc[c][0], pc[c][1], pc[c][2], tv[zz][c], cv[zz][c])) mask |= 1u << (zz * 4 + c);
-            pc[c][0] += inc0;
-            pc[c][1] += inc1;
-            pc[c][2] += inc2;
+            const float e = pc[c][2] + (float)ZB * inc2;
+            near_plane |= (int)(fminf(pc[c][2], e) < 0x1p-10f) & (int)(fmaxf(pc[c][2], e) > -0x1p-10f);
+        }
+        if (P.tiled || __any(near_plane)) {
+#pragma unroll
+            for (int zz = 0; zz < ZB; ++zz) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (hv_tsdf_eval_fast<true, EVAL == 2>(P, frame_px, mult, pc[c][0], pc[c][1], pc[c][2], tv[zz][c], cv[zz][c]))
+                        mask |= 1u << (zz * 4 + c);
+                    pc[c][0] += inc0;
+                    pc[c][1] += inc1;
+                    pc[c][2] += inc2;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int zz = 0; zz < ZB; ++zz) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (hv_tsdf_eval_fast<false, EVAL == 2>(P, frame_px, mult, pc[c][0], pc[c][1], pc[c][2], tv[zz][c], cv[zz][c]))
+                        mask |= 1u << (zz * 4 + c);
+                    pc[c][0] += inc0;
+                    pc[c][1] += inc1;
+                    pc[c][2] += inc2;
+                }
+            }
         }
     }
     float4 vt[ZB];
@@ -448,14 +486,15 @@ __device__ __forceinline__ void hv_tsdf_slabs(const HvFrameParams &P, const uint
     }
 }
 
-// VARIANT 0: production (evaluate first, then fetch only the pieces that are updated).  6: unconditional
+// VARIANT 0: production (evaluate first - predicated, all gathers of a lane in flight -, then fetch only the pieces that are updated).  9: the same with the branching evaluation; 8 / 10 / 11: with the multiplier table, ZB = 2 / 4 / 1.  6: unconditional
 // prefetch of all 4 z-slabs (round-1 first version).  3: per-slab loads (A/B of the prefetch).  1: no voxel-plane traffic (math + gathers only).  2: plane traffic only
 // (no projection/gather/update).  1 and 2 exist for the roofline ablation in profiles/ (env
 // HV_TSDF_DEBUG_VARIANT); they do not produce a valid volume.
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int32_t *__restrict__ list,
                                                          int parity, char *__restrict__ pool,
-                                                         const uint2 *__restrict__ frame_px, HvFrameParams P) {
+                                                         const uint2 *__restrict__ frame_px, HvFrameParams P,
+                                                         const float *__restrict__ mult) {
     int n_touched = table.counters[HV_CNT_TOUCH0 + parity];
     if (n_touched > table.max_blocks) n_touched = table.max_blocks;
     // the next frame's touch pass appends to the other parity's counter: zero it here (stream order)
@@ -510,13 +549,16 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int
             }
             continue;
         }
-        if (VARIANT == 0 || VARIANT == 5 || VARIANT == 7) {
+        if (VARIANT == 0 || VARIANT == 5 || VARIANT == 7 || VARIANT >= 8) {
             // z-slabs evaluated per batch: 2 (107 VGPRs, 4 waves/SIMD) measured 7269 fps vs 6342 for 4
             // (180 VGPRs, 2 waves/SIMD) on the headline config
-            constexpr int ZB = (VARIANT == 0) ? 2 : (VARIANT == 7 ? 1 : 4);
+            constexpr int ZB = (VARIANT == 5 || VARIANT == 10) ? 4 : (VARIANT == 7 || VARIANT == 11 ? 1 : 2);
+            // production (0): predicated evaluation without the table (measured 8.5 k frames/s; 7.9 k with the table: the
+            // online kernel waits on memory, an extra gather costs more than the VALU work it saves; 6.2-7.2 k branching)
+            constexpr int EVAL = VARIANT == 9 ? 0 : (VARIANT >= 8 ? 2 : 1);
 #pragma unroll
             for (int zb = 0; zb < 4; zb += ZB) {
-                hv_tsdf_slabs<ZB>(P, frame_px, unit, (z0 + zb) * RR + x * R + y0, pc, inc0, inc1, inc2);
+                hv_tsdf_slabs<ZB, EVAL>(P, frame_px, mult, unit, (z0 + zb) * RR + x * R + y0, pc, inc0, inc1, inc2);
             }
             continue;
         }
@@ -1305,6 +1347,25 @@ static int tsdf_launch_touch(hv_volume *v, hipStream_t s, const HvFrameParams &P
 
 // Second half on the volume's stream: sweep the touched units.  Grid: enough workgroups to fill
 // 256 CUs; grid-stride over the device-side touched count (no host round trip between launches).
+// (Re)build the per-pixel multiplier table when the intrinsics or the image size changed (stream-ordered).
+static int tsdf_multiplier_table(hv_volume *v, const HvFrameParams &P) {
+    const float key[4] = {P.cx, P.cy, P.ffl_inv_x, P.ffl_inv_y};
+    if (v->mult_table != nullptr && v->mult_W == P.W && v->mult_H == P.H && memcmp(key, v->mult_key, sizeof(key)) == 0)
+        return HV_OK;
+    const size_t npx = (size_t)P.W * P.H;
+    void *buf = v->mult_table;
+    int rc = hv_ensure_buffer(v, &buf, &v->mult_table_bytes, npx * sizeof(float));
+    if (rc != HV_OK) return rc;
+    v->mult_table = (float *)buf;
+    hipLaunchKernelGGL(k_tsdf_multiplier_table, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream, P,
+                       v->mult_table);
+    HV_HIP(hipGetLastError());
+    memcpy(v->mult_key, key, sizeof(key));
+    v->mult_W = P.W;
+    v->mult_H = P.H;
+    return HV_OK;
+}
+
 static int tsdf_launch_integrate(hv_volume *v, const HvFrameParams &P, int parity) {
     static const int grid_blocks = getenv("HV_TSDF_GRID") ? atoi(getenv("HV_TSDF_GRID")) : 8192; // > touched units of a frame: no second pass per block
     const dim3 grid(grid_blocks), block(256);
@@ -1312,16 +1373,23 @@ static int tsdf_launch_integrate(hv_volume *v, const HvFrameParams &P, int parit
     const uint2 *px = frame_px_of(v, parity);
     char *pool = (char *)v->pool;
     hv_profile_begin(v);
+    const float *mult = v->mult_table;
+#define HV_LAUNCH_ONLINE(V) hipLaunchKernelGGL(k_tsdf_integrate<V>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P, mult)
     switch (v->debug_variant) {
-    case 1: hipLaunchKernelGGL(k_tsdf_integrate<1>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
-    case 2: hipLaunchKernelGGL(k_tsdf_integrate<2>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
-    case 3: hipLaunchKernelGGL(k_tsdf_integrate<3>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
-    case 4: hipLaunchKernelGGL(k_tsdf_integrate<4>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
-    case 5: hipLaunchKernelGGL(k_tsdf_integrate<5>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
-    case 6: hipLaunchKernelGGL(k_tsdf_integrate<6>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
-    case 7: hipLaunchKernelGGL(k_tsdf_integrate<7>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
-    default: hipLaunchKernelGGL(k_tsdf_integrate<0>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P); break;
+    case 1: HV_LAUNCH_ONLINE(1); break;
+    case 2: HV_LAUNCH_ONLINE(2); break;
+    case 3: HV_LAUNCH_ONLINE(3); break;
+    case 4: HV_LAUNCH_ONLINE(4); break;
+    case 5: HV_LAUNCH_ONLINE(5); break;
+    case 6: HV_LAUNCH_ONLINE(6); break;
+    case 7: HV_LAUNCH_ONLINE(7); break;
+    case 8: HV_LAUNCH_ONLINE(8); break;
+    case 9: HV_LAUNCH_ONLINE(9); break;
+    case 10: HV_LAUNCH_ONLINE(10); break;
+    case 11: HV_LAUNCH_ONLINE(11); break;
+    default: HV_LAUNCH_ONLINE(0); break;
     }
+#undef HV_LAUNCH_ONLINE
     hv_profile_end(v, 0);
     HV_HIP(hipGetLastError());
     return HV_OK;
@@ -1345,26 +1413,11 @@ static int tsdf_integrate_one(hv_volume *v, const void *d_depth, int depth_dtype
     tsdf_next_frame(v, P, parity);
     int rc = tsdf_launch_touch(v, v->stream, P, parity, d_depth, d_rgb);
     if (rc != HV_OK) return rc;
+    if (v->debug_variant == 8 || v->debug_variant >= 10) {
+        rc = tsdf_multiplier_table(v, P);
+        if (rc != HV_OK) return rc;
+    }
     return tsdf_launch_integrate(v, P, parity);
-}
-
-// (Re)build the per-pixel multiplier table when the intrinsics or the image size changed (stream-ordered).
-static int tsdf_multiplier_table(hv_volume *v, const HvFrameParams &P) {
-    const float key[4] = {P.cx, P.cy, P.ffl_inv_x, P.ffl_inv_y};
-    if (v->mult_table != nullptr && v->mult_W == P.W && v->mult_H == P.H && memcmp(key, v->mult_key, sizeof(key)) == 0)
-        return HV_OK;
-    const size_t npx = (size_t)P.W * P.H;
-    void *buf = v->mult_table;
-    int rc = hv_ensure_buffer(v, &buf, &v->mult_table_bytes, npx * sizeof(float));
-    if (rc != HV_OK) return rc;
-    v->mult_table = (float *)buf;
-    hipLaunchKernelGGL(k_tsdf_multiplier_table, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream, P,
-                       v->mult_table);
-    HV_HIP(hipGetLastError());
-    memcpy(v->mult_key, key, sizeof(key));
-    v->mult_W = P.W;
-    v->mult_H = P.H;
-    return HV_OK;
 }
 
 static int check_tsdf_args(hv_volume *v, const void *depth, const uint8_t *rgb, int H, int W,
