@@ -45,10 +45,10 @@ BYTES_PER_VOXEL = 20   # {f32 tsdf, u32 weight, 3 x u32 colour sums}
 # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this script at N=1, headline config;
 # 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, as MI355X_MICROARCH.md prescribes for gfx950).  They are
 # recorded measurements, not live ones: null when the configuration differs.
-PMC_TRAFFIC_BYTES = {"k_tsdf_integrate": int((2 * 136.6e3 + 209.8e3) * 1024),
-                     "k_tsdf_integrate_batch_col": int((2 * 649.7e3 + 373.0e3) * 1024)}
+PMC_TRAFFIC_BYTES = {"k_tsdf_integrate": int((2 * 137.5e3 + 209.8e3) * 1024),
+                     "k_tsdf_integrate_batch_col": int((2 * 739.6e3 + 439.5e3) * 1024)}
 # Recorded SQ counters of the multi-frame sweep (profiles/r01/pmc_sq_summary.txt): it is VALU-bound, not HBM-bound.
-SWEEP_VALU = {"valu_busy": 0.83, "valu_instr_per_voxel_visit": 86, "source": "profiles/r01/pmc_sq_summary.txt "
+SWEEP_VALU = {"valu_busy": 0.80, "valu_instr_per_voxel_visit": 54, "source": "profiles/r01/pmc_sq_summary.txt "
               "(SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); SQ_INSTS_VALU x 64 / voxel visits)"}
 
 
