@@ -743,10 +743,12 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
             const int32_t slot = hv_table_insert(table, key);
             if (slot >= 0) {
                 const bool hits = hv_unit_hits_tile(P, ux, uy, uz);
+                // both L1-bypassing pre-checks in flight together
+                const unsigned long long seen = __hip_atomic_load(&frame_mask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int32_t stamped = __hip_atomic_load(&stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // frame bit (skip the atomic when another wave of this frame already set it)
-                if (hits && !(__hip_atomic_load(&frame_mask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & fbit))
-                    atomicOr(&frame_mask[slot], fbit);
-                if (__hip_atomic_load(&stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != batch_stamp) {
+                if (hits && !(seen & fbit)) atomicOr(&frame_mask[slot], fbit);
+                if (stamped != batch_stamp) {
                     const int32_t old = atomicExch(&stamp[slot], batch_stamp);
                     if (old != batch_stamp) {
                         const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0], 1);
