@@ -250,42 +250,6 @@ __device__ __forceinline__ bool hv_tsdf_eval(const HvFrameParams &P, const uint2
     return true;
 }
 
-// Image patch of one unit staged in LDS: pixels [u0, u0+pw) x [v0, v0+ph) of the frame records.
-struct HvPatch {
-    const uint2 *lds; // nullptr: no patch (footprint too large / behind the camera) -> gather from global
-    int u0, v0, pw, ph;
-};
-
-// Same as hv_tsdf_eval, but the 8-byte frame record comes from the unit's LDS patch when the pixel
-// lies inside it (always, when a patch exists: the patch is the bounding box of the unit's
-// projection, padded), else from global memory.  Bit-identical results by construction.
-__device__ __forceinline__ bool hv_tsdf_eval_patch(const HvFrameParams &P, const uint2 *__restrict__ frame_px,
-                                                   const HvPatch &patch, float pc0, float pc1, float pc2, float &t,
-                                                   uint32_t &rgb) {
-    if (pc2 <= 0.0f) return false;
-    const float u_f = pc0 * P.fx / pc2 + P.cx + 0.5f;
-    const float v_f = pc1 * P.fy / pc2 + P.cy + 0.5f;
-    if (!(u_f >= 0.0001f && u_f < P.safe_width_f && v_f >= 0.0001f && v_f < P.safe_height_f)) return false;
-    const int u = (int)u_f;
-    const int v = (int)v_f;
-    if (P.tiled && (u < P.tile_u0 || u >= P.tile_u1 || v < P.tile_v0 || v >= P.tile_v1)) return false;
-    const int du = u - patch.u0, dv = v - patch.v0;
-    uint2 rec;
-    if (patch.lds != nullptr && du >= 0 && du < patch.pw && dv >= 0 && dv < patch.ph) {
-        rec = patch.lds[dv * patch.pw + du];
-    } else {
-        rec = frame_px[(int64_t)v * P.W + u];
-    }
-    const float d = __uint_as_float(rec.x);
-    if (d <= 0.0f) return false;
-    const float sdf = (d - pc2) * hv_multiplier(P, u, v);
-    if (!(sdf > -P.sdf_trunc_f)) return false;
-    t = sdf * P.sdf_trunc_inv_f;
-    if (t > 1.0f) t = 1.0f;
-    rgb = rec.y;
-    return true;
-}
-
 // a / b correctly rounded for operands clear of the overflow / denormal bands (same chain as hv_div2).
 __device__ __forceinline__ float hv_div1(float a, float b) {
     float r = __builtin_amdgcn_rcpf(b);
@@ -486,10 +450,10 @@ __device__ __forceinline__ void hv_tsdf_slabs(const HvFrameParams &P, const uint
     }
 }
 
-// VARIANT 0: production (evaluate first - predicated, all gathers of a lane in flight -, then fetch only the pieces that are updated).  9: the same with the branching evaluation; 8 / 10 / 11: with the multiplier table, ZB = 2 / 4 / 1.  6: unconditional
-// prefetch of all 4 z-slabs (round-1 first version).  3: per-slab loads (A/B of the prefetch).  1: no voxel-plane traffic (math + gathers only).  2: plane traffic only
-// (no projection/gather/update).  1 and 2 exist for the roofline ablation in profiles/ (env
-// HV_TSDF_DEBUG_VARIANT); they do not produce a valid volume.
+// VARIANT 0: production (evaluate first - predicated, all gathers of a lane in flight -, then fetch only the pieces that
+// are updated).  9: the same with the branching evaluation; 8: with the multiplier table of the sweep.  1: no voxel-plane
+// traffic (math + gathers only); 2: plane traffic only (no projection / gather / update) - 1 and 2 exist for the roofline
+// ablation in profiles/ (env HV_TSDF_DEBUG_VARIANT); they do not produce a valid volume.
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int32_t *__restrict__ list,
                                                          int parity, char *__restrict__ pool,
@@ -537,50 +501,33 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int
             }
         }
         char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
-        if (VARIANT == 4) { // ablation: the same 80 KiB read+written as one linear 20 KiB run per wave
-            uint4 *lin = (uint4 *)(unit + wave * 20480) + lane;
-            uint4 buf[20];
-#pragma unroll
-            for (int i = 0; i < 20; ++i) buf[i] = lin[i * 64];
-#pragma unroll
-            for (int i = 0; i < 20; ++i) {
-                buf[i].x += 1u;
-                lin[i * 64] = buf[i];
-            }
-            continue;
-        }
-        if (VARIANT == 0 || VARIANT == 5 || VARIANT == 7 || VARIANT >= 8) {
-            // z-slabs evaluated per batch: 2 (107 VGPRs, 4 waves/SIMD) measured 7269 fps vs 6342 for 4
-            // (180 VGPRs, 2 waves/SIMD) on the headline config
-            constexpr int ZB = (VARIANT == 5 || VARIANT == 10) ? 4 : (VARIANT == 7 || VARIANT == 11 ? 1 : 2);
-            // production (0): predicated evaluation without the table (measured 8.5 k frames/s; 7.9 k with the table: the
-            // online kernel waits on memory, an extra gather costs more than the VALU work it saves; 6.2-7.2 k branching)
-            constexpr int EVAL = VARIANT == 9 ? 0 : (VARIANT >= 8 ? 2 : 1);
+        if (VARIANT == 0 || VARIANT >= 8) {
+            // 2 z-slabs evaluated per batch: (107 VGPRs, 4 waves/SIMD) measured 7269 frames/s vs 6342 for 4
+            // (180 VGPRs, 2 waves/SIMD) on the headline config.  Evaluation form: predicated without the table
+            // (8.5 k frames/s; 7.9 k with the table: this kernel waits on memory, an extra gather costs more than the
+            // VALU work it saves; 6.2-7.2 k branching)
+            constexpr int ZB = 2;
+            constexpr int EVAL = VARIANT == 9 ? 0 : (VARIANT == 8 ? 2 : 1);
 #pragma unroll
             for (int zb = 0; zb < 4; zb += ZB) {
                 hv_tsdf_slabs<ZB, EVAL>(P, frame_px, mult, unit, (z0 + zb) * RR + x * R + y0, pc, inc0, inc1, inc2);
             }
             continue;
         }
+        // ablations: VARIANT 1 keeps the math and the gathers but no plane traffic, 2 the plane traffic only
         const int word0 = z0 * RR + x * R + y0;
-        // issue all 4 z-slabs' loads (20 x 1 KiB bursts per wave) before the first use
         float4 vt[4];
         uint4 vw[4], vr[4], vg[4], vb[4];
-        if (VARIANT == 3) {
-            // loads issued per z-slab inside the loop below (lower register pressure, 6 waves/SIMD)
-        } else if (VARIANT != 1) {
 #pragma unroll
-            for (int zz = 0; zz < 4; ++zz) {
+        for (int zz = 0; zz < 4; ++zz) {
+            if (VARIANT == 2) {
                 const int q = (word0 + zz * RR) >> 2;
                 vt[zz] = ((const float4 *)(unit + 0 * PLANE_BYTES))[q];
                 vw[zz] = ((const uint4 *)(unit + 1 * PLANE_BYTES))[q];
                 vr[zz] = ((const uint4 *)(unit + 2 * PLANE_BYTES))[q];
                 vg[zz] = ((const uint4 *)(unit + 3 * PLANE_BYTES))[q];
                 vb[zz] = ((const uint4 *)(unit + 4 * PLANE_BYTES))[q];
-            }
-        } else {
-#pragma unroll
-            for (int zz = 0; zz < 4; ++zz) {
+            } else {
                 vt[zz] = make_float4(0.f, 0.f, 0.f, 0.f);
                 vw[zz] = vr[zz] = vg[zz] = vb[zz] = make_uint4(0u, 0u, 0u, 0u);
             }
@@ -588,27 +535,15 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int
 #pragma unroll
         for (int zz = 0; zz < 4; ++zz) {
             bool any = false;
-            if (VARIANT == 3) {
-                const int q = (word0 + zz * RR) >> 2;
-                vt[zz] = ((const float4 *)(unit + 0 * PLANE_BYTES))[q];
-                vw[zz] = ((const uint4 *)(unit + 1 * PLANE_BYTES))[q];
-                vr[zz] = ((const uint4 *)(unit + 2 * PLANE_BYTES))[q];
-                vg[zz] = ((const uint4 *)(unit + 3 * PLANE_BYTES))[q];
-                vb[zz] = ((const uint4 *)(unit + 4 * PLANE_BYTES))[q];
-            }
-            if (VARIANT != 2) {
+            if (VARIANT == 1) {
                 any |= hv_tsdf_update(P, frame_px, pc[0][0], pc[0][1], pc[0][2], vt[zz].x, vw[zz].x, vr[zz].x, vg[zz].x, vb[zz].x);
                 any |= hv_tsdf_update(P, frame_px, pc[1][0], pc[1][1], pc[1][2], vt[zz].y, vw[zz].y, vr[zz].y, vg[zz].y, vb[zz].y);
                 any |= hv_tsdf_update(P, frame_px, pc[2][0], pc[2][1], pc[2][2], vt[zz].z, vw[zz].z, vr[zz].z, vg[zz].z, vb[zz].z);
                 any |= hv_tsdf_update(P, frame_px, pc[3][0], pc[3][1], pc[3][2], vt[zz].w, vw[zz].w, vr[zz].w, vg[zz].w, vb[zz].w);
-            } else {
-                vw[zz].x += 1u;
-                any = true;
-            }
-            if (VARIANT == 1) {
                 // keep the math alive without plane traffic
                 if (any && vt[zz].x == 123.456f) ((float *)unit)[0] = vt[zz].y + (float)(vr[zz].x + vg[zz].y + vb[zz].z + vw[zz].w);
-            } else if (any) {
+            } else {
+                vw[zz].x += 1u;
                 const int q = (word0 + zz * RR) >> 2;
                 ((float4 *)(unit + 0 * PLANE_BYTES))[q] = vt[zz];
                 ((uint4 *)(unit + 1 * PLANE_BYTES))[q] = vw[zz];
@@ -632,9 +567,9 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int
 //   k_tsdf_prep_touch_batch  one launch for all B frames (grid.y = frame): packs every frame and ORs
 //                            bit f into the 64-bit frame mask of each unit frame f touches; the first
 //                            toucher of a unit in the batch appends it to the union list
-//   k_tsdf_integrate_batch   one 4-wave workgroup per union unit: the lane's 16 voxels are loaded
-//                            ONCE, then for every frame bit in ascending (= chronological) order the
-//                            voxels are evaluated and updated in registers, then stored once.
+//   k_tsdf_integrate_batch_col  per union unit: a lane's voxels are loaded ONCE, then for every frame bit in
+//                            ascending (= chronological) order the voxels are evaluated and updated in
+//                            registers, then stored once.
 // Identical results to B successive hv_tsdf_integrate calls: a unit is updated by frame f iff frame
 // f touched it, and its frames are applied in order.  Plane traffic per frame drops by ~B x (the
 // union of 32 consecutive frames' units is ~1.6x one frame's); what remains is the per-voxel math
@@ -760,115 +695,14 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
     }
 }
 
-// ZPW = z-slabs per wave, SPLIT = workgroups per unit: a workgroup has 16 / (ZPW * SPLIT) waves and sweeps the
-// z range [part * 16 / SPLIT, (part + 1) * 16 / SPLIT) of its unit.  Fewer slabs per wave = fewer state registers =
-// more resident waves to hide the frame-gather latency; SPLIT > 1 halves the longest work item (a unit seen by all
-// frames of the batch is otherwise one ~250 us workgroup, which bounds the sweep when a GPU owns few units:
-// multi-GPU ownership sharding) and evens out the tail.  Work items are independent: the unit's frame mask is
-// only read here and cleared afterwards by k_tsdf_batch_finish.
-template <int ZPW, int SPLIT>
-__global__ __launch_bounds__(64 * 16 / (ZPW * SPLIT)) void k_tsdf_integrate_batch(HvTable table, const int32_t *__restrict__ list,
-                                                               const unsigned long long *__restrict__ frame_mask,
-                                                               char *__restrict__ pool, const uint2 *__restrict__ frame_px,
-                                                               const HvFrameParams *__restrict__ Ps, int parity) {
-    int n_units = table.counters[HV_CNT_TOUCH0 + parity];
-    if (n_units > table.max_blocks) n_units = table.max_blocks;
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    const int x = lane >> 2;
-    const int y0 = (lane & 3) << 2;
-    for (int item = blockIdx.x; item < n_units * SPLIT; item += gridDim.x) {
-        const int t = item / SPLIT;
-        const int z0 = (item % SPLIT) * (16 / SPLIT) + wave * ZPW;
-        const int32_t slot = list[t];
-        const int32_t idx = table.vals[slot];
-        unsigned long long mask = frame_mask[slot];
-        if (idx < 0 || mask == 0ull) continue;
-        int32_t ux, uy, uz;
-        hv_unpack_key(table.keys[slot], ux, uy, uz);
-        char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
-        const int wordb = z0 * RR + x * R + y0;
-        float4 vt[ZPW];
-        uint4 vw[ZPW], vr[ZPW], vg[ZPW], vb[ZPW];
-#pragma unroll
-        for (int zz = 0; zz < ZPW; ++zz) {
-            const int q = (wordb + zz * RR) >> 2;
-            vt[zz] = ((const float4 *)(unit + 0 * PLANE_BYTES))[q];
-            vw[zz] = ((const uint4 *)(unit + 1 * PLANE_BYTES))[q];
-            vr[zz] = ((const uint4 *)(unit + 2 * PLANE_BYTES))[q];
-            vg[zz] = ((const uint4 *)(unit + 3 * PLANE_BYTES))[q];
-            vb[zz] = ((const uint4 *)(unit + 4 * PLANE_BYTES))[q];
-        }
-        unsigned dirty = 0; // bit zz: slab zz holds an updated voxel of this lane
-        while (mask) {
-            const int f = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const HvFrameParams &P = Ps[f];
-            const uint2 *px = frame_px + (int64_t)f * P.H * P.W;
-            const float inc0 = P.ext_scaled_col2[0], inc1 = P.ext_scaled_col2[1], inc2 = P.ext_scaled_col2[2];
-            const double o0 = (double)ux * P.unit_length;
-            const double o1 = (double)uy * P.unit_length;
-            const double o2 = (double)uz * P.unit_length;
-            const float p0 = (float)((double)(P.half_voxel_length_f + P.voxel_length_f * (float)x) + o0);
-            const float p2 = (float)((double)P.half_voxel_length_f + o2);
-            float pc[4][3];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float p1 = (float)((double)(P.half_voxel_length_f + P.voxel_length_f * (float)(y0 + c)) + o1);
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    pc[c][r] = ((P.ext[r * 4 + 0] * p0 + P.ext[r * 4 + 1] * p1) + P.ext[r * 4 + 2] * p2) + P.ext[r * 4 + 3];
-                }
-            }
-            for (int s = 0; s < z0; ++s) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    pc[c][0] += inc0;
-                    pc[c][1] += inc1;
-                    pc[c][2] += inc2;
-                }
-            }
-#pragma unroll
-            for (int zz = 0; zz < ZPW; ++zz) {
-                float tv[4];
-                uint32_t cv[4];
-                unsigned m = 0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    tv[c] = 0.f;
-                    cv[c] = 0u;
-                    if (hv_tsdf_eval(P, px, pc[c][0], pc[c][1], pc[c][2], tv[c], cv[c])) m |= 1u << c;
-                    pc[c][0] += inc0;
-                    pc[c][1] += inc1;
-                    pc[c][2] += inc2;
-                }
-                hv_tsdf_apply(m & 1u, tv[0], cv[0], vt[zz].x, vw[zz].x, vr[zz].x, vg[zz].x, vb[zz].x);
-                hv_tsdf_apply(m & 2u, tv[1], cv[1], vt[zz].y, vw[zz].y, vr[zz].y, vg[zz].y, vb[zz].y);
-                hv_tsdf_apply(m & 4u, tv[2], cv[2], vt[zz].z, vw[zz].z, vr[zz].z, vg[zz].z, vb[zz].z);
-                hv_tsdf_apply(m & 8u, tv[3], cv[3], vt[zz].w, vw[zz].w, vr[zz].w, vg[zz].w, vb[zz].w);
-                if (m) dirty |= 1u << zz;
-            }
-        }
-#pragma unroll
-        for (int zz = 0; zz < ZPW; ++zz) {
-            if (dirty & (1u << zz)) {
-                const int q = (wordb + zz * RR) >> 2;
-                ((float4 *)(unit + 0 * PLANE_BYTES))[q] = vt[zz];
-                ((uint4 *)(unit + 1 * PLANE_BYTES))[q] = vw[zz];
-                ((uint4 *)(unit + 2 * PLANE_BYTES))[q] = vr[zz];
-                ((uint4 *)(unit + 3 * PLANE_BYTES))[q] = vg[zz];
-                ((uint4 *)(unit + 4 * PLANE_BYTES))[q] = vb[zz];
-            }
-        }
-    }
-}
-
-// Column mapping of the same sweep: lane -> one (x, y) column of the unit, wave -> 64 consecutive columns (4 x-values:
-// word index z*256 + cg*64 + lane, so every plane access of a wave is one contiguous 256-byte dword burst) and ZH
-// consecutive z.  Compared with the slab mapping above (lane -> 4 y's of one x, 2 z-slabs per wave) a lane projects ONE
-// column per frame instead of four and replays at most 16 - ZH steps of the reference's z-walk instead of up to 14
-// steps on four columns: fewer VALU instructions per voxel (the sweep is VALU-bound: 85 % VALU busy).
-// A unit = 4 column groups x (16 / ZH) z ranges = 64 / ZH wave tasks, SPLIT workgroups per unit.
+// Column mapping: lane -> one (x, y) column of the unit, wave -> 64 consecutive columns (4 x-values: word index
+// z*256 + cg*64 + lane, so every plane access of a wave is one contiguous 256-byte dword burst) and ZH consecutive z.
+// Compared with the online kernel's slab mapping (lane -> 4 y's of one x) a lane projects ONE column per frame instead of
+// four and replays at most 16 - ZH steps of the reference's z-walk: fewer VALU instructions per voxel (the sweep is
+// VALU-bound).  A unit = 4 column groups x (16 / ZH) z ranges = 64 / ZH wave tasks, SPLIT workgroups per unit: a unit
+// seen by all frames of the batch is otherwise one long work item, which bounds the sweep when a GPU owns few units
+// (multi-GPU ownership sharding).  Work items are independent: the unit's frame mask is only read here and cleared
+// afterwards by k_tsdf_batch_finish.
 // 5 waves / SIMD for the production configuration (96 VGPRs, 20 B of scratch in the rare-regime code): 28.5 k vs 27.7 k
 // frames/s at 4 (100 VGPRs).
 template <int ZH, int SPLIT, bool MT, int WPE = (ZH == 4 && MT) ? 5 : 1>
@@ -1053,174 +887,6 @@ __global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const
     }
 }
 
-// Multi-frame sweep with the unit's image footprint staged in LDS.  In the sweep above every voxel
-// evaluation is an 8-byte gather through the vector L1 (64 lanes -> 20-40 distinct lines per
-// instruction); the sweep is bound by that gather path plus VALU, not by HBM.  Here the workgroup
-// first projects the unit's 8 corners for every frame of its mask (512 threads = 64 frames x 8
-// corners, one pass), then per frame loads the padded bounding rectangle of the projection (a few
-// KB, coalesced row segments, served by L2) into LDS once and the 4096 voxel evaluations read LDS
-// instead.  Pixels outside the patch (or frames whose footprint does not fit / crosses the camera
-// plane) fall back to the global gather, so results are bit-identical.
-static constexpr int HV_PATCH_MAX_PX = 2304; // 18 KiB of LDS: e.g. 48 x 48 pixels
-
-__global__ __launch_bounds__(512, 4) void k_tsdf_integrate_batch_lds(HvTable table, const int32_t *__restrict__ list,
-                                                                   unsigned long long *__restrict__ frame_mask,
-                                                                   char *__restrict__ pool,
-                                                                   const uint2 *__restrict__ frame_px,
-                                                                   const HvFrameParams *__restrict__ Ps) {
-    constexpr int ZPW = 2;
-    __shared__ uint2 s_px[HV_PATCH_MAX_PX];
-    __shared__ int s_rect[64][4]; // per frame bit: u0, v0, pw, ph (pw == 0: no patch)
-    int n_units = table.counters[HV_CNT_TOUCH0];
-    if (n_units > table.max_blocks) n_units = table.max_blocks;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6;
-    const int lane = tid & 63;
-    const int x = lane >> 2;
-    const int y0 = (lane & 3) << 2;
-    const int z0 = wave * ZPW;
-    for (int t = blockIdx.x; t < n_units; t += gridDim.x) {
-        const int32_t slot = list[t];
-        const int32_t idx = table.vals[slot];
-        unsigned long long mask = frame_mask[slot];
-        __syncthreads(); // every wave has finished with s_rect/s_px of the previous unit
-        if (idx < 0 || mask == 0ull) continue;
-        int32_t ux, uy, uz;
-        hv_unpack_key(table.keys[slot], ux, uy, uz);
-        {   // footprint rectangles: thread -> (frame f = tid / 8, corner = tid % 8)
-            const int f = tid >> 3, corner = tid & 7;
-            float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
-            bool behind = false;
-            if (mask & (1ull << f)) {
-                const HvFrameParams &P = Ps[f];
-                const float len = (float)P.unit_length;
-                const float cx = (float)((double)ux * P.unit_length) + ((corner & 1) ? len : 0.0f);
-                const float cy = (float)((double)uy * P.unit_length) + ((corner & 2) ? len : 0.0f);
-                const float cz = (float)((double)uz * P.unit_length) + ((corner & 4) ? len : 0.0f);
-                const float pz = P.ext[8] * cx + P.ext[9] * cy + P.ext[10] * cz + P.ext[11];
-                if (pz <= 1.0e-3f) {
-                    behind = true;
-                } else {
-                    const float pxc = P.ext[0] * cx + P.ext[1] * cy + P.ext[2] * cz + P.ext[3];
-                    const float pyc = P.ext[4] * cx + P.ext[5] * cy + P.ext[6] * cz + P.ext[7];
-                    umin = umax = pxc * P.fx / pz + P.cx + 0.5f;
-                    vmin = vmax = pyc * P.fy / pz + P.cy + 0.5f;
-                }
-            }
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) { // reduce over the 8 corner lanes of this frame
-                umin = fminf(umin, __shfl_xor(umin, o));
-                umax = fmaxf(umax, __shfl_xor(umax, o));
-                vmin = fminf(vmin, __shfl_xor(vmin, o));
-                vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-                behind = behind || (__shfl_xor((int)behind, o) != 0);
-            }
-            if (corner == 0) {
-                int u0 = 0, v0 = 0, pw = 0, ph = 0;
-                if ((mask & (1ull << f)) && !behind) {
-                    const HvFrameParams &P = Ps[f];
-                    const int a0 = max(0, (int)floorf(umin) - 1), a1 = min(P.W, (int)floorf(umax) + 2);
-                    const int b0 = max(0, (int)floorf(vmin) - 1), b1 = min(P.H, (int)floorf(vmax) + 2);
-                    if (a1 > a0 && b1 > b0 && (a1 - a0) * (b1 - b0) <= HV_PATCH_MAX_PX) {
-                        u0 = a0; v0 = b0; pw = a1 - a0; ph = b1 - b0;
-                    }
-                }
-                s_rect[f][0] = u0; s_rect[f][1] = v0; s_rect[f][2] = pw; s_rect[f][3] = ph;
-            }
-        }
-        char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
-        const int wordb = z0 * RR + x * R + y0;
-        float4 vt[ZPW];
-        uint4 vw[ZPW], vr[ZPW], vg[ZPW], vb[ZPW];
-#pragma unroll
-        for (int zz = 0; zz < ZPW; ++zz) {
-            const int q = (wordb + zz * RR) >> 2;
-            vt[zz] = ((const float4 *)(unit + 0 * PLANE_BYTES))[q];
-            vw[zz] = ((const uint4 *)(unit + 1 * PLANE_BYTES))[q];
-            vr[zz] = ((const uint4 *)(unit + 2 * PLANE_BYTES))[q];
-            vg[zz] = ((const uint4 *)(unit + 3 * PLANE_BYTES))[q];
-            vb[zz] = ((const uint4 *)(unit + 4 * PLANE_BYTES))[q];
-        }
-        __syncthreads(); // s_rect complete
-        unsigned dirty = 0;
-        while (mask) {
-            const int f = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const HvFrameParams &P = Ps[f];
-            const uint2 *px = frame_px + (int64_t)f * P.H * P.W;
-            HvPatch patch;
-            patch.u0 = s_rect[f][0];
-            patch.v0 = s_rect[f][1];
-            patch.pw = s_rect[f][2];
-            patch.ph = s_rect[f][3];
-            patch.lds = patch.pw > 0 ? s_px : nullptr;
-            if (patch.pw > 0) { // stage the footprint: coalesced row segments
-                const int npx_patch = patch.pw * patch.ph;
-                for (int i = tid; i < npx_patch; i += 512) {
-                    const int r = i / patch.pw, c = i - r * patch.pw;
-                    s_px[i] = px[(int64_t)(patch.v0 + r) * P.W + patch.u0 + c];
-                }
-            }
-            __syncthreads(); // patch visible
-            const float inc0 = P.ext_scaled_col2[0], inc1 = P.ext_scaled_col2[1], inc2 = P.ext_scaled_col2[2];
-            const double o0 = (double)ux * P.unit_length;
-            const double o1 = (double)uy * P.unit_length;
-            const double o2 = (double)uz * P.unit_length;
-            const float p0 = (float)((double)(P.half_voxel_length_f + P.voxel_length_f * (float)x) + o0);
-            const float p2 = (float)((double)P.half_voxel_length_f + o2);
-            float pc[4][3];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float p1 = (float)((double)(P.half_voxel_length_f + P.voxel_length_f * (float)(y0 + c)) + o1);
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    pc[c][r] = ((P.ext[r * 4 + 0] * p0 + P.ext[r * 4 + 1] * p1) + P.ext[r * 4 + 2] * p2) + P.ext[r * 4 + 3];
-                }
-            }
-            for (int s = 0; s < z0; ++s) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    pc[c][0] += inc0;
-                    pc[c][1] += inc1;
-                    pc[c][2] += inc2;
-                }
-            }
-#pragma unroll
-            for (int zz = 0; zz < ZPW; ++zz) {
-                float tv[4];
-                uint32_t cv[4];
-                unsigned m = 0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    tv[c] = 0.f;
-                    cv[c] = 0u;
-                    if (hv_tsdf_eval_patch(P, px, patch, pc[c][0], pc[c][1], pc[c][2], tv[c], cv[c])) m |= 1u << c;
-                    pc[c][0] += inc0;
-                    pc[c][1] += inc1;
-                    pc[c][2] += inc2;
-                }
-                hv_tsdf_apply(m & 1u, tv[0], cv[0], vt[zz].x, vw[zz].x, vr[zz].x, vg[zz].x, vb[zz].x);
-                hv_tsdf_apply(m & 2u, tv[1], cv[1], vt[zz].y, vw[zz].y, vr[zz].y, vg[zz].y, vb[zz].y);
-                hv_tsdf_apply(m & 4u, tv[2], cv[2], vt[zz].z, vw[zz].z, vr[zz].z, vg[zz].z, vb[zz].z);
-                hv_tsdf_apply(m & 8u, tv[3], cv[3], vt[zz].w, vw[zz].w, vr[zz].w, vg[zz].w, vb[zz].w);
-                if (m) dirty |= 1u << zz;
-            }
-            __syncthreads(); // all reads of s_px done before the next frame's patch overwrites it
-        }
-#pragma unroll
-        for (int zz = 0; zz < ZPW; ++zz) {
-            if (dirty & (1u << zz)) {
-                const int q = (wordb + zz * RR) >> 2;
-                ((float4 *)(unit + 0 * PLANE_BYTES))[q] = vt[zz];
-                ((uint4 *)(unit + 1 * PLANE_BYTES))[q] = vw[zz];
-                ((uint4 *)(unit + 2 * PLANE_BYTES))[q] = vr[zz];
-                ((uint4 *)(unit + 3 * PLANE_BYTES))[q] = vg[zz];
-                ((uint4 *)(unit + 4 * PLANE_BYTES))[q] = vb[zz];
-            }
-        }
-    }
-}
-
 // ---- numerators export / import (multi-GPU merge) ----------------------------------------------
 __global__ void k_tsdf_export(HvTable table, const char *__restrict__ pool, const int32_t *__restrict__ keys,
                               int64_t k, float *__restrict__ payload) {
@@ -1382,15 +1048,8 @@ static int tsdf_launch_integrate(hv_volume *v, const HvFrameParams &P, int parit
     switch (v->debug_variant) {
     case 1: HV_LAUNCH_ONLINE(1); break;
     case 2: HV_LAUNCH_ONLINE(2); break;
-    case 3: HV_LAUNCH_ONLINE(3); break;
-    case 4: HV_LAUNCH_ONLINE(4); break;
-    case 5: HV_LAUNCH_ONLINE(5); break;
-    case 6: HV_LAUNCH_ONLINE(6); break;
-    case 7: HV_LAUNCH_ONLINE(7); break;
     case 8: HV_LAUNCH_ONLINE(8); break;
     case 9: HV_LAUNCH_ONLINE(9); break;
-    case 10: HV_LAUNCH_ONLINE(10); break;
-    case 11: HV_LAUNCH_ONLINE(11); break;
     default: HV_LAUNCH_ONLINE(0); break;
     }
 #undef HV_LAUNCH_ONLINE
@@ -1417,7 +1076,7 @@ static int tsdf_integrate_one(hv_volume *v, const void *d_depth, int depth_dtype
     tsdf_next_frame(v, P, parity);
     int rc = tsdf_launch_touch(v, v->stream, P, parity, d_depth, d_rgb);
     if (rc != HV_OK) return rc;
-    if (v->debug_variant == 8 || v->debug_variant >= 10) {
+    if (v->debug_variant == 8) {
         rc = tsdf_multiplier_table(v, P);
         if (rc != HV_OK) return rc;
     }
@@ -1521,59 +1180,27 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
                            (const char *)d_depth + npx * dsz * (size_t)f0, (int64_t)(npx * dsz),
                            (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks);
         hv_profile_begin(v);
-        static const int zpw = getenv("HV_TSDF_BATCH_ZPW") ? atoi(getenv("HV_TSDF_BATCH_ZPW")) : 2;
+        // workgroups per unit (2 / 4 / 8; 4 measured best at 1 and 8 ranks)
         static const int split = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : 4;
-        // LDS footprint staging is OFF by default.  Measured on the headline config (frames/s): plain
-        // sweep 13.9k; LDS variant 7.4k at 140 VGPRs (one 8-wave workgroup per CU: the load -> barrier ->
-        // evaluate phases of a unit cannot overlap another workgroup's) and 12.2k when forced to 128 VGPRs
-        // (two workgroups per CU, 24 B/lane scratch).  The two barriers per (unit, frame) still cost more
-        // than the L1 gathers they replace; a double-buffered asynchronous patch load is the next step.
-        static const int use_lds = getenv("HV_TSDF_BATCH_LDS") ? atoi(getenv("HV_TSDF_BATCH_LDS")) : 0;
-        const unsigned long long *d_mask = (const unsigned long long *)v->touched_mask;
-#define HV_LAUNCH_SWEEP(Z, S)                                                                                          \
-    hipLaunchKernelGGL((k_tsdf_integrate_batch<Z, S>), dim3(8192), dim3(64 * 16 / (Z * S)), 0, v->stream, v->table,      \
-                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0)
-        static const int layout_col = getenv("HV_TSDF_BATCH_COL") ? atoi(getenv("HV_TSDF_BATCH_COL")) : 4; // ZH of the column mapping (default), 0 = slab mapping
-        // 1: run the general (branching) evaluation everywhere instead of the predicated one (A/B and parity tests)
+        // 1: run the EXACT evaluation with integer weights everywhere (A/B and parity checks of the rare-regime code)
         static const int general = getenv("HV_TSDF_BATCH_GENERAL") ? atoi(getenv("HV_TSDF_BATCH_GENERAL")) : 0;
-        // per-pixel multiplier table (HV_TSDF_BATCH_MULT=0: compute it per voxel visit instead)
+        // per-pixel multiplier table (HV_TSDF_BATCH_MULT=0: compute the multiplier per voxel visit instead)
         static const int use_mult = getenv("HV_TSDF_BATCH_MULT") ? atoi(getenv("HV_TSDF_BATCH_MULT")) : 1;
+        const unsigned long long *d_mask = (const unsigned long long *)v->touched_mask;
         const float *d_mult = nullptr;
         if (use_mult) {
             rc = tsdf_multiplier_table(v, params[0]);
             if (rc != HV_OK) return rc;
             d_mult = v->mult_table;
         }
-#define HV_LAUNCH_COL(Z, S)                                                                                            \
-    do {                                                                                                               \
-        if (d_mult)                                                                                                    \
-            hipLaunchKernelGGL((k_tsdf_integrate_batch_col<Z, S, true>), dim3(8192), dim3(64 * (64 / Z) / S), 0, v->stream, \
-                               v->table, v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0, general, d_mult);   \
-        else                                                                                                           \
-            hipLaunchKernelGGL((k_tsdf_integrate_batch_col<Z, S, false>), dim3(8192), dim3(64 * (64 / Z) / S), 0,         \
-                               v->stream, v->table, v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0, general, \
-                               d_mult);                                                                                \
-    } while (0)
-        if (false) {
-        } else if (use_lds && zpw == 2) {
-            hipLaunchKernelGGL(k_tsdf_integrate_batch_lds, dim3(4096), dim3(512), 0, v->stream, v->table, v->touched_list,
-                               (unsigned long long *)v->touched_mask, (char *)v->pool, d_px, d_params);
-        } else if (layout_col == 8) {
-            if (split == 1) HV_LAUNCH_COL(8, 1); else if (split == 4) HV_LAUNCH_COL(8, 4); else if (split == 8) HV_LAUNCH_COL(8, 8); else HV_LAUNCH_COL(8, 2);
-        } else if (layout_col == 16) {
-            if (split == 1) HV_LAUNCH_COL(16, 1); else if (split == 4) HV_LAUNCH_COL(16, 4); else HV_LAUNCH_COL(16, 2);
-        } else if (layout_col == 4) {
-            if (split == 1) HV_LAUNCH_COL(4, 1); else if (split == 4) HV_LAUNCH_COL(4, 4); else if (split == 8) HV_LAUNCH_COL(4, 8); else if (split == 16) HV_LAUNCH_COL(4, 16); else HV_LAUNCH_COL(4, 2);
-        } else if (layout_col == 2) {
-            if (split == 4) HV_LAUNCH_COL(2, 4); else if (split == 8) HV_LAUNCH_COL(2, 8); else if (split == 16) HV_LAUNCH_COL(2, 16); else HV_LAUNCH_COL(2, 2);
-        } else if (zpw == 4) {
-            if (split == 1) HV_LAUNCH_SWEEP(4, 1); else HV_LAUNCH_SWEEP(4, 2);
-        } else if (zpw == 1) {
-            if (split == 1) HV_LAUNCH_SWEEP(1, 1); else if (split == 2) HV_LAUNCH_SWEEP(1, 2); else HV_LAUNCH_SWEEP(1, 4);
+#define HV_LAUNCH_COL(S, MT)                                                                                           \
+    hipLaunchKernelGGL((k_tsdf_integrate_batch_col<4, S, MT>), dim3(8192), dim3(64 * 16 / S), 0, v->stream, v->table,     \
+                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0, general, d_mult)
+        if (d_mult) {
+            if (split == 2) HV_LAUNCH_COL(2, true); else if (split == 8) HV_LAUNCH_COL(8, true); else HV_LAUNCH_COL(4, true);
         } else {
-            if (split == 1) HV_LAUNCH_SWEEP(2, 1); else if (split == 4) HV_LAUNCH_SWEEP(2, 4); else if (split == 8) HV_LAUNCH_SWEEP(2, 8); else HV_LAUNCH_SWEEP(2, 2);
+            if (split == 2) HV_LAUNCH_COL(2, false); else if (split == 8) HV_LAUNCH_COL(8, false); else HV_LAUNCH_COL(4, false);
         }
-#undef HV_LAUNCH_SWEEP
 #undef HV_LAUNCH_COL
         hv_profile_end(v, B);
         hipLaunchKernelGGL(k_tsdf_batch_finish, dim3(1), dim3(1024), 0, v->stream, v->table, v->touched_list,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/ablate.sh "0 2 4" [extra bench args]  -- prints frames/s and ms/step per kernel variant
+# usage: tools/ablate.sh "0 1 2 8 9" [extra bench args]  -- prints frames/s and ms/step per online-kernel variant (HV_TSDF_DEBUG_VARIANT)
 VARS="$1"; shift
 for V in $VARS; do
   HV_TSDF_DEBUG_VARIANT=$V timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" 2>&1 | tail -1 > /tmp/ab_$V.json
