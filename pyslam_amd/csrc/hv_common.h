@@ -206,6 +206,7 @@ struct HvFrameParams { // per-frame constants of the TSDF kernels (passed by val
     int32_t tile_u0, tile_v0, tile_u1, tile_v1; // image-space tile owned by this GPU: [u0,u1) x [v0,v1)
     int32_t tiled;                              // 0: the tile is the whole image (the per-voxel tile test is skipped)
     int32_t owner_rank, owner_world;            // unit ownership sharding: this GPU fuses units with owner(key) == rank
+    int32_t touch_box_bits;                     // touch pass: largest unit box enumerated through the LDS bitmap (0: never)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -234,6 +235,7 @@ struct hv_volume {
     uint64_t *touched_mask = nullptr; // [table_capacity] per-slot frame bitmask of the multi-frame sweep
     void *frame_px = nullptr;         // [max_points] uint2 {depth f32 bits, packed rgb}: the gather target
     int debug_variant = 0;            // env HV_TSDF_DEBUG_VARIANT (roofline ablation only)
+    int touch_box_bits = 2048;        // env HV_TSDF_TOUCH_BOX_BITS (0 forces the touch pass's general path; tests)
     int32_t frame_counter = 0;
     int32_t last_touch_parity = 0;
     bool touch_counters_clean = true; // both touched-list counters are zero (false after an online frame)

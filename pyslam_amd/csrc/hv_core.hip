@@ -219,6 +219,7 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
         HV_TRY(hipMalloc(&v->touched_mask, sizeof(uint64_t) * v->table_capacity));
         HV_TRY(hipMalloc(&v->frame_px, 8 * (size_t)cfg->max_points));
         if (const char *dv = getenv("HV_TSDF_DEBUG_VARIANT")) v->debug_variant = atoi(dv);
+        if (const char *tb = getenv("HV_TSDF_TOUCH_BOX_BITS")) v->touch_box_bits = std::min(std::max(atoi(tb), 0), 2048);
     } else {
         HV_TRY(hipMalloc(&v->sort_keys_in, sizeof(uint32_t) * cfg->max_points));
         HV_TRY(hipMalloc(&v->sort_keys_out, sizeof(uint32_t) * cfg->max_points));

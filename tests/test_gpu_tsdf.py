@@ -266,3 +266,43 @@ def test_sweep_weights_near_2_pow_24(w0):
     assert int(da[2].max()) > w0 + 4  # weights really moved past the guard
     for x, y in zip(da, db):
         np.testing.assert_array_equal(x, y)
+
+
+def test_sweep_multiplier_table_follows_intrinsics():
+    """The sweep's per-pixel multiplier table is keyed on (intrinsics, image size): batches from two different cameras
+    into one volume, interleaved, against the oracle."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic
+
+    sa, fa = synthetic_frames("tiny_160x120_2cm", 0, 6)
+    sb, fb = synthetic_frames("tum1_640x480_5mm", 3, 4)
+    gpu, cpu = make_pair(0.02, 0.08, max_blocks=1 << 14)
+    for s, frames in ((sa, fa[:3]), (sb, fb[:2]), (sa, fa[3:]), (sb, fb[2:])):
+        K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+        gpu.integrate_batch(np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), K,
+                            np.stack([f[2] for f in frames]), depth_scale=1.0, depth_trunc=4.0)
+        for depth, rgb, T in frames:
+            cpu.integrate(depth, rgb, K.as_array(), T, 1.0, 4.0)
+    assert_same_volume(gpu, cpu)
+
+
+@pytest.mark.parametrize("box_bits", ["0", "8", "2048"])
+def test_touch_pass_paths_open_the_same_units(box_bits, monkeypatch):
+    """The touch pass enumerates a sample patch's units through an LDS bitmap of their bounding box, or - when the box
+    is too large - sample by sample with ballot de-duplication.  HV_TSDF_TOUCH_BOX_BITS (read at volume creation)
+    bounds the box: 0 forces the general path everywhere, 8 mixes both, 2048 is the default.  Same units, same volume,
+    online and multi-frame, including a truncation band wider than a unit (27+ units per sample)."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic
+
+    monkeypatch.setenv("HV_TSDF_TOUCH_BOX_BITS", box_bits)
+    s, frames = synthetic_frames("tiny_160x120_2cm", 2, 4)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    for voxel, trunc in ((0.02, 0.08), (0.01, 0.2)):  # unit 32 cm / band 8 cm; unit 16 cm / band 20 cm
+        gpu, cpu = make_pair(voxel, trunc, max_blocks=1 << 14)
+        integrate_both(gpu, cpu, s, frames[:2])
+        np.testing.assert_array_equal(gpu.touched_keys(), cpu.touched_keys())
+        gpu.integrate_batch(np.stack([f[0] for f in frames[2:]]), np.stack([f[1] for f in frames[2:]]), K,
+                            np.stack([f[2] for f in frames[2:]]), depth_scale=1.0, depth_trunc=4.0)
+        for depth, rgb, T in frames[2:]:
+            cpu.integrate(depth, rgb, K.as_array(), T, 1.0, 4.0)
+        assert gpu.dropped_points() == 0
+        assert_same_volume(gpu, cpu)
