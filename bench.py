@@ -4,26 +4,38 @@
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
 For N > 1 the driver launches it with torch.distributed.run (one rank per GPU, RCCL).
 
-Workload (BASELINE.json configs[1]): synthetic 640x480 RGB-D stream, 5 mm voxels, sdf_trunc 0.04 m,
-depth_trunc 4 m, Open3D ScalableTSDFVolume semantics.  A *step* fuses one batch of
-``--frames-per-step`` consecutive posed frames that are already resident in HBM; value = frames/s
-of the whole job.  N > 1 ("strong" scaling: total work is fixed): every rank sees every frame;
-default --sharding owner: a unit is fused and stored by GPU hash(unit index) % N (SURVEY §8e "zero
-reduce" form: bit-identical to one GPU, no collective while fusing; units all ranks processed = the
-whole frame); --sharding tile: north-star image tiles + one RCCL numerator sum-reduce (timed).
+Workload (BASELINE.json configs[1]): synthetic 640x480 RGB-D stream (30 Hz camera on a 600-pose loop), 5 mm
+voxels, sdf_trunc 0.04 m, depth_trunc 4 m, Open3D ScalableTSDFVolume semantics.  A *step* fuses one batch of
+``--frames-per-step`` consecutive posed frames that are already resident in HBM; value = frames/s of the whole job.
 
-Launch modes: --mode batch (default) fuses the step's frames with one multi-frame sweep
-(hv_tsdf_integrate_batch, the rebuild()/offline-replay path); --mode online calls hv_tsdf_integrate
-once per frame (pySLAM's live flow).  Both produce identical volumes.
+``--window sliding`` (default, the headline): step k fuses frames 32k .. 32k+31 of the stream into ONE volume that
+is empty when the timed region starts (the warm-up steps run on the same frames and the volume is reset after
+them) — first-touch allocation of every unit and the frame-to-frame overlap of a moving camera are inside the
+timing.  ``--window replay``: every step re-fuses the same 32 frames (the round-1 figure; reported as the secondary
+key ``replay_mode`` at N = 1).
 
-Extra objects on the JSON line:
-  roofline     dominant kernel of the timed region: algorithmic bytes per launch = the oracle's
-               per-frame figure (U_touched*4096*20 B read + N_updated*20 B written) x the
-               frames one launch processes / mean launch duration from HIP events on the kernel's
-               stream, vs the 8 TB/s HBM3E peak; `traffic` = recorded PMC bytes (profiles/r01).
-  online_mode  (N=1, batch mode) a short second pass in online mode: frames/s + that kernel's roofline.
-  cpu_baseline oracle/tsdf_oracle.c (Open3D-semantics restatement, kind "port") timed on the host
-               cores on a bounded sample of the same frames (N=1 only).
+N > 1 ("strong" scaling: total work is fixed): every rank sees every frame; --sharding owner (default): a unit is
+fused and stored by GPU hash(unit index) % N (SURVEY §8e "zero reduce" form: bit-identical to one GPU, no
+collective while fusing); --sharding tile: north-star image tiles + RCCL merge of the shared units (timed).
+
+Objects on the JSON line (N = 1):
+  roofline      the dominant kernel of the timed region, the multi-frame sweep k_tsdf_integrate_batch_col.  It keeps a
+                unit's voxels in registers across the batch's frames, so it is bound by VALU issue, not by HBM:
+                ``bound: "valu"``, achieved = VALU wave-instructions per launch (SQ_INSTS_VALU from the rocprofv3 --pmc
+                pass recorded under profiles/, parsed at run time and only used when it was taken on THIS build and
+                command) / the mean launch duration measured live with HIP events on the kernel's stream; peak = 1024
+                SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.  ``roofline.hbm`` is the HBM figure of the same
+                launches from BATCH-level algorithmic bytes (oracle: distinct units touched by the batch x 81 920 B
+                read + distinct voxels updated x 20 B written), with the PMC traffic beside it.
+  online_mode   one hv_tsdf_integrate per frame (pySLAM's live flow) on the same sliding stream: frames/s and that
+                kernel's roofline — the HBM-bound one: per-frame algorithmic bytes (U_touched*4096*20 B +
+                N_updated*20 B, oracle counts of exactly the frames timed) / mean launch duration vs 8 TB/s.
+  extraction    extract_triangle_mesh + extract_point_cloud of the volume the timed region built (BASELINE configs[2]
+                shape of work), wall ms and kernel ms, B_mc roofline.
+  voxel_grid    the cpp/volumetric VOXEL_GRID mode on the same frames: per-frame and batched frames/s, B_vox
+                roofline, and the COMPILED REFERENCE (oracle/_ref, kind "reference") timed beside it.
+  cpu_baseline  oracle/tsdf_oracle.c (Open3D-semantics restatement, kind "port") timed on the host cores over
+                the same sliding stream (N = 1 only, bounded by --cpu-budget-s).
 """
 import argparse
 import json
@@ -39,47 +51,87 @@ sys.path.insert(0, ROOT)
 VOXEL = 0.005
 SDF_TRUNC = 0.04
 DEPTH_TRUNC = 4.0
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BYTES_PER_VOXEL = 20   # {f32 tsdf, u32 weight, 3 x u32 colour sums}
-# HBM bytes per launch from the PMC passes committed under profiles/r01/pmc_fetch_write_summary.txt
-# (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this script at N=1, headline config;
-# 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, as MI355X_MICROARCH.md prescribes for gfx950).  They are
-# recorded measurements, not live ones: null when the configuration differs.
-PMC_TRAFFIC_BYTES = {"k_tsdf_integrate": int((2 * 137.5e3 + 209.8e3) * 1024),
-                     "k_tsdf_integrate_batch_col": int((2 * 739.6e3 + 439.5e3) * 1024)}
-# Recorded SQ counters of the multi-frame sweep (profiles/r01/pmc_sq_summary.txt): it is VALU-bound, not HBM-bound.
-SWEEP_VALU = {"valu_busy": 0.80, "valu_instr_per_voxel_visit": 54, "source": "profiles/r01/pmc_sq_summary.txt "
-              "(SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); SQ_INSTS_VALU x 64 / voxel visits)"}
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_GINSTR = 1024 * 2.4 / 4.0  # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction = 614.4 G wave-instr/s
+BYTES_PER_VOXEL = 20     # {f32 tsdf, u32 weight, 3 x u32 colour sums}
+UNIT_BYTES = 4096 * BYTES_PER_VOXEL
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
 
 
-def load_frames(config, n_frames, start=0):
-    """Synthetic frames, cached under /tmp (generation is host-side numpy ray casting)."""
+def load_frames(config, n_frames, start=0, rank=0, barrier=None):
+    """Synthetic frames, cached under /tmp (generation is host-side numpy ray casting, spread over the host cores).
+    With several ranks on the node rank 0 renders, the others wait and read the cache."""
     from pyslam_amd.synthetic import SyntheticRGBD
 
     s = SyntheticRGBD(config)
     cache = f"/tmp/pyslam_amd_bench_{config}_{start}_{n_frames}.npz"
-    if os.path.exists(cache):
-        z = np.load(cache)
-        return s, z["depth"], z["rgb"], z["T"]
-    depth, rgb, T = s.batch(start, n_frames)
+    if not os.path.exists(cache) and rank == 0:
+        depth, rgb, T = s.batch(start, n_frames)
+        try:
+            tmp = f"{cache}.{os.getpid()}.tmp.npz"
+            np.savez(tmp, depth=depth, rgb=rgb, T=T)
+            os.replace(tmp, cache)
+        except OSError:
+            if barrier is None:
+                return s, depth, rgb, T
+            raise
+    if barrier is not None:
+        barrier()
+    z = np.load(cache)
+    return s, z["depth"], z["rgb"], z["T"]
+
+
+def pmc_summary(build_digest):
+    """profiles/r02/pmc_summary.json (written by tools/pmc_summary.py --json from the rocprofv3 --pmc passes of
+    tools/profile_round.sh).  Only trusted when it was recorded on the library build that is running now."""
     try:
-        tmp = f"{cache}.{os.getpid()}.tmp.npz"  # per-process name: N ranks may generate concurrently
-        np.savez(tmp, depth=depth, rgb=rgb, T=T)
-        os.replace(tmp, cache)
+        with open(PMC_SUMMARY) as f:
+            z = json.load(f)
+    except (OSError, ValueError):
+        return None
+    z["stale"] = z.get("build_digest") != build_digest
+    return z
+
+
+def current_build_digest():
+    try:
+        with open(os.path.join(ROOT, "pyslam_amd", "lib", ".build_digest")) as f:
+            return f.read().strip()
     except OSError:
-        pass
-    return s, depth, rgb, T
+        return None
 
 
-def cpu_baseline_and_counts(s, depth, rgb, T, budget_s, threads):
-    """Time the CPU restatement on a bounded prefix of the frames and collect the per-frame
-    algorithmic counts (touched units, updated voxels) the roofline figure needs."""
+def pmc_kernel(pmc, name, command_key):
+    """Mean per-launch counters of kernel `name` from the recorded passes, or None when absent / stale / taken on a
+    different command."""
+    if not pmc or pmc.get("stale") or pmc.get("command_key") != command_key:
+        return None
+    for k, v in pmc.get("kernels", {}).items():
+        if name in k:
+            return v
+    return None
+
+
+def hbm_traffic(pk):
+    """MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the
+    bytes read -> traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024."""
+    if not pk or "FETCH_SIZE" not in pk or "WRITE_SIZE" not in pk:
+        return None
+    return int((2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024)
+
+
+def cpu_baseline_and_counts(s, depth, rgb, T, B, max_steps, budget_s, threads, window):
+    """Time the CPU restatement over the same stream step by step (bounded by budget_s) and collect the oracle
+    counts the roofline figures need: per frame (touched units, updated voxels) and per batch (distinct units
+    touched, distinct voxels updated)."""
     import oracle
 
+    oracle.use_native_port()  # -O3 -march=native build for THIS host (falls back to the travelling .so)
     K = np.array(s.intrinsics, dtype=np.float64)
+    n_res = len(depth)
     if threads <= 0:
-        # pick the OpenMP width that is actually fastest on this host (oversubscribing a 256-thread
-        # box is slower than 32 threads for ~4k independent units)
+        # the OpenMP width that is actually fastest on this host (oversubscribing a 256-thread box is slower than
+        # 32 threads for ~4k independent units)
         cores = os.cpu_count() or 1
         best = (0.0, 1)
         for cand in sorted({c for c in (1, 8, 32, 96, cores) if c <= cores}):
@@ -87,58 +139,121 @@ def cpu_baseline_and_counts(s, depth, rgb, T, budget_s, threads):
             probe.integrate(depth[0], rgb[0], K, T[0], 1.0, DEPTH_TRUNC)
             t0 = time.perf_counter()
             for i in range(1, 4):
-                probe.integrate(depth[i % len(depth)], rgb[i % len(depth)], K, T[i % len(depth)], 1.0, DEPTH_TRUNC)
+                probe.integrate(depth[i % n_res], rgb[i % n_res], K, T[i % n_res], 1.0, DEPTH_TRUNC)
             fps = 3.0 / (time.perf_counter() - t0)
             if fps > best[0]:
                 best = (fps, cand)
             del probe
         threads = best[1]
     vol = oracle.PortTsdf(VOXEL, SDF_TRUNC, threads=threads)
-    # untimed first frame: allocates the units (calloc-dominated), as warm-up
-    vol.integrate(depth[0], rgb[0], K, T[0], 1.0, DEPTH_TRUNC)
-    touched, updated, times = [], [], []
+    steps = []
     t_begin = time.perf_counter()
-    i = 0
-    # replay the batch (as the GPU steps do) until the CPU budget is spent; per-frame counts of the
-    # first pass over the batch feed the roofline figure
-    while True:
-        j = i % len(depth)
-        t0 = time.perf_counter()
-        vol.integrate(depth[j], rgb[j], K, T[j], 1.0, DEPTH_TRUNC)
-        times.append(time.perf_counter() - t0)
-        if i < len(depth):
+    t_frames = 0.0
+    for k in range(max_steps):
+        vol.batch_begin()
+        touched, updated = [], []
+        for j in range(B):
+            i = (k * B + j) % n_res if window == "sliding" else j
+            t0 = time.perf_counter()
+            vol.integrate(depth[i], rgb[i], K, T[i], 1.0, DEPTH_TRUNC)
+            t_frames += time.perf_counter() - t0
             touched.append(vol.num_touched())
             updated.append(vol.last_updated())
-        i += 1
-        if time.perf_counter() - t_begin > budget_s and i >= min(4, len(depth)):
+        u, v = vol.batch_end()
+        steps.append({"touched": touched, "updated": updated, "union_units": u, "union_voxels": v})
+        if time.perf_counter() - t_begin > budget_s:
             break
-    n = len(times)
-    return {
-        "threads": threads,
-        "fps": n / sum(times),
-        "frames": n,
-        "seconds": sum(times),
-        "touched_per_frame": float(np.mean(touched)),
-        "updated_per_frame": float(np.mean(updated)),
-    }
+    n = len(steps) * B
+    return {"threads": threads, "fps": n / t_frames, "frames": n, "seconds": t_frames, "steps": steps,
+            "units": vol.num_units()}
+
+
+def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_frames):
+    """Secondary: the cpp/volumetric VOXEL_GRID mode (VoxelBlockGrid.integrate_rgbd = fused depth2pointcloud + world
+    transform + integrate_raw semantics) on the first `frames` frames, with the compiled reference beside it."""
+    import oracle
+    from oracle import host_prep as hp
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    g = VoxelBlockGrid(VOXEL, 8, max_blocks=1 << 18, max_points=1 << 20)
+
+    def step():
+        for f in range(frames):
+            g.integrate_rgbd(depth_d[f], rgb_d[f], *s.intrinsics, T_h[f], max_depth=DEPTH_TRUNC)
+
+    step()
+    g.synchronize()
+    g.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    g.synchronize()
+    dt = time.perf_counter() - t0
+    k_ms, k_launches, _ = g.profile_read()
+    g.profile_enable(False)
+    gb = VoxelBlockGrid(VOXEL, 8, max_blocks=1 << 18, max_points=frames * s.width * s.height)
+    gb.integrate_rgbd_batch(depth_d[:frames], rgb_d[:frames], *s.intrinsics, T_h[:frames], max_depth=DEPTH_TRUNC)
+    gb.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gb.integrate_rgbd_batch(depth_d[:frames], rgb_d[:frames], *s.intrinsics, T_h[:frames], max_depth=DEPTH_TRUNC)
+    gb.synchronize()
+    dt_b = time.perf_counter() - t0
+    # oracle counts for B_vox (SURVEY 8d): 2 x 28 B per distinct voxel a frame touches (steady state: no new blocks in
+    # the timed replay) + CPU baseline = the compiled reference on the same float32 world points
+    pts = [hp.frame_to_world_f32(depth_h[i], rgb_h[i], *s.intrinsics, T_h[i], DEPTH_TRUNC)[:2] for i in range(cpu_frames)]
+    v_touched = []
+    for p, _c in pts:
+        vk = oracle.keys(p, VOXEL, 8, which="port")[0]
+        v_touched.append(len(np.unique(vk, axis=0)))
+    b_vox = 2 * 28 * float(np.mean(v_touched))
+    b_in = s.width * s.height * 7
+    out = {"metric": "RGB-D frames/sec fused (640x480, 5 mm, VOXEL_GRID cpp/volumetric semantics)",
+           "value": round(steps * frames / dt, 1), "unit": "frames/s",
+           "batched_replay": {"value": round(steps * frames / dt_b, 1), "unit": "frames/s", "frames_per_call": frames},
+           "blocks": int(g.num_blocks())}
+    if k_launches:
+        avg_s = k_ms * 1e-3 / k_launches
+        out["roofline"] = {"bound": "hbm", "kernels": "unproject + keys + sort + reduce of one integrate_rgbd call (HIP events around the call's launches)",
+                           "algorithmic_bytes_per_frame": int(b_vox + b_in), "avg_us_per_frame": round(avg_s * 1e6, 2),
+                           "achieved": round((b_vox + b_in) / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round((b_vox + b_in) / avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                           "note": "B_vox = 2 x 28 B x distinct voxels touched per frame (oracle keys) + B_in 7 B/px: a ~20 MB/frame "
+                                   "path bounded by launch latency and the device-wide sort, not by HBM"}
+    for kind, cls in (("reference", oracle.RefGrid if oracle.ref_available() else None), ("port", oracle.PortGrid)):
+        if cls is None:
+            continue
+        c = cls(VOXEL, 8)
+        c.integrate(*pts[0])
+        t0 = time.perf_counter()
+        for p, col in pts[1:]:
+            c.integrate(p, col)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline" if kind == "reference" or "cpu_baseline" not in out else "cpu_port"] = {
+            "value": round((len(pts) - 1) / dtc, 3), "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": f"{len(pts) - 1} frames, integrate_raw<float,float> on the same float32 world points"
+                      + (" (unmodified cpp/volumetric sources compiled by oracle/Makefile, sequential non-TBB branch)" if kind == "reference" else "")}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-step", type=int, default=32)
     ap.add_argument("--config", default="synthetic_640x480_5mm")
-    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    ap.add_argument("--window", choices=["sliding", "replay"], default="sliding")
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = pick the fastest OpenMP width on this host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the replay / online / extraction / voxel-grid legs (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--all-on-device0", action="store_true",
                     help="testing only: every rank uses GPU 0 (multi-rank code path on a 1-GPU box, with --backend gloo)")
     ap.add_argument("--sharding", choices=["owner", "tile"], default="owner",
                     help="N > 1: owner = unit-ownership sharding, no collective while fusing (default); "
-                         "tile = image tiles + RCCL numerator sum-reduce at the end")
+                         "tile = image tiles + RCCL merge of the shared units at the end")
     ap.add_argument("--mode", choices=["batch", "online"], default="batch",
                     help="batch: one multi-frame sweep per step (replay/rebuild path); online: one integrate() per frame")
     args = ap.parse_args()
@@ -164,26 +279,32 @@ def main():
             dist.init_process_group(args.backend)
 
     from pyslam_amd.distributed import ShardedTSDF
-    from pyslam_amd.volumetric import PinholeCameraIntrinsic
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage
 
     B = args.frames_per_step
-    s, depth_h, rgb_h, T_h = load_frames(args.config, B)
+    n_poses = SyntheticRGBD(args.config).n_poses
+    n_distinct = B if args.window == "replay" else min(args.steps * B, n_poses)
+    s, depth_h, rgb_h, T_h = load_frames(args.config, n_distinct, rank=rank, barrier=dist.barrier if dist is not None else None)
+    # resident stream: the distinct frames + the first B again, so that a window that wraps the loop is still one
+    # contiguous slice (no gather inside the timed region)
+    wrap = np.arange(n_distinct + B) % n_distinct
     Kcam = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
-    depth_d = torch.from_numpy(depth_h).cuda()
-    rgb_d = torch.from_numpy(rgb_h).cuda()
+    depth_d = torch.from_numpy(depth_h[wrap]).cuda()
+    rgb_d = torch.from_numpy(rgb_h[wrap]).cuda()
+    T_res = T_h[wrap]
 
-    fuser = ShardedTSDF(VOXEL, SDF_TRUNC, s.width, s.height, device=local_rank, max_blocks=1 << 15,
+    fuser = ShardedTSDF(VOXEL, SDF_TRUNC, s.width, s.height, device=local_rank, max_blocks=1 << 17,
                         rank=rank, world_size=world, sharding=args.sharding)
     vol = fuser.volume
 
-    from pyslam_amd.volumetric import RGBDImage
-
-    def step():
-        if args.mode == "batch":
-            vol.integrate_batch(depth_d, rgb_d, Kcam, T_h, depth_scale=1.0, depth_trunc=DEPTH_TRUNC)
+    def step(k, mode=None, window=None):
+        lo = (k * B) % n_distinct if (window or args.window) == "sliding" else 0
+        if (mode or args.mode) == "batch":
+            vol.integrate_batch(depth_d[lo:lo + B], rgb_d[lo:lo + B], Kcam, T_res[lo:lo + B], depth_scale=1.0, depth_trunc=DEPTH_TRUNC)
         else:
-            for f in range(B):
-                vol.integrate(RGBDImage(rgb_d[f], depth_d[f], 1.0, DEPTH_TRUNC), Kcam, T_h[f])
+            for f in range(lo, lo + B):
+                vol.integrate(RGBDImage(rgb_d[f], depth_d[f], 1.0, DEPTH_TRUNC), Kcam, T_res[f])
 
     def fence():
         vol.synchronize()
@@ -191,89 +312,140 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     fence()
+    if args.window == "sliding":
+        vol.reset()  # the timed region starts on an empty volume: every unit is allocated inside it
+        fence()
     vol.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     if world > 1 and args.sharding == "tile":
-        fuser.merge()  # tile sharding leaves partial means: one merge makes the volume consistent (timed)
+        fuser.merge()  # tile sharding leaves partial means on the shared units: one merge makes the volume consistent (timed)
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches, _ = vol.profile_read()
+    launch_ms = vol.profile_launches()
+    vol.profile_read()
     vol.profile_enable(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
     frames = args.steps * B
     fps = frames / elapsed
+    units_allocated = int(vol.num_blocks())
+    secondary = world == 1 and args.mode == "batch" and not args.no_secondary
 
-    # second, short pass in the other launch mode (single GPU only): the online per-frame path when the
-    # headline ran multi-frame sweeps, so that both kernels' numbers sit on the same JSON line
-    other = None
-    if world == 1 and args.mode == "batch":
-        args.mode = "online"
-        step()
+    # ---- secondary legs (single GPU): extraction of the volume just built, replay figure, online mode ----
+    extraction = replay = online = None
+    if secondary:
+        vol.profile_enable(True)
+        t1 = time.perf_counter()
+        mesh = vol.extract_triangle_mesh()
+        t_mesh = time.perf_counter() - t1
+        k_mesh = vol.profile_read()[0]
+        t1 = time.perf_counter()
+        pc = vol.extract_point_cloud()
+        t_pc = time.perf_counter() - t1
+        k_pc = vol.profile_read()[0]
+        vol.profile_enable(False)
+        nv, nt, npts = len(mesh.vertices), len(mesh.triangles), len(pc.points)
+        b_mc_in = units_allocated * 4096 * 8
+        b_mesh_out = nv * 48 + nt * 12
+        b_pc_out = npts * 48
+        extraction = {
+            "what": "extract_triangle_mesh + extract_point_cloud of the volume the timed region built "
+                    "(host-visible results: count pass + fill pass + D2H of the arrays, as the C ABI returns them)",
+            "units": units_allocated, "vertices": nv, "triangles": nt, "points": npts,
+            "mesh_wall_ms": round(t_mesh * 1e3, 2), "mesh_kernel_ms": round(k_mesh, 3),
+            "points_wall_ms": round(t_pc * 1e3, 2), "points_kernel_ms": round(k_pc, 3),
+            "roofline": {"bound": "hbm", "kernel": "k_mc_classify + k_mc_prefix + scans (x2: count and fill calls) + k_mc_vertices + k_mc_triangles",
+                         "algorithmic_bytes": int(b_mc_in + b_mesh_out), "achieved": round((b_mc_in + b_mesh_out) / (k_mesh * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((b_mc_in + b_mesh_out) / (k_mesh * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": None, "note": "B_mc = U_alloc x 4096 x 8 B (tsdf + weight read once) + output bytes (SURVEY 8d)"},
+            "points_roofline": {"bound": "hbm", "kernel": "k_pc_extract (x2: count and fill calls)", "algorithmic_bytes": int(b_mc_in + b_pc_out),
+                                "achieved": round((b_mc_in + b_pc_out) / (k_pc * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round((b_mc_in + b_pc_out) / (k_pc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
+        }
+        del mesh, pc
+        # replay figure (round-1 headline): the same 32 frames re-fused every step, no allocation after the first
+        vol.reset()
+        for k in range(3):
+            step(k, window="replay")
         fence()
         vol.profile_enable(True)
         t1 = time.perf_counter()
-        n_other = max(2, args.steps // 2)
-        for _ in range(n_other):
-            step()
+        n_rep = max(4, args.steps // 2)
+        for k in range(n_rep):
+            step(k, window="replay")
         fence()
-        other_elapsed = time.perf_counter() - t1
-        o_ms, o_launches, _ = vol.profile_read()
+        dt = time.perf_counter() - t1
+        rep_ms, rep_launches, _ = vol.profile_read()
         vol.profile_enable(False)
-        args.mode = "batch"
-        other = {"fps": n_other * B / other_elapsed, "kernel_ms": o_ms, "launches": o_launches, "frames": n_other * B}
+        replay = {"value": round(n_rep * B / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / n_rep * 1e3, 4),
+                  "sweep_avg_launch_us": round(rep_ms / max(rep_launches, 1) * 1e3, 2),
+                  "what": "every step re-fuses frames 0..31 (maximum frustum overlap, nothing allocated in the timed region)"}
+        # online mode on the sliding stream, fresh volume
+        vol.reset()
+        fence()
+        n_on = max(2, min(args.steps // 4, n_distinct // B))
+        vol.profile_enable(True)
+        t1 = time.perf_counter()
+        for k in range(n_on):
+            step(k, mode="online", window="sliding")
+        fence()
+        dt = time.perf_counter() - t1
+        on_launch_ms = vol.profile_launches()
+        vol.profile_read()
+        vol.profile_enable(False)
+        online = {"fps": n_on * B / dt, "launch_ms": on_launch_ms, "steps": n_on}
 
     if rank == 0:
         cpu = None
-        cores = args.cpu_threads
         if not args.no_cpu_baseline:
-            # the timed CPU baseline belongs to the N=1 line only; at N>1 a 4-frame oracle pass still
-            # provides the touched/updated counts the roofline figure needs
+            # the timed CPU baseline belongs to the N=1 line; at N>1 a two-step oracle pass still provides the counts
             budget = args.cpu_budget_s if world == 1 else 0.0
-            cpu = cpu_baseline_and_counts(s, depth_h, rgb_h, T_h, budget, args.cpu_threads if world == 1 else 8)
-            cores = cpu["threads"]
-
-        def roofline_of(kernel_ms_, launches_, frames_):
-            # algorithmic bytes of one frame (oracle counts: U_touched*4096*20 B read +
-            # N_updated*20 B written) x the frames one launch processes, on this rank's tile (/world)
-            frames_per_launch = frames_ / launches_
-            alg_frame = (cpu["touched_per_frame"] * 4096 * BYTES_PER_VOXEL + cpu["updated_per_frame"] * BYTES_PER_VOXEL) / world
-            alg_bytes = alg_frame * frames_per_launch
-            avg_s = kernel_ms_ * 1e-3 / launches_
-            achieved = alg_bytes / avg_s / 1e9
-            r = {
-                "bound": "hbm", "kernel": "k_tsdf_integrate_batch_col" if frames_per_launch > 1 else "k_tsdf_integrate",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(avg_s * 1e6, 2),
-                "launches": int(launches_), "frames_per_launch": round(frames_per_launch, 2),
-            }
-            if args.config == "synthetic_640x480_5mm" and world == 1 and frames_per_launch in (1.0, 32.0):
-                r["traffic"] = PMC_TRAFFIC_BYTES[r["kernel"]]
-                r["traffic_source"] = "profiles/r01/pmc_fetch_write_summary.txt (recorded rocprofv3 --pmc passes)"
-            if frames_per_launch > 1:
-                if r["traffic"]:
-                    r["launch_hbm"] = {"bytes": r["traffic"], "GB/s": round(r["traffic"] / avg_s / 1e9, 1),
-                                       "frac_of_peak": round(r["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS, 4)}
-                    r["valu"] = SWEEP_VALU
-                r["note"] = ("`achieved`/`frac` follow the bench contract: SURVEY 8d's PER-FRAME algorithmic bytes x the frames "
-                             "one launch fuses.  The multi-frame sweep reads and writes each unit slab once per launch and "
-                             "applies all the launch's frames in registers, so the HBM traffic it really causes (`launch_hbm`, "
-                             "PMC) is ~10x below that figure and `frac` can exceed 1: this kernel is VALU-bound (`valu`), the "
-                             "HBM-bound kernel of the path is the per-frame one reported under online_mode.roofline")
-            return r
+            cpu = cpu_baseline_and_counts(s, depth_h, rgb_h, T_h, B, args.steps, budget, args.cpu_threads if world == 1 else 8, args.window)
+        digest = current_build_digest()
+        pmc = pmc_summary(digest)
+        command_key = f"steps={args.steps} warmup={args.warmup} B={B} window={args.window} config={args.config}"
 
         roofline = None
-        if cpu is not None and launches > 0:
-            roofline = roofline_of(kernel_ms, launches, frames)
+        if cpu is not None and len(launch_ms) and args.mode == "batch":
+            # launches covered by the oracle pass (normally all of them)
+            n_cov = min(len(cpu["steps"]), len(launch_ms))
+            t_cov = float(np.sum(launch_ms[:n_cov])) * 1e-3
+            avg_s = t_cov / n_cov
+            alg = sum(st["union_units"] * UNIT_BYTES + st["union_voxels"] * BYTES_PER_VOXEL for st in cpu["steps"][:n_cov]) / world
+            visits = sum(sum(st["touched"]) for st in cpu["steps"][:n_cov]) * 4096 / world
+            pk = pmc_kernel(pmc, "k_tsdf_integrate_batch_col", command_key) if world == 1 else None
+            traffic = hbm_traffic(pk)
+            hbm = {"algorithmic_bytes_per_launch": int(alg / n_cov), "achieved": round(alg / t_cov / 1e9, 1), "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "frac": round(alg / t_cov / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                   "what": "BATCH-level algorithmic bytes (oracle): distinct units touched by the batch x 81 920 B read + distinct "
+                           "voxels updated x 20 B written; a unit's slab is read and written once per launch whatever the number of frames"}
+            if traffic:
+                hbm["traffic_GBs"] = round(traffic / avg_s / 1e9, 1)
+                hbm["traffic_over_algorithmic"] = round(traffic / (alg / n_cov), 3)
+            roofline = {"bound": "valu", "kernel": "k_tsdf_integrate_batch_col", "achieved": None, "peak": VALU_PEAK_GINSTR,
+                        "unit": "G wave-instr/s", "frac": None, "traffic": traffic,
+                        "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(n_cov), "frames_per_launch": B,
+                        "voxel_visits_per_launch": int(visits / n_cov), "hbm": hbm}
+            if pk and "SQ_INSTS_VALU" in pk:
+                ach = pk["SQ_INSTS_VALU"] / avg_s / 1e9
+                roofline.update({"achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GINSTR, 4),
+                                 "valu_instr_per_launch": int(pk["SQ_INSTS_VALU"]),
+                                 "valu_instr_per_voxel_visit": round(pk["SQ_INSTS_VALU"] * 64 / (visits / n_cov), 2),
+                                 "counter_source": os.path.relpath(PMC_SUMMARY, ROOT) + " (rocprofv3 --pmc SQ pass of this command on this build; "
+                                                   "duration measured live with HIP events)"})
+                if "SQ_ACTIVE_INST_VALU" in pk and "GRBM_GUI_ACTIVE" in pk:
+                    roofline["valu_busy_in_pmc_pass"] = round(pk["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * pk["GRBM_GUI_ACTIVE"] / 8), 4)
+            else:
+                roofline["note"] = ("VALU instruction count unavailable: " +
+                                    ("profiles/r02/pmc_summary.json was recorded on another build or command" if pmc else "no profiles/r02/pmc_summary.json"))
+
         out = {
             "metric": "RGB-D frames/sec fused (640x480, 5 mm voxel TSDF)",
             "value": round(fps, 2),
@@ -288,30 +460,49 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.config}: synthetic 640x480 RGB-D @ 30 Hz stream, 5 mm TSDF (sdf_trunc 0.04 m, "
-                            f"depth_trunc 4 m), {B} posed frames per step resident in HBM, Open3D ScalableTSDFVolume semantics",
+                "workload": f"{args.config}: synthetic 640x480 RGB-D @ 30 Hz stream, 5 mm TSDF (sdf_trunc 0.04 m, depth_trunc 4 m), "
+                            f"{B} posed frames per step resident in HBM, Open3D ScalableTSDFVolume semantics",
                 "frames_per_step": B,
+                "window": ("sliding: step k fuses frames 32k..32k+31 of the 600-pose loop into one volume that is empty when the timed region starts"
+                           if args.window == "sliding" else "replay: every step re-fuses frames 0..31"),
                 "mode": "multi-frame sweep (hv_tsdf_integrate_batch)" if args.mode == "batch" else "one hv_tsdf_integrate per frame",
                 "sharding": "single spatial tile" if world == 1 else (
                     f"unit ownership: unit -> GPU hash(index) % {world}; every GPU sees every frame, fuses and stores only its "
                     f"units; no collective while fusing" if args.sharding == "owner"
-                    else f"{world} vertical image tiles + RCCL numerator sum-reduce merge (timed)"),
-                "units_allocated": int(vol.num_blocks()),
+                    else f"{world} vertical image tiles + RCCL merge of the shared units (timed)"),
+                "units_allocated": units_allocated,
+                "build_digest": digest,
             },
             "roofline": roofline,
             "cpu_baseline": None if (cpu is None or world > 1) else {
-                "value": round(cpu["fps"], 3), "unit": "frames/s", "cores": cores, "kind": "port",
-                "sample": f"{cpu['frames']} frames of the same stream ({cpu['seconds']:.1f} s), oracle/tsdf_oracle.c "
-                          f"(Open3D-semantics restatement; open3d itself is not installed), OpenMP over touched units",
+                "value": round(cpu["fps"], 3), "unit": "frames/s", "cores": cpu["threads"], "kind": "port",
+                "sample": f"the first {cpu['frames']} frames of the same sliding stream ({cpu['seconds']:.1f} s of integrate calls, allocation "
+                          f"included), oracle/tsdf_oracle.c (Open3D-semantics restatement, per-frame multiplier image as Open3D, "
+                          f"gcc -O3 -march=native on this host; open3d itself is not installed), OpenMP over touched units",
             },
         }
         if cpu is not None and world == 1:
             out["speedup_vs_cpu"] = round(fps / cpu["fps"], 1)
-        if other is not None:
-            out["online_mode"] = {
-                "value": round(other["fps"], 2), "unit": "frames/s", "what": "one hv_tsdf_integrate per frame (pySLAM's online flow)",
-                "roofline": roofline_of(other["kernel_ms"], other["launches"], other["frames"]) if cpu is not None and other["launches"] else None,
-            }
+        if online is not None:
+            om = {"value": round(online["fps"], 2), "unit": "frames/s",
+                  "what": "one hv_tsdf_integrate per frame (pySLAM's online flow), same sliding stream, fresh volume", "roofline": None}
+            if cpu is not None and len(cpu["steps"]) >= online["steps"]:
+                n_l = online["steps"] * B
+                t_l = float(np.sum(online["launch_ms"][:n_l])) * 1e-3
+                alg = sum((t * UNIT_BYTES + u * BYTES_PER_VOXEL) for st in cpu["steps"][:online["steps"]] for t, u in zip(st["touched"], st["updated"]))
+                pk = pmc_kernel(pmc, "k_tsdf_integrate<", command_key)
+                om["roofline"] = {"bound": "hbm", "kernel": "k_tsdf_integrate", "achieved": round(alg / t_l / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(alg / t_l / 1e9 / HBM_PEAK_GBS, 4), "traffic": hbm_traffic(pk),
+                                  "algorithmic_bytes_per_launch": int(alg / n_l), "avg_launch_us": round(t_l / n_l * 1e6, 2), "launches": int(n_l),
+                                  "frames_per_launch": 1}
+            out["online_mode"] = om
+        if replay is not None:
+            out["replay_mode"] = replay
+        if extraction is not None:
+            out["extraction"] = extraction
+        if secondary and not args.no_cpu_baseline:
+            del vol, fuser
+            out["voxel_grid"] = voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, min(B, n_distinct), 3, 6)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -300,6 +300,9 @@ int hv_tsdf_unit_keys(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n);
 int hv_profile_enable(hv_volume *v, int32_t on);
 int hv_profile_read(hv_volume *v, double *kernel_ms_total, int64_t *kernel_launches,
                     int64_t *units_processed);
+/* The same measurement launch by launch: durations (ms) of the bracketed launches since hv_profile_enable / the last
+ * read, in issue order, into launch_ms[0 .. min(*n, cap)); *n = launches recorded.  Does not reset (hv_profile_read does). */
+int hv_profile_read_launches(hv_volume *v, float *launch_ms, int64_t cap, int64_t *n);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY — ctypes front-ends of the CPU oracles.
 
-Import rules (enforced by tests/test_no_oracle_in_product.py): only ``tests/``,
+Import rules (enforced by tests/test_abi.py::test_product_never_touches_the_oracle): only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this package; the
 product package ``pyslam_amd`` never does.
 
@@ -74,6 +74,8 @@ def _load_port():
     for name in ("to_num_units", "to_num_touched", "to_last_updated"):
         getattr(L, name).restype = _i64
         getattr(L, name).argtypes = [_vp]
+    L.to_batch_begin.argtypes = [_vp]
+    L.to_batch_end.argtypes = [_vp, _vp, _vp]
     L.to_touched_keys.restype = _i64
     L.to_touched_keys.argtypes = [_vp, _vp]
     L.to_dump.restype = _i64
@@ -130,6 +132,42 @@ def port_lib():
     if _port is None:
         _port = _load_port()
     return _port
+
+
+def use_native_port():
+    """bench.py's cpu_baseline leg: rebuild the C restatement with -O3 -march=native FOR THE HOST IT RUNS ON (the
+    travelling liboracle_port.so is built without -march so that it loads anywhere) into a per-host temp dir and use
+    it from now on.  Same sources, same -ffp-contract=off: results are unchanged, only the baseline gets faster.
+    Falls back silently to the travelling library when no compiler is around."""
+    global _port
+    import hashlib
+    import tempfile
+
+    srcs = [os.path.join(_HERE, n) for n in ("voxel_oracle.c", "tsdf_oracle.c", "semantic_oracle.c", "semantic2_oracle.c")]
+    mc_dir = os.path.join(os.path.dirname(_HERE), "pyslam_amd", "csrc")
+    h = hashlib.sha256()
+    for path in srcs + [os.path.join(mc_dir, "mc_tables.h")]:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    out_dir = os.path.join(tempfile.gettempdir(), f"pyslam_amd_oracle_native_{h.hexdigest()[:16]}")
+    so = os.path.join(out_dir, "liboracle_port_native.so")
+    try:
+        if not os.path.exists(so):
+            os.makedirs(out_dir, exist_ok=True)
+            tmp = f"{so}.{os.getpid()}.tmp"
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-std=c11", "-ffp-contract=off", "-fopenmp",
+                                   "-I" + mc_dir, "-o", tmp] + srcs + ["-lm"], stderr=subprocess.DEVNULL)
+            os.replace(tmp, so)
+        global _PORT_SO
+        prev = _PORT_SO
+        _PORT_SO = so
+        try:
+            _port = _load_port()
+        finally:
+            _PORT_SO = prev
+        return True
+    except (OSError, subprocess.CalledProcessError):
+        return False
 
 
 def ref_lib():
@@ -327,6 +365,16 @@ class PortTsdf:
 
     def last_updated(self):
         return self._lib.to_last_updated(self._h)
+
+    def batch_begin(self):
+        """Accounting for bench.py: count the distinct units touched / voxels updated by the next integrate() calls."""
+        self._lib.to_batch_begin(self._h)
+
+    def batch_end(self):
+        """-> (distinct units touched, distinct voxels updated) since batch_begin(); switches the accounting off."""
+        u, v = _c.c_int64(0), _c.c_int64(0)
+        self._lib.to_batch_end(self._h, _c.byref(u), _c.byref(v))
+        return u.value, v.value
 
     def touched_keys(self):
         n = self._lib.to_num_touched(self._h)

@@ -38,6 +38,8 @@ typedef struct {
     int32_t index[3]; /* VolumeUnit::index_ */
     to_voxel *voxels; /* res^3, IndexOf(x,y,z) = x*res*res + y*res + z */
     int64_t touched_frame;
+    int64_t touched_batch; /* accounting only (to_batch_begin): last batch that touched the unit */
+    uint8_t *dirty;        /* accounting only: voxels updated since to_batch_begin, allocated on first use */
 } to_unit;
 
 typedef struct {
@@ -51,6 +53,10 @@ typedef struct {
     int64_t *touched; /* indices of units touched by the last integrate(), in touch order */
     int64_t num_touched, cap_touched;
     int64_t last_updated; /* voxels updated by the last integrate() (roofline accounting) */
+    /* batch-level accounting for bench.py's roofline (distinct units touched / distinct voxels updated by a run of
+     * integrate() calls); off unless to_batch_begin was called: the timed baseline never pays for it */
+    int64_t batch /* id of the running accounting batch, 0 = off */, batch_seq, batch_units, batch_voxels;
+    const float *multiplier; /* per-frame multiplier image of the running integrate() */
 } to_volume;
 
 static uint64_t to_mix(int32_t x, int32_t y, int32_t z) {
@@ -90,7 +96,10 @@ to_volume *to_create(double voxel_length, double sdf_trunc, int unit_resolution,
 void to_set_threads(to_volume *v, int threads) { v->threads = threads < 1 ? 1 : threads; }
 
 void to_reset(to_volume *v) { /* ScalableTSDFVolume::Reset(): volume_units_.clear() */
-    for (int64_t u = 0; u < v->num_units; ++u) free(v->units[u].voxels);
+    for (int64_t u = 0; u < v->num_units; ++u) {
+        free(v->units[u].voxels);
+        free(v->units[u].dirty);
+    }
     v->num_units = 0;
     v->num_touched = 0;
     to_table_rebuild(v, 1024);
@@ -127,6 +136,8 @@ static int64_t to_open_unit(to_volume *v, int32_t x, int32_t y, int32_t z) {
     v->units[u].index[0] = x; v->units[u].index[1] = y; v->units[u].index[2] = z;
     v->units[u].voxels = (to_voxel *)calloc((size_t)v->res * v->res * v->res, sizeof(to_voxel));
     v->units[u].touched_frame = -1;
+    v->units[u].touched_batch = 0;
+    v->units[u].dirty = NULL;
     if (v->num_units * 2 > v->table_size) {
         to_table_rebuild(v, v->table_size * 2);
     } else {
@@ -208,7 +219,7 @@ static int64_t to_integrate_unit(const to_volume *vol, to_unit *unit, const to_f
                 const int v = (int)v_f;
                 const float d = f->depth[(int64_t)v * f->W + u];
                 if (d <= 0.0f) continue;
-                const float sdf = (d - pc[2]) * to_multiplier(f, u, v);
+                const float sdf = (d - pc[2]) * vol->multiplier[(int64_t)v * f->W + u];
                 if (sdf > -f->sdf_trunc_f) {
                     float tsdf = sdf * f->sdf_trunc_inv_f;
                     if (tsdf > 1.0f) tsdf = 1.0f; /* std::min(1.0f, sdf * inv) */
@@ -220,6 +231,7 @@ static int64_t to_integrate_unit(const to_volume *vol, to_unit *unit, const to_f
                     vx->tsdf = (vx->tsdf * vx->weight + tsdf) / (vx->weight + 1.0f);
                     vx->weight += 1.0f;
                     ++updated;
+                    if (unit->dirty) unit->dirty[(x * R + y) * R + z] = 1;
                 }
             }
         }
@@ -293,6 +305,24 @@ void to_integrate(to_volume *vol, const void *depth_in, int depth_kind, const ui
                     }
         }
     }
+    /* ScalableTSDFVolume::Integrate: auto depth2cameradistance =
+     * Image::CreateDepthToCameraDistanceMultiplierFloatImage(intrinsic), once per frame */
+    float *mult = (float *)malloc(sizeof(float) * (size_t)npx);
+    for (int v = 0; v < H; ++v)
+        for (int u = 0; u < W; ++u) mult[(int64_t)v * W + u] = to_multiplier(&f, u, v);
+    vol->multiplier = mult;
+    if (vol->batch > 0) {
+        const int64_t nv = (int64_t)vol->res * vol->res * vol->res;
+        for (int64_t t = 0; t < vol->num_touched; ++t) {
+            to_unit *un = &vol->units[vol->touched[t]];
+            if (un->touched_batch != vol->batch) {
+                un->touched_batch = vol->batch;
+                vol->batch_units += 1;
+                if (!un->dirty) un->dirty = (uint8_t *)malloc((size_t)nv);
+                memset(un->dirty, 0, (size_t)nv);
+            }
+        }
+    }
     /* each touched unit is integrated exactly once per frame; units are independent */
     int64_t updated = 0;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(vol->threads) if (vol->threads > 1) reduction(+ : updated)
@@ -300,7 +330,33 @@ void to_integrate(to_volume *vol, const void *depth_in, int depth_kind, const ui
         updated += to_integrate_unit(vol, &vol->units[vol->touched[t]], &f);
     }
     vol->last_updated = updated;
+    vol->multiplier = NULL;
+    free(mult);
     free(depth);
+}
+
+/* Accounting (bench.py roofline): start counting the DISTINCT units touched and voxels updated by the following
+ * integrate() calls; to_batch_end returns them and switches the accounting off again. */
+void to_batch_begin(to_volume *v) {
+    v->batch = ++v->batch_seq;
+    v->batch_units = 0;
+    v->batch_voxels = 0;
+}
+
+void to_batch_end(to_volume *v, int64_t *units, int64_t *voxels) {
+    const int64_t nv = (int64_t)v->res * v->res * v->res;
+    int64_t vox = 0;
+    for (int64_t i = 0; i < v->num_units; ++i) {
+        to_unit *un = &v->units[i];
+        if (un->touched_batch == v->batch && un->dirty) {
+            for (int64_t k = 0; k < nv; ++k) vox += un->dirty[k];
+            free(un->dirty);
+            un->dirty = NULL;
+        }
+    }
+    if (units) *units = v->batch_units;
+    if (voxels) *voxels = vox;
+    v->batch = 0; /* off */
 }
 
 int64_t to_num_units(const to_volume *v) { return v->num_units; }

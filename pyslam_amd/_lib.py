@@ -103,6 +103,7 @@ SIGNATURES = {
     "hv_tsdf_unit_keys": (_i32, [_vp, _vp, _i64, _pi64]),
     "hv_profile_enable": (_i32, [_vp, _i32]),
     "hv_profile_read": (_i32, [_vp, _c.POINTER(_f64), _pi64, _pi64]),
+    "hv_profile_read_launches": (_i32, [_vp, _vp, _i64, _pi64]),
 }
 
 _lib = None

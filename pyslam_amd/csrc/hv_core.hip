@@ -467,4 +467,13 @@ int hv_profile_read(hv_volume *v, double *kernel_ms_total, int64_t *kernel_launc
     return HV_OK;
 }
 
+int hv_profile_read_launches(hv_volume *v, float *launch_ms, int64_t cap, int64_t *n) {
+    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_profile_read_launches: null argument");
+    HV_HIP(hipStreamSynchronize(v->stream));
+    *n = (int64_t)v->events_used;
+    for (size_t i = 0; i < v->events_used && (int64_t)i < cap && launch_ms != nullptr; ++i)
+        HV_HIP(hipEventElapsedTime(&launch_ms[i], v->events[i].start, v->events[i].stop));
+    return HV_OK;
+}
+
 } // extern "C"

@@ -385,6 +385,7 @@ int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, 
     int32_t *tri_count = vert_count + (n + 1);
     int32_t *vert_base = tri_count + (n + 1);
     int32_t *tri_base = vert_base + (n + 1);
+    hv_profile_begin(v); // measurement hook: classify + prefix + scans (both calls of the count / fill pair)
     HV_HIP(hipMemsetAsync(edge_mask, 0, mask_bytes, v->stream));
     HV_HIP(hipMemsetAsync(vert_count, 0, 2 * cnt_bytes, v->stream));
     hipLaunchKernelGGL(k_mc_classify, dim3(n), dim3(256), 0, v->stream, v->table, (const char *)v->pool, n, edge_mask,
@@ -395,6 +396,7 @@ int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, 
     if (rc != HV_OK) return rc;
     rc = exclusive_scan_i32(v, tri_count, tri_base, n + 1);
     if (rc != HV_OK) return rc;
+    hv_profile_end(v, n);
     int32_t totals[2] = {0, 0};
     HV_HIP(hipMemcpyAsync(&totals[0], vert_base + n, sizeof(int32_t), hipMemcpyDeviceToHost, v->stream));
     HV_HIP(hipMemcpyAsync(&totals[1], tri_base + n, sizeof(int32_t), hipMemcpyDeviceToHost, v->stream));
@@ -411,10 +413,12 @@ int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, 
     double *d_vert = (double *)v->out_a, *d_col = d_vert + 3 * nv;
     HvMcParams M{v->cfg.voxel_size, v->cfg.voxel_size * 0.5};
     const int64_t total_edges = (int64_t)n * 3 * RRR;
+    hv_profile_begin(v); // vertices + triangles (D2H of the results is outside the bracket)
     hipLaunchKernelGGL(k_mc_vertices, dim3((unsigned)((total_edges + 255) / 256)), dim3(256), 0, v->stream, v->table,
                        (const char *)v->pool, n, edge_mask, word_prefix, vert_base, M, d_vert, d_col, nv);
     hipLaunchKernelGGL(k_mc_triangles, dim3(n), dim3(256), 0, v->stream, v->table, (const char *)v->pool, n, edge_mask,
                        word_prefix, vert_base, tri_base, (int32_t *)v->out_b, nt);
+    hv_profile_end(v, n);
     HV_HIP(hipGetLastError());
     if (nv > 0) {
         HV_HIP(hipMemcpyAsync(vertices, d_vert, sizeof(double) * 3 * nv, hipMemcpyDeviceToHost, v->stream));
@@ -445,8 +449,10 @@ int hv_tsdf_extract_points(hv_volume *v, double *points, double *colors, int64_t
     HvMcParams M{v->cfg.voxel_size, v->cfg.voxel_size * 0.5};
     HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
     const int64_t total = nb * RRR;
+    hv_profile_begin(v);
     hipLaunchKernelGGL(k_pc_extract, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, v->table,
                        (const char *)v->pool, (int)nb, M, v->cfg.voxel_size * (double)R, d_pts, d_cols, want ? cap : 0);
+    hv_profile_end(v, nb);
     HV_HIP(hipGetLastError());
     rc = hv_read_counters(v);
     if (rc != HV_OK) return rc;

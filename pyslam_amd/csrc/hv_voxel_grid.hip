@@ -316,12 +316,12 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
     const unsigned blocks = (unsigned)((n + 255) / 256);
     int rc = ensure_sort_tmp(v, n);
     if (rc != HV_OK) return rc;
+    hv_profile_begin(v); // measurement hook: keys + sort + ordered reduce of one integrate call
     hipLaunchKernelGGL(k_vg_keys, dim3(blocks), dim3(256), 0, v->stream, v->table, d_pts, n, G, v->sort_keys_in,
                        v->sort_vals_in, d_valid);
     size_t tmp_bytes = v->sort_tmp_bytes;
     HV_HIP(rocprim::radix_sort_pairs(v->sort_tmp, tmp_bytes, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                                      v->sort_vals_out, (size_t)n, 0, sort_bits(v), v->stream));
-    hv_profile_begin(v);
     if (color_kind == HV_COLOR_U8) {
         hipLaunchKernelGGL(k_vg_reduce<HV_COLOR_U8>, dim3(blocks), dim3(256), 0, v->stream, v->table,
                            (HvVoxel *)v->pool, v->sort_keys_out, v->sort_vals_out, n, G, d_pts, d_cols);

@@ -149,11 +149,56 @@ class SyntheticRGBD:
     def labels(self, i):
         return render(trajectory_pose(i, self.n_poses)[1], self.width, self.height, self.fx, self.fy, self.cx, self.cy)[2]
 
-    def batch(self, start, count):
-        ds, cs, Ts = [], [], []
-        for i in range(start, start + count):
-            d, c, T = self[i]
-            ds.append(d)
-            cs.append(c)
-            Ts.append(T)
-        return np.stack(ds), np.stack(cs), np.stack(Ts)
+    def _args(self):
+        return dict(config=dict(width=self.width, height=self.height, fx=self.fx, fy=self.fy, cx=self.cx, cy=self.cy,
+                                voxel=self.voxel), noise=self.noise, invalid_frac=self.invalid_frac, seed=self.seed,
+                    n_poses=self.n_poses, depth_dtype=self.depth_dtype, depth_map_factor=self.depth_map_factor)
+
+    def frames(self, start, count, workers=None):
+        """[(depth, rgb, T_cw)] for frames start .. start+count-1.  Rendering is host-side numpy (~0.25 s per 640x480
+        frame on one core): longer runs are spread over worker subprocesses (`python -m pyslam_amd.synthetic`, fresh
+        interpreters rather than forks: the caller may hold a HIP context).  Frames are seeded per index, so the result
+        does not depend on the worker count."""
+        import os
+
+        if workers is None:
+            workers = min(os.cpu_count() or 1, 32, count // 4)
+        if workers <= 1:
+            return [self[i] for i in range(start, start + count)]
+        import json
+        import subprocess
+        import sys
+        import tempfile
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        per = (count + workers - 1) // workers
+        with tempfile.TemporaryDirectory(prefix="pyslam_amd_synth_") as tmp:
+            jobs = []
+            for w in range(workers):
+                lo = start + w * per
+                n = min(per, start + count - lo)
+                if n <= 0:
+                    break
+                out = os.path.join(tmp, f"part{w}.npz")
+                cmd = [sys.executable, "-m", "pyslam_amd.synthetic", json.dumps(self._args()), str(lo), str(n), out]
+                jobs.append((subprocess.Popen(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")), out))
+            frames = []
+            for proc, out in jobs:
+                if proc.wait() != 0:
+                    raise RuntimeError("synthetic frame worker failed")
+                z = np.load(out)
+                frames.extend((z["depth"][k], z["rgb"][k], z["T"][k]) for k in range(len(z["T"])))
+        return frames
+
+    def batch(self, start, count, workers=None):
+        fr = self.frames(start, count, workers)
+        return np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), np.stack([f[2] for f in fr])
+
+
+if __name__ == "__main__":  # worker of SyntheticRGBD.frames: <json ctor args> <start> <count> <out.npz>
+    import json
+    import sys
+
+    _s = SyntheticRGBD(**json.loads(sys.argv[1]))
+    _d, _c, _T = _s.batch(int(sys.argv[2]), int(sys.argv[3]), workers=1)
+    np.savez(sys.argv[4], depth=_d, rgb=_c, T=_T)

@@ -93,6 +93,15 @@ class _Volume:
         L.check(self._lib.hv_profile_read(self._h, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(units)))
         return ms.value, launches.value, units.value
 
+    def profile_launches(self):
+        """Durations (ms) of the bracketed launches since profile_enable / the last profile_read, in issue order."""
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_profile_read_launches(self._h, None, 0, ctypes.byref(n)))
+        out = np.zeros(n.value, np.float32)
+        if n.value:
+            L.check(self._lib.hv_profile_read_launches(self._h, L.ptr(out), n.value, ctypes.byref(n)))
+        return out
+
     def filter_shadow_points(self, depth, delta_x=2, delta_y=2, fill_value=-1.0):
         """pyslam.utilities.depth.filter_shadow_points(depth, delta_depth=None, ...) on the GPU."""
         if hasattr(depth, "data_ptr"):

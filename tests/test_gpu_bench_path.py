@@ -1,0 +1,132 @@
+"""GPU parity of the EXACT code path and configuration bench.py times.
+
+bench.py's step = ``ScalableTSDFVolume.integrate_batch`` with B = 32 posed frames of
+``synthetic_640x480_5mm`` at voxel 0.005 m / sdf_trunc 0.04 m / depth_trunc 4 m, batches taken as a sliding
+window over the stream (step k fuses frames 32k .. 32k+31 into the same volume).  These tests run that call
+with those arguments against ``oracle.PortTsdf`` and compare the FULL dump: unit keys and weights exact, tsdf
+bitwise, colour <= 1e-4 (north-star tolerance; reference call sites
+pyslam/dense/volumetric_integrator_tsdf.py:215-223,260).  Mesh and point-cloud extraction are compared at the
+same configuration and at BASELINE configs[2] (Replica-shaped 1200x680 @ 4 mm).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.conftest import canonical_mesh, sort_rows, synthetic_frames
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+VOXEL, SDF_TRUNC, DEPTH_TRUNC, B = 0.005, 0.04, 4.0, 32  # == bench.py VOXEL / SDF_TRUNC / DEPTH_TRUNC / --frames-per-step
+THREADS = min(32, os.cpu_count() or 1)
+
+
+def assert_same_volume_chunked(gpu, cpu):
+    """Full comparison, evaluated a slice of units at a time (a 5 mm volume dump is ~1 GB per side)."""
+    ka, ta, wa, ca = gpu.dump()
+    kb, tb, wb, cb = cpu.dump()
+    np.testing.assert_array_equal(ka, kb)  # unit indices bit-exact
+    np.testing.assert_array_equal(wa, wb)  # weights exact
+    np.testing.assert_array_equal(ta.view(np.uint32), tb.view(np.uint32))  # tsdf bit-identical
+    worst = 0.0
+    for lo in range(0, len(ka), 512):
+        worst = max(worst, float(np.abs(ca[lo:lo + 512] - cb[lo:lo + 512]).max()))
+    assert worst / 255.0 <= TOL
+    return len(ka), int(wa.max())
+
+
+def batch_arrays(frames):
+    return np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), np.stack([f[2] for f in frames])
+
+
+def test_bench_step_b32_sliding_window_matches_oracle():
+    """Two consecutive bench steps (frames 0..31, then 32..63) through integrate_batch, device-resident inputs as in
+    bench.py, against the oracle fusing the same 64 frames one by one."""
+    import torch
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    s, frames = synthetic_frames("synthetic_640x480_5mm", 0, 2 * B)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    gpu = ScalableTSDFVolume(VOXEL, SDF_TRUNC, max_blocks=1 << 15)
+    cpu = oracle.PortTsdf(VOXEL, SDF_TRUNC, threads=THREADS)
+    for step in range(2):
+        depth, rgb, T = batch_arrays(frames[step * B:(step + 1) * B])
+        gpu.integrate_batch(torch.from_numpy(depth).cuda(), torch.from_numpy(rgb).cuda(), K, T, depth_scale=1.0,
+                            depth_trunc=DEPTH_TRUNC)
+        for f in frames[step * B:(step + 1) * B]:
+            cpu.integrate(f[0], f[1], K.as_array(), f[2], 1.0, DEPTH_TRUNC)
+        assert gpu.num_blocks() == cpu.num_units()
+    n_units, w_max = assert_same_volume_chunked(gpu, cpu)
+    assert n_units > 6000 and w_max >= 2 * B - 8  # revisits really happened across the two batches
+    assert gpu.dropped_points() == 0
+
+
+def test_bench_step_replay_equals_online():
+    """The replay form of the step (the same 32 frames fused twice, bench.py --window replay) equals 64 online
+    integrate() calls, bitwise in every plane."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+
+    s, frames = synthetic_frames("synthetic_640x480_5mm", 100, B)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    a = ScalableTSDFVolume(VOXEL, SDF_TRUNC, max_blocks=1 << 15)
+    b = ScalableTSDFVolume(VOXEL, SDF_TRUNC, max_blocks=1 << 15)
+    depth, rgb, T = batch_arrays(frames)
+    for _ in range(2):
+        a.integrate_batch(depth, rgb, K, T, depth_scale=1.0, depth_trunc=DEPTH_TRUNC)
+        for d, c, Tcw in frames:
+            b.integrate(RGBDImage.create_from_color_and_depth(c, d, 1.0, DEPTH_TRUNC, False), K, Tcw)
+    for x, y in zip(a.dump(), b.dump()):
+        np.testing.assert_array_equal(x, y)
+
+
+def compare_extraction(gpu, cpu, min_triangles):
+    m = gpu.extract_triangle_mesh()
+    vb, tb, cb = cpu.extract_triangle_mesh()
+    assert m.vertices.shape == vb.shape and m.triangles.shape == tb.shape
+    assert len(tb) >= min_triangles
+    va, ca, ta = canonical_mesh(m.vertices, m.triangles, m.vertex_colors)
+    vb, cb, tb = canonical_mesh(vb, tb, cb)
+    np.testing.assert_allclose(va, vb, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(ca, cb, rtol=0, atol=TOL)
+    np.testing.assert_array_equal(ta, tb)
+    pc = gpu.extract_point_cloud()
+    pb, qb = cpu.extract_point_cloud()
+    assert pc.points.shape == pb.shape
+    pa, qa = sort_rows(np.round(pc.points, 9), pc.colors)
+    pb, qb = sort_rows(np.round(pb, 9), qb)
+    np.testing.assert_allclose(pa, pb, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(qa, qb, rtol=0, atol=TOL)
+
+
+def test_extraction_matches_oracle_at_headline_config():
+    """Marching cubes + point cloud of a 640x480 / 5 mm volume (8 frames through the sweep) vs the oracle:
+    identical vertex sets (<= 1e-9), colours <= 1e-4, identical triangles after canonical re-indexing."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    s, frames = synthetic_frames("synthetic_640x480_5mm", 0, 8)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    gpu = ScalableTSDFVolume(VOXEL, SDF_TRUNC, max_blocks=1 << 15)
+    cpu = oracle.PortTsdf(VOXEL, SDF_TRUNC, threads=THREADS)
+    depth, rgb, T = batch_arrays(frames)
+    gpu.integrate_batch(depth, rgb, K, T, depth_scale=1.0, depth_trunc=DEPTH_TRUNC)
+    for d, c, Tcw in frames:
+        cpu.integrate(d, c, K.as_array(), Tcw, 1.0, DEPTH_TRUNC)
+    compare_extraction(gpu, cpu, min_triangles=1_000_000)
+
+
+def test_extraction_matches_oracle_replica_4mm():
+    """BASELINE configs[2]: Replica-shaped 1200x680, 4 mm TSDF + colour: fuse (sweep), extract, compare."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    s, frames = synthetic_frames("replica_1200x680_4mm", 0, 4)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    gpu = ScalableTSDFVolume(0.004, 0.04, max_blocks=1 << 16, max_points=s.width * s.height)
+    cpu = oracle.PortTsdf(0.004, 0.04, threads=THREADS)
+    depth, rgb, T = batch_arrays(frames)
+    gpu.integrate_batch(depth, rgb, K, T, depth_scale=1.0, depth_trunc=DEPTH_TRUNC)
+    for d, c, Tcw in frames:
+        cpu.integrate(d, c, K.as_array(), Tcw, 1.0, DEPTH_TRUNC)
+    assert gpu.num_blocks() == cpu.num_units()
+    compare_extraction(gpu, cpu, min_triangles=1_000_000)

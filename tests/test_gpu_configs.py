@@ -28,18 +28,33 @@ def test_tsdf_frame_matches_oracle(config, voxel, trunc, max_blocks):
     cpu.integrate(depth, rgb, K.as_array(), T, 1.0, 4.0)
     np.testing.assert_array_equal(gpu.touched_keys(), cpu.touched_keys())
     assert gpu.num_blocks() == cpu.num_units()
-    # compare a deterministic sample of units in full (a full dump at 2 mm is several GB on the host)
-    ka = gpu.unit_keys()
-    assert len(ka) == cpu.num_units()
-    kb, tb, wb, cb = cpu.dump()
-    sel = np.arange(0, len(kb), max(1, len(kb) // 200))
-    payload = gpu.export_numerators(kb[sel])
-    w = payload[..., 1]
-    # export order is the library's internal z*256 + x*16 + y; oracle dump order is x*256 + y*16 + z
-    perm = np.arange(4096).reshape(16, 16, 16).transpose(2, 0, 1).reshape(-1)  # internal index -> oracle index map
-    wb_i, tb_i = wb[sel][:, perm], tb[sel][:, perm]
-    np.testing.assert_array_equal(w, wb_i)
-    np.testing.assert_array_equal(payload[..., 0], tb_i * wb_i)  # weight is 0 or 1 after one frame: numerator == tsdf
+    perm = np.arange(4096).reshape(16, 16, 16).transpose(2, 0, 1).reshape(-1)  # internal index z*256+x*16+y -> oracle index x*256+y*16+z
+
+    def compare_sample():
+        """A deterministic sample of ~200 units in full (a full dump at 2 mm is several GB on the host): weights exact,
+        tsdf bitwise (as the f32 numerator tsdf*w both sides form identically), colour <= 1e-4 on [0, 1]."""
+        ka = gpu.unit_keys()
+        assert len(ka) == cpu.num_units()
+        kb, tb, wb, cb = cpu.dump()
+        sel = np.arange(0, len(kb), max(1, len(kb) // 200))
+        payload = gpu.export_numerators(kb[sel])
+        wb_i, tb_i, cb_i = wb[sel][:, perm], tb[sel][:, perm], cb[sel][:, perm]
+        np.testing.assert_array_equal(payload[..., 1], wb_i)
+        np.testing.assert_array_equal(payload[..., 0], tb_i * wb_i)
+        mean = payload[..., 2:5].astype(np.float64) / np.maximum(wb_i, 1.0)[..., None]
+        assert np.abs(mean - cb_i).max() / 255.0 <= 1e-4
+        return int(wb_i.max())
+
+    assert compare_sample() == 1
+    # the multi-frame sweep at this configuration: 8 further frames in one call, revisiting the first frame's units
+    s2, more = synthetic_frames(config, 4, 8)
+    gpu.integrate_batch(np.stack([f[0] for f in more]), np.stack([f[1] for f in more]), K, np.stack([f[2] for f in more]),
+                        depth_scale=1.0, depth_trunc=4.0)
+    for d, c, Tcw in more:
+        cpu.integrate(d, c, K.as_array(), Tcw, 1.0, 4.0)
+    assert gpu.num_blocks() == cpu.num_units()
+    assert compare_sample() >= 8
+    assert gpu.dropped_points() == 0
 
 
 @pytest.mark.parametrize("config,voxel", [("replica_1200x680_4mm", 0.004), ("scannet_1296x968_2mm", 0.002)])

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
-from tests.conftest import sort_rows, synthetic_frames
+from tests.conftest import canonical_mesh, sort_rows, synthetic_frames
 
 pytestmark = pytest.mark.gpu
 
@@ -44,10 +44,11 @@ def assert_same_volume(gpu, cpu, exact_tsdf=True):
     assert np.abs(ca - cb).max() / 255.0 <= TOL
 
 
-@pytest.mark.parametrize("config,voxel", [("tiny_160x120_2cm", 0.02), ("synthetic_640x480_5mm", 0.01)])
-def test_integrate_matches_oracle(config, voxel):
+@pytest.mark.parametrize("config,voxel,trunc", [("tiny_160x120_2cm", 0.02, 0.08), ("synthetic_640x480_5mm", 0.005, 0.04),
+                                                ("synthetic_640x480_5mm", 0.01, 0.04)])
+def test_integrate_matches_oracle(config, voxel, trunc):
     s, frames = synthetic_frames(config, 5, 3)
-    gpu, cpu = make_pair(voxel, 4 * voxel if voxel > 0.01 else 0.04, max_blocks=1 << 14)
+    gpu, cpu = make_pair(voxel, trunc, max_blocks=1 << 15)
     for f in frames:
         integrate_both(gpu, cpu, s, [f])
         np.testing.assert_array_equal(gpu.touched_keys(), cpu.touched_keys())  # K7 parity per frame
@@ -109,20 +110,6 @@ def test_empty_and_invalid_inputs():
     small.integrate(RGBDImage.create_from_color_and_depth(rgb, d, 1.0, 4.0, False), K, np.eye(4))
     with pytest.raises(RuntimeError, match="pool exhausted"):
         small.num_blocks()
-
-
-def canonical_mesh(verts, tris, cols):
-    """Order-free form: vertices rounded to 1e-9 and sorted; triangles as sorted tuples of the
-    re-indexed vertices, rotation-normalised (orientation preserved)."""
-    key = np.round(verts, 9)
-    order = np.lexsort(key.T[::-1])
-    rank = np.empty(len(order), np.int64)
-    rank[order] = np.arange(len(order))
-    t = rank[tris]
-    rot = np.argmin(t, axis=1)
-    t = np.stack([np.roll(row, -r) for row, r in zip(t, rot)]) if len(t) else t
-    t = t[np.lexsort(t.T[::-1])] if len(t) else t
-    return verts[order], cols[order], t
 
 
 def test_marching_cubes_and_point_cloud_match_oracle():

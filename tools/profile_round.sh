@@ -1,18 +1,27 @@
 #!/bin/bash
-# Produces the rocprofv3 evidence for one round under gpurun_out/ (copy the summaries to profiles/rNN/):
-#   kernel-trace + stats (timing), then FETCH_SIZE and WRITE_SIZE in separate --pmc passes, then one SQ pass and one
-#   TCP pass (counters only, no trace domains besides --kernel-trace).
+# Produces the rocprofv3 evidence for one round under gpurun_out/prof_round/ (copy the summaries to profiles/rNN/):
+#   kernel-trace + stats (timing) of the DEFAULT bench command, then FETCH_SIZE and WRITE_SIZE in separate --pmc
+#   passes, one SQ pass and one TCP pass (counters only: --pmc with --kernel-trace, no other trace domain), all on the
+#   same command so that per-launch means line up with the bench line; tools/pmc_summary.py merges the passes into
+#   pmc_summary.json (with the library build digest), which bench.py parses at run time.
+# usage: GRAFT_GIT_HEAD=<rev> tools/profile_round.sh        (on the GPU box, from the repo root)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-mkdir -p $R/gpurun_out
+O=$R/gpurun_out/prof_round
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt -o bench -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_kt.log 2>&1
-cat $R/gpurun_out/prof_kt/bench_kernel_stats.csv | cut -c1-200
+STEPS=${STEPS:-20}; WARM=${WARM:-5}
+KEY="steps=$STEPS warmup=$WARM B=32 window=sliding config=synthetic_640x480_5mm"
+BENCH="python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- $BENCH > $O/kt.log 2>&1
+cp $O/kt/bench_kernel_stats.csv $O/rocprofv3_kernel_stats.csv 2>/dev/null || find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_kernel_stats.csv \;
+cut -c1-200 $O/rocprofv3_kernel_stats.csv
 pmc_pass() { # name, counters...
   local name=$1; shift
-  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$name -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_$name.log 2>&1
-  python $R/tools/pmc_summary.py $R/gpurun_out/pmc_$name
+  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$name -o pmc -- $BENCH > $O/pmc_$name.log 2>&1
 }
 pmc_pass FETCH_SIZE FETCH_SIZE
 pmc_pass WRITE_SIZE WRITE_SIZE
 pmc_pass sq SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM GRBM_GUI_ACTIVE
 pmc_pass tcp TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum
+python $R/tools/pmc_summary.py --json $O/pmc_summary.json --command-key "$KEY" --range k_tsdf_integrate_batch_col:$WARM:$((WARM+STEPS)) --range k_tsdf_prep_touch_batch:$WARM:$((WARM+STEPS)) --range k_tsdf_batch_finish:$WARM:$((WARM+STEPS)) $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq $O/pmc_tcp > $O/pmc_summary.txt
+cat $O/pmc_summary.txt
