@@ -241,6 +241,8 @@ struct hv_volume {
     bool touch_counters_clean = true; // both touched-list counters are zero (false after an online frame)
     void *batch_buf = nullptr;        // multi-frame sweep scratch: B frame records + B HvFrameParams
     size_t batch_buf_bytes = 0;
+    uint32_t *tile_max = nullptr;     // multi-frame sweep: per frame, per 16x16-pixel tile, max packed depth (float bits) - the sweep's cull test
+    size_t tile_max_bytes = 0;
     float *mult_table = nullptr;      // per-pixel depth-to-distance multiplier of the current intrinsics (multi-frame sweep)
     size_t mult_table_bytes = 0;
     float mult_key[4] = {0.f, 0.f, 0.f, 0.f}; // cx, cy, 1/fx, 1/fy the table was built for

@@ -53,16 +53,28 @@ def synthetic_frames(config, start, count, **kw):
     return s, s.frames(start, count)
 
 
+def _lex_less(a, b):
+    """Row-wise lexicographic a < b for two [n, k] arrays."""
+    d = a != b
+    idx = d.argmax(axis=1)
+    rows = np.arange(len(a))
+    return d.any(axis=1) & (a[rows, idx] < b[rows, idx])
+
+
 def canonical_mesh(verts, tris, cols):
-    """Order-free form of a triangle mesh: vertices rounded to 1e-9 and sorted; triangles as tuples of the re-indexed
-    vertices, rotated so that the smallest index comes first (orientation preserved), then sorted."""
+    """Order-free form of a triangle mesh: vertices (rounded to 1e-9) sorted, with their colours; triangles as rows of
+    their three vertex POSITIONS [n, 9], each rotated to its lexicographically smallest rotation (orientation preserved)
+    and the rows sorted.  Positions instead of vertex indices: marching cubes emits coincident vertices on different
+    edges when a tsdf value is exactly 0 at a voxel corner, and ranks of coincident vertices are arbitrary."""
     key = np.round(verts, 9)
     order = np.lexsort(key.T[::-1])
-    rank = np.empty(len(order), np.int64)
-    rank[order] = np.arange(len(order))
-    t = rank[tris]
-    if len(t):
-        rot = np.argmin(t, axis=1)
-        t = t[np.arange(len(t))[:, None], (rot[:, None] + np.arange(3)[None, :]) % 3]
+    t = np.zeros((0, 9))
+    if len(tris):
+        p = key[tris]  # [n, 3, 3]
+        rots = [np.concatenate([p[:, (r + k) % 3] for k in range(3)], axis=1) for r in range(3)]
+        t = rots[0]
+        for r in rots[1:]:
+            less = _lex_less(r, t)
+            t = np.where(less[:, None], r, t)
         t = t[np.lexsort(t.T[::-1])]
     return verts[order], cols[order], t
