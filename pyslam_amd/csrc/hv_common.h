@@ -187,6 +187,9 @@ struct __attribute__((aligned(16))) HvVoxel {
 static_assert(sizeof(HvVoxel) == 32, "HvVoxel must be 32 bytes");
 
 struct HvFrameParams { // per-frame constants of the TSDF kernels (passed by value)
+    // the multi-frame sweep's per-frame constants, laid out the way its float2 arithmetic consumes them (one 16-dword scalar
+    // load; pairs land in aligned scalar register pairs): {e0,e4, e1,e5, e2,e6, e3,e7, e8,e11, e9,e10, inc0,inc1, inc2,0}
+    float sweep_k[16];
     float ext[12];          // T_cw.cast<float>() rows 0..2
     float ext_scaled_col2[3];
     float fx, fy, cx, cy;
@@ -241,8 +244,6 @@ struct hv_volume {
     bool touch_counters_clean = true; // both touched-list counters are zero (false after an online frame)
     void *batch_buf = nullptr;        // multi-frame sweep scratch: B frame records + B HvFrameParams
     size_t batch_buf_bytes = 0;
-    uint32_t *tile_max = nullptr;     // multi-frame sweep: per frame, per 16x16-pixel tile, max packed depth (float bits) - the sweep's cull test
-    size_t tile_max_bytes = 0;
     float *mult_table = nullptr;      // per-pixel depth-to-distance multiplier of the current intrinsics (multi-frame sweep)
     size_t mult_table_bytes = 0;
     float mult_key[4] = {0.f, 0.f, 0.f, 0.f}; // cx, cy, 1/fx, 1/fy the table was built for

@@ -34,8 +34,6 @@ static constexpr int RR = R * R;
 static constexpr int RRR = R * R * R;
 static constexpr int PLANE_BYTES = RRR * 4;
 static constexpr int HV_TOUCH_FAN = 8; // lanes per depth sample in the online touch pass
-static constexpr int HV_TILE_SHIFT = 4; // the sweep's cull test looks depth maxima up per 16 x 16 pixel tile
-static constexpr int HV_TILE = 1 << HV_TILE_SHIFT;
 
 // Image::CreateDepthToCameraDistanceMultiplierFloatImage, evaluated per gather instead of tabulated.
 __device__ __forceinline__ float hv_multiplier(const HvFrameParams &P, int u, int v) {
@@ -746,8 +744,7 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
                                                                 const uint8_t *__restrict__ rgb,
                                                                 uint2 *__restrict__ frame_px,
                                                                 const HvFrameParams *__restrict__ Ps, int n_prep_blocks,
-                                                                int n_touch_blocks, int n_frames,
-                                                                uint32_t *__restrict__ tile_max, int tiles_w, int tiles_h) {
+                                                                int n_touch_blocks, int n_frames) {
     // block order: the touch blocks of ALL frames first, then the pack blocks.  A touch wave is one chain of dependent
     // memory round trips (depth -> hash probe -> mask / stamp -> atomics; a patch on a long depth discontinuity walks
     // several such chains), the pack blocks are pure streaming: dispatched last they fill the machine while the touch
@@ -792,26 +789,6 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
             }
             ((uint4 *)dst)[0] = make_uint4(__float_as_uint(d[0]), col[0], __float_as_uint(d[1]), col[1]);
             ((uint4 *)dst)[1] = make_uint4(__float_as_uint(d[2]), col[2], __float_as_uint(d[3]), col[3]);
-            // per-tile maximum of the packed depths (HV_TILE x HV_TILE pixels; bit patterns of non-negative floats order
-            // like the values, anything else sorts above them and makes the sweep's cull test keep the tile)
-            uint32_t m = max(max(__float_as_uint(d[0]), __float_as_uint(d[1])), max(__float_as_uint(d[2]), __float_as_uint(d[3])));
-            if ((P.W & 3) == 0) { // the thread's 4 pixels share a row and a tile
-                const int row = (int)(i0 / P.W), colx = (int)(i0 % P.W);
-                bool writer = true;
-                if ((P.W & (HV_TILE - 1)) == 0 && (npx & 255) == 0) { // wave-uniform: every wave is full
-                    // lanes 4k .. 4k+3 cover 16 consecutive pixels of one tile row: one atomic for the four
-                    m = max(m, (uint32_t)__shfl_xor((int)m, 1));
-                    m = max(m, (uint32_t)__shfl_xor((int)m, 2));
-                    writer = (hv_lane_id() & 3) == 0;
-                }
-                if (writer && m != 0u) atomicMax(&tile_max[((int64_t)f * tiles_h + (row >> HV_TILE_SHIFT)) * tiles_w + (colx >> HV_TILE_SHIFT)], m);
-            } else {
-                for (int k = 0; k < 4; ++k) {
-                    const int64_t i = i0 + k;
-                    atomicMax(&tile_max[((int64_t)f * tiles_h + ((int)(i / P.W) >> HV_TILE_SHIFT)) * tiles_w + ((int)(i % P.W) >> HV_TILE_SHIFT)],
-                              __float_as_uint(d[k]));
-                }
-            }
         } else {
             for (int64_t i = i0; i < npx && i < i0 + 4; ++i) {
                 const uint8_t *c = rgb_f + i * 3;
@@ -819,7 +796,6 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
                 rec.x = __float_as_uint(hv_convert_depth(P, depth_f, i));
                 rec.y = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
                 frame_px[(int64_t)f * npx + i] = rec;
-                atomicMax(&tile_max[((int64_t)f * tiles_h + ((int)(i / P.W) >> HV_TILE_SHIFT)) * tiles_w + ((int)(i % P.W) >> HV_TILE_SHIFT)], rec.x);
             }
         }
         return;
@@ -1017,74 +993,49 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_integrate_
 
 // ================================================================================================
 // Sweep, second form (production).  Same mapping and results as k_tsdf_integrate_batch_col (lane = one voxel column,
-// wave = 64 columns x ZH z, frames applied in order in registers), three changes that cut VALU work - the sweep is
-// VALU-issue-bound (profiles/r02/baseline: 0.79 of the wave-instruction peak, 54 instructions per voxel visit):
-//  1. WAVE-LEVEL CULL.  Open3D visits every voxel of a touched unit, but a voxel is only updated where it projects
-//     into the image onto a valid depth d with d > z - sdf_trunc (sdf > -trunc and multiplier >= 1); ~48 % of the
-//     visits update nothing, most of them in sub-blocks lying entirely behind the surface band or outside the image.
-//     Before its frame loop a wave tests ITS sub-block (4 x 16 x ZH voxels = 2 x 8 x 2 cm at 5 mm) against all frames
-//     of the batch at once, lane f <-> frame f: project the 8 corners, pad the pixel box, look the depth maximum up in
-//     the frame's 16 x 16-pixel tile maxima (taken by the pack role) and drop the frame when no pixel of the box can
-//     pass the sdf test.  Conservative by construction (a kept frame costs time, a dropped one would cost parity; the
-//     parity tests run with the cull on and, via HV_TSDF_SWEEP_CULL=0, off); a wave whose frames are all dropped does
-//     not even load its voxels.
-//  2. The (u, v) projection chain is written on float2 values of ONE voxel ((pc0, pc1) walk, (a0, a1) / pc2 with the
-//     refined reciprocal broadcast): v_pk_* instructions without the register shuffles the auto-vectoriser needed to
-//     pair two voxels' chains (25 v_mov per 4 visits in the first form).
-//  3. Gathers go through raw buffer descriptors (out-of-range offsets return 0, so garbage lanes need no select),
-//     the pixel index is a 24-bit mad, the near-plane test is one compare, and the running mean of a voxel pair is
-//     skipped when no lane of the wave updates either voxel.
+// wave = 64 columns x ZH z, frames applied in order in registers).  The sweep is bound by VALU issue, not by HBM
+// (profiles/r02/baseline: 0.79 of the wave-instruction peak at 54 instructions per voxel visit), so this form is about
+// instructions and issue slots:
+//  * the (u, v) projection chain is written on float2 values of ONE voxel ((pc0, pc1) walk, (a0, a1) / pc2 with the
+//    refined reciprocal broadcast): v_pk_* instructions without the register shuffles the auto-vectoriser needed to
+//    pair two voxels' chains in the first form (25 v_mov per 4 visits);
+//  * gathers go through raw buffer descriptors (out-of-range offsets return 0: garbage lanes need no select), the pixel
+//    index is a 24-bit mad;
+//  * what does not depend on the frame (intrinsics, image size, truncation) is read once per work item, the 16 dwords
+//    that do (extrinsics and the z step) are fetched one frame AHEAD into scalar registers, so the scalar-load latency
+//    of a frame hides behind the previous frame's arithmetic;
+//  * the near-camera-plane regime is detected once per work item (lane f tests frame f) instead of once per frame and
+//    column, and routes the whole item to the EXACT loop;
+//  * the running mean of a voxel pair is skipped when no lane of the wave updates either voxel;
+//  * colour is accumulated in two packed registers per voxel (16-bit r and b fields, g in bits 8..23: <= 64 frames x 255
+//    fit) and the three colour planes are only loaded for the final add of voxels that were updated.
+// Measured (profiles/r02): 31.4 k frames/s against 29.2 k for the first form at 128 VGPRs / 4 waves per SIMD.
+// Dead end kept out of the code: a wave-level cull (lane f projecting the wave's sub-block into frame f and testing it
+// against per-tile depth maxima).  The instrumented oracle bounds it: only 18.9 % of (sub-block, frame) pairs update
+// nothing (5 % outside the image, 14 % behind the band) although 47 % of voxel visits do - the 4 x 16 x 4 sub-block is
+// long in y - and a conservative 16-pixel-tile test catches a third of those: 28.0 k with the cull against 28.3 k without.
 // ================================================================================================
 typedef float hv_f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ hv_f2 hv_fma2(hv_f2 a, hv_f2 b, hv_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ hv_f2 hv_splat(float x) { return hv_f2{x, x}; }
 
-// Can frame P update any voxel of the box of voxel centres [lo, hi] (world, metres)?  `tiles` = the frame's tile maxima.
-// Everything is padded: 2 pixels around the projected box, 1e-3 m on the depth comparison (the kernel's own camera-space
-// values differ from these by float rounding only: < 1e-5 m, < 1e-2 pixel).
-__device__ __forceinline__ bool hv_box_may_update(const HvFrameParams &P, const uint32_t *__restrict__ tiles, int tiles_w,
-                                                  const float lo[3], const float hi[3]) {
-    const float e0 = P.ext[0], e1 = P.ext[1], e2 = P.ext[2], e3 = P.ext[3];
-    const float e4 = P.ext[4], e5 = P.ext[5], e6 = P.ext[6], e7 = P.ext[7];
-    const float e8 = P.ext[8], e9 = P.ext[9], e10 = P.ext[10], e11 = P.ext[11];
-    const float d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
-    const float bx = e0 * lo[0] + e1 * lo[1] + e2 * lo[2] + e3;
-    const float by = e4 * lo[0] + e5 * lo[1] + e6 * lo[2] + e7;
-    const float bz = e8 * lo[0] + e9 * lo[1] + e10 * lo[2] + e11;
-    const float zmin = bz + fminf(e8 * d0, 0.f) + fminf(e9 * d1, 0.f) + fminf(e10 * d2, 0.f);
-    if (!(zmin > 0.05f)) return true; // near or behind the camera plane: no projection bound, keep
-    float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float sx = (c & 1) ? d0 : 0.f, sy = (c & 2) ? d1 : 0.f, sz = (c & 4) ? d2 : 0.f;
-        const float X = bx + e0 * sx + e1 * sy + e2 * sz;
-        const float Y = by + e4 * sx + e5 * sy + e6 * sz;
-        const float Z = bz + e8 * sx + e9 * sy + e10 * sz;
-        const float iz = 1.0f / Z;
-        const float u = X * P.fx * iz, v = Y * P.fy * iz;
-        umin = fminf(umin, u); umax = fmaxf(umax, u);
-        vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
-    }
-    // the voxel's pixel is trunc(u + cx + 0.5): pad by 2 pixels on each side
-    const float ulo = umin + P.cx - 1.5f, uhi = umax + P.cx + 2.5f, vlo = vmin + P.cy - 1.5f, vhi = vmax + P.cy + 2.5f;
-    if (!(uhi >= 0.f && ulo < (float)P.W && vhi >= 0.f && vlo < (float)P.H)) return !(uhi == uhi && vhi == vhi); // outside the image (NaN: keep)
-    const int tu0 = (int)fmaxf(ulo, 0.f) >> HV_TILE_SHIFT, tu1 = (int)fminf(uhi, (float)(P.W - 1)) >> HV_TILE_SHIFT;
-    const int tv0 = (int)fmaxf(vlo, 0.f) >> HV_TILE_SHIFT, tv1 = (int)fminf(vhi, (float)(P.H - 1)) >> HV_TILE_SHIFT;
-    if ((tu1 - tu0 + 1) * (tv1 - tv0 + 1) > 36) return true; // a close-up box: not worth the lookups
-    uint32_t dmax = 0u;
-    for (int tv = tv0; tv <= tv1; ++tv)
-        for (int tu = tu0; tu <= tu1; ++tu) dmax = max(dmax, tiles[tv * tiles_w + tu]);
-    if (dmax > 0x7f800000u) return true;  // a negative or NaN depth somewhere in the tiles: keep
-    // a voxel is updated only where d > 0 and (d - z) * multiplier > -sdf_trunc with multiplier >= 1, i.e. d > z - sdf_trunc
-    return dmax != 0u && __uint_as_float(dmax) > zmin - P.sdf_trunc_f - 1.0e-3f;
+struct HvSweepFrameK { // HvFrameParams::sweep_k in registers (plain members: the two prefetch sets must live in scalar registers)
+    hv_f2 e04, e15, e26, e37;
+    float e8, e11;
+    hv_f2 e9_10, i01;
+    float i2;
+};
+__device__ __forceinline__ HvSweepFrameK hv_sweep_frame_k(const HvFrameParams *__restrict__ Ps, int f) {
+    const float *k = Ps[f].sweep_k;
+    return HvSweepFrameK{hv_f2{k[0], k[1]}, hv_f2{k[2], k[3]}, hv_f2{k[4], k[5]}, hv_f2{k[6], k[7]}, k[8], k[9], hv_f2{k[10], k[11]}, hv_f2{k[12], k[13]}, k[14]};
 }
 
 template <int ZH, int SPLIT, int WPE>
 __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
     char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
-    int general, const float *__restrict__ mult, const uint32_t *__restrict__ tile_max, int tiles_w, int tiles_h, int cull) {
+    int general, const float *__restrict__ mult) {
     static_assert(ZH % 2 == 0, "voxels are folded in pairs");
     constexpr int TASKS = 64 / ZH;          // wave tasks per unit
     constexpr int WAVES = TASKS / SPLIT;    // waves per workgroup
@@ -1092,6 +1043,18 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
     if (n_units > table.max_blocks) n_units = table.max_blocks;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    // frame-independent constants (one camera and one volume per batch)
+    const HvFrameParams &P0 = Ps[0];
+    const float vl = P0.voxel_length_f, hl = P0.half_voxel_length_f;
+    const double unit_length = P0.unit_length;
+    const bool tiled = P0.tiled != 0;
+    const int npx = P0.H * P0.W;
+    const hv_f2 F = {P0.fx, P0.fy}, C = {P0.cx, P0.cy};
+    const uint32_t lo = __float_as_uint(0.0001f);
+    const uint32_t wlim = __float_as_uint(P0.safe_width_f) - lo, hlim = __float_as_uint(P0.safe_height_f) - lo;
+    const uint32_t W24 = (uint32_t)P0.W;
+    const float ntrunc = -P0.sdf_trunc_f, tinv = P0.sdf_trunc_inv_f;
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void *)mult, 0, npx * 4, 0x00020000);
     for (int item = blockIdx.x; item < n_units * SPLIT; item += gridDim.x) {
         const int t = item / SPLIT;
         const int task = (item % SPLIT) * WAVES + wave;
@@ -1105,46 +1068,29 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
         if (idx < 0 || mask == 0ull) continue;
         int32_t ux, uy, uz;
         hv_unpack_key(table.keys[slot], ux, uy, uz);
-        const HvFrameParams &P0 = Ps[__ffsll((long long)mask) - 1];
-        const double o0 = (double)ux * P0.unit_length, o1 = (double)uy * P0.unit_length, o2 = (double)uz * P0.unit_length;
-        const float vl = P0.voxel_length_f, hl = P0.half_voxel_length_f;
-        const bool tiled = P0.tiled != 0; // image-tile sharding is a property of the volume: the same for every frame
-        // lane f <-> frame f pre-pass over this wave's sub-block (the box of its voxel centres):
-        //  * does the box come within 3 cm of frame f's camera plane?  Then a voxel may leave the band the short division
-        //    chain is verified for (pc2 >= 2^-20 where pc2 > 0): the whole task takes the EXACT loop (rare: a frame only
-        //    has a unit in its mask when it sees a surface within sdf_trunc of it);
-        //  * (cull) can frame f update any voxel of the box at all?
-        bool near_any;
-        {
-            const float blo[3] = {(float)((double)(hl + vl * (float)(cg * 4)) + o0), (float)((double)hl + o1),
-                                  (float)((double)(hl + vl * (float)z0) + o2)};
-            const float bhi[3] = {(float)((double)(hl + vl * (float)(cg * 4 + 3)) + o0), (float)((double)(hl + vl * 15.0f) + o1),
-                                  (float)((double)(hl + vl * (float)(z0 + ZH - 1)) + o2)};
-            bool keep = false, near = false;
-            if (lane < n_frames && ((mask >> lane) & 1ull)) {
-                const HvFrameParams &Pl = Ps[lane];
-                const float zmin = (Pl.ext[8] * blo[0] + Pl.ext[9] * blo[1] + Pl.ext[10] * blo[2] + Pl.ext[11]) +
-                                   fminf(Pl.ext[8] * (bhi[0] - blo[0]), 0.f) + fminf(Pl.ext[9] * (bhi[1] - blo[1]), 0.f) +
-                                   fminf(Pl.ext[10] * (bhi[2] - blo[2]), 0.f);
-                near = !(zmin > 0.03f);
-                keep = !cull || hv_box_may_update(Pl, tile_max + (int64_t)lane * tiles_w * tiles_h, tiles_w, blo, bhi);
-            }
-            mask &= __ballot(keep);
-            if (mask == 0ull) continue;
-            near_any = __any(near);
+        const double o0 = (double)ux * unit_length, o1 = (double)uy * unit_length, o2 = (double)uz * unit_length;
+        // lane f <-> frame f: does the box of this wave's voxel centres come within 3 cm of frame f's camera plane?  Then a
+        // voxel may leave the band the short division chain is verified for (pc2 >= 2^-20 where pc2 > 0) and the whole
+        // item takes the EXACT loop (rare: a frame only has a unit in its mask when it sees a surface within sdf_trunc of it)
+        bool near = false;
+        if (lane < n_frames && ((mask >> lane) & 1ull)) {
+            const HvFrameParams &Pl = Ps[lane];
+            const float bx = (float)((double)(hl + vl * (float)(cg * 4)) + o0), by = (float)((double)hl + o1),
+                        bz = (float)((double)(hl + vl * (float)z0) + o2);
+            const float zmin = (Pl.ext[8] * bx + Pl.ext[9] * by + Pl.ext[10] * bz + Pl.ext[11]) + fminf(Pl.ext[8] * (3.0f * vl), 0.f) +
+                               fminf(Pl.ext[9] * (15.0f * vl), 0.f) + fminf(Pl.ext[10] * ((float)(ZH - 1) * vl), 0.f);
+            near = !(zmin > 0.03f);
         }
+        const bool near_any = __any(near);
         char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
         const int wordb = z0 * RR + cg * 64 + lane;
         float vt[ZH];
-        uint32_t vw[ZH], vr[ZH], vg[ZH], vb[ZH];
+        uint32_t vw[ZH];
 #pragma unroll
         for (int zz = 0; zz < ZH; ++zz) {
             const int q = wordb + zz * RR;
             vt[zz] = ((const float *)(unit + 0 * PLANE_BYTES))[q];
             vw[zz] = ((const uint32_t *)(unit + 1 * PLANE_BYTES))[q];
-            vr[zz] = ((const uint32_t *)(unit + 2 * PLANE_BYTES))[q];
-            vg[zz] = ((const uint32_t *)(unit + 3 * PLANE_BYTES))[q];
-            vb[zz] = ((const uint32_t *)(unit + 4 * PLANE_BYTES))[q];
         }
         // the voxel centre of (x, y, z = 0) does not depend on the frame
         const float p0 = (float)((double)(hl + vl * (float)x) + o0);
@@ -1155,12 +1101,20 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
         for (int zz = 0; zz < ZH; ++zz) heavy |= vw[zz] >= (1u << 24) - 64u;
         unsigned dirty = 0;
         if (general || tiled || near_any || __any(heavy)) {
-            // rare regimes: EXACT evaluation with integer weights, frame by frame (first form's code)
+            // rare regimes: EXACT evaluation with integer weights, frame by frame (the first form's code)
+            uint32_t vr[ZH], vg[ZH], vb[ZH];
+#pragma unroll
+            for (int zz = 0; zz < ZH; ++zz) {
+                const int q = wordb + zz * RR;
+                vr[zz] = ((const uint32_t *)(unit + 2 * PLANE_BYTES))[q];
+                vg[zz] = ((const uint32_t *)(unit + 3 * PLANE_BYTES))[q];
+                vb[zz] = ((const uint32_t *)(unit + 4 * PLANE_BYTES))[q];
+            }
             while (mask) {
                 const int f = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 const HvFrameParams &P = Ps[f];
-                const uint2 *px = frame_px + (int64_t)f * P.H * P.W;
+                const uint2 *px = frame_px + (int64_t)f * npx;
                 const float inc0 = P.ext_scaled_col2[0], inc1 = P.ext_scaled_col2[1], inc2 = P.ext_scaled_col2[2];
                 float pc0 = ((P.ext[0] * p0 + P.ext[1] * p1) + P.ext[2] * p2) + P.ext[3];
                 float pc1 = ((P.ext[4] * p0 + P.ext[5] * p1) + P.ext[6] * p2) + P.ext[7];
@@ -1182,112 +1136,129 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
                     if (ok) dirty |= 1u << zz;
                 }
             }
-        } else {
-            hv_f2 VT[ZH / 2], WF[ZH / 2];
-#pragma unroll
-            for (int zp = 0; zp < ZH / 2; ++zp) {
-                VT[zp] = hv_f2{vt[2 * zp], vt[2 * zp + 1]};
-                WF[zp] = hv_f2{(float)vw[2 * zp], (float)vw[2 * zp + 1]};
-            }
-            while (mask) {
-                const int f = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const HvFrameParams &P = Ps[f];
-                const int npx = P.H * P.W;
-                const __amdgpu_buffer_rsrc_t rs_px = __builtin_amdgcn_make_buffer_rsrc((void *)(frame_px + (int64_t)f * npx), 0, npx * 8, 0x00020000);
-                const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void *)mult, 0, npx * 4, 0x00020000);
-                const hv_f2 INC = {P.ext_scaled_col2[0], P.ext_scaled_col2[1]};
-                const float inc2 = P.ext_scaled_col2[2];
-                // pc = ((e0 p0 + e1 p1) + e2 p2) + e3, rows 0 and 1 as one float2 (same IEEE ops as the reference)
-                hv_f2 XY = ((hv_f2{P.ext[0], P.ext[4]} * p0 + hv_f2{P.ext[1], P.ext[5]} * p1) + hv_f2{P.ext[2], P.ext[6]} * p2) +
-                           hv_f2{P.ext[3], P.ext[7]};
-                float Z = ((P.ext[8] * p0 + P.ext[9] * p1) + P.ext[10] * p2) + P.ext[11];
-                for (int s = 0; s < z0; ++s) { // the reference's repeated float additions along z, replayed
-                    XY += INC;
-                    Z += inc2;
-                }
-                const hv_f2 F = {P.fx, P.fy}, C = {P.cx, P.cy};
-                const uint32_t lo = __float_as_uint(0.0001f);
-                const uint32_t wlim = __float_as_uint(P.safe_width_f) - lo, hlim = __float_as_uint(P.safe_height_f) - lo;
-                const uint32_t W24 = (uint32_t)P.W;
-                const float ntrunc = -P.sdf_trunc_f, tinv = P.sdf_trunc_inv_f;
-                // ---- evaluation of the ZH voxels: all 2 ZH gathers in flight, then the tests ----
-                uint2 rec[ZH];
-                float mm[ZH], zk[ZH];
-                bool ok[ZH];
-#pragma unroll
-                for (int k = 0; k < ZH; ++k) {
-                    // (a0, a1) / pc2, correctly rounded, sharing one refined reciprocal (hv_div2's chain on a float2)
-                    float r = __builtin_amdgcn_rcpf(Z);
-                    const float e = fmaf(-Z, r, 1.0f);
-                    r = fmaf(e, r, r);
-                    const hv_f2 A = XY * F;
-                    const hv_f2 R = hv_splat(r), NZ = hv_splat(-Z);
-                    hv_f2 Q = A * R;
-                    hv_f2 REM = hv_fma2(NZ, Q, A);
-                    Q = hv_fma2(REM, R, Q);
-                    REM = hv_fma2(NZ, Q, A);
-                    Q = hv_fma2(REM, R, Q);
-                    const hv_f2 UV = (Q + C) + hv_splat(0.5f);
-                    const bool in_u = (__float_as_uint(UV.x) - lo) < wlim;
-                    const bool in_v = (__float_as_uint(UV.y) - lo) < hlim;
-                    ok[k] = (int)(Z > 0.0f) & (int)in_u & (int)in_v;
-                    const uint32_t u = (uint32_t)(int)UV.x, v = (uint32_t)(int)UV.y; // saturating conversions: garbage lanes stay defined
-                    const uint32_t off = __umul24(v, W24) + u; // exact for every in-image pixel; garbage lanes read 0 or some pixel, unused
-                    rec[k] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs_px, (int)(off << 3), 0, 0));
-                    mm[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_m, (int)(off << 2), 0, 0));
-                    zk[k] = Z;
-                    XY += INC;
-                    Z += inc2;
-                }
-                // ---- fold, two voxels at a time ----
-#pragma unroll
-                for (int zp = 0; zp < ZH / 2; ++zp) {
-                    const int k0 = 2 * zp, k1 = 2 * zp + 1;
-                    const float da = __uint_as_float(rec[k0].x), db = __uint_as_float(rec[k1].x);
-                    const float sa = (da - zk[k0]) * mm[k0], sb = (db - zk[k1]) * mm[k1];
-                    const bool oka = (int)ok[k0] & (int)(da > 0.0f) & (int)(sa > ntrunc);
-                    const bool okb = (int)ok[k1] & (int)(db > 0.0f) & (int)(sb > ntrunc);
-                    if (!__any((int)oka | (int)okb)) continue; // no lane of the wave updates either voxel
-                    const hv_f2 T = {fminf(sa * tinv, 1.0f), fminf(sb * tinv, 1.0f)}; // == `if (t > 1) t = 1` for the non-NaN t of an accepted voxel
-                    // running mean (tsdf * w + t) / (w + 1) with float weights (exact below 2^24), hv_div1's chain on a float2
-                    const hv_f2 W1 = WF[zp] + hv_splat(1.0f);
-                    const hv_f2 NUM = VT[zp] * WF[zp] + T;
-                    hv_f2 R = {__builtin_amdgcn_rcpf(W1.x), __builtin_amdgcn_rcpf(W1.y)};
-                    const hv_f2 E = hv_fma2(-W1, R, hv_splat(1.0f));
-                    R = hv_fma2(E, R, R);
-                    hv_f2 Q = NUM * R;
-                    hv_f2 REM = hv_fma2(-W1, Q, NUM);
-                    Q = hv_fma2(REM, R, Q);
-                    REM = hv_fma2(-W1, Q, NUM);
-                    Q = hv_fma2(REM, R, Q);
-                    VT[zp].x = oka ? Q.x : VT[zp].x;
-                    VT[zp].y = okb ? Q.y : VT[zp].y;
-                    WF[zp].x = oka ? W1.x : WF[zp].x;
-                    WF[zp].y = okb ? W1.y : WF[zp].y;
-                    const uint32_t ca = oka ? rec[k0].y : 0u, cb = okb ? rec[k1].y : 0u;
-                    vr[k0] += ca & 255u; vg[k0] += (ca >> 8) & 255u; vb[k0] += (ca >> 16) & 255u;
-                    vr[k1] += cb & 255u; vg[k1] += (cb >> 8) & 255u; vb[k1] += (cb >> 16) & 255u;
-                }
-            }
 #pragma unroll
             for (int zz = 0; zz < ZH; ++zz) {
-                const float wfz = (zz & 1) ? WF[zz / 2].y : WF[zz / 2].x;
-                vt[zz] = (zz & 1) ? VT[zz / 2].y : VT[zz / 2].x;
-                const uint32_t nw = (uint32_t)wfz;
-                if (nw != vw[zz]) dirty |= 1u << zz;
-                vw[zz] = nw;
+                if (dirty & (1u << zz)) {
+                    const int q = wordb + zz * RR;
+                    ((float *)(unit + 0 * PLANE_BYTES))[q] = vt[zz];
+                    ((uint32_t *)(unit + 1 * PLANE_BYTES))[q] = vw[zz];
+                    ((uint32_t *)(unit + 2 * PLANE_BYTES))[q] = vr[zz];
+                    ((uint32_t *)(unit + 3 * PLANE_BYTES))[q] = vg[zz];
+                    ((uint32_t *)(unit + 4 * PLANE_BYTES))[q] = vb[zz];
+                }
             }
+            continue;
+        }
+        hv_f2 VT[ZH / 2], WF[ZH / 2];
+        uint32_t arb[ZH], ag[ZH]; // colour of the batch: r | b << 16 and g << 8
+#pragma unroll
+        for (int zp = 0; zp < ZH / 2; ++zp) {
+            VT[zp] = hv_f2{vt[2 * zp], vt[2 * zp + 1]};
+            WF[zp] = hv_f2{(float)vw[2 * zp], (float)vw[2 * zp + 1]};
+            arb[2 * zp] = arb[2 * zp + 1] = ag[2 * zp] = ag[2 * zp + 1] = 0u;
+        }
+        // One frame folded into the registers; K = the frame's 16 constant dwords, already in scalar registers.
+        auto fold_frame = [&](const HvSweepFrameK K, const int f, HvSweepFrameK &Knext, const unsigned long long rest) __attribute__((always_inline)) {
+            const __amdgpu_buffer_rsrc_t rs_px = __builtin_amdgcn_make_buffer_rsrc((void *)(frame_px + (int64_t)f * npx), 0, npx * 8, 0x00020000);
+            const hv_f2 INC = K.i01;
+            const float inc2 = K.i2;
+            // pc = ((e0 p0 + e1 p1) + e2 p2) + e3, rows 0 and 1 as one float2 (same IEEE ops as the reference)
+            hv_f2 XY = ((K.e04 * p0 + K.e15 * p1) + K.e26 * p2) + K.e37;
+            const hv_f2 Z12 = K.e9_10 * hv_f2{p1, p2};
+            float Z = ((K.e8 * p0 + Z12.x) + Z12.y) + K.e11;
+            // K is consumed (the wait for its scalar loads sits above): only now issue the loads of the next frame's constants,
+            // so that wait does not include them (scalar loads return out of order: there is only "wait for all")
+            __builtin_amdgcn_sched_barrier(0);
+            Knext = hv_sweep_frame_k(Ps, rest ? __ffsll((long long)rest) - 1 : f); // (the last frame re-reads itself: no branch, the order above holds)
+            __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < z0; ++s) { // the reference's repeated float additions along z, replayed
+                XY += INC;
+                Z += inc2;
+            }
+            // ---- evaluation of the ZH voxels: all 2 ZH gathers in flight, then the tests ----
+            uint2 rec[ZH];
+            float mm[ZH], zk[ZH];
+            bool ok[ZH];
+#pragma unroll
+            for (int k = 0; k < ZH; ++k) {
+                // (a0, a1) / pc2, correctly rounded, sharing one refined reciprocal (hv_div2's chain on a float2)
+                float r = __builtin_amdgcn_rcpf(Z);
+                const float e = fmaf(-Z, r, 1.0f);
+                r = fmaf(e, r, r);
+                const hv_f2 A = XY * F;
+                const hv_f2 R = hv_splat(r), NZ = hv_splat(-Z);
+                hv_f2 Q = A * R;
+                hv_f2 REM = hv_fma2(NZ, Q, A);
+                Q = hv_fma2(REM, R, Q);
+                REM = hv_fma2(NZ, Q, A);
+                Q = hv_fma2(REM, R, Q);
+                const hv_f2 UV = (Q + C) + hv_splat(0.5f);
+                // u_f in [0.0001, safe_width) as ONE unsigned compare (bit patterns of non-negative floats order like the values)
+                const bool in_u = (__float_as_uint(UV.x) - lo) < wlim;
+                const bool in_v = (__float_as_uint(UV.y) - lo) < hlim;
+                ok[k] = (int)(Z > 0.0f) & (int)in_u & (int)in_v;
+                const uint32_t u = (uint32_t)(int)UV.x, v = (uint32_t)(int)UV.y; // saturating conversions: garbage lanes stay defined
+                const uint32_t off = __umul24(v, W24) + u; // exact for every in-image pixel; a garbage lane reads 0 or some pixel, unused
+                rec[k] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs_px, (int)(off << 3), 0, 0));
+                mm[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_m, (int)(off << 2), 0, 0));
+                zk[k] = Z;
+                XY += INC;
+                Z += inc2;
+            }
+            // ---- fold, two voxels at a time ----
+#pragma unroll
+            for (int zp = 0; zp < ZH / 2; ++zp) {
+                const int k0 = 2 * zp, k1 = 2 * zp + 1;
+                const float da = __uint_as_float(rec[k0].x), db = __uint_as_float(rec[k1].x);
+                const float sa = (da - zk[k0]) * mm[k0], sb = (db - zk[k1]) * mm[k1];
+                const bool oka = (int)ok[k0] & (int)(da > 0.0f) & (int)(sa > ntrunc);
+                const bool okb = (int)ok[k1] & (int)(db > 0.0f) & (int)(sb > ntrunc);
+                if (!__any((int)oka | (int)okb)) continue; // no lane of the wave updates either voxel
+                const hv_f2 T = {fminf(sa * tinv, 1.0f), fminf(sb * tinv, 1.0f)}; // == `if (t > 1) t = 1` for the non-NaN t of an accepted voxel
+                // running mean (tsdf * w + t) / (w + 1) with float weights (exact below 2^24), hv_div1's chain on a float2
+                const hv_f2 W1 = WF[zp] + hv_splat(1.0f);
+                const hv_f2 NUM = VT[zp] * WF[zp] + T;
+                hv_f2 R = {__builtin_amdgcn_rcpf(W1.x), __builtin_amdgcn_rcpf(W1.y)};
+                const hv_f2 E = hv_fma2(-W1, R, hv_splat(1.0f));
+                R = hv_fma2(E, R, R);
+                hv_f2 Q = NUM * R;
+                hv_f2 REM = hv_fma2(-W1, Q, NUM);
+                Q = hv_fma2(REM, R, Q);
+                REM = hv_fma2(-W1, Q, NUM);
+                Q = hv_fma2(REM, R, Q);
+                VT[zp].x = oka ? Q.x : VT[zp].x;
+                VT[zp].y = okb ? Q.y : VT[zp].y;
+                WF[zp].x = oka ? W1.x : WF[zp].x;
+                WF[zp].y = okb ? W1.y : WF[zp].y;
+                const uint32_t ca = oka ? rec[k0].y : 0u, cb = okb ? rec[k1].y : 0u;
+                arb[k0] += ca & 0x00ff00ffu; ag[k0] += ca & 0x0000ff00u;
+                arb[k1] += cb & 0x00ff00ffu; ag[k1] += cb & 0x0000ff00u;
+            }
+        };
+        // Frame constants are fetched one frame AHEAD, alternating between two scalar register sets (a copy between sets
+        // would make the wave wait for the load at once): the scalar-load latency of frame n+1 hides behind frame n's fold.
+        HvSweepFrameK ka = hv_sweep_frame_k(Ps, __ffsll((long long)mask) - 1), kb = ka;
+        while (true) {
+            const int fa = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            fold_frame(ka, fa, kb, mask);
+            if (!mask) break;
+            const int fb = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            fold_frame(kb, fb, ka, mask);
+            if (!mask) break;
         }
 #pragma unroll
         for (int zz = 0; zz < ZH; ++zz) {
-            if (dirty & (1u << zz)) {
+            const float wfz = (zz & 1) ? WF[zz / 2].y : WF[zz / 2].x;
+            const uint32_t nw = (uint32_t)wfz;
+            if (nw != vw[zz]) { // updated by at least one frame: fold the batch's colour into the planes
                 const int q = wordb + zz * RR;
-                ((float *)(unit + 0 * PLANE_BYTES))[q] = vt[zz];
-                ((uint32_t *)(unit + 1 * PLANE_BYTES))[q] = vw[zz];
-                ((uint32_t *)(unit + 2 * PLANE_BYTES))[q] = vr[zz];
-                ((uint32_t *)(unit + 3 * PLANE_BYTES))[q] = vg[zz];
-                ((uint32_t *)(unit + 4 * PLANE_BYTES))[q] = vb[zz];
+                ((float *)(unit + 0 * PLANE_BYTES))[q] = (zz & 1) ? VT[zz / 2].y : VT[zz / 2].x;
+                ((uint32_t *)(unit + 1 * PLANE_BYTES))[q] = nw;
+                ((uint32_t *)(unit + 2 * PLANE_BYTES))[q] += arb[zz] & 0xffffu;
+                ((uint32_t *)(unit + 3 * PLANE_BYTES))[q] += ag[zz] >> 8;
+                ((uint32_t *)(unit + 4 * PLANE_BYTES))[q] += arb[zz] >> 16;
             }
         }
     }
@@ -1296,9 +1267,7 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
 // After the sweep (one workgroup): clear the frame masks of the batch's units and zero both touched-list counters, so
 // that the next batch / online frame starts clean without a memset launch per counter.
 __global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const int32_t *__restrict__ list,
-                                                             unsigned long long *__restrict__ frame_mask, int parity,
-                                                             uint32_t *__restrict__ tile_max, int tile_words) {
-    for (int i = (int)threadIdx.x; i < tile_words; i += (int)blockDim.x) tile_max[i] = 0u; // the next batch's pack role takes maxima into it
+                                                             unsigned long long *__restrict__ frame_mask, int parity) {
     int n_units = table.counters[HV_CNT_TOUCH0 + parity];
     if (n_units > table.max_blocks) n_units = table.max_blocks;
     __syncthreads(); // every thread holds n_units before the counters are reset
@@ -1392,6 +1361,15 @@ static int make_frame_params(hv_volume *v, int H, int W, const double *intr, con
     P->voxel_length_f = (float)v->cfg.voxel_size;
     P->half_voxel_length_f = P->voxel_length_f * 0.5f;
     for (int r = 0; r < 3; ++r) P->ext_scaled_col2[r] = P->ext[r * 4 + 2] * P->voxel_length_f;
+    for (int c = 0; c < 4; ++c) {
+        P->sweep_k[2 * c] = P->ext[c];
+        P->sweep_k[2 * c + 1] = P->ext[4 + c];
+    }
+    P->sweep_k[8] = P->ext[8];
+    P->sweep_k[9] = P->ext[11];
+    P->sweep_k[10] = P->ext[9];
+    P->sweep_k[11] = P->ext[10];
+    for (int r = 0; r < 3; ++r) P->sweep_k[12 + r] = P->ext_scaled_col2[r];
     P->fx = (float)intr[0];
     P->fy = (float)intr[1];
     P->cx = (float)intr[2];
@@ -1608,31 +1586,19 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         v->touch_counters_clean = true;
         const int n_prep_blocks = (int)((npx + 1023) / 1024); // 4 pixels per thread
         const int n_touch_blocks = (hv_touch_patches(width, height, v->cfg.depth_sampling_stride) + 3) / 4;
-        // per-frame tile maxima of the packed depth (the sweep's cull test): zero at first use, re-zeroed by every finish kernel
-        const int tiles_w = (width + HV_TILE - 1) / HV_TILE, tiles_h = (height + HV_TILE - 1) / HV_TILE;
-        const size_t tile_bytes = sizeof(uint32_t) * (size_t)tiles_w * tiles_h * BMAX;
-        if (v->tile_max == nullptr || v->tile_max_bytes < tile_bytes) {
-            void *buf = v->tile_max;
-            rc = hv_ensure_buffer(v, &buf, &v->tile_max_bytes, tile_bytes);
-            if (rc != HV_OK) return rc;
-            v->tile_max = (uint32_t *)buf;
-            HV_HIP(hipMemsetAsync(v->tile_max, 0, v->tile_max_bytes, v->stream));
-        }
-        const int tile_words = (int)(v->tile_max_bytes / sizeof(uint32_t));
         hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3((n_prep_blocks + n_touch_blocks) * B), dim3(256), 0, v->stream,
                            v->table, v->touched_stamp, (unsigned long long *)v->touched_mask, v->touched_list, batch_stamp,
                            (const char *)d_depth + npx * dsz * (size_t)f0, (int64_t)(npx * dsz),
-                           (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks, n_touch_blocks, B,
-                           v->tile_max, tiles_w, tiles_h);
+                           (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks, n_touch_blocks, B);
         hv_profile_begin(v);
-        // sweep form: 2 = k_tsdf_sweep (production: wave-level cull + float2 projection chain), 1 = first form (A/B, and
+        // sweep form: 2 = k_tsdf_sweep (production: float2 projection chain, prefetched frame constants), 1 = first form (A/B, and
         // the only one that runs without the multiplier table).  The switches are read per call (a handful of getenv per
         // batch): the parity tests flip them inside one process.
         const int sweep_form = getenv("HV_TSDF_SWEEP") ? atoi(getenv("HV_TSDF_SWEEP")) : 2;
-        const int sweep_cull = getenv("HV_TSDF_SWEEP_CULL") ? atoi(getenv("HV_TSDF_SWEEP_CULL")) : 1;
         const int sweep_zh = getenv("HV_TSDF_SWEEP_ZH") ? atoi(getenv("HV_TSDF_SWEEP_ZH")) : 4;
-        // workgroups per unit (2 / 4 / 8; 4 measured best at 1 and 8 ranks)
-        const int split = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : 4;
+        // workgroups per unit (2 / 4 / 8).  Second form: 8 (two waves per workgroup; 32.7 k frames/s against 31.6 k at 4 and
+        // 29.0 k at 2); the first form measured best at 4
+        const int split = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : (sweep_form == 2 ? 8 : 4);
         // 1: run the EXACT evaluation with integer weights everywhere (A/B and parity checks of the rare-regime code)
         const int general = getenv("HV_TSDF_BATCH_GENERAL") ? atoi(getenv("HV_TSDF_BATCH_GENERAL")) : 0;
         // per-pixel multiplier table (HV_TSDF_BATCH_MULT=0: compute the multiplier per voxel visit instead)
@@ -1652,13 +1618,17 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
                        v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0, general, d_mult)
 #define HV_LAUNCH_SWEEP(ZH, S, WPE)                                                                                    \
     hipLaunchKernelGGL((k_tsdf_sweep<ZH, S, WPE>), dim3(sweep_grid), dim3(64 * (64 / ZH) / S), 0, v->stream, v->table,   \
-                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult, v->tile_max, tiles_w,  \
-                       tiles_h, sweep_cull)
+                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult)
         if (d_mult && sweep_form == 2) {
+            const int wpe = getenv("HV_TSDF_SWEEP_WPE") ? atoi(getenv("HV_TSDF_SWEEP_WPE")) : 4; // 4 waves / SIMD = 128 VGPRs: nothing spills
             if (sweep_zh == 8) {
-                if (split == 2) HV_LAUNCH_SWEEP(8, 2, 1); else HV_LAUNCH_SWEEP(8, 4, 1);
+                if (split == 2) HV_LAUNCH_SWEEP(8, 2, 1); else if (wpe == 4) HV_LAUNCH_SWEEP(8, 4, 2); else HV_LAUNCH_SWEEP(8, 4, 1);
+            } else if (split == 2) {
+                if (wpe == 4) HV_LAUNCH_SWEEP(4, 2, 4); else HV_LAUNCH_SWEEP(4, 2, 1);
+            } else if (split == 8) {
+                if (wpe == 4) HV_LAUNCH_SWEEP(4, 8, 4); else if (wpe == 5) HV_LAUNCH_SWEEP(4, 8, 5); else HV_LAUNCH_SWEEP(4, 8, 1);
             } else {
-                if (split == 2) HV_LAUNCH_SWEEP(4, 2, 1); else if (split == 8) HV_LAUNCH_SWEEP(4, 8, 1); else HV_LAUNCH_SWEEP(4, 4, 5);
+                if (wpe == 4) HV_LAUNCH_SWEEP(4, 4, 4); else if (wpe == 3) HV_LAUNCH_SWEEP(4, 4, 3); else if (wpe == 1) HV_LAUNCH_SWEEP(4, 4, 1); else HV_LAUNCH_SWEEP(4, 4, 5);
             }
         } else if (d_mult) {
             if (split == 2) HV_LAUNCH_COL(2, true); else if (split == 8) HV_LAUNCH_COL(8, true); else HV_LAUNCH_COL(4, true);
@@ -1669,7 +1639,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
 #undef HV_LAUNCH_SWEEP
         hv_profile_end(v, B);
         hipLaunchKernelGGL(k_tsdf_batch_finish, dim3(1), dim3(1024), 0, v->stream, v->table, v->touched_list,
-                           (unsigned long long *)v->touched_mask, 0, v->tile_max, tile_words);
+                           (unsigned long long *)v->touched_mask, 0);
         HV_HIP(hipGetLastError());
     }
     return HV_OK;

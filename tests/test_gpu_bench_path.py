@@ -144,8 +144,9 @@ def sweep_case():
 
 
 SWEEP_FORMS = [
-    {"HV_TSDF_SWEEP": "2"},                              # production: cull + float2 chain
-    {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_CULL": "0"},   # the same kernel, every frame of the unit mask applied
+    {"HV_TSDF_SWEEP": "2"},                              # production: float2 chain, prefetched frame constants, packed colour
+    {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_WPE": "5"},    # the same at 96 VGPRs (5 waves / SIMD)
+    {"HV_TSDF_SWEEP": "2", "HV_TSDF_BATCH_SPLIT": "8"},  # 8 workgroups per unit
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_ZH": "8"},     # 8 voxels of a column per lane
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_BATCH_GENERAL": "1"},  # EXACT evaluation with integer weights everywhere
     {"HV_TSDF_SWEEP": "1"},                              # first form (round 1)
@@ -155,8 +156,7 @@ SWEEP_FORMS = [
 @pytest.mark.parametrize("env", SWEEP_FORMS, ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
 def test_sweep_forms_match_oracle(env, sweep_case, monkeypatch):
     """Every form of the multi-frame sweep (the switches are read per call) against the oracle at the bench
-    configuration, two batches of 8 frames: keys and weights exact, tsdf bitwise, colour <= 1e-4.  The cull may only
-    drop (sub-block, frame) pairs that update nothing, so culled and unculled runs must give the same bits."""
+    configuration, two batches of 8 frames: keys and weights exact, tsdf bitwise, colour <= 1e-4."""
     from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
 
     for k, v in env.items():

@@ -33,6 +33,19 @@ constexpr int ITER = 4096;
 #define A_SQRT(k) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[k]));
 #define A_CVT(k) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[k]));
 #define A_CND(k) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(b) : );
+#define A_CND64(k) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[k]) : "v"(b) : );
+#define A_CNDIMM(k) asm volatile("v_cndmask_b32_e64 %0, 0, %1, s[20:21]" : "+v"(a[k]) : "v"(b) : );
+#define A_CMPCND(k) asm volatile("v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[k]) : "v"(b), "v"(c) : "vcc");
+#define A_CMPCND64(k) asm volatile("v_cmp_gt_u32_e64 s[22:23], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %2, s[22:23]" : "+v"(a[k]) : "v"(b), "v"(c) : "s22", "s23");
+#define A_BFI(k) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(a[k]) : "v"(b), "v"(c));
+#define A_ASHR(k) asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(a[k]));
+#define A_AND(k) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define A_ANDOR(k) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define A_FMADEP(k) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(b), "v"(c));
+#define A_PKFMADEP(k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(b), "v"(c));
+#define A_SUBU(k) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define A_MULF(k) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define A_SNOP(k) asm volatile("s_nop 0");
 #define A_MAD24(k) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
 #define A_MULLO(k) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
 #define A_ADDU(k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
@@ -61,6 +74,19 @@ KERNEL(k_rcp, DECL32, A_RCP)
 KERNEL(k_sqrt, DECL32, A_SQRT)
 KERNEL(k_cvt, DECL32, A_CVT)
 KERNEL(k_cndmask, DECL32, A_CND)
+KERNEL(k_cndmask64, DECL32, A_CND64)
+KERNEL(k_cndmaskimm, DECL32, A_CNDIMM)
+KERNEL(k_cmpcnd, DECL32, A_CMPCND)
+KERNEL(k_cmpcnd64, DECL32, A_CMPCND64)
+KERNEL(k_bfi, DECL32, A_BFI)
+KERNEL(k_ashr, DECL32, A_ASHR)
+KERNEL(k_and, DECL32, A_AND)
+KERNEL(k_andor, DECL32, A_ANDOR)
+KERNEL(k_fmadep, DECL32, A_FMADEP)
+KERNEL(k_subu, DECL32, A_SUBU)
+KERNEL(k_mulf, DECL32, A_MULF)
+KERNEL(k_snop, DECL32, A_SNOP)
+KERNEL(k_pkfmadep, DECL64, A_PKFMADEP)
 KERNEL(k_mad_u32_u24, DECL32, A_MAD24)
 KERNEL(k_mul_lo_u32, DECL32, A_MULLO)
 KERNEL(k_add_u32, DECL32, A_ADDU)
@@ -94,7 +120,10 @@ int main() {
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     std::vector<Entry> es = {{"v_fma_f32", k_fma}, {"v_add_f32", k_add}, {"v_mov_b32", k_mov}, {"v_rcp_f32", k_rcp}, {"v_sqrt_f32", k_sqrt},
-                             {"v_cvt_i32_f32", k_cvt}, {"v_cndmask_b32", k_cndmask}, {"v_mad_u32_u24", k_mad_u32_u24}, {"v_mul_lo_u32", k_mul_lo_u32},
+                             {"v_cvt_i32_f32", k_cvt}, {"v_cndmask_b32", k_cndmask}, {"v_cndmask_b32_e64 sgpr", k_cndmask64}, {"v_cndmask_b32_e64 0,v,sgpr", k_cndmaskimm},
+                             {"v_cmp+v_cndmask vcc (x2)", k_cmpcnd}, {"v_cmp+v_cndmask sgpr (x2)", k_cmpcnd64}, {"v_bfi_b32", k_bfi}, {"v_ashrrev_i32", k_ashr},
+                             {"v_and_b32", k_and}, {"v_and_or_b32", k_andor}, {"v_fma_f32 dependent chain", k_fmadep}, {"v_pk_fma_f32 dep chain", k_pkfmadep},
+                             {"v_sub_u32", k_subu}, {"v_mul_f32", k_mulf}, {"s_nop 0", k_snop}, {"v_mad_u32_u24", k_mad_u32_u24}, {"v_mul_lo_u32", k_mul_lo_u32},
                              {"v_add_u32", k_add_u32}, {"v_add_u32_sdwa", k_add_u32_sdwa}, {"v_dot4_u32_u8", k_dot4_u32_u8}, {"v_cmp_gt_u32 vcc", k_cmp_vcc},
                              {"v_cmp_gt_u32 sgpr", k_cmp_sgpr}, {"v_min_f32", k_min}, {"v_med3_f32", k_med3}, {"v_bfe_u32", k_bfe}, {"v_perm_b32", k_perm},
                              {"v_lshl_add_u32", k_lshl_add_u32}, {"v_pk_fma_f32", k_pk_fma}, {"v_pk_add_f32", k_pk_add}, {"v_pk_mul_f32", k_pk_mul},
