@@ -323,7 +323,7 @@ def main():
     for k in range(args.steps):
         step(k)
     if world > 1 and args.sharding == "tile":
-        fuser.merge()  # tile sharding leaves partial means on the shared units: one merge makes the volume consistent (timed)
+        fuser.merge_halo()  # tile sharding leaves partial means on the units several ranks updated: all-reduce of those units (timed)
     fence()
     elapsed = time.perf_counter() - t0
     launch_ms = vol.profile_launches()

@@ -294,6 +294,31 @@ int hv_tsdf_import_numerators(hv_volume *v, const int32_t *keys, int64_t k, cons
 /* All allocated unit keys (unsorted) for the key all-gather; keys may be NULL. */
 int hv_tsdf_unit_keys(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n);
 
+/* ---- halo merge of image-tile-sharded volumes (SURVEY 8b `hv_merge_halo`, 8e; north-star "RCCL all-reduce of
+ * overlapping-block TSDF/weight").  pySLAM has no multi-GPU path (no NCCL/MPI/torch.distributed call anywhere in the
+ * reference): these are new.  With hv_tsdf_set_tile each GPU fuses the voxels that project into its image tile, so units
+ * on tile borders (and revisits from other viewpoints) hold PARTIAL running means on several GPUs.  A merge:
+ *   1. hv_tsdf_dirty_keys      every rank: the units it stamped since its last merge (sorted, 12 B per key)
+ *   2. (caller) all-gather of the key lists
+ *   3. hv_merge_halo_plan      every rank, same input -> same output: keys listed by >= 2 ranks, in sorted order, and what
+ *                              THIS rank does with each: 0 = does not hold it, 1 = keeps it (lowest listing rank), 2 = zeroes it
+ *   4. hv_merge_halo_pack      additive numerators {sum w*tsdf, w, sum r, sum g, sum b} of the shared units only, dense
+ *                              [K, 16^3, 5] f32 in plan order (zeros where the rank does not hold a unit)
+ *   5. (caller) all-reduce(sum) of that buffer - message size = shared units x 81 920 B, not the whole volume
+ *   6. hv_merge_halo_unpack    keeper: state := reduced numerators; other holders: unit zeroed (they go on fusing deltas)
+ *   7. hv_tsdf_mark_merged
+ * Afterwards the sum over ranks of every unit's numerators is still the single-GPU total, and every shared unit is complete
+ * on exactly one rank.  The library does the device work; the caller owns the transport (pyslam_amd/distributed.py:
+ * torch.distributed, backend nccl = RCCL over xGMI). */
+int hv_tsdf_dirty_keys(hv_volume *v, int32_t *keys /* [cap,3] host, may be NULL */, int64_t cap, int64_t *n);
+int hv_tsdf_mark_merged(hv_volume *v);
+/* Host-only.  gathered_keys = the ranks' lists back to back ([sum counts, 3]); shared_keys/action may be NULL to query *n_shared. */
+int hv_merge_halo_plan(const int32_t *gathered_keys, const int64_t *counts, int32_t world_size, int32_t rank,
+                       int32_t *shared_keys, uint8_t *action, int64_t cap, int64_t *n_shared);
+int hv_merge_halo_pack(hv_volume *v, const int32_t *shared_keys, int64_t k, float *payload, int32_t loc);
+int hv_merge_halo_unpack(hv_volume *v, const int32_t *shared_keys, int64_t k, const float *payload, const uint8_t *action,
+                         int32_t loc);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------
  * When enabled, the dominant kernel of each integrate call is bracketed by HIP events on the
  * volume's stream; hv_profile_read synchronises and returns the summed device time. */

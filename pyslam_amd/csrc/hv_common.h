@@ -240,6 +240,7 @@ struct hv_volume {
     int debug_variant = 0;            // env HV_TSDF_DEBUG_VARIANT (roofline ablation only)
     int touch_box_bits = 2048;        // env HV_TSDF_TOUCH_BOX_BITS (0 forces the touch pass's general path; tests)
     int32_t frame_counter = 0;
+    int32_t merge_stamp = 0;          // frame_counter at the last hv_tsdf_mark_merged: units stamped later are "dirty"
     int32_t last_touch_parity = 0;
     bool touch_counters_clean = true; // both touched-list counters are zero (false after an online frame)
     void *batch_buf = nullptr;        // multi-frame sweep scratch: B frame records + B HvFrameParams
@@ -273,6 +274,13 @@ struct hv_volume {
     float *scratch_points = nullptr; // [max_points*3]
     float *scratch_colors = nullptr; // [max_points*3]
     int local_bits = 9;
+
+    // Surface-extraction cache (TSDF): the C ABI is "ask for the sizes, then fetch", i.e. two calls per extraction; the first
+    // call does all the device work into out_a / out_b and the second only copies, as long as the volume did not change in
+    // between (content_version is bumped by every call that changes voxels).
+    uint64_t content_version = 1;
+    uint64_t mesh_cache_version = 0, points_cache_version = 0; // content_version the cached results belong to (0: none)
+    int64_t mesh_cache_nv = 0, mesh_cache_nt = 0, points_cache_n = 0;
 
     // output scratch (grown on demand)
     void *out_a = nullptr;

@@ -280,7 +280,9 @@ int hv_reset(hv_volume *v) {
     if (v->touched_stamp) HV_HIP(hipMemsetAsync(v->touched_stamp, 0, sizeof(int32_t) * v->table_capacity, v->stream));
     if (v->touched_mask) HV_HIP(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * v->table_capacity, v->stream));
     memset(v->h_counters, 0, sizeof(int32_t) * HV_CNT_COUNT);
+    v->content_version += 1;
     v->frame_counter = 0;
+    v->merge_stamp = 0;
     v->last_touch_parity = 0;
     v->touch_counters_clean = true;
     return HV_OK;

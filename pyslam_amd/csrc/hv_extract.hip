@@ -52,10 +52,12 @@ __device__ inline void load_neighbours(const HvTable &table, int idx, int *s_nbr
     }
 }
 
-// stage (tsdf, weight) of the 17^3 neighbourhood into LDS; absent units read as weight 0
+// stage (tsdf, weight) of the 17^3 neighbourhood into LDS; absent units read as weight 0.  The loop runs in the order of
+// the planes in memory (word = z*256 + x*16 + y: y fastest), so a wave reads 64-byte runs; the LDS index (x*17 + y)*17 + z
+// has an odd stride in every direction (no bank conflicts on the transposing writes).
 __device__ inline void load_slab(const char *pool, const int *s_nbr, float *s_f, uint32_t *s_w) {
     for (int e = threadIdx.x; e < H * H * H; e += blockDim.x) {
-        const int x = e / (H * H), y = (e / H) % H, z = e % H;
+        const int z = e / (H * H), x = (e / H) % H, y = e % H;
         const int n = (x >= R ? 1 : 0) | (y >= R ? 2 : 0) | (z >= R ? 4 : 0);
         const int idx = s_nbr[n];
         float f = 0.f;
@@ -66,8 +68,9 @@ __device__ inline void load_slab(const char *pool, const int *s_nbr, float *s_f,
             f = ((const float *)unit)[word];
             w = ((const uint32_t *)(unit + PLANE_BYTES))[word];
         }
-        s_f[e] = f;
-        s_w[e] = w;
+        const int l = (x * H + y) * H + z;
+        s_f[l] = f;
+        s_w[l] = w;
     }
 }
 
@@ -257,17 +260,22 @@ __global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, const char 
     }
 }
 
-// ScalableTSDFVolume::ExtractPointCloud: one thread per voxel, wave-ballot compaction of the hits.
-__global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *__restrict__ pool, int n_units,
-                                                     HvMcParams M, double unit_length, double *__restrict__ points,
-                                                     double *__restrict__ colors, int64_t cap) {
+// ScalableTSDFVolume::ExtractPointCloud: one thread per voxel, three candidate edges (+x, +y, +z) each.  Hits are ranked
+// inside the 1024-thread workgroup (wave prefix + LDS across the 16 waves) and the workgroup takes its output range with ONE
+// atomic - the first version's one atomic per wave and axis on a single counter serialised the kernel (8.8 ms for 32 k
+// units; profiles/r02/baseline).
+__global__ __launch_bounds__(1024) void k_pc_extract(HvTable table, const char *__restrict__ pool, int n_units,
+                                                      HvMcParams M, double unit_length, double *__restrict__ points,
+                                                      double *__restrict__ colors, int64_t cap) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = gid < (int64_t)n_units * RRR;
     const int idx = in_range ? (int)(gid / RRR) : 0;
     const int lin = in_range ? (int)(gid % RRR) : 0;
     const int z = lin / RR, x = (lin / R) % R, y = lin % R;
     const char *u0 = pool + (int64_t)idx * UNIT_BYTES;
-    float f0 = 0.f, c0[3] = {0, 0, 0};
+    float f0 = 0.f;
     uint32_t w0 = 0;
     int32_t ux = 0, uy = 0, uz = 0;
     if (in_range) {
@@ -276,54 +284,86 @@ __global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *_
         hv_unpack_key(table.block_keys[idx], ux, uy, uz);
     }
     const bool base_ok = in_range && w0 != 0u && f0 < 0.98f && f0 >= -0.98f;
+    float f1[3] = {0.f, 0.f, 0.f};
+    int nidx[3] = {-1, -1, -1}, nl[3] = {0, 0, 0};
+    unsigned hits = 0;
     if (base_ok) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) // color_.cast<float>() of the double running mean
-            c0[k] = (float)((double)((const uint32_t *)(u0 + (2 + k) * PLANE_BYTES))[lin] / (double)w0);
-    }
-    const double p0[3] = {(M.half_voxel_length + M.voxel_length * (double)x) + (double)ux * unit_length,
-                          (M.half_voxel_length + M.voxel_length * (double)y) + (double)uy * unit_length,
-                          (M.half_voxel_length + M.voxel_length * (double)z) + (double)uz * unit_length};
-    for (int i = 0; i < 3; ++i) {
-        bool hit = false;
-        float f1 = 0.f, c1[3] = {0, 0, 0};
-        if (base_ok) {
+        for (int i = 0; i < 3; ++i) {
             int nx = x + (i == 0), ny = y + (i == 1), nz = z + (i == 2);
-            int nidx = idx;
+            int ni = idx;
             if (nx >= R || ny >= R || nz >= R) {
                 const int32_t kx = ux + (nx >= R), ky = uy + (ny >= R), kz = uz + (nz >= R);
-                nidx = -1;
+                ni = -1;
                 if (hv_key_in_range(kx, ky, kz)) {
                     const int32_t slot = hv_table_find(table, hv_pack_key(kx, ky, kz));
-                    if (slot >= 0) nidx = table.vals[slot];
+                    if (slot >= 0) ni = table.vals[slot];
                 }
                 nx &= R - 1; ny &= R - 1; nz &= R - 1;
             }
-            if (nidx >= 0) {
-                const char *u1 = pool + (int64_t)nidx * UNIT_BYTES;
-                const int nl = voxel_word(nx, ny, nz);
-                f1 = ((const float *)u1)[nl];
-                const uint32_t w1 = ((const uint32_t *)(u1 + PLANE_BYTES))[nl];
-                if (w1 != 0u && f1 < 0.98f && f1 >= -0.98f && f0 * f1 < 0) {
-                    hit = true;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        c1[k] = (float)((double)((const uint32_t *)(u1 + (2 + k) * PLANE_BYTES))[nl] / (double)w1);
-                }
+            if (ni < 0) continue;
+            const char *u1 = pool + (int64_t)ni * UNIT_BYTES;
+            const int l1 = voxel_word(nx, ny, nz);
+            const float f = ((const float *)u1)[l1];
+            const uint32_t w1 = ((const uint32_t *)(u1 + PLANE_BYTES))[l1];
+            if (w1 != 0u && f < 0.98f && f >= -0.98f && f0 * f < 0) {
+                hits |= 1u << i;
+                f1[i] = f;
+                nidx[i] = ni;
+                nl[i] = l1;
             }
         }
-        const int32_t at = hv_wave_append(&table.counters[HV_CNT_OUT], hit);
-        if (hit && at < cap && points != nullptr) {
-            const float r0 = fabsf(f0), r1 = fabsf(f1);
+    }
+    // rank of this thread's hits inside the workgroup
+    const int mine = __popc(hits);
+    const int lane = hv_lane_id(), wave = threadIdx.x >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < HV_WAVE; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == HV_WAVE - 1) s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int c = s_wave[w];
+            s_wave[w] = total;
+            total += c;
+        }
+        s_base = total ? atomicAdd(&table.counters[HV_CNT_OUT], total) : 0;
+    }
+    __syncthreads();
+    if (!hits || points == nullptr) return;
+    int64_t at = (int64_t)s_base + s_wave[wave] + incl - mine;
+    float c0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) // color_.cast<float>() of the double running mean
+        c0[k] = (float)((double)((const uint32_t *)(u0 + (2 + k) * PLANE_BYTES))[lin] / (double)w0);
+    const double p0[3] = {(M.half_voxel_length + M.voxel_length * (double)x) + (double)ux * unit_length,
+                          (M.half_voxel_length + M.voxel_length * (double)y) + (double)uy * unit_length,
+                          (M.half_voxel_length + M.voxel_length * (double)z) + (double)uz * unit_length};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (!(hits & (1u << i))) continue;
+        if (at < cap) {
+            const char *u1 = pool + (int64_t)nidx[i] * UNIT_BYTES;
+            const double w1 = (double)((const uint32_t *)(u1 + PLANE_BYTES))[nl[i]];
+            float c1[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c1[k] = (float)((double)((const uint32_t *)(u1 + (2 + k) * PLANE_BYTES))[nl[i]] / w1);
+            const float r0 = fabsf(f0), r1 = fabsf(f1[i]);
             double p[3] = {p0[0], p0[1], p0[2]};
             const double p1i = p0[i] + M.voxel_length;
             p[i] = (p0[i] * (double)r1 + p1i * (double)r0) / (double)(r0 + r1);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                points[(int64_t)at * 3 + k] = p[k];
-                colors[(int64_t)at * 3 + k] = (double)((c0[k] * r1 + c1[k] * r0) / (r0 + r1) / 255.0f);
+                points[at * 3 + k] = p[k];
+                colors[at * 3 + k] = (double)((c0[k] * r1 + c1[k] * r0) / (r0 + r1) / 255.0f);
             }
         }
+        ++at;
     }
 }
 
@@ -357,20 +397,23 @@ static int exclusive_scan_i32(hv_volume *v, int32_t *in, int32_t *out, int n) {
 
 extern "C" {
 
-int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, int64_t cap_vertices,
-                         int32_t *triangles, int64_t cap_triangles, int64_t *n_vertices, int64_t *n_triangles) {
-    HV_REQUIRE(v != nullptr && n_vertices != nullptr && n_triangles != nullptr, HV_ERR_INVALID,
-               "hv_tsdf_extract_mesh: null argument");
-    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_extract_mesh: volume is not in TSDF mode");
-    HV_HIP(hipSetDevice(v->device));
+// Both extraction entry points follow the "sizes first, data second" protocol of the reference binding (numpy arrays are
+// allocated by the caller).  The call without output pointers does ALL the device work into out_a / out_b and records it
+// under the volume's content_version; the call with pointers then only copies - unless the volume changed in between (or
+// no size query preceded it), in which case it recomputes first.
+static int mesh_compute(hv_volume *v) {
     int rc = upload_tables(v->device);
     if (rc != HV_OK) return rc;
     int64_t nb = 0;
     rc = hv_num_blocks(v, &nb);
     if (rc != HV_OK) return rc;
-    *n_vertices = 0;
-    *n_triangles = 0;
-    if (nb == 0) return HV_OK;
+    v->mesh_cache_version = 0;
+    v->points_cache_version = 0; // shares out_a
+    v->mesh_cache_nv = v->mesh_cache_nt = 0;
+    if (nb == 0) {
+        v->mesh_cache_version = v->content_version;
+        return HV_OK;
+    }
     const int n = (int)nb;
     // scratch: [edge_mask nb*192 u64][word_prefix nb*192 u32][vert_count n+1][tri_count n+1][vert_base n+1][tri_base n+1]
     const size_t mask_bytes = sizeof(uint64_t) * MASK_WORDS * (size_t)n;
@@ -385,7 +428,7 @@ int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, 
     int32_t *tri_count = vert_count + (n + 1);
     int32_t *vert_base = tri_count + (n + 1);
     int32_t *tri_base = vert_base + (n + 1);
-    hv_profile_begin(v); // measurement hook: classify + prefix + scans (both calls of the count / fill pair)
+    hv_profile_begin(v); // measurement hook: classify + prefix + scans
     HV_HIP(hipMemsetAsync(edge_mask, 0, mask_bytes, v->stream));
     HV_HIP(hipMemsetAsync(vert_count, 0, 2 * cnt_bytes, v->stream));
     hipLaunchKernelGGL(k_mc_classify, dim3(n), dim3(256), 0, v->stream, v->table, (const char *)v->pool, n, edge_mask,
@@ -401,25 +444,44 @@ int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, 
     HV_HIP(hipMemcpyAsync(&totals[0], vert_base + n, sizeof(int32_t), hipMemcpyDeviceToHost, v->stream));
     HV_HIP(hipMemcpyAsync(&totals[1], tri_base + n, sizeof(int32_t), hipMemcpyDeviceToHost, v->stream));
     HV_HIP(hipStreamSynchronize(v->stream));
-    *n_vertices = totals[0];
-    *n_triangles = totals[1];
+    const int64_t nv = totals[0], nt = totals[1];
+    if (nv > 0 || nt > 0) {
+        rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, sizeof(double) * 6 * (size_t)std::max<int64_t>(nv, 1));
+        if (rc != HV_OK) return rc;
+        rc = hv_ensure_buffer(v, &v->out_b, &v->out_b_bytes, sizeof(int32_t) * 3 * (size_t)std::max<int64_t>(nt, 1));
+        if (rc != HV_OK) return rc;
+        double *d_vert = (double *)v->out_a, *d_col = d_vert + 3 * nv;
+        HvMcParams M{v->cfg.voxel_size, v->cfg.voxel_size * 0.5};
+        const int64_t total_edges = (int64_t)n * 3 * RRR;
+        hv_profile_begin(v); // vertices + triangles (D2H of the results is outside the bracket)
+        hipLaunchKernelGGL(k_mc_vertices, dim3((unsigned)((total_edges + 255) / 256)), dim3(256), 0, v->stream, v->table,
+                           (const char *)v->pool, n, edge_mask, word_prefix, vert_base, M, d_vert, d_col, nv);
+        hipLaunchKernelGGL(k_mc_triangles, dim3(n), dim3(256), 0, v->stream, v->table, (const char *)v->pool, n, edge_mask,
+                           word_prefix, vert_base, tri_base, (int32_t *)v->out_b, nt);
+        hv_profile_end(v, n);
+        HV_HIP(hipGetLastError());
+    }
+    v->mesh_cache_nv = nv;
+    v->mesh_cache_nt = nt;
+    v->mesh_cache_version = v->content_version;
+    return HV_OK;
+}
+
+int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, int64_t cap_vertices,
+                         int32_t *triangles, int64_t cap_triangles, int64_t *n_vertices, int64_t *n_triangles) {
+    HV_REQUIRE(v != nullptr && n_vertices != nullptr && n_triangles != nullptr, HV_ERR_INVALID,
+               "hv_tsdf_extract_mesh: null argument");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_extract_mesh: volume is not in TSDF mode");
+    HV_HIP(hipSetDevice(v->device));
+    if (v->mesh_cache_version != v->content_version) {
+        const int rc = mesh_compute(v);
+        if (rc != HV_OK) return rc;
+    }
+    *n_vertices = v->mesh_cache_nv;
+    *n_triangles = v->mesh_cache_nt;
     if (vertices == nullptr || vertex_colors == nullptr || triangles == nullptr) return HV_OK;
-    const int64_t nv = std::min<int64_t>(totals[0], cap_vertices), nt = std::min<int64_t>(totals[1], cap_triangles);
-    if (nv == 0 && nt == 0) return HV_OK;
-    rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, sizeof(double) * 6 * (size_t)std::max<int64_t>(nv, 1));
-    if (rc != HV_OK) return rc;
-    rc = hv_ensure_buffer(v, &v->out_b, &v->out_b_bytes, sizeof(int32_t) * 3 * (size_t)std::max<int64_t>(nt, 1));
-    if (rc != HV_OK) return rc;
-    double *d_vert = (double *)v->out_a, *d_col = d_vert + 3 * nv;
-    HvMcParams M{v->cfg.voxel_size, v->cfg.voxel_size * 0.5};
-    const int64_t total_edges = (int64_t)n * 3 * RRR;
-    hv_profile_begin(v); // vertices + triangles (D2H of the results is outside the bracket)
-    hipLaunchKernelGGL(k_mc_vertices, dim3((unsigned)((total_edges + 255) / 256)), dim3(256), 0, v->stream, v->table,
-                       (const char *)v->pool, n, edge_mask, word_prefix, vert_base, M, d_vert, d_col, nv);
-    hipLaunchKernelGGL(k_mc_triangles, dim3(n), dim3(256), 0, v->stream, v->table, (const char *)v->pool, n, edge_mask,
-                       word_prefix, vert_base, tri_base, (int32_t *)v->out_b, nt);
-    hv_profile_end(v, n);
-    HV_HIP(hipGetLastError());
+    const int64_t nv = std::min<int64_t>(v->mesh_cache_nv, cap_vertices), nt = std::min<int64_t>(v->mesh_cache_nt, cap_triangles);
+    const double *d_vert = (const double *)v->out_a, *d_col = d_vert + 3 * v->mesh_cache_nv;
     if (nv > 0) {
         HV_HIP(hipMemcpyAsync(vertices, d_vert, sizeof(double) * 3 * nv, hipMemcpyDeviceToHost, v->stream));
         HV_HIP(hipMemcpyAsync(vertex_colors, d_col, sizeof(double) * 3 * nv, hipMemcpyDeviceToHost, v->stream));
@@ -429,41 +491,62 @@ int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, 
     return HV_OK;
 }
 
-int hv_tsdf_extract_points(hv_volume *v, double *points, double *colors, int64_t cap, int64_t *n) {
-    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_tsdf_extract_points: null argument");
-    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_extract_points: volume is not in TSDF mode");
-    HV_HIP(hipSetDevice(v->device));
+static int points_compute(hv_volume *v) {
     int64_t nb = 0;
     int rc = hv_num_blocks(v, &nb);
     if (rc != HV_OK) return rc;
-    *n = 0;
-    if (nb == 0) return HV_OK;
-    const bool want = points != nullptr && colors != nullptr && cap > 0;
-    double *d_pts = nullptr, *d_cols = nullptr;
-    if (want) {
-        rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, sizeof(double) * 6 * (size_t)cap);
-        if (rc != HV_OK) return rc;
-        d_pts = (double *)v->out_a;
-        d_cols = d_pts + 3 * cap;
+    v->points_cache_version = 0;
+    v->mesh_cache_version = 0; // shares out_a
+    v->points_cache_n = 0;
+    if (nb == 0) {
+        v->points_cache_version = v->content_version;
+        return HV_OK;
     }
     HvMcParams M{v->cfg.voxel_size, v->cfg.voxel_size * 0.5};
-    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
     const int64_t total = nb * RRR;
+    const unsigned blocks = (unsigned)((total + 1023) / 1024);
+    // pass 1 counts (tsdf + weight planes only), pass 2 writes into a buffer of exactly that size
     hv_profile_begin(v);
-    hipLaunchKernelGGL(k_pc_extract, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, v->table,
-                       (const char *)v->pool, (int)nb, M, v->cfg.voxel_size * (double)R, d_pts, d_cols, want ? cap : 0);
+    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
+    hipLaunchKernelGGL(k_pc_extract, dim3(blocks), dim3(1024), 0, v->stream, v->table, (const char *)v->pool, (int)nb, M,
+                       v->cfg.voxel_size * (double)R, (double *)nullptr, (double *)nullptr, (int64_t)0);
     hv_profile_end(v, nb);
     HV_HIP(hipGetLastError());
     rc = hv_read_counters(v);
     if (rc != HV_OK) return rc;
-    *n = v->h_counters[HV_CNT_OUT];
-    if (want) {
-        const int64_t m = std::min<int64_t>(*n, cap);
-        if (m > 0) {
-            HV_HIP(hipMemcpyAsync(points, d_pts, sizeof(double) * 3 * m, hipMemcpyDeviceToHost, v->stream));
-            HV_HIP(hipMemcpyAsync(colors, d_cols, sizeof(double) * 3 * m, hipMemcpyDeviceToHost, v->stream));
-            HV_HIP(hipStreamSynchronize(v->stream));
-        }
+    const int64_t n = v->h_counters[HV_CNT_OUT];
+    if (n > 0) {
+        rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, sizeof(double) * 6 * (size_t)n);
+        if (rc != HV_OK) return rc;
+        double *d_pts = (double *)v->out_a, *d_cols = d_pts + 3 * n;
+        hv_profile_begin(v);
+        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
+        hipLaunchKernelGGL(k_pc_extract, dim3(blocks), dim3(1024), 0, v->stream, v->table, (const char *)v->pool, (int)nb, M,
+                           v->cfg.voxel_size * (double)R, d_pts, d_cols, n);
+        hv_profile_end(v, nb);
+        HV_HIP(hipGetLastError());
+    }
+    v->points_cache_n = n;
+    v->points_cache_version = v->content_version;
+    return HV_OK;
+}
+
+int hv_tsdf_extract_points(hv_volume *v, double *points, double *colors, int64_t cap, int64_t *n) {
+    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_tsdf_extract_points: null argument");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_extract_points: volume is not in TSDF mode");
+    HV_HIP(hipSetDevice(v->device));
+    if (v->points_cache_version != v->content_version) {
+        const int rc = points_compute(v);
+        if (rc != HV_OK) return rc;
+    }
+    *n = v->points_cache_n;
+    if (points == nullptr || colors == nullptr || cap <= 0) return HV_OK;
+    const int64_t m = std::min<int64_t>(v->points_cache_n, cap);
+    if (m > 0) {
+        const double *d_pts = (const double *)v->out_a, *d_cols = d_pts + 3 * v->points_cache_n;
+        HV_HIP(hipMemcpyAsync(points, d_pts, sizeof(double) * 3 * m, hipMemcpyDeviceToHost, v->stream));
+        HV_HIP(hipMemcpyAsync(colors, d_cols, sizeof(double) * 3 * m, hipMemcpyDeviceToHost, v->stream));
+        HV_HIP(hipStreamSynchronize(v->stream));
     }
     return HV_OK;
 }

@@ -77,8 +77,12 @@ __device__ inline bool hv_unit_hits_tile(const HvFrameParams &P, int32_t ux, int
         umin = fminf(umin, u); umax = fmaxf(umax, u);
         vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
     }
-    return umax + 2.0f >= (float)P.tile_u0 && umin - 2.0f < (float)P.tile_u1 && vmax + 2.0f >= (float)P.tile_v0 &&
-           vmin - 2.0f < (float)P.tile_v1;
+    // tiles on the image border extend outwards without bound: a touched unit that projects entirely outside the image (it
+    // only has a sample's +/- sdf_trunc box in view) still belongs to exactly the ranks it is nearest to, so the union of the
+    // ranks' units stays Open3D's set of opened units
+    const bool u_ok = (P.tile_u0 <= 0 || umax + 2.0f >= (float)P.tile_u0) && (P.tile_u1 >= P.W || umin - 2.0f < (float)P.tile_u1);
+    const bool v_ok = (P.tile_v0 <= 0 || vmax + 2.0f >= (float)P.tile_v0) && (P.tile_v1 >= P.H || vmin - 2.0f < (float)P.tile_v1);
+    return u_ok && v_ok;
 }
 
 // ---- touch pass: PointCloud::CreateFromDepthImage(stride) + unit enumeration, all f64 -------------------------------
@@ -315,13 +319,15 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch(HvTable table, int32_t 
             if (lane == first) leader = true;
             remaining &= ~same;
         }
-        if (leader) {
+        // image-tile sharding: a unit none of whose voxels can project into this GPU's tile is neither allocated nor
+        // stamped here (whole-image tile: always true) - so "stamped since the last merge" == "may hold updates"
+        if (leader && hv_unit_hits_tile(P, ux, uy, uz)) {
             const int32_t slot = hv_table_insert(table, key);
             if (slot >= 0) {
                 // L1-bypassing pre-check: most units were already stamped by another wave this frame
                 if (__hip_atomic_load(&stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.frame_id) {
                     const int32_t old = atomicExch(&stamp[slot], P.frame_id);
-                    if (old != P.frame_id && hv_unit_hits_tile(P, ux, uy, uz)) {
+                    if (old != P.frame_id) {
                         const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0 + parity], 1);
                         if (at < table.max_blocks) list[at] = slot;
                     }
@@ -807,14 +813,15 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
     const unsigned long long fbit = 1ull << f;
     hv_touch_patch(table, P, depth_f, patch, scratch[threadIdx.x / HV_WAVE],
                    [&](unsigned long long key, int32_t ux, int32_t uy, int32_t uz) {
+                       // image-tile sharding: units that cannot project into this GPU's tile are not allocated here
+                       if (!hv_unit_hits_tile(P, ux, uy, uz)) return;
                        const int32_t slot = hv_table_insert(table, key);
                        if (slot < 0) return;
-                       const bool hits = hv_unit_hits_tile(P, ux, uy, uz);
                        // both L1-bypassing pre-checks in flight together
                        const unsigned long long seen = __hip_atomic_load(&frame_mask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                        const int32_t stamped = __hip_atomic_load(&stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                        // frame bit (skip the atomic when another wave of this frame already set it)
-                       if (hits && !(seen & fbit)) atomicOr(&frame_mask[slot], fbit);
+                       if (!(seen & fbit)) atomicOr(&frame_mask[slot], fbit);
                        if (stamped != batch_stamp) {
                            const int32_t old = atomicExch(&stamp[slot], batch_stamp);
                            if (old != batch_stamp) {
@@ -1350,6 +1357,60 @@ __global__ void k_tsdf_import(HvTable table, char *__restrict__ pool, const int3
     ((uint32_t *)(unit + 4 * PLANE_BYTES))[word] = (uint32_t)src[4];
 }
 
+// ---- halo merge (image-tile sharding): units stamped since the last merge, and the unpack ------------
+__global__ void k_tsdf_collect_dirty(HvTable table, const int32_t *__restrict__ stamp, int32_t merge_stamp, int32_t n_blocks,
+                                     int32_t *__restrict__ keys, int32_t cap) {
+    const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    bool dirty = false;
+    int32_t kx = 0, ky = 0, kz = 0;
+    if (idx < n_blocks) {
+        const unsigned long long key = table.block_keys[idx];
+        const int32_t slot = hv_table_find(table, key);
+        dirty = slot >= 0 && stamp[slot] > merge_stamp;
+        hv_unpack_key(key, kx, ky, kz);
+    }
+    const int32_t at = hv_wave_append(&table.counters[HV_CNT_OUT], dirty);
+    if (dirty && at < cap) {
+        keys[at * 3 + 0] = kx;
+        keys[at * 3 + 1] = ky;
+        keys[at * 3 + 2] = kz;
+    }
+}
+
+// action[u]: 0 = leave the unit alone (this GPU does not hold it), 1 = replace its state by the reduced numerators (this GPU
+// keeps the unit), 2 = zero it (another GPU keeps it; this one goes on fusing deltas into an empty unit)
+__global__ void k_tsdf_halo_unpack(HvTable table, char *__restrict__ pool, const int32_t *__restrict__ keys, int64_t k,
+                                   const float *__restrict__ payload, const uint8_t *__restrict__ action) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= k * RRR) return;
+    const int64_t ui = gid / RRR;
+    const int act = action[ui];
+    if (act == 0) return;
+    const int word = (int)(gid % RRR);
+    const int32_t kx = keys[ui * 3], ky = keys[ui * 3 + 1], kz = keys[ui * 3 + 2];
+    if (!hv_key_in_range(kx, ky, kz)) return;
+    const int32_t slot = hv_table_find(table, hv_pack_key(kx, ky, kz));
+    const int32_t idx = slot >= 0 ? table.vals[slot] : -1;
+    if (idx < 0) return;
+    char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
+    float tsdf = 0.f;
+    uint32_t w = 0u, r = 0u, g = 0u, b = 0u;
+    if (act == 1) {
+        const float *src = payload + gid * 5;
+        const float wf = src[1];
+        tsdf = wf > 0.f ? src[0] / wf : 0.f;
+        w = (uint32_t)wf;
+        r = (uint32_t)src[2];
+        g = (uint32_t)src[3];
+        b = (uint32_t)src[4];
+    }
+    ((float *)unit)[word] = tsdf;
+    ((uint32_t *)(unit + PLANE_BYTES))[word] = w;
+    ((uint32_t *)(unit + 2 * PLANE_BYTES))[word] = r;
+    ((uint32_t *)(unit + 3 * PLANE_BYTES))[word] = g;
+    ((uint32_t *)(unit + 4 * PLANE_BYTES))[word] = b;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1472,6 +1533,7 @@ static int tsdf_launch_integrate(hv_volume *v, const HvFrameParams &P, int parit
 }
 
 static void tsdf_next_frame(hv_volume *v, HvFrameParams &P, int &parity) {
+    v->content_version += 1;
     v->frame_counter += 1;
     P.frame_id = v->frame_counter;
     parity = v->frame_counter & 1;
@@ -1549,6 +1611,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         return HV_OK;
     }
     // multi-frame sweeps of up to 64 frames (one bit per frame in the per-unit mask)
+    v->content_version += 1;
     const int BMAX = 64;
     for (int f0 = 0; f0 < n_frames; f0 += BMAX) {
         const int B = std::min(BMAX, n_frames - f0);
@@ -1761,6 +1824,7 @@ int hv_tsdf_export_numerators(hv_volume *v, const int32_t *keys, int64_t k, floa
     const size_t bytes = sizeof(float) * 5 * RRR * (size_t)k;
     float *d_payload = payload;
     if (loc == HV_HOST) {
+        v->mesh_cache_version = v->points_cache_version = 0; // out_a is about to be overwritten
         rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, bytes);
         if (rc != HV_OK) return rc;
         d_payload = (float *)v->out_a;
@@ -1781,6 +1845,7 @@ int hv_tsdf_import_numerators(hv_volume *v, const int32_t *keys, int64_t k, cons
                "hv_tsdf_import_numerators: null argument");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_import_numerators: not a TSDF volume");
     if (k == 0) return HV_OK;
+    v->content_version += 1;
     HV_HIP(hipSetDevice(v->device));
     const void *d_keys = nullptr, *d_payload = nullptr;
     int rc = hv_stage_in(v, keys, sizeof(int32_t) * 3 * k, HV_HOST, 0, &d_keys);
@@ -1794,6 +1859,113 @@ int hv_tsdf_import_numerators(hv_volume *v, const int32_t *keys, int64_t k, cons
                        (char *)v->pool, (const int32_t *)d_keys, k, (const float *)d_payload);
     HV_HIP(hipGetLastError());
     HV_HIP(hipStreamSynchronize(v->stream));
+    return HV_OK;
+}
+
+// ---- halo merge entry points (SURVEY 8b hv_merge_halo, 8e): the library packs / unpacks on the device, the caller runs
+// the two collectives (all-gather of key lists, all-reduce of the dense buffer) with whatever transport it has -
+// torch.distributed over RCCL in pyslam_amd/distributed.py ----
+int hv_tsdf_dirty_keys(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n) {
+    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_tsdf_dirty_keys: null argument");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_dirty_keys: not a TSDF volume");
+    HV_HIP(hipSetDevice(v->device));
+    int64_t nb = 0;
+    int rc = hv_num_blocks(v, &nb);
+    if (rc != HV_OK) return rc;
+    *n = 0;
+    if (nb == 0) return HV_OK;
+    v->mesh_cache_version = v->points_cache_version = 0; // out_a is reused below
+    rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, sizeof(int32_t) * 3 * (size_t)nb);
+    if (rc != HV_OK) return rc;
+    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
+    hipLaunchKernelGGL(k_tsdf_collect_dirty, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, v->stream, v->table,
+                       (const int32_t *)v->touched_stamp, v->merge_stamp, (int32_t)nb, (int32_t *)v->out_a, (int32_t)nb);
+    HV_HIP(hipGetLastError());
+    rc = hv_read_counters(v);
+    if (rc != HV_OK) return rc;
+    const int64_t nd = v->h_counters[HV_CNT_OUT];
+    *n = nd;
+    if (keys == nullptr || nd == 0) return HV_OK;
+    std::vector<std::array<int32_t, 3>> out((size_t)nd);
+    HV_HIP(hipMemcpy(out.data(), v->out_a, sizeof(int32_t) * 3 * (size_t)nd, hipMemcpyDeviceToHost));
+    std::sort(out.begin(), out.end());
+    const int64_t m = std::min(nd, cap);
+    for (int64_t i = 0; i < m; ++i) memcpy(keys + i * 3, out[i].data(), 12);
+    return HV_OK;
+}
+
+int hv_tsdf_mark_merged(hv_volume *v) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_tsdf_mark_merged: null volume");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_mark_merged: not a TSDF volume");
+    v->merge_stamp = v->frame_counter;
+    return HV_OK;
+}
+
+int hv_merge_halo_plan(const int32_t *gathered_keys, const int64_t *counts, int32_t world_size, int32_t rank,
+                       int32_t *shared_keys, uint8_t *action, int64_t cap, int64_t *n_shared) {
+    HV_REQUIRE(counts != nullptr && n_shared != nullptr && world_size >= 1 && rank >= 0 && rank < world_size, HV_ERR_INVALID,
+               "hv_merge_halo_plan: bad argument");
+    // (key, rank) pairs of every rank's dirty list, sorted by key then rank; a key listed by >= 2 ranks is shared
+    struct Entry { std::array<int32_t, 3> key; int32_t rank; };
+    int64_t total = 0;
+    for (int r = 0; r < world_size; ++r) total += counts[r];
+    HV_REQUIRE(total == 0 || gathered_keys != nullptr, HV_ERR_INVALID, "hv_merge_halo_plan: null key list");
+    std::vector<Entry> all((size_t)total);
+    int64_t at = 0;
+    for (int r = 0; r < world_size; ++r)
+        for (int64_t i = 0; i < counts[r]; ++i, ++at) {
+            memcpy(all[at].key.data(), gathered_keys + at * 3, 12);
+            all[at].rank = r;
+        }
+    std::sort(all.begin(), all.end(), [](const Entry &a, const Entry &b) { return a.key != b.key ? a.key < b.key : a.rank < b.rank; });
+    int64_t ns = 0;
+    for (int64_t i = 0; i < total;) {
+        int64_t j = i;
+        bool mine = false;
+        while (j < total && all[j].key == all[i].key) {
+            mine |= all[j].rank == rank;
+            ++j;
+        }
+        if (j - i >= 2) { // listed by two ranks or more (a rank lists a key once)
+            if (shared_keys != nullptr && action != nullptr && ns < cap) {
+                memcpy(shared_keys + ns * 3, all[i].key.data(), 12);
+                action[ns] = !mine ? 0 : (all[i].rank == rank ? 1 : 2); // the lowest listing rank keeps the unit
+            }
+            ++ns;
+        }
+        i = j;
+    }
+    *n_shared = ns;
+    return HV_OK;
+}
+
+int hv_merge_halo_pack(hv_volume *v, const int32_t *shared_keys, int64_t k, float *payload, int32_t loc) {
+    return hv_tsdf_export_numerators(v, shared_keys, k, payload, loc);
+}
+
+int hv_merge_halo_unpack(hv_volume *v, const int32_t *shared_keys, int64_t k, const float *payload, const uint8_t *action,
+                         int32_t loc) {
+    HV_REQUIRE(v != nullptr && (k == 0 || (shared_keys != nullptr && payload != nullptr && action != nullptr)), HV_ERR_INVALID,
+               "hv_merge_halo_unpack: null argument");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_merge_halo_unpack: not a TSDF volume");
+    if (k == 0) return HV_OK;
+    v->content_version += 1;
+    HV_HIP(hipSetDevice(v->device));
+    // keys + actions in one staging buffer, payload in the other
+    std::vector<char> host((size_t)k * 13);
+    memcpy(host.data(), shared_keys, (size_t)k * 12);
+    memcpy(host.data() + (size_t)k * 12, action, (size_t)k);
+    const void *d_ka = nullptr, *d_payload = nullptr;
+    int rc = hv_stage_in(v, host.data(), host.size(), HV_HOST, 0, &d_ka);
+    if (rc != HV_OK) return rc;
+    rc = hv_stage_in(v, payload, sizeof(float) * 5 * RRR * (size_t)k, loc, 1, &d_payload);
+    if (rc != HV_OK) return rc;
+    const int64_t total = k * RRR;
+    hipLaunchKernelGGL(k_tsdf_halo_unpack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, v->table,
+                       (char *)v->pool, (const int32_t *)d_ka, k, (const float *)d_payload,
+                       (const uint8_t *)d_ka + (size_t)k * 12);
+    HV_HIP(hipGetLastError());
+    HV_HIP(hipStreamSynchronize(v->stream)); // `host` goes out of scope
     return HV_OK;
 }
 

@@ -11,17 +11,24 @@ it is free next to the ~0.5 GB of voxel traffic it causes).  Two ways to split t
     it on one rank when a mesh is wanted.
 
 ``sharding="tile"`` (north-star form) — rank r fuses only the voxels whose projection falls into its
-    vertical image tile (``hv_tsdf_set_tile``); all ranks allocate all touched units, units that
-    cannot project into a rank's tile are not swept.  Each rank then holds *partial* running means
-    which ``merge()`` turns into additive numerators {sum w*tsdf, w, sum r, sum g, sum b} and
-    sum-reduces to the root in ~64 MB buckets (ring collectives over xGMI are per-link bound,
-    ~153 GB/s: few, large messages); the root imports the merged state, the other ranks are cleared
-    and keep fusing deltas, so the next merge is again a plain sum.
+    vertical image tile (``hv_tsdf_set_tile``); a unit that cannot project into a rank's tile is neither
+    allocated nor swept there.  Units on tile borders (and revisits from other viewpoints) then hold
+    *partial* running means on several ranks.  ``merge_halo()`` (BASELINE north star: "RCCL
+    all-reduce of overlapping-block TSDF/weight") consolidates exactly those:
+      all-gather of the key lists of the units each rank stamped since its last merge (12 B/key) ->
+      ``hv_merge_halo_plan``: keys listed by >= 2 ranks, identical order everywhere ->
+      ``hv_merge_halo_pack``: additive numerators {sum w*tsdf, w, sum r, sum g, sum b} of THOSE units into one
+      dense buffer -> ``all_reduce(SUM)`` in ~64 MB buckets (ring collectives over xGMI are per-link bound,
+      ~153 GB/s: few, large messages) -> ``hv_merge_halo_unpack``: the lowest listing rank keeps the unit with the
+      reduced state, the others zero theirs and go on fusing deltas.
+    The message is shared units x 81 920 B, not the volume.  The sum over ranks of a unit's numerators stays the
+    single-GPU total at all times, so ``gather_to_root()`` (union of all keys, sum-reduce to one rank) yields the
+    complete volume whenever a mesh is wanted.
 
-Collectives used: an all-gather of unit keys (12 B/unit) and the bucketed sum-reduce — only inside
-merge()/gather_to_root(), never per frame.  The volume object is duck-typed (unit_keys /
-export_numerators / import_numerators / reset / set_tile / set_owner) so the collective logic is
-exercised on CPU with the gloo backend in tests/.
+Collectives used: all-gather of unit keys, all-reduce (merge_halo) / reduce (gather_to_root) of numerator
+buffers — only at merge points, never per frame.  The volume object is duck-typed (unit_keys / dirty_keys /
+export_numerators / import_numerators / halo_unpack / mark_merged / reset / set_tile / set_owner) so the
+collective logic is exercised on CPU with the gloo backend in tests/.
 """
 import numpy as np
 
@@ -120,6 +127,50 @@ class ShardedTSDF:
         return k
 
     gather_to_root = merge
+
+    def merge_halo(self):
+        """All-reduce of the units that two or more ranks updated since their last merge (see the module docstring).
+        Returns (shared units, units this rank listed as dirty).  ``last_halo`` keeps the keys / actions of the call
+        for inspection (tests assert that nothing but shared units travelled)."""
+        if not self.distributed:
+            return 0, 0
+        import ctypes
+
+        import torch
+        import torch.distributed as dist
+
+        from . import _lib as L
+
+        lib = L.load()
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+        mine = np.ascontiguousarray(self.volume.dirty_keys(), dtype=np.int32).reshape(-1, 3)
+        lists = self._gather_keys(mine, dist, torch, dev)
+        counts = np.array([len(x) for x in lists], dtype=np.int64)
+        gathered = np.ascontiguousarray(np.concatenate([x.reshape(-1, 3) for x in lists], axis=0), dtype=np.int32)
+        n = ctypes.c_int64()
+        L.check(lib.hv_merge_halo_plan(L.ptr(gathered), L.ptr(counts), self.world_size, self.rank, None, None, 0, ctypes.byref(n)))
+        k = n.value
+        shared = np.zeros((k, 3), np.int32)
+        action = np.zeros(k, np.uint8)
+        if k:
+            L.check(lib.hv_merge_halo_plan(L.ptr(gathered), L.ptr(counts), self.world_size, self.rank, L.ptr(shared), L.ptr(action), k,
+                                           ctypes.byref(n)))
+        self.last_halo = {"shared_keys": shared, "action": action, "dirty": len(mine), "payload_bytes": 0}
+        res3 = self.volume.res ** 3
+        units_per_bucket = max(1, self.BUCKET_BYTES // (res3 * 5 * 4))
+        for b0 in range(0, k, units_per_bucket):
+            sub, act = shared[b0 : b0 + units_per_bucket], action[b0 : b0 + units_per_bucket]
+            payload = torch.empty((sub.shape[0], res3, 5), dtype=torch.float32, device=dev)
+            self.volume.export_numerators(sub, out=payload if on_gpu else payload.numpy())  # == hv_merge_halo_pack
+            dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=self.group)
+            if on_gpu:
+                torch.cuda.current_stream().synchronize()  # RCCL result visible before the unpack kernel reads it
+            self.last_halo["payload_bytes"] += payload.numel() * 4
+            self.volume.halo_unpack(sub, payload if on_gpu else payload.numpy(), act)
+            del payload
+        self.volume.mark_merged()
+        return k, len(mine)
 
 
 class TileShardedTSDF(ShardedTSDF):

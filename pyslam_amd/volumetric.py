@@ -591,6 +591,24 @@ class ScalableTSDFVolume(_Volume):
             L.check(self._lib.hv_tsdf_unit_keys(self._h, L.ptr(keys), n.value, ctypes.byref(n)))
         return keys
 
+    def dirty_keys(self):
+        """Units this GPU stamped (i.e. may have updated) since the last mark_merged(), sorted [K,3] int32."""
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_tsdf_dirty_keys(self._h, None, 0, ctypes.byref(n)))
+        keys = np.zeros((n.value, 3), np.int32)
+        if n.value:
+            L.check(self._lib.hv_tsdf_dirty_keys(self._h, L.ptr(keys), n.value, ctypes.byref(n)))
+        return keys
+
+    def mark_merged(self):
+        L.check(self._lib.hv_tsdf_mark_merged(self._h))
+
+    def halo_unpack(self, keys, payload, action):
+        """hv_merge_halo_unpack: action[k] 0 = not held here, 1 = keep (state := payload), 2 = zero the unit."""
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        action = np.ascontiguousarray(action, dtype=np.uint8)
+        L.check(self._lib.hv_merge_halo_unpack(self._h, L.ptr(keys), keys.shape[0], L.ptr(payload), L.ptr(action), L.location(payload)))
+
     def export_numerators(self, keys, out=None):
         """keys [K,3] int32 -> payload [K, R^3, 5] float32 {sum tsdf*w, w, sum r, sum g, sum b}."""
         keys = np.ascontiguousarray(keys, dtype=np.int32)

@@ -22,7 +22,8 @@ class OracleBackedVolume:
         import oracle
 
         self.vol = oracle.PortTsdf(0.02, 0.08)
-        self.imported = {}
+        self.imported = {}   # key -> numerators that REPLACE the oracle's state of that unit (import / halo unpack)
+        self.dirty = set()
 
     def set_tile(self, *a):
         pass
@@ -32,9 +33,23 @@ class OracleBackedVolume:
 
     def integrate(self, depth, rgb, K, T):
         self.vol.integrate(depth, rgb, K, T, 1.0, 4.0)
+        self.dirty.update(tuple(k) for k in self.vol.touched_keys())
 
     def unit_keys(self):
         return self.vol.dump()[0]
+
+    def dirty_keys(self):
+        return np.array(sorted(self.dirty), dtype=np.int32).reshape(-1, 3)
+
+    def mark_merged(self):
+        self.dirty.clear()
+
+    def halo_unpack(self, keys, payload, action):
+        for j, key in enumerate(keys):
+            if action[j] == 1:
+                self.imported[tuple(key)] = np.array(payload[j])
+            elif action[j] == 2:
+                self.imported[tuple(key)] = np.zeros_like(payload[j])
 
     def export_numerators(self, keys, out=None):
         k, tsdf, w, col = self.vol.dump()
@@ -43,6 +58,9 @@ class OracleBackedVolume:
             out = np.zeros((len(keys), 4096, 5), np.float32)
         out[:] = 0
         for j, key in enumerate(keys):
+            if tuple(key) in self.imported:
+                out[j] = self.imported[tuple(key)]
+                continue
             i = idx.get(tuple(key))
             if i is not None:
                 out[j, :, 0] = tsdf[i] * w[i]
@@ -111,6 +129,95 @@ def test_two_rank_merge_equals_single_volume(tmp_path):
     ww = np.maximum(w, 1)
     assert np.abs(p[..., 0] / ww - tsdf).max() < 1e-5
     assert np.abs(p[..., 2:5] / ww[..., None] - col).max() < 1e-3  # 0..255 scale, float32 numerators
+
+
+def _halo_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from pyslam_amd.distributed import TileShardedTSDF
+    from pyslam_amd.synthetic import SyntheticRGBD
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    K = np.array(s.intrinsics)
+    backend = OracleBackedVolume()
+    fuser = TileShardedTSDF(0.02, 0.08, s.width, s.height, rank=rank, world_size=world, volume=backend)
+    fuser.BUCKET_BYTES = 1 << 20  # several buckets
+    # overlapping but different views: rank 0 fuses frames 0, 1, 40; rank 1 fuses frames 2, 3, 80
+    for i in (0, 1, 40) if rank == 0 else (2, 3, 80):
+        d, c, T = s[i]
+        backend.integrate(d, c, K, T)
+    mine = {tuple(k) for k in backend.dirty_keys()}
+    n_shared, n_dirty = fuser.merge_halo()
+    h = fuser.last_halo
+    np.savez(os.path.join(tmpdir, f"halo{rank}.npz"), mine=np.array(sorted(mine)), shared=h["shared_keys"], action=h["action"],
+             payload_bytes=h["payload_bytes"], n_shared=n_shared, n_dirty=n_dirty, dirty_after=len(backend.dirty_keys()))
+    # the volume is still complete as the sum over ranks: gather and save on the root
+    n = fuser.gather_to_root(root=0)
+    if rank == 0:
+        keys = np.array(sorted(backend.imported))
+        np.savez(os.path.join(tmpdir, "gathered.npz"), keys=keys, payload=np.stack([backend.imported[tuple(k)] for k in keys]), n=n)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_halo_merge_reduces_only_shared_units(tmp_path):
+    """merge_halo over gloo: the plan's shared set is exactly the intersection of the two ranks' dirty lists, only those
+    units travel (payload bytes = shared x 81 920), the lowest rank keeps a shared unit and the other zeroes it, and the
+    gathered volume afterwards equals fusing all six frames in one volume."""
+    import torch.multiprocessing as mp
+
+    import oracle
+    from pyslam_amd.synthetic import SyntheticRGBD
+
+    port = 29500 + ((os.getpid() + 777) % 2000)
+    mp.spawn(_halo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    h0, h1 = np.load(tmp_path / "halo0.npz"), np.load(tmp_path / "halo1.npz")
+    a, b = {tuple(k) for k in h0["mine"]}, {tuple(k) for k in h1["mine"]}
+    inter = sorted(a & b)
+    assert 0 < len(inter) < min(len(a), len(b))  # a genuine halo: some, not all
+    for h in (h0, h1):
+        assert [tuple(k) for k in h["shared"]] == inter          # same plan on both ranks, sorted
+        assert int(h["payload_bytes"]) == len(inter) * 4096 * 5 * 4  # nothing but shared units was reduced
+        assert int(h["n_shared"]) == len(inter) and int(h["dirty_after"]) == 0
+    assert (h0["action"] == 1).all() and (h1["action"] == 2).all()  # lowest listing rank keeps, the other zeroes
+    z = np.load(tmp_path / "gathered.npz")
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    K = np.array(s.intrinsics)
+    full = oracle.PortTsdf(0.02, 0.08)
+    for i in (0, 1, 40, 2, 3, 80):
+        d, c, T = s[i]
+        full.integrate(d, c, K, T, 1.0, 4.0)
+    k, tsdf, w, col = full.dump()
+    np.testing.assert_array_equal(z["keys"], k)
+    p = z["payload"]
+    np.testing.assert_array_equal(p[..., 1], w)
+    ww = np.maximum(w, 1)
+    assert np.abs(p[..., 0] / ww - tsdf).max() < 1e-4
+    assert np.abs(p[..., 2:5] / ww[..., None] - col).max() < 1e-2  # 0..255 scale, float32 numerators
+
+
+def test_merge_halo_plan_three_ranks():
+    """hv_merge_halo_plan (host-only C): keys listed by >= 2 ranks, sorted; the lowest listing rank keeps."""
+    import ctypes
+
+    from pyslam_amd import _lib as L
+
+    lib = L.load()
+    lists = [np.array([[0, 0, 0], [1, 0, 0], [5, 5, 5]], np.int32), np.array([[1, 0, 0], [2, 2, 2], [-3, 0, 1]], np.int32),
+             np.array([[-3, 0, 1], [1, 0, 0], [9, 9, 9]], np.int32)]
+    counts = np.array([len(x) for x in lists], np.int64)
+    gathered = np.ascontiguousarray(np.concatenate(lists))
+    want = {0: [0, 1], 1: [1, 2], 2: [2, 2]}  # shared (sorted): [-3,0,1] by ranks 1,2; [1,0,0] by ranks 0,1,2
+    for rank in range(3):
+        n = ctypes.c_int64()
+        shared, action = np.zeros((4, 3), np.int32), np.zeros(4, np.uint8)
+        L.check(lib.hv_merge_halo_plan(L.ptr(gathered), L.ptr(counts), 3, rank, L.ptr(shared), L.ptr(action), 4, ctypes.byref(n)))
+        assert n.value == 2 and shared[:2].tolist() == [[-3, 0, 1], [1, 0, 0]]
+        assert action[:2].tolist() == want[rank]
 
 
 def test_tile_bounds_partition_the_image():
