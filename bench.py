@@ -19,7 +19,7 @@ fused and stored by GPU hash(unit index) % N (SURVEY §8e "zero reduce" form: bi
 collective while fusing); --sharding tile: north-star image tiles + RCCL merge of the shared units (timed).
 
 Objects on the JSON line (N = 1):
-  roofline      the dominant kernel of the timed region, the multi-frame sweep k_tsdf_integrate_batch_col.  It keeps a
+  roofline      the dominant kernel of the timed region, the multi-frame sweep k_tsdf_sweep.  It keeps a
                 unit's voxels in registers across the batch's frames, so it is bound by VALU issue, not by HBM:
                 ``bound: "valu"``, achieved = VALU wave-instructions per launch (SQ_INSTS_VALU from the rocprofv3 --pmc
                 pass recorded under profiles/, parsed at run time and only used when it was taken on THIS build and
@@ -420,7 +420,7 @@ def main():
             avg_s = t_cov / n_cov
             alg = sum(st["union_units"] * UNIT_BYTES + st["union_voxels"] * BYTES_PER_VOXEL for st in cpu["steps"][:n_cov]) / world
             visits = sum(sum(st["touched"]) for st in cpu["steps"][:n_cov]) * 4096 / world
-            pk = pmc_kernel(pmc, "k_tsdf_integrate_batch_col", command_key) if world == 1 else None
+            pk = pmc_kernel(pmc, "k_tsdf_sweep", command_key) if world == 1 else None
             traffic = hbm_traffic(pk)
             hbm = {"algorithmic_bytes_per_launch": int(alg / n_cov), "achieved": round(alg / t_cov / 1e9, 1), "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": round(alg / t_cov / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -429,7 +429,7 @@ def main():
             if traffic:
                 hbm["traffic_GBs"] = round(traffic / avg_s / 1e9, 1)
                 hbm["traffic_over_algorithmic"] = round(traffic / (alg / n_cov), 3)
-            roofline = {"bound": "valu", "kernel": "k_tsdf_integrate_batch_col", "achieved": None, "peak": VALU_PEAK_GINSTR,
+            roofline = {"bound": "valu", "kernel": "k_tsdf_sweep", "achieved": None, "peak": VALU_PEAK_GINSTR,
                         "unit": "G wave-instr/s", "frac": None, "traffic": traffic,
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(n_cov), "frames_per_launch": B,
                         "voxel_visits_per_launch": int(visits / n_cov), "hbm": hbm}

@@ -213,6 +213,28 @@ struct HvFrameParams { // per-frame constants of the TSDF kernels (passed by val
 };
 
 // ------------------------------------------------------------------------------------------------
+// Pool occupancy as the last finished integrate call left it, in pinned host memory the device writes directly (no
+// read-back, no synchronisation): the last kernel of every call that can allocate blocks publishes {blocks, overflow, seq}.
+// hv_capacity_gate() reads it before the next call launches anything: grow in time, or fail BEFORE fusing on.
+// ------------------------------------------------------------------------------------------------
+struct HvStatus {
+    int32_t blocks;
+    int32_t overflow;
+    int32_t seq;
+    int32_t pad;
+};
+
+#ifdef __HIPCC__
+__device__ inline void hv_publish_status(const HvTable &t, HvStatus *status, int32_t seq) {
+    volatile HvStatus *s = status;
+    s->blocks = t.counters[HV_CNT_BLOCKS];
+    s->overflow = t.counters[HV_CNT_OVERFLOW];
+    __threadfence_system();
+    s->seq = seq;
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // host-side volume object
 // ------------------------------------------------------------------------------------------------
 struct HvEventPair {
@@ -231,6 +253,12 @@ struct hv_volume {
     void *pool = nullptr; // max_blocks * bytes_per_block, zero-initialised
     int64_t bytes_per_block = 0;
     int32_t *h_counters = nullptr; // pinned mirror [HV_CNT_COUNT]
+    HvStatus *h_status = nullptr;  // pinned + device-visible: written by the last kernel of each allocating call
+    HvStatus *d_status = nullptr;  // the same memory as the device addresses it
+    int32_t status_seq_issued = 0, status_seq_seen = 0;
+    int64_t known_blocks = 0;      // blocks in use as of status_seq_seen
+    int64_t max_new_per_call = 0;  // largest growth of `blocks` seen between two published states
+    bool status_exact = false;     // known_blocks was read with the stream idle (after creation / reset / growth: true until the next launch)
 
     // TSDF per-frame state
     int32_t *touched_stamp = nullptr; // [table_capacity] last frame id that touched the slot
@@ -296,6 +324,17 @@ struct hv_volume {
 };
 
 int hv_ensure_buffer(hv_volume *v, void **buf, size_t *cur, size_t want);
+// Before an integrate call launches anything.  HV_ERR_CAPACITY if an earlier call ran out of pool (nothing more is fused
+// until hv_reserve_blocks / hv_reset); grows the pool when more than half of it is known to be in use; *checked = the
+// caller must verify its claim pass synchronously (hv_claims_fit) because the headroom is not known to cover this call.
+int hv_capacity_gate(hv_volume *v, bool *checked);
+// After the kernel that claims blocks, in checked mode: synchronise, and if some claims did not fit, grow the pool (the table
+// is rebuilt without the failed keys) and return HV_RETRY_CLAIM so that the caller relaunches its claim pass - nothing was
+// written to voxels yet, so nothing is lost.  HV_ERR_CAPACITY if the pool cannot grow.
+int hv_claims_fit(hv_volume *v);
+static constexpr int HV_RETRY_CLAIM = 1000;
+int32_t hv_next_status_seq(hv_volume *v); // sequence number for the call's publishing kernel
+void hv_launch_publish_status(hv_volume *v); // modes whose last kernel does not publish by itself
 int hv_read_counters(hv_volume *v); // D2H of the counter block (synchronises the stream)
 int hv_stage_in(hv_volume *v, const void *src, size_t bytes, int32_t loc, int which, const void **dev);
 void hv_profile_begin(hv_volume *v);

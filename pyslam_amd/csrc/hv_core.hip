@@ -100,6 +100,89 @@ void hv_profile_end(hv_volume *v, int64_t units) {
     v->prof_units += units;
 }
 
+__global__ void k_publish_status(HvTable table, HvStatus *status, int32_t seq) { hv_publish_status(table, status, seq); }
+
+int32_t hv_next_status_seq(hv_volume *v) {
+    v->status_exact = false;
+    return ++v->status_seq_issued;
+}
+
+void hv_launch_publish_status(hv_volume *v) {
+    hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(1), 0, v->stream, v->table, v->d_status, hv_next_status_seq(v));
+}
+
+static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep);
+static uint64_t next_pow2(uint64_t x);
+
+static bool hv_auto_grow() { return !(getenv("HV_AUTO_GROW") && atoi(getenv("HV_AUTO_GROW")) == 0); }
+
+// Double the pool while it fits (60 % of the free HBM, 32-bit sort keys of the grid modes).
+static int hv_grow(hv_volume *v, int64_t at_least) {
+    int64_t want = v->cfg.max_blocks;
+    while (want < at_least) want *= 2;
+    if (want == v->cfg.max_blocks) want *= 2;
+    size_t free_b = 0, total_b = 0;
+    uint64_t cap = 1;
+    while (cap < (uint64_t)want * 4) cap <<= 1;
+    const bool fits_keys = v->cfg.mode == HV_MODE_TSDF || (cap << v->local_bits) < (1ull << 32);
+    if (!hv_auto_grow() || !fits_keys || want >= (1ll << 30) || hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+        (double)want * (double)v->bytes_per_block >= 0.6 * (double)free_b)
+        return HV_ERR_CAPACITY;
+    return hv_reserve_blocks(v, want);
+}
+
+int hv_capacity_gate(hv_volume *v, bool *checked) {
+    // consume the newest published state (seq is written last, behind a system-scope fence)
+    const volatile HvStatus *st = v->h_status;
+    const int32_t seq = st->seq;
+    int64_t overflow = 0;
+    if (seq != v->status_seq_seen && seq > 0) {
+        const int64_t blocks = st->blocks;
+        overflow = st->overflow;
+        if (st->seq == seq) { // not torn by a newer publication (then the next call sees it)
+            v->max_new_per_call = std::max<int64_t>(v->max_new_per_call, blocks - v->known_blocks);
+            v->known_blocks = std::max<int64_t>(v->known_blocks, std::min<int64_t>(blocks, v->cfg.max_blocks));
+            v->status_seq_seen = seq;
+        }
+    }
+    HV_REQUIRE(overflow == 0, HV_ERR_CAPACITY,
+               "block pool exhausted during an earlier integrate call (max_blocks=%lld): units that did not fit were not fused; "
+               "nothing more is fused until hv_reserve_blocks or hv_reset",
+               (long long)v->cfg.max_blocks);
+    if (v->known_blocks * 2 > v->cfg.max_blocks) (void)hv_grow(v, v->cfg.max_blocks * 2); // may fail: the checked mode below covers it
+    // calls issued but not yet reported may each add up to the largest growth seen so far
+    const int64_t in_flight = v->status_seq_issued - v->status_seq_seen;
+    const int64_t headroom = v->cfg.max_blocks - v->known_blocks - in_flight * v->max_new_per_call;
+    // max_new_per_call == 0: nothing is known yet about what a call allocates (first call after creation / reset)
+    *checked = v->max_new_per_call == 0 || headroom < std::max<int64_t>(1024, 4 * v->max_new_per_call);
+    return HV_OK;
+}
+
+int hv_claims_fit(hv_volume *v) {
+    int rc = hv_read_counters(v); // synchronises the stream
+    if (rc != HV_OK) return rc;
+    const int64_t blocks = v->h_counters[HV_CNT_BLOCKS];
+    if (v->h_counters[HV_CNT_OVERFLOW] == 0) {
+        v->max_new_per_call = std::max<int64_t>(v->max_new_per_call, blocks - v->known_blocks);
+        v->known_blocks = blocks;
+        return HV_OK;
+    }
+    // some claims did not fit: the pool index counter ran past max_blocks (the excess = the blocks that are missing)
+    rc = hv_grow(v, blocks + blocks / 4);
+    if (rc != HV_OK) {
+        // roll the claim pass back: the blocks it did get are released again (nothing was written to them), the failed keys
+        // leave the table - the volume is exactly what it was before the call
+        const int64_t before = v->h_status->seq == v->status_seq_issued && v->status_seq_issued > 0 ? v->h_status->blocks : v->known_blocks;
+        const int64_t max_blocks = v->cfg.max_blocks;
+        (void)hv_rebuild(v, max_blocks, before);
+        hv_set_error("block pool exhausted: %lld blocks needed, max_blocks=%lld and the pool cannot grow (HV_AUTO_GROW=0, no free HBM, "
+                     "or the 32-bit sort keys of the grid modes); the frame was NOT fused, the volume is unchanged",
+                     (long long)blocks, (long long)max_blocks);
+        return HV_ERR_CAPACITY;
+    }
+    return HV_RETRY_CLAIM;
+}
+
 static uint64_t next_pow2(uint64_t x) {
     uint64_t p = 1;
     while (p < x) p <<= 1;
@@ -211,6 +294,9 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
     HV_TRY(hipMalloc(&v->table.counters, sizeof(int32_t) * HV_CNT_COUNT));
     HV_TRY(hipHostMalloc((void **)&v->h_counters, sizeof(int32_t) * HV_CNT_COUNT));
     memset(v->h_counters, 0, sizeof(int32_t) * HV_CNT_COUNT);
+    HV_TRY(hipHostMalloc((void **)&v->h_status, sizeof(HvStatus), hipHostMallocMapped));
+    memset(v->h_status, 0, sizeof(HvStatus));
+    HV_TRY(hipHostGetDevicePointer((void **)&v->d_status, v->h_status, 0));
     HV_TRY(hipMalloc(&v->pool, (size_t)cfg->max_blocks * v->bytes_per_block));
 
     if (cfg->mode == HV_MODE_TSDF) {
@@ -249,6 +335,7 @@ void hv_destroy(hv_volume *v) {
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (v->h_counters) (void)hipHostFree(v->h_counters);
+    if (v->h_status) (void)hipHostFree(v->h_status);
     hv_segments_cache_free(v->segments_cache);
     for (int i = 0; i < 4; ++i) {
         if (v->pinned_params[i]) (void)hipHostFree(v->pinned_params[i]);
@@ -283,6 +370,13 @@ int hv_reset(hv_volume *v) {
     v->content_version += 1;
     v->frame_counter = 0;
     v->merge_stamp = 0;
+    // pool occupancy: known exactly again (the stream is drained first so that no kernel publishes a stale state later)
+    HV_HIP(hipStreamSynchronize(v->stream));
+    memset(v->h_status, 0, sizeof(HvStatus));
+    v->status_seq_issued = v->status_seq_seen = 0;
+    v->known_blocks = 0;
+    v->max_new_per_call = 0;
+    v->status_exact = true;
     v->last_touch_parity = 0;
     v->touch_counters_clean = true;
     return HV_OK;
@@ -320,11 +414,27 @@ __global__ void k_rehash(HvTable t, const unsigned long long *__restrict__ block
     }
 }
 
+// Carry the per-slot "last touched" stamps of the TSDF mode over to a rebuilt table (slots move; pool indices do not).
+__global__ void k_restamp(HvTable old_t, HvTable new_t, const int32_t *__restrict__ old_stamp, int32_t *__restrict__ new_stamp, int32_t n) {
+    const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const unsigned long long key = new_t.block_keys[idx];
+    const int32_t so = hv_table_find(old_t, key), sn = hv_table_find(new_t, key);
+    if (so >= 0 && sn >= 0) new_stamp[sn] = old_stamp[so];
+}
+
 // Grow the block pool and the hash to `new_max_blocks` (>= the current capacity), keeping every block: the pool is
 // copied (block indices persist), the table is rebuilt at 4x the new capacity.  Synchronises the stream.
+// Rebuild pool + table at `new_max_blocks` keeping the first `keep` blocks (-1: all that have a pool slot).
+static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep);
+
 int hv_reserve_blocks(hv_volume *v, int64_t new_max_blocks) {
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_reserve_blocks: null volume");
     if (new_max_blocks <= v->cfg.max_blocks) return HV_OK;
+    return hv_rebuild(v, new_max_blocks, -1);
+}
+
+static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
     HV_REQUIRE(new_max_blocks < (1ll << 30), HV_ERR_INVALID, "hv_reserve_blocks: max_blocks out of range");
     const uint64_t new_cap = next_pow2((uint64_t)new_max_blocks * 4);
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF || (new_cap << v->local_bits) < (1ull << 32), HV_ERR_CAPACITY,
@@ -333,7 +443,8 @@ int hv_reserve_blocks(hv_volume *v, int64_t new_max_blocks) {
     HV_HIP(hipStreamSynchronize(v->stream));
     int rc = hv_read_counters(v);
     if (rc != HV_OK) return rc;
-    const int64_t used = std::min<int64_t>(v->h_counters[HV_CNT_BLOCKS], v->cfg.max_blocks);
+    int64_t used = std::min<int64_t>(v->h_counters[HV_CNT_BLOCKS], v->cfg.max_blocks);
+    if (keep >= 0) used = std::min(used, keep);
     size_t free_b = 0, total_b = 0;
     HV_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t need = (size_t)new_max_blocks * v->bytes_per_block + new_cap * 24 + (size_t)new_max_blocks * 16;
@@ -341,44 +452,72 @@ int hv_reserve_blocks(hv_volume *v, int64_t new_max_blocks) {
                free_b / 1073741824.0);
     void *pool = nullptr;
     unsigned long long *keys = nullptr, *block_keys = nullptr;
-    int32_t *vals = nullptr;
-    HV_HIP(hipMalloc(&pool, (size_t)new_max_blocks * v->bytes_per_block));
-    HV_HIP(hipMalloc((void **)&keys, sizeof(uint64_t) * new_cap));
-    HV_HIP(hipMalloc((void **)&vals, sizeof(int32_t) * new_cap));
-    HV_HIP(hipMalloc((void **)&block_keys, sizeof(uint64_t) * new_max_blocks));
-    HV_HIP(hipMemcpyAsync(pool, v->pool, (size_t)used * v->bytes_per_block, hipMemcpyDeviceToDevice, v->stream));
-    HV_HIP(hipMemsetAsync((char *)pool + (size_t)used * v->bytes_per_block, 0, (size_t)(new_max_blocks - used) * v->bytes_per_block,
-                          v->stream));
-    HV_HIP(hipMemcpyAsync(block_keys, v->table.block_keys, sizeof(uint64_t) * used, hipMemcpyDeviceToDevice, v->stream));
-    HV_HIP(hipMemsetAsync(keys, 0xFF, sizeof(uint64_t) * new_cap, v->stream));
-    HV_HIP(hipMemsetAsync(vals, 0xFF, sizeof(int32_t) * new_cap, v->stream));
+    int32_t *vals = nullptr, *stamp = nullptr, *list = nullptr;
+    uint64_t *mask = nullptr;
+    // every allocation is released again if a later step fails (HV_HIP returns from the middle)
+    auto release = [&]() {
+        for (void *p : {pool, (void *)keys, (void *)vals, (void *)block_keys, (void *)stamp, (void *)list, (void *)mask})
+            if (p) (void)hipFree(p);
+    };
+#define HV_TRY_GROW(call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            hv_set_error("hv_reserve_blocks: %s failed: %s", #call, hipGetErrorString(e_));        \
+            release();                                                                             \
+            return HV_ERR_DEVICE;                                                                  \
+        }                                                                                          \
+    } while (0)
+    HV_TRY_GROW(hipMalloc(&pool, (size_t)new_max_blocks * v->bytes_per_block));
+    HV_TRY_GROW(hipMalloc((void **)&keys, sizeof(uint64_t) * new_cap));
+    HV_TRY_GROW(hipMalloc((void **)&vals, sizeof(int32_t) * new_cap));
+    HV_TRY_GROW(hipMalloc((void **)&block_keys, sizeof(uint64_t) * new_max_blocks));
+    HV_TRY_GROW(hipMemcpyAsync(pool, v->pool, (size_t)used * v->bytes_per_block, hipMemcpyDeviceToDevice, v->stream));
+    HV_TRY_GROW(hipMemsetAsync((char *)pool + (size_t)used * v->bytes_per_block, 0, (size_t)(new_max_blocks - used) * v->bytes_per_block,
+                               v->stream));
+    HV_TRY_GROW(hipMemcpyAsync(block_keys, v->table.block_keys, sizeof(uint64_t) * used, hipMemcpyDeviceToDevice, v->stream));
+    HV_TRY_GROW(hipMemsetAsync(keys, 0xFF, sizeof(uint64_t) * new_cap, v->stream));
+    HV_TRY_GROW(hipMemsetAsync(vals, 0xFF, sizeof(int32_t) * new_cap, v->stream));
     HvTable nt = v->table;
     nt.keys = keys;
     nt.vals = vals;
     nt.block_keys = block_keys;
     nt.mask = (uint32_t)(new_cap - 1);
     nt.max_blocks = (int32_t)new_max_blocks;
+    // the table is rebuilt from the keys of the blocks that HAVE a pool slot: keys whose claim overflowed the old pool
+    // (vals = -1) disappear, so a caller that saw the overflow can simply claim again
     if (used > 0) hipLaunchKernelGGL(k_rehash, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, v->stream, nt, block_keys, (int32_t)used);
-    HV_HIP(hipGetLastError());
+    HV_TRY_GROW(hipGetLastError());
     if (v->cfg.mode == HV_MODE_TSDF) { // per-slot frame stamps / masks and the touched list follow the table
-        int32_t *stamp = nullptr, *list = nullptr;
-        uint64_t *mask = nullptr;
-        HV_HIP(hipMalloc((void **)&stamp, sizeof(int32_t) * new_cap));
-        HV_HIP(hipMalloc((void **)&list, sizeof(int32_t) * new_max_blocks));
-        HV_HIP(hipMalloc((void **)&mask, sizeof(uint64_t) * new_cap));
-        HV_HIP(hipMemsetAsync(stamp, 0, sizeof(int32_t) * new_cap, v->stream));
-        HV_HIP(hipMemsetAsync(mask, 0, sizeof(uint64_t) * new_cap, v->stream));
-        HV_HIP(hipStreamSynchronize(v->stream));
+        HV_TRY_GROW(hipMalloc((void **)&stamp, sizeof(int32_t) * new_cap));
+        HV_TRY_GROW(hipMalloc((void **)&list, sizeof(int32_t) * new_max_blocks));
+        HV_TRY_GROW(hipMalloc((void **)&mask, sizeof(uint64_t) * new_cap));
+        HV_TRY_GROW(hipMemsetAsync(stamp, 0, sizeof(int32_t) * new_cap, v->stream));
+        HV_TRY_GROW(hipMemsetAsync(mask, 0, sizeof(uint64_t) * new_cap, v->stream));
+        // stamps carry "touched since the last merge": re-stamp the surviving blocks' slots in the new table
+        if (used > 0 && v->touched_stamp != nullptr)
+            hipLaunchKernelGGL(k_restamp, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, v->stream, v->table, nt,
+                               (const int32_t *)v->touched_stamp, stamp, (int32_t)used);
+        HV_TRY_GROW(hipGetLastError());
+    }
+    // the block counter may have run past the old capacity and the overflow counter is set: both describe claims that
+    // no longer exist
+    const int32_t fixed[2] = {(int32_t)used, 0};
+    HV_TRY_GROW(hipMemcpyAsync(&v->table.counters[HV_CNT_BLOCKS], fixed, sizeof(fixed), hipMemcpyHostToDevice, v->stream));
+    if (v->cfg.mode == HV_MODE_TSDF) {
+        HV_TRY_GROW(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream)); // lists are void now
+        v->touch_counters_clean = true;
+    }
+    HV_TRY_GROW(hipStreamSynchronize(v->stream));
+#undef HV_TRY_GROW
+    if (v->cfg.mode == HV_MODE_TSDF) {
         (void)hipFree(v->touched_stamp);
         (void)hipFree(v->touched_list);
         (void)hipFree(v->touched_mask);
         v->touched_stamp = stamp;
         v->touched_list = list;
         v->touched_mask = mask;
-        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream)); // lists are void now
-        v->touch_counters_clean = true;
     }
-    HV_HIP(hipStreamSynchronize(v->stream));
     (void)hipFree(v->pool);
     (void)hipFree(v->table.keys);
     (void)hipFree(v->table.vals);
@@ -387,6 +526,15 @@ int hv_reserve_blocks(hv_volume *v, int64_t new_max_blocks) {
     v->table = nt;
     v->table_capacity = new_cap;
     v->cfg.max_blocks = new_max_blocks;
+    // occupancy is exact again; states published by kernels that ran before the rebuild are stale
+    v->h_counters[HV_CNT_BLOCKS] = (int32_t)used;
+    v->h_counters[HV_CNT_OVERFLOW] = 0;
+    v->h_status->blocks = (int32_t)used;
+    v->h_status->overflow = 0;
+    v->h_status->seq = v->status_seq_issued;
+    v->status_seq_seen = v->status_seq_issued;
+    v->known_blocks = used;
+    v->status_exact = true;
     return HV_OK;
 }
 
@@ -404,17 +552,10 @@ int hv_num_blocks(hv_volume *v, int64_t *n) {
                "block pool exhausted: max_blocks=%lld; recreate the volume with a larger pool (or call hv_reserve_blocks "
                "earlier: blocks that did not fit were dropped)",
                (long long)v->cfg.max_blocks);
-    static const bool auto_grow = !(getenv("HV_AUTO_GROW") && atoi(getenv("HV_AUTO_GROW")) == 0);
-    if (auto_grow && nb * 2 > v->cfg.max_blocks) {
-        const int64_t want = v->cfg.max_blocks * 2;
-        size_t free_b = 0, total_b = 0;
-        const bool fits_keys = v->cfg.mode == HV_MODE_TSDF || (next_pow2((uint64_t)want * 4) << v->local_bits) < (1ull << 32);
-        if (fits_keys && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-            (double)want * (double)v->bytes_per_block < 0.6 * (double)free_b) {
-            rc = hv_reserve_blocks(v, want);
-            if (rc != HV_OK) return rc;
-        }
-    }
+    v->known_blocks = nb; // the stream is idle: exact
+    v->status_seq_seen = v->status_seq_issued;
+    v->status_exact = true;
+    if (nb * 2 > v->cfg.max_blocks) (void)hv_grow(v, v->cfg.max_blocks * 2); // best effort; the integrate calls check again
     return HV_OK;
 }
 

@@ -214,13 +214,26 @@ static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d
                          const uint32_t *valid_mask_keys = nullptr) {
     const HvSemParams G = sem_params(v);
     const unsigned blocks = (unsigned)((n + 255) / 256);
+    bool checked = false;
+    int rc = hv_capacity_gate(v, &checked); // may grow the pool: the sort-key width follows the table
+    if (rc != HV_OK) return rc;
     size_t bytes = 0;
     HV_HIP(rocprim::radix_sort_pairs(nullptr, bytes, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in, v->sort_vals_out,
                                      (size_t)n, 0, sem_sort_bits(v), v->stream));
-    int rc = hv_ensure_buffer(v, &v->sort_tmp, &v->sort_tmp_bytes, bytes);
+    rc = hv_ensure_buffer(v, &v->sort_tmp, &v->sort_tmp_bytes, bytes);
     if (rc != HV_OK) return rc;
-    hipLaunchKernelGGL(k_sem_keys<PT>, dim3(blocks), dim3(256), 0, v->stream, v->table, d_pts, n, G, v->sort_keys_in,
-                       v->sort_vals_in, valid_mask_keys);
+    for (int attempt = 0;; ++attempt) {
+        hipLaunchKernelGGL(k_sem_keys<PT>, dim3(blocks), dim3(256), 0, v->stream, v->table, d_pts, n, G, v->sort_keys_in,
+                           v->sort_vals_in, valid_mask_keys);
+        if (!checked) break;
+        rc = hv_claims_fit(v); // blocks that did not fit: grow, claim again (sort keys embed table slots)
+        if (rc == HV_OK) break;
+        if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
+        HV_HIP(rocprim::radix_sort_pairs(nullptr, bytes, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in, v->sort_vals_out,
+                                         (size_t)n, 0, sem_sort_bits(v), v->stream));
+        rc = hv_ensure_buffer(v, &v->sort_tmp, &v->sort_tmp_bytes, bytes);
+        if (rc != HV_OK) return rc;
+    }
     bytes = v->sort_tmp_bytes;
     HV_HIP(rocprim::radix_sort_pairs(v->sort_tmp, bytes, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                                      v->sort_vals_out, (size_t)n, 0, sem_sort_bits(v), v->stream));
@@ -235,6 +248,7 @@ static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d
         hipLaunchKernelGGL((k_sem_reduce<VOX, PT, HV_COLOR_NONE>), dim3(blocks), dim3(256), 0, v->stream, v->table, pool,
                            v->sort_keys_out, v->sort_vals_out, n, G, d_pts, d_cols, d_cls, d_inst, d_depths);
     }
+    hv_launch_publish_status(v); // pool occupancy for the next call's hv_capacity_gate
     HV_HIP(hipGetLastError());
     v->frame_counter += 1;
     return HV_OK;

@@ -625,11 +625,15 @@ template <int VARIANT>
 __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int32_t *__restrict__ list,
                                                          int parity, char *__restrict__ pool,
                                                          const uint2 *__restrict__ frame_px, HvFrameParams P,
-                                                         const float *__restrict__ mult) {
+                                                         const float *__restrict__ mult, HvStatus *status, int32_t status_seq) {
     int n_touched = table.counters[HV_CNT_TOUCH0 + parity];
     if (n_touched > table.max_blocks) n_touched = table.max_blocks;
-    // the next frame's touch pass appends to the other parity's counter: zero it here (stream order)
-    if (blockIdx.x == 0 && threadIdx.x == 0) table.counters[HV_CNT_TOUCH0 + (parity ^ 1)] = 0;
+    // the next frame's touch pass appends to the other parity's counter: zero it here (stream order); the pool occupancy
+    // this frame's touch pass left goes to the host-visible status word (hv_capacity_gate reads it before the next call)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        table.counters[HV_CNT_TOUCH0 + (parity ^ 1)] = 0;
+        hv_publish_status(table, status, status_seq);
+    }
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int x = lane >> 2;
@@ -1274,7 +1278,8 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
 // After the sweep (one workgroup): clear the frame masks of the batch's units and zero both touched-list counters, so
 // that the next batch / online frame starts clean without a memset launch per counter.
 __global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const int32_t *__restrict__ list,
-                                                             unsigned long long *__restrict__ frame_mask, int parity) {
+                                                             unsigned long long *__restrict__ frame_mask, int parity,
+                                                             HvStatus *status, int32_t status_seq) {
     int n_units = table.counters[HV_CNT_TOUCH0 + parity];
     if (n_units > table.max_blocks) n_units = table.max_blocks;
     __syncthreads(); // every thread holds n_units before the counters are reset
@@ -1294,6 +1299,7 @@ __global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const
     if (threadIdx.x == 0) {
         table.counters[HV_CNT_TOUCH0] = 0;
         table.counters[HV_CNT_TOUCH1] = 0;
+        hv_publish_status(table, status, status_seq); // pool occupancy after this batch, for hv_capacity_gate
     }
 }
 
@@ -1518,7 +1524,8 @@ static int tsdf_launch_integrate(hv_volume *v, const HvFrameParams &P, int parit
     char *pool = (char *)v->pool;
     hv_profile_begin(v);
     const float *mult = v->mult_table;
-#define HV_LAUNCH_ONLINE(V) hipLaunchKernelGGL(k_tsdf_integrate<V>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P, mult)
+    const int32_t seq = hv_next_status_seq(v);
+#define HV_LAUNCH_ONLINE(V) hipLaunchKernelGGL(k_tsdf_integrate<V>, grid, block, 0, v->stream, v->table, list, parity, pool, px, P, mult, v->d_status, seq)
     switch (v->debug_variant) {
     case 1: HV_LAUNCH_ONLINE(1); break;
     case 2: HV_LAUNCH_ONLINE(2); break;
@@ -1541,16 +1548,29 @@ static void tsdf_next_frame(hv_volume *v, HvFrameParams &P, int &parity) {
     v->touch_counters_clean = false; // this parity's counter keeps the frame's touched count until the next frame's sweep
 }
 
-// Online path: both halves back to back on the volume's stream.
+// Online path: both halves back to back on the volume's stream.  In checked mode (hv_capacity_gate: the pool's headroom is
+// not known to cover this frame) the claims of the touch pass are verified before anything is fused: if some did not fit
+// the pool grows and the touch pass runs again under a fresh stamp.
 static int tsdf_integrate_one(hv_volume *v, const void *d_depth, int depth_dtype, const uint8_t *d_rgb,
                               int H, int W, const double *intr, const double *T_cw, double depth_scale,
                               double depth_trunc) {
+    bool checked = false;
+    int rc = hv_capacity_gate(v, &checked);
+    if (rc != HV_OK) return rc;
     HvFrameParams P;
     make_frame_params(v, H, W, intr, T_cw, depth_scale, depth_trunc, depth_dtype, &P);
     int parity = 0;
-    tsdf_next_frame(v, P, parity);
-    int rc = tsdf_launch_touch(v, v->stream, P, parity, d_depth, d_rgb);
-    if (rc != HV_OK) return rc;
+    for (int attempt = 0;; ++attempt) {
+        tsdf_next_frame(v, P, parity);
+        if (attempt > 0) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
+        rc = tsdf_launch_touch(v, v->stream, P, parity, d_depth, d_rgb);
+        if (rc != HV_OK) return rc;
+        if (!checked) break;
+        rc = hv_claims_fit(v);
+        if (rc == HV_OK) break;
+        if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
+        make_frame_params(v, H, W, intr, T_cw, depth_scale, depth_trunc, depth_dtype, &P); // (touch_box_bits etc. unchanged; cheap)
+    }
     if (v->debug_variant == 8) {
         rc = tsdf_multiplier_table(v, P);
         if (rc != HV_OK) return rc;
@@ -1615,6 +1635,10 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
     const int BMAX = 64;
     for (int f0 = 0; f0 < n_frames; f0 += BMAX) {
         const int B = std::min(BMAX, n_frames - f0);
+        // pool headroom (grows here when more than half is known to be used; see hv_capacity_gate)
+        bool checked = false;
+        rc = hv_capacity_gate(v, &checked);
+        if (rc != HV_OK) return rc;
         // per-frame constants go through a ring of 4 pinned host buffers: the H2D copy is truly
         // asynchronous and a slot is only rewritten after the copy that last used it has completed,
         // so consecutive calls queue up on the stream without a host synchronisation
@@ -1633,7 +1657,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
             v->frame_counter += 1;
             params[f].frame_id = v->frame_counter;
         }
-        const int batch_stamp = v->frame_counter;
+        int batch_stamp = v->frame_counter;
         v->last_touch_parity = 0;
         // scratch: [B frame records of npx uint2][B HvFrameParams]
         const size_t px_bytes = sizeof(uint2) * npx * (size_t)B;
@@ -1645,14 +1669,25 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         HV_HIP(hipEventRecord(v->params_ev[ri], v->stream));
         // the touched-list counters are zero after hv_reset and k_tsdf_batch_finish; an online frame leaves its own
         // parity's count behind
-        if (!v->touch_counters_clean) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
-        v->touch_counters_clean = true;
         const int n_prep_blocks = (int)((npx + 1023) / 1024); // 4 pixels per thread
         const int n_touch_blocks = (hv_touch_patches(width, height, v->cfg.depth_sampling_stride) + 3) / 4;
-        hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3((n_prep_blocks + n_touch_blocks) * B), dim3(256), 0, v->stream,
-                           v->table, v->touched_stamp, (unsigned long long *)v->touched_mask, v->touched_list, batch_stamp,
-                           (const char *)d_depth + npx * dsz * (size_t)f0, (int64_t)(npx * dsz),
-                           (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks, n_touch_blocks, B);
+        for (int attempt = 0;; ++attempt) {
+            if (!v->touch_counters_clean) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
+            v->touch_counters_clean = true;
+            hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3((n_prep_blocks + n_touch_blocks) * B), dim3(256), 0, v->stream,
+                               v->table, v->touched_stamp, (unsigned long long *)v->touched_mask, v->touched_list, batch_stamp,
+                               (const char *)d_depth + npx * dsz * (size_t)f0, (int64_t)(npx * dsz),
+                               (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks, n_touch_blocks, B);
+            if (!checked) break;
+            // checked mode: nothing is fused before every unit of the batch has its pool slot; if some claims did not fit, the
+            // pool has grown (table rebuilt without them, stamps kept) and the touch pass runs again under a fresh stamp
+            rc = hv_claims_fit(v);
+            if (rc == HV_OK) break;
+            if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
+            v->frame_counter += 1;
+            batch_stamp = v->frame_counter;
+            v->touch_counters_clean = false;
+        }
         hv_profile_begin(v);
         // sweep form: 2 = k_tsdf_sweep (production: float2 projection chain, prefetched frame constants), 1 = first form (A/B, and
         // the only one that runs without the multiplier table).  The switches are read per call (a handful of getenv per
@@ -1702,7 +1737,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
 #undef HV_LAUNCH_SWEEP
         hv_profile_end(v, B);
         hipLaunchKernelGGL(k_tsdf_batch_finish, dim3(1), dim3(1024), 0, v->stream, v->table, v->touched_list,
-                           (unsigned long long *)v->touched_mask, 0);
+                           (unsigned long long *)v->touched_mask, 0, v->d_status, hv_next_status_seq(v));
         HV_HIP(hipGetLastError());
     }
     return HV_OK;

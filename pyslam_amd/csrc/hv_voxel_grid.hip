@@ -316,9 +316,22 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
     const unsigned blocks = (unsigned)((n + 255) / 256);
     int rc = ensure_sort_tmp(v, n);
     if (rc != HV_OK) return rc;
+    bool checked = false;
+    rc = hv_capacity_gate(v, &checked); // may grow the pool: the sort-key width follows the table
+    if (rc != HV_OK) return rc;
+    rc = ensure_sort_tmp(v, n);
+    if (rc != HV_OK) return rc;
     hv_profile_begin(v); // measurement hook: keys + sort + ordered reduce of one integrate call
-    hipLaunchKernelGGL(k_vg_keys, dim3(blocks), dim3(256), 0, v->stream, v->table, d_pts, n, G, v->sort_keys_in,
-                       v->sort_vals_in, d_valid);
+    for (int attempt = 0;; ++attempt) {
+        hipLaunchKernelGGL(k_vg_keys, dim3(blocks), dim3(256), 0, v->stream, v->table, d_pts, n, G, v->sort_keys_in,
+                           v->sort_vals_in, d_valid);
+        if (!checked) break;
+        rc = hv_claims_fit(v); // blocks that did not fit: grow, claim again (sort keys embed table slots)
+        if (rc == HV_OK) break;
+        if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
+        rc = ensure_sort_tmp(v, n);
+        if (rc != HV_OK) return rc;
+    }
     size_t tmp_bytes = v->sort_tmp_bytes;
     HV_HIP(rocprim::radix_sort_pairs(v->sort_tmp, tmp_bytes, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                                      v->sort_vals_out, (size_t)n, 0, sort_bits(v), v->stream));
@@ -332,6 +345,7 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
         hipLaunchKernelGGL(k_vg_reduce<HV_COLOR_NONE>, dim3(blocks), dim3(256), 0, v->stream, v->table,
                            (HvVoxel *)v->pool, v->sort_keys_out, v->sort_vals_out, n, G, d_pts, d_cols);
     }
+    hv_launch_publish_status(v); // pool occupancy for the next call's hv_capacity_gate
     hv_profile_end(v, n);
     HV_HIP(hipGetLastError());
     v->frame_counter += 1;

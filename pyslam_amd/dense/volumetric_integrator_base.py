@@ -5,8 +5,9 @@ Differences that are deliberate (MI355X-first):
 * the worker is always a *spawned* process (the reference already spawns for TSDF, base.py:348-362)
   and owns the HIP context; the volume stays resident in HBM for the life of the worker;
 * queues are plain multiprocessing queues of the spawn context instead of Manager proxies (one
-  pickle instead of two per frame); the names q_in / q_out / q_management and their semantics
-  (push-to-front for regular tasks, RESET on q_management) are unchanged;
+  pickle instead of two per frame on q_out); the names q_in / q_out / q_management and their semantics
+  (push-to-front for regular tasks, RESET on q_management) are unchanged: q_in and q_management are manager queues
+  like the reference's, because drain-and-refill needs put() to be synchronous;
 * undistortion: the maps are computed by a restatement of OpenCV's getOptimalNewCameraMatrix /
   initUndistortRectifyMap (pyslam_amd/prep.py) and cv2.remap runs on the GPU (hv_remap); cv2 is not
   available here, so parity with OpenCV at that step is unpinned (validated geometrically).
@@ -228,9 +229,16 @@ class VolumetricIntegratorBase:
         self.save_request_completed = mp.Value("i", -1)
         self.save_request_condition = mp.Condition()
 
-        self.q_in = mp.Queue()          # regular tasks (integrate, update output, save)
-        self.q_out = mp.Queue()         # outputs (visualise, save)
-        self.q_management = mp.Queue()  # management tasks (reset / rebuild)
+        # q_in / q_management are MANAGER queues as in the reference (base.py:401 MultiprocessingManager): push_to_front,
+        # empty_queue, rebuild and reset_if_requested drain with get(block=False) and expect to see what this very process
+        # just put - true for a manager queue (put returns when the item is in the queue), not for mp.Queue, whose feeder
+        # thread delivers later (push_to_front then degrades to append, rebuild()'s drain misses in-flight INTEGRATE tasks
+        # and their pre-loop-closure poses get fused into the fresh volume).  q_out only ever carries one consumer's
+        # outputs (meshes of 100s of MB): it stays a plain mp.Queue to avoid a second pickle of those.
+        self._mp_manager = mp.Manager()
+        self.q_in = self._mp_manager.Queue()          # regular tasks (integrate, update output, save)
+        self.q_out = mp.Queue()                       # outputs (visualise, save)
+        self.q_management = self._mp_manager.Queue()  # management tasks (reset / rebuild)
         self.parameters_dict = static_fields_to_dict(Parameters)  # snapshot for the child, base.py:412-416
         self.q_in_condition = mp.Condition()
         self.q_out_condition = mp.Condition()
@@ -245,7 +253,7 @@ class VolumetricIntegratorBase:
     # -- pickling for the spawned child (base.py:495-526): drop what must not cross --------------
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("keyframe_queue_timer", "keyframe_queue_lock", "keyframe_queue", "process", "mp", "volume"):
+        for k in ("keyframe_queue_timer", "keyframe_queue_lock", "keyframe_queue", "process", "mp", "volume", "_mp_manager"):
             state.pop(k, None)
         return state
 
@@ -314,6 +322,10 @@ class VolumetricIntegratorBase:
         self.process.join(timeout=2 * Parameters.kMultiprocessingProcessJoinDefaultTimeout)
         if self.process.is_alive():
             self.process.terminate()
+        try:
+            self._mp_manager.shutdown()  # the queues' server process
+        except Exception:
+            pass
 
     def flush_keyframe_queue(self):  # base.py:1120-1188
         with self.keyframe_queue_lock:
@@ -563,6 +575,11 @@ class VolumetricIntegratorBase:
                 self.reset_if_requested(reset_mutex, reset_requested, q_in, q_in_condition, q_out, q_out_condition)
             except Exception:
                 traceback.print_exc()  # base.py:952-954: log and keep going
+                # ... but never leave save() waiting for a SAVE task that died (e.g. the volume reported an error)
+                if save_request_completed.value == 0:
+                    with save_request_condition:
+                        save_request_completed.value = 1
+                        save_request_condition.notify_all()
         is_looping.value = 0
         self._stop_volume_integrator_implementation()
         empty_queue(q_in)

@@ -274,7 +274,16 @@ class VoxelBlockGrid(_Volume):
         """Fused depth2pointcloud + world transform + integrate for one posed RGB-D frame
         (pyslam/utilities/depth.py:45-85, volumetric_integrator_voxel_grid.py:251-300)."""
         dkind = L.HV_DEPTH_U16 if str(depth.dtype) in ("uint16", "torch.uint16") else L.HV_DEPTH_F32
+        if hasattr(depth, "data_ptr"):  # torch: the kernels read packed f32 / u16 depth and packed u8 colour
+            if str(depth.dtype) not in ("torch.float32", "torch.uint16") or not depth.is_contiguous() or not rgb.is_contiguous() \
+                    or str(rgb.dtype) != "torch.uint8":
+                raise RuntimeError("integrate_rgbd: device inputs must be contiguous float32|uint16 depth and uint8 colour")
+        else:  # host arrays: float64 / strided inputs are converted, not silently misread
+            depth = np.ascontiguousarray(depth, dtype=np.uint16 if dkind == L.HV_DEPTH_U16 else np.float32)
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
         H, W = int(depth.shape[0]), int(depth.shape[1])
+        if tuple(rgb.shape) != (H, W, 3):
+            raise RuntimeError(f"integrate_rgbd: colour image {tuple(rgb.shape)} does not match depth {(H, W)}")
         intr = np.array([fx, fy, cx, cy], dtype=np.float64)
         T = _as_f64_4x4(T_cw)
         maxd = float(min(max_depth, 3.0e38))
@@ -291,7 +300,7 @@ class VoxelBlockGrid(_Volume):
         dkind = L.HV_DEPTH_U16 if str(depth.dtype) in ("uint16", "torch.uint16") else L.HV_DEPTH_F32
         F, H, W = (int(x) for x in depth.shape)
         if not hasattr(depth, "data_ptr"):
-            depth = np.ascontiguousarray(depth)
+            depth = np.ascontiguousarray(depth, dtype=np.uint16 if dkind == L.HV_DEPTH_U16 else np.float32)
             rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
         intr = np.array([fx, fy, cx, cy], dtype=np.float64)
         T = np.ascontiguousarray(np.asarray(T_cw, dtype=np.float64).reshape(F, 16))

@@ -180,3 +180,22 @@ def test_semantic_point_cloud_output_without_instances(small_params):
     assert pc.points.dtype == np.float32 and pc.semantics.dtype == np.int32 and len(pc.points) == len(pc.semantics) > 0
     assert pc.semantic_colors.shape == pc.points.shape and pc.object_colors.shape == pc.points.shape
     assert set(np.unique(pc.object_ids)) <= {0}  # no instance image: default object id 0
+
+
+def test_push_to_front_is_newest_first_and_rebuild_drains():
+    """the drain-and-refill idioms need queues whose put() is synchronous (manager queues, as in the reference).
+    A backlog pushed with front=True must come out newest-first, and empty_queue must see everything this process put."""
+    import multiprocessing as mp
+
+    from pyslam_amd.dense.volumetric_integrator_base import empty_queue, push_to_front
+
+    with mp.Manager() as m:
+        q = m.Queue()
+        for i in range(100):
+            push_to_front(q, i)
+        out = [q.get(block=False) for _ in range(100)]
+        assert out == list(range(99, -1, -1))
+        for i in range(50):
+            q.put(i)
+        empty_queue(q)
+        assert q.empty()

@@ -60,3 +60,56 @@ def test_grid_pools_grow(mode):
     assert small.max_blocks() > 1024
     for a, b in zip(small.dump(), big.dump()):
         np.testing.assert_array_equal(a, b)
+
+
+def test_long_batch_replay_into_small_pool_loses_nothing():
+    """VERDICT r01 #8 / ADVICE: a replay made of batch calls only (no data-returning call in between, as rebuild() does) into
+    a pool that is far too small: the pool grows inside the integrate calls - in time, or after a verified claim pass - and
+    the result is bit-identical to a volume that was created large.  No call returns an error, no unit is dropped."""
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    small = ScalableTSDFVolume(0.02, 0.08, max_blocks=64)
+    big = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 14)
+    for lo in range(0, 120, 8):  # 15 batch calls back to back, the camera moves on: new units in every call
+        d, c, Ts = s.batch(lo * 4, 8)
+        for v in (small, big):
+            v.integrate_batch(d, c, K, Ts, depth_scale=1.0, depth_trunc=4.0)
+    assert small.dropped_points() == 0
+    assert small.max_blocks() >= small.num_blocks() > 64
+    for a, b in zip(small.dump(), big.dump()):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_pool_that_cannot_grow_fails_before_fusing(monkeypatch):
+    """HV_AUTO_GROW=0: the call whose units do not fit returns the capacity error BEFORE its frame is fused, the volume keeps
+    exactly what it had, later calls keep failing (nothing is silently dropped) until reserve_blocks() makes room."""
+    from pyslam_amd._lib import HipVolError
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+
+    monkeypatch.setenv("HV_AUTO_GROW", "0")
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    frames = [s[i] for i in (0, 40, 80, 120)]
+    probe = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 13)
+    probe.integrate(RGBDImage.create_from_color_and_depth(frames[0][1], frames[0][0], 1.0, 4.0, False), K, frames[0][2])
+    first = probe.num_blocks()
+    vol = ScalableTSDFVolume(0.02, 0.08, max_blocks=first + 8)  # room for the first view, not for a second one
+    vol.integrate(RGBDImage.create_from_color_and_depth(frames[0][1], frames[0][0], 1.0, 4.0, False), K, frames[0][2])
+    before = vol.dump()
+    with pytest.raises(HipVolError, match="NOT fused"):
+        vol.integrate(RGBDImage.create_from_color_and_depth(frames[1][1], frames[1][0], 1.0, 4.0, False), K, frames[1][2])
+    with pytest.raises(HipVolError, match="pool exhausted"):  # sticky: the batch path refuses as well
+        d, c, Ts = np.stack([f[0] for f in frames[2:]]), np.stack([f[1] for f in frames[2:]]), np.stack([f[2] for f in frames[2:]])
+        vol.integrate_batch(d, c, K, Ts, depth_scale=1.0, depth_trunc=4.0)
+    vol.reserve_blocks(1 << 13)  # explicit growth is still possible: the table is rebuilt without the failed claims
+    for a, b in zip(vol.dump(), before):
+        np.testing.assert_array_equal(a, b)  # nothing of the refused frames went in, nothing of the first one was lost
+    for f in frames[1:]:
+        vol.integrate(RGBDImage.create_from_color_and_depth(f[1], f[0], 1.0, 4.0, False), K, f[2])
+        probe.integrate(RGBDImage.create_from_color_and_depth(f[1], f[0], 1.0, 4.0, False), K, f[2])
+    for a, b in zip(vol.dump(), probe.dump()):
+        np.testing.assert_array_equal(a, b)

@@ -104,12 +104,11 @@ def test_empty_and_invalid_inputs():
         gpu.integrate(RGBDImage.create_from_color_and_depth(rgb[:, :32], depth, 1.0, 4.0, False), K, np.eye(4))
     with pytest.raises(RuntimeError, match="Unsupported image format"):
         RGBDImage.create_from_color_and_depth(rgb, depth, 1.0, 4.0, True)
-    # pool exhaustion is reported, not silently dropped
+    # a pool that is too small grows before anything is fused (the first call verifies its claims) ...
     small = ScalableTSDFVolume(0.02, 0.08, max_blocks=4)
     d = np.full((48, 64), 1.0, np.float32)
     small.integrate(RGBDImage.create_from_color_and_depth(rgb, d, 1.0, 4.0, False), K, np.eye(4))
-    with pytest.raises(RuntimeError, match="pool exhausted"):
-        small.num_blocks()
+    assert small.max_blocks() > 4 and small.num_blocks() > 4
 
 
 def test_marching_cubes_and_point_cloud_match_oracle():
