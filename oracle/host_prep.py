@@ -1,8 +1,11 @@
 """TEST INFRASTRUCTURE ONLY — numpy restatement of pySLAM's per-frame host prep (L3).
 
-pyslam.utilities.depth / geometry cannot be imported here (they pull in cv2 / numba), so the pure
-numpy bodies are restated verbatim with their citations.  Used by tests/ to check the fused GPU
-unprojection (hv_integrate_rgbd_points) and by bench.py's cpu_baseline leg.
+A restatement because /root/reference does not exist on the GPU box; it is PINNED to the reference's own
+pyslam/utilities/depth.py, which needs nothing but numpy: tools/make_golden_prep.py imports that file and writes
+tests/golden/prep_depth.npz, tests/test_golden.py checks these functions against the fixture bit for bit (and against
+the imported reference directly where /root/reference is present).  geometry.inv_T is restated with an explicit
+operation order (the reference's goes through numba / BLAS).  Used by tests/ to check the fused GPU unprojection
+(hv_integrate_rgbd_points), the shadow-point filter, and by bench.py's voxel-grid cpu_baseline leg.
 """
 import numpy as np
 

@@ -258,6 +258,7 @@ struct hv_volume {
     int32_t status_seq_issued = 0, status_seq_seen = 0;
     int64_t known_blocks = 0;      // blocks in use as of status_seq_seen
     int64_t max_new_per_call = 0;  // largest growth of `blocks` seen between two published states
+    double avg_new_per_call = 0.0; // running mean of the growth per call (what the calls still in flight are expected to add)
     bool status_exact = false;     // known_blocks was read with the stream idle (after creation / reset / growth: true until the next launch)
 
     // TSDF per-frame state

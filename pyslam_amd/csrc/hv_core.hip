@@ -140,7 +140,10 @@ int hv_capacity_gate(hv_volume *v, bool *checked) {
         const int64_t blocks = st->blocks;
         overflow = st->overflow;
         if (st->seq == seq) { // not torn by a newer publication (then the next call sees it)
-            v->max_new_per_call = std::max<int64_t>(v->max_new_per_call, blocks - v->known_blocks);
+            const int64_t grown = std::max<int64_t>(0, blocks - v->known_blocks);
+            const int64_t calls = std::max<int64_t>(1, seq - v->status_seq_seen);
+            v->max_new_per_call = std::max<int64_t>(v->max_new_per_call, grown / calls + (grown % calls != 0));
+            v->avg_new_per_call = 0.75 * v->avg_new_per_call + 0.25 * (double)grown / (double)calls;
             v->known_blocks = std::max<int64_t>(v->known_blocks, std::min<int64_t>(blocks, v->cfg.max_blocks));
             v->status_seq_seen = seq;
         }
@@ -150,11 +153,13 @@ int hv_capacity_gate(hv_volume *v, bool *checked) {
                "nothing more is fused until hv_reserve_blocks or hv_reset",
                (long long)v->cfg.max_blocks);
     if (v->known_blocks * 2 > v->cfg.max_blocks) (void)hv_grow(v, v->cfg.max_blocks * 2); // may fail: the checked mode below covers it
-    // calls issued but not yet reported may each add up to the largest growth seen so far
+    // Unchecked (fully asynchronous) only when the free part of the pool covers the largest growth a call ever caused, 4 x the
+    // recent growth per call for every call still in flight, and a margin; otherwise the call verifies its claims.  A burst
+    // beyond that inside the lag window cannot be lost silently either: the next gate sees the overflow and refuses.
     const int64_t in_flight = v->status_seq_issued - v->status_seq_seen;
-    const int64_t headroom = v->cfg.max_blocks - v->known_blocks - in_flight * v->max_new_per_call;
+    const int64_t need = v->max_new_per_call + (int64_t)(4.0 * v->avg_new_per_call * (double)(in_flight + 1)) + 1024;
     // max_new_per_call == 0: nothing is known yet about what a call allocates (first call after creation / reset)
-    *checked = v->max_new_per_call == 0 || headroom < std::max<int64_t>(1024, 4 * v->max_new_per_call);
+    *checked = v->max_new_per_call == 0 || v->cfg.max_blocks - v->known_blocks < need;
     return HV_OK;
 }
 
@@ -163,7 +168,9 @@ int hv_claims_fit(hv_volume *v) {
     if (rc != HV_OK) return rc;
     const int64_t blocks = v->h_counters[HV_CNT_BLOCKS];
     if (v->h_counters[HV_CNT_OVERFLOW] == 0) {
-        v->max_new_per_call = std::max<int64_t>(v->max_new_per_call, blocks - v->known_blocks);
+        const int64_t grown = std::max<int64_t>(0, blocks - v->known_blocks);
+        v->max_new_per_call = std::max<int64_t>(v->max_new_per_call, std::max<int64_t>(grown, 1));
+        v->avg_new_per_call = 0.75 * v->avg_new_per_call + 0.25 * (double)grown;
         v->known_blocks = blocks;
         return HV_OK;
     }
@@ -376,6 +383,7 @@ int hv_reset(hv_volume *v) {
     v->status_seq_issued = v->status_seq_seen = 0;
     v->known_blocks = 0;
     v->max_new_per_call = 0;
+    v->avg_new_per_call = 0.0;
     v->status_exact = true;
     v->last_touch_parity = 0;
     v->touch_counters_clean = true;

@@ -108,3 +108,37 @@ def test_frustum_contains_matches_reference_golden():
         assert ok == bool(g["inside"][i])
         np.testing.assert_array_equal(uvd, g["uvd"][i])
     np.testing.assert_array_equal(oracle.frustum_bbox(intr, s.width, s.height, T, 8.0, 0.01, "port"), g["bbox"])
+
+
+# ---- host prep: pinned to the reference's own pyslam/utilities/depth.py -------------------
+def test_host_prep_matches_reference_depth_fixture():
+    """tests/golden/prep_depth.npz was produced by IMPORTING the reference's depth.py (tools/make_golden_prep.py): the
+    restatement that travels to the GPU box must reproduce depth2pointcloud and filter_shadow_points bit for bit."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "prep_depth.npz"))
+    fx, fy, cx, cy = z["intr"]
+    pts, cols, valid = hp.depth2pointcloud(z["depth"], z["rgb"], fx, fy, cx, cy, float(z["max_depth"]), float(z["min_depth"]))
+    np.testing.assert_array_equal(pts, z["points"])
+    np.testing.assert_array_equal(cols, z["colors"])
+    assert valid.sum() == len(z["points"])
+    np.testing.assert_array_equal(hp.filter_shadow_points(z["depth"]), z["shadow_mad"])
+    np.testing.assert_array_equal(hp.filter_shadow_points(z["depth"], delta_depth=0.05, delta_x=3, delta_y=1, fill_value=0.0), z["shadow_fixed"])
+    assert (z["shadow_mad"] == -1).sum() > 0 and (z["shadow_fixed"] != z["depth"]).sum() > 0
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/pyslam/utilities/depth.py"), reason="reference tree not present (GPU box)")
+def test_host_prep_matches_imported_reference():
+    """Dev container: the reference file itself as the oracle (it needs nothing but numpy), on fresh random inputs."""
+    from tools.make_golden_prep import load_reference_depth
+
+    ref = load_reference_depth()
+    rng = np.random.default_rng(11)
+    for _ in range(3):
+        depth = (0.3 + 3.0 * rng.random((37, 53))).astype(np.float32)
+        depth[rng.random(depth.shape) < 0.1] = 0.0
+        rgb = rng.integers(0, 255, (37, 53, 3)).astype(np.uint8)
+        pc = ref.depth2pointcloud(depth, rgb, 60.0, 61.0, 26.0, 18.0, max_depth=3.0, min_depth=0.4)
+        pts, cols, _ = hp.depth2pointcloud(depth, rgb, 60.0, 61.0, 26.0, 18.0, 3.0, 0.4)
+        np.testing.assert_array_equal(pts, pc.points)
+        np.testing.assert_array_equal(cols, pc.colors)
+        for kw in ({}, {"delta_depth": 0.1, "delta_x": 1, "delta_y": 3, "fill_value": 0.0}):
+            np.testing.assert_array_equal(hp.filter_shadow_points(depth, **kw), ref.filter_shadow_points(depth, **kw))

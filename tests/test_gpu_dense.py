@@ -274,3 +274,24 @@ def test_dense_reconstruction_cli_from_saved_state(tmp_path):
     v, t, c = cpu.extract_triangle_mesh()
     assert pts.shape == v.shape and faces.shape == t.shape
     np.testing.assert_allclose(np.sort(pts, axis=0), np.sort(v, axis=0), atol=1e-6)
+
+
+def test_prep_kernels_match_reference_depth_fixture():
+    """The GPU prep kernels against tests/golden/prep_depth.npz, i.e. against outputs of the reference's own
+    pyslam/utilities/depth.py (tools/make_golden_prep.py): the shadow-point filter bit for bit (MAD and fixed threshold), the
+    fused depth2pointcloud + integrate through the voxel rows it produces."""
+    import os
+
+    import oracle
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "prep_depth.npz"))
+    g = VoxelBlockGrid(0.02, 8, max_blocks=1 << 12, max_points=1 << 16)
+    np.testing.assert_array_equal(g.filter_shadow_points(z["depth"]), z["shadow_mad"])
+    # reference points (camera frame; identity pose) -> oracle grid; fused GPU path from the raw depth -> same grid
+    fx, fy, cx, cy = z["intr"]
+    g.integrate_rgbd(z["depth"], z["rgb"], fx, fy, cx, cy, np.eye(4), max_depth=float(z["max_depth"]), min_depth=float(z["min_depth"]))
+    ref = oracle.RefGrid(0.02, 8) if oracle.ref_available() else oracle.PortGrid(0.02, 8)
+    ref.integrate(z["points"].astype(np.float32), z["colors"].astype(np.float32))
+    for a, b in zip(g.dump(), ref.dump()):
+        np.testing.assert_array_equal(a, b)

@@ -71,3 +71,33 @@ def test_gpu_remap_undistorts_analytic_scene():
     sx, sy = np.rint(und.map_x).astype(int), np.rint(und.map_y).astype(int)
     ok = (sx >= 0) & (sx < W) & (sy >= 0) & (sy < H)
     np.testing.assert_array_equal(lab_u[ok], lab[sy[ok], sx[ok]])  # exact nearest-neighbour lookup
+
+
+CV2_FIXTURE = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "remap_cv2.npz")
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(CV2_FIXTURE), reason="tests/golden/remap_cv2.npz not generated yet (needs cv2: tools/make_golden_remap.py)")
+def test_maps_match_opencv_fixture():
+    """PIN of rows P2 / N1 - active once tools/make_golden_remap.py has run where OpenCV exists: the restated
+    getOptimalNewCameraMatrix / initUndistortRectifyMap against cv2's (new K to 1e-6, maps to 1e-3 px)."""
+    z = np.load(CV2_FIXTURE)
+    W_, H_ = (int(x) for x in z["size"])
+    new_K, _ = prep.get_optimal_new_camera_matrix(z["K"], z["D"], (W_, H_), 0.0, (W_, H_))
+    np.testing.assert_allclose(new_K, z["new_K"], atol=1e-6)
+    mx, my = prep.init_undistort_rectify_map(z["K"], z["D"], z["new_K"], (W_, H_))
+    assert np.abs(mx - z["map_x"]).max() < 1e-3 and np.abs(my - z["map_y"]).max() < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not __import__("os").path.exists(CV2_FIXTURE), reason="tests/golden/remap_cv2.npz not generated yet (needs cv2: tools/make_golden_remap.py)")
+def test_gpu_remap_matches_opencv_fixture():
+    """hv_remap against cv2.remap on OpenCV's own maps: nearest-neighbour results identical, bilinear colour within 1/255
+    (cv2 interpolates with 5-bit fixed-point weights)."""
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    z = np.load(CV2_FIXTURE)
+    vol = VoxelBlockGrid(0.05, 8, max_blocks=1 << 10, max_points=1 << 16)
+    np.testing.assert_array_equal(vol.remap(z["depth"], z["map_x"], z["map_y"], linear=False), z["depth_nearest"])
+    np.testing.assert_array_equal(vol.remap(z["labels"], z["map_x"], z["map_y"], linear=False), z["labels_nearest"])
+    got = vol.remap(z["img"], z["map_x"], z["map_y"], linear=True).astype(np.int32)
+    assert np.abs(got - z["img_linear"].astype(np.int32)).max() <= 1
