@@ -300,6 +300,11 @@ struct hv_volume {
     uint32_t *sort_vals_in = nullptr, *sort_vals_out = nullptr;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    // per-frame bucket path of the VOXEL_GRID mode (hv_voxel_grid.hip): per-slot point counts / bucket cursors, the list of
+    // slots a frame touches; sized by the table, re-allocated when it grows
+    int32_t *vg_cnt = nullptr, *vg_cur = nullptr, *vg_touched = nullptr;
+    uint64_t vg_cap = 0;
+    int vg_parity = 0;               // which of the two touched-list counters the next frame appends to
     float *scratch_points = nullptr; // [max_points*3]
     float *scratch_colors = nullptr; // [max_points*3]
     int local_bits = 9;

@@ -110,6 +110,178 @@ __global__ __launch_bounds__(256) void k_vg_reduce(HvTable table, HvVoxel *__res
     *vx = acc;
 }
 
+// ================================================================================================
+// Per-frame bucket path (production for single frames).  The device-wide radix sort above is 18 small launches and 115 of
+// the 140 us a 640x480 frame takes (profiles/r01): a frame's points only have to be grouped per BLOCK (a few thousand
+// buckets of a few dozen to a few hundred points) and ordered inside a block by (voxel, point index) - SURVEY 7.2 K4.
+//   k_vgb_count    1 thread / point: key arithmetic + block claim as k_vg_keys; counts the points per table slot, the
+//                  first point of a slot appends the slot to the frame's touched list
+//   k_vgb_offsets  1 thread / touched slot: takes the slot's bucket range from a global cursor
+//   k_vgb_scatter  1 thread / point: entry (local voxel index << 20 | point index) into its slot's bucket
+//   k_vgb_fold     1 workgroup / touched slot: bucket -> LDS, bitonic sort of the 32-bit entries (= by voxel, then by point
+//                  index), the first thread of every voxel run folds its points in point order into the voxel record -
+//                  exactly the order of the reference's sequential branch, so the result is bit-identical to the radix
+//                  path and to the reference.  Buckets beyond the LDS capacity (a block that catches > 4096 points of one
+//                  frame: coarse voxels / very close surfaces) are folded in point-index windows of 4096, still exact.
+// 4 launches instead of ~20.  Needs point indices < 2^20 and local_bits <= 12; larger inputs take the radix path.
+// ================================================================================================
+static constexpr int HV_VGB_IDX_BITS = 20;
+static constexpr int HV_VGB_CAP = 4096; // entries of one bucket sorted in LDS at a time
+
+__global__ __launch_bounds__(256) void k_vgb_count(HvTable table, const float *__restrict__ pts, int64_t n, HvGridParams G,
+                                                    int32_t *__restrict__ pslot, uint32_t *__restrict__ plidx,
+                                                    const uint32_t *__restrict__ valid_mask_keys, int32_t *__restrict__ cnt,
+                                                    int32_t *__restrict__ touched, int parity) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t slot = -1;
+    uint32_t lidx = 0;
+    const bool masked = valid_mask_keys != nullptr && valid_mask_keys[i] == HV_SORT_SENTINEL; // pixel rejected by the unprojection
+    if (!masked) {
+        const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+        if (isfinite(x) && isfinite(y) && isfinite(z) && fabsf(x * G.inv_voxel_size) < 1.0e9f &&
+            fabsf(y * G.inv_voxel_size) < 1.0e9f && fabsf(z * G.inv_voxel_size) < 1.0e9f) {
+            const HvPointKey k = hv_point_key(x, y, z, G);
+            if (hv_key_in_range(k.b[0], k.b[1], k.b[2])) {
+                slot = hv_table_insert(table, hv_pack_key(k.b[0], k.b[1], k.b[2]));
+                lidx = (uint32_t)(k.l[0] + k.l[1] * G.bs + k.l[2] * G.bs * G.bs); // voxel_block.h:67-70
+            }
+        }
+        if (slot < 0) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
+    }
+    pslot[i] = slot;
+    plidx[i] = lidx;
+    if (slot >= 0 && atomicAdd(&cnt[slot], 1) == 0) {
+        const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0 + parity], 1);
+        touched[at] = slot; // at < allocated blocks <= max_blocks: a slot is listed once per frame
+    }
+}
+
+__global__ __launch_bounds__(256) void k_vgb_offsets(HvTable table, const int32_t *__restrict__ touched, int parity,
+                                                      const int32_t *__restrict__ cnt, int32_t *__restrict__ cur) {
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= table.counters[HV_CNT_TOUCH0 + parity]) return;
+    const int32_t slot = touched[t];
+    cur[slot] = atomicAdd(&table.counters[HV_CNT_AUX], cnt[slot]);
+}
+
+__global__ __launch_bounds__(256) void k_vgb_scatter(const int32_t *__restrict__ pslot, const uint32_t *__restrict__ plidx, int64_t n,
+                                                      int32_t *__restrict__ cur, uint32_t *__restrict__ entries) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t slot = pslot[i];
+    if (slot < 0) return;
+    entries[atomicAdd(&cur[slot], 1)] = (plidx[i] << HV_VGB_IDX_BITS) | (uint32_t)i;
+}
+
+// update_voxel_direct (voxel_block_grid.hpp:524-614) folded over the sorted entries s[0 .. m) of one block
+template <int COLOR_KIND>
+__device__ __forceinline__ void hv_vgb_fold_sorted(const uint32_t *s, int m, HvVoxel *__restrict__ block, const float *__restrict__ pts,
+                                                   const void *__restrict__ cols) {
+    const float inv_255 = 1.0f / 255.0f; // voxel_data.h:82
+    for (int e = threadIdx.x; e < m; e += blockDim.x) {
+        const uint32_t lidx = s[e] >> HV_VGB_IDX_BITS;
+        if (e > 0 && (s[e - 1] >> HV_VGB_IDX_BITS) == lidx) continue; // not the head of its voxel's run
+        HvVoxel *vx = block + lidx;
+        HvVoxel acc = *vx;
+        int j = e;
+        do {
+            const int64_t p = s[j] & ((1u << HV_VGB_IDX_BITS) - 1u);
+            acc.pos[0] += pts[p * 3 + 0];
+            acc.pos[1] += pts[p * 3 + 1];
+            acc.pos[2] += pts[p * 3 + 2];
+            if (COLOR_KIND == HV_COLOR_U8) {
+                const uint8_t *c = (const uint8_t *)cols + p * 3;
+                acc.col[0] += (float)c[0] * inv_255;
+                acc.col[1] += (float)c[1] * inv_255;
+                acc.col[2] += (float)c[2] * inv_255;
+            } else if (COLOR_KIND == HV_COLOR_F32) {
+                const float *c = (const float *)cols + p * 3;
+                acc.col[0] += c[0];
+                acc.col[1] += c[1];
+                acc.col[2] += c[2];
+            }
+            acc.count = acc.count == 0 ? 1 : acc.count + 1;
+            ++j;
+        } while (j < m && (s[j] >> HV_VGB_IDX_BITS) == lidx);
+        *vx = acc;
+    }
+}
+
+__device__ __forceinline__ void hv_vgb_bitonic(uint32_t *s, int m2) { // ascending, m2 a power of two, all threads of the block
+    for (int k = 2; k <= m2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < m2; t += blockDim.x) {
+                const int x = t ^ j;
+                if (x > t) {
+                    const uint32_t a = s[t], b = s[x];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) {
+                        s[t] = b;
+                        s[x] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int COLOR_KIND>
+__global__ __launch_bounds__(256) void k_vgb_fold(HvTable table, HvVoxel *__restrict__ pool, const int32_t *__restrict__ touched,
+                                                   int parity, int32_t *__restrict__ cnt, const int32_t *__restrict__ cur,
+                                                   const uint32_t *__restrict__ entries, HvGridParams G, const float *__restrict__ pts,
+                                                   const void *__restrict__ cols, int64_t n_points, HvStatus *status, int32_t status_seq) {
+    __shared__ uint32_t s[HV_VGB_CAP];
+    __shared__ int s_m;
+    const int n_touched = table.counters[HV_CNT_TOUCH0 + parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        table.counters[HV_CNT_TOUCH0 + (parity ^ 1)] = 0; // the next frame's list
+        table.counters[HV_CNT_AUX] = 0;                   // ... and bucket cursor
+        hv_publish_status(table, status, status_seq);
+    }
+    for (int t = blockIdx.x; t < n_touched; t += gridDim.x) {
+        const int32_t slot = touched[t];
+        const int32_t nb = cnt[slot];
+        const int32_t start = cur[slot] - nb;
+        const int32_t idx = table.vals[slot];
+        __syncthreads(); // s[] of the previous iteration is no longer read
+        if (threadIdx.x == 0) cnt[slot] = 0; // clean for the next frame
+        if (idx < 0) continue;               // (the block did not get a pool slot: overflow, reported by the caller)
+        HvVoxel *block = pool + (int64_t)idx * G.nvox;
+        if (nb <= HV_VGB_CAP) {
+            int m2 = 1;
+            while (m2 < nb) m2 <<= 1;
+            for (int e = threadIdx.x; e < m2; e += blockDim.x) s[e] = e < nb ? entries[start + e] : 0xFFFFFFFFu;
+            __syncthreads();
+            hv_vgb_bitonic(s, m2);
+            hv_vgb_fold_sorted<COLOR_KIND>(s, nb, block, pts, cols);
+            continue;
+        }
+        // a bucket larger than the LDS window: fold the points of index window [w, w + CAP) at a time, windows ascending - a
+        // voxel's points still arrive in point order (a window holds <= CAP entries: point indices are distinct)
+        for (int64_t w = 0; w < n_points; w += HV_VGB_CAP) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_m = 0;
+            __syncthreads();
+            for (int e = threadIdx.x; e < nb; e += blockDim.x) {
+                const uint32_t ent = entries[start + e];
+                const int64_t p = ent & ((1u << HV_VGB_IDX_BITS) - 1u);
+                if (p >= w && p < w + HV_VGB_CAP) s[atomicAdd(&s_m, 1)] = ent;
+            }
+            __syncthreads();
+            const int m = s_m;
+            if (m == 0) continue;
+            int m2 = 1;
+            while (m2 < m) m2 <<= 1;
+            for (int e = m + threadIdx.x; e < m2; e += blockDim.x) s[e] = 0xFFFFFFFFu;
+            __syncthreads();
+            hv_vgb_bitonic(s, m2);
+            hv_vgb_fold_sorted<COLOR_KIND>(s, m, block, pts, cols);
+        }
+    }
+}
+
 // depth2pointcloud (pyslam/utilities/depth.py:45-85) + world transform
 // (volumetric_integrator_voxel_grid.py:262-281), f64 arithmetic in a fixed order, rounded to f32.
 struct HvUnprojectParams {
@@ -309,16 +481,70 @@ static int ensure_sort_tmp(hv_volume *v, int64_t n) {
     return hv_ensure_buffer(v, &v->sort_tmp, &v->sort_tmp_bytes, bytes);
 }
 
-// keys -> sort -> ordered reduce over device-resident points/colours
+static int ensure_bucket_buffers(hv_volume *v) {
+    if (v->vg_cap == v->table_capacity && v->vg_cnt != nullptr) return HV_OK;
+    HV_HIP(hipStreamSynchronize(v->stream));
+    for (int32_t **p : {&v->vg_cnt, &v->vg_cur, &v->vg_touched}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    HV_HIP(hipMalloc((void **)&v->vg_cnt, sizeof(int32_t) * v->table_capacity));
+    HV_HIP(hipMalloc((void **)&v->vg_cur, sizeof(int32_t) * v->table_capacity));
+    HV_HIP(hipMalloc((void **)&v->vg_touched, sizeof(int32_t) * v->table_capacity));
+    HV_HIP(hipMemsetAsync(v->vg_cnt, 0, sizeof(int32_t) * v->table_capacity, v->stream));
+    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
+    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_AUX], 0, sizeof(int32_t), v->stream));
+    v->vg_cap = v->table_capacity;
+    v->vg_parity = 0;
+    return HV_OK;
+}
+
+// keys -> group -> ordered reduce over device-resident points/colours.  Single frames (n < 2^20 points) take the bucket path
+// (4 launches), larger inputs - the batched replay - the device-wide radix sort; HV_VG_PATH=sort forces the latter (A/B, tests).
 static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, const void *d_cols,
                                    int color_kind, const uint32_t *d_valid) {
     const HvGridParams G = grid_params(v);
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    int rc = ensure_sort_tmp(v, n);
-    if (rc != HV_OK) return rc;
     bool checked = false;
-    rc = hv_capacity_gate(v, &checked); // may grow the pool: the sort-key width follows the table
+    int rc = hv_capacity_gate(v, &checked); // may grow the pool: the sort-key width / bucket arrays follow the table
     if (rc != HV_OK) return rc;
+    const char *force = getenv("HV_VG_PATH");
+    const bool bucket = n < (1ll << HV_VGB_IDX_BITS) && v->local_bits <= 32 - HV_VGB_IDX_BITS && !(force && strcmp(force, "sort") == 0);
+    if (bucket) {
+        hv_profile_begin(v); // measurement hook: the four launches of one integrate call
+        int parity = 0;
+        for (int attempt = 0;; ++attempt) {
+            rc = ensure_bucket_buffers(v);
+            if (rc != HV_OK) return rc;
+            parity = v->vg_parity;
+            hipLaunchKernelGGL(k_vgb_count, dim3(blocks), dim3(256), 0, v->stream, v->table, d_pts, n, G, (int32_t *)v->sort_vals_in,
+                               v->sort_keys_out, d_valid, v->vg_cnt, v->vg_touched, parity);
+            if (!checked) break;
+            rc = hv_claims_fit(v); // blocks that did not fit: grow and claim again (the counts restart from clean arrays)
+            if (rc == HV_OK) break;
+            v->vg_cap = 0; // counts / list of the aborted claim pass are void (and the table may have moved): fresh arrays next time
+            if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
+        }
+        v->vg_parity ^= 1;
+        // the touched list is at most the number of allocated blocks; its length stays on the device
+        const unsigned list_blocks = (unsigned)((std::min<int64_t>(n, v->cfg.max_blocks) + 255) / 256);
+        hipLaunchKernelGGL(k_vgb_offsets, dim3(list_blocks), dim3(256), 0, v->stream, v->table, (const int32_t *)v->vg_touched, parity,
+                           (const int32_t *)v->vg_cnt, v->vg_cur);
+        hipLaunchKernelGGL(k_vgb_scatter, dim3(blocks), dim3(256), 0, v->stream, (const int32_t *)v->sort_vals_in,
+                           (const uint32_t *)v->sort_keys_out, n, v->vg_cur, v->sort_keys_in);
+        const int32_t seq = hv_next_status_seq(v);
+        const unsigned fold_grid = (unsigned)std::min<int64_t>(std::max<int64_t>(n / 32, 256), 16384);
+#define HV_LAUNCH_FOLD(CK)                                                                                             \
+    hipLaunchKernelGGL(k_vgb_fold<CK>, dim3(fold_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool,          \
+                       (const int32_t *)v->vg_touched, parity, v->vg_cnt, (const int32_t *)v->vg_cur,                   \
+                       (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, n, v->d_status, seq)
+        if (color_kind == HV_COLOR_U8) HV_LAUNCH_FOLD(HV_COLOR_U8); else if (color_kind == HV_COLOR_F32) HV_LAUNCH_FOLD(HV_COLOR_F32); else HV_LAUNCH_FOLD(HV_COLOR_NONE);
+#undef HV_LAUNCH_FOLD
+        hv_profile_end(v, n);
+        HV_HIP(hipGetLastError());
+        v->frame_counter += 1;
+        return HV_OK;
+    }
     rc = ensure_sort_tmp(v, n);
     if (rc != HV_OK) return rc;
     hv_profile_begin(v); // measurement hook: keys + sort + ordered reduce of one integrate call

@@ -267,3 +267,31 @@ def test_batched_replay_is_bit_identical_to_per_frame():
         g.integrate_rgbd_batch(d, c, *s.intrinsics, T, max_depth=4.0)
         for a, b in zip(g.dump(), one.dump()):
             np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("voxel,bs", [(0.005, 8), (0.05, 8), (0.1, 16)])
+def test_bucket_path_equals_sort_path_and_reference(voxel, bs, monkeypatch):
+    """Single frames take the per-block bucket path (count / offsets / scatter / LDS sort + ordered fold), larger inputs and
+    HV_VG_PATH=sort the device-wide radix sort.  Both fold a voxel's points in point order: identical bits, and identical
+    to the compiled reference.  Coarse voxels (5 cm x 8 = 40 cm blocks, 10 cm x 16 = 1.6 m blocks) put far more than the
+    4096-entry LDS window into one block: the windowed fold of oversized buckets is covered too."""
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    s, frames = synthetic_frames("synthetic_640x480_5mm", 20, 3)
+    ref = make_oracle(voxel, bs)
+    grids = {}
+    for path in ("bucket", "sort"):
+        if path == "sort":
+            monkeypatch.setenv("HV_VG_PATH", "sort")
+        g = VoxelBlockGrid(voxel, bs, max_blocks=1 << 17, max_points=1 << 19)
+        for depth, rgb, T in frames:
+            g.integrate_rgbd(depth, rgb, *s.intrinsics, T, max_depth=4.0)
+        grids[path] = g
+    for depth, rgb, T in frames:
+        pts, cols, _ = hp.frame_to_world_f32(depth, rgb, *s.intrinsics, T, 4.0)
+        ref.integrate(pts, cols)
+    assert_same_grid(grids["bucket"], ref)
+    for a, b in zip(grids["bucket"].dump(), grids["sort"].dump()):
+        np.testing.assert_array_equal(a, b)
+    if voxel >= 0.05:  # blocks really caught more points than one LDS window: 3 frames x 300 k points over few blocks
+        assert grids["bucket"].dump()[2].sum(axis=1).max() > 3 * 4096
