@@ -128,50 +128,99 @@ __global__ __launch_bounds__(256) void k_vg_reduce(HvTable table, HvVoxel *__res
 static constexpr int HV_VGB_IDX_BITS = 20;
 static constexpr int HV_VGB_CAP = 4096; // entries of one bucket sorted in LDS at a time
 
+// Lanes of a wave that hold the same slot form a group (neighbouring pixels fall into the same block: a wave of 64 points
+// meets a handful of distinct slots).  One lane per group - the leader - talks to memory; every member learns the group's
+// size and its own rank.  Ballot + shuffle only.
+struct HvWaveGroup {
+    bool leader;
+    int leader_lane, size, rank;
+};
+__device__ __forceinline__ HvWaveGroup hv_wave_group_by(int32_t slot) {
+    HvWaveGroup g{false, 0, 0, 0};
+    const int lane = hv_lane_id();
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    unsigned long long remaining = __ballot(slot >= 0);
+    while (remaining) {
+        const int first = __ffsll((long long)remaining) - 1;
+        const int32_t fslot = __shfl(slot, first);
+        const unsigned long long same = __ballot(slot == fslot) & remaining;
+        if (slot == fslot) {
+            g.leader = lane == first;
+            g.leader_lane = first;
+            g.size = __popcll(same);
+            g.rank = __popcll(same & lt);
+        }
+        remaining &= ~same;
+    }
+    return g;
+}
+
 __global__ __launch_bounds__(256) void k_vgb_count(HvTable table, const float *__restrict__ pts, int64_t n, HvGridParams G,
                                                     int32_t *__restrict__ pslot, uint32_t *__restrict__ plidx,
                                                     const uint32_t *__restrict__ valid_mask_keys, int32_t *__restrict__ cnt,
                                                     int32_t *__restrict__ touched, int parity) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     int32_t slot = -1;
     uint32_t lidx = 0;
-    const bool masked = valid_mask_keys != nullptr && valid_mask_keys[i] == HV_SORT_SENTINEL; // pixel rejected by the unprojection
-    if (!masked) {
-        const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
-        if (isfinite(x) && isfinite(y) && isfinite(z) && fabsf(x * G.inv_voxel_size) < 1.0e9f &&
-            fabsf(y * G.inv_voxel_size) < 1.0e9f && fabsf(z * G.inv_voxel_size) < 1.0e9f) {
-            const HvPointKey k = hv_point_key(x, y, z, G);
-            if (hv_key_in_range(k.b[0], k.b[1], k.b[2])) {
-                slot = hv_table_insert(table, hv_pack_key(k.b[0], k.b[1], k.b[2]));
-                lidx = (uint32_t)(k.l[0] + k.l[1] * G.bs + k.l[2] * G.bs * G.bs); // voxel_block.h:67-70
+    if (i < n) {
+        const bool masked = valid_mask_keys != nullptr && valid_mask_keys[i] == HV_SORT_SENTINEL; // pixel rejected by the unprojection
+        if (!masked) {
+            const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+            if (isfinite(x) && isfinite(y) && isfinite(z) && fabsf(x * G.inv_voxel_size) < 1.0e9f &&
+                fabsf(y * G.inv_voxel_size) < 1.0e9f && fabsf(z * G.inv_voxel_size) < 1.0e9f) {
+                const HvPointKey k = hv_point_key(x, y, z, G);
+                if (hv_key_in_range(k.b[0], k.b[1], k.b[2])) {
+                    slot = hv_table_insert(table, hv_pack_key(k.b[0], k.b[1], k.b[2]));
+                    lidx = (uint32_t)(k.l[0] + k.l[1] * G.bs + k.l[2] * G.bs * G.bs); // voxel_block.h:67-70
+                }
             }
+            if (slot < 0) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
         }
-        if (slot < 0) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
+        pslot[i] = slot;
+        plidx[i] = lidx;
     }
-    pslot[i] = slot;
-    plidx[i] = lidx;
-    if (slot >= 0 && atomicAdd(&cnt[slot], 1) == 0) {
+    const HvWaveGroup g = hv_wave_group_by(slot);
+    if (g.leader && atomicAdd(&cnt[slot], g.size) == 0) {
         const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0 + parity], 1);
-        touched[at] = slot; // at < allocated blocks <= max_blocks: a slot is listed once per frame
+        touched[at] = slot; // at < allocated blocks: a slot is listed once per frame
     }
 }
 
 __global__ __launch_bounds__(256) void k_vgb_offsets(HvTable table, const int32_t *__restrict__ touched, int parity,
                                                       const int32_t *__restrict__ cnt, int32_t *__restrict__ cur) {
     const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= table.counters[HV_CNT_TOUCH0 + parity]) return;
-    const int32_t slot = touched[t];
-    cur[slot] = atomicAdd(&table.counters[HV_CNT_AUX], cnt[slot]);
+    const bool live = t < table.counters[HV_CNT_TOUCH0 + parity];
+    const int32_t slot = live ? touched[t] : 0;
+    const int32_t c = live ? cnt[slot] : 0;
+    // bucket ranges from one global cursor: wave prefix sum, one atomic per wave
+    const int lane = hv_lane_id();
+    int32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < HV_WAVE; o <<= 1) {
+        const int32_t up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    const int32_t total = __shfl(incl, HV_WAVE - 1);
+    int32_t base = 0;
+    if (lane == HV_WAVE - 1 && total > 0) base = atomicAdd(&table.counters[HV_CNT_AUX], total);
+    base = __shfl(base, HV_WAVE - 1);
+    if (live) cur[slot] = base + incl - c;
+    // largest bucket of the frame (the host picks the fold kernel of the NEXT frame by it)
+    int32_t mx = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if (lane == 0 && mx > 0) atomicMax(&table.counters[HV_CNT_OUT2], mx);
 }
 
 __global__ __launch_bounds__(256) void k_vgb_scatter(const int32_t *__restrict__ pslot, const uint32_t *__restrict__ plidx, int64_t n,
                                                       int32_t *__restrict__ cur, uint32_t *__restrict__ entries) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t slot = pslot[i];
-    if (slot < 0) return;
-    entries[atomicAdd(&cur[slot], 1)] = (plidx[i] << HV_VGB_IDX_BITS) | (uint32_t)i;
+    const int32_t slot = i < n ? pslot[i] : -1;
+    const HvWaveGroup g = hv_wave_group_by(slot);
+    int32_t base = 0;
+    if (g.leader) base = atomicAdd(&cur[slot], g.size);
+    base = __shfl(base, g.leader_lane);
+    if (slot >= 0) entries[base + g.rank] = (plidx[i] << HV_VGB_IDX_BITS) | (uint32_t)i;
 }
 
 // update_voxel_direct (voxel_block_grid.hpp:524-614) folded over the sorted entries s[0 .. m) of one block
@@ -227,6 +276,126 @@ __device__ __forceinline__ void hv_vgb_bitonic(uint32_t *s, int m2) { // ascendi
     }
 }
 
+// Wave-level counterparts of the two helpers above: a wave owns its LDS window, lanes synchronise with wave barriers only.
+__device__ __forceinline__ void hv_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void hv_vgb_bitonic_wave(uint32_t *s, int m2) { // ascending, m2 a power of two >= 64
+    const int lane = hv_lane_id();
+    for (int k = 2; k <= m2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < m2; t += HV_WAVE) {
+                const int x = t ^ j;
+                if (x > t) {
+                    const uint32_t a = s[t], b = s[x];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) {
+                        s[t] = b;
+                        s[x] = a;
+                    }
+                }
+            }
+            hv_wave_lds_sync();
+        }
+    }
+}
+template <int COLOR_KIND>
+__device__ __forceinline__ void hv_vgb_fold_sorted_wave(const uint32_t *s, int m, HvVoxel *__restrict__ block, const float *__restrict__ pts,
+                                                        const void *__restrict__ cols) {
+    const float inv_255 = 1.0f / 255.0f; // voxel_data.h:82
+    for (int e = hv_lane_id(); e < m; e += HV_WAVE) {
+        const uint32_t lidx = s[e] >> HV_VGB_IDX_BITS;
+        if (e > 0 && (s[e - 1] >> HV_VGB_IDX_BITS) == lidx) continue; // not the head of its voxel's run
+        HvVoxel *vx = block + lidx;
+        HvVoxel acc = *vx;
+        int j = e;
+        do {
+            const int64_t p = s[j] & ((1u << HV_VGB_IDX_BITS) - 1u);
+            acc.pos[0] += pts[p * 3 + 0];
+            acc.pos[1] += pts[p * 3 + 1];
+            acc.pos[2] += pts[p * 3 + 2];
+            if (COLOR_KIND == HV_COLOR_U8) {
+                const uint8_t *c = (const uint8_t *)cols + p * 3;
+                acc.col[0] += (float)c[0] * inv_255;
+                acc.col[1] += (float)c[1] * inv_255;
+                acc.col[2] += (float)c[2] * inv_255;
+            } else if (COLOR_KIND == HV_COLOR_F32) {
+                const float *c = (const float *)cols + p * 3;
+                acc.col[0] += c[0];
+                acc.col[1] += c[1];
+                acc.col[2] += c[2];
+            }
+            acc.count = acc.count == 0 ? 1 : acc.count + 1;
+            ++j;
+        } while (j < m && (s[j] >> HV_VGB_IDX_BITS) == lidx);
+        *vx = acc;
+    }
+}
+
+// One WAVE per touched slot (a frame's buckets hold a few dozen points: a 256-thread workgroup with block barriers per bucket
+// spends its time in barriers).  Buckets of up to HV_VGB_WCAP entries are sorted in the wave's LDS window at once, larger ones
+// in point-index windows of HV_VGB_WCAP (correct for any size; when the previous frame had such buckets the host launches the
+// workgroup form k_vgb_fold instead).
+static constexpr int HV_VGB_WCAP = 1024;
+template <int COLOR_KIND>
+__global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *__restrict__ pool, const int32_t *__restrict__ touched,
+                                                        int parity, int32_t *__restrict__ cnt, const int32_t *__restrict__ cur,
+                                                        const uint32_t *__restrict__ entries, HvGridParams G, const float *__restrict__ pts,
+                                                        const void *__restrict__ cols, int64_t n_points, HvStatus *status, int32_t status_seq) {
+    __shared__ uint32_t s_all[4][HV_VGB_WCAP];
+    const int n_touched = table.counters[HV_CNT_TOUCH0 + parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        table.counters[HV_CNT_TOUCH0 + (parity ^ 1)] = 0; // the next frame's list
+        table.counters[HV_CNT_AUX] = 0;                   // ... and bucket cursor
+        status->pad = table.counters[HV_CNT_OUT2];        // largest bucket of this frame
+        table.counters[HV_CNT_OUT2] = 0;
+        hv_publish_status(table, status, status_seq);
+    }
+    const int wave = threadIdx.x >> 6, lane = hv_lane_id();
+    uint32_t *s = s_all[wave];
+    for (int t = blockIdx.x * 4 + wave; t < n_touched; t += gridDim.x * 4) {
+        const int32_t slot = touched[t];
+        const int32_t nb = cnt[slot];
+        const int32_t start = cur[slot] - nb;
+        const int32_t idx = table.vals[slot];
+        hv_wave_lds_sync(); // the window of the previous bucket is no longer read
+        if (lane == 0) cnt[slot] = 0; // clean for the next frame
+        if (idx < 0) continue;        // (the block did not get a pool slot: overflow, reported by the caller)
+        HvVoxel *block = pool + (int64_t)idx * G.nvox;
+        if (nb <= HV_VGB_WCAP) {
+            int m2 = HV_WAVE;
+            while (m2 < nb) m2 <<= 1;
+            for (int e = lane; e < m2; e += HV_WAVE) s[e] = e < nb ? entries[start + e] : 0xFFFFFFFFu;
+            hv_wave_lds_sync();
+            hv_vgb_bitonic_wave(s, m2);
+            hv_vgb_fold_sorted_wave<COLOR_KIND>(s, nb, block, pts, cols);
+            continue;
+        }
+        for (int64_t w = 0; w < n_points; w += HV_VGB_WCAP) { // point-index windows, ascending: a voxel's points stay in order
+            hv_wave_lds_sync();
+            int m = 0;
+            for (int e0 = 0; e0 < nb; e0 += HV_WAVE) {
+                const int e = e0 + lane;
+                const uint32_t ent = e < nb ? entries[start + e] : 0u;
+                const int64_t p = ent & ((1u << HV_VGB_IDX_BITS) - 1u);
+                const bool in = e < nb && p >= w && p < w + HV_VGB_WCAP;
+                const unsigned long long bm = __ballot(in);
+                const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+                if (in) s[m + __popcll(bm & lt)] = ent;
+                m += __popcll(bm);
+            }
+            if (m == 0) continue;
+            int m2 = HV_WAVE;
+            while (m2 < m) m2 <<= 1;
+            for (int e = m + lane; e < m2; e += HV_WAVE) s[e] = 0xFFFFFFFFu;
+            hv_wave_lds_sync();
+            hv_vgb_bitonic_wave(s, m2);
+            hv_vgb_fold_sorted_wave<COLOR_KIND>(s, m, block, pts, cols);
+        }
+    }
+}
+
 template <int COLOR_KIND>
 __global__ __launch_bounds__(256) void k_vgb_fold(HvTable table, HvVoxel *__restrict__ pool, const int32_t *__restrict__ touched,
                                                    int parity, int32_t *__restrict__ cnt, const int32_t *__restrict__ cur,
@@ -238,6 +407,8 @@ __global__ __launch_bounds__(256) void k_vgb_fold(HvTable table, HvVoxel *__rest
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         table.counters[HV_CNT_TOUCH0 + (parity ^ 1)] = 0; // the next frame's list
         table.counters[HV_CNT_AUX] = 0;                   // ... and bucket cursor
+        status->pad = table.counters[HV_CNT_OUT2];        // largest bucket of this frame
+        table.counters[HV_CNT_OUT2] = 0;
         hv_publish_status(table, status, status_seq);
     }
     for (int t = blockIdx.x; t < n_touched; t += gridDim.x) {
@@ -494,6 +665,7 @@ static int ensure_bucket_buffers(hv_volume *v) {
     HV_HIP(hipMemsetAsync(v->vg_cnt, 0, sizeof(int32_t) * v->table_capacity, v->stream));
     HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
     HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_AUX], 0, sizeof(int32_t), v->stream));
+    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT2], 0, sizeof(int32_t), v->stream));
     v->vg_cap = v->table_capacity;
     v->vg_parity = 0;
     return HV_OK;
@@ -533,11 +705,21 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
         hipLaunchKernelGGL(k_vgb_scatter, dim3(blocks), dim3(256), 0, v->stream, (const int32_t *)v->sort_vals_in,
                            (const uint32_t *)v->sort_keys_out, n, v->vg_cur, v->sort_keys_in);
         const int32_t seq = hv_next_status_seq(v);
-        const unsigned fold_grid = (unsigned)std::min<int64_t>(std::max<int64_t>(n / 32, 256), 16384);
+        // one wave per bucket, or - when the last finished frame had buckets beyond a wave's LDS window (coarse voxels, very
+        // close surfaces) - one workgroup per bucket; both are exact for any bucket size
+        const bool big = v->h_status->pad > HV_VGB_WCAP;
+        const unsigned fold_grid = (unsigned)std::min<int64_t>(std::max<int64_t>(n / (big ? 32 : 128), 256), 16384);
 #define HV_LAUNCH_FOLD(CK)                                                                                             \
-    hipLaunchKernelGGL(k_vgb_fold<CK>, dim3(fold_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool,          \
-                       (const int32_t *)v->vg_touched, parity, v->vg_cnt, (const int32_t *)v->vg_cur,                   \
-                       (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, n, v->d_status, seq)
+    do {                                                                                                               \
+        if (big)                                                                                                       \
+            hipLaunchKernelGGL(k_vgb_fold<CK>, dim3(fold_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool,  \
+                               (const int32_t *)v->vg_touched, parity, v->vg_cnt, (const int32_t *)v->vg_cur,           \
+                               (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, n, v->d_status, seq);               \
+        else                                                                                                           \
+            hipLaunchKernelGGL(k_vgb_fold_wave<CK>, dim3(fold_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool, \
+                               (const int32_t *)v->vg_touched, parity, v->vg_cnt, (const int32_t *)v->vg_cur,           \
+                               (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, n, v->d_status, seq);               \
+    } while (0)
         if (color_kind == HV_COLOR_U8) HV_LAUNCH_FOLD(HV_COLOR_U8); else if (color_kind == HV_COLOR_F32) HV_LAUNCH_FOLD(HV_COLOR_F32); else HV_LAUNCH_FOLD(HV_COLOR_NONE);
 #undef HV_LAUNCH_FOLD
         hv_profile_end(v, n);
