@@ -12,6 +12,7 @@ struct HvGridParams {
     int32_t bs;           // block_size
     int32_t nvox;         // bs^3
     int32_t local_bits;
+    int32_t bs_shift;     // log2(bs) when bs is a power of two (the default 8 and 16), else -1
 };
 
 // floor_div, voxel_hashing.h:139-142

@@ -35,8 +35,11 @@ __device__ __forceinline__ HvPointKey hv_point_key(float x, float y, float z, co
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         k.v[a] = (int32_t)f[a];
-        k.b[a] = hv_floor_div(k.v[a], G.bs);
-        k.l[a] = (int32_t)((int64_t)k.v[a] - (int64_t)k.b[a] * G.bs);
+        // floor_div (voxel_hashing.h:139-142) without the 64-bit division (3 per point: most of the key kernel's time): an
+        // arithmetic shift for power-of-two blocks, else floor(v * (1 / bs) + 2^-10) in double - exact for |v| < 2^31 and
+        // bs <= 16: a non-integer v / bs is at least 1/16 away from an integer, the product's error is below 2^-20
+        k.b[a] = G.bs_shift >= 0 ? (k.v[a] >> G.bs_shift) : (int32_t)floor(fma((double)k.v[a], 1.0 / (double)G.bs, 0x1p-10));
+        k.l[a] = k.v[a] - k.b[a] * G.bs; // in [0, bs): no overflow (|b * bs| <= |v| + bs)
     }
     return k;
 }
@@ -338,6 +341,7 @@ __device__ __forceinline__ void hv_vgb_fold_sorted_wave(const uint32_t *s, int m
 // in point-index windows of HV_VGB_WCAP (correct for any size; when the previous frame had such buckets the host launches the
 // workgroup form k_vgb_fold instead).
 static constexpr int HV_VGB_WCAP = 1024;
+static constexpr int HV_VGB_RANK = 256; // buckets up to this size are rank-sorted (<= 4 entries per lane)
 template <int COLOR_KIND>
 __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *__restrict__ pool, const int32_t *__restrict__ touched,
                                                         int parity, int32_t *__restrict__ cnt, const int32_t *__restrict__ cur,
@@ -363,6 +367,32 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
         if (lane == 0) cnt[slot] = 0; // clean for the next frame
         if (idx < 0) continue;        // (the block did not get a pool slot: overflow, reported by the caller)
         HvVoxel *block = pool + (int64_t)idx * G.nvox;
+        if (nb <= HV_VGB_RANK) {
+            // small bucket (the common case: a few dozen points): every lane ranks its <= 4 entries against the whole bucket
+            // (LDS broadcast reads, entries are distinct) and drops them at their rank - no passes, one synchronisation
+            uint32_t mine[HV_VGB_RANK / HV_WAVE];
+            int rank[HV_VGB_RANK / HV_WAVE];
+#pragma unroll
+            for (int q = 0; q < HV_VGB_RANK / HV_WAVE; ++q) {
+                const int e = lane + q * HV_WAVE;
+                mine[q] = e < nb ? entries[start + e] : 0xFFFFFFFFu;
+                rank[q] = 0;
+                if (e < nb) s[e] = mine[q];
+            }
+            hv_wave_lds_sync();
+            for (int j = 0; j < nb; ++j) {
+                const uint32_t o = s[j];
+#pragma unroll
+                for (int q = 0; q < HV_VGB_RANK / HV_WAVE; ++q) rank[q] += o < mine[q];
+            }
+            hv_wave_lds_sync();
+#pragma unroll
+            for (int q = 0; q < HV_VGB_RANK / HV_WAVE; ++q)
+                if (lane + q * HV_WAVE < nb) s[rank[q]] = mine[q];
+            hv_wave_lds_sync();
+            hv_vgb_fold_sorted_wave<COLOR_KIND>(s, nb, block, pts, cols);
+            continue;
+        }
         if (nb <= HV_VGB_WCAP) {
             int m2 = HV_WAVE;
             while (m2 < nb) m2 <<= 1;
@@ -636,6 +666,9 @@ static HvGridParams grid_params(const hv_volume *v) {
     G.bs = v->cfg.block_size;
     G.nvox = G.bs * G.bs * G.bs;
     G.local_bits = v->local_bits;
+    G.bs_shift = -1;
+    for (int sh = 0; sh <= 4; ++sh)
+        if ((1 << sh) == G.bs) G.bs_shift = sh;
     return G;
 }
 
