@@ -182,20 +182,25 @@ __global__ __launch_bounds__(256) void k_vgb_count(HvTable table, const float *_
         pslot[i] = slot;
         plidx[i] = lidx;
     }
+    // one fire-and-forget atomic per (wave, slot); the list of touched slots is built by k_vgb_offsets from the allocated
+    // blocks (an append here would be ~7000 returning atomics on ONE counter per frame: 20 of this kernel's 29 us)
     const HvWaveGroup g = hv_wave_group_by(slot);
-    if (g.leader && atomicAdd(&cnt[slot], g.size) == 0) {
-        const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0 + parity], 1);
-        touched[at] = slot; // at < allocated blocks: a slot is listed once per frame
-    }
+    if (g.leader) atomicAdd(&cnt[slot], g.size);
 }
 
-__global__ __launch_bounds__(256) void k_vgb_offsets(HvTable table, const int32_t *__restrict__ touched, int parity,
+// 1 thread / allocated block: blocks that received points this frame take their bucket range from the global cursor and
+// enter the frame's touched list - both with one atomic per wave (prefix sums inside the wave).
+__global__ __launch_bounds__(256) void k_vgb_offsets(HvTable table, int32_t *__restrict__ touched, int parity,
                                                       const int32_t *__restrict__ cnt, int32_t *__restrict__ cur) {
-    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = t < table.counters[HV_CNT_TOUCH0 + parity];
-    const int32_t slot = live ? touched[t] : 0;
-    const int32_t c = live ? cnt[slot] : 0;
-    // bucket ranges from one global cursor: wave prefix sum, one atomic per wave
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t n_blocks = table.counters[HV_CNT_BLOCKS];
+    if (n_blocks > table.max_blocks) n_blocks = table.max_blocks;
+    int32_t slot = -1, c = 0;
+    if (b < n_blocks) {
+        slot = hv_table_find(table, table.block_keys[b]);
+        c = slot >= 0 ? cnt[slot] : 0;
+    }
+    const bool live = c > 0;
     const int lane = hv_lane_id();
     int32_t incl = c;
 #pragma unroll
@@ -204,10 +209,19 @@ __global__ __launch_bounds__(256) void k_vgb_offsets(HvTable table, const int32_
         if (lane >= o) incl += up;
     }
     const int32_t total = __shfl(incl, HV_WAVE - 1);
-    int32_t base = 0;
-    if (lane == HV_WAVE - 1 && total > 0) base = atomicAdd(&table.counters[HV_CNT_AUX], total);
+    const unsigned long long lm = __ballot(live);
+    int32_t base = 0, lbase = 0;
+    if (lane == HV_WAVE - 1 && total > 0) {
+        base = atomicAdd(&table.counters[HV_CNT_AUX], total);
+        lbase = atomicAdd(&table.counters[HV_CNT_TOUCH0 + parity], (int32_t)__popcll(lm));
+    }
     base = __shfl(base, HV_WAVE - 1);
-    if (live) cur[slot] = base + incl - c;
+    lbase = __shfl(lbase, HV_WAVE - 1);
+    if (live) {
+        cur[slot] = base + incl - c;
+        const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        touched[lbase + __popcll(lm & lt)] = slot;
+    }
     // largest bucket of the frame (the host picks the fold kernel of the NEXT frame by it)
     int32_t mx = c;
 #pragma unroll
@@ -731,9 +745,10 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
             if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
         }
         v->vg_parity ^= 1;
-        // the touched list is at most the number of allocated blocks; its length stays on the device
-        const unsigned list_blocks = (unsigned)((std::min<int64_t>(n, v->cfg.max_blocks) + 255) / 256);
-        hipLaunchKernelGGL(k_vgb_offsets, dim3(list_blocks), dim3(256), 0, v->stream, v->table, (const int32_t *)v->vg_touched, parity,
+        // one thread per allocated block (their number stays on the device: the grid covers what the host knows plus what this
+        // frame can add - a point opens at most one block)
+        const unsigned list_blocks = (unsigned)((std::min<int64_t>(v->known_blocks + 2 * v->max_new_per_call + n, v->cfg.max_blocks) + 255) / 256);
+        hipLaunchKernelGGL(k_vgb_offsets, dim3(list_blocks), dim3(256), 0, v->stream, v->table, v->vg_touched, parity,
                            (const int32_t *)v->vg_cnt, v->vg_cur);
         hipLaunchKernelGGL(k_vgb_scatter, dim3(blocks), dim3(256), 0, v->stream, (const int32_t *)v->sort_vals_in,
                            (const uint32_t *)v->sort_keys_out, n, v->vg_cur, v->sort_keys_in);
