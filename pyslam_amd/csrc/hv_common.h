@@ -303,6 +303,7 @@ struct hv_volume {
     // per-frame bucket path of the VOXEL_GRID mode (hv_voxel_grid.hip): per-slot point counts / bucket cursors, the list of
     // slots a frame touches; sized by the table, re-allocated when it grows
     int32_t *vg_cnt = nullptr, *vg_cur = nullptr, *vg_touched = nullptr;
+    unsigned long long *vg_cursor = nullptr; // [2] per frame parity: bucket cursor (low 32 bits) | touched-list length (high 32 bits)
     uint64_t vg_cap = 0;
     int vg_parity = 0;               // which of the two touched-list counters the next frame appends to
     float *scratch_points = nullptr; // [max_points*3]

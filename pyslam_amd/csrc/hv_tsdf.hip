@@ -827,13 +827,35 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
                        // frame bit (skip the atomic when another wave of this frame already set it)
                        if (!(seen & fbit)) atomicOr(&frame_mask[slot], fbit);
                        if (stamped != batch_stamp) {
-                           const int32_t old = atomicExch(&stamp[slot], batch_stamp);
-                           if (old != batch_stamp) {
-                               const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0], 1);
-                               if (at < table.max_blocks) list[at] = slot;
+                           if (list == nullptr) {
+                               // the union list is built afterwards from the allocated units (k_tsdf_batch_list): an append here
+                               // is one returning atomic on a single counter per first touch - thousands per batch, serialised
+                               __hip_atomic_store(&stamp[slot], batch_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                           } else {
+                               const int32_t old = atomicExch(&stamp[slot], batch_stamp);
+                               if (old != batch_stamp) {
+                                   const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0], 1);
+                                   if (at < table.max_blocks) list[at] = slot;
+                               }
                            }
                        }
                    });
+}
+
+// Union list of a batch from the allocated units: unit b belongs to it iff its slot carries the batch's stamp.  One thread per
+// unit, one atomic per wave (ballot + prefix), list in pool order.
+__global__ __launch_bounds__(256) void k_tsdf_batch_list(HvTable table, const int32_t *__restrict__ stamp, int batch_stamp,
+                                                          int32_t *__restrict__ list) {
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t n_blocks = table.counters[HV_CNT_BLOCKS];
+    if (n_blocks > table.max_blocks) n_blocks = table.max_blocks;
+    int32_t slot = -1;
+    if (b < n_blocks) {
+        slot = hv_table_find(table, table.block_keys[b]);
+        if (slot >= 0 && stamp[slot] != batch_stamp) slot = -1;
+    }
+    const int32_t at = hv_wave_append(&table.counters[HV_CNT_TOUCH0], slot >= 0);
+    if (slot >= 0) list[at] = slot;
 }
 
 // Column mapping: lane -> one (x, y) column of the unit, wave -> 64 consecutive columns (4 x-values: word index
@@ -1671,12 +1693,14 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         // parity's count behind
         const int n_prep_blocks = (int)((npx + 1023) / 1024); // 4 pixels per thread
         const int n_touch_blocks = (hv_touch_patches(width, height, v->cfg.depth_sampling_stride) + 3) / 4;
+        // HV_TSDF_LIST=touch: the touch pass appends first-touched units to the union list itself (round-1 form, A/B)
+        const bool list_in_touch = getenv("HV_TSDF_LIST") && strcmp(getenv("HV_TSDF_LIST"), "touch") == 0;
         for (int attempt = 0;; ++attempt) {
             if (!v->touch_counters_clean) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
             v->touch_counters_clean = true;
             hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3((n_prep_blocks + n_touch_blocks) * B), dim3(256), 0, v->stream,
-                               v->table, v->touched_stamp, (unsigned long long *)v->touched_mask, v->touched_list, batch_stamp,
-                               (const char *)d_depth + npx * dsz * (size_t)f0, (int64_t)(npx * dsz),
+                               v->table, v->touched_stamp, (unsigned long long *)v->touched_mask, list_in_touch ? v->touched_list : nullptr,
+                               batch_stamp, (const char *)d_depth + npx * dsz * (size_t)f0, (int64_t)(npx * dsz),
                                (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks, n_touch_blocks, B);
             if (!checked) break;
             // checked mode: nothing is fused before every unit of the batch has its pool slot; if some claims did not fit, the
@@ -1687,6 +1711,11 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
             v->frame_counter += 1;
             batch_stamp = v->frame_counter;
             v->touch_counters_clean = false;
+        }
+        if (!list_in_touch) {
+            // one thread per pool slot (how many are allocated is only known on the device; threads beyond leave at once)
+            hipLaunchKernelGGL(k_tsdf_batch_list, dim3((unsigned)((v->cfg.max_blocks + 255) / 256)), dim3(256), 0, v->stream, v->table,
+                               (const int32_t *)v->touched_stamp, batch_stamp, v->touched_list);
         }
         hv_profile_begin(v);
         // sweep form: 2 = k_tsdf_sweep (production: float2 projection chain, prefetched frame constants), 1 = first form (A/B, and

@@ -113,6 +113,49 @@ __global__ __launch_bounds__(256) void k_vg_reduce(HvTable table, HvVoxel *__res
     *vx = acc;
 }
 
+// depth2pointcloud (pyslam/utilities/depth.py:45-85) + world transform
+// (volumetric_integrator_voxel_grid.py:262-281), f64 arithmetic in a fixed order, rounded to f32.
+struct HvUnprojectParams {
+    double cx, cy, inv_fx, inv_fy;
+    double Rwc[9], twc[3];
+    float min_depth, max_depth, depth_scale_f;
+    int32_t H, W, depth_is_u16;
+};
+
+__device__ __forceinline__ bool hv_unproject_pixel(const HvUnprojectParams &U, const void *__restrict__ depth_raw,
+                                                   const uint8_t *__restrict__ rgb, int64_t i, float pt[3], float col[3]) {
+    float d = U.depth_is_u16 ? (float)((const uint16_t *)depth_raw)[i] : ((const float *)depth_raw)[i];
+    if (U.depth_scale_f != 1.0f) d = d / U.depth_scale_f;
+    if (!((d > U.min_depth) && (d < U.max_depth))) return false;
+    const int row = (int)((uint32_t)i / (uint32_t)U.W), col_px = (int)((uint32_t)i - (uint32_t)row * (uint32_t)U.W); // i < 2^31 (max_points)
+    const double z = (double)d;
+    const double x = ((double)col_px - U.cx) * z * U.inv_fx;
+    const double y = ((double)row - U.cy) * z * U.inv_fy;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pt[r] = (float)(((U.Rwc[r * 3 + 0] * x + U.Rwc[r * 3 + 1] * y) + U.Rwc[r * 3 + 2] * z) + U.twc[r]);
+    const uint8_t *c = rgb + i * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) col[k] = (float)((double)c[k] / 255.0);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_vg_unproject(const void *__restrict__ depth_raw,
+                                                       const uint8_t *__restrict__ rgb, HvUnprojectParams U,
+                                                       float *__restrict__ pts_out, float *__restrict__ cols_out,
+                                                       uint32_t *__restrict__ valid_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)U.H * U.W) return;
+    float pt[3], col[3];
+    const bool valid = hv_unproject_pixel(U, depth_raw, rgb, i, pt, col);
+    valid_out[i] = valid ? 0u : HV_SORT_SENTINEL;
+    if (!valid) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        pts_out[i * 3 + k] = pt[k];
+        cols_out[i * 3 + k] = col[k];
+    }
+}
+
 // ================================================================================================
 // Per-frame bucket path (production for single frames).  The device-wide radix sort above is 18 small launches and 115 of
 // the 140 us a 640x480 frame takes (profiles/r01): a frame's points only have to be grouped per BLOCK (a few thousand
@@ -158,17 +201,38 @@ __device__ __forceinline__ HvWaveGroup hv_wave_group_by(int32_t slot) {
     return g;
 }
 
-__global__ __launch_bounds__(256) void k_vgb_count(HvTable table, const float *__restrict__ pts, int64_t n, HvGridParams G,
+// FUSED: the points do not exist yet - the thread unprojects its pixel (k_vg_unproject's arithmetic), stores point and colour
+// for the fold and goes on with the key: one launch and one pass over the points less per RGB-D frame.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_vgb_count(HvTable table, float *__restrict__ pts, int64_t n, HvGridParams G,
                                                     int32_t *__restrict__ pslot, uint32_t *__restrict__ plidx,
                                                     const uint32_t *__restrict__ valid_mask_keys, int32_t *__restrict__ cnt,
-                                                    int32_t *__restrict__ touched, int parity) {
+                                                    HvUnprojectParams U, const void *__restrict__ depth_raw,
+                                                    const uint8_t *__restrict__ rgb, float *__restrict__ cols_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int32_t slot = -1;
     uint32_t lidx = 0;
     if (i < n) {
-        const bool masked = valid_mask_keys != nullptr && valid_mask_keys[i] == HV_SORT_SENTINEL; // pixel rejected by the unprojection
+        bool masked;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (FUSED) {
+            float pt[3], col[3];
+            masked = !hv_unproject_pixel(U, depth_raw, rgb, i, pt, col);
+            if (!masked) {
+                x = pt[0]; y = pt[1]; z = pt[2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    pts[i * 3 + k] = pt[k];
+                    cols_out[i * 3 + k] = col[k];
+                }
+            }
+        } else {
+            masked = valid_mask_keys != nullptr && valid_mask_keys[i] == HV_SORT_SENTINEL; // pixel rejected by the unprojection
+            if (!masked) {
+                x = pts[i * 3 + 0]; y = pts[i * 3 + 1]; z = pts[i * 3 + 2];
+            }
+        }
         if (!masked) {
-            const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
             if (isfinite(x) && isfinite(y) && isfinite(z) && fabsf(x * G.inv_voxel_size) < 1.0e9f &&
                 fabsf(y * G.inv_voxel_size) < 1.0e9f && fabsf(z * G.inv_voxel_size) < 1.0e9f) {
                 const HvPointKey k = hv_point_key(x, y, z, G);
@@ -190,7 +254,8 @@ __global__ __launch_bounds__(256) void k_vgb_count(HvTable table, const float *_
 
 // 1 thread / allocated block: blocks that received points this frame take their bucket range from the global cursor and
 // enter the frame's touched list - both with one atomic per wave (prefix sums inside the wave).
-__global__ __launch_bounds__(256) void k_vgb_offsets(HvTable table, int32_t *__restrict__ touched, int parity,
+static constexpr int HV_VGB_WCAP_DECL = 1024; // == HV_VGB_WCAP (defined with the wave fold below)
+__global__ __launch_bounds__(256) void k_vgb_offsets(HvTable table, int32_t *__restrict__ touched, unsigned long long *__restrict__ cursor_and_len,
                                                       const int32_t *__restrict__ cnt, int32_t *__restrict__ cur) {
     const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     int32_t n_blocks = table.counters[HV_CNT_BLOCKS];
@@ -210,23 +275,18 @@ __global__ __launch_bounds__(256) void k_vgb_offsets(HvTable table, int32_t *__r
     }
     const int32_t total = __shfl(incl, HV_WAVE - 1);
     const unsigned long long lm = __ballot(live);
-    int32_t base = 0, lbase = 0;
-    if (lane == HV_WAVE - 1 && total > 0) {
-        base = atomicAdd(&table.counters[HV_CNT_AUX], total);
-        lbase = atomicAdd(&table.counters[HV_CNT_TOUCH0 + parity], (int32_t)__popcll(lm));
-    }
-    base = __shfl(base, HV_WAVE - 1);
-    lbase = __shfl(lbase, HV_WAVE - 1);
+    // bucket cursor (low 32 bits) and list length (high 32 bits) move together: ONE returning atomic per wave
+    unsigned long long got = 0ull;
+    if (lane == HV_WAVE - 1 && total > 0)
+        got = atomicAdd(cursor_and_len, (unsigned long long)(uint32_t)total | ((unsigned long long)__popcll(lm) << 32));
+    got = __shfl(got, HV_WAVE - 1);
     if (live) {
-        cur[slot] = base + incl - c;
+        cur[slot] = (int32_t)(uint32_t)got + incl - c;
         const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-        touched[lbase + __popcll(lm & lt)] = slot;
+        touched[(int32_t)(got >> 32) + __popcll(lm & lt)] = slot;
     }
-    // largest bucket of the frame (the host picks the fold kernel of the NEXT frame by it)
-    int32_t mx = c;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
-    if (lane == 0 && mx > 0) atomicMax(&table.counters[HV_CNT_OUT2], mx);
+    // a bucket beyond a wave's LDS window: tell the host (it picks the fold kernel of the NEXT frame by it)
+    if (c > HV_VGB_WCAP_DECL) atomicMax(&table.counters[HV_CNT_OUT2], c);
 }
 
 __global__ __launch_bounds__(256) void k_vgb_scatter(const int32_t *__restrict__ pslot, const uint32_t *__restrict__ plidx, int64_t n,
@@ -354,18 +414,18 @@ __device__ __forceinline__ void hv_vgb_fold_sorted_wave(const uint32_t *s, int m
 // spends its time in barriers).  Buckets of up to HV_VGB_WCAP entries are sorted in the wave's LDS window at once, larger ones
 // in point-index windows of HV_VGB_WCAP (correct for any size; when the previous frame had such buckets the host launches the
 // workgroup form k_vgb_fold instead).
-static constexpr int HV_VGB_WCAP = 1024;
+static constexpr int HV_VGB_WCAP = HV_VGB_WCAP_DECL;
 static constexpr int HV_VGB_RANK = 256; // buckets up to this size are rank-sorted (<= 4 entries per lane)
 template <int COLOR_KIND>
 __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *__restrict__ pool, const int32_t *__restrict__ touched,
-                                                        int parity, int32_t *__restrict__ cnt, const int32_t *__restrict__ cur,
+                                                        int parity, unsigned long long *__restrict__ cursor_and_len, int32_t *__restrict__ cnt,
+                                                        const int32_t *__restrict__ cur,
                                                         const uint32_t *__restrict__ entries, HvGridParams G, const float *__restrict__ pts,
                                                         const void *__restrict__ cols, int64_t n_points, HvStatus *status, int32_t status_seq) {
     __shared__ uint32_t s_all[4][HV_VGB_WCAP];
-    const int n_touched = table.counters[HV_CNT_TOUCH0 + parity];
+    const int n_touched = (int)(cursor_and_len[parity] >> 32);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        table.counters[HV_CNT_TOUCH0 + (parity ^ 1)] = 0; // the next frame's list
-        table.counters[HV_CNT_AUX] = 0;                   // ... and bucket cursor
+        cursor_and_len[parity ^ 1] = 0ull;                // the next frame's bucket cursor and list length
         status->pad = table.counters[HV_CNT_OUT2];        // largest bucket of this frame
         table.counters[HV_CNT_OUT2] = 0;
         hv_publish_status(table, status, status_seq);
@@ -442,15 +502,15 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
 
 template <int COLOR_KIND>
 __global__ __launch_bounds__(256) void k_vgb_fold(HvTable table, HvVoxel *__restrict__ pool, const int32_t *__restrict__ touched,
-                                                   int parity, int32_t *__restrict__ cnt, const int32_t *__restrict__ cur,
+                                                   int parity, unsigned long long *__restrict__ cursor_and_len, int32_t *__restrict__ cnt,
+                                                   const int32_t *__restrict__ cur,
                                                    const uint32_t *__restrict__ entries, HvGridParams G, const float *__restrict__ pts,
                                                    const void *__restrict__ cols, int64_t n_points, HvStatus *status, int32_t status_seq) {
     __shared__ uint32_t s[HV_VGB_CAP];
     __shared__ int s_m;
-    const int n_touched = table.counters[HV_CNT_TOUCH0 + parity];
+    const int n_touched = (int)(cursor_and_len[parity] >> 32);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        table.counters[HV_CNT_TOUCH0 + (parity ^ 1)] = 0; // the next frame's list
-        table.counters[HV_CNT_AUX] = 0;                   // ... and bucket cursor
+        cursor_and_len[parity ^ 1] = 0ull;                // the next frame's bucket cursor and list length
         status->pad = table.counters[HV_CNT_OUT2];        // largest bucket of this frame
         table.counters[HV_CNT_OUT2] = 0;
         hv_publish_status(table, status, status_seq);
@@ -495,40 +555,6 @@ __global__ __launch_bounds__(256) void k_vgb_fold(HvTable table, HvVoxel *__rest
             hv_vgb_fold_sorted<COLOR_KIND>(s, m, block, pts, cols);
         }
     }
-}
-
-// depth2pointcloud (pyslam/utilities/depth.py:45-85) + world transform
-// (volumetric_integrator_voxel_grid.py:262-281), f64 arithmetic in a fixed order, rounded to f32.
-struct HvUnprojectParams {
-    double cx, cy, inv_fx, inv_fy;
-    double Rwc[9], twc[3];
-    float min_depth, max_depth, depth_scale_f;
-    int32_t H, W, depth_is_u16;
-};
-
-__global__ __launch_bounds__(256) void k_vg_unproject(const void *__restrict__ depth_raw,
-                                                       const uint8_t *__restrict__ rgb, HvUnprojectParams U,
-                                                       float *__restrict__ pts_out, float *__restrict__ cols_out,
-                                                       uint32_t *__restrict__ valid_out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)U.H * U.W) return;
-    float d = U.depth_is_u16 ? (float)((const uint16_t *)depth_raw)[i] : ((const float *)depth_raw)[i];
-    if (U.depth_scale_f != 1.0f) d = d / U.depth_scale_f;
-    const bool valid = (d > U.min_depth) && (d < U.max_depth);
-    valid_out[i] = valid ? 0u : HV_SORT_SENTINEL;
-    if (!valid) return;
-    const int row = (int)(i / U.W), col = (int)(i % U.W);
-    const double z = (double)d;
-    const double x = ((double)col - U.cx) * z * U.inv_fx;
-    const double y = ((double)row - U.cy) * z * U.inv_fy;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const double w = ((U.Rwc[r * 3 + 0] * x + U.Rwc[r * 3 + 1] * y) + U.Rwc[r * 3 + 2] * z) + U.twc[r];
-        pts_out[i * 3 + r] = (float)w;
-    }
-    const uint8_t *c = rgb + i * 3;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) cols_out[i * 3 + k] = (float)((double)c[k] / 255.0);
 }
 
 // Shared predicate of get_voxels / get_voxels_in_bb / get_voxels_in_camera_frustrum / carve.
@@ -706,12 +732,12 @@ static int ensure_bucket_buffers(hv_volume *v) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
+    if (v->vg_cursor == nullptr) HV_HIP(hipMalloc((void **)&v->vg_cursor, 2 * sizeof(unsigned long long)));
+    HV_HIP(hipMemsetAsync(v->vg_cursor, 0, 2 * sizeof(unsigned long long), v->stream));
     HV_HIP(hipMalloc((void **)&v->vg_cnt, sizeof(int32_t) * v->table_capacity));
     HV_HIP(hipMalloc((void **)&v->vg_cur, sizeof(int32_t) * v->table_capacity));
     HV_HIP(hipMalloc((void **)&v->vg_touched, sizeof(int32_t) * v->table_capacity));
     HV_HIP(hipMemsetAsync(v->vg_cnt, 0, sizeof(int32_t) * v->table_capacity, v->stream));
-    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
-    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_AUX], 0, sizeof(int32_t), v->stream));
     HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT2], 0, sizeof(int32_t), v->stream));
     v->vg_cap = v->table_capacity;
     v->vg_parity = 0;
@@ -720,8 +746,16 @@ static int ensure_bucket_buffers(hv_volume *v) {
 
 // keys -> group -> ordered reduce over device-resident points/colours.  Single frames (n < 2^20 points) take the bucket path
 // (4 launches), larger inputs - the batched replay - the device-wide radix sort; HV_VG_PATH=sort forces the latter (A/B, tests).
+// `frame` != nullptr: the points do not exist yet - they are one posed RGB-D frame (device pointers + unprojection constants);
+// the bucket path unprojects inside its count kernel, the radix path launches k_vg_unproject first.
+struct HvFrameSource {
+    HvUnprojectParams U;
+    const void *d_depth;
+    const uint8_t *d_rgb;
+};
+
 static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, const void *d_cols,
-                                   int color_kind, const uint32_t *d_valid) {
+                                   int color_kind, const uint32_t *d_valid, const HvFrameSource *frame = nullptr) {
     const HvGridParams G = grid_params(v);
     const unsigned blocks = (unsigned)((n + 255) / 256);
     bool checked = false;
@@ -736,8 +770,14 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
             rc = ensure_bucket_buffers(v);
             if (rc != HV_OK) return rc;
             parity = v->vg_parity;
-            hipLaunchKernelGGL(k_vgb_count, dim3(blocks), dim3(256), 0, v->stream, v->table, d_pts, n, G, (int32_t *)v->sort_vals_in,
-                               v->sort_keys_out, d_valid, v->vg_cnt, v->vg_touched, parity);
+            if (frame)
+                hipLaunchKernelGGL(k_vgb_count<true>, dim3(blocks), dim3(256), 0, v->stream, v->table, (float *)d_pts, n, G,
+                                   (int32_t *)v->sort_vals_in, v->sort_keys_out, (const uint32_t *)nullptr, v->vg_cnt, frame->U,
+                                   frame->d_depth, frame->d_rgb, (float *)d_cols);
+            else
+                hipLaunchKernelGGL(k_vgb_count<false>, dim3(blocks), dim3(256), 0, v->stream, v->table, (float *)d_pts, n, G,
+                                   (int32_t *)v->sort_vals_in, v->sort_keys_out, d_valid, v->vg_cnt, HvUnprojectParams{},
+                                   (const void *)nullptr, (const uint8_t *)nullptr, (float *)nullptr);
             if (!checked) break;
             rc = hv_claims_fit(v); // blocks that did not fit: grow and claim again (the counts restart from clean arrays)
             if (rc == HV_OK) break;
@@ -745,10 +785,9 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
             if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
         }
         v->vg_parity ^= 1;
-        // one thread per allocated block (their number stays on the device: the grid covers what the host knows plus what this
-        // frame can add - a point opens at most one block)
-        const unsigned list_blocks = (unsigned)((std::min<int64_t>(v->known_blocks + 2 * v->max_new_per_call + n, v->cfg.max_blocks) + 255) / 256);
-        hipLaunchKernelGGL(k_vgb_offsets, dim3(list_blocks), dim3(256), 0, v->stream, v->table, v->vg_touched, parity,
+        // one thread per pool slot (how many are allocated is only known on the device; threads beyond leave at once)
+        const unsigned list_blocks = (unsigned)((v->cfg.max_blocks + 255) / 256);
+        hipLaunchKernelGGL(k_vgb_offsets, dim3(list_blocks), dim3(256), 0, v->stream, v->table, v->vg_touched, v->vg_cursor + parity,
                            (const int32_t *)v->vg_cnt, v->vg_cur);
         hipLaunchKernelGGL(k_vgb_scatter, dim3(blocks), dim3(256), 0, v->stream, (const int32_t *)v->sort_vals_in,
                            (const uint32_t *)v->sort_keys_out, n, v->vg_cur, v->sort_keys_in);
@@ -761,11 +800,11 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
     do {                                                                                                               \
         if (big)                                                                                                       \
             hipLaunchKernelGGL(k_vgb_fold<CK>, dim3(fold_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool,  \
-                               (const int32_t *)v->vg_touched, parity, v->vg_cnt, (const int32_t *)v->vg_cur,           \
+                               (const int32_t *)v->vg_touched, parity, v->vg_cursor, v->vg_cnt, (const int32_t *)v->vg_cur, \
                                (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, n, v->d_status, seq);               \
         else                                                                                                           \
             hipLaunchKernelGGL(k_vgb_fold_wave<CK>, dim3(fold_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool, \
-                               (const int32_t *)v->vg_touched, parity, v->vg_cnt, (const int32_t *)v->vg_cur,           \
+                               (const int32_t *)v->vg_touched, parity, v->vg_cursor, v->vg_cnt, (const int32_t *)v->vg_cur, \
                                (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, n, v->d_status, seq);               \
     } while (0)
         if (color_kind == HV_COLOR_U8) HV_LAUNCH_FOLD(HV_COLOR_U8); else if (color_kind == HV_COLOR_F32) HV_LAUNCH_FOLD(HV_COLOR_F32); else HV_LAUNCH_FOLD(HV_COLOR_NONE);
@@ -774,6 +813,11 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
         HV_HIP(hipGetLastError());
         v->frame_counter += 1;
         return HV_OK;
+    }
+    if (frame) { // radix path on a frame: unproject first (validity flags go straight into the sort-key input buffer)
+        hipLaunchKernelGGL(k_vg_unproject, dim3(blocks), dim3(256), 0, v->stream, frame->d_depth, frame->d_rgb, frame->U, (float *)d_pts,
+                           (float *)d_cols, v->sort_keys_out);
+        d_valid = v->sort_keys_out;
     }
     rc = ensure_sort_tmp(v, n);
     if (rc != HV_OK) return rc;
@@ -884,10 +928,8 @@ int hv_integrate_points(hv_volume *v, const float *points, int64_t n, const void
 // v->scratch_points / v->scratch_colors (float32) with the per-pixel validity flags in v->sort_keys_out.
 // d_depth_out receives the device address of the (staged) depth image.
 // k_vg_unproject of one frame already in HBM into slice [out_offset, out_offset + H*W) of the scratch arrays.
-static int unproject_device(hv_volume *v, const void *d_depth, int32_t depth_dtype, double depth_scale, const uint8_t *d_rgb,
-                            int32_t height, int32_t width, const double *intr, const double *T_cw, double min_depth,
-                            double max_depth, int64_t out_offset) {
-    const int64_t npx = (int64_t)height * width;
+static HvUnprojectParams unproject_params(int32_t depth_dtype, double depth_scale, int32_t height, int32_t width, const double *intr,
+                                          const double *T_cw, double min_depth, double max_depth) {
     HvUnprojectParams U;
     U.cx = intr[2];
     U.cy = intr[3];
@@ -904,6 +946,14 @@ static int unproject_device(hv_volume *v, const void *d_depth, int32_t depth_dty
     U.H = height;
     U.W = width;
     U.depth_is_u16 = depth_dtype == HV_DEPTH_U16;
+    return U;
+}
+
+static int unproject_device(hv_volume *v, const void *d_depth, int32_t depth_dtype, double depth_scale, const uint8_t *d_rgb,
+                            int32_t height, int32_t width, const double *intr, const double *T_cw, double min_depth,
+                            double max_depth, int64_t out_offset) {
+    const int64_t npx = (int64_t)height * width;
+    const HvUnprojectParams U = unproject_params(depth_dtype, depth_scale, height, width, intr, T_cw, min_depth, max_depth);
     // the unprojection's validity flags go straight into the sort-key input buffer
     hipLaunchKernelGGL(k_vg_unproject, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream, d_depth, d_rgb, U,
                        v->scratch_points + 3 * out_offset, v->scratch_colors + 3 * out_offset, v->sort_keys_out + out_offset);
@@ -971,9 +1021,16 @@ extern "C" int hv_integrate_rgbd_points(hv_volume *v, const void *depth, int32_t
     const int64_t npx = (int64_t)height * width;
     HV_REQUIRE(npx <= v->cfg.max_points, HV_ERR_CAPACITY, "hv_integrate_rgbd_points: image exceeds max_points");
     HV_HIP(hipSetDevice(v->device));
-    int rc = hv_unproject_frame(v, depth, depth_dtype, depth_scale, rgb, height, width, intr, T_cw, min_depth, max_depth, loc, nullptr);
+    HvFrameSource frame;
+    const void *d_depth = nullptr, *d_rgb = nullptr;
+    int rc = hv_stage_in(v, depth, (size_t)npx * (depth_dtype == HV_DEPTH_U16 ? 2 : 4), loc, 0, &d_depth);
     if (rc != HV_OK) return rc;
-    return integrate_device_points(v, v->scratch_points, npx, v->scratch_colors, HV_COLOR_F32, v->sort_keys_out);
+    rc = hv_stage_in(v, rgb, (size_t)npx * 3, loc, 1, &d_rgb);
+    if (rc != HV_OK) return rc;
+    frame.U = unproject_params(depth_dtype, depth_scale, height, width, intr, T_cw, min_depth, max_depth);
+    frame.d_depth = d_depth;
+    frame.d_rgb = (const uint8_t *)d_rgb;
+    return integrate_device_points(v, v->scratch_points, npx, v->scratch_colors, HV_COLOR_F32, nullptr, &frame);
 }
 
 extern "C" {
