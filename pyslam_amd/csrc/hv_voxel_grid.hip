@@ -416,6 +416,7 @@ __device__ __forceinline__ void hv_vgb_fold_sorted_wave(const uint32_t *s, int m
 // workgroup form k_vgb_fold instead).
 static constexpr int HV_VGB_WCAP = HV_VGB_WCAP_DECL;
 static constexpr int HV_VGB_RANK = 256; // buckets up to this size are rank-sorted (<= 4 entries per lane)
+static constexpr int HV_VGB_STAGE = 128; // ... and up to this size their points are staged in the window's spare 3 KB (24 B each)
 template <int COLOR_KIND>
 __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *__restrict__ pool, const int32_t *__restrict__ touched,
                                                         int parity, unsigned long long *__restrict__ cursor_and_len, int32_t *__restrict__ cnt,
@@ -464,6 +465,50 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
             for (int q = 0; q < HV_VGB_RANK / HV_WAVE; ++q)
                 if (lane + q * HV_WAVE < nb) s[rank[q]] = mine[q];
             hv_wave_lds_sync();
+            if (nb <= HV_VGB_STAGE) {
+                // every lane fetches ITS sorted entries' point and colour (all gathers of the bucket in flight at once) into the
+                // rest of the wave's LDS window; the run heads then add from LDS instead of chasing one global load per point
+                float *stage = (float *)(s + HV_VGB_RANK);
+                for (int e = lane; e < nb; e += HV_WAVE) {
+                    const int64_t p = s[e] & ((1u << HV_VGB_IDX_BITS) - 1u);
+                    stage[e * 6 + 0] = pts[p * 3 + 0];
+                    stage[e * 6 + 1] = pts[p * 3 + 1];
+                    stage[e * 6 + 2] = pts[p * 3 + 2];
+                    if (COLOR_KIND == HV_COLOR_U8) {
+                        const uint8_t *c = (const uint8_t *)cols + p * 3;
+                        stage[e * 6 + 3] = (float)c[0] * (1.0f / 255.0f); // voxel_data.h:82
+                        stage[e * 6 + 4] = (float)c[1] * (1.0f / 255.0f);
+                        stage[e * 6 + 5] = (float)c[2] * (1.0f / 255.0f);
+                    } else if (COLOR_KIND == HV_COLOR_F32) {
+                        const float *c = (const float *)cols + p * 3;
+                        stage[e * 6 + 3] = c[0];
+                        stage[e * 6 + 4] = c[1];
+                        stage[e * 6 + 5] = c[2];
+                    }
+                }
+                hv_wave_lds_sync();
+                for (int e = lane; e < nb; e += HV_WAVE) {
+                    const uint32_t lidx = s[e] >> HV_VGB_IDX_BITS;
+                    if (e > 0 && (s[e - 1] >> HV_VGB_IDX_BITS) == lidx) continue; // not the head of its voxel's run
+                    HvVoxel *vx = block + lidx;
+                    HvVoxel acc = *vx;
+                    int j = e;
+                    do { // update_voxel_direct, in point order
+                        acc.pos[0] += stage[j * 6 + 0];
+                        acc.pos[1] += stage[j * 6 + 1];
+                        acc.pos[2] += stage[j * 6 + 2];
+                        if (COLOR_KIND != HV_COLOR_NONE) {
+                            acc.col[0] += stage[j * 6 + 3];
+                            acc.col[1] += stage[j * 6 + 4];
+                            acc.col[2] += stage[j * 6 + 5];
+                        }
+                        acc.count = acc.count == 0 ? 1 : acc.count + 1;
+                        ++j;
+                    } while (j < nb && (s[j] >> HV_VGB_IDX_BITS) == lidx);
+                    *vx = acc;
+                }
+                continue;
+            }
             hv_vgb_fold_sorted_wave<COLOR_KIND>(s, nb, block, pts, cols);
             continue;
         }
