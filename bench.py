@@ -183,22 +183,29 @@ def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_fr
 
     step()
     g.synchronize()
-    g.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    g.synchronize()
-    dt = time.perf_counter() - t0
-    k_ms, k_launches, _ = g.profile_read()
-    g.profile_enable(False)
+    dt = None
+    for _ in range(3):  # a few ms per repetition: the best of three keeps one page-in or clock ramp from deciding the figure
+        g.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        g.synchronize()
+        t = time.perf_counter() - t0
+        ms, launches, _ = g.profile_read()
+        g.profile_enable(False)
+        if dt is None or t < dt:
+            dt, k_ms, k_launches = t, ms, launches
     gb = VoxelBlockGrid(VOXEL, 8, max_blocks=1 << 18, max_points=frames * s.width * s.height)
     gb.integrate_rgbd_batch(depth_d[:frames], rgb_d[:frames], *s.intrinsics, T_h[:frames], max_depth=DEPTH_TRUNC)
     gb.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        gb.integrate_rgbd_batch(depth_d[:frames], rgb_d[:frames], *s.intrinsics, T_h[:frames], max_depth=DEPTH_TRUNC)
-    gb.synchronize()
-    dt_b = time.perf_counter() - t0
+    dt_b = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gb.integrate_rgbd_batch(depth_d[:frames], rgb_d[:frames], *s.intrinsics, T_h[:frames], max_depth=DEPTH_TRUNC)
+        gb.synchronize()
+        t = time.perf_counter() - t0
+        dt_b = t if dt_b is None else min(dt_b, t)
     # oracle counts for B_vox: 2 x 28 B per distinct voxel a frame touches (steady state: no new blocks in
     # the timed replay) + CPU baseline = the compiled reference on the same float32 world points
     pts = [hp.frame_to_world_f32(depth_h[i], rgb_h[i], *s.intrinsics, T_h[i], DEPTH_TRUNC)[:2] for i in range(cpu_frames)]
@@ -214,12 +221,12 @@ def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_fr
            "blocks": int(g.num_blocks())}
     if k_launches:
         avg_s = k_ms * 1e-3 / k_launches
-        out["roofline"] = {"bound": "hbm", "kernels": "unproject + keys + sort + reduce of one integrate_rgbd call (HIP events around the call's launches)",
+        out["roofline"] = {"bound": "hbm", "kernels": "k_vgb_count (fused unprojection + keys + block claim) + k_vgb_offsets + k_vgb_scatter + k_vgb_fold_wave of one integrate_rgbd call (HIP events around the call's launches)",
                            "algorithmic_bytes_per_frame": int(b_vox + b_in), "avg_us_per_frame": round(avg_s * 1e6, 2),
                            "achieved": round((b_vox + b_in) / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round((b_vox + b_in) / avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                           "note": "B_vox = 2 x 28 B x distinct voxels touched per frame (oracle keys) + B_in 7 B/px: a ~20 MB/frame "
-                                   "path bounded by launch latency and the device-wide sort, not by HBM"}
+                           "note": "B_vox = 2 x 28 B x distinct voxels touched per frame (oracle keys) + B_in 7 B/px: a ~15 MB/frame "
+                                   "path bounded by four dependent launches and their latency chains, not by HBM"}
     for kind, cls in (("reference", oracle.RefGrid if oracle.ref_available() else None), ("port", oracle.PortGrid)):
         if cls is None:
             continue
@@ -502,7 +509,7 @@ def main():
             out["extraction"] = extraction
         if secondary and not args.no_cpu_baseline:
             del vol, fuser
-            out["voxel_grid"] = voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, min(B, n_distinct), 3, 6)
+            out["voxel_grid"] = voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, min(B, n_distinct), 5, 6)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

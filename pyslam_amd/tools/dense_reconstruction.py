@@ -40,16 +40,20 @@ def run(keyframes, camera, environment_type, sensor_type, integrator_type, outpu
                 if integ.pop_output(timeout=0.05) is not None:
                     outputs += 1
         log(f"inserted #keyframes: {n}")
-        # wait until the worker has fused the last keyframe, then ask for one final output and save
+        # Completion (the reference's script is GUI-driven and has none): keyframes wait in the integrator's keyframe queue until
+        # its timer moves them to q_in, INTEGRATE tasks are pushed to the FRONT of q_in (newest first), UPDATE_OUTPUT tasks are
+        # appended - so once the keyframe queue is empty, the answer to an UPDATE_OUTPUT sent NOW comes after every INTEGRATE.
         t0 = time.time()
+        while len(integ.keyframe_queue) > 0 and time.time() - t0 < drain_timeout:
+            integ.flush_keyframe_queue()
+            time.sleep(0.02)
+        integ.add_update_output_task()
         done = False
         while not done and time.time() - t0 < drain_timeout:
-            integ.add_update_output_task()
             out = integ.pop_output(timeout=1.0)
             while out is not None:
                 outputs += 1
-                if out.task_type != VolumetricIntegrationTaskType.RESET and out.id == last_id:
-                    done = True
+                done = done or out.task_type == VolumetricIntegrationTaskType.UPDATE_OUTPUT
                 out = integ.pop_output(timeout=0.05)
         os.makedirs(output_path, exist_ok=True)
         integ.save(output_path)
