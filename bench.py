@@ -364,15 +364,15 @@ def main():
         b_pc_out = npts * 48
         extraction = {
             "what": "extract_triangle_mesh + extract_point_cloud of the volume the timed region built "
-                    "(host-visible results: count pass + fill pass + D2H of the arrays, as the C ABI returns them)",
+                    "(host-visible results: size query = all device work, fetch = D2H of the arrays, as the C ABI returns them)",
             "units": units_allocated, "vertices": nv, "triangles": nt, "points": npts,
             "mesh_wall_ms": round(t_mesh * 1e3, 2), "mesh_kernel_ms": round(k_mesh, 3),
             "points_wall_ms": round(t_pc * 1e3, 2), "points_kernel_ms": round(k_pc, 3),
-            "roofline": {"bound": "hbm", "kernel": "k_mc_classify + k_mc_prefix + scans (x2: count and fill calls) + k_mc_vertices + k_mc_triangles",
+            "roofline": {"bound": "hbm", "kernel": "k_mc_classify + k_mc_prefix + scans + k_mc_vertices + k_mc_triangles (once: the size query computes, the fetch copies)",
                          "algorithmic_bytes": int(b_mc_in + b_mesh_out), "achieved": round((b_mc_in + b_mesh_out) / (k_mesh * 1e-3) / 1e9, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((b_mc_in + b_mesh_out) / (k_mesh * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": None, "note": "B_mc = U_alloc x 4096 x 8 B (tsdf + weight read once) + output bytes (SURVEY 8d)"},
-            "points_roofline": {"bound": "hbm", "kernel": "k_pc_extract (x2: count and fill calls)", "algorithmic_bytes": int(b_mc_in + b_pc_out),
+            "points_roofline": {"bound": "hbm", "kernel": "k_pc_extract x2 (count pass + fill pass inside the size query)", "algorithmic_bytes": int(b_mc_in + b_pc_out),
                                 "achieved": round((b_mc_in + b_pc_out) / (k_pc * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round((b_mc_in + b_pc_out) / (k_pc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
         }

@@ -2,6 +2,7 @@
 # Round evidence in one GPU call: GPU test suite, the default bench line, rocprofv3 kernel stats + PMC passes of the same
 # command (tools/profile_round.sh), the ownership-sharding projection, the VOXEL_GRID kernel table.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+export GRAFT_GIT_HEAD=29b4d81
 cd $R
 mkdir -p gpurun_out
 ( time python -m pytest tests -m gpu -q --durations=5 ) > gpurun_out/pytest_gpu.log 2>&1
