@@ -52,36 +52,36 @@ __device__ inline void load_neighbours(const HvTable &table, int idx, int *s_nbr
     }
 }
 
-// stage (tsdf, weight) of the 17^3 neighbourhood into LDS; absent units read as weight 0.  The loop runs in the order of
-// the planes in memory (word = z*256 + x*16 + y: y fastest), so a wave reads 64-byte runs; the LDS index (x*17 + y)*17 + z
-// has an odd stride in every direction (no bank conflicts on the transposing writes).
-__device__ inline void load_slab(const char *pool, const int *s_nbr, float *s_f, uint32_t *s_w) {
+// stage the tsdf of the 17^3 neighbourhood into LDS, NaN where the weight is 0 (and for absent units): marching cubes only
+// asks "observed?" and "negative?", so one 4-byte word per voxel does (19.7 KB per workgroup: 8 resident per CU instead of
+// 4, half the LDS reads per cube).  The loop runs in the order of the planes in memory (word = z*256 + x*16 + y: y fastest),
+// so a wave reads 64-byte runs; the LDS index (x*17 + y)*17 + z has an odd stride in every direction (no bank conflicts on
+// the transposing writes).
+__device__ inline void load_slab(const char *pool, const int *s_nbr, float *s_f) {
     for (int e = threadIdx.x; e < H * H * H; e += blockDim.x) {
         const int z = e / (H * H), x = (e / H) % H, y = e % H;
         const int n = (x >= R ? 1 : 0) | (y >= R ? 2 : 0) | (z >= R ? 4 : 0);
         const int idx = s_nbr[n];
-        float f = 0.f;
-        uint32_t w = 0;
+        float f = __uint_as_float(0x7fc00000u);
         if (idx >= 0) {
             const char *unit = pool + (int64_t)idx * UNIT_BYTES;
             const int word = voxel_word(x & (R - 1), y & (R - 1), z & (R - 1));
-            f = ((const float *)unit)[word];
-            w = ((const uint32_t *)(unit + PLANE_BYTES))[word];
+            const float t = ((const float *)unit)[word];
+            const uint32_t w = ((const uint32_t *)(unit + PLANE_BYTES))[word];
+            if (w != 0u) f = t;
         }
-        const int l = (x * H + y) * H + z;
-        s_f[l] = f;
-        s_w[l] = w;
+        s_f[(x * H + y) * H + z] = f;
     }
 }
 
 // Open3D cube loop body: cube_index or 0 if any corner weight is 0
-__device__ __forceinline__ int cube_case(const float *s_f, const uint32_t *s_w, int x, int y, int z) {
+__device__ __forceinline__ int cube_case(const float *s_f, int x, int y, int z) {
     int cube = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int e = ((x + hv_mc_shift[i][0]) * H + (y + hv_mc_shift[i][1])) * H + (z + hv_mc_shift[i][2]);
-        if (s_w[e] == 0u) return 0;
-        if (s_f[e] < 0.0f) cube |= 1 << i;
+        const float f = s_f[((x + hv_mc_shift[i][0]) * H + (y + hv_mc_shift[i][1])) * H + (z + hv_mc_shift[i][2])];
+        if (f != f) return 0;
+        if (f < 0.0f) cube |= 1 << i;
     }
     return cube == 255 ? 0 : cube;
 }
@@ -96,22 +96,23 @@ __device__ __forceinline__ void edge_owner(int x, int y, int z, int i, int &n, i
 
 __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const char *__restrict__ pool, int n_units,
                                                       unsigned long long *__restrict__ edge_mask,
-                                                      int32_t *__restrict__ tri_count) {
+                                                      int32_t *__restrict__ tri_count, uint8_t *__restrict__ cases) {
     __shared__ int s_nbr[8];
     __shared__ float s_f[H * H * H];
-    __shared__ uint32_t s_w[H * H * H];
     __shared__ int s_tris;
     const int idx = blockIdx.x;
     if (idx >= n_units) return;
     if (threadIdx.x == 0) s_tris = 0;
     load_neighbours(table, idx, s_nbr);
     __syncthreads();
-    load_slab(pool, s_nbr, s_f, s_w);
+    load_slab(pool, s_nbr, s_f);
     __syncthreads();
     const int x = threadIdx.x >> 4, y = threadIdx.x & 15;
     int tris = 0;
+    uint32_t packed[4] = {0u, 0u, 0u, 0u}; // the column's 16 cube cases, one byte each: the triangle pass reads them back
     for (int z = 0; z < R; ++z) {
-        const int cube = cube_case(s_f, s_w, x, y, z);
+        const int cube = cube_case(s_f, x, y, z);
+        packed[z >> 2] |= (uint32_t)cube << ((z & 3) * 8);
         if (cube == 0) continue;
         tris += c_tri_count[cube];
         const unsigned em = c_edge_table[cube];
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const char *
             atomicOr(&edge_mask[(int64_t)oidx * MASK_WORDS + axis * (RRR / 64) + (lin >> 6)], 1ull << (lin & 63));
         }
     }
+    ((uint4 *)(cases + (int64_t)idx * RRR))[threadIdx.x] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
     if (tris) atomicAdd(&s_tris, tris);
     __syncthreads();
     if (threadIdx.x == 0) tri_count[idx] = s_tris;
@@ -152,90 +154,97 @@ struct HvMcParams {
     double voxel_length, half_voxel_length;
 };
 
+// One workgroup per unit, one thread per 64-bit word of its edge mask (192 words), walking the word's set bits: a unit has
+// ~120 vertices among 12 288 candidate edges - the first version's one thread per candidate launched 390 M threads for
+// 3.8 M vertices.
 __global__ __launch_bounds__(256) void k_mc_vertices(HvTable table, const char *__restrict__ pool, int n_units,
                                                       const unsigned long long *__restrict__ edge_mask,
                                                       const uint32_t *__restrict__ word_prefix,
                                                       const int32_t *__restrict__ vert_base, HvMcParams M,
                                                       double *__restrict__ vertices, double *__restrict__ colors,
                                                       int64_t cap) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (int64_t)n_units * 3 * RRR) return;
-    const int idx = (int)(gid / (3 * RRR));
-    const int rem = (int)(gid % (3 * RRR));
-    const int axis = rem / RRR, lin = rem % RRR;
-    const int word = axis * (RRR / 64) + (lin >> 6);
-    const unsigned long long m = edge_mask[(int64_t)idx * MASK_WORDS + word];
-    const unsigned long long bit = 1ull << (lin & 63);
-    if (!(m & bit)) return;
-    const int64_t vi = (int64_t)vert_base[idx] + word_prefix[(int64_t)idx * MASK_WORDS + word] + __popcll(m & (bit - 1));
-    if (vi >= cap) return;
-    // owner voxel and its +axis neighbour
-    const int z = lin / RR, x = (lin / R) % R, y = lin % R;
+    const int idx = blockIdx.x;
+    const int word = threadIdx.x;
+    if (idx >= n_units || word >= MASK_WORDS) return;
+    unsigned long long m = edge_mask[(int64_t)idx * MASK_WORDS + word];
+    if (m == 0ull) return;
+    const int axis = word / (RRR / 64);
+    int64_t vi = (int64_t)vert_base[idx] + word_prefix[(int64_t)idx * MASK_WORDS + word];
     int32_t ux, uy, uz;
     hv_unpack_key(table.block_keys[idx], ux, uy, uz);
-    int nx = x + (axis == 0), ny = y + (axis == 1), nz = z + (axis == 2);
-    int nidx = idx;
-    if (nx >= R || ny >= R || nz >= R) {
-        const int32_t slot = hv_table_find(table, hv_pack_key(ux + (nx >= R), uy + (ny >= R), uz + (nz >= R)));
-        nidx = slot >= 0 ? table.vals[slot] : -1;
-        nx &= R - 1; ny &= R - 1; nz &= R - 1;
-    }
     const char *u0 = pool + (int64_t)idx * UNIT_BYTES;
-    const double f0 = fabs((double)((const float *)u0)[lin]);
-    const double w0 = (double)((const uint32_t *)(u0 + PLANE_BYTES))[lin];
-    double c0[3], c1[3] = {0, 0, 0};
+    for (; m != 0ull; m &= m - 1ull, ++vi) {
+        if (vi >= cap) return;
+        const int lin = (word % (RRR / 64)) * 64 + (__ffsll((long long)m) - 1);
+        // owner voxel and its +axis neighbour
+        const int z = lin / RR, x = (lin / R) % R, y = lin % R;
+        int nx = x + (axis == 0), ny = y + (axis == 1), nz = z + (axis == 2);
+        int nidx = idx;
+        if (nx >= R || ny >= R || nz >= R) {
+            const int32_t slot = hv_table_find(table, hv_pack_key(ux + (nx >= R), uy + (ny >= R), uz + (nz >= R)));
+            nidx = slot >= 0 ? table.vals[slot] : -1;
+            nx &= R - 1; ny &= R - 1; nz &= R - 1;
+        }
+        const double f0 = fabs((double)((const float *)u0)[lin]);
+        const double w0 = (double)((const uint32_t *)(u0 + PLANE_BYTES))[lin];
+        double c0[3], c1[3] = {0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) c0[k] = ((double)((const uint32_t *)(u0 + (2 + k) * PLANE_BYTES))[lin] / w0) / 255.0;
-    double f1 = 0.0;
-    if (nidx >= 0) {
-        const char *u1 = pool + (int64_t)nidx * UNIT_BYTES;
-        const int nl = voxel_word(nx, ny, nz);
-        f1 = fabs((double)((const float *)u1)[nl]);
-        const double w1 = (double)((const uint32_t *)(u1 + PLANE_BYTES))[nl];
+        for (int k = 0; k < 3; ++k) c0[k] = ((double)((const uint32_t *)(u0 + (2 + k) * PLANE_BYTES))[lin] / w0) / 255.0;
+        double f1 = 0.0;
+        if (nidx >= 0) {
+            const char *u1 = pool + (int64_t)nidx * UNIT_BYTES;
+            const int nl = voxel_word(nx, ny, nz);
+            f1 = fabs((double)((const float *)u1)[nl]);
+            const double w1 = (double)((const uint32_t *)(u1 + PLANE_BYTES))[nl];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) c1[k] = ((double)((const uint32_t *)(u1 + (2 + k) * PLANE_BYTES))[nl] / w1) / 255.0;
-    }
-    double pt[3] = {M.half_voxel_length + M.voxel_length * (double)(ux * R + x),
-                    M.half_voxel_length + M.voxel_length * (double)(uy * R + y),
-                    M.half_voxel_length + M.voxel_length * (double)(uz * R + z)};
-    pt[axis] += f0 * M.voxel_length / (f0 + f1);
+            for (int k = 0; k < 3; ++k) c1[k] = ((double)((const uint32_t *)(u1 + (2 + k) * PLANE_BYTES))[nl] / w1) / 255.0;
+        }
+        double pt[3] = {M.half_voxel_length + M.voxel_length * (double)(ux * R + x),
+                        M.half_voxel_length + M.voxel_length * (double)(uy * R + y),
+                        M.half_voxel_length + M.voxel_length * (double)(uz * R + z)};
+        pt[axis] += f0 * M.voxel_length / (f0 + f1);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        vertices[vi * 3 + k] = pt[k];
-        colors[vi * 3 + k] = (f1 * c0[k] + f0 * c1[k]) / (f0 + f1);
+        for (int k = 0; k < 3; ++k) {
+            vertices[vi * 3 + k] = pt[k];
+            colors[vi * 3 + k] = (f1 * c0[k] + f0 * c1[k]) / (f0 + f1);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, const char *__restrict__ pool, int n_units,
+// Reads the cube cases k_mc_classify left (16 bytes per thread: its column) instead of staging the slab again.
+__global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, int n_units, const uint8_t *__restrict__ cases,
                                                        const unsigned long long *__restrict__ edge_mask,
                                                        const uint32_t *__restrict__ word_prefix,
                                                        const int32_t *__restrict__ vert_base,
                                                        const int32_t *__restrict__ tri_base,
                                                        int32_t *__restrict__ triangles, int64_t cap) {
     __shared__ int s_nbr[8];
-    __shared__ float s_f[H * H * H];
-    __shared__ uint32_t s_w[H * H * H];
-    __shared__ int s_scan[256];
+    __shared__ int s_wave[4];
     const int idx = blockIdx.x;
     if (idx >= n_units) return;
     load_neighbours(table, idx, s_nbr);
-    __syncthreads();
-    load_slab(pool, s_nbr, s_f, s_w);
-    __syncthreads();
     const int x = threadIdx.x >> 4, y = threadIdx.x & 15;
+    const uint4 pk = ((const uint4 *)(cases + (int64_t)idx * RRR))[threadIdx.x];
+    const uint32_t packed[4] = {pk.x, pk.y, pk.z, pk.w};
     int tris = 0;
-    for (int z = 0; z < R; ++z) tris += c_tri_count[cube_case(s_f, s_w, x, y, z)];
-    s_scan[threadIdx.x] = tris;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int add = (int)threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
-        __syncthreads();
-        s_scan[threadIdx.x] += add;
-        __syncthreads();
+#pragma unroll
+    for (int z = 0; z < R; ++z) tris += c_tri_count[(packed[z >> 2] >> ((z & 3) * 8)) & 255u];
+    // rank of this thread's triangles inside the unit: wave prefix + the 4 wave totals
+    const int lane = hv_lane_id(), wave = threadIdx.x >> 6;
+    int incl = tris;
+#pragma unroll
+    for (int o = 1; o < HV_WAVE; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
     }
-    int64_t at = (int64_t)tri_base[idx] + s_scan[threadIdx.x] - tris;
+    if (lane == HV_WAVE - 1) s_wave[wave] = incl;
+    __syncthreads(); // also orders s_nbr
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    int64_t at = (int64_t)tri_base[idx] + before + incl - tris;
+    if (tris == 0) return;
     for (int z = 0; z < R; ++z) {
-        const int cube = cube_case(s_f, s_w, x, y, z);
+        const int cube = (int)((packed[z >> 2] >> ((z & 3) * 8)) & 255u);
         if (cube == 0) continue;
         for (int i = 0; c_tri_table[cube][i] != -1; i += 3) {
             const int order[3] = {i, i + 2, i + 1}; // Open3D emits (e[i], e[i+2], e[i+1])
@@ -415,11 +424,12 @@ static int mesh_compute(hv_volume *v) {
         return HV_OK;
     }
     const int n = (int)nb;
-    // scratch: [edge_mask nb*192 u64][word_prefix nb*192 u32][vert_count n+1][tri_count n+1][vert_base n+1][tri_base n+1]
+    // scratch: [edge_mask nb*192 u64][word_prefix nb*192 u32][vert_count n+1][tri_count n+1][vert_base n+1][tri_base n+1][cases nb*4096 u8]
     const size_t mask_bytes = sizeof(uint64_t) * MASK_WORDS * (size_t)n;
     const size_t prefix_bytes = sizeof(uint32_t) * MASK_WORDS * (size_t)n;
     const size_t cnt_bytes = sizeof(int32_t) * (size_t)(n + 1);
-    rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, mask_bytes + prefix_bytes + 4 * cnt_bytes + 64);
+    const size_t cases_off = (mask_bytes + prefix_bytes + 4 * cnt_bytes + 255) & ~(size_t)255;
+    rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, cases_off + (size_t)n * RRR + 64);
     if (rc != HV_OK) return rc;
     char *base = (char *)v->out_c;
     unsigned long long *edge_mask = (unsigned long long *)base;
@@ -428,11 +438,12 @@ static int mesh_compute(hv_volume *v) {
     int32_t *tri_count = vert_count + (n + 1);
     int32_t *vert_base = tri_count + (n + 1);
     int32_t *tri_base = vert_base + (n + 1);
+    uint8_t *cases = (uint8_t *)(base + cases_off);
     hv_profile_begin(v); // measurement hook: classify + prefix + scans
     HV_HIP(hipMemsetAsync(edge_mask, 0, mask_bytes, v->stream));
     HV_HIP(hipMemsetAsync(vert_count, 0, 2 * cnt_bytes, v->stream));
     hipLaunchKernelGGL(k_mc_classify, dim3(n), dim3(256), 0, v->stream, v->table, (const char *)v->pool, n, edge_mask,
-                       tri_count);
+                       tri_count, cases);
     hipLaunchKernelGGL(k_mc_prefix, dim3(n), dim3(256), 0, v->stream, edge_mask, n, word_prefix, vert_count);
     HV_HIP(hipGetLastError());
     rc = exclusive_scan_i32(v, vert_count, vert_base, n + 1);
@@ -452,11 +463,10 @@ static int mesh_compute(hv_volume *v) {
         if (rc != HV_OK) return rc;
         double *d_vert = (double *)v->out_a, *d_col = d_vert + 3 * nv;
         HvMcParams M{v->cfg.voxel_size, v->cfg.voxel_size * 0.5};
-        const int64_t total_edges = (int64_t)n * 3 * RRR;
         hv_profile_begin(v); // vertices + triangles (D2H of the results is outside the bracket)
-        hipLaunchKernelGGL(k_mc_vertices, dim3((unsigned)((total_edges + 255) / 256)), dim3(256), 0, v->stream, v->table,
+        hipLaunchKernelGGL(k_mc_vertices, dim3(n), dim3(256), 0, v->stream, v->table,
                            (const char *)v->pool, n, edge_mask, word_prefix, vert_base, M, d_vert, d_col, nv);
-        hipLaunchKernelGGL(k_mc_triangles, dim3(n), dim3(256), 0, v->stream, v->table, (const char *)v->pool, n, edge_mask,
+        hipLaunchKernelGGL(k_mc_triangles, dim3(n), dim3(256), 0, v->stream, v->table, n, (const uint8_t *)cases, edge_mask,
                            word_prefix, vert_base, tri_base, (int32_t *)v->out_b, nt);
         hv_profile_end(v, n);
         HV_HIP(hipGetLastError());

@@ -1918,8 +1918,19 @@ int hv_tsdf_import_numerators(hv_volume *v, const int32_t *keys, int64_t k, cons
     if (rc != HV_OK) return rc;
     rc = hv_stage_in(v, payload, sizeof(float) * 5 * RRR * (size_t)k, loc, 1, &d_payload);
     if (rc != HV_OK) return rc;
-    hipLaunchKernelGGL(k_tsdf_import_claim, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, v->stream, v->table,
-                       (const int32_t *)d_keys, k);
+    // the imported units are claimed first and the claims verified (this call synchronises anyway): a pool that is too small
+    // grows before anything is written, or the call fails with the volume unchanged (a gather onto a root whose
+    // pool was sized like every other rank's)
+    bool checked = false;
+    rc = hv_capacity_gate(v, &checked);
+    if (rc != HV_OK) return rc;
+    for (int attempt = 0;; ++attempt) {
+        hipLaunchKernelGGL(k_tsdf_import_claim, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, v->stream, v->table,
+                           (const int32_t *)d_keys, k);
+        rc = hv_claims_fit(v);
+        if (rc == HV_OK) break;
+        if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
+    }
     const int64_t total = k * RRR;
     hipLaunchKernelGGL(k_tsdf_import, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, v->table,
                        (char *)v->pool, (const int32_t *)d_keys, k, (const float *)d_payload);

@@ -118,8 +118,11 @@ class ShardedTSDF:
             if on_gpu:
                 torch.cuda.current_stream().synchronize()  # RCCL result visible before the import kernel reads it
             if self.rank == root:
-                # (owner sharding: the root now also *stores* foreign units; it keeps fusing only its own,
-                # the cleared ranks keep fusing theirs, and a later gather sums the deltas onto these)
+                # (owner sharding: the root now also *stores* foreign units; it keeps fusing only its own, the cleared ranks
+                # keep fusing theirs, and a later gather sums the deltas onto these.  The first gather reproduces a single
+                # GPU's volume up to the export / import round trip (weights and colours exact, tsdf to ~1e-6); later gathers
+                # re-sum float32 numerators tsdf*w and are equal to the north-star tolerance 1e-4, not bit for bit.  The
+                # import claims the units first and grows the root's pool when they do not fit.)
                 self.volume.import_numerators(sub, payload if on_gpu else payload.numpy())
             del payload
         if self.rank != root:
