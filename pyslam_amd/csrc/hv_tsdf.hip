@@ -1064,7 +1064,17 @@ __device__ __forceinline__ HvSweepFrameK hv_sweep_frame_k(const HvFrameParams *_
     return HvSweepFrameK{hv_f2{k[0], k[1]}, hv_f2{k[2], k[3]}, hv_f2{k[4], k[5]}, hv_f2{k[6], k[7]}, k[8], k[9], hv_f2{k[10], k[11]}, hv_f2{k[12], k[13]}, k[14]};
 }
 
-template <int ZH, int SPLIT, int WPE>
+template <int ZH>
+struct HvSweepGather { // what a frame's evaluation leaves for its fold: the gathered records, multipliers, depths along z, tests
+    uint2 rec[ZH];
+    float mm[ZH], zk[ZH];
+    bool ok[ZH];
+};
+
+// PIPE: the evaluation (projection + gathers) of frame n+1 is issued BEFORE frame n is folded - the gathers of the next
+// frame travel while the running means of this one are computed (the frame records of a 32-frame batch are 79 MB: they
+// come from the Infinity Cache, not from L2).
+template <int ZH, int SPLIT, int WPE, bool PIPE = false>
 __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
     char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
@@ -1191,7 +1201,8 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
             arb[2 * zp] = arb[2 * zp + 1] = ag[2 * zp] = ag[2 * zp + 1] = 0u;
         }
         // One frame folded into the registers; K = the frame's 16 constant dwords, already in scalar registers.
-        auto fold_frame = [&](const HvSweepFrameK K, const int f, HvSweepFrameK &Knext, const unsigned long long rest) __attribute__((always_inline)) {
+        auto project_frame = [&](const HvSweepFrameK K, const int f, HvSweepFrameK &Knext, const unsigned long long rest,
+                                 HvSweepGather<ZH> &g) __attribute__((always_inline)) {
             const __amdgpu_buffer_rsrc_t rs_px = __builtin_amdgcn_make_buffer_rsrc((void *)(frame_px + (int64_t)f * npx), 0, npx * 8, 0x00020000);
             const hv_f2 INC = K.i01;
             const float inc2 = K.i2;
@@ -1208,10 +1219,7 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
                 XY += INC;
                 Z += inc2;
             }
-            // ---- evaluation of the ZH voxels: all 2 ZH gathers in flight, then the tests ----
-            uint2 rec[ZH];
-            float mm[ZH], zk[ZH];
-            bool ok[ZH];
+            // ---- evaluation of the ZH voxels: all 2 ZH gathers in flight ----
 #pragma unroll
             for (int k = 0; k < ZH; ++k) {
                 // (a0, a1) / pc2, correctly rounded, sharing one refined reciprocal (hv_div2's chain on a float2)
@@ -1229,23 +1237,25 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
                 // u_f in [0.0001, safe_width) as ONE unsigned compare (bit patterns of non-negative floats order like the values)
                 const bool in_u = (__float_as_uint(UV.x) - lo) < wlim;
                 const bool in_v = (__float_as_uint(UV.y) - lo) < hlim;
-                ok[k] = (int)(Z > 0.0f) & (int)in_u & (int)in_v;
+                g.ok[k] = (int)(Z > 0.0f) & (int)in_u & (int)in_v;
                 const uint32_t u = (uint32_t)(int)UV.x, v = (uint32_t)(int)UV.y; // saturating conversions: garbage lanes stay defined
                 const uint32_t off = __umul24(v, W24) + u; // exact for every in-image pixel; a garbage lane reads 0 or some pixel, unused
-                rec[k] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs_px, (int)(off << 3), 0, 0));
-                mm[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_m, (int)(off << 2), 0, 0));
-                zk[k] = Z;
+                g.rec[k] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs_px, (int)(off << 3), 0, 0));
+                g.mm[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_m, (int)(off << 2), 0, 0));
+                g.zk[k] = Z;
                 XY += INC;
                 Z += inc2;
             }
-            // ---- fold, two voxels at a time ----
+        };
+        // ---- fold of an evaluated frame, two voxels at a time ----
+        auto apply_frame = [&](const HvSweepGather<ZH> &g) __attribute__((always_inline)) {
 #pragma unroll
             for (int zp = 0; zp < ZH / 2; ++zp) {
                 const int k0 = 2 * zp, k1 = 2 * zp + 1;
-                const float da = __uint_as_float(rec[k0].x), db = __uint_as_float(rec[k1].x);
-                const float sa = (da - zk[k0]) * mm[k0], sb = (db - zk[k1]) * mm[k1];
-                const bool oka = (int)ok[k0] & (int)(da > 0.0f) & (int)(sa > ntrunc);
-                const bool okb = (int)ok[k1] & (int)(db > 0.0f) & (int)(sb > ntrunc);
+                const float da = __uint_as_float(g.rec[k0].x), db = __uint_as_float(g.rec[k1].x);
+                const float sa = (da - g.zk[k0]) * g.mm[k0], sb = (db - g.zk[k1]) * g.mm[k1];
+                const bool oka = (int)g.ok[k0] & (int)(da > 0.0f) & (int)(sa > ntrunc);
+                const bool okb = (int)g.ok[k1] & (int)(db > 0.0f) & (int)(sb > ntrunc);
                 if (!__any((int)oka | (int)okb)) continue; // no lane of the wave updates either voxel
                 const hv_f2 T = {fminf(sa * tinv, 1.0f), fminf(sb * tinv, 1.0f)}; // == `if (t > 1) t = 1` for the non-NaN t of an accepted voxel
                 // running mean (tsdf * w + t) / (w + 1) with float weights (exact below 2^24), hv_div1's chain on a float2
@@ -1263,7 +1273,7 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
                 VT[zp].y = okb ? Q.y : VT[zp].y;
                 WF[zp].x = oka ? W1.x : WF[zp].x;
                 WF[zp].y = okb ? W1.y : WF[zp].y;
-                const uint32_t ca = oka ? rec[k0].y : 0u, cb = okb ? rec[k1].y : 0u;
+                const uint32_t ca = oka ? g.rec[k0].y : 0u, cb = okb ? g.rec[k1].y : 0u;
                 arb[k0] += ca & 0x00ff00ffu; ag[k0] += ca & 0x0000ff00u;
                 arb[k1] += cb & 0x00ff00ffu; ag[k1] += cb & 0x0000ff00u;
             }
@@ -1271,15 +1281,42 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
         // Frame constants are fetched one frame AHEAD, alternating between two scalar register sets (a copy between sets
         // would make the wave wait for the load at once): the scalar-load latency of frame n+1 hides behind frame n's fold.
         HvSweepFrameK ka = hv_sweep_frame_k(Ps, __ffsll((long long)mask) - 1), kb = ka;
-        while (true) {
-            const int fa = __ffsll((long long)mask) - 1;
+        HvSweepGather<ZH> ga, gb;
+        if (!PIPE) {
+            while (true) {
+                const int fa = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                project_frame(ka, fa, kb, mask, ga);
+                apply_frame(ga);
+                if (!mask) break;
+                const int fb = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                project_frame(kb, fb, ka, mask, gb);
+                apply_frame(gb);
+                if (!mask) break;
+            }
+        } else {
+            int f = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
-            fold_frame(ka, fa, kb, mask);
-            if (!mask) break;
-            const int fb = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            fold_frame(kb, fb, ka, mask);
-            if (!mask) break;
+            project_frame(ka, f, kb, mask, ga);
+            while (true) {
+                if (!mask) {
+                    apply_frame(ga);
+                    break;
+                }
+                f = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                project_frame(kb, f, ka, mask, gb); // frame n+1's gathers leave ...
+                apply_frame(ga);                    // ... while frame n is folded
+                if (!mask) {
+                    apply_frame(gb);
+                    break;
+                }
+                f = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                project_frame(ka, f, kb, mask, ga);
+                apply_frame(gb);
+            }
         }
 #pragma unroll
         for (int zz = 0; zz < ZH; ++zz) {
@@ -1745,15 +1782,21 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
 #define HV_LAUNCH_COL(S, MT)                                                                                           \
     hipLaunchKernelGGL((k_tsdf_integrate_batch_col<4, S, MT>), dim3(sweep_grid), dim3(64 * 16 / S), 0, v->stream, v->table, \
                        v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0, general, d_mult)
+#define HV_LAUNCH_SWEEP_P(ZH, S, WPE)                                                                                  \
+    hipLaunchKernelGGL((k_tsdf_sweep<ZH, S, WPE, true>), dim3(sweep_grid), dim3(64 * (64 / ZH) / S), 0, v->stream, v->table, \
+                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult)
 #define HV_LAUNCH_SWEEP(ZH, S, WPE)                                                                                    \
     hipLaunchKernelGGL((k_tsdf_sweep<ZH, S, WPE>), dim3(sweep_grid), dim3(64 * (64 / ZH) / S), 0, v->stream, v->table,   \
                        v->touched_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult)
         if (d_mult && sweep_form == 2) {
             const int wpe = getenv("HV_TSDF_SWEEP_WPE") ? atoi(getenv("HV_TSDF_SWEEP_WPE")) : 4; // 4 waves / SIMD = 128 VGPRs: nothing spills
+            const int pipe = getenv("HV_TSDF_SWEEP_PIPE") ? atoi(getenv("HV_TSDF_SWEEP_PIPE")) : 0;
             if (sweep_zh == 8) {
                 if (split == 2) HV_LAUNCH_SWEEP(8, 2, 1); else if (wpe == 4) HV_LAUNCH_SWEEP(8, 4, 2); else HV_LAUNCH_SWEEP(8, 4, 1);
             } else if (split == 2) {
                 if (wpe == 4) HV_LAUNCH_SWEEP(4, 2, 4); else HV_LAUNCH_SWEEP(4, 2, 1);
+            } else if (split == 8 && pipe) {
+                if (wpe == 3) HV_LAUNCH_SWEEP_P(4, 8, 3); else if (wpe == 2) HV_LAUNCH_SWEEP_P(4, 8, 2); else HV_LAUNCH_SWEEP_P(4, 8, 4);
             } else if (split == 8) {
                 if (wpe == 4) HV_LAUNCH_SWEEP(4, 8, 4); else if (wpe == 5) HV_LAUNCH_SWEEP(4, 8, 5); else HV_LAUNCH_SWEEP(4, 8, 1);
             } else {
@@ -1766,6 +1809,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         }
 #undef HV_LAUNCH_COL
 #undef HV_LAUNCH_SWEEP
+#undef HV_LAUNCH_SWEEP_P
         hv_profile_end(v, B);
         hipLaunchKernelGGL(k_tsdf_batch_finish, dim3(1), dim3(1024), 0, v->stream, v->table, v->touched_list,
                            (unsigned long long *)v->touched_mask, 0, v->d_status, hv_next_status_seq(v));
