@@ -34,6 +34,8 @@ Objects on the JSON line (N = 1):
                 shape of work), wall ms and kernel ms, B_mc roofline.
   voxel_grid    the cpp/volumetric VOXEL_GRID mode on the same frames: per-frame and batched frames/s, B_vox
                 roofline, and the COMPILED REFERENCE (oracle/_ref, kind "reference") timed beside it.
+  semantic      pySLAM's per-keyframe semantic flow (shadow filter, assign_object_ids_to_instance_ids, remap, integrate) for
+                the voting and the probabilistic payload, keyframes/s, next to the compiled reference (tools/bench_semantic.py).
   cpu_baseline  oracle/tsdf_oracle.c (Open3D-semantics restatement, kind "port") timed on the host cores over
                 the same sliding stream (N = 1 only, bounded by --cpu-budget-s).
 """
@@ -347,67 +349,76 @@ def main():
 
     # ---- secondary legs (single GPU): extraction of the volume just built, replay figure, online mode ----
     extraction = replay = online = None
-    if secondary:
-        vol.profile_enable(True)
-        t1 = time.perf_counter()
-        mesh = vol.extract_triangle_mesh()
-        t_mesh = time.perf_counter() - t1
-        k_mesh = vol.profile_read()[0]
-        t1 = time.perf_counter()
-        pc = vol.extract_point_cloud()
-        t_pc = time.perf_counter() - t1
-        k_pc = vol.profile_read()[0]
-        vol.profile_enable(False)
-        nv, nt, npts = len(mesh.vertices), len(mesh.triangles), len(pc.points)
-        b_mc_in = units_allocated * 4096 * 8
-        b_mesh_out = nv * 48 + nt * 12
-        b_pc_out = npts * 48
-        extraction = {
-            "what": "extract_triangle_mesh + extract_point_cloud of the volume the timed region built "
-                    "(host-visible results: size query = all device work, fetch = D2H of the arrays, as the C ABI returns them)",
-            "units": units_allocated, "vertices": nv, "triangles": nt, "points": npts,
-            "mesh_wall_ms": round(t_mesh * 1e3, 2), "mesh_kernel_ms": round(k_mesh, 3),
-            "points_wall_ms": round(t_pc * 1e3, 2), "points_kernel_ms": round(k_pc, 3),
-            "roofline": {"bound": "hbm", "kernel": "k_mc_classify + k_mc_prefix + scans + k_mc_vertices + k_mc_triangles (once: the size query computes, the fetch copies)",
-                         "algorithmic_bytes": int(b_mc_in + b_mesh_out), "achieved": round((b_mc_in + b_mesh_out) / (k_mesh * 1e-3) / 1e9, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((b_mc_in + b_mesh_out) / (k_mesh * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": None, "note": "B_mc = U_alloc x 4096 x 8 B (tsdf + weight read once) + output bytes (SURVEY 8d)"},
-            "points_roofline": {"bound": "hbm", "kernel": "k_pc_extract x2 (count pass + fill pass inside the size query)", "algorithmic_bytes": int(b_mc_in + b_pc_out),
-                                "achieved": round((b_mc_in + b_pc_out) / (k_pc * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round((b_mc_in + b_pc_out) / (k_pc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
-        }
-        del mesh, pc
-        # replay figure (round-1 headline): the same 32 frames re-fused every step, no allocation after the first
-        vol.reset()
-        for k in range(3):
-            step(k, window="replay")
-        fence()
-        vol.profile_enable(True)
-        t1 = time.perf_counter()
-        n_rep = max(4, args.steps // 2)
-        for k in range(n_rep):
-            step(k, window="replay")
-        fence()
-        dt = time.perf_counter() - t1
-        rep_ms, rep_launches, _ = vol.profile_read()
-        vol.profile_enable(False)
-        replay = {"value": round(n_rep * B / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / n_rep * 1e3, 4),
-                  "sweep_avg_launch_us": round(rep_ms / max(rep_launches, 1) * 1e3, 2),
-                  "what": "every step re-fuses frames 0..31 (maximum frustum overlap, nothing allocated in the timed region)"}
-        # online mode on the sliding stream, fresh volume
-        vol.reset()
-        fence()
-        n_on = max(2, min(args.steps // 4, n_distinct // B))
-        vol.profile_enable(True)
-        t1 = time.perf_counter()
-        for k in range(n_on):
-            step(k, mode="online", window="sliding")
-        fence()
-        dt = time.perf_counter() - t1
-        on_launch_ms = vol.profile_launches()
-        vol.profile_read()
-        vol.profile_enable(False)
-        online = {"fps": n_on * B / dt, "launch_ms": on_launch_ms, "steps": n_on}
+    secondary_error = None
+    try:
+        if secondary:
+            vol.profile_enable(True)
+            t1 = time.perf_counter()
+            mesh = vol.extract_triangle_mesh()
+            t_mesh = time.perf_counter() - t1
+            k_mesh = vol.profile_read()[0]
+            t1 = time.perf_counter()
+            pc = vol.extract_point_cloud()
+            t_pc = time.perf_counter() - t1
+            k_pc = vol.profile_read()[0]
+            vol.profile_enable(False)
+            nv, nt, npts = len(mesh.vertices), len(mesh.triangles), len(pc.points)
+            b_mc_in = units_allocated * 4096 * 8
+            b_mesh_out = nv * 48 + nt * 12
+            b_pc_out = npts * 48
+            extraction = {
+                "what": "extract_triangle_mesh + extract_point_cloud of the volume the timed region built "
+                        "(host-visible results: size query = all device work, fetch = D2H of the arrays, as the C ABI returns them)",
+                "units": units_allocated, "vertices": nv, "triangles": nt, "points": npts,
+                "mesh_wall_ms": round(t_mesh * 1e3, 2), "mesh_kernel_ms": round(k_mesh, 3),
+                "points_wall_ms": round(t_pc * 1e3, 2), "points_kernel_ms": round(k_pc, 3),
+                "roofline": {"bound": "hbm", "kernel": "k_mc_classify + k_mc_prefix + scans + k_mc_vertices + k_mc_triangles (once: the size query computes, the fetch copies)",
+                             "algorithmic_bytes": int(b_mc_in + b_mesh_out), "achieved": round((b_mc_in + b_mesh_out) / (k_mesh * 1e-3) / 1e9, 1),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((b_mc_in + b_mesh_out) / (k_mesh * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "traffic": None, "note": "B_mc = U_alloc x 4096 x 8 B (tsdf + weight read once) + output bytes (SURVEY 8d)"},
+                "points_roofline": {"bound": "hbm", "kernel": "k_pc_extract x2 (count pass + fill pass inside the size query)", "algorithmic_bytes": int(b_mc_in + b_pc_out),
+                                    "achieved": round((b_mc_in + b_pc_out) / (k_pc * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round((b_mc_in + b_pc_out) / (k_pc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
+            }
+            del mesh, pc
+            # replay figure (round-1 headline): the same 32 frames re-fused every step, no allocation after the first
+            vol.reset()
+            for k in range(3):
+                step(k, window="replay")
+            fence()
+            vol.profile_enable(True)
+            t1 = time.perf_counter()
+            n_rep = max(4, args.steps // 2)
+            for k in range(n_rep):
+                step(k, window="replay")
+            fence()
+            dt = time.perf_counter() - t1
+            rep_ms, rep_launches, _ = vol.profile_read()
+            vol.profile_enable(False)
+            replay = {"value": round(n_rep * B / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / n_rep * 1e3, 4),
+                      "sweep_avg_launch_us": round(rep_ms / max(rep_launches, 1) * 1e3, 2),
+                      "what": "every step re-fuses frames 0..31 (maximum frustum overlap, nothing allocated in the timed region)"}
+            # online mode on the sliding stream, fresh volume
+            vol.reset()
+            fence()
+            n_on = max(2, min(args.steps // 4, n_distinct // B))
+            vol.profile_enable(True)
+            t1 = time.perf_counter()
+            for k in range(n_on):
+                step(k, mode="online", window="sliding")
+            fence()
+            dt = time.perf_counter() - t1
+            on_launch_ms = vol.profile_launches()
+            vol.profile_read()
+            vol.profile_enable(False)
+            online = {"fps": n_on * B / dt, "launch_ms": on_launch_ms, "steps": n_on}
+
+
+    except Exception as e:  # a secondary leg must never cost the headline line
+        import traceback
+
+        traceback.print_exc()
+        secondary_error = f"{type(e).__name__}: {e}"
 
     if rank == 0:
         cpu = None
@@ -507,9 +518,19 @@ def main():
             out["replay_mode"] = replay
         if extraction is not None:
             out["extraction"] = extraction
+        if secondary_error:
+            out["secondary_error"] = secondary_error
         if secondary and not args.no_cpu_baseline:
             del vol, fuser
-            out["voxel_grid"] = voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, min(B, n_distinct), 5, 6)
+            for key, leg in (("voxel_grid", lambda: voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, min(B, n_distinct), 5, 6)),
+                             ("semantic", lambda: __import__("tools.bench_semantic", fromlist=["semantic_leg"]).semantic_leg(10, 2, 0.01))):
+                try:
+                    out[key] = leg()
+                except Exception as e:  # a secondary leg must never cost the headline line
+                    import traceback
+
+                    traceback.print_exc()
+                    out[key] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -16,13 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--frames", type=int, default=24)
-    ap.add_argument("--cpu-frames", type=int, default=4)
-    ap.add_argument("--voxel", type=float, default=0.01)
-    args = ap.parse_args()
+def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01):
+    """-> dict (bench.py's `semantic` key / this tool's JSON line)."""
+    import types
 
+    args = types.SimpleNamespace(frames=n_frames, cpu_frames=cpu_frames, voxel=voxel)
     import oracle
     from oracle import host_prep as hp
     from pyslam_amd.synthetic import SyntheticRGBD
@@ -90,7 +88,16 @@ def main():
             res["speedup_vs_cpu_reference"] = round(fps / res["cpu_reference"]["value"], 1)
         out[name] = res
         del g
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--voxel", type=float, default=0.01)
+    args = ap.parse_args()
+    print(json.dumps(semantic_leg(args.frames, args.cpu_frames, args.voxel)))
 
 
 if __name__ == "__main__":
