@@ -2,18 +2,21 @@
 // (Open3D ScalableTSDFVolume::ExtractTriangleMesh / ExtractPointCloud semantics; reference call
 // sites pyslam/dense/volumetric_integrator_tsdf.py:239-267).
 //
-// Marching cubes, one workgroup per allocated unit, the unit's (tsdf, weight) slab plus its +1 halo
-// (17^3 x 8 B = 39 KB) staged in LDS so the 8 corner fetches of every cube are LDS reads:
-//   k_mc_classify   cube validity/case per voxel; valid cubes OR their crossed edges into a per-unit
-//                   bitmask (3 axes x 4096 bits) keyed by the edge's owning voxel — the GPU analogue
-//                   of Open3D's edgeindex_to_vertexindex map; per-unit triangle counts
+// Marching cubes, one workgroup per allocated unit:
+//   k_mc_classify   the unit's tsdf slab plus its +1 halo (17^3 words, NaN where the weight is 0: 19.7 KB of LDS, 8 workgroups
+//                   per CU) staged so that the 8 corner fetches of every cube are LDS reads; cube case per voxel (kept, one
+//                   byte each, for the triangle pass); valid cubes OR their crossed edges into a per-unit bitmask (3 axes x
+//                   4096 bits) keyed by the edge's owning voxel - the GPU analogue of Open3D's edgeindex_to_vertexindex map;
+//                   per-unit triangle counts
 //   k_mc_prefix     per-unit popcount prefix of the edge bitmask (vertex rank inside the unit)
 //   rocPRIM scan    unit bases for vertices and triangles
-//   k_mc_vertices   one thread per set edge bit: interpolated vertex + colour (f64, as Open3D)
-//   k_mc_triangles  re-derives the cube case from LDS and emits triangles whose vertex indices are
-//                   base[unit(edge)] + rank(edge) — no hash map, no atomics in the emit passes.
+//   k_mc_vertices   one thread per 64-bit mask word walking its set bits: interpolated vertex + colour (f64, as Open3D)
+//   k_mc_triangles  reads the stored cube cases and emits triangles whose vertex indices are
+//                   base[unit(edge)] + rank(edge) - no hash map, no atomics in the emit passes.
 // Vertex/triangle *order* differs from Open3D's unordered_map iteration order (so does Open3D's
 // own from run to run); the vertex and triangle *sets* are identical to the CPU restatement.
+// "Sizes first, data second" (the binding's protocol) costs one computation: the size query does all the device work and
+// records it under the volume's content_version, the fetch only copies.
 #include <algorithm>
 
 #include "hv_common.h"

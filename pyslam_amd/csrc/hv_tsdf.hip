@@ -1075,7 +1075,7 @@ template <int ZH, int SPLIT, int WPE>
 __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
     char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
-    int general, const float *__restrict__ mult) {
+    int general, const float *__restrict__ mult, int xcd_aware) {
     static_assert(ZH % 2 == 0, "voxels are folded in pairs");
     constexpr int TASKS = 64 / ZH;          // wave tasks per unit
     constexpr int WAVES = TASKS / SPLIT;    // waves per workgroup
@@ -1095,9 +1095,24 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
     const uint32_t W24 = (uint32_t)P0.W;
     const float ntrunc = -P0.sdf_trunc_f, tinv = P0.sdf_trunc_inv_f;
     const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void *)mult, 0, npx * 4, 0x00020000);
-    for (int item = blockIdx.x; item < n_units * SPLIT; item += gridDim.x) {
-        const int t = item / SPLIT;
-        const int task = (item % SPLIT) * WAVES + wave;
+    // XCD-aware work distribution (workgroup b runs on XCD b % 8; each XCD has its own L2): the union list is in touch order,
+    // i.e. roughly in image raster order of the first frames, so XCD k takes the k-th CONTIGUOUS eighth of the list, all SPLIT
+    // parts of a unit included - its units project into one band of the images and its L2 only has to hold that band of the
+    // frame records, instead of every XCD pulling every frame whole (profiles/r02/baseline: 2.0x the algorithmic traffic).
+    const int chunk = (n_units + 7) >> 3;
+    for (int item = blockIdx.x; item < chunk * 8 * SPLIT; item += gridDim.x) {
+        int t, part;
+        if (xcd_aware) {
+            const int xcd = item & 7, j = item >> 3;
+            t = xcd * chunk + j / SPLIT;
+            part = j % SPLIT;
+            if (t >= n_units || j / SPLIT >= chunk) continue;
+        } else {
+            t = item / SPLIT;
+            part = item % SPLIT;
+            if (t >= n_units) continue;
+        }
+        const int task = part * WAVES + wave;
         const int cg = task & 3;            // column group: x in [4 cg, 4 cg + 4)
         const int z0 = (task >> 2) * ZH;
         const int x = cg * 4 + (lane >> 4);
@@ -1759,9 +1774,10 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
                        v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0, general, d_mult)
 #define HV_LAUNCH_SWEEP(ZH, S, WPE)                                                                                    \
     hipLaunchKernelGGL((k_tsdf_sweep<ZH, S, WPE>), dim3(sweep_grid), dim3(64 * (64 / ZH) / S), 0, v->stream, v->table,   \
-                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult)
+                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware)
         if (d_mult && sweep_form == 2) {
             const int wpe = getenv("HV_TSDF_SWEEP_WPE") ? atoi(getenv("HV_TSDF_SWEEP_WPE")) : 4; // 4 waves / SIMD = 128 VGPRs: nothing spills
+            const int xcd_aware = getenv("HV_TSDF_SWEEP_XCD") ? atoi(getenv("HV_TSDF_SWEEP_XCD")) : 1;
             if (sweep_zh == 8) {
                 if (split == 2) HV_LAUNCH_SWEEP(8, 2, 1); else if (wpe == 4) HV_LAUNCH_SWEEP(8, 4, 2); else HV_LAUNCH_SWEEP(8, 4, 1);
             } else if (split == 2) {

@@ -145,6 +145,7 @@ def sweep_case():
 
 SWEEP_FORMS = [
     {"HV_TSDF_SWEEP": "2"},                              # production: float2 chain, prefetched frame constants, packed colour
+    {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_XCD": "0"},    # work items in list order instead of one contiguous list eighth per XCD
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_WPE": "5"},    # the same at 96 VGPRs (5 waves / SIMD)
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_BATCH_SPLIT": "8"},  # 8 workgroups per unit
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_ZH": "8"},     # 8 voxels of a column per lane
