@@ -352,6 +352,18 @@ def main():
     secondary_error = None
     try:
         if secondary:
+            # first output tick of the process: includes the one-off page-locking of the host result arrays
+            t1 = time.perf_counter()
+            mesh = vol.extract_triangle_mesh()
+            t_mesh_cold = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            pc = vol.extract_point_cloud()
+            t_pc_cold = time.perf_counter() - t1
+            del mesh, pc
+            # every later tick (what a running reconstruction pays): one more keyframe - a revisit, so the unit set stays the
+            # one the timed region built - invalidates the cached result, then both extractions run again
+            vol.integrate(RGBDImage(rgb_d[0], depth_d[0], 1.0, DEPTH_TRUNC), Kcam, T_res[0])
+            fence()
             vol.profile_enable(True)
             t1 = time.perf_counter()
             mesh = vol.extract_triangle_mesh()
@@ -363,14 +375,21 @@ def main():
             k_pc = vol.profile_read()[0]
             vol.profile_enable(False)
             nv, nt, npts = len(mesh.vertices), len(mesh.triangles), len(pc.points)
+            # an unchanged volume extracted again (a paused map): the device result is cached, what is left is the D2H copy
+            del mesh
+            t1 = time.perf_counter()
+            mesh = vol.extract_triangle_mesh()
+            t_mesh_fetch = time.perf_counter() - t1
             b_mc_in = units_allocated * 4096 * 8
             b_mesh_out = nv * 48 + nt * 12
             b_pc_out = npts * 48
             extraction = {
                 "what": "extract_triangle_mesh + extract_point_cloud of the volume the timed region built "
-                        "(host-visible results: size query = all device work, fetch = D2H of the arrays, as the C ABI returns them)",
+                        "(host-visible results: size query = all device work, fetch = D2H into page-locked numpy arrays; *_wall_ms = a tick of a "
+                        "running reconstruction, *_first_call_ms = the first tick, which also page-locks the result arrays)",
                 "units": units_allocated, "vertices": nv, "triangles": nt, "points": npts,
-                "mesh_wall_ms": round(t_mesh * 1e3, 2), "mesh_kernel_ms": round(k_mesh, 3),
+                "mesh_wall_ms": round(t_mesh * 1e3, 2), "mesh_kernel_ms": round(k_mesh, 3), "mesh_fetch_only_ms": round(t_mesh_fetch * 1e3, 2),
+                "mesh_first_call_ms": round(t_mesh_cold * 1e3, 2), "points_first_call_ms": round(t_pc_cold * 1e3, 2),
                 "points_wall_ms": round(t_pc * 1e3, 2), "points_kernel_ms": round(k_pc, 3),
                 "roofline": {"bound": "hbm", "kernel": "k_mc_classify + k_mc_prefix + scans + k_mc_vertices + k_mc_triangles (once: the size query computes, the fetch copies)",
                              "algorithmic_bytes": int(b_mc_in + b_mesh_out), "achieved": round((b_mc_in + b_mesh_out) / (k_mesh * 1e-3) / 1e9, 1),

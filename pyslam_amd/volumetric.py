@@ -18,6 +18,25 @@ import numpy as np
 from . import _lib as L
 
 
+def _result_array(shape, dtype):
+    """Host array a large device result is copied into.  Page-locked when torch can provide it (hipHostMalloc behind torch's
+    caching host allocator: the block is reused from one output tick to the next) - the D2H copy of a 270 MB mesh then runs
+    as one DMA at PCIe speed instead of through the runtime's pageable staging; plain numpy otherwise or with
+    PYSLAM_AMD_PINNED_RESULTS=0.  Either way the caller gets an ordinary writable numpy array."""
+    import os
+
+    n = int(np.prod(shape))
+    if n * np.dtype(dtype).itemsize >= (1 << 20) and os.environ.get("PYSLAM_AMD_PINNED_RESULTS", "1") != "0":
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                return torch.empty(tuple(shape), dtype=getattr(torch, np.dtype(dtype).name), pin_memory=True).numpy()
+        except Exception:  # no torch / no pinned memory left: the pageable copy is still correct
+            pass
+    return np.empty(shape, dtype)
+
+
 def _as_f64_4x4(T):
     T = np.ascontiguousarray(np.asarray(T, dtype=np.float64))
     if T.shape != (4, 4):
@@ -550,9 +569,9 @@ class ScalableTSDFVolume(_Volume):
     def extract_triangle_mesh(self):
         nv, nt = ctypes.c_int64(), ctypes.c_int64()
         L.check(self._lib.hv_tsdf_extract_mesh(self._h, None, None, 0, None, 0, ctypes.byref(nv), ctypes.byref(nt)))
-        verts = np.zeros((nv.value, 3), np.float64)
-        cols = np.zeros((nv.value, 3), np.float64)
-        tris = np.zeros((nt.value, 3), np.int32)
+        verts = _result_array((nv.value, 3), np.float64)
+        cols = _result_array((nv.value, 3), np.float64)
+        tris = _result_array((nt.value, 3), np.int32)
         if nv.value or nt.value:
             L.check(
                 self._lib.hv_tsdf_extract_mesh(
@@ -564,8 +583,8 @@ class ScalableTSDFVolume(_Volume):
     def extract_point_cloud(self):
         n = ctypes.c_int64()
         L.check(self._lib.hv_tsdf_extract_points(self._h, None, None, 0, ctypes.byref(n)))
-        pts = np.zeros((n.value, 3), np.float64)
-        cols = np.zeros((n.value, 3), np.float64)
+        pts = _result_array((n.value, 3), np.float64)
+        cols = _result_array((n.value, 3), np.float64)
         if n.value:
             L.check(self._lib.hv_tsdf_extract_points(self._h, L.ptr(pts), L.ptr(cols), n.value, ctypes.byref(n)))
         return PointCloud(pts, cols)
