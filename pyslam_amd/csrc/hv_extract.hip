@@ -2,17 +2,17 @@
 // (Open3D ScalableTSDFVolume::ExtractTriangleMesh / ExtractPointCloud semantics; reference call
 // sites pyslam/dense/volumetric_integrator_tsdf.py:239-267).
 //
-// Marching cubes, one workgroup per allocated unit:
-//   k_mc_classify   the unit's tsdf slab plus its +1 halo (17^3 words, NaN where the weight is 0: 19.7 KB of LDS, 8 workgroups
-//                   per CU) staged so that the 8 corner fetches of every cube are LDS reads; cube case per voxel (kept, one
-//                   byte each, for the triangle pass); valid cubes OR their crossed edges into a per-unit bitmask (3 axes x
-//                   4096 bits) keyed by the edge's owning voxel - the GPU analogue of Open3D's edgeindex_to_vertexindex map;
-//                   per-unit triangle counts
-//   k_mc_prefix     per-unit popcount prefix of the edge bitmask (vertex rank inside the unit)
+// Marching cubes, per allocated unit:
+//   k_mc_classify   (workgroup) observed / negative bit masks per voxel column of the unit's 18^3 neighbourhood, straight from
+//                   the tsdf and weight planes; cube cases (kept, one byte each, for the triangle pass), the unit's own edge
+//                   bitmask (3 axes x 4096 bits, keyed by the edge's owning voxel - the GPU analogue of Open3D's
+//                   edgeindex_to_vertexindex map) as wave ballots, per-unit triangle counts.  No float slab, no atomics.
+//   k_mc_prefix     (workgroup) popcount prefix of the edge bitmask (vertex rank inside the unit)
 //   rocPRIM scan    unit bases for vertices and triangles
-//   k_mc_vertices   one thread per 64-bit mask word walking its set bits: interpolated vertex + colour (f64, as Open3D)
-//   k_mc_triangles  reads the stored cube cases and emits triangles whose vertex indices are
+//   k_mc_vertices   (wave) lane j builds vertices j, j + 64, ... of the unit: interpolated vertex + colour (f64, as Open3D)
+//   k_mc_triangles  (workgroup) reads the stored cube cases and emits triangles whose vertex indices are
 //                   base[unit(edge)] + rank(edge) - no hash map, no atomics in the emit passes.
+// Point cloud: k_pc_extract<false> counts per unit over a 17^3 LDS slab, scan, k_pc_extract<true> writes - no atomics either.
 // Vertex/triangle *order* differs from Open3D's unordered_map iteration order (so does Open3D's
 // own from run to run); the vertex and triangle *sets* are identical to the CPU restatement.
 // "Sizes first, data second" (the binding's protocol) costs one computation: the size query does all the device work and
@@ -113,35 +113,127 @@ __device__ __forceinline__ void edge_owner(int x, int y, int z, int i, int &n, i
     lin = voxel_word(ox & (R - 1), oy & (R - 1), oz & (R - 1));
 }
 
+// Classification of one unit from per-COLUMN bit masks.  Marching cubes only asks two things of a voxel - observed (weight
+// != 0) and negative - so a column (cx, cy) of the unit's 18^3 neighbourhood (-1 .. 16 in every direction: the cubes that
+// share this unit's edges reach one voxel back, its own cubes one voxel forward) is two 18-bit masks along z.  A thread
+// assembles the masks of its column straight from the (tsdf, weight) planes - every wave load is one 256-byte run -, the
+// 68 halo columns go to the first 68 threads, and 2.6 KB of LDS hold them all.  Then, per thread and with its 3 x 3
+// neighbouring column masks in registers:
+//   valid cubes of a cube column  V = AND over its four corner columns of (obs & obs >> 1)
+//   cube case of (x, y, z)        8 bits picked from the four negative masks (0 if !V or all set) - 16 bytes per thread
+//   vertex on the +z edge         (neg ^ neg >> 1) & obs-pair & (a valid cube among the four around the edge)
+//   vertex on the +x / +y edge    (neg ^ neg of the next column) & both observed & (a valid cube among the four)
+// which is Open3D's "for every valid cube with a mixed case, every crossing edge gets a vertex".  A unit's 192 mask words are
+// wave ballots (word = z * 4 + wave for each axis) and are all written: no atomics, nothing to clear.  (First form: a 17^3
+// float slab in LDS, 8 LDS reads per cube, one global atomicOr per crossing edge and cube - 0.45 of its 0.87 ms per 24 k
+// units were those atomics, profiles/r02.)
+static constexpr int H2 = 18;
 __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const char *__restrict__ pool, int n_units,
                                                       unsigned long long *__restrict__ edge_mask,
                                                       int32_t *__restrict__ tri_count, uint8_t *__restrict__ cases) {
-    __shared__ int s_nbr[8];
-    __shared__ float s_f[H * H * H];
+    __shared__ int s_nbr[27]; // pool index of the unit at offset (dx, dy, dz) in {-1, 0, 1}^3: [(dx + 1) + 3 (dy + 1) + 9 (dz + 1)]
+    __shared__ uint32_t s_obs[H2 * H2], s_neg[H2 * H2]; // [(cx + 1) * 18 + (cy + 1)], bit k <-> z = k - 1
     __shared__ int s_tris;
     const int idx = blockIdx.x;
     if (idx >= n_units) return;
     if (threadIdx.x == 0) s_tris = 0;
-    load_neighbours(table, idx, s_nbr);
-    __syncthreads();
-    load_slab(pool, s_nbr, s_f);
-    __syncthreads();
-    const int x = threadIdx.x >> 4, y = threadIdx.x & 15;
-    int tris = 0;
-    uint32_t packed[4] = {0u, 0u, 0u, 0u}; // the column's 16 cube cases, one byte each: the triangle pass reads them back
-    for (int z = 0; z < R; ++z) {
-        const int cube = cube_case(s_f, x, y, z);
-        packed[z >> 2] |= (uint32_t)cube << ((z & 3) * 8);
-        if (cube == 0) continue;
-        tris += c_tri_count[cube];
-        const unsigned em = c_edge_table[cube];
-        for (int i = 0; i < 12; ++i) {
-            if (!(em & (1u << i))) continue;
-            int n, axis, lin;
-            edge_owner(x, y, z, i, n, axis, lin);
-            const int oidx = s_nbr[n]; // exists: the owner is a corner with non-zero weight
-            atomicOr(&edge_mask[(int64_t)oidx * MASK_WORDS + axis * (RRR / 64) + (lin >> 6)], 1ull << (lin & 63));
+    if (threadIdx.x < 27) {
+        int32_t ux, uy, uz;
+        hv_unpack_key(table.block_keys[idx], ux, uy, uz);
+        const int n = threadIdx.x;
+        const int32_t kx = ux + n % 3 - 1, ky = uy + (n / 3) % 3 - 1, kz = uz + n / 9 - 1;
+        int r = -1;
+        if (n == 13) {
+            r = idx;
+        } else if (hv_key_in_range(kx, ky, kz)) {
+            const int32_t slot = hv_table_find(table, hv_pack_key(kx, ky, kz));
+            if (slot >= 0) r = table.vals[slot];
         }
+        s_nbr[n] = r;
+    }
+    __syncthreads();
+    // ---- column masks ----
+    for (int pass = 0; pass < 2; ++pass) {
+        int cx, cy;
+        if (pass == 0) {
+            cx = threadIdx.x >> 4;
+            cy = threadIdx.x & 15;
+        } else {
+            const int h = threadIdx.x; // halo columns: cx = -1 (18), cx = 16 (18), cy = -1 (16), cy = 16 (16)
+            if (h >= 68) break;
+            if (h < 18) { cx = -1; cy = h - 1; }
+            else if (h < 36) { cx = 16; cy = h - 19; }
+            else if (h < 52) { cx = h - 36; cy = -1; }
+            else { cx = h - 52; cy = 16; }
+        }
+        const int nxy = (cx < 0 ? 0 : cx >= R ? 2 : 1) + 3 * (cy < 0 ? 0 : cy >= R ? 2 : 1);
+        const int col = (cx & (R - 1)) * R + (cy & (R - 1));
+        float t[H2];
+        uint32_t w[H2];
+#pragma unroll
+        for (int k = 0; k < H2; ++k) {
+            const int z = k - 1;
+            const int nb = s_nbr[nxy + 9 * (z < 0 ? 0 : z >= R ? 2 : 1)];
+            t[k] = 0.f;
+            w[k] = 0u;
+            if (nb >= 0) {
+                const char *unit = pool + (int64_t)nb * UNIT_BYTES;
+                const int word = (z & (R - 1)) * RR + col;
+                t[k] = ((const float *)unit)[word];
+                w[k] = ((const uint32_t *)(unit + PLANE_BYTES))[word];
+            }
+        }
+        uint32_t obs = 0u, neg = 0u;
+#pragma unroll
+        for (int k = 0; k < H2; ++k) {
+            obs |= (w[k] != 0u ? 1u : 0u) << k;
+            neg |= (w[k] != 0u && t[k] < 0.0f ? 1u : 0u) << k;
+        }
+        s_obs[(cx + 1) * H2 + (cy + 1)] = obs;
+        s_neg[(cx + 1) * H2 + (cy + 1)] = neg;
+    }
+    __syncthreads();
+    // ---- classification of column (x, y) ----
+    const int x = threadIdx.x >> 4, y = threadIdx.x & 15;
+    uint32_t o[3][3], g[3][3]; // [dx + 1][dy + 1]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            o[a][b] = s_obs[(x + a) * H2 + (y + b)];
+            g[a][b] = s_neg[(x + a) * H2 + (y + b)];
+        }
+    auto pairz = [](uint32_t m) { return m & (m >> 1); };                                    // bit k: voxels k and k + 1
+    auto cubes = [&](int a, int b) { return pairz(o[a][b]) & pairz(o[a + 1][b]) & pairz(o[a][b + 1]) & pairz(o[a + 1][b + 1]); }; // bit k: cube z = k - 1 of cube column (x + a - 1, y + b - 1)
+    const uint32_t V11 = cubes(1, 1), V01 = cubes(0, 1), V10 = cubes(1, 0), V00 = cubes(0, 0);
+    // edges owned by voxel (x, y, z): bit z + 1
+    const uint32_t Wx = V11 | V10, Wy = V11 | V01;
+    const uint32_t Ex = (g[1][1] ^ g[2][1]) & o[1][1] & o[2][1] & (Wx | (Wx << 1));
+    const uint32_t Ey = (g[1][1] ^ g[1][2]) & o[1][1] & o[1][2] & (Wy | (Wy << 1));
+    const uint32_t Ez = (g[1][1] ^ (g[1][1] >> 1)) & pairz(o[1][1]) & (V11 | V01 | V10 | V00);
+    // this unit's mask words: axis * 64 + z * 4 + wave, bit = lane (= voxel_word & 63)
+    const int lane = hv_lane_id(), wave = threadIdx.x >> 6;
+    unsigned long long mine = 0ull; // lane k keeps ballot k (k = axis * 16 + z)
+#pragma unroll
+    for (int z = 0; z < R; ++z) {
+        const unsigned long long bx = __ballot((Ex >> (z + 1)) & 1u), by = __ballot((Ey >> (z + 1)) & 1u), bz = __ballot((Ez >> (z + 1)) & 1u);
+        if (lane == z) mine = bx;
+        if (lane == 16 + z) mine = by;
+        if (lane == 32 + z) mine = bz;
+    }
+    if (lane < 48) edge_mask[(int64_t)idx * MASK_WORDS + (lane >> 4) * (RRR / 64) + (lane & 15) * 4 + wave] = mine;
+    // cube cases of the column (corner i of hv_mc_shift: columns (x + sx, y + sy), voxel z + sz)
+    const uint32_t c0 = g[1][1] >> 1, c1 = g[2][1] >> 1, c2 = g[2][2] >> 1, c3 = g[1][2] >> 1; // bit z <-> voxel z
+    int tris = 0;
+    uint32_t packed[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int z = 0; z < R; ++z) {
+        int cube = (int)(((c0 >> z) & 1u) | (((c1 >> z) & 1u) << 1) | (((c2 >> z) & 1u) << 2) | (((c3 >> z) & 1u) << 3) |
+                         (((c0 >> (z + 1)) & 1u) << 4) | (((c1 >> (z + 1)) & 1u) << 5) | (((c2 >> (z + 1)) & 1u) << 6) |
+                         (((c3 >> (z + 1)) & 1u) << 7));
+        if (!((V11 >> (z + 1)) & 1u) || cube == 255) cube = 0;
+        packed[z >> 2] |= (uint32_t)cube << ((z & 3) * 8);
+        tris += c_tri_count[cube];
     }
     ((uint4 *)(cases + (int64_t)idx * RRR))[threadIdx.x] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
     if (tris) atomicAdd(&s_tris, tris);
@@ -173,28 +265,60 @@ struct HvMcParams {
     double voxel_length, half_voxel_length;
 };
 
-// One workgroup per unit, one thread per 64-bit word of its edge mask (192 words), walking the word's set bits: a unit has
-// ~120 vertices among 12 288 candidate edges - the first version's one thread per candidate launched 390 M threads for
-// 3.8 M vertices.
-__global__ __launch_bounds__(256) void k_mc_vertices(HvTable table, const char *__restrict__ pool, int n_units,
-                                                      const unsigned long long *__restrict__ edge_mask,
-                                                      const uint32_t *__restrict__ word_prefix,
-                                                      const int32_t *__restrict__ vert_base, HvMcParams M,
-                                                      double *__restrict__ vertices, double *__restrict__ colors,
-                                                      int64_t cap) {
+// One WAVE per unit.  A unit has ~120 vertices among 12 288 candidate edges, in ~40 of its 192 mask words: a thread per word
+// (second version) left most lanes idle behind a few that walked two or three vertices, one dependent round trip after the
+// other.  Here the unit's masks and prefixes go to LDS, vertex r of the unit is found by a binary search over the word
+// prefixes plus a select-the-nth-set-bit, and lane j builds vertices j, j + 64, ... - every lane busy, all their loads in
+// flight together, and four times as many units resident per CU.
+__device__ __forceinline__ int hv_nth_set_bit(unsigned long long m, int n) { // position of the n-th (0-based) set bit of m
+    int pos = 0;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const int c = __popcll((m >> pos) & ((1ull << s) - 1ull));
+        if (n >= c) {
+            n -= c;
+            pos += s;
+        }
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(64) void k_mc_vertices(HvTable table, const char *__restrict__ pool, int n_units,
+                                                     const unsigned long long *__restrict__ edge_mask,
+                                                     const uint32_t *__restrict__ word_prefix,
+                                                     const int32_t *__restrict__ vert_base, HvMcParams M,
+                                                     double *__restrict__ vertices, double *__restrict__ colors,
+                                                     int64_t cap) {
+    __shared__ unsigned long long s_mask[MASK_WORDS];
+    __shared__ uint32_t s_prefix[MASK_WORDS + 1];
     const int idx = blockIdx.x;
-    const int word = threadIdx.x;
-    if (idx >= n_units || word >= MASK_WORDS) return;
-    unsigned long long m = edge_mask[(int64_t)idx * MASK_WORDS + word];
-    if (m == 0ull) return;
-    const int axis = word / (RRR / 64);
-    int64_t vi = (int64_t)vert_base[idx] + word_prefix[(int64_t)idx * MASK_WORDS + word];
+    if (idx >= n_units) return;
+    const int lane = threadIdx.x;
+    for (int w = lane; w < MASK_WORDS; w += HV_WAVE) {
+        s_mask[w] = edge_mask[(int64_t)idx * MASK_WORDS + w];
+        s_prefix[w] = word_prefix[(int64_t)idx * MASK_WORDS + w];
+    }
+    const int64_t vbase = vert_base[idx];
+    const int total = (int)(vert_base[idx + 1] - vbase);
+    if (lane == 0) s_prefix[MASK_WORDS] = (uint32_t)total;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (total == 0) return;
     int32_t ux, uy, uz;
     hv_unpack_key(table.block_keys[idx], ux, uy, uz);
     const char *u0 = pool + (int64_t)idx * UNIT_BYTES;
-    for (; m != 0ull; m &= m - 1ull, ++vi) {
+    for (int r = lane; r < total; r += HV_WAVE) {
+        const int64_t vi = vbase + r;
         if (vi >= cap) return;
-        const int lin = (word % (RRR / 64)) * 64 + (__ffsll((long long)m) - 1);
+        // the word holding vertex r: the last one whose exclusive prefix is <= r (empty words share their successor's prefix)
+        int lo = 0, hi = MASK_WORDS; // prefix[lo] <= r < prefix[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_prefix[mid] <= (uint32_t)r) lo = mid; else hi = mid;
+        }
+        const int word = lo;
+        const int axis = word / (RRR / 64);
+        const int lin = (word % (RRR / 64)) * 64 + hv_nth_set_bit(s_mask[word], r - (int)s_prefix[word]);
         // owner voxel and its +axis neighbour
         const int z = lin / RR, x = (lin / R) % R, y = lin % R;
         int nx = x + (axis == 0), ny = y + (axis == 1), nz = z + (axis == 2);
@@ -288,74 +412,40 @@ __global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, int n_units
     }
 }
 
-// ScalableTSDFVolume::ExtractPointCloud: one thread per voxel, three candidate edges (+x, +y, +z) each.  Hits are ranked
-// inside the 1024-thread workgroup (wave prefix + LDS across the 16 waves) and the workgroup takes its output range with ONE
-// atomic - the first version's one atomic per wave and axis on a single counter serialised the kernel (8.8 ms for 32 k
-// units; profiles/r02/baseline).
-__global__ __launch_bounds__(1024) void k_pc_extract(HvTable table, const char *__restrict__ pool, int n_units,
-                                                      HvMcParams M, double unit_length, double *__restrict__ points,
-                                                      double *__restrict__ colors, int64_t cap) {
-    __shared__ int s_wave[16];
-    __shared__ int s_base;
-    __shared__ int s_nbr3[3]; // pool indices of the +x, +y, +z neighbour units (a workgroup = a quarter of ONE unit)
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = gid < (int64_t)n_units * RRR;
-    const int idx = in_range ? (int)(gid / RRR) : 0;
-    if (threadIdx.x < 3) {
-        int r = -1;
-        if ((int64_t)blockIdx.x * blockDim.x < (int64_t)n_units * RRR) {
-            int32_t kx, ky, kz;
-            hv_unpack_key(table.block_keys[(int)(((int64_t)blockIdx.x * blockDim.x) / RRR)], kx, ky, kz);
-            kx += threadIdx.x == 0;
-            ky += threadIdx.x == 1;
-            kz += threadIdx.x == 2;
-            if (hv_key_in_range(kx, ky, kz)) {
-                const int32_t slot = hv_table_find(table, hv_pack_key(kx, ky, kz));
-                if (slot >= 0) r = table.vals[slot];
-            }
-        }
-        s_nbr3[threadIdx.x] = r;
-    }
+// ScalableTSDFVolume::ExtractPointCloud: a voxel (weight != 0, tsdf in [-0.98, 0.98)) and its +x / +y / +z neighbour of the
+// same kind with the opposite sign give one interpolated point.  One workgroup per unit over the same 17^3 LDS slab as the
+// mesh passes (NaN = not observed), one thread per (x, y) column.  Pass 1 (FILL = false) counts the unit's points; after an
+// exclusive scan over the units pass 2 stages the slab again and writes every point at its final index - no atomics, and the
+// output order is deterministic (unit, column, z, axis).  (Second form.  The first - one thread per voxel, its neighbours
+// re-read from global memory, a workgroup-aggregated append - cost 1.43 ms per pass over 32 k units, 128 k returning atomics
+// on one counter; profiles/r02.)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *__restrict__ pool, int n_units, HvMcParams M,
+                                                     double unit_length, int32_t *__restrict__ count,
+                                                     const int32_t *__restrict__ base, double *__restrict__ points,
+                                                     double *__restrict__ colors, int64_t cap) {
+    __shared__ int s_nbr[8];
+    __shared__ float s_f[H * H * H];
+    __shared__ int s_wave[4];
+    const int idx = blockIdx.x;
+    if (idx >= n_units) return;
+    load_neighbours(table, idx, s_nbr);
     __syncthreads();
-    const int lin = in_range ? (int)(gid % RRR) : 0;
-    const int z = lin / RR, x = (lin / R) % R, y = lin % R;
-    const char *u0 = pool + (int64_t)idx * UNIT_BYTES;
-    float f0 = 0.f;
-    uint32_t w0 = 0;
-    int32_t ux = 0, uy = 0, uz = 0;
-    if (in_range) {
-        f0 = ((const float *)u0)[lin];
-        w0 = ((const uint32_t *)(u0 + PLANE_BYTES))[lin];
-        hv_unpack_key(table.block_keys[idx], ux, uy, uz);
-    }
-    const bool base_ok = in_range && w0 != 0u && f0 < 0.98f && f0 >= -0.98f;
-    float f1[3] = {0.f, 0.f, 0.f};
-    int nidx[3] = {-1, -1, -1}, nl[3] = {0, 0, 0};
-    unsigned hits = 0;
-    if (base_ok) {
+    load_slab(pool, s_nbr, s_f);
+    __syncthreads();
+    const int x = threadIdx.x >> 4, y = threadIdx.x & 15;
+    // hits of this column: bit z * 3 + axis
+    unsigned long long hits = 0ull;
+    for (int z = 0; z < R; ++z) {
+        const float f0 = s_f[(x * H + y) * H + z];
+        if (!(f0 < 0.98f && f0 >= -0.98f)) continue; // also rejects NaN (weight 0)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            int nx = x + (i == 0), ny = y + (i == 1), nz = z + (i == 2);
-            int ni = idx;
-            if (nx >= R || ny >= R || nz >= R) { // the +axis neighbour lives in the next unit along that axis (looked up once per workgroup)
-                ni = s_nbr3[i];
-                nx &= R - 1; ny &= R - 1; nz &= R - 1;
-            }
-            if (ni < 0) continue;
-            const char *u1 = pool + (int64_t)ni * UNIT_BYTES;
-            const int l1 = voxel_word(nx, ny, nz);
-            const float f = ((const float *)u1)[l1];
-            const uint32_t w1 = ((const uint32_t *)(u1 + PLANE_BYTES))[l1];
-            if (w1 != 0u && f < 0.98f && f >= -0.98f && f0 * f < 0) {
-                hits |= 1u << i;
-                f1[i] = f;
-                nidx[i] = ni;
-                nl[i] = l1;
-            }
+            const float f = s_f[((x + (i == 0)) * H + (y + (i == 1))) * H + (z + (i == 2))];
+            if (f < 0.98f && f >= -0.98f && f0 * f < 0) hits |= 1ull << (z * 3 + i);
         }
     }
-    // rank of this thread's hits inside the workgroup
-    const int mine = __popc(hits);
+    const int mine = __popcll(hits);
     const int lane = hv_lane_id(), wave = threadIdx.x >> 6;
     int incl = mine;
 #pragma unroll
@@ -365,45 +455,49 @@ __global__ __launch_bounds__(1024) void k_pc_extract(HvTable table, const char *
     }
     if (lane == HV_WAVE - 1) s_wave[wave] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int total = 0;
-        for (int w = 0; w < 16; ++w) {
-            const int c = s_wave[w];
-            s_wave[w] = total;
-            total += c;
-        }
-        s_base = total ? atomicAdd(&table.counters[HV_CNT_OUT], total) : 0;
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    if (!FILL) {
+        if (threadIdx.x == 255) count[idx] = before + incl;
+        return;
     }
-    __syncthreads();
-    if (!hits || points == nullptr) return;
-    int64_t at = (int64_t)s_base + s_wave[wave] + incl - mine;
-    float c0[3];
+    if (!hits) return;
+    int64_t at = (int64_t)base[idx] + before + incl - mine;
+    int32_t ux, uy, uz;
+    hv_unpack_key(table.block_keys[idx], ux, uy, uz);
+    const char *u0 = pool + (int64_t)idx * UNIT_BYTES;
+    for (; hits != 0ull; hits &= hits - 1ull, ++at) {
+        if (at >= cap) return;
+        const int bit = __ffsll((long long)hits) - 1;
+        const int z = bit / 3, i = bit - z * 3;
+        const int lin = voxel_word(x, y, z);
+        const float f0 = ((const float *)u0)[lin];
+        const uint32_t w0 = ((const uint32_t *)(u0 + PLANE_BYTES))[lin];
+        int nx = x + (i == 0), ny = y + (i == 1), nz = z + (i == 2);
+        const int ni = s_nbr[(nx >= R ? 1 : 0) | (ny >= R ? 2 : 0) | (nz >= R ? 4 : 0)];
+        nx &= R - 1; ny &= R - 1; nz &= R - 1;
+        const char *u1 = pool + (int64_t)ni * UNIT_BYTES;
+        const int l1 = voxel_word(nx, ny, nz);
+        const float f1 = ((const float *)u1)[l1];
+        const double w1 = (double)((const uint32_t *)(u1 + PLANE_BYTES))[l1];
+        float c0[3], c1[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) // color_.cast<float>() of the double running mean
-        c0[k] = (float)((double)((const uint32_t *)(u0 + (2 + k) * PLANE_BYTES))[lin] / (double)w0);
-    const double p0[3] = {(M.half_voxel_length + M.voxel_length * (double)x) + (double)ux * unit_length,
-                          (M.half_voxel_length + M.voxel_length * (double)y) + (double)uy * unit_length,
-                          (M.half_voxel_length + M.voxel_length * (double)z) + (double)uz * unit_length};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        if (!(hits & (1u << i))) continue;
-        if (at < cap) {
-            const char *u1 = pool + (int64_t)nidx[i] * UNIT_BYTES;
-            const double w1 = (double)((const uint32_t *)(u1 + PLANE_BYTES))[nl[i]];
-            float c1[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) c1[k] = (float)((double)((const uint32_t *)(u1 + (2 + k) * PLANE_BYTES))[nl[i]] / w1);
-            const float r0 = fabsf(f0), r1 = fabsf(f1[i]);
-            double p[3] = {p0[0], p0[1], p0[2]};
-            const double p1i = p0[i] + M.voxel_length;
-            p[i] = (p0[i] * (double)r1 + p1i * (double)r0) / (double)(r0 + r1);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                points[at * 3 + k] = p[k];
-                colors[at * 3 + k] = (double)((c0[k] * r1 + c1[k] * r0) / (r0 + r1) / 255.0f);
-            }
+        for (int k = 0; k < 3; ++k) { // color_.cast<float>() of the double running mean
+            c0[k] = (float)((double)((const uint32_t *)(u0 + (2 + k) * PLANE_BYTES))[lin] / (double)w0);
+            c1[k] = (float)((double)((const uint32_t *)(u1 + (2 + k) * PLANE_BYTES))[l1] / w1);
         }
-        ++at;
+        const double p0[3] = {(M.half_voxel_length + M.voxel_length * (double)x) + (double)ux * unit_length,
+                              (M.half_voxel_length + M.voxel_length * (double)y) + (double)uy * unit_length,
+                              (M.half_voxel_length + M.voxel_length * (double)z) + (double)uz * unit_length};
+        const float r0 = fabsf(f0), r1 = fabsf(f1);
+        double p[3] = {p0[0], p0[1], p0[2]};
+        const double p1i = p0[i] + M.voxel_length;
+        p[i] = (p0[i] * (double)r1 + p1i * (double)r0) / (double)(r0 + r1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            points[at * 3 + k] = p[k];
+            colors[at * 3 + k] = (double)((c0[k] * r1 + c1[k] * r0) / (r0 + r1) / 255.0f);
+        }
     }
 }
 
@@ -471,7 +565,6 @@ static int mesh_compute(hv_volume *v) {
     int32_t *tri_base = vert_base + (n + 1);
     uint8_t *cases = (uint8_t *)(base + cases_off);
     hv_profile_begin(v); // measurement hook: classify + prefix + scans
-    HV_HIP(hipMemsetAsync(edge_mask, 0, mask_bytes, v->stream));
     HV_HIP(hipMemsetAsync(vert_count, 0, 2 * cnt_bytes, v->stream));
     hipLaunchKernelGGL(k_mc_classify, dim3(n), dim3(256), 0, v->stream, v->table, (const char *)v->pool, n, edge_mask,
                        tri_count, cases);
@@ -495,7 +588,7 @@ static int mesh_compute(hv_volume *v) {
         double *d_vert = (double *)v->out_a, *d_col = d_vert + 3 * nv;
         HvMcParams M{v->cfg.voxel_size, v->cfg.voxel_size * 0.5};
         hv_profile_begin(v); // vertices + triangles (D2H of the results is outside the bracket)
-        hipLaunchKernelGGL(k_mc_vertices, dim3(n), dim3(256), 0, v->stream, v->table,
+        hipLaunchKernelGGL(k_mc_vertices, dim3(n), dim3(64), 0, v->stream, v->table,
                            (const char *)v->pool, n, edge_mask, word_prefix, vert_base, M, d_vert, d_col, nv);
         hipLaunchKernelGGL(k_mc_triangles, dim3(n), dim3(256), 0, v->stream, v->table, n, (const uint8_t *)cases, edge_mask,
                            word_prefix, vert_base, tri_base, (int32_t *)v->out_b, nt);
@@ -544,26 +637,31 @@ static int points_compute(hv_volume *v) {
         return HV_OK;
     }
     HvMcParams M{v->cfg.voxel_size, v->cfg.voxel_size * 0.5};
-    const int64_t total = nb * RRR;
-    const unsigned blocks = (unsigned)((total + 1023) / 1024);
-    // pass 1 counts (tsdf + weight planes only), pass 2 writes into a buffer of exactly that size
-    hv_profile_begin(v);
-    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
-    hipLaunchKernelGGL(k_pc_extract, dim3(blocks), dim3(1024), 0, v->stream, v->table, (const char *)v->pool, (int)nb, M,
-                       v->cfg.voxel_size * (double)R, (double *)nullptr, (double *)nullptr, (int64_t)0);
-    hv_profile_end(v, nb);
-    HV_HIP(hipGetLastError());
-    rc = hv_read_counters(v);
+    const int nu = (int)nb;
+    // scratch: [count nu+1][base nu+1]
+    rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, sizeof(int32_t) * 2 * (size_t)(nu + 1));
     if (rc != HV_OK) return rc;
-    const int64_t n = v->h_counters[HV_CNT_OUT];
+    int32_t *count = (int32_t *)v->out_c, *base = count + (nu + 1);
+    // pass 1 counts per unit (tsdf + weight planes only), the scan places the units, pass 2 writes into a buffer of exactly
+    // that size
+    hv_profile_begin(v);
+    hipLaunchKernelGGL(k_pc_extract<false>, dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, nu, M,
+                       v->cfg.voxel_size * (double)R, count, (const int32_t *)nullptr, (double *)nullptr, (double *)nullptr, (int64_t)0);
+    HV_HIP(hipGetLastError());
+    rc = exclusive_scan_i32(v, count, base, nu + 1);
+    if (rc != HV_OK) return rc;
+    hv_profile_end(v, nb);
+    int32_t total = 0;
+    HV_HIP(hipMemcpyAsync(&total, base + nu, sizeof(int32_t), hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipStreamSynchronize(v->stream));
+    const int64_t n = total;
     if (n > 0) {
         rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, sizeof(double) * 6 * (size_t)n);
         if (rc != HV_OK) return rc;
         double *d_pts = (double *)v->out_a, *d_cols = d_pts + 3 * n;
         hv_profile_begin(v);
-        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
-        hipLaunchKernelGGL(k_pc_extract, dim3(blocks), dim3(1024), 0, v->stream, v->table, (const char *)v->pool, (int)nb, M,
-                           v->cfg.voxel_size * (double)R, d_pts, d_cols, n);
+        hipLaunchKernelGGL(k_pc_extract<true>, dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, nu, M,
+                           v->cfg.voxel_size * (double)R, (int32_t *)nullptr, (const int32_t *)base, d_pts, d_cols, n);
         hv_profile_end(v, nb);
         HV_HIP(hipGetLastError());
     }
