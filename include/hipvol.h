@@ -98,6 +98,10 @@ int hv_dropped_points(hv_volume *v, int64_t *n); /* points/pixels rejected becau
  *   Result is bit-identical to the reference's sequential (point-index-order) accumulation. */
 int hv_integrate_points(hv_volume *v, const float *points, int64_t n, const void *colors,
                         int32_t color_dtype, int32_t loc);
+/* The binding's float64 overload (volumetric_grid_module.h:738-741 -> integrate_raw<double, ...>): voxel keys come from the
+ * doubles (floor(x * (double)inv_voxel_size)), the voxel sums take static_cast<float>(x) (voxel_data.h:54-56). */
+int hv_integrate_points_f64(hv_volume *v, const double *points, int64_t n, const void *colors,
+                            int32_t color_dtype, int32_t loc);
 
 /* Fused L3 prep + integrate for one posed RGB-D frame: depth2pointcloud (pyslam/utilities/depth.py:
  * 45-85) + world transform (volumetric_integrator_voxel_grid.py:262-281) + integrate, without the

@@ -102,6 +102,7 @@ def _load_ref():
     L.ref_grid_destroy.argtypes = [_vp]
     L.ref_grid_clear.argtypes = [_vp]
     L.ref_grid_integrate.argtypes = [_vp, _vp, _i64, _vp, _i32]
+    L.ref_grid_integrate_f64.argtypes = [_vp, _vp, _i64, _vp, _i32]
     for name in ("ref_grid_num_blocks", "ref_grid_size", "ref_grid_total_voxel_count"):
         getattr(L, name).restype = _i64
         getattr(L, name).argtypes = [_vp]
@@ -206,8 +207,14 @@ class _GridBase:
             self._h = None
 
     def integrate(self, points, colors=None):
-        points = np.ascontiguousarray(points, dtype=np.float32)
+        """float64 points take the binding's double overload where the library has it (the compiled reference); everything
+        else goes through float32, as pybind11's no-convert pass dispatches."""
         kind, cols = _color_kind(colors)
+        if np.asarray(points).dtype == np.float64 and "integrate_f64" in self._names:
+            points = np.ascontiguousarray(points, dtype=np.float64)
+            getattr(self._lib, self._names["integrate_f64"])(self._h, _ptr(points), points.shape[0], _ptr(cols), kind)
+            return
+        points = np.ascontiguousarray(points, dtype=np.float32)
         getattr(self._lib, self._names["integrate"])(self._h, _ptr(points), points.shape[0], _ptr(cols), kind)
 
     def num_blocks(self):
@@ -288,7 +295,7 @@ class RefGrid(_GridBase):
         self._names = {
             k: "ref_grid_" + k
             for k in (
-                "create destroy integrate num_blocks size empty clear remove_low_count dump "
+                "create destroy integrate integrate_f64 num_blocks size empty clear remove_low_count dump "
                 "get_voxels get_voxels_in_bb get_voxels_in_frustum carve"
             ).split()
         }

@@ -89,6 +89,20 @@ void ref_grid_integrate(void *gv, const float *pts, int64_t n, const void *cols,
     }
 }
 
+// the binding's py::array_t<double> overload (volumetric_grid_module.h:738-741): integrate_raw<double, ...>
+void ref_grid_integrate_f64(void *gv, const double *pts, int64_t n, const void *cols, int color_kind) {
+    auto *g = static_cast<DumpableGrid *>(gv);
+    if (color_kind == 0) {
+        g->integrate_raw<double>(pts, static_cast<size_t>(n));
+    } else if (color_kind == 1) {
+        g->integrate_raw<double, uint8_t>(pts, static_cast<size_t>(n),
+                                          static_cast<const uint8_t *>(cols));
+    } else {
+        g->integrate_raw<double, float>(pts, static_cast<size_t>(n),
+                                        static_cast<const float *>(cols));
+    }
+}
+
 int64_t ref_grid_num_blocks(void *g) {
     return static_cast<int64_t>(static_cast<DumpableGrid *>(g)->num_blocks());
 }

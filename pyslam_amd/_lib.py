@@ -56,6 +56,7 @@ SIGNATURES = {
     "hv_bytes_per_block": (_i32, [_vp, _pi64]),
     "hv_dropped_points": (_i32, [_vp, _pi64]),
     "hv_integrate_points": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32]),
+    "hv_integrate_points_f64": (_i32, [_vp, _vp, _i64, _vp, _i32, _i32]),
     "hv_integrate_rgbd_points": (_i32, [_vp, _vp, _i32, _f64, _vp, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_integrate_rgbd_points_batch": (_i32, [_vp, _vp, _i32, _f64, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_remap": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32]),

@@ -28,10 +28,14 @@ struct HvPointKey {
     int32_t v[3], b[3], l[3];
 };
 
-// get_voxel_key_inv<float,float> + get_block_key + get_local_voxel_key
-__device__ __forceinline__ HvPointKey hv_point_key(float x, float y, float z, const HvGridParams &G) {
+// get_voxel_key_inv<Tp,float> + get_block_key + get_local_voxel_key.  Tp = float: floorf(x * inv) in float; Tp = double (the
+// binding's py::array_t<double> overload, volumetric_grid_module.h:738-741): the float inverse voxel size is promoted and the
+// product and floor are double - a float64 point near a cell border keeps its own cell instead of its float32 neighbour's.
+template <typename Tp>
+__device__ __forceinline__ HvPointKey hv_point_key(Tp x, Tp y, Tp z, const HvGridParams &G) {
     HvPointKey k;
-    const float f[3] = {floorf(x * G.inv_voxel_size), floorf(y * G.inv_voxel_size), floorf(z * G.inv_voxel_size)};
+    const Tp inv = (Tp)G.inv_voxel_size;
+    const Tp f[3] = {floor(x * inv), floor(y * inv), floor(z * inv)};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         k.v[a] = (int32_t)f[a];
@@ -43,11 +47,19 @@ __device__ __forceinline__ HvPointKey hv_point_key(float x, float y, float z, co
     }
     return k;
 }
+// the point is finite and its voxel index fits the 32-bit key
+template <typename Tp>
+__device__ __forceinline__ bool hv_point_keyable(Tp x, Tp y, Tp z, const HvGridParams &G) {
+    const Tp inv = (Tp)G.inv_voxel_size, lim = (Tp)1.0e9;
+    return isfinite(x) && isfinite(y) && isfinite(z) && fabs(x * inv) < lim && fabs(y * inv) < lim && fabs(z * inv) < lim;
+}
 
-__global__ __launch_bounds__(256) void k_vg_keys(HvTable table, const float *__restrict__ pts, int64_t n,
+// pts64 != nullptr: the caller's points are float64 - keys from the doubles, and the float32 narrowing the voxel sums take
+// (position_sum += static_cast<float>(x), voxel_data.h:54-56) is written to pts for the reduce.
+__global__ __launch_bounds__(256) void k_vg_keys(HvTable table, float *__restrict__ pts, int64_t n,
                                                   HvGridParams G, uint32_t *__restrict__ keys_out,
                                                   uint32_t *__restrict__ vals_out,
-                                                  const uint32_t *__restrict__ valid_mask_keys) {
+                                                  const uint32_t *__restrict__ valid_mask_keys, const double *__restrict__ pts64) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     vals_out[i] = (uint32_t)i;
@@ -55,11 +67,22 @@ __global__ __launch_bounds__(256) void k_vg_keys(HvTable table, const float *__r
         keys_out[i] = HV_SORT_SENTINEL;
         return;
     }
-    const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
     uint32_t key = HV_SORT_SENTINEL;
-    if (isfinite(x) && isfinite(y) && isfinite(z) && fabsf(x * G.inv_voxel_size) < 1.0e9f &&
-        fabsf(y * G.inv_voxel_size) < 1.0e9f && fabsf(z * G.inv_voxel_size) < 1.0e9f) {
-        const HvPointKey k = hv_point_key(x, y, z, G);
+    bool keyable;
+    HvPointKey k;
+    if (pts64 != nullptr) {
+        const double x = pts64[i * 3 + 0], y = pts64[i * 3 + 1], z = pts64[i * 3 + 2];
+        pts[i * 3 + 0] = (float)x;
+        pts[i * 3 + 1] = (float)y;
+        pts[i * 3 + 2] = (float)z;
+        keyable = hv_point_keyable(x, y, z, G);
+        if (keyable) k = hv_point_key(x, y, z, G);
+    } else {
+        const float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+        keyable = hv_point_keyable(x, y, z, G);
+        if (keyable) k = hv_point_key(x, y, z, G);
+    }
+    if (keyable) {
         if (hv_key_in_range(k.b[0], k.b[1], k.b[2])) {
             const int32_t slot = hv_table_insert(table, hv_pack_key(k.b[0], k.b[1], k.b[2]));
             if (slot >= 0) {
@@ -208,13 +231,15 @@ __global__ __launch_bounds__(256) void k_vgb_count(HvTable table, float *__restr
                                                     int32_t *__restrict__ pslot, uint32_t *__restrict__ plidx,
                                                     const uint32_t *__restrict__ valid_mask_keys, int32_t *__restrict__ cnt,
                                                     HvUnprojectParams U, const void *__restrict__ depth_raw,
-                                                    const uint8_t *__restrict__ rgb, float *__restrict__ cols_out) {
+                                                    const uint8_t *__restrict__ rgb, float *__restrict__ cols_out,
+                                                    const double *__restrict__ pts64) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int32_t slot = -1;
     uint32_t lidx = 0;
     if (i < n) {
         bool masked;
         float x = 0.f, y = 0.f, z = 0.f;
+        double xd = 0.0, yd = 0.0, zd = 0.0; // pts64 != nullptr (never with FUSED): float64 points, see k_vg_keys
         if (FUSED) {
             float pt[3], col[3];
             masked = !hv_unproject_pixel(U, depth_raw, rgb, i, pt, col);
@@ -229,13 +254,18 @@ __global__ __launch_bounds__(256) void k_vgb_count(HvTable table, float *__restr
         } else {
             masked = valid_mask_keys != nullptr && valid_mask_keys[i] == HV_SORT_SENTINEL; // pixel rejected by the unprojection
             if (!masked) {
-                x = pts[i * 3 + 0]; y = pts[i * 3 + 1]; z = pts[i * 3 + 2];
+                if (pts64 != nullptr) {
+                    xd = pts64[i * 3 + 0]; yd = pts64[i * 3 + 1]; zd = pts64[i * 3 + 2];
+                    pts[i * 3 + 0] = (float)xd; pts[i * 3 + 1] = (float)yd; pts[i * 3 + 2] = (float)zd;
+                } else {
+                    x = pts[i * 3 + 0]; y = pts[i * 3 + 1]; z = pts[i * 3 + 2];
+                }
             }
         }
         if (!masked) {
-            if (isfinite(x) && isfinite(y) && isfinite(z) && fabsf(x * G.inv_voxel_size) < 1.0e9f &&
-                fabsf(y * G.inv_voxel_size) < 1.0e9f && fabsf(z * G.inv_voxel_size) < 1.0e9f) {
-                const HvPointKey k = hv_point_key(x, y, z, G);
+            const bool wide = !FUSED && pts64 != nullptr;
+            if (wide ? hv_point_keyable(xd, yd, zd, G) : hv_point_keyable(x, y, z, G)) {
+                const HvPointKey k = wide ? hv_point_key(xd, yd, zd, G) : hv_point_key(x, y, z, G);
                 if (hv_key_in_range(k.b[0], k.b[1], k.b[2])) {
                     slot = hv_table_insert(table, hv_pack_key(k.b[0], k.b[1], k.b[2]));
                     lidx = (uint32_t)(k.l[0] + k.l[1] * G.bs + k.l[2] * G.bs * G.bs); // voxel_block.h:67-70
@@ -800,7 +830,8 @@ struct HvFrameSource {
 };
 
 static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, const void *d_cols,
-                                   int color_kind, const uint32_t *d_valid, const HvFrameSource *frame = nullptr) {
+                                   int color_kind, const uint32_t *d_valid, const HvFrameSource *frame = nullptr,
+                                   const double *d_pts64 = nullptr) {
     const HvGridParams G = grid_params(v);
     const unsigned blocks = (unsigned)((n + 255) / 256);
     bool checked = false;
@@ -818,11 +849,11 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
             if (frame)
                 hipLaunchKernelGGL(k_vgb_count<true>, dim3(blocks), dim3(256), 0, v->stream, v->table, (float *)d_pts, n, G,
                                    (int32_t *)v->sort_vals_in, v->sort_keys_out, (const uint32_t *)nullptr, v->vg_cnt, frame->U,
-                                   frame->d_depth, frame->d_rgb, (float *)d_cols);
+                                   frame->d_depth, frame->d_rgb, (float *)d_cols, (const double *)nullptr);
             else
                 hipLaunchKernelGGL(k_vgb_count<false>, dim3(blocks), dim3(256), 0, v->stream, v->table, (float *)d_pts, n, G,
                                    (int32_t *)v->sort_vals_in, v->sort_keys_out, d_valid, v->vg_cnt, HvUnprojectParams{},
-                                   (const void *)nullptr, (const uint8_t *)nullptr, (float *)nullptr);
+                                   (const void *)nullptr, (const uint8_t *)nullptr, (float *)nullptr, d_pts64);
             if (!checked) break;
             rc = hv_claims_fit(v); // blocks that did not fit: grow and claim again (the counts restart from clean arrays)
             if (rc == HV_OK) break;
@@ -868,8 +899,8 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
     if (rc != HV_OK) return rc;
     hv_profile_begin(v); // measurement hook: keys + sort + ordered reduce of one integrate call
     for (int attempt = 0;; ++attempt) {
-        hipLaunchKernelGGL(k_vg_keys, dim3(blocks), dim3(256), 0, v->stream, v->table, d_pts, n, G, v->sort_keys_in,
-                           v->sort_vals_in, d_valid);
+        hipLaunchKernelGGL(k_vg_keys, dim3(blocks), dim3(256), 0, v->stream, v->table, (float *)d_pts, n, G, v->sort_keys_in,
+                           v->sort_vals_in, d_valid, d_pts64);
         if (!checked) break;
         rc = hv_claims_fit(v); // blocks that did not fit: grow, claim again (sort keys embed table slots)
         if (rc == HV_OK) break;
@@ -965,6 +996,30 @@ int hv_integrate_points(hv_volume *v, const float *points, int64_t n, const void
         if (rc != HV_OK) return rc;
     }
     return integrate_device_points(v, (const float *)d_pts, n, d_cols, color_dtype, nullptr);
+}
+
+int hv_integrate_points_f64(hv_volume *v, const double *points, int64_t n, const void *colors, int32_t color_dtype,
+                            int32_t loc) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_integrate_points_f64: null volume");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_GRID, HV_ERR_MODE, "hv_integrate_points_f64: volume is not in VOXEL_GRID mode");
+    if (n == 0) return HV_OK; // integrate_raw: `if (num_points == 0) return;`
+    HV_REQUIRE(points != nullptr && n > 0, HV_ERR_INVALID, "points must be a contiguous Nx3 array");
+    HV_REQUIRE(color_dtype == HV_COLOR_NONE || color_dtype == HV_COLOR_U8 || color_dtype == HV_COLOR_F32,
+               HV_ERR_INVALID, "Colors must be uint8 or float32");
+    HV_REQUIRE(color_dtype == HV_COLOR_NONE || colors != nullptr, HV_ERR_INVALID,
+               "points and colors must have the same size");
+    HV_REQUIRE(n <= v->cfg.max_points, HV_ERR_CAPACITY, "hv_integrate_points_f64: %lld points exceed max_points=%lld",
+               (long long)n, (long long)v->cfg.max_points);
+    HV_HIP(hipSetDevice(v->device));
+    const void *d_pts64 = nullptr, *d_cols = nullptr;
+    int rc = hv_stage_in(v, points, sizeof(double) * 3 * (size_t)n, loc, 0, &d_pts64);
+    if (rc != HV_OK) return rc;
+    if (color_dtype != HV_COLOR_NONE) {
+        rc = hv_stage_in(v, colors, (color_dtype == HV_COLOR_U8 ? 1 : 4) * 3 * (size_t)n, loc, 1, &d_cols);
+        if (rc != HV_OK) return rc;
+    }
+    // keys from the doubles; the key kernel leaves the float32 narrowing the voxel sums take in scratch_points
+    return integrate_device_points(v, v->scratch_points, n, d_cols, color_dtype, nullptr, nullptr, (const double *)d_pts64);
 }
 
 } // extern "C" (reopened below)

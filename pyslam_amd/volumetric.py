@@ -250,18 +250,21 @@ class VoxelBlockGrid(_Volume):
 
     # -- integrate -------------------------------------------------------------------------------
     def integrate(self, points, colors=None):
-        """points: [N,3] float32 (float64 is narrowed to float32); colors: [N,3] uint8|float32|None."""
+        """points: [N,3] float32 or float64 (the binding's two overloads, volumetric_grid_module.h:738-749: float64 points
+        are keyed in double, anything else goes through float32); colors: [N,3] uint8|float32|None."""
         is_torch = hasattr(points, "data_ptr")
         if is_torch:
             if points.dim() != 2 or points.shape[1] != 3:
                 raise RuntimeError("points must be a contiguous Nx3 array")
-            pts = points.contiguous().float()
+            wide = str(points.dtype) == "torch.float64"
+            pts = points.contiguous() if wide else points.contiguous().float()
             n = pts.shape[0]
         else:
             pts = np.asarray(points)
             if pts.ndim != 2 or pts.shape[1] != 3:
                 raise RuntimeError("points must be a contiguous Nx3 array")
-            pts = np.ascontiguousarray(pts, dtype=np.float32)
+            wide = pts.dtype == np.float64
+            pts = np.ascontiguousarray(pts, dtype=np.float64 if wide else np.float32)
             n = pts.shape[0]
         if n == 0:
             return
@@ -287,7 +290,8 @@ class VoxelBlockGrid(_Volume):
                 raise RuntimeError(f"Colors must be uint8 or float32, got dtype with {dt}")
             if L.location(cols) != L.location(pts):
                 raise RuntimeError("points and colors must live on the same device")
-        L.check(self._lib.hv_integrate_points(self._h, L.ptr(pts), n, L.ptr(cols), kind, L.location(pts)))
+        fn = self._lib.hv_integrate_points_f64 if wide else self._lib.hv_integrate_points
+        L.check(fn(self._h, L.ptr(pts), n, L.ptr(cols), kind, L.location(pts)))
 
     def integrate_rgbd(self, depth, rgb, fx, fy, cx, cy, T_cw, max_depth=np.inf, min_depth=0.0, depth_scale=1.0):
         """Fused depth2pointcloud + world transform + integrate for one posed RGB-D frame

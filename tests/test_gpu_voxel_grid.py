@@ -295,3 +295,46 @@ def test_bucket_path_equals_sort_path_and_reference(voxel, bs, monkeypatch):
         np.testing.assert_array_equal(a, b)
     if voxel >= 0.05:  # blocks really caught more points than one LDS window: 3 frames x 300 k points over few blocks
         assert grids["bucket"].dump()[2].sum(axis=1).max() > 3 * 4096
+
+
+def float64_border_points(rng, voxel, n):
+    """float64 points whose float32 narrowing lands in the neighbouring cell: a hair below / above exact multiples of the
+    (float32) voxel size, block borders, plus an ordinary cloud."""
+    vs = float(np.float32(voxel))
+    k = rng.integers(-4000, 4000, size=(n, 3)).astype(np.float64)
+    below = k * vs * (1.0 - 1e-12)
+    above = k * vs * (1.0 + 1e-12)
+    blocks = (rng.integers(-500, 500, size=(n, 3)) * 8).astype(np.float64) * vs - 1e-13
+    rand = (rng.random((n, 3)) - 0.5) * 40.0
+    return np.concatenate([below, above, blocks, rand])
+
+
+@pytest.mark.skipif(not oracle.ref_available(), reason="compiled reference not available")
+@pytest.mark.parametrize("path", ["bucket", "sort"])
+@pytest.mark.parametrize("bs", [8, 5])
+def test_float64_points_take_the_double_overload(path, bs, monkeypatch):
+    """VoxelBlockGrid.integrate(float64 points) == the binding's py::array_t<double> overload (volumetric_grid_module.h:738-741):
+    keys from the doubles, float32-narrowed sums - bitwise against the compiled reference, on the per-frame bucket path and on
+    the radix path, power-of-two and odd block sizes, numpy and device-resident inputs; and NOT what narrowing first gives."""
+    import torch
+
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    if path == "sort":
+        monkeypatch.setenv("HV_VG_PATH", "sort")
+    rng = np.random.default_rng(5)
+    pts = float64_border_points(rng, 0.005, 50_000)
+    cols = rng.integers(0, 256, size=(len(pts), 3), dtype=np.uint8)
+    ref64, ref32 = oracle.RefGrid(0.005, bs), oracle.RefGrid(0.005, bs)
+    ref64.integrate(pts, cols)
+    ref32.integrate(pts.astype(np.float32), cols)
+    assert not np.array_equal(ref64.dump()[2], ref32.dump()[2]) or not np.array_equal(ref64.dump()[0], ref32.dump()[0])
+    g = VoxelBlockGrid(0.005, bs, max_blocks=1 << 18, max_points=1 << 18)
+    g.integrate(pts, cols)
+    assert_same_grid(g, ref64)
+    g.integrate(torch.from_numpy(pts).cuda(), torch.from_numpy(cols).cuda())  # device-resident float64
+    ref64.integrate(pts, cols)
+    assert_same_grid(g, ref64)
+    g32 = VoxelBlockGrid(0.005, bs, max_blocks=1 << 18, max_points=1 << 18)
+    g32.integrate(pts.astype(np.float32), cols)
+    assert_same_grid(g32, ref32)
