@@ -263,8 +263,8 @@ struct hv_volume {
 
     // TSDF per-frame state
     int32_t *touched_stamp = nullptr; // [table_capacity] last frame id that touched the slot
-    int32_t *touched_list = nullptr;  // [max_blocks] slots touched this frame
-    uint64_t *touched_mask = nullptr; // [table_capacity] per-slot frame bitmask of the multi-frame sweep
+    int32_t *touched_list = nullptr;  // [2][max_blocks] slots touched this frame / batch (second half: the batch pipeline's other set)
+    uint64_t *touched_mask = nullptr; // [2][table_capacity] per-slot frame bitmask of the multi-frame sweep (ditto)
     void *frame_px = nullptr;         // [max_points] uint2 {depth f32 bits, packed rgb}: the gather target
     int debug_variant = 0;            // env HV_TSDF_DEBUG_VARIANT (roofline ablation only)
     int touch_box_bits = 2048;        // env HV_TSDF_TOUCH_BOX_BITS (0 forces the touch pass's general path; tests)
@@ -274,6 +274,16 @@ struct hv_volume {
     bool touch_counters_clean = true; // both touched-list counters are zero (false after an online frame)
     void *batch_buf = nullptr;        // multi-frame sweep scratch: B frame records + B HvFrameParams
     size_t batch_buf_bytes = 0;
+    // batch pipeline (hv_tsdf_integrate_batch): the touch + pack launch of batch k+1 runs on stream_aux while batch k is swept
+    // on `stream`; two sets of scratch (batch_buf / batch_buf2, the halves of touched_list / touched_mask, TOUCH0 / TOUCH1)
+    void *batch_buf2 = nullptr;
+    size_t batch_buf2_bytes = 0;
+    hipStream_t stream_aux = nullptr;
+    hipEvent_t ev_prep = nullptr;     // touch + pack of the current batch done (stream_aux -> stream)
+    hipEvent_t ev_presweep = nullptr; // everything on `stream` up to the point just before the previous batch's sweep
+    int batch_parity = 0;             // scratch set of the next batch
+    bool pipe_armed = false;          // ev_presweep is recorded and ...
+    uint64_t pipe_version = 0;        // ... content_version has this value iff nothing else touched the volume since that batch
     float *mult_table = nullptr;      // per-pixel depth-to-distance multiplier of the current intrinsics (multi-frame sweep)
     size_t mult_table_bytes = 0;
     float mult_key[4] = {0.f, 0.f, 0.f, 0.f}; // cx, cy, 1/fx, 1/fy the table was built for

@@ -308,8 +308,8 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
 
     if (cfg->mode == HV_MODE_TSDF) {
         HV_TRY(hipMalloc(&v->touched_stamp, sizeof(int32_t) * v->table_capacity));
-        HV_TRY(hipMalloc(&v->touched_list, sizeof(int32_t) * cfg->max_blocks));
-        HV_TRY(hipMalloc(&v->touched_mask, sizeof(uint64_t) * v->table_capacity));
+        HV_TRY(hipMalloc(&v->touched_list, sizeof(int32_t) * 2 * cfg->max_blocks));
+        HV_TRY(hipMalloc(&v->touched_mask, sizeof(uint64_t) * 2 * v->table_capacity));
         HV_TRY(hipMalloc(&v->frame_px, 8 * (size_t)cfg->max_points));
         if (const char *dv = getenv("HV_TSDF_DEBUG_VARIANT")) v->debug_variant = atoi(dv);
         if (const char *tb = getenv("HV_TSDF_TOUCH_BOX_BITS")) v->touch_box_bits = std::min(std::max(atoi(tb), 0), 2048);
@@ -333,12 +333,13 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
 void hv_destroy(hv_volume *v) {
     if (!v) return;
     (void)hipSetDevice(v->device);
+    if (v->stream_aux) (void)hipStreamSynchronize(v->stream_aux);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     void *bufs[] = {v->table.keys, v->table.vals, v->table.block_keys, v->table.counters, v->pool,
                     v->touched_stamp, v->touched_list, v->touched_mask, v->frame_px,
                     v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                     v->sort_vals_out, v->sort_tmp, v->scratch_points, v->scratch_colors, v->out_a,
-                    v->out_b, v->out_c, v->batch_buf, v->assoc_buf, v->mult_table, v->vg_cnt, v->vg_cur, v->vg_touched, v->vg_cursor};
+                    v->out_b, v->out_c, v->batch_buf, v->assoc_buf, v->mult_table, v->vg_cnt, v->vg_cur, v->vg_touched, v->vg_cursor, v->batch_buf2};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (v->h_counters) (void)hipHostFree(v->h_counters);
@@ -352,6 +353,9 @@ void hv_destroy(hv_volume *v) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);
     }
+    if (v->ev_prep) (void)hipEventDestroy(v->ev_prep);
+    if (v->ev_presweep) (void)hipEventDestroy(v->ev_presweep);
+    if (v->stream_aux) (void)hipStreamDestroy(v->stream_aux);
     if (v->stream && v->own_stream) (void)hipStreamDestroy(v->stream);
     delete v;
 }
@@ -372,7 +376,7 @@ int hv_reset(hv_volume *v) {
     HV_HIP(hipMemsetAsync(v->table.vals, 0xFF, sizeof(int32_t) * v->table_capacity, v->stream));
     HV_HIP(hipMemsetAsync(v->table.counters, 0, sizeof(int32_t) * HV_CNT_COUNT, v->stream));
     if (v->touched_stamp) HV_HIP(hipMemsetAsync(v->touched_stamp, 0, sizeof(int32_t) * v->table_capacity, v->stream));
-    if (v->touched_mask) HV_HIP(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * v->table_capacity, v->stream));
+    if (v->touched_mask) HV_HIP(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * 2 * v->table_capacity, v->stream));
     memset(v->h_counters, 0, sizeof(int32_t) * HV_CNT_COUNT);
     v->content_version += 1;
     v->frame_counter = 0;
@@ -499,10 +503,10 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
     HV_TRY_GROW(hipGetLastError());
     if (v->cfg.mode == HV_MODE_TSDF) { // per-slot frame stamps / masks and the touched list follow the table
         HV_TRY_GROW(hipMalloc((void **)&stamp, sizeof(int32_t) * new_cap));
-        HV_TRY_GROW(hipMalloc((void **)&list, sizeof(int32_t) * new_max_blocks));
-        HV_TRY_GROW(hipMalloc((void **)&mask, sizeof(uint64_t) * new_cap));
+        HV_TRY_GROW(hipMalloc((void **)&list, sizeof(int32_t) * 2 * new_max_blocks));
+        HV_TRY_GROW(hipMalloc((void **)&mask, sizeof(uint64_t) * 2 * new_cap));
         HV_TRY_GROW(hipMemsetAsync(stamp, 0, sizeof(int32_t) * new_cap, v->stream));
-        HV_TRY_GROW(hipMemsetAsync(mask, 0, sizeof(uint64_t) * new_cap, v->stream));
+        HV_TRY_GROW(hipMemsetAsync(mask, 0, sizeof(uint64_t) * 2 * new_cap, v->stream));
         // stamps carry "touched since the last merge": re-stamp the surviving blocks' slots in the new table
         if (used > 0 && v->touched_stamp != nullptr)
             hipLaunchKernelGGL(k_restamp, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, v->stream, v->table, nt,

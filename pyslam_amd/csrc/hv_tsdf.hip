@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
                                                                 const uint8_t *__restrict__ rgb,
                                                                 uint2 *__restrict__ frame_px,
                                                                 const HvFrameParams *__restrict__ Ps, int n_prep_blocks,
-                                                                int n_touch_blocks, int n_frames) {
+                                                                int n_touch_blocks, int n_frames, int parity) {
     // block order: the touch blocks of ALL frames first, then the pack blocks.  A touch wave is one chain of dependent
     // memory round trips (depth -> hash probe -> mask / stamp -> atomics; a patch on a long depth discontinuity walks
     // several such chains), the pack blocks are pure streaming: dispatched last they fill the machine while the touch
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
                            } else {
                                const int32_t old = atomicExch(&stamp[slot], batch_stamp);
                                if (old != batch_stamp) {
-                                   const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0], 1);
+                                   const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0 + parity], 1);
                                    if (at < table.max_blocks) list[at] = slot;
                                }
                            }
@@ -1075,11 +1075,11 @@ template <int ZH, int SPLIT, int WPE>
 __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
     char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
-    int general, const float *__restrict__ mult, int xcd_aware) {
+    int general, const float *__restrict__ mult, int xcd_aware, int parity) {
     static_assert(ZH % 2 == 0, "voxels are folded in pairs");
     constexpr int TASKS = 64 / ZH;          // wave tasks per unit
     constexpr int WAVES = TASKS / SPLIT;    // waves per workgroup
-    int n_units = table.counters[HV_CNT_TOUCH0];
+    int n_units = table.counters[HV_CNT_TOUCH0 + parity];
     if (n_units > table.max_blocks) n_units = table.max_blocks;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1331,7 +1331,7 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
     }
 }
 
-// After the sweep (one workgroup): clear the frame masks of the batch's units and zero both touched-list counters, so
+// After the sweep (one workgroup): clear the frame masks of the batch's units and zero the batch's touched-list counter, so
 // that the next batch / online frame starts clean without a memset launch per counter.
 __global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const int32_t *__restrict__ list,
                                                              unsigned long long *__restrict__ frame_mask, int parity,
@@ -1353,8 +1353,7 @@ __global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const
             if (slot[k] >= 0) frame_mask[slot[k]] = 0ull;
     }
     if (threadIdx.x == 0) {
-        table.counters[HV_CNT_TOUCH0] = 0;
-        table.counters[HV_CNT_TOUCH1] = 0;
+        table.counters[HV_CNT_TOUCH0 + parity] = 0; // (the other set's counter may be filling: the next batch's touch pass)
         hv_publish_status(table, status, status_seq); // pool occupancy after this batch, for hv_capacity_gate
     }
 }
@@ -1687,14 +1686,46 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         return HV_OK;
     }
     // multi-frame sweeps of up to 64 frames (one bit per frame in the per-unit mask)
+    //
+    // Batch pipeline.  A batch is [touch + pack launch: HBM streaming and hash-insert latency chains] -> [sweep: VALU-bound]
+    // -> [finish].  When batches follow each other with nothing else done to the volume in between (a replay / rebuild loop),
+    // the touch + pack launch of batch k+1 goes to a second stream and runs WHILE batch k is swept: it only inserts units and
+    // fills its own scratch set (frame records, union list, frame masks, list counter: two sets, alternating), the sweep of
+    // batch k reads none of that.  Hand-offs: the aux stream waits for the event recorded on the main stream just before the
+    // PREVIOUS sweep (everything older than that sweep is done - in particular the batch that last used this scratch set);
+    // the main stream waits for this batch's touch + pack before its own sweep.  Every other entry point works on the main
+    // stream behind those waits and never meets the aux stream; a call that finds the volume touched by anything else since
+    // the previous batch (content_version), host-resident frames, the checked capacity mode or HV_TSDF_PIPELINE=0 runs
+    // everything on the main stream as before.
+    const bool pipeline_on = !(getenv("HV_TSDF_PIPELINE") && atoi(getenv("HV_TSDF_PIPELINE")) == 0);
+    bool chain_ok = v->pipe_armed && v->pipe_version == v->content_version; // nothing but batches since ev_presweep was recorded
     v->content_version += 1;
     const int BMAX = 64;
     for (int f0 = 0; f0 < n_frames; f0 += BMAX) {
         const int B = std::min(BMAX, n_frames - f0);
         // pool headroom (grows here when more than half is known to be used; see hv_capacity_gate)
         bool checked = false;
+        const int64_t max_before = v->cfg.max_blocks;
         rc = hv_capacity_gate(v, &checked);
         if (rc != HV_OK) return rc;
+        // The touch pass appends first-touched units to the union list itself.  HV_TSDF_LIST=kernel: build the list afterwards
+        // from the allocated units instead (one atomic per wave instead of one per unit on a single counter; measured equal at
+        // one rank - 32.2 k vs 32.3 k frames/s - for one launch more: kept for A/B only)
+        const bool list_in_touch = !(getenv("HV_TSDF_LIST") && strcmp(getenv("HV_TSDF_LIST"), "kernel") == 0);
+        if (v->cfg.max_blocks != max_before) chain_ok = false; // the pool grew: the stream was drained, start a fresh chain
+        const bool overlap = pipeline_on && chain_ok && !checked && loc == HV_DEVICE && list_in_touch;
+        if (v->stream_aux == nullptr) {
+            HV_HIP(hipStreamCreateWithFlags(&v->stream_aux, hipStreamNonBlocking));
+            HV_HIP(hipEventCreateWithFlags(&v->ev_prep, hipEventDisableTiming));
+            HV_HIP(hipEventCreateWithFlags(&v->ev_presweep, hipEventDisableTiming));
+        }
+        hipStream_t ps = overlap ? v->stream_aux : v->stream; // where this batch's touch + pack launch goes
+        // scratch set
+        const int parity = list_in_touch ? v->batch_parity : 0;
+        if (list_in_touch) v->batch_parity ^= 1;
+        int32_t *d_list = v->touched_list + (size_t)parity * (size_t)v->cfg.max_blocks;
+        unsigned long long *d_mask_rw = (unsigned long long *)v->touched_mask + (size_t)parity * (size_t)v->table_capacity;
+        if (overlap) HV_HIP(hipStreamWaitEvent(v->stream_aux, v->ev_presweep, 0));
         // per-frame constants go through a ring of 4 pinned host buffers: the H2D copy is truly
         // asynchronous and a slot is only rewritten after the copy that last used it has completed,
         // so consecutive calls queue up on the stream without a host synchronisation
@@ -1714,30 +1745,28 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
             params[f].frame_id = v->frame_counter;
         }
         int batch_stamp = v->frame_counter;
-        v->last_touch_parity = 0;
+        v->last_touch_parity = parity;
         // scratch: [B frame records of npx uint2][B HvFrameParams]
         const size_t px_bytes = sizeof(uint2) * npx * (size_t)B;
-        rc = hv_ensure_buffer(v, &v->batch_buf, &v->batch_buf_bytes, px_bytes + sizeof(HvFrameParams) * (size_t)B + 256);
+        void **bb = parity ? &v->batch_buf2 : &v->batch_buf;
+        size_t *bb_bytes = parity ? &v->batch_buf2_bytes : &v->batch_buf_bytes;
+        rc = hv_ensure_buffer(v, bb, bb_bytes, px_bytes + sizeof(HvFrameParams) * (size_t)B + 256); // (re-allocation drains the main stream, and with it every batch whose touch pass it waited for)
         if (rc != HV_OK) return rc;
-        uint2 *d_px = (uint2 *)v->batch_buf;
-        HvFrameParams *d_params = (HvFrameParams *)((char *)v->batch_buf + ((px_bytes + 255) & ~(size_t)255));
-        HV_HIP(hipMemcpyAsync(d_params, params, sizeof(HvFrameParams) * (size_t)B, hipMemcpyHostToDevice, v->stream));
-        HV_HIP(hipEventRecord(v->params_ev[ri], v->stream));
+        uint2 *d_px = (uint2 *)*bb;
+        HvFrameParams *d_params = (HvFrameParams *)((char *)*bb + ((px_bytes + 255) & ~(size_t)255));
+        HV_HIP(hipMemcpyAsync(d_params, params, sizeof(HvFrameParams) * (size_t)B, hipMemcpyHostToDevice, ps));
+        HV_HIP(hipEventRecord(v->params_ev[ri], ps));
         // the touched-list counters are zero after hv_reset and k_tsdf_batch_finish; an online frame leaves its own
         // parity's count behind
         const int n_prep_blocks = (int)((npx + 1023) / 1024); // 4 pixels per thread
         const int n_touch_blocks = (hv_touch_patches(width, height, v->cfg.depth_sampling_stride) + 3) / 4;
-        // The touch pass appends first-touched units to the union list itself.  HV_TSDF_LIST=kernel: build the list afterwards
-        // from the allocated units instead (one atomic per wave instead of one per unit on a single counter; measured equal at
-        // one rank - 32.2 k vs 32.3 k frames/s - for one launch more: kept for A/B only)
-        const bool list_in_touch = !(getenv("HV_TSDF_LIST") && strcmp(getenv("HV_TSDF_LIST"), "kernel") == 0);
         for (int attempt = 0;; ++attempt) {
-            if (!v->touch_counters_clean) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
+            if (!v->touch_counters_clean) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream)); // (never while a chain runs: only an online frame or an aborted claim leaves them dirty)
             v->touch_counters_clean = true;
-            hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3((n_prep_blocks + n_touch_blocks) * B), dim3(256), 0, v->stream,
-                               v->table, v->touched_stamp, (unsigned long long *)v->touched_mask, list_in_touch ? v->touched_list : nullptr,
+            hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3((n_prep_blocks + n_touch_blocks) * B), dim3(256), 0, ps,
+                               v->table, v->touched_stamp, d_mask_rw, list_in_touch ? d_list : nullptr,
                                batch_stamp, (const char *)d_depth + npx * dsz * (size_t)f0, (int64_t)(npx * dsz),
-                               (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks, n_touch_blocks, B);
+                               (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks, n_touch_blocks, B, parity);
             if (!checked) break;
             // checked mode: nothing is fused before every unit of the batch has its pool slot; if some claims did not fit, the
             // pool has grown (table rebuilt without them, stamps kept) and the touch pass runs again under a fresh stamp
@@ -1747,12 +1776,21 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
             v->frame_counter += 1;
             batch_stamp = v->frame_counter;
             v->touch_counters_clean = false;
+            // the tables were rebuilt: the scratch set's arrays moved
+            d_list = v->touched_list + (size_t)parity * (size_t)v->cfg.max_blocks;
+            d_mask_rw = (unsigned long long *)v->touched_mask + (size_t)parity * (size_t)v->table_capacity;
         }
         if (!list_in_touch) {
             // one thread per pool slot (how many are allocated is only known on the device; threads beyond leave at once)
             hipLaunchKernelGGL(k_tsdf_batch_list, dim3((unsigned)((v->cfg.max_blocks + 255) / 256)), dim3(256), 0, v->stream, v->table,
-                               (const int32_t *)v->touched_stamp, batch_stamp, v->touched_list);
+                               (const int32_t *)v->touched_stamp, batch_stamp, d_list);
         }
+        if (overlap) {
+            HV_HIP(hipEventRecord(v->ev_prep, v->stream_aux));
+            HV_HIP(hipStreamWaitEvent(v->stream, v->ev_prep, 0));
+        }
+        HV_HIP(hipEventRecord(v->ev_presweep, v->stream)); // what the NEXT batch's touch + pack launch waits for
+        chain_ok = true;                                   // (the next chunk of this call may follow this one directly)
         hv_profile_begin(v);
         // sweep form: 2 = k_tsdf_sweep (production: float2 projection chain, prefetched frame constants), 1 = first form (A/B, and
         // the only one that runs without the multiplier table).  The switches are read per call (a handful of getenv per
@@ -1766,7 +1804,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         const int general = getenv("HV_TSDF_BATCH_GENERAL") ? atoi(getenv("HV_TSDF_BATCH_GENERAL")) : 0;
         // per-pixel multiplier table (HV_TSDF_BATCH_MULT=0: compute the multiplier per voxel visit instead)
         const int use_mult = getenv("HV_TSDF_BATCH_MULT") ? atoi(getenv("HV_TSDF_BATCH_MULT")) : 1;
-        const unsigned long long *d_mask = (const unsigned long long *)v->touched_mask;
+        const unsigned long long *d_mask = d_mask_rw;
         const float *d_mult = nullptr;
         if (use_mult) {
             rc = tsdf_multiplier_table(v, params[0]);
@@ -1778,10 +1816,10 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         const int sweep_grid = getenv("HV_TSDF_BATCH_GRID") ? atoi(getenv("HV_TSDF_BATCH_GRID")) : 65536;
 #define HV_LAUNCH_COL(S, MT)                                                                                           \
     hipLaunchKernelGGL((k_tsdf_integrate_batch_col<4, S, MT>), dim3(sweep_grid), dim3(64 * 16 / S), 0, v->stream, v->table, \
-                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, 0, general, d_mult)
+                       d_list, d_mask, (char *)v->pool, d_px, d_params, parity, general, d_mult)
 #define HV_LAUNCH_SWEEP(ZH, S, WPE)                                                                                    \
     hipLaunchKernelGGL((k_tsdf_sweep<ZH, S, WPE>), dim3(sweep_grid), dim3(64 * (64 / ZH) / S), 0, v->stream, v->table,   \
-                       v->touched_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware)
+                       d_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware, parity)
         if (d_mult && sweep_form == 2) {
             const int wpe = getenv("HV_TSDF_SWEEP_WPE") ? atoi(getenv("HV_TSDF_SWEEP_WPE")) : 4; // 4 waves / SIMD = 128 VGPRs: nothing spills
             const int xcd_aware = getenv("HV_TSDF_SWEEP_XCD") ? atoi(getenv("HV_TSDF_SWEEP_XCD")) : 2; // list entries per XCD group (0: list order)
@@ -1802,10 +1840,12 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
 #undef HV_LAUNCH_COL
 #undef HV_LAUNCH_SWEEP
         hv_profile_end(v, B);
-        hipLaunchKernelGGL(k_tsdf_batch_finish, dim3(1), dim3(1024), 0, v->stream, v->table, v->touched_list,
-                           (unsigned long long *)v->touched_mask, 0, v->d_status, hv_next_status_seq(v));
+        hipLaunchKernelGGL(k_tsdf_batch_finish, dim3(1), dim3(1024), 0, v->stream, v->table, d_list, d_mask_rw, parity, v->d_status,
+                           hv_next_status_seq(v));
         HV_HIP(hipGetLastError());
     }
+    v->pipe_armed = true;
+    v->pipe_version = v->content_version;
     return HV_OK;
 }
 

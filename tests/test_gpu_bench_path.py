@@ -145,6 +145,7 @@ def sweep_case():
 
 SWEEP_FORMS = [
     {"HV_TSDF_SWEEP": "2"},                              # production: float2 chain, prefetched frame constants, packed colour
+    {"HV_TSDF_SWEEP": "2", "HV_TSDF_PIPELINE": "0"},     # every launch of a batch on the one stream (no touch / sweep overlap between batches)
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_XCD": "0"},    # work items in list order instead of one contiguous list eighth per XCD
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_WPE": "5"},    # the same at 96 VGPRs (5 waves / SIMD)
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_BATCH_SPLIT": "8"},  # 8 workgroups per unit
@@ -173,3 +174,68 @@ def test_sweep_forms_match_oracle(env, sweep_case, monkeypatch):
     np.testing.assert_array_equal(wa, wb)
     np.testing.assert_array_equal(ta.view(np.uint32), tb.view(np.uint32))
     assert max(float(np.abs(ca[lo:lo + 512] - cb[lo:lo + 512]).max()) for lo in range(0, len(ka), 512)) / 255.0 <= TOL
+
+
+def test_batch_pipeline_with_interleaved_calls_matches_oracle():
+    """The batch pipeline (touch + pack of batch k+1 on a second stream while batch k is swept, two scratch sets) under the
+    call patterns that start, break and restart a chain: device-resident batches back to back, an online frame in between,
+    an extraction in between, a host-resident batch, a long call that is cut into 64-frame chunks, a reset.  Full dump
+    against the oracle fusing the same frames one by one; and bitwise equal to the same calls with the pipeline off."""
+    import torch
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+
+    s, frames = synthetic_frames("tiny_160x120_2cm", 0, 200)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+
+    def run(gpu, cpu=None):
+        def batch(lo, hi, device=True):
+            depth, rgb, T = batch_arrays(frames[lo:hi])
+            if device:
+                depth, rgb = torch.from_numpy(depth).cuda(), torch.from_numpy(rgb).cuda()
+            gpu.integrate_batch(depth, rgb, K, T, depth_scale=1.0, depth_trunc=DEPTH_TRUNC)
+            if cpu is not None:
+                for f in frames[lo:hi]:
+                    cpu.integrate(f[0], f[1], K.as_array(), f[2], 1.0, DEPTH_TRUNC)
+
+        def online(i):
+            d, c, T = frames[i]
+            gpu.integrate(RGBDImage.create_from_color_and_depth(c, d, 1.0, DEPTH_TRUNC, False), K, T)
+            if cpu is not None:
+                cpu.integrate(d, c, K.as_array(), T, 1.0, DEPTH_TRUNC)
+
+        batch(0, 8)
+        gpu.reset()                       # a chain must not survive a reset
+        if cpu is not None:
+            cpu.reset()
+        for lo in range(0, 48, 8):        # six batches back to back: the chain is running from the second on
+            batch(lo, lo + 8)
+        online(48)                        # breaks the chain
+        batch(49, 57)
+        batch(57, 65)
+        n_pts = len(gpu.extract_point_cloud().points)  # a synchronous reader between two batches
+        batch(65, 73)
+        batch(73, 81, device=False)       # host-resident frames: staged on the main stream
+        batch(81, 89)
+        batch(89, 189)                    # 100 frames: two chunks inside one call
+        batch(189, 200)
+        return n_pts
+
+    vol_size = 0.02, 0.08
+    gpu = ScalableTSDFVolume(*vol_size, max_blocks=1 << 13)
+    cpu = oracle.PortTsdf(*vol_size, threads=THREADS)
+    n_pts = run(gpu, cpu)
+    assert n_pts > 1000
+    ka, ta, wa, ca = gpu.dump()
+    kb, tb, wb, cb = cpu.dump()
+    np.testing.assert_array_equal(ka, kb)
+    np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    assert float(np.abs(ca - cb).max()) / 255.0 <= TOL
+    os.environ["HV_TSDF_PIPELINE"] = "0"
+    try:
+        plain = ScalableTSDFVolume(*vol_size, max_blocks=1 << 13)
+        run(plain)
+    finally:
+        del os.environ["HV_TSDF_PIPELINE"]
+    for x, y in zip(gpu.dump(), plain.dump()):
+        np.testing.assert_array_equal(x, y)
