@@ -228,7 +228,24 @@ def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_fr
                            "achieved": round((b_vox + b_in) / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round((b_vox + b_in) / avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                            "note": "B_vox = 2 x 28 B x distinct voxels touched per frame (oracle keys) + B_in 7 B/px: a ~15 MB/frame "
-                                   "path bounded by four dependent launches and their latency chains, not by HBM"}
+                                   "path bounded by four dependent launches; the fold moves whole 128-byte lines for 32-byte voxel "
+                                   "records scattered over the frame's ~13 000 blocks (see traffic)"}
+        # HBM bytes of the four per-frame kernels from the recorded --pmc passes of tools/bench_voxel_grid.py on this build
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02", "pmc_voxel_grid.json")) as f:
+                vp = json.load(f)
+            if vp.get("build_digest") == current_build_digest():
+                per = {}
+                for name in ("k_vgb_count", "k_vgb_offsets", "k_vgb_scatter", "k_vgb_fold_wave"):
+                    t = hbm_traffic(next((v for k, v in vp.get("kernels", {}).items() if name in k), None))
+                    if t is not None:
+                        per[name] = t
+                if len(per) == 4:
+                    out["roofline"]["traffic"] = int(sum(per.values()))
+                    out["roofline"]["traffic_per_kernel"] = per
+                    out["roofline"]["traffic_GBs"] = round(sum(per.values()) / avg_s / 1e9, 1)
+        except (OSError, ValueError):
+            pass
     for kind, cls in (("reference", oracle.RefGrid if oracle.ref_available() else None), ("port", oracle.PortGrid)):
         if cls is None:
             continue
