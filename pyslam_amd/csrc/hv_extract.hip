@@ -11,7 +11,8 @@
 //   rocPRIM scan    unit bases for vertices and triangles
 //   k_mc_vertices   (wave) lane j builds vertices j, j + 64, ... of the unit: interpolated vertex + colour (f64, as Open3D)
 //   k_mc_triangles  (workgroup) reads the stored cube cases and emits triangles whose vertex indices are
-//                   base[unit(edge)] + rank(edge) - no hash map, no atomics in the emit passes.
+//                   base[unit(edge)] + rank(edge) - no hash map, no atomics in the emit passes; like the vertices and the
+//                   points, the unit's triangles are dealt out evenly over the threads (rank -> column by binary search).
 // Point cloud: k_pc_extract<false> counts per unit over a 17^3 LDS slab, scan, k_pc_extract<true> writes - no atomics either.
 // Vertex/triangle *order* differs from Open3D's unordered_map iteration order (so does Open3D's
 // own from run to run); the vertex and triangle *sets* are identical to the CPU restatement.
@@ -366,7 +367,6 @@ __global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, int n_units
     const int idx = blockIdx.x;
     if (idx >= n_units) return;
     load_neighbours(table, idx, s_nbr);
-    const int x = threadIdx.x >> 4, y = threadIdx.x & 15;
     const uint4 pk = ((const uint4 *)(cases + (int64_t)idx * RRR))[threadIdx.x];
     const uint32_t packed[4] = {pk.x, pk.y, pk.z, pk.w};
     int tris = 0;
@@ -384,12 +384,35 @@ __global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, int n_units
     __syncthreads(); // also orders s_nbr
     int before = 0;
     for (int w = 0; w < wave; ++w) before += s_wave[w];
-    int64_t at = (int64_t)tri_base[idx] + before + incl - tris;
-    if (tris == 0) return;
-    for (int z = 0; z < R; ++z) {
-        const int cube = (int)((packed[z >> 2] >> ((z & 3) * 8)) & 255u);
-        if (cube == 0) continue;
-        for (int i = 0; c_tri_table[cube][i] != -1; i += 3) {
+    // The unit's triangles are dealt out evenly (as the vertices and the points are): triangle r belongs to the column whose
+    // exclusive count is the last one <= r; inside the column it is found by walking the 16 stored cases.
+    __shared__ uint4 s_cases[256];
+    __shared__ int s_pre[257];
+    s_cases[threadIdx.x] = pk;
+    s_pre[threadIdx.x] = before + incl - tris;
+    if (threadIdx.x == 255) s_pre[256] = before + incl;
+    __syncthreads();
+    const int total = s_pre[256];
+    const int64_t tbase = tri_base[idx];
+    for (int r = threadIdx.x; r < total; r += 256) {
+        const int64_t at = tbase + r;
+        int lo = 0, hi = 256; // s_pre[lo] <= r < s_pre[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pre[mid] <= r) lo = mid; else hi = mid;
+        }
+        const int x = lo >> 4, y = lo & 15;
+        const uint4 cpk = s_cases[lo];
+        int j = r - s_pre[lo], z = 0, cube = 0;
+        for (; z < R; ++z) {
+            const uint32_t cw = z < 4 ? cpk.x : z < 8 ? cpk.y : z < 12 ? cpk.z : cpk.w;
+            cube = (int)((cw >> ((z & 3) * 8)) & 255u);
+            const int c = c_tri_count[cube];
+            if (j < c) break;
+            j -= c;
+        }
+        {
+            const int i = 3 * j;
             const int order[3] = {i, i + 2, i + 1}; // Open3D emits (e[i], e[i+2], e[i+1])
             int32_t vid[3];
 #pragma unroll
@@ -407,7 +430,6 @@ __global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, int n_units
                 triangles[at * 3 + 1] = vid[1];
                 triangles[at * 3 + 2] = vid[2];
             }
-            ++at;
         }
     }
 }
@@ -461,14 +483,32 @@ __global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *_
         if (threadIdx.x == 255) count[idx] = before + incl;
         return;
     }
-    if (!hits) return;
-    int64_t at = (int64_t)base[idx] + before + incl - mine;
+    // The unit's points are dealt out evenly: thread r builds point r, r + 256, ... (a column holds one to six crossings, and
+    // a thread that walks its own would chase six dependent round trips while most of the workgroup idles).  Point r belongs
+    // to the column whose exclusive count is the last one <= r: binary search over the column prefixes, then select the
+    // (r - prefix)-th set bit of that column's hit mask.
+    __shared__ unsigned long long s_hits[256];
+    __shared__ int s_pre[257];
+    s_hits[threadIdx.x] = hits;
+    s_pre[threadIdx.x] = before + incl - mine;
+    if (threadIdx.x == 255) s_pre[256] = before + incl;
+    __syncthreads();
+    const int total = s_pre[256];
+    if (total == 0) return;
     int32_t ux, uy, uz;
     hv_unpack_key(table.block_keys[idx], ux, uy, uz);
     const char *u0 = pool + (int64_t)idx * UNIT_BYTES;
-    for (; hits != 0ull; hits &= hits - 1ull, ++at) {
+    const int64_t vbase = base[idx];
+    for (int r = threadIdx.x; r < total; r += 256) {
+        const int64_t at = vbase + r;
         if (at >= cap) return;
-        const int bit = __ffsll((long long)hits) - 1;
+        int lo = 0, hi = 256; // s_pre[lo] <= r < s_pre[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pre[mid] <= r) lo = mid; else hi = mid;
+        }
+        const int x = lo >> 4, y = lo & 15;
+        const int bit = hv_nth_set_bit(s_hits[lo], r - s_pre[lo]);
         const int z = bit / 3, i = bit - z * 3;
         const int lin = voxel_word(x, y, z);
         const float f0 = ((const float *)u0)[lin];

@@ -1715,7 +1715,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         if (v->cfg.max_blocks != max_before) chain_ok = false; // the pool grew: the stream was drained, start a fresh chain
         const bool overlap = pipeline_on && chain_ok && !checked && loc == HV_DEVICE && list_in_touch;
         if (v->stream_aux == nullptr) {
-            HV_HIP(hipStreamCreateWithFlags(&v->stream_aux, hipStreamNonBlocking));
+            HV_HIP(hipStreamCreateWithFlags(&v->stream_aux, hipStreamNonBlocking)); // (queue priority high / low against the sweep's: measured, no effect)
             HV_HIP(hipEventCreateWithFlags(&v->ev_prep, hipEventDisableTiming));
             HV_HIP(hipEventCreateWithFlags(&v->ev_presweep, hipEventDisableTiming));
         }
