@@ -56,3 +56,35 @@ def test_frustum_contains():
             np.testing.assert_array_equal(a[1], b[1])
         np.testing.assert_array_equal(oracle.frustum_bbox(intr, s.width, s.height, T, 8.0, 0.01, "port"),
                                       oracle.frustum_bbox(intr, s.width, s.height, T, 8.0, 0.01, "ref"))
+
+
+@pytest.mark.skipif(not oracle.ref_available(), reason="compiled reference not available")
+def test_reference_double_overload_keys_in_double():
+    """Pins what `integrate(points float64)` means in the reference (volumetric_grid_module.h:738-741 ->
+    integrate_raw<double, ...>): the voxel index is floor(x * (double)inv_voxel_size_f32) in DOUBLE, the voxel sums take
+    static_cast<float>(x).  Checked on points whose float32 narrowing lands in the neighbouring cell; the GPU path is held to
+    the same compiled reference in tests/test_gpu_voxel_grid.py::test_float64_points_take_the_double_overload."""
+    rng = np.random.default_rng(5)
+    vs = float(np.float32(0.005))
+    inv = float(np.float32(1.0) / np.float32(0.005))
+    k = rng.integers(-4000, 4000, size=(20000, 3)).astype(np.float64)
+    pts = np.concatenate([k * vs * (1.0 - 1e-12), k * vs * (1.0 + 1e-12), (rng.random((20000, 3)) - 0.5) * 40.0])
+    g = oracle.RefGrid(0.005, 8)
+    g.integrate(pts)
+    keys, _, counts, sums = g.dump()
+    # restatement: voxel index in double, block = floor_div(v, 8), local = v - 8 block, linear x + 8 y + 64 z
+    v = np.floor(pts * inv).astype(np.int64)
+    b = v >> 3
+    lin = (v - 8 * b) @ np.array([1, 8, 64])
+    order = {tuple(key): i for i, key in enumerate(keys)}
+    want = np.zeros_like(counts)
+    pos = np.zeros(counts.shape + (3,), np.float32)
+    for row, (bk, l) in enumerate(zip(map(tuple, b), lin)):  # sequential float32 accumulation, point order
+        i = order[bk]
+        want[i, l] += 1
+        pos[i, l] += pts[row].astype(np.float32)
+    np.testing.assert_array_equal(counts, want)
+    np.testing.assert_array_equal(sums[..., :3].view(np.uint32), pos.view(np.uint32))
+    g32 = oracle.RefGrid(0.005, 8)
+    g32.integrate(pts.astype(np.float32))
+    assert g32.dump()[0].shape != keys.shape or not np.array_equal(g32.dump()[2], counts)  # and NOT the float overload's result
