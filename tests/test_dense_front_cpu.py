@@ -199,3 +199,18 @@ def test_push_to_front_is_newest_first_and_rebuild_drains():
             q.put(i)
         empty_queue(q)
         assert q.empty()
+
+
+def test_result_arrays_fall_back_to_plain_numpy(monkeypatch):
+    """Extraction results go to page-locked arrays where torch can provide them; without a GPU, for small results, or with
+    PYSLAM_AMD_PINNED_RESULTS=0 the caller gets a plain numpy array of the same shape and dtype."""
+    import numpy as np
+
+    from pyslam_amd.volumetric import _result_array
+
+    for shape, dtype in (((0, 3), np.float64), ((5, 3), np.int32), ((200_000, 3), np.float64)):
+        a = _result_array(shape, dtype)
+        assert isinstance(a, np.ndarray) and a.shape == shape and a.dtype == dtype and a.flags.writeable
+    monkeypatch.setenv("PYSLAM_AMD_PINNED_RESULTS", "0")
+    a = _result_array((200_000, 3), np.float64)
+    assert a.shape == (200_000, 3) and a.base is None  # an owning numpy array, not a view of a torch tensor
