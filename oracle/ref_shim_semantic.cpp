@@ -366,3 +366,59 @@ int64_t ref_sem2_get_class_segments(void *h, int min_count, float min_confidence
 }
 
 } // extern "C"
+
+// ---- 3D bounding boxes (cpp/volumetric/bounding_boxes_3d.h/.cpp, bindings bounding_boxes_module.h:49-160): thin C exports
+// of the reference's own classes, so that the Python mirrors in pyslam_amd can be compared with the compiled code.
+// aabb = {min xyz, max xyz} (6 doubles); obb = {center xyz, quaternion wxyz, size xyz} (10 doubles).
+namespace {
+volumetric::BoundingBox3D mk_aabb(const double *b) { return volumetric::BoundingBox3D(b[0], b[1], b[2], b[3], b[4], b[5]); }
+volumetric::OrientedBoundingBox3D mk_obb(const double *o) {
+    return volumetric::OrientedBoundingBox3D(Eigen::Vector3d(o[0], o[1], o[2]), Eigen::Quaterniond(o[3], o[4], o[5], o[6]),
+                                             Eigen::Vector3d(o[7], o[8], o[9]));
+}
+void put_obb(const volumetric::OrientedBoundingBox3D &b, double *o) {
+    o[0] = b.center.x(); o[1] = b.center.y(); o[2] = b.center.z();
+    o[3] = b.orientation.w(); o[4] = b.orientation.x(); o[5] = b.orientation.y(); o[6] = b.orientation.z();
+    o[7] = b.size.x(); o[8] = b.size.y(); o[9] = b.size.z();
+}
+} // namespace
+
+extern "C" {
+void ref_aabb3_scalars(const double *b, double *out9) { // center 3, size 3, volume, surface area, diagonal
+    const auto a = mk_aabb(b);
+    const auto c = a.get_center(), s = a.get_size();
+    out9[0] = c.x(); out9[1] = c.y(); out9[2] = c.z(); out9[3] = s.x(); out9[4] = s.y(); out9[5] = s.z();
+    out9[6] = a.get_volume(); out9[7] = a.get_surface_area(); out9[8] = a.get_diagonal_length();
+}
+void ref_aabb3_contains(const double *b, const double *pts, int64_t n, uint8_t *out) {
+    const auto a = mk_aabb(b);
+    for (int64_t i = 0; i < n; ++i) out[i] = a.contains<double>(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]) ? 1 : 0;
+}
+int ref_aabb3_intersects(const double *a, const double *b) { return mk_aabb(a).intersects(mk_aabb(b)) ? 1 : 0; }
+void ref_aabb3_from_points(const double *pts, int64_t n, double *out6) {
+    std::vector<Eigen::Vector3d> v((size_t)n);
+    for (int64_t i = 0; i < n; ++i) v[i] = Eigen::Vector3d(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    const auto a = volumetric::BoundingBox3D::compute_from_points<double>(v);
+    out6[0] = a.min_x; out6[1] = a.min_y; out6[2] = a.min_z; out6[3] = a.max_x; out6[4] = a.max_y; out6[5] = a.max_z;
+}
+void ref_obb3_scalars(const double *o, double *out3, double *M16, double *Minv16, double *corners24) {
+    const auto b = mk_obb(o);
+    out3[0] = b.get_volume(); out3[1] = b.get_surface_area(); out3[2] = b.get_diagonal_length();
+    const Eigen::Matrix4d M = b.get_matrix(), Mi = b.get_inverse_matrix();
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) { M16[r * 4 + c] = M(r, c); Minv16[r * 4 + c] = Mi(r, c); }
+    const auto cs = b.get_corners();
+    for (int i = 0; i < 8; ++i) { corners24[3 * i] = cs[i].x(); corners24[3 * i + 1] = cs[i].y(); corners24[3 * i + 2] = cs[i].z(); }
+}
+void ref_obb3_contains(const double *o, const double *pts, int64_t n, uint8_t *out) {
+    const auto b = mk_obb(o);
+    for (int64_t i = 0; i < n; ++i) out[i] = b.contains<double>(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]) ? 1 : 0;
+}
+int ref_obb3_intersects_obb(const double *a, const double *b) { return mk_obb(a).intersects(mk_obb(b)) ? 1 : 0; }
+int ref_obb3_intersects_aabb(const double *a, const double *b) { return mk_obb(a).intersects(mk_aabb(b)) ? 1 : 0; }
+void ref_obb3_from_points(const double *pts, int64_t n, double *out10) {
+    std::vector<Eigen::Vector3d> v((size_t)n);
+    for (int64_t i = 0; i < n; ++i) v[i] = Eigen::Vector3d(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    put_obb(volumetric::OrientedBoundingBox3D::compute_from_points<double>(v, volumetric::OBBComputationMethod::PCA), out10);
+}
+}

@@ -182,14 +182,62 @@ class _Volume:
 # `volumetric` module mirror
 # ================================================================================================
 class BoundingBox3D:
-    """cpp/volumetric/bounding_boxes_3d.h:39-80 (axis-aligned)."""
+    """Axis-aligned box: cpp/volumetric/bounding_boxes_3d.h:39-80, bounding_boxes_3d.cpp:174-247, bindings
+    bounding_boxes_module.h:49-93.  BoundingBox3D(), BoundingBox3D(min_point, max_point) or the six scalars."""
 
-    def __init__(self, min_point, max_point):
-        self.min_x, self.min_y, self.min_z = (float(x) for x in min_point)
-        self.max_x, self.max_y, self.max_z = (float(x) for x in max_point)
+    def __init__(self, *args):
+        if len(args) == 0:
+            vals = (0.0,) * 6
+        elif len(args) == 2:
+            vals = tuple(float(x) for x in args[0]) + tuple(float(x) for x in args[1])
+        elif len(args) == 6:
+            vals = tuple(float(x) for x in args)
+        else:
+            raise TypeError("BoundingBox3D(), BoundingBox3D(min_point, max_point) or BoundingBox3D(min_x, min_y, min_z, max_x, max_y, max_z)")
+        self.min_x, self.min_y, self.min_z, self.max_x, self.max_y, self.max_z = vals
 
     def as_array(self):
         return np.array([self.min_x, self.min_y, self.min_z, self.max_x, self.max_y, self.max_z], np.float64)
+
+    def get_min_point(self):
+        return np.array([self.min_x, self.min_y, self.min_z], np.float64)
+
+    def get_max_point(self):
+        return np.array([self.max_x, self.max_y, self.max_z], np.float64)
+
+    def get_center(self):
+        return (self.get_min_point() + self.get_max_point()) / 2.0
+
+    def get_size(self):
+        return self.get_max_point() - self.get_min_point()
+
+    def get_volume(self):
+        sx, sy, sz = self.get_size()
+        return float(sx * sy * sz)
+
+    def get_surface_area(self):
+        sx, sy, sz = self.get_size()
+        return float(2.0 * (sx * sy + sx * sz + sy * sz))
+
+    def get_diagonal_length(self):
+        sx, sy, sz = self.get_size()
+        return float(np.sqrt(sx * sx + sy * sy + sz * sz))
+
+    def contains(self, points):
+        """One point [3] -> bool; several [N,3] -> list of bool (the binding's two overloads).  Closed box."""
+        p = np.asarray(points, np.float64)
+        m = np.all((p >= self.get_min_point()) & (p <= self.get_max_point()), axis=-1)
+        return bool(m) if p.ndim == 1 else [bool(x) for x in m]
+
+    def intersects(self, other):
+        return bool(np.all((self.get_min_point() <= other.get_max_point()) & (self.get_max_point() >= other.get_min_point())))
+
+    @staticmethod
+    def compute_from_points(points):
+        p = np.asarray(points, np.float64).reshape(-1, 3)
+        if len(p) == 0:
+            return BoundingBox3D()
+        return BoundingBox3D(p.min(axis=0), p.max(axis=0))
 
 
 class CameraFrustrum:

@@ -20,8 +20,40 @@ from . import _lib as L
 from .volumetric import VoxelGridData, _Volume
 
 
+class OBBComputationMethod:
+    """bounding_boxes_3d.h:28-31."""
+
+    PCA = 0
+    CONVEX_HULL_MINIMAL = 1
+
+
+def _sat_intersects(ca, ha, Ra, cb, hb, Rb):
+    """Separating-axis test of two boxes {centre, half extents, axes as columns}: bounding_boxes_3d.cpp:60-170 (the 3 + 3
+    face axes and the 9 edge-edge axes of Gottschalk et al., the same 1e-9 padding of |R|)."""
+    R = Ra.T @ Rb
+    A = np.abs(R) + 1e-9
+    tw = cb - ca
+    t = Ra.T @ tw
+    for i in range(3):
+        if abs(t[i]) > ha[i] + hb @ A[i]:
+            return False
+    for j in range(3):
+        if abs(tw @ Rb[:, j]) > ha @ A[:, j] + hb[j]:
+            return False
+    for i in range(3):
+        i1, i2 = (i + 1) % 3, (i + 2) % 3
+        for j in range(3):
+            j1, j2 = (j + 1) % 3, (j + 2) % 3
+            ra = ha[i1] * A[i2, j] + ha[i2] * A[i1, j]
+            rb = hb[j1] * A[i, j2] + hb[j2] * A[i, j1]
+            if abs(t[i2] * R[i1, j] - t[i1] * R[i2, j]) > ra + rb:
+                return False
+    return True
+
+
 class OrientedBoundingBox3D:
-    """bounding_boxes_3d.h:82-131: center (3,), orientation quaternion (w, x, y, z), size (3,)."""
+    """bounding_boxes_3d.h:82-131, bounding_boxes_3d.cpp:253-345, bindings bounding_boxes_module.h:97-160: center (3,),
+    orientation quaternion (w, x, y, z) object -> world, size (3,)."""
 
     def __init__(self, center=(0.0, 0.0, 0.0), orientation=(1.0, 0.0, 0.0, 0.0), size=(0.0, 0.0, 0.0)):
         self.center = np.asarray(center, np.float64).copy()
@@ -35,13 +67,29 @@ class OrientedBoundingBox3D:
                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
     def get_matrix(self):
+        """object -> world."""
         M = np.eye(4)
         M[:3, :3] = self.get_rotation_matrix()
         M[:3, 3] = self.center
         return M
 
+    def get_inverse_matrix(self):
+        """world -> object."""
+        M = np.eye(4)
+        Rt = self.get_rotation_matrix().T
+        M[:3, :3] = Rt
+        M[:3, 3] = -Rt @ self.center
+        return M
+
     def get_volume(self):
         return float(np.prod(self.size))
+
+    def get_surface_area(self):
+        sx, sy, sz = self.size
+        return float(2.0 * (sx * sy + sx * sz + sy * sz))
+
+    def get_diagonal_length(self):
+        return float(np.sqrt(np.sum(self.size * self.size)))
 
     def get_corners(self):
         """bounding_boxes_3d.cpp:287-318 (same corner order)."""
@@ -49,9 +97,29 @@ class OrientedBoundingBox3D:
         signs = [(1, 1, -1), (-1, 1, -1), (-1, -1, -1), (1, -1, -1), (1, 1, 1), (-1, 1, 1), (-1, -1, 1), (1, -1, 1)]
         return np.array([self.center + R @ (h * np.array(s, np.float64)) for s in signs])
 
+    def contains(self, points):
+        """One point [3] -> bool; several [N,3] -> list of bool.  Closed box with the reference's 1e-10 slack
+        (bounding_boxes_3d.cpp:320-337)."""
+        p = np.asarray(points, np.float64)
+        q = (p - self.center) @ self.get_rotation_matrix()  # rows: R^T (p - c)
+        h = self.size / 2.0 + 1e-10
+        m = np.all((q >= -h) & (q <= h), axis=-1)
+        return bool(m) if p.ndim == 1 else [bool(x) for x in m]
+
+    def intersects(self, other):
+        """Against another OrientedBoundingBox3D or a BoundingBox3D (bounding_boxes_3d.cpp:339-345)."""
+        if isinstance(other, OrientedBoundingBox3D):
+            cb, hb, Rb = other.center, other.size / 2.0, other.get_rotation_matrix()
+        else:
+            cb, hb, Rb = other.get_center(), other.get_size() / 2.0, np.eye(3)
+        return _sat_intersects(self.center, self.size / 2.0, self.get_rotation_matrix(), cb, hb, Rb)
+
     @staticmethod
-    def compute_from_points(points):
-        """OrientedBoundingBox3D::compute_from_points(points, PCA), bounding_boxes_3d.cpp:373-553."""
+    def compute_from_points(points, method=OBBComputationMethod.PCA):
+        """OrientedBoundingBox3D::compute_from_points(points, PCA), bounding_boxes_3d.cpp:373-553.  The convex-hull variant
+        needs Qhull in the reference too (QHULL_FOUND) and is not provided here."""
+        if method != OBBComputationMethod.PCA:
+            raise NotImplementedError("OBBComputationMethod.CONVEX_HULL_MINIMAL is not provided (PCA is the reference's default)")
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
         obb = np.zeros(10, np.float64)
         L.check(L.load().hv_compute_obb_pca(L.ptr(pts), pts.shape[0], L.ptr(obb)))
