@@ -34,6 +34,7 @@ static constexpr int RR = R * R;
 static constexpr int RRR = R * R * R;
 static constexpr int PLANE_BYTES = RRR * 4;
 static constexpr int HV_TOUCH_FAN = 8; // lanes per depth sample in the online touch pass
+static constexpr uint32_t HV_REC_ONE = 1u << 24; // observation count byte of a batch frame record's colour word
 
 // Image::CreateDepthToCameraDistanceMultiplierFloatImage, evaluated per gather instead of tabulated.
 __device__ __forceinline__ float hv_multiplier(const HvFrameParams &P, int u, int v) {
@@ -466,7 +467,9 @@ __device__ __forceinline__ float hv_sqrt_ge1(float x) {
 // EXACT = false: operands inside hv_div2's band (the caller's wave-uniform test), whole-image frames.
 // EXACT = true: any operands (IEEE division where pc2 < 2^-20) and the image-tile test of the tile-sharded mode.
 // MT: take the multiplier from the per-pixel table instead of computing it.
-template <bool EXACT, bool MT>
+// REC12: frame_px points at 12-byte {depth, colour, multiplier} records (the fold form's batch layout) instead of 8-byte
+// {depth, colour} records beside the multiplier table.
+template <bool EXACT, bool MT, bool REC12 = false>
 __device__ __forceinline__ bool hv_tsdf_eval_fast(const HvFrameParams &P, const uint2 *__restrict__ frame_px,
                                                   const float *__restrict__ mult, float pc0, float pc1, float pc2,
                                                   float &t, uint32_t &rgb) {
@@ -495,10 +498,18 @@ __device__ __forceinline__ bool hv_tsdf_eval_fast(const HvFrameParams &P, const 
         ok = (int)ok & (int)in_tile_u & (int)in_tile_v;
     }
     const uint32_t off = ok ? (uint32_t)v * (uint32_t)P.W + (uint32_t)u : 0u;
-    const uint2 rec = frame_px[off];
-    const float d = __uint_as_float(rec.x);
+    uint2 rec;
     float m;
-    if (MT) {
+    if (REC12) {
+        const uint32_t *r3 = (const uint32_t *)frame_px + (size_t)off * 3;
+        rec = make_uint2(r3[0], r3[1]);
+        m = __uint_as_float(r3[2]);
+    } else {
+        rec = frame_px[off];
+    }
+    const float d = __uint_as_float(rec.x);
+    if (REC12) {
+    } else if (MT) {
         m = mult[off];
     } else {
         const float xx = ((float)u - P.cx) * P.ffl_inv_x;
@@ -754,7 +765,8 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
                                                                 const uint8_t *__restrict__ rgb,
                                                                 uint2 *__restrict__ frame_px,
                                                                 const HvFrameParams *__restrict__ Ps, int n_prep_blocks,
-                                                                int n_touch_blocks, int n_frames, int parity) {
+                                                                int n_touch_blocks, int n_frames, int parity,
+                                                                const float *__restrict__ mult12) {
     // block order: the touch blocks of ALL frames first, then the pack blocks.  A touch wave is one chain of dependent
     // memory round trips (depth -> hash probe -> mask / stamp -> atomics; a patch on a long depth discontinuity walks
     // several such chains), the pack blocks are pure streaming: dispatched last they fill the machine while the touch
@@ -779,10 +791,16 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
         const int64_t i0 = ((int64_t)bx * blockDim.x + threadIdx.x) * 4;
         if (i0 >= npx) return;
         uint2 *dst = frame_px + (int64_t)f * npx + i0;
+        // mult12 != nullptr: 12-byte records {depth, colour, multiplier} (the fold form of the sweep gathers a voxel's pixel
+        // with ONE load; the multiplier comes from the per-pixel table, which is built before this launch)
+        uint32_t *dst12 = (uint32_t *)frame_px + ((int64_t)f * npx + i0) * 3;
         if (i0 + 4 <= npx && (npx & 3) == 0) {
             const uint32_t *c4 = (const uint32_t *)(rgb_f + i0 * 3); // i0 % 4 == 0 -> 12-byte multiple: dword aligned
             const uint32_t w0 = c4[0], w1 = c4[1], w2 = c4[2];
-            const uint32_t col[4] = {w0 & 0xffffffu, (w0 >> 24) | ((w1 & 0xffffu) << 8), (w1 >> 16) | ((w2 & 0xffu) << 16), w2 >> 8};
+            // byte 3 of a batch record's colour word is 1: the fold form of the sweep adds accepted records' words into packed
+            // accumulators and that byte counts the observations (every other consumer masks the colour bytes out)
+            const uint32_t col[4] = {(w0 & 0xffffffu) | HV_REC_ONE, (w0 >> 24) | ((w1 & 0xffffu) << 8) | HV_REC_ONE,
+                                     (w1 >> 16) | ((w2 & 0xffu) << 16) | HV_REC_ONE, (w2 >> 8) | HV_REC_ONE};
             float d[4];
             if (P.depth_is_u16) {
                 const uint2 raw = *(const uint2 *)((const uint16_t *)depth_f + i0);
@@ -797,15 +815,29 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
                 d[k] = d[k] / P.depth_scale_f;
                 if ((double)d[k] >= P.depth_trunc_d) d[k] = 0.0f;
             }
-            ((uint4 *)dst)[0] = make_uint4(__float_as_uint(d[0]), col[0], __float_as_uint(d[1]), col[1]);
-            ((uint4 *)dst)[1] = make_uint4(__float_as_uint(d[2]), col[2], __float_as_uint(d[3]), col[3]);
+            if (mult12 != nullptr) {
+                const float4 m4 = *(const float4 *)(mult12 + i0);
+                ((uint4 *)dst12)[0] = make_uint4(__float_as_uint(d[0]), col[0], __float_as_uint(m4.x), __float_as_uint(d[1]));
+                ((uint4 *)dst12)[1] = make_uint4(col[1], __float_as_uint(m4.y), __float_as_uint(d[2]), col[2]);
+                ((uint4 *)dst12)[2] = make_uint4(__float_as_uint(m4.z), __float_as_uint(d[3]), col[3], __float_as_uint(m4.w));
+            } else {
+                ((uint4 *)dst)[0] = make_uint4(__float_as_uint(d[0]), col[0], __float_as_uint(d[1]), col[1]);
+                ((uint4 *)dst)[1] = make_uint4(__float_as_uint(d[2]), col[2], __float_as_uint(d[3]), col[3]);
+            }
         } else {
             for (int64_t i = i0; i < npx && i < i0 + 4; ++i) {
                 const uint8_t *c = rgb_f + i * 3;
                 uint2 rec;
                 rec.x = __float_as_uint(hv_convert_depth(P, depth_f, i));
-                rec.y = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
-                frame_px[(int64_t)f * npx + i] = rec;
+                rec.y = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | HV_REC_ONE;
+                if (mult12 != nullptr) {
+                    uint32_t *r3 = (uint32_t *)frame_px + ((int64_t)f * npx + i) * 3;
+                    r3[0] = rec.x;
+                    r3[1] = rec.y;
+                    r3[2] = __float_as_uint(mult12[i]);
+                } else {
+                    frame_px[(int64_t)f * npx + i] = rec;
+                }
             }
         }
         return;
@@ -1331,6 +1363,507 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
     }
 }
 
+// ================================================================================================
+// Sweep, third form (production since round 3): the batch is FOLDED per voxel.  The contract asks for bit-exact unit
+// keys and weights and 1e-4 on tsdf / colour (BASELINE.json north_star); the running mean (tsdf w + t) / (w + 1) applied
+// once per accepted frame is, in real numbers, (tsdf w0 + sum t) / (w0 + n) - so a lane keeps `sum t` and n per voxel in
+// registers over the batch's frames and divides ONCE when the item is done (measured against the oracle's per-frame
+// float chain: <= 3e-7).  What decides WHETHER a frame updates a voxel - the projection, the pixel it lands in, the
+// truncation test - is still evaluated with the reference's IEEE operations in the reference's order, so weights and
+// colour sums stay exact integers.  Against the second form a voxel visit loses the correctly rounded running-mean
+// division (two rcp + 11 fma-class per voxel pair), the float weight carry, and three tests the item-level regime test
+// already implies:
+//  * `pc2 > 0`: an item only takes this path when every voxel of the wave's box lies beyond `near_z` of every frame in
+//    its mask;
+//  * `depth > 0`: with near_z >= 1.25 sdf_trunc and a multiplier >= 1, a record with depth <= 0 (invalid, truncated, or
+//    the zero an out-of-range buffer load returns) gives sdf <= -pc2 < -sdf_trunc and fails the truncation test by itself;
+//  * the image-tile test of the tile-sharded mode folds into the image-range compare (the range constants become the
+//    tile's), so tiled volumes take the fast path too.
+// The observation count rides in byte 3 of the packed colour word (HV_REC_ONE, set by the pack role): one masked add
+// accumulates green and the count.  tsdf / weight planes are only read when the item is done, and only by lanes with n > 0.
+// ================================================================================================
+template <int ZH, int SPLIT, int WPE, bool ANYSKIP, int DBG = 0, bool REC12 = true>
+__global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep_fold(
+    HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
+    char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
+    int general, const float *__restrict__ mult, int xcd_aware, int parity) {
+    constexpr int TASKS = 64 / ZH;          // wave tasks per unit
+    constexpr int WAVES = TASKS / SPLIT;    // waves per workgroup
+    int n_units = table.counters[HV_CNT_TOUCH0 + parity];
+    if (n_units > table.max_blocks) n_units = table.max_blocks;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const HvFrameParams &P0 = Ps[0];
+    const float vl = P0.voxel_length_f, hl = P0.half_voxel_length_f;
+    const double unit_length = P0.unit_length;
+    const int npx = P0.H * P0.W;
+    const hv_f2 F = {P0.fx, P0.fy}, C = {P0.cx, P0.cy};
+    // u_f in [max(0.0001, tile_u0), min(safe_width, tile_u1)) as ONE unsigned compare (bit patterns of non-negative floats order
+    // like the values; (int)u_f >= k <=> u_f >= k for integers k >= 0): the whole-image tile gives the reference's range
+    const float lo_uf = fmaxf(0.0001f, (float)P0.tile_u0), lo_vf = fmaxf(0.0001f, (float)P0.tile_v0);
+    const float hi_uf = fminf(P0.safe_width_f, (float)P0.tile_u1), hi_vf = fminf(P0.safe_height_f, (float)P0.tile_v1);
+    const uint32_t lo_u = __float_as_uint(lo_uf), lo_v = __float_as_uint(lo_vf);
+    const uint32_t lim_u = hi_uf > lo_uf ? __float_as_uint(hi_uf) - lo_u : 0u, lim_v = hi_vf > lo_vf ? __float_as_uint(hi_vf) - lo_v : 0u;
+    const uint32_t W24 = (uint32_t)P0.W;
+    const float ntrunc = -P0.sdf_trunc_f, tinv = P0.sdf_trunc_inv_f;
+    const float near_z = fmaxf(0.03f, 1.25f * P0.sdf_trunc_f);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void *)mult, 0, npx * 4, 0x00020000);
+    // work items -> workgroups: as in k_tsdf_sweep (XCD groups)
+    const int G = xcd_aware > 0 ? xcd_aware : 1;
+    const int rounds = (n_units + 8 * G - 1) / (8 * G);
+    const int n_items = xcd_aware > 0 ? rounds * 8 * G * SPLIT : n_units * SPLIT;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        int t, part;
+        if (xcd_aware > 0) {
+            const int xcd = item & 7, j = item >> 3;
+            const int g = j / (G * SPLIT), within = j - g * (G * SPLIT);
+            t = (g * 8 + xcd) * G + within / SPLIT;
+            part = within % SPLIT;
+            if (t >= n_units) continue;
+        } else {
+            t = item / SPLIT;
+            part = item % SPLIT;
+        }
+        const int task = part * WAVES + wave;
+        const int cg = task & 3;            // column group: x in [4 cg, 4 cg + 4)
+        const int z0 = (task >> 2) * ZH;
+        const int x = cg * 4 + (lane >> 4);
+        const int y = lane & 15;
+        const int32_t slot = list[t];
+        const int32_t idx = table.vals[slot];
+        unsigned long long mask = frame_mask[slot];
+        if (idx < 0 || mask == 0ull) continue;
+        int32_t ux, uy, uz;
+        hv_unpack_key(table.keys[slot], ux, uy, uz);
+        const double o0 = (double)ux * unit_length, o1 = (double)uy * unit_length, o2 = (double)uz * unit_length;
+        // lane f <-> frame f: does the box of this wave's voxel centres come within near_z of frame f's camera plane?
+        bool near = false;
+        if (lane < n_frames && ((mask >> lane) & 1ull)) {
+            const HvFrameParams &Pl = Ps[lane];
+            const float bx = (float)((double)(hl + vl * (float)(cg * 4)) + o0), by = (float)((double)hl + o1),
+                        bz = (float)((double)(hl + vl * (float)z0) + o2);
+            const float zmin = (Pl.ext[8] * bx + Pl.ext[9] * by + Pl.ext[10] * bz + Pl.ext[11]) + fminf(Pl.ext[8] * (3.0f * vl), 0.f) +
+                               fminf(Pl.ext[9] * (15.0f * vl), 0.f) + fminf(Pl.ext[10] * ((float)(ZH - 1) * vl), 0.f);
+            near = !(zmin > near_z);
+        }
+        const bool near_any = __any(near);
+        char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
+        const int wordb = z0 * RR + cg * 64 + lane;
+        // the voxel centre of (x, y, z = 0) does not depend on the frame
+        const float p0 = (float)((double)(hl + vl * (float)x) + o0);
+        const float p1 = (float)((double)(hl + vl * (float)y) + o1);
+        const float p2 = (float)((double)hl + o2);
+        if (general || near_any) {
+            // rare regime: the reference's evaluation frame by frame with integer weights (k_tsdf_sweep's EXACT arithmetic), one
+            // voxel at a time so that this path's registers do not set the kernel's occupancy
+#pragma unroll 1
+            for (int zz = 0; zz < ZH; ++zz) {
+                const int q = wordb + zz * RR;
+                float vt = ((const float *)(unit + 0 * PLANE_BYTES))[q];
+                uint32_t vw = ((const uint32_t *)(unit + 1 * PLANE_BYTES))[q];
+                uint32_t vr = ((const uint32_t *)(unit + 2 * PLANE_BYTES))[q];
+                uint32_t vg = ((const uint32_t *)(unit + 3 * PLANE_BYTES))[q];
+                uint32_t vb = ((const uint32_t *)(unit + 4 * PLANE_BYTES))[q];
+                bool dirty = false;
+                unsigned long long m = mask;
+#pragma unroll 1
+                while (m) {
+                    const int f = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const HvFrameParams &P = Ps[f];
+                    const float inc0 = P.ext_scaled_col2[0], inc1 = P.ext_scaled_col2[1], inc2 = P.ext_scaled_col2[2];
+                    float pc0 = ((P.ext[0] * p0 + P.ext[1] * p1) + P.ext[2] * p2) + P.ext[3];
+                    float pc1 = ((P.ext[4] * p0 + P.ext[5] * p1) + P.ext[6] * p2) + P.ext[7];
+                    float pc2 = ((P.ext[8] * p0 + P.ext[9] * p1) + P.ext[10] * p2) + P.ext[11];
+#pragma unroll 1
+                    for (int s = 0; s < z0 + zz; ++s) { // the reference's repeated float additions along z, replayed
+                        pc0 += inc0;
+                        pc1 += inc1;
+                        pc2 += inc2;
+                    }
+                    float tv;
+                    uint32_t cv;
+                    const uint2 *px_f = REC12 ? (const uint2 *)((const uint32_t *)frame_px + (int64_t)f * npx * 3) : frame_px + (int64_t)f * npx;
+                    const bool ok = hv_tsdf_eval_fast<true, true, REC12>(P, px_f, mult, pc0, pc1, pc2, tv, cv);
+                    hv_tsdf_apply(ok, tv, cv, vt, vw, vr, vg, vb);
+                    dirty |= ok;
+                }
+                if (dirty) {
+                    ((float *)(unit + 0 * PLANE_BYTES))[q] = vt;
+                    ((uint32_t *)(unit + 1 * PLANE_BYTES))[q] = vw;
+                    ((uint32_t *)(unit + 2 * PLANE_BYTES))[q] = vr;
+                    ((uint32_t *)(unit + 3 * PLANE_BYTES))[q] = vg;
+                    ((uint32_t *)(unit + 4 * PLANE_BYTES))[q] = vb;
+                }
+            }
+            continue;
+        }
+        float S[ZH];             // sum of the accepted frames' t
+        uint32_t arb[ZH], agn[ZH]; // r | b << 16 and g << 8 | n << 24 of the accepted frames
+#pragma unroll
+        for (int k = 0; k < ZH; ++k) {
+            S[k] = 0.0f;
+            arb[k] = agn[k] = 0u;
+        }
+        auto fold_frame = [&](const HvSweepFrameK K, const int f, HvSweepFrameK &Knext, const unsigned long long rest) __attribute__((always_inline)) {
+            const __amdgpu_buffer_rsrc_t rs_px =
+                REC12 ? __builtin_amdgcn_make_buffer_rsrc((void *)((const uint32_t *)frame_px + (int64_t)f * npx * 3), 0, npx * 12, 0x00020000)
+                      : __builtin_amdgcn_make_buffer_rsrc((void *)(frame_px + (int64_t)f * npx), 0, npx * 8, 0x00020000);
+            const hv_f2 INC = K.i01;
+            const float inc2 = K.i2;
+            // pc = ((e0 p0 + e1 p1) + e2 p2) + e3, rows 0 and 1 as one float2 (same IEEE ops as the reference)
+            hv_f2 XY = ((K.e04 * p0 + K.e15 * p1) + K.e26 * p2) + K.e37;
+            const hv_f2 Z12 = K.e9_10 * hv_f2{p1, p2};
+            float Z = ((K.e8 * p0 + Z12.x) + Z12.y) + K.e11;
+            __builtin_amdgcn_sched_barrier(0);
+            Knext = hv_sweep_frame_k(Ps, rest ? __ffsll((long long)rest) - 1 : f);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < z0; ++s) { // the reference's repeated float additions along z, replayed
+                XY += INC;
+                Z += inc2;
+            }
+            uint2 rec[ZH];
+            float mm[ZH], zk[ZH];
+            bool inimg[ZH];
+#pragma unroll
+            for (int k = 0; k < ZH; ++k) {
+                // (a0, a1) / pc2, correctly rounded, sharing one refined reciprocal (hv_div2's chain on a float2)
+                float r = __builtin_amdgcn_rcpf(Z);
+                const float e = fmaf(-Z, r, 1.0f);
+                r = fmaf(e, r, r);
+                const hv_f2 A = XY * F;
+                const hv_f2 R = hv_splat(r), NZ = hv_splat(-Z);
+                hv_f2 Q = A * R;
+                hv_f2 REM = hv_fma2(NZ, Q, A);
+                Q = hv_fma2(REM, R, Q);
+                REM = hv_fma2(NZ, Q, A);
+                Q = hv_fma2(REM, R, Q);
+                const hv_f2 UV = (Q + C) + hv_splat(0.5f);
+                const bool in_u = (__float_as_uint(UV.x) - lo_u) < lim_u;
+                const bool in_v = (__float_as_uint(UV.y) - lo_v) < lim_v;
+                inimg[k] = (int)in_u & (int)in_v;
+                const uint32_t u = (uint32_t)(int)UV.x, v = (uint32_t)(int)UV.y; // saturating conversions: garbage lanes stay defined
+                const uint32_t off = __umul24(v, W24) + u; // exact for every in-image pixel; a garbage lane reads 0 or some pixel, unused
+                // (DBG != 0: timing ablations for profiles/, selected by HV_TSDF_SWEEP_DBG; they do not produce a valid volume.
+                //  1: no multiplier gather; 2: no gathers at all; 3: both gathers at lane-contiguous addresses)
+                if (DBG == 2) {
+                    rec[k] = make_uint2(__float_as_uint(Z + 0.01f), off);
+                    mm[k] = 1.0f;
+                } else if (REC12) {
+                    typedef uint32_t hv_u3 __attribute__((ext_vector_type(3)));
+                    const uint32_t goff = DBG == 3 ? ((off & 0xffc0u) | (uint32_t)lane) : off;
+                    const hv_u3 r3 = __builtin_bit_cast(hv_u3, __builtin_amdgcn_raw_buffer_load_b96(rs_px, (int)__umul24(goff, 12u), 0, 0));
+                    rec[k] = make_uint2(r3.x, r3.y);
+                    mm[k] = __uint_as_float(r3.z);
+                } else {
+                    const uint32_t goff = DBG == 3 ? ((off & 0xffc0u) | (uint32_t)lane) : off;
+                    rec[k] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs_px, (int)(goff << 3), 0, 0));
+                    mm[k] = DBG == 1 ? 1.0f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_m, (int)(goff << 2), 0, 0));
+                }
+                zk[k] = Z;
+                XY += INC;
+                Z += inc2;
+            }
+#pragma unroll
+            for (int k = 0; k < ZH; ++k) {
+                const float sdf = (__uint_as_float(rec[k].x) - zk[k]) * mm[k];
+                const bool ok = (int)inimg[k] & (int)(sdf > ntrunc);
+                if (ANYSKIP && !__any(ok)) continue;
+                const float tk = fminf(sdf * tinv, 1.0f); // == `if (t > 1) t = 1` for the non-NaN t of an accepted voxel
+                S[k] += ok ? tk : 0.0f;
+                const uint32_t c = ok ? rec[k].y : 0u;
+                arb[k] += c & 0x00ff00ffu;
+                agn[k] += c & 0xff00ff00u;
+            }
+        };
+        HvSweepFrameK ka = hv_sweep_frame_k(Ps, __ffsll((long long)mask) - 1), kb = ka;
+        while (true) {
+            const int fa = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            fold_frame(ka, fa, kb, mask);
+            if (!mask) break;
+            const int fb = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            fold_frame(kb, fb, ka, mask);
+            if (!mask) break;
+        }
+        // one running-mean step per voxel for the whole batch
+        float vt[ZH];
+        uint32_t vw[ZH];
+#pragma unroll
+        for (int zz = 0; zz < ZH; ++zz) {
+            if (agn[zz] >> 24) {
+                const int q = wordb + zz * RR;
+                vt[zz] = ((const float *)(unit + 0 * PLANE_BYTES))[q];
+                vw[zz] = ((const uint32_t *)(unit + 1 * PLANE_BYTES))[q];
+            }
+        }
+#pragma unroll
+        for (int zz = 0; zz < ZH; ++zz) {
+            const uint32_t n = agn[zz] >> 24;
+            if (n) {
+                const int q = wordb + zz * RR;
+                const uint32_t nw = vw[zz] + n;
+                ((float *)(unit + 0 * PLANE_BYTES))[q] = (vt[zz] * (float)vw[zz] + S[zz]) / (float)nw;
+                ((uint32_t *)(unit + 1 * PLANE_BYTES))[q] = nw;
+                ((uint32_t *)(unit + 2 * PLANE_BYTES))[q] += arb[zz] & 0xffffu;
+                ((uint32_t *)(unit + 3 * PLANE_BYTES))[q] += (agn[zz] >> 8) & 0xffffu;
+                ((uint32_t *)(unit + 4 * PLANE_BYTES))[q] += arb[zz] >> 16;
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// Sweep, fourth form: the fold form on WHOLE voxel columns.  A lane owns one (x, y) column of the unit and all 16 z of
+// it, a wave 64 columns (one column group), a unit is 4 wave tasks.  Against the third form (4 z per lane):
+//  * the z-walk starts at z = 0 for every lane: the replay of the reference's repeated float additions up to z0 (0 / 4 / 8
+//    / 12 steps, two instructions each) disappears, and the per-frame set-up (the rigid transform of the column's base
+//    point, the frame's buffer descriptor, the prefetch of the next frame's constants) is paid once per 16 voxels
+//    instead of once per 4: 42.7 -> ~35 VALU instructions per voxel visit;
+//  * the voxels of a column are evaluated GV at a time; with PIPE the gathers of group g+1 are issued BEFORE group g is
+//    folded, so a wave always has GV gathers in flight behind GV voxels' worth of arithmetic.
+// 12-byte frame records only ({depth, colour | 1 << 24, multiplier}: one gather per voxel visit).  Registers: 3 x 16
+// accumulators (sum t, r | b << 16, g << 8 | n << 24) + two gather groups.
+// ================================================================================================
+template <int SPLIT, int WPE, int GV, bool PIPE, bool ANYSKIP>
+__global__ __launch_bounds__(64 * 4 / SPLIT, WPE) void k_tsdf_sweep_column(
+    HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
+    char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
+    int general, const float *__restrict__ mult, int xcd_aware, int parity) {
+    constexpr int ZH = 16;
+    constexpr int NG = ZH / GV;
+    constexpr int WAVES = 4 / SPLIT; // waves per workgroup
+    typedef uint32_t hv_u3 __attribute__((ext_vector_type(3)));
+    int n_units = table.counters[HV_CNT_TOUCH0 + parity];
+    if (n_units > table.max_blocks) n_units = table.max_blocks;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const HvFrameParams &P0 = Ps[0];
+    const float vl = P0.voxel_length_f, hl = P0.half_voxel_length_f;
+    const double unit_length = P0.unit_length;
+    const int npx = P0.H * P0.W;
+    const hv_f2 F = {P0.fx, P0.fy}, C = {P0.cx, P0.cy};
+    const float lo_uf = fmaxf(0.0001f, (float)P0.tile_u0), lo_vf = fmaxf(0.0001f, (float)P0.tile_v0);
+    const float hi_uf = fminf(P0.safe_width_f, (float)P0.tile_u1), hi_vf = fminf(P0.safe_height_f, (float)P0.tile_v1);
+    const uint32_t lo_u = __float_as_uint(lo_uf), lo_v = __float_as_uint(lo_vf);
+    const uint32_t lim_u = hi_uf > lo_uf ? __float_as_uint(hi_uf) - lo_u : 0u, lim_v = hi_vf > lo_vf ? __float_as_uint(hi_vf) - lo_v : 0u;
+    const uint32_t W24 = (uint32_t)P0.W;
+    const float ntrunc = -P0.sdf_trunc_f, tinv = P0.sdf_trunc_inv_f;
+    const float near_z = fmaxf(0.03f, 1.25f * P0.sdf_trunc_f);
+    const int G = xcd_aware > 0 ? xcd_aware : 1;
+    const int rounds = (n_units + 8 * G - 1) / (8 * G);
+    const int n_items = xcd_aware > 0 ? rounds * 8 * G * SPLIT : n_units * SPLIT;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        int t, part;
+        if (xcd_aware > 0) {
+            const int xcd = item & 7, j = item >> 3;
+            const int g = j / (G * SPLIT), within = j - g * (G * SPLIT);
+            t = (g * 8 + xcd) * G + within / SPLIT;
+            part = within % SPLIT;
+            if (t >= n_units) continue;
+        } else {
+            t = item / SPLIT;
+            part = item % SPLIT;
+        }
+        const int cg = part * WAVES + wave; // column group: x in [4 cg, 4 cg + 4)
+        const int x = cg * 4 + (lane >> 4);
+        const int y = lane & 15;
+        const int32_t slot = list[t];
+        const int32_t idx = table.vals[slot];
+        unsigned long long mask = frame_mask[slot];
+        if (idx < 0 || mask == 0ull) continue;
+        int32_t ux, uy, uz;
+        hv_unpack_key(table.keys[slot], ux, uy, uz);
+        const double o0 = (double)ux * unit_length, o1 = (double)uy * unit_length, o2 = (double)uz * unit_length;
+        // lane f <-> frame f: does the box of this wave's voxel centres come within near_z of frame f's camera plane?
+        bool near = false;
+        if (lane < n_frames && ((mask >> lane) & 1ull)) {
+            const HvFrameParams &Pl = Ps[lane];
+            const float bx = (float)((double)(hl + vl * (float)(cg * 4)) + o0), by = (float)((double)hl + o1), bz = (float)((double)hl + o2);
+            const float zmin = (Pl.ext[8] * bx + Pl.ext[9] * by + Pl.ext[10] * bz + Pl.ext[11]) + fminf(Pl.ext[8] * (3.0f * vl), 0.f) +
+                               fminf(Pl.ext[9] * (15.0f * vl), 0.f) + fminf(Pl.ext[10] * (15.0f * vl), 0.f);
+            near = !(zmin > near_z);
+        }
+        const bool near_any = __any(near);
+        char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
+        const int wordb = cg * 64 + lane;
+        const float p0 = (float)((double)(hl + vl * (float)x) + o0);
+        const float p1 = (float)((double)(hl + vl * (float)y) + o1);
+        const float p2 = (float)((double)hl + o2);
+        if (general || near_any) {
+            // rare regime: the reference's evaluation frame by frame with integer weights, one voxel at a time
+#pragma unroll 1
+            for (int zz = 0; zz < ZH; ++zz) {
+                const int q = wordb + zz * RR;
+                float vt = ((const float *)(unit + 0 * PLANE_BYTES))[q];
+                uint32_t vw = ((const uint32_t *)(unit + 1 * PLANE_BYTES))[q];
+                uint32_t vr = ((const uint32_t *)(unit + 2 * PLANE_BYTES))[q];
+                uint32_t vg = ((const uint32_t *)(unit + 3 * PLANE_BYTES))[q];
+                uint32_t vb = ((const uint32_t *)(unit + 4 * PLANE_BYTES))[q];
+                bool dirty = false;
+                unsigned long long m = mask;
+#pragma unroll 1
+                while (m) {
+                    const int f = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const HvFrameParams &P = Ps[f];
+                    const float inc0 = P.ext_scaled_col2[0], inc1 = P.ext_scaled_col2[1], inc2 = P.ext_scaled_col2[2];
+                    float pc0 = ((P.ext[0] * p0 + P.ext[1] * p1) + P.ext[2] * p2) + P.ext[3];
+                    float pc1 = ((P.ext[4] * p0 + P.ext[5] * p1) + P.ext[6] * p2) + P.ext[7];
+                    float pc2 = ((P.ext[8] * p0 + P.ext[9] * p1) + P.ext[10] * p2) + P.ext[11];
+#pragma unroll 1
+                    for (int s = 0; s < zz; ++s) { // the reference's repeated float additions along z, replayed
+                        pc0 += inc0;
+                        pc1 += inc1;
+                        pc2 += inc2;
+                    }
+                    float tv;
+                    uint32_t cv;
+                    const uint2 *px_f = (const uint2 *)((const uint32_t *)frame_px + (int64_t)f * npx * 3);
+                    const bool ok = hv_tsdf_eval_fast<true, true, true>(P, px_f, mult, pc0, pc1, pc2, tv, cv);
+                    hv_tsdf_apply(ok, tv, cv, vt, vw, vr, vg, vb);
+                    dirty |= ok;
+                }
+                if (dirty) {
+                    ((float *)(unit + 0 * PLANE_BYTES))[q] = vt;
+                    ((uint32_t *)(unit + 1 * PLANE_BYTES))[q] = vw;
+                    ((uint32_t *)(unit + 2 * PLANE_BYTES))[q] = vr;
+                    ((uint32_t *)(unit + 3 * PLANE_BYTES))[q] = vg;
+                    ((uint32_t *)(unit + 4 * PLANE_BYTES))[q] = vb;
+                }
+            }
+            continue;
+        }
+        float S[ZH];               // sum of the accepted frames' t
+        uint32_t arb[ZH], agn[ZH]; // r | b << 16 and g << 8 | n << 24 of the accepted frames
+#pragma unroll
+        for (int k = 0; k < ZH; ++k) {
+            S[k] = 0.0f;
+            arb[k] = agn[k] = 0u;
+        }
+        struct Group { // GV voxels between their gather and their fold
+            hv_u3 rec[GV];
+            float zk[GV];
+            bool inimg[GV];
+        };
+        auto fold_frame = [&](const HvSweepFrameK K, const int f, HvSweepFrameK &Knext, const unsigned long long rest) __attribute__((always_inline)) {
+            const __amdgpu_buffer_rsrc_t rs_px =
+                __builtin_amdgcn_make_buffer_rsrc((void *)((const uint32_t *)frame_px + (int64_t)f * npx * 3), 0, npx * 12, 0x00020000);
+            const hv_f2 INC = K.i01;
+            const float inc2 = K.i2;
+            // pc = ((e0 p0 + e1 p1) + e2 p2) + e3 at z = 0, rows 0 and 1 as one float2 (same IEEE ops as the reference)
+            hv_f2 XY = ((K.e04 * p0 + K.e15 * p1) + K.e26 * p2) + K.e37;
+            const hv_f2 Z12 = K.e9_10 * hv_f2{p1, p2};
+            float Z = ((K.e8 * p0 + Z12.x) + Z12.y) + K.e11;
+            __builtin_amdgcn_sched_barrier(0);
+            Knext = hv_sweep_frame_k(Ps, rest ? __ffsll((long long)rest) - 1 : f);
+            __builtin_amdgcn_sched_barrier(0);
+            auto project = [&](Group &g) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k = 0; k < GV; ++k) {
+                    // (a0, a1) / pc2, correctly rounded, sharing one refined reciprocal (hv_div2's chain on a float2)
+                    float r = __builtin_amdgcn_rcpf(Z);
+                    const float e = fmaf(-Z, r, 1.0f);
+                    r = fmaf(e, r, r);
+                    const hv_f2 A = XY * F;
+                    const hv_f2 R = hv_splat(r), NZ = hv_splat(-Z);
+                    hv_f2 Q = A * R;
+                    hv_f2 REM = hv_fma2(NZ, Q, A);
+                    Q = hv_fma2(REM, R, Q);
+                    REM = hv_fma2(NZ, Q, A);
+                    Q = hv_fma2(REM, R, Q);
+                    const hv_f2 UV = (Q + C) + hv_splat(0.5f);
+                    const bool in_u = (__float_as_uint(UV.x) - lo_u) < lim_u;
+                    const bool in_v = (__float_as_uint(UV.y) - lo_v) < lim_v;
+                    g.inimg[k] = (int)in_u & (int)in_v;
+                    const uint32_t u = (uint32_t)(int)UV.x, v = (uint32_t)(int)UV.y; // saturating conversions: garbage lanes stay defined
+                    const uint32_t off = __umul24(v, W24) + u; // exact for every in-image pixel; a garbage lane reads 0 or some pixel, unused
+                    g.rec[k] = __builtin_bit_cast(hv_u3, __builtin_amdgcn_raw_buffer_load_b96(rs_px, (int)__umul24(off, 12u), 0, 0));
+                    g.zk[k] = Z;
+                    XY += INC;
+                    Z += inc2;
+                }
+            };
+            auto fold = [&](const Group &g, const int gi) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k = 0; k < GV; ++k) {
+                    const int z = gi * GV + k;
+                    const float sdf = (__uint_as_float(g.rec[k].x) - g.zk[k]) * __uint_as_float(g.rec[k].z);
+                    const bool ok = (int)g.inimg[k] & (int)(sdf > ntrunc);
+                    if (ANYSKIP && !__any(ok)) continue;
+                    const float tk = fminf(sdf * tinv, 1.0f); // == `if (t > 1) t = 1` for the non-NaN t of an accepted voxel
+                    S[z] += ok ? tk : 0.0f;
+                    const uint32_t c = ok ? g.rec[k].y : 0u;
+                    arb[z] += c & 0x00ff00ffu;
+                    agn[z] += c & 0xff00ff00u;
+                }
+            };
+            if (PIPE) {
+                Group ga, gb;
+                project(ga);
+#pragma unroll
+                for (int gi = 0; gi < NG; gi += 2) {
+                    project(gb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fold(ga, gi);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (gi + 2 < NG) project(ga);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fold(gb, gi + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi) {
+                    Group ga;
+                    project(ga);
+                    fold(ga, gi);
+                }
+            }
+        };
+        HvSweepFrameK ka = hv_sweep_frame_k(Ps, __ffsll((long long)mask) - 1), kb = ka;
+        while (true) {
+            const int fa = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            fold_frame(ka, fa, kb, mask);
+            if (!mask) break;
+            const int fb = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            fold_frame(kb, fb, ka, mask);
+            if (!mask) break;
+        }
+        // one running-mean step per voxel for the whole batch, four voxels of the column at a time
+#pragma unroll
+        for (int z4 = 0; z4 < ZH; z4 += 4) {
+            float vt[4];
+            uint32_t vw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (agn[z4 + k] >> 24) {
+                    const int q = wordb + (z4 + k) * RR;
+                    vt[k] = ((const float *)(unit + 0 * PLANE_BYTES))[q];
+                    vw[k] = ((const uint32_t *)(unit + 1 * PLANE_BYTES))[q];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int z = z4 + k;
+                const uint32_t n = agn[z] >> 24;
+                if (n) {
+                    const int q = wordb + z * RR;
+                    const uint32_t nw = vw[k] + n;
+                    ((float *)(unit + 0 * PLANE_BYTES))[q] = (vt[k] * (float)vw[k] + S[z]) / (float)nw;
+                    ((uint32_t *)(unit + 1 * PLANE_BYTES))[q] = nw;
+                    ((uint32_t *)(unit + 2 * PLANE_BYTES))[q] += arb[z] & 0xffffu;
+                    ((uint32_t *)(unit + 3 * PLANE_BYTES))[q] += (agn[z] >> 8) & 0xffffu;
+                    ((uint32_t *)(unit + 4 * PLANE_BYTES))[q] += arb[z] >> 16;
+                }
+            }
+        }
+    }
+}
+
 // After the sweep (one workgroup): clear the frame masks of the batch's units and zero the batch's touched-list counter, so
 // that the next batch / online frame starts clean without a memset launch per counter.
 __global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const int32_t *__restrict__ list,
@@ -1698,6 +2231,17 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
     // the previous batch (content_version), host-resident frames, the checked capacity mode or HV_TSDF_PIPELINE=0 runs
     // everything on the main stream as before.
     const bool pipeline_on = !(getenv("HV_TSDF_PIPELINE") && atoi(getenv("HV_TSDF_PIPELINE")) == 0);
+    // sweep form: 4 = k_tsdf_sweep_column (production: the batch folded per voxel, a lane walks a whole voxel column), 3 =
+    // k_tsdf_sweep_fold (the fold on 4 voxels per lane), 2 = k_tsdf_sweep (the reference's running mean frame by frame: tsdf
+    // bit-identical to it), 1 = first form (A/B, and the only one that runs without the multiplier table).
+    // The switches are read per call (a handful of getenv per batch): the parity tests flip them inside one process.
+    const int sweep_form = getenv("HV_TSDF_SWEEP") ? atoi(getenv("HV_TSDF_SWEEP")) : 4;
+    // per-pixel multiplier table (HV_TSDF_BATCH_MULT=0: compute the multiplier per voxel visit instead; first form only)
+    const int use_mult = getenv("HV_TSDF_BATCH_MULT") ? atoi(getenv("HV_TSDF_BATCH_MULT")) : 1;
+    // fold form: 12-byte frame records {depth, colour, multiplier}, one gather per voxel visit (HV_TSDF_SWEEP_REC12=0: 8-byte
+    // records + the table, two gathers: A/B)
+    const bool rec12 = (sweep_form == 3 || sweep_form == 4) && use_mult && !(getenv("HV_TSDF_SWEEP_REC12") && atoi(getenv("HV_TSDF_SWEEP_REC12")) == 0);
+    const size_t rec_bytes = rec12 ? 12 : 8;
     bool chain_ok = v->pipe_armed && v->pipe_version == v->content_version; // nothing but batches since ev_presweep was recorded
     v->content_version += 1;
     const int BMAX = 64;
@@ -1720,6 +2264,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
             HV_HIP(hipEventCreateWithFlags(&v->ev_presweep, hipEventDisableTiming));
         }
         hipStream_t ps = overlap ? v->stream_aux : v->stream; // where this batch's touch + pack launch goes
+        bool overlap_this = overlap;
         // scratch set
         const int parity = list_in_touch ? v->batch_parity : 0;
         if (list_in_touch) v->batch_parity ^= 1;
@@ -1746,8 +2291,25 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         }
         int batch_stamp = v->frame_counter;
         v->last_touch_parity = parity;
+        const float *d_mult = nullptr;
+        if (use_mult) {
+            // (the pack role copies the multipliers into 12-byte records: when the table has to be rebuilt - first call, other
+            // intrinsics - it is rebuilt on the main stream and this batch's touch + pack launch follows it there)
+            const float *before = v->mult_table;
+            const int mw = v->mult_W, mh = v->mult_H;
+            float key_before[4];
+            memcpy(key_before, v->mult_key, sizeof(key_before));
+            rc = tsdf_multiplier_table(v, params[0]);
+            if (rc != HV_OK) return rc;
+            d_mult = v->mult_table;
+            if (before != v->mult_table || mw != v->mult_W || mh != v->mult_H || memcmp(key_before, v->mult_key, sizeof(key_before)) != 0) {
+                if (ps != v->stream) HV_HIP(hipStreamSynchronize(v->stream_aux)); // nothing of an older batch still reads the old table there
+                ps = v->stream;
+                overlap_this = false;
+            }
+        }
         // scratch: [B frame records of npx uint2][B HvFrameParams]
-        const size_t px_bytes = sizeof(uint2) * npx * (size_t)B;
+        const size_t px_bytes = rec_bytes * npx * (size_t)B;
         void **bb = parity ? &v->batch_buf2 : &v->batch_buf;
         size_t *bb_bytes = parity ? &v->batch_buf2_bytes : &v->batch_buf_bytes;
         rc = hv_ensure_buffer(v, bb, bb_bytes, px_bytes + sizeof(HvFrameParams) * (size_t)B + 256); // (re-allocation drains the main stream, and with it every batch whose touch pass it waited for)
@@ -1766,7 +2328,8 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
             hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3((n_prep_blocks + n_touch_blocks) * B), dim3(256), 0, ps,
                                v->table, v->touched_stamp, d_mask_rw, list_in_touch ? d_list : nullptr,
                                batch_stamp, (const char *)d_depth + npx * dsz * (size_t)f0, (int64_t)(npx * dsz),
-                               (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks, n_touch_blocks, B, parity);
+                               (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks, n_touch_blocks, B, parity,
+                               rec12 ? d_mult : nullptr);
             if (!checked) break;
             // checked mode: nothing is fused before every unit of the batch has its pool slot; if some claims did not fit, the
             // pool has grown (table rebuilt without them, stamps kept) and the touch pass runs again under a fresh stamp
@@ -1785,32 +2348,21 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
             hipLaunchKernelGGL(k_tsdf_batch_list, dim3((unsigned)((v->cfg.max_blocks + 255) / 256)), dim3(256), 0, v->stream, v->table,
                                (const int32_t *)v->touched_stamp, batch_stamp, d_list);
         }
-        if (overlap) {
+        if (overlap_this) {
             HV_HIP(hipEventRecord(v->ev_prep, v->stream_aux));
             HV_HIP(hipStreamWaitEvent(v->stream, v->ev_prep, 0));
         }
         HV_HIP(hipEventRecord(v->ev_presweep, v->stream)); // what the NEXT batch's touch + pack launch waits for
         chain_ok = true;                                   // (the next chunk of this call may follow this one directly)
         hv_profile_begin(v);
-        // sweep form: 2 = k_tsdf_sweep (production: float2 projection chain, prefetched frame constants), 1 = first form (A/B, and
-        // the only one that runs without the multiplier table).  The switches are read per call (a handful of getenv per
-        // batch): the parity tests flip them inside one process.
-        const int sweep_form = getenv("HV_TSDF_SWEEP") ? atoi(getenv("HV_TSDF_SWEEP")) : 2;
         const int sweep_zh = getenv("HV_TSDF_SWEEP_ZH") ? atoi(getenv("HV_TSDF_SWEEP_ZH")) : 4;
         // workgroups per unit (2 / 4 / 8).  Second form: 8 (two waves per workgroup; 32.7 k frames/s against 31.6 k at 4 and
         // 29.0 k at 2); the first form measured best at 4
-        const int split = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : (sweep_form == 2 ? 8 : 4);
+        const int split = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : (sweep_form >= 2 ? 8 : 4);
+        (void)split;
         // 1: run the EXACT evaluation with integer weights everywhere (A/B and parity checks of the rare-regime code)
         const int general = getenv("HV_TSDF_BATCH_GENERAL") ? atoi(getenv("HV_TSDF_BATCH_GENERAL")) : 0;
-        // per-pixel multiplier table (HV_TSDF_BATCH_MULT=0: compute the multiplier per voxel visit instead)
-        const int use_mult = getenv("HV_TSDF_BATCH_MULT") ? atoi(getenv("HV_TSDF_BATCH_MULT")) : 1;
         const unsigned long long *d_mask = d_mask_rw;
-        const float *d_mult = nullptr;
-        if (use_mult) {
-            rc = tsdf_multiplier_table(v, params[0]);
-            if (rc != HV_OK) return rc;
-            d_mult = v->mult_table;
-        }
         // workgroups in the grid: one work item (unit x SPLIT part) each up to 16 384 units per batch, grid-stride beyond;
         // measured 28.2 k frames/s at 8192 (3.3 items per workgroup: coarser tail), 29.0 k at 16 384, 29.6 k at 65 536
         const int sweep_grid = getenv("HV_TSDF_BATCH_GRID") ? atoi(getenv("HV_TSDF_BATCH_GRID")) : 65536;
@@ -1820,7 +2372,64 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
 #define HV_LAUNCH_SWEEP(ZH, S, WPE)                                                                                    \
     hipLaunchKernelGGL((k_tsdf_sweep<ZH, S, WPE>), dim3(sweep_grid), dim3(64 * (64 / ZH) / S), 0, v->stream, v->table,   \
                        d_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware, parity)
-        if (d_mult && sweep_form == 2) {
+#define HV_LAUNCH_FOLD(ZH, S, WPE, ANY)                                                                                \
+    hipLaunchKernelGGL((k_tsdf_sweep_fold<ZH, S, WPE, ANY>), dim3(sweep_grid), dim3(64 * (64 / ZH) / S), 0, v->stream,   \
+                       v->table, d_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware, parity)
+#define HV_LAUNCH_COLUMN(S, WPE, GV, PIPE, ANY)                                                                         \
+    hipLaunchKernelGGL((k_tsdf_sweep_column<S, WPE, GV, PIPE, ANY>), dim3(sweep_grid), dim3(64 * 4 / S), 0, v->stream,   \
+                       v->table, d_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware, parity)
+        if (d_mult && sweep_form == 4) {
+            // column form: HV_TSDF_SWEEP_WPE (waves / SIMD the registers are capped for), _GV (voxels per gather group), _PIPE
+            // (next group's gathers before this group's fold), _ANYSKIP, HV_TSDF_BATCH_SPLIT (workgroups per unit: 1 / 2 / 4)
+            const int wpe = getenv("HV_TSDF_SWEEP_WPE") ? atoi(getenv("HV_TSDF_SWEEP_WPE")) : 4;
+            const int xcd_aware = getenv("HV_TSDF_SWEEP_XCD") ? atoi(getenv("HV_TSDF_SWEEP_XCD")) : 2;
+            const int anyskip = getenv("HV_TSDF_SWEEP_ANYSKIP") ? atoi(getenv("HV_TSDF_SWEEP_ANYSKIP")) : 1;
+            const int gv = getenv("HV_TSDF_SWEEP_GV") ? atoi(getenv("HV_TSDF_SWEEP_GV")) : 4;
+            const int pipe = getenv("HV_TSDF_SWEEP_PIPE") ? atoi(getenv("HV_TSDF_SWEEP_PIPE")) : 1;
+            const int csplit = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : 4;
+            if (csplit == 1) {
+                if (wpe >= 5) HV_LAUNCH_COLUMN(1, 5, 2, true, true); else HV_LAUNCH_COLUMN(1, 4, 2, true, true);
+            } else if (csplit == 2) {
+                if (wpe >= 5) HV_LAUNCH_COLUMN(2, 5, 2, true, true); else HV_LAUNCH_COLUMN(2, 4, 2, true, true);
+            } else if (!anyskip) {
+                if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 2, true, false); else HV_LAUNCH_COLUMN(4, 4, 2, true, false);
+            } else if (gv == 4) {
+                if (pipe) { if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 4, true, true); else if (wpe == 3) HV_LAUNCH_COLUMN(4, 3, 4, true, true); else HV_LAUNCH_COLUMN(4, 4, 4, true, true); }
+                else { if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 4, false, true); else HV_LAUNCH_COLUMN(4, 4, 4, false, true); }
+            } else if (gv == 1) {
+                if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 1, true, true); else HV_LAUNCH_COLUMN(4, 4, 1, true, true);
+            } else {
+                if (pipe) { if (wpe >= 6) HV_LAUNCH_COLUMN(4, 6, 2, true, true); else if (wpe == 5) HV_LAUNCH_COLUMN(4, 5, 2, true, true); else if (wpe == 3) HV_LAUNCH_COLUMN(4, 3, 2, true, true); else HV_LAUNCH_COLUMN(4, 4, 2, true, true); }
+                else { if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 2, false, true); else HV_LAUNCH_COLUMN(4, 4, 2, false, true); }
+            }
+        } else if (d_mult && sweep_form == 3) {
+            // fold form (production); HV_TSDF_SWEEP_WPE / _ZH / _ANYSKIP / _REC12 / HV_TSDF_BATCH_SPLIT select the measured alternatives
+            const int wpe = getenv("HV_TSDF_SWEEP_WPE") ? atoi(getenv("HV_TSDF_SWEEP_WPE")) : 4;
+            const int xcd_aware = getenv("HV_TSDF_SWEEP_XCD") ? atoi(getenv("HV_TSDF_SWEEP_XCD")) : 2;
+            const int anyskip = getenv("HV_TSDF_SWEEP_ANYSKIP") ? atoi(getenv("HV_TSDF_SWEEP_ANYSKIP")) : 0;
+            if (!rec12) {
+                hipLaunchKernelGGL((k_tsdf_sweep_fold<4, 8, 4, false, 0, false>), dim3(sweep_grid), dim3(64 * 16 / 8), 0, v->stream, v->table,
+                                   d_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware, parity);
+            } else if (sweep_zh == 8) {
+                if (split == 4) HV_LAUNCH_FOLD(8, 4, 4, false); else if (wpe <= 2) HV_LAUNCH_FOLD(8, 8, 2, false); else HV_LAUNCH_FOLD(8, 8, 4, false);
+            } else if (split == 4) {
+                if (wpe >= 8) HV_LAUNCH_FOLD(4, 4, 8, false); else HV_LAUNCH_FOLD(4, 4, 4, false);
+            } else if (split == 16) {
+                if (wpe >= 8) HV_LAUNCH_FOLD(4, 16, 8, false); else HV_LAUNCH_FOLD(4, 16, 6, false);
+            } else if (anyskip) {
+                if (wpe >= 8) HV_LAUNCH_FOLD(4, 8, 8, true); else HV_LAUNCH_FOLD(4, 8, 6, true);
+            } else if (getenv("HV_TSDF_SWEEP_DBG") && atoi(getenv("HV_TSDF_SWEEP_DBG")) > 0) {
+                const int dbg = atoi(getenv("HV_TSDF_SWEEP_DBG"));
+#define HV_LAUNCH_FOLD_DBG(D)                                                                                          \
+    hipLaunchKernelGGL((k_tsdf_sweep_fold<4, 8, 4, false, D>), dim3(sweep_grid), dim3(64 * 16 / 8), 0, v->stream, v->table, \
+                       d_list, d_mask, (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware, parity)
+                if (dbg == 1) HV_LAUNCH_FOLD_DBG(1); else if (dbg == 2) HV_LAUNCH_FOLD_DBG(2); else HV_LAUNCH_FOLD_DBG(3);
+#undef HV_LAUNCH_FOLD_DBG
+            } else {
+                if (wpe >= 8) HV_LAUNCH_FOLD(4, 8, 8, false); else if (wpe == 6 || wpe == 7) HV_LAUNCH_FOLD(4, 8, 6, false);
+                else if (wpe == 5) HV_LAUNCH_FOLD(4, 8, 5, false); else HV_LAUNCH_FOLD(4, 8, 4, false);
+            }
+        } else if (d_mult && sweep_form == 2) {
             const int wpe = getenv("HV_TSDF_SWEEP_WPE") ? atoi(getenv("HV_TSDF_SWEEP_WPE")) : 4; // 4 waves / SIMD = 128 VGPRs: nothing spills
             const int xcd_aware = getenv("HV_TSDF_SWEEP_XCD") ? atoi(getenv("HV_TSDF_SWEEP_XCD")) : 2; // list entries per XCD group (0: list order)
             if (sweep_zh == 8) {
@@ -1839,6 +2448,8 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         }
 #undef HV_LAUNCH_COL
 #undef HV_LAUNCH_SWEEP
+#undef HV_LAUNCH_FOLD
+#undef HV_LAUNCH_COLUMN
         hv_profile_end(v, B);
         hipLaunchKernelGGL(k_tsdf_batch_finish, dim3(1), dim3(1024), 0, v->stream, v->table, d_list, d_mask_rw, parity, v->d_status,
                            hv_next_status_seq(v));

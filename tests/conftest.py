@@ -39,6 +39,44 @@ def ref_available():
     return oracle.ref_available()
 
 
+FOLD_TSDF_TOL = 5e-6  # fold form of the sweep vs the oracle's per-frame float chain (contract: 1e-4; measured <= 1e-6)
+
+
+def sweep_is_bitwise():
+    """HV_TSDF_SWEEP=1|2 select the forms of the multi-frame sweep that replay the reference's running mean frame by
+    frame (tsdf bit-identical to the oracle); the production forms (4: whole voxel columns, the default; 3: four voxels
+    per lane) fold a batch per voxel (tsdf within FOLD_TSDF_TOL)."""
+    return os.environ.get("HV_TSDF_SWEEP", "4") in ("1", "2")
+
+
+def assert_tsdf_parity(ta, tb, swept=True):
+    """tsdf planes of the HIP volume vs the oracle: bitwise for the online path and the bitwise sweep forms, within
+    FOLD_TSDF_TOL when the volume went through the fold form of the sweep."""
+    if not swept or sweep_is_bitwise():
+        np.testing.assert_array_equal(ta.view(np.uint32), tb.view(np.uint32))
+        return 0.0
+    worst = 0.0
+    for lo in range(0, len(ta), 512):
+        worst = max(worst, float(np.abs(ta[lo:lo + 512] - tb[lo:lo + 512]).max()))
+    assert worst <= FOLD_TSDF_TOL, worst
+    return worst
+
+
+def assert_dumps_match(da, db, swept=True):
+    """(keys, tsdf, weight, colour) of two volumes: keys, weights and colours identical, tsdf per assert_tsdf_parity."""
+    np.testing.assert_array_equal(da[0], db[0])
+    np.testing.assert_array_equal(da[2], db[2])
+    np.testing.assert_array_equal(da[3], db[3])
+    assert_tsdf_parity(da[1], db[1], swept)
+
+
+@pytest.fixture(params=["fold", "bitwise"])
+def sweep_form(request, monkeypatch):
+    """Runs a test once per production form of the multi-frame sweep (the switch is read per call)."""
+    monkeypatch.setenv("HV_TSDF_SWEEP", "4" if request.param == "fold" else "2")
+    return request.param
+
+
 def sort_rows(*arrays):
     """Sort rows of the first array lexicographically and apply the same permutation to the rest."""
     a = arrays[0]

@@ -3,9 +3,11 @@
 bench.py's step = ``ScalableTSDFVolume.integrate_batch`` with B = 32 posed frames of
 ``synthetic_640x480_5mm`` at voxel 0.005 m / sdf_trunc 0.04 m / depth_trunc 4 m, batches taken as a sliding
 window over the stream (step k fuses frames 32k .. 32k+31 into the same volume).  These tests run that call
-with those arguments against ``oracle.PortTsdf`` and compare the FULL dump: unit keys and weights exact, tsdf
-bitwise, colour <= 1e-4 (north-star tolerance; reference call sites
-pyslam/dense/volumetric_integrator_tsdf.py:215-223,260).  Mesh and point-cloud extraction are compared at the
+with those arguments against ``oracle.PortTsdf`` and compare the FULL dump: unit keys and weights exact, colour
+<= 1e-4 (north-star tolerance; reference call sites pyslam/dense/volumetric_integrator_tsdf.py:215-223,260), tsdf
+within ``FOLD_TSDF_TOL`` = 5e-6 for the production (fold) form of the sweep - which applies one running-mean step per
+voxel and batch instead of one per frame - and bitwise for the forms that replay the reference's chain frame by
+frame (``HV_TSDF_SWEEP=2`` / ``1``).  Mesh and point-cloud extraction are compared at the
 same configuration and at BASELINE configs[2] (Replica-shaped 1200x680 @ 4 mm).
 """
 import os
@@ -14,7 +16,8 @@ import numpy as np
 import pytest
 
 import oracle
-from tests.conftest import canonical_mesh, sort_rows, synthetic_frames
+from tests.conftest import (FOLD_TSDF_TOL, assert_dumps_match, assert_tsdf_parity, canonical_mesh, sort_rows, sweep_is_bitwise,
+                            synthetic_frames)
 
 pytestmark = pytest.mark.gpu
 
@@ -29,7 +32,7 @@ def assert_same_volume_chunked(gpu, cpu):
     kb, tb, wb, cb = cpu.dump()
     np.testing.assert_array_equal(ka, kb)  # unit indices bit-exact
     np.testing.assert_array_equal(wa, wb)  # weights exact
-    np.testing.assert_array_equal(ta.view(np.uint32), tb.view(np.uint32))  # tsdf bit-identical
+    assert_tsdf_parity(ta, tb)  # bitwise (forms 1, 2) / <= FOLD_TSDF_TOL (fold form)
     worst = 0.0
     for lo in range(0, len(ka), 512):
         worst = max(worst, float(np.abs(ca[lo:lo + 512] - cb[lo:lo + 512]).max()))
@@ -41,7 +44,7 @@ def batch_arrays(frames):
     return np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), np.stack([f[2] for f in frames])
 
 
-def test_bench_step_b32_sliding_window_matches_oracle():
+def test_bench_step_b32_sliding_window_matches_oracle(sweep_form):
     """Two consecutive bench steps (frames 0..31, then 32..63) through integrate_batch, device-resident inputs as in
     bench.py, against the oracle fusing the same 64 frames one by one."""
     import torch
@@ -63,9 +66,9 @@ def test_bench_step_b32_sliding_window_matches_oracle():
     assert gpu.dropped_points() == 0
 
 
-def test_bench_step_replay_equals_online():
+def test_bench_step_replay_equals_online(sweep_form):
     """The replay form of the step (the same 32 frames fused twice, bench.py --window replay) equals 64 online
-    integrate() calls, bitwise in every plane."""
+    integrate() calls: keys, weights and colour sums identical, tsdf bitwise (form 2) / within FOLD_TSDF_TOL (fold)."""
     from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
 
     s, frames = synthetic_frames("synthetic_640x480_5mm", 100, B)
@@ -77,8 +80,7 @@ def test_bench_step_replay_equals_online():
         a.integrate_batch(depth, rgb, K, T, depth_scale=1.0, depth_trunc=DEPTH_TRUNC)
         for d, c, Tcw in frames:
             b.integrate(RGBDImage.create_from_color_and_depth(c, d, 1.0, DEPTH_TRUNC, False), K, Tcw)
-    for x, y in zip(a.dump(), b.dump()):
-        np.testing.assert_array_equal(x, y)
+    assert_dumps_match(a.dump(), b.dump())
 
 
 def compare_extraction(gpu, cpu, min_triangles):
@@ -100,10 +102,13 @@ def compare_extraction(gpu, cpu, min_triangles):
     np.testing.assert_allclose(qa, qb, rtol=0, atol=TOL)
 
 
-def test_extraction_matches_oracle_at_headline_config():
-    """Marching cubes + point cloud of a 640x480 / 5 mm volume (8 frames through the sweep) vs the oracle:
-    identical vertex sets (<= 1e-9), colours <= 1e-4, identical triangles after canonical re-indexing."""
+def test_extraction_matches_oracle_at_headline_config(monkeypatch):
+    """Marching cubes + point cloud of a 640x480 / 5 mm volume (8 frames through the bitwise form of the sweep, so that
+    both sides extract from identical tsdf values) vs the oracle: identical vertex sets (<= 1e-9), colours <= 1e-4,
+    identical triangles after canonical re-indexing."""
     from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    monkeypatch.setenv("HV_TSDF_SWEEP", "2")
 
     s, frames = synthetic_frames("synthetic_640x480_5mm", 0, 8)
     K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
@@ -116,9 +121,40 @@ def test_extraction_matches_oracle_at_headline_config():
     compare_extraction(gpu, cpu, min_triangles=1_000_000)
 
 
-def test_extraction_matches_oracle_replica_4mm():
-    """BASELINE configs[2]: Replica-shaped 1200x680, 4 mm TSDF + colour: fuse (sweep), extract, compare."""
+def test_extraction_of_fold_form_volume_within_tolerance(monkeypatch):
+    """The production (fold) form leaves tsdf within FOLD_TSDF_TOL of the oracle, so the extracted surface cannot be
+    compared vertex for vertex: a zero crossing on an edge whose two values differ by 1e-3 moves by ~1e-5 m, and a value
+    within 1e-6 of zero may change sign.  Held instead: vertex / triangle / point counts within 0.1 % of the oracle's,
+    and 99.9 % of the vertices (points) within 1e-5 m of an oracle vertex (point), all within 1e-3 m (a fifth of a voxel)."""
+    from scipy.spatial import cKDTree
+
     from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    monkeypatch.setenv("HV_TSDF_SWEEP", "4")
+    s, frames = synthetic_frames("synthetic_640x480_5mm", 0, 8)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    gpu = ScalableTSDFVolume(VOXEL, SDF_TRUNC, max_blocks=1 << 15)
+    cpu = oracle.PortTsdf(VOXEL, SDF_TRUNC, threads=THREADS)
+    depth, rgb, T = batch_arrays(frames)
+    gpu.integrate_batch(depth, rgb, K, T, depth_scale=1.0, depth_trunc=DEPTH_TRUNC)
+    for d, c, Tcw in frames:
+        cpu.integrate(d, c, K.as_array(), Tcw, 1.0, DEPTH_TRUNC)
+    m = gpu.extract_triangle_mesh()
+    vb, tb, _ = cpu.extract_triangle_mesh()
+    pc = gpu.extract_point_cloud()
+    pb, _ = cpu.extract_point_cloud()
+    for mine, theirs in ((m.vertices, vb), (pc.points, pb)):
+        assert abs(len(mine) - len(theirs)) <= 1e-3 * len(theirs)
+        dist, _ = cKDTree(theirs).query(mine, k=1)
+        assert float((dist <= 1e-5).mean()) >= 0.999 and float(dist.max()) <= 1e-3, (float((dist <= 1e-5).mean()), float(dist.max()))
+    assert abs(len(m.triangles) - len(tb)) <= 1e-3 * len(tb)
+
+
+def test_extraction_matches_oracle_replica_4mm(monkeypatch):
+    """BASELINE configs[2]: Replica-shaped 1200x680, 4 mm TSDF + colour: fuse (bitwise form of the sweep), extract, compare."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    monkeypatch.setenv("HV_TSDF_SWEEP", "2")
 
     s, frames = synthetic_frames("replica_1200x680_4mm", 0, 4)
     K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
@@ -144,6 +180,27 @@ def sweep_case():
 
 
 SWEEP_FORMS = [
+    {"HV_TSDF_SWEEP": "3"},                              # production: batch folded per voxel (tsdf <= FOLD_TSDF_TOL, the rest exact)
+    {"HV_TSDF_SWEEP": "3", "HV_TSDF_PIPELINE": "0"},
+    {"HV_TSDF_SWEEP": "3", "HV_TSDF_SWEEP_XCD": "0"},
+    {"HV_TSDF_SWEEP": "3", "HV_TSDF_SWEEP_WPE": "8"},    # 64 VGPRs
+    {"HV_TSDF_SWEEP": "3", "HV_TSDF_SWEEP_WPE": "4"},
+    {"HV_TSDF_SWEEP": "3", "HV_TSDF_SWEEP_ANYSKIP": "1"},  # fold skipped for voxels no lane of the wave updates
+    {"HV_TSDF_SWEEP": "3", "HV_TSDF_BATCH_SPLIT": "4"},
+    {"HV_TSDF_SWEEP": "3", "HV_TSDF_BATCH_SPLIT": "16"},
+    {"HV_TSDF_SWEEP": "3", "HV_TSDF_SWEEP_ZH": "8"},
+    {"HV_TSDF_SWEEP": "3", "HV_TSDF_BATCH_GENERAL": "1"},  # the fold kernel's rare-regime path everywhere: bitwise again
+    {"HV_TSDF_SWEEP": "3", "HV_TSDF_SWEEP_REC12": "0"},    # 8-byte records + multiplier table (two gathers per visit)
+    {"HV_TSDF_SWEEP": "4"},                                # fold on whole voxel columns (16 z per lane), pipelined gather groups
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_WPE": "5"},
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_WPE": "3"},
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_GV": "2"},
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_GV": "1"},
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_PIPE": "0"},
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_ANYSKIP": "0"},
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_BATCH_SPLIT": "2"},
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_BATCH_SPLIT": "1"},
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_BATCH_GENERAL": "1"},
     {"HV_TSDF_SWEEP": "2"},                              # production: float2 chain, prefetched frame constants, packed colour
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_PIPELINE": "0"},     # every launch of a batch on the one stream (no touch / sweep overlap between batches)
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_XCD": "0"},    # work items in list order instead of one contiguous list eighth per XCD
@@ -158,7 +215,8 @@ SWEEP_FORMS = [
 @pytest.mark.parametrize("env", SWEEP_FORMS, ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
 def test_sweep_forms_match_oracle(env, sweep_case, monkeypatch):
     """Every form of the multi-frame sweep (the switches are read per call) against the oracle at the bench
-    configuration, two batches of 8 frames: keys and weights exact, tsdf bitwise, colour <= 1e-4."""
+    configuration, two batches of 8 frames: keys and weights exact, colour <= 1e-4, tsdf bitwise for the forms that apply
+    the running mean frame by frame (1, 2, and the fold kernel's rare-regime path) and <= FOLD_TSDF_TOL for the fold."""
     from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
 
     for k, v in env.items():
@@ -172,11 +230,15 @@ def test_sweep_forms_match_oracle(env, sweep_case, monkeypatch):
     ka, ta, wa, ca = gpu.dump()
     np.testing.assert_array_equal(ka, kb)
     np.testing.assert_array_equal(wa, wb)
-    np.testing.assert_array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    if env.get("HV_TSDF_BATCH_GENERAL") == "1":
+        np.testing.assert_array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    else:
+        worst = assert_tsdf_parity(ta, tb)
+        print(f"[sweep form {env}] max |tsdf - oracle| = {worst:.3e}")
     assert max(float(np.abs(ca[lo:lo + 512] - cb[lo:lo + 512]).max()) for lo in range(0, len(ka), 512)) / 255.0 <= TOL
 
 
-def test_batch_pipeline_with_interleaved_calls_matches_oracle():
+def test_batch_pipeline_with_interleaved_calls_matches_oracle(sweep_form):
     """The batch pipeline (touch + pack of batch k+1 on a second stream while batch k is swept, two scratch sets) under the
     call patterns that start, break and restart a chain: device-resident batches back to back, an online frame in between,
     an extraction in between, a host-resident batch, a long call that is cut into 64-frame chunks, a reset.  Full dump
@@ -229,7 +291,7 @@ def test_batch_pipeline_with_interleaved_calls_matches_oracle():
     kb, tb, wb, cb = cpu.dump()
     np.testing.assert_array_equal(ka, kb)
     np.testing.assert_array_equal(wa, wb)
-    np.testing.assert_array_equal(ta.view(np.uint32), tb.view(np.uint32))
+    assert_tsdf_parity(ta, tb)
     assert float(np.abs(ca - cb).max()) / 255.0 <= TOL
     os.environ["HV_TSDF_PIPELINE"] = "0"
     try:

@@ -69,7 +69,7 @@ def test_two_ranks_equal_single_gpu(tmp_path, sharding):
     local = int(np.load(tmp_path / "local_units.npy")[0])
     if sharding == "owner":  # a rank stores only its share of the units (hash-balanced), and nothing is double counted
         assert 0.3 * len(k) < local < 0.7 * len(k)
-        assert np.abs(z["tsdf"] - tsdf).max() <= 1e-6  # disjoint units: only the export/import round trip rounds
+        assert np.abs(z["tsdf"] - tsdf).max() <= 5e-6  # disjoint units: the sweep's batch fold and the export/import round trip round
     else:  # a rank allocates only the units that can project into its image tile
         assert 0.3 * len(k) < local < len(k)
 
