@@ -19,19 +19,25 @@ fused and stored by GPU hash(unit index) % N (SURVEY §8e "zero reduce" form: bi
 collective while fusing); --sharding tile: north-star image tiles + RCCL merge of the shared units (timed).
 
 Objects on the JSON line (N = 1):
-  roofline      the dominant kernel of the timed region, the multi-frame sweep k_tsdf_sweep.  It keeps a
-                unit's voxels in registers across the batch's frames, so it is bound by VALU issue, not by HBM:
-                ``bound: "valu"``, achieved = VALU wave-instructions per launch (SQ_INSTS_VALU from the rocprofv3 --pmc
-                pass recorded under profiles/, parsed at run time and only used when it was taken on THIS build and
-                command) / the mean launch duration measured live with HIP events on the kernel's stream; peak = 1024
-                SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.  ``roofline.hbm`` is the HBM figure of the same
-                launches from BATCH-level algorithmic bytes (oracle: distinct units touched by the batch x 81 920 B
-                read + distinct voxels updated x 20 B written), with the PMC traffic beside it.
+  roofline      the dominant kernel of the timed region, the multi-frame sweep k_tsdf_sweep_column, against the bound
+                SURVEY 8d names for the path: HBM.  achieved = BATCH-level algorithmic bytes (oracle: distinct units
+                touched by the batch x 81 920 B read + distinct voxels updated x 20 B written - the sweep reads and
+                writes a unit's slab once per launch whatever the number of frames) / the mean launch duration measured
+                live with HIP events on the kernel's stream; peak = 8 TB/s; traffic = HBM bytes per launch from the
+                rocprofv3 --pmc passes recorded under profiles/ (parsed at run time, only used when taken on THIS build
+                and command).  ``roofline.flops``: SURVEY 8d's 40 flop per voxel visit x the oracle's visit count / the
+                same duration against the 157.3 TFLOP/s vector-f32 peak.  ``roofline.valu_utilisation`` is NOT a
+                roofline: the kernel's own SQ_INSTS_VALU / duration against the wave64 issue rate (both the 4-cycle
+                rate tools/valu_rates.hip measures for FMA-class instructions and the guide's 2-cycle figure).
   online_mode   one hv_tsdf_integrate per frame (pySLAM's live flow) on the same sliding stream: frames/s and that
                 kernel's roofline — the HBM-bound one: per-frame algorithmic bytes (U_touched*4096*20 B +
                 N_updated*20 B, oracle counts of exactly the frames timed) / mean launch duration vs 8 TB/s.
   extraction    extract_triangle_mesh + extract_point_cloud of the volume the timed region built (BASELINE configs[2]
                 shape of work), wall ms and kernel ms, B_mc roofline.
+  host_mode     the path the drop-in really drives (tools/bench_host.py): the same stream handed over as pageable per-keyframe
+                numpy arrays - PCIe INSIDE the timed region (never `value`) - through integrate_frames (page-locked staging slots
+                + copy stream, overlapped with the previous batch's sweep), next to the H2D-bound rate measured in the same
+                process, one integrate() per host frame, and the whole front (add_keyframe -> worker process -> pop_output) once.
   voxel_grid    the cpp/volumetric VOXEL_GRID mode on the same frames: per-frame and batched frames/s, B_vox
                 roofline, and the COMPILED REFERENCE (oracle/_ref, kind "reference") timed beside it.
   semantic      pySLAM's per-keyframe semantic flow (shadow filter, assign_object_ids_to_instance_ids, remap, integrate) for
@@ -57,7 +63,11 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GINSTR = 1024 * 2.4 / 4.0  # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction = 614.4 G wave-instr/s
 BYTES_PER_VOXEL = 20     # {f32 tsdf, u32 weight, 3 x u32 colour sums}
 UNIT_BYTES = 4096 * BYTES_PER_VOXEL
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
+VALU_PEAK_GINSTR_2CYC = 1024 * 2.4 / 2.0  # MI355X_MICROARCH.md lists wave64 v_fma_f32 at 2 cycles: 1228.8 G wave-instr/s
+VECTOR_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector (non-MFMA) fp32
+FLOP_PER_VISIT = 40  # "TSDF ~ 40 flop / voxel visited"
+PROFILE_ROUND = "r03"
+PMC_SUMMARY = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_summary.json")
 
 
 def load_frames(config, n_frames, start=0, rank=0, barrier=None):
@@ -84,7 +94,7 @@ def load_frames(config, n_frames, start=0, rank=0, barrier=None):
 
 
 def pmc_summary(build_digest):
-    """profiles/r02/pmc_summary.json (written by tools/pmc_summary.py --json from the rocprofv3 --pmc passes of
+    """profiles/<round>/pmc_summary.json (written by tools/pmc_summary.py --json from the rocprofv3 --pmc passes of
     tools/profile_round.sh).  Only trusted when it was recorded on the library build that is running now."""
     try:
         with open(PMC_SUMMARY) as f:
@@ -232,7 +242,7 @@ def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_fr
                                    "records scattered over the frame's ~13 000 blocks (see traffic)"}
         # HBM bytes of the four per-frame kernels from the recorded --pmc passes of tools/bench_voxel_grid.py on this build
         try:
-            with open(os.path.join(ROOT, "profiles", "r02", "pmc_voxel_grid.json")) as f:
+            with open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_voxel_grid.json")) as f:
                 vp = json.load(f)
             if vp.get("build_digest") == current_build_digest():
                 per = {}
@@ -483,22 +493,35 @@ def main():
             if traffic:
                 hbm["traffic_GBs"] = round(traffic / avg_s / 1e9, 1)
                 hbm["traffic_over_algorithmic"] = round(traffic / (alg / n_cov), 3)
-            roofline = {"bound": "valu", "kernel": "k_tsdf_sweep", "achieved": None, "peak": VALU_PEAK_GINSTR,
-                        "unit": "G wave-instr/s", "frac": None, "traffic": traffic,
+            roofline = {"bound": "hbm", "kernel": "k_tsdf_sweep_column (multi-frame sweep: a batch folded per voxel, one lane per voxel column)",
+                        "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"], "traffic": traffic,
+                        "algorithmic_bytes_per_launch": hbm["algorithmic_bytes_per_launch"], "what": hbm["what"],
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(n_cov), "frames_per_launch": B,
-                        "voxel_visits_per_launch": int(visits / n_cov), "hbm": hbm}
+                        "voxel_visits_per_launch": int(visits / n_cov)}
+            if traffic:
+                roofline["traffic_GBs"] = hbm["traffic_GBs"]
+                roofline["traffic_over_algorithmic"] = hbm["traffic_over_algorithmic"]
+            tf = FLOP_PER_VISIT * visits / t_cov / 1e12
+            roofline["flops"] = {"achieved": round(tf, 2), "peak": VECTOR_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / VECTOR_F32_PEAK_TFLOPS, 4),
+                                 "what": f"{FLOP_PER_VISIT} flop per voxel visit (SURVEY 8d) x the oracle's visits (touched units x 4096, per frame) vs the vector fp32 peak"}
+            util = {"what": "the kernel's OWN VALU instruction count per second against the wave64 issue rate: how busy the vector "
+                            "issue slots are, not a fraction of an algorithmic roofline (wasted instructions raise it)",
+                    "achieved": None, "unit": "G wave-instr/s", "peak_4cyc": VALU_PEAK_GINSTR, "peak_2cyc": VALU_PEAK_GINSTR_2CYC}
             if pk and "SQ_INSTS_VALU" in pk:
                 ach = pk["SQ_INSTS_VALU"] / avg_s / 1e9
-                roofline.update({"achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GINSTR, 4),
-                                 "valu_instr_per_launch": int(pk["SQ_INSTS_VALU"]),
-                                 "valu_instr_per_voxel_visit": round(pk["SQ_INSTS_VALU"] * 64 / (visits / n_cov), 2),
-                                 "counter_source": os.path.relpath(PMC_SUMMARY, ROOT) + " (rocprofv3 --pmc SQ pass of this command on this build; "
-                                                   "duration measured live with HIP events)"})
+                util.update({"achieved": round(ach, 1), "frac_of_4cyc_rate": round(ach / VALU_PEAK_GINSTR, 4), "frac_of_2cyc_rate": round(ach / VALU_PEAK_GINSTR_2CYC, 4),
+                             "valu_instr_per_launch": int(pk["SQ_INSTS_VALU"]),
+                             "valu_instr_per_voxel_visit": round(pk["SQ_INSTS_VALU"] * 64 / (visits / n_cov), 2),
+                             "counter_source": os.path.relpath(PMC_SUMMARY, ROOT) + " (rocprofv3 --pmc SQ pass of this command on this build; "
+                                               "duration measured live with HIP events)",
+                             "peaks": "4-cycle: the sustained rate tools/valu_rates.hip measures for FMA-class / v_pk_* / cvt / cmp instructions "
+                                      "(profiles/r02/valu_issue_rates.txt: 4.1-4.7 cycles; add / mul / mov 2.5); 2-cycle: MI355X_MICROARCH.md's v_fma_f32 row"})
                 if "SQ_ACTIVE_INST_VALU" in pk and "GRBM_GUI_ACTIVE" in pk:
-                    roofline["valu_busy_in_pmc_pass"] = round(pk["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * pk["GRBM_GUI_ACTIVE"] / 8), 4)
+                    util["valu_busy_in_pmc_pass"] = round(pk["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * pk["GRBM_GUI_ACTIVE"] / 8), 4)
             else:
-                roofline["note"] = ("VALU instruction count unavailable: " +
-                                    ("profiles/r02/pmc_summary.json was recorded on another build or command" if pmc else "no profiles/r02/pmc_summary.json"))
+                util["note"] = ("VALU instruction count unavailable: " +
+                                (f"profiles/{PROFILE_ROUND}/pmc_summary.json was recorded on another build or command" if pmc else f"no profiles/{PROFILE_ROUND}/pmc_summary.json"))
+            roofline["valu_utilisation"] = util
 
         out = {
             "metric": "RGB-D frames/sec fused (640x480, 5 mm voxel TSDF)",
@@ -558,7 +581,9 @@ def main():
             out["secondary_error"] = secondary_error
         if secondary and not args.no_cpu_baseline:
             del vol, fuser
-            for key, leg in (("voxel_grid", lambda: voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, min(B, n_distinct), 5, 6)),
+            for key, leg in (("host_mode", lambda: __import__("tools.bench_host", fromlist=["host_leg"]).host_leg(
+                                 s, depth_h, rgb_h, T_h, VOXEL, SDF_TRUNC, DEPTH_TRUNC, B=B, steps=min(6, n_distinct // B))),
+                             ("voxel_grid", lambda: voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, min(B, n_distinct), 5, 6)),
                              ("semantic", lambda: __import__("tools.bench_semantic", fromlist=["semantic_leg"]).semantic_leg(10, 2, 0.01))):
                 try:
                     out[key] = leg()

@@ -262,6 +262,15 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
                             int32_t n_frames, int32_t height, int32_t width, const double *intr,
                             const double *T_cw, double depth_scale, double depth_trunc, int32_t loc);
 
+/* The same for HOST-resident frames given one pointer per frame - what pySLAM's worker holds after draining its queue of
+ * INTEGRATE tasks (volumetric_integrator_base.py:101-137: every keyframe carries its own pageable numpy arrays).  The frames
+ * are copied to page-locked slots by worker threads and cross PCIe on a copy stream while the previous batch is swept; the
+ * caller's memory has been read completely when the call returns.  depth_frames[f]: H*W of depth_dtype, rgb_frames[f]:
+ * H*W*3 uint8, T_cw: F*16. */
+int hv_tsdf_integrate_frames(hv_volume *v, const void *const *depth_frames, int32_t depth_dtype, const uint8_t *const *rgb_frames,
+                             int32_t n_frames, int32_t height, int32_t width, const double *intr, const double *T_cw,
+                             double depth_scale, double depth_trunc);
+
 /* Multi-GPU image-tile sharding (north-star form): this volume fuses only voxels whose
  * projection lands in pixel tile [u0,u1) x [v0,v1); units that cannot project into the tile are
  * allocated (so all GPUs agree on the unit set) but not swept.  All zeros = whole image (default). */

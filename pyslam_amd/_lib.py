@@ -93,6 +93,7 @@ SIGNATURES = {
     "hv_remove_low_confidence_voxels": (_i32, [_vp, _f32]),
     "hv_tsdf_integrate": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_tsdf_integrate_batch": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
+    "hv_tsdf_integrate_frames": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64]),
     "hv_tsdf_set_tile": (_i32, [_vp, _i32, _i32, _i32, _i32]),
     "hv_tsdf_set_owner": (_i32, [_vp, _i32, _i32]),
     "hv_tsdf_extract_mesh": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _pi64, _pi64]),

@@ -304,6 +304,19 @@ struct hv_volume {
     void *stage_a = nullptr;
     void *stage_b = nullptr;
     size_t stage_a_bytes = 0, stage_b_bytes = 0;
+    // pipelined staging of host-resident FRAMES (hv_stage_frames): caller memory -> one of two page-locked slots (worker
+    // threads) -> DMA on a copy stream into one of two device sets, so that the next sub-chunk is copied by the CPU while
+    // the previous one crosses PCIe, and batch k+1 crosses PCIe while batch k is swept
+    void *hs_pinned[2] = {nullptr, nullptr};
+    size_t hs_pinned_bytes[2] = {0, 0};
+    hipEvent_t hs_pinned_done[2] = {nullptr, nullptr}; // the DMA that last read the slot has completed
+    void *hs_dev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // [set][depth | colour]
+    size_t hs_dev_bytes[2][2] = {{0, 0}, {0, 0}};
+    hipEvent_t hs_dev_ready[2] = {nullptr, nullptr};   // the set's frames have arrived (copy stream -> consumer stream)
+    hipEvent_t hs_dev_free[2] = {nullptr, nullptr};    // the kernels that read the set are done (consumer -> copy stream)
+    bool hs_dev_free_valid[2] = {false, false};
+    hipStream_t hs_stream = nullptr;
+    int hs_set = 0, hs_slot = 0;
 
     // VOXEL_GRID scratch
     uint32_t *sort_keys_in = nullptr, *sort_keys_out = nullptr;
@@ -354,6 +367,14 @@ int32_t hv_next_status_seq(hv_volume *v); // sequence number for the call's publ
 void hv_launch_publish_status(hv_volume *v); // modes whose last kernel does not publish by itself
 int hv_read_counters(hv_volume *v); // D2H of the counter block (synchronises the stream)
 int hv_stage_in(hv_volume *v, const void *src, size_t bytes, int32_t loc, int which, const void **dev);
+// Host-resident frames -> device (pipelined, see hv_volume::hs_*).  Frame f's depth is depth_ptrs[f] when depth_ptrs is given,
+// else depth_base + f * depth_frame_bytes (same for colour).  Returns the device arrays (frames contiguous) and the set whose
+// hs_dev_ready event the consuming stream has to wait for; hv_stage_frames_consumed records hs_dev_free on that stream after
+// the last kernel that reads the set.  The caller's memory has been read completely when hv_stage_frames returns.
+int hv_stage_frames(hv_volume *v, const void *const *depth_ptrs, const void *depth_base, size_t depth_frame_bytes,
+                    const void *const *rgb_ptrs, const void *rgb_base, size_t rgb_frame_bytes, int n_frames,
+                    const void **d_depth, const void **d_rgb, int *set);
+int hv_stage_frames_consumed(hv_volume *v, int set, hipStream_t consumer);
 void hv_profile_begin(hv_volume *v);
 void hv_profile_end(hv_volume *v, int64_t units);
 void hv_invert4x4(const double *m, double *out);

@@ -3,6 +3,10 @@
 #include <cstdlib>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 #include "hv_common.h"
 
@@ -80,6 +84,160 @@ int hv_stage_in(hv_volume *v, const void *src, size_t bytes, int32_t loc, int wh
     if (rc != HV_OK) return rc;
     HV_HIP(hipMemcpyAsync(*buf, src, bytes, hipMemcpyHostToDevice, v->stream));
     *dev = *buf;
+    return HV_OK;
+}
+
+// ---- pipelined staging of host-resident frames ------------------------------------------------------------------------
+// pySLAM hands every keyframe over as pageable numpy arrays (volumetric_integrator_base.py:101-137, _tsdf.py:215-223).  A
+// pageable hipMemcpyAsync is staged by the runtime through its own bounce buffers on the calling thread and blocks the
+// compute stream it is issued on.  Here instead: a few worker threads copy a sub-chunk of frames into one of two
+// page-locked slots, the slot goes to the device with ONE asynchronous DMA on a copy stream, and while it is in flight
+// the threads fill the other slot; the frames land in one of two device sets, so the DMA of batch k+1 runs while batch k is
+// swept.  Measured in bench.py (`host_mode`).
+namespace {
+class HvCopyPool { // n persistent workers; run(fn) executes fn(i, n) on all of them and returns when every one is done
+  public:
+    explicit HvCopyPool(int n) : n_(n) {
+        for (int i = 0; i < n; ++i) th_.emplace_back([this, i] { loop(i); });
+        for (auto &t : th_) t.detach(); // process-lifetime pool (the library is never unloaded before exit)
+    }
+    int size() const { return n_; }
+    void run(const std::function<void(int, int)> &fn) {
+        std::unique_lock<std::mutex> lk(m_);
+        job_ = &fn;
+        pending_ = n_;
+        ++gen_;
+        cv_.notify_all();
+        done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+  private:
+    void loop(int i) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int, int)> *job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                job = job_;
+            }
+            (*job)(i, n_);
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int, int)> *job_ = nullptr;
+    uint64_t gen_ = 0;
+    int pending_ = 0;
+};
+
+HvCopyPool *hv_copy_pool() {
+    static HvCopyPool *pool = [] {
+        int n = 4;
+        if (const char *e = getenv("HV_STAGE_THREADS")) n = atoi(e);
+        n = std::max(1, std::min(n, 32));
+        return new HvCopyPool(n);
+    }();
+    return pool;
+}
+} // namespace
+
+int hv_stage_frames(hv_volume *v, const void *const *depth_ptrs, const void *depth_base, size_t depth_frame_bytes,
+                    const void *const *rgb_ptrs, const void *rgb_base, size_t rgb_frame_bytes, int n_frames,
+                    const void **d_depth, const void **d_rgb, int *set_out) {
+    if (v->hs_stream == nullptr) {
+        HV_HIP(hipStreamCreateWithFlags(&v->hs_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HV_HIP(hipEventCreateWithFlags(&v->hs_pinned_done[i], hipEventDisableTiming));
+            HV_HIP(hipEventCreateWithFlags(&v->hs_dev_ready[i], hipEventDisableTiming));
+            HV_HIP(hipEventCreateWithFlags(&v->hs_dev_free[i], hipEventDisableTiming));
+        }
+    }
+    const int set = v->hs_set;
+    v->hs_set ^= 1;
+    const size_t frame_bytes = depth_frame_bytes + rgb_frame_bytes;
+    // device set (grown on demand; its previous readers are done once hs_dev_free has fired)
+    const size_t want[2] = {depth_frame_bytes * (size_t)n_frames, rgb_frame_bytes * (size_t)n_frames};
+    for (int a = 0; a < 2; ++a) {
+        if (v->hs_dev_bytes[set][a] < want[a] || v->hs_dev[set][a] == nullptr) {
+            if (v->hs_dev_free_valid[set]) HV_HIP(hipEventSynchronize(v->hs_dev_free[set]));
+            HV_HIP(hipStreamSynchronize(v->hs_stream));
+            if (v->hs_dev[set][a]) HV_HIP(hipFree(v->hs_dev[set][a]));
+            v->hs_dev[set][a] = nullptr;
+            v->hs_dev_bytes[set][a] = 0;
+            const size_t bytes = std::max<size_t>(4096, want[a] + want[a] / 4);
+            HV_HIP(hipMalloc(&v->hs_dev[set][a], bytes));
+            v->hs_dev_bytes[set][a] = bytes;
+        }
+    }
+    if (v->hs_dev_free_valid[set]) HV_HIP(hipStreamWaitEvent(v->hs_stream, v->hs_dev_free[set], 0));
+    // sub-chunks of about 8 MB: long enough for the DMA engine to reach its rate, short enough that the first one is on its
+    // way early
+    size_t sub_target = 8u << 20;
+    if (const char *e = getenv("HV_STAGE_CHUNK_MB")) sub_target = (size_t)std::max(1, atoi(e)) << 20;
+    const int per_sub = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, sub_target / std::max<size_t>(1, frame_bytes)));
+    HvCopyPool *pool = hv_copy_pool();
+    for (int c0 = 0; c0 < n_frames; c0 += per_sub) {
+        const int nc = std::min(per_sub, n_frames - c0);
+        const int slot = v->hs_slot;
+        v->hs_slot ^= 1;
+        const size_t need = frame_bytes * (size_t)nc;
+        if (v->hs_pinned_bytes[slot] < need) {
+            if (v->hs_pinned[slot]) {
+                HV_HIP(hipEventSynchronize(v->hs_pinned_done[slot]));
+                HV_HIP(hipHostFree(v->hs_pinned[slot]));
+                v->hs_pinned[slot] = nullptr;
+                v->hs_pinned_bytes[slot] = 0;
+            }
+            const size_t bytes = std::max(need, frame_bytes * (size_t)per_sub);
+            HV_HIP(hipHostMalloc(&v->hs_pinned[slot], bytes));
+            v->hs_pinned_bytes[slot] = bytes;
+        } else {
+            HV_HIP(hipEventSynchronize(v->hs_pinned_done[slot])); // (an event that was never recorded reports complete)
+        }
+        char *pd = (char *)v->hs_pinned[slot];
+        char *pc = pd + depth_frame_bytes * (size_t)nc;
+        // every worker copies its slice of every frame of the sub-chunk (64-byte aligned cuts)
+        pool->run([&](int i, int n) {
+            auto slice = [&](size_t len, size_t &lo, size_t &hi) {
+                const size_t step = ((len + (size_t)n - 1) / (size_t)n + 63) & ~(size_t)63;
+                lo = std::min(len, step * (size_t)i);
+                hi = std::min(len, lo + step);
+            };
+            for (int f = 0; f < nc; ++f) {
+                size_t lo, hi;
+                const char *sd = depth_ptrs ? (const char *)depth_ptrs[c0 + f] : (const char *)depth_base + depth_frame_bytes * (size_t)(c0 + f);
+                slice(depth_frame_bytes, lo, hi);
+                if (hi > lo) memcpy(pd + depth_frame_bytes * (size_t)f + lo, sd + lo, hi - lo);
+                const char *sc = rgb_ptrs ? (const char *)rgb_ptrs[c0 + f] : (const char *)rgb_base + rgb_frame_bytes * (size_t)(c0 + f);
+                slice(rgb_frame_bytes, lo, hi);
+                if (hi > lo) memcpy(pc + rgb_frame_bytes * (size_t)f + lo, sc + lo, hi - lo);
+            }
+        });
+        HV_HIP(hipMemcpyAsync((char *)v->hs_dev[set][0] + depth_frame_bytes * (size_t)c0, pd, depth_frame_bytes * (size_t)nc,
+                              hipMemcpyHostToDevice, v->hs_stream));
+        HV_HIP(hipMemcpyAsync((char *)v->hs_dev[set][1] + rgb_frame_bytes * (size_t)c0, pc, rgb_frame_bytes * (size_t)nc,
+                              hipMemcpyHostToDevice, v->hs_stream));
+        HV_HIP(hipEventRecord(v->hs_pinned_done[slot], v->hs_stream));
+    }
+    HV_HIP(hipEventRecord(v->hs_dev_ready[set], v->hs_stream));
+    *d_depth = v->hs_dev[set][0];
+    *d_rgb = v->hs_dev[set][1];
+    *set_out = set;
+    return HV_OK;
+}
+
+int hv_stage_frames_consumed(hv_volume *v, int set, hipStream_t consumer) {
+    HV_HIP(hipEventRecord(v->hs_dev_free[set], consumer));
+    v->hs_dev_free_valid[set] = true;
     return HV_OK;
 }
 
@@ -335,6 +493,16 @@ void hv_destroy(hv_volume *v) {
     (void)hipSetDevice(v->device);
     if (v->stream_aux) (void)hipStreamSynchronize(v->stream_aux);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
+    if (v->hs_stream) (void)hipStreamSynchronize(v->hs_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (v->hs_pinned[i]) (void)hipHostFree(v->hs_pinned[i]);
+        for (int a = 0; a < 2; ++a)
+            if (v->hs_dev[i][a]) (void)hipFree(v->hs_dev[i][a]);
+        if (v->hs_pinned_done[i]) (void)hipEventDestroy(v->hs_pinned_done[i]);
+        if (v->hs_dev_ready[i]) (void)hipEventDestroy(v->hs_dev_ready[i]);
+        if (v->hs_dev_free[i]) (void)hipEventDestroy(v->hs_dev_free[i]);
+    }
+    if (v->hs_stream) (void)hipStreamDestroy(v->hs_stream);
     void *bufs[] = {v->table.keys, v->table.vals, v->table.block_keys, v->table.counters, v->pool,
                     v->touched_stamp, v->touched_list, v->touched_mask, v->frame_px,
                     v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,

@@ -1626,7 +1626,7 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep_fold
 // 12-byte frame records only ({depth, colour | 1 << 24, multiplier}: one gather per voxel visit).  Registers: 3 x 16
 // accumulators (sum t, r | b << 16, g << 8 | n << 24) + two gather groups.
 // ================================================================================================
-template <int SPLIT, int WPE, int GV, bool PIPE, bool ANYSKIP>
+template <int SPLIT, int WPE, int GV, int PIPE, bool ANYSKIP>
 __global__ __launch_bounds__(64 * 4 / SPLIT, WPE) void k_tsdf_sweep_column(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
     char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
@@ -1747,91 +1747,143 @@ __global__ __launch_bounds__(64 * 4 / SPLIT, WPE) void k_tsdf_sweep_column(
             float zk[GV];
             bool inimg[GV];
         };
-        auto fold_frame = [&](const HvSweepFrameK K, const int f, HvSweepFrameK &Knext, const unsigned long long rest) __attribute__((always_inline)) {
-            const __amdgpu_buffer_rsrc_t rs_px =
-                __builtin_amdgcn_make_buffer_rsrc((void *)((const uint32_t *)frame_px + (int64_t)f * npx * 3), 0, npx * 12, 0x00020000);
-            const hv_f2 INC = K.i01;
-            const float inc2 = K.i2;
+        // the frame whose voxels are being projected
+        hv_f2 XY, INC;
+        float Z, inc2;
+        __amdgpu_buffer_rsrc_t rs_px;
+        auto begin_frame = [&](const HvSweepFrameK K, const int f, HvSweepFrameK &Knext, const unsigned long long rest) __attribute__((always_inline)) {
+            rs_px = __builtin_amdgcn_make_buffer_rsrc((void *)((const uint32_t *)frame_px + (int64_t)f * npx * 3), 0, npx * 12, 0x00020000);
+            INC = K.i01;
+            inc2 = K.i2;
             // pc = ((e0 p0 + e1 p1) + e2 p2) + e3 at z = 0, rows 0 and 1 as one float2 (same IEEE ops as the reference)
-            hv_f2 XY = ((K.e04 * p0 + K.e15 * p1) + K.e26 * p2) + K.e37;
+            XY = ((K.e04 * p0 + K.e15 * p1) + K.e26 * p2) + K.e37;
             const hv_f2 Z12 = K.e9_10 * hv_f2{p1, p2};
-            float Z = ((K.e8 * p0 + Z12.x) + Z12.y) + K.e11;
+            Z = ((K.e8 * p0 + Z12.x) + Z12.y) + K.e11;
+            // K is consumed: only now issue the scalar loads of the next frame's constants (scalar loads return out of order, a
+            // wait is always "for all"), so that their latency hides behind this frame's arithmetic
             __builtin_amdgcn_sched_barrier(0);
             Knext = hv_sweep_frame_k(Ps, rest ? __ffsll((long long)rest) - 1 : f);
             __builtin_amdgcn_sched_barrier(0);
-            auto project = [&](Group &g) __attribute__((always_inline)) {
+        };
+        auto project = [&](Group &g) __attribute__((always_inline)) {
 #pragma unroll
-                for (int k = 0; k < GV; ++k) {
-                    // (a0, a1) / pc2, correctly rounded, sharing one refined reciprocal (hv_div2's chain on a float2)
-                    float r = __builtin_amdgcn_rcpf(Z);
-                    const float e = fmaf(-Z, r, 1.0f);
-                    r = fmaf(e, r, r);
-                    const hv_f2 A = XY * F;
-                    const hv_f2 R = hv_splat(r), NZ = hv_splat(-Z);
-                    hv_f2 Q = A * R;
-                    hv_f2 REM = hv_fma2(NZ, Q, A);
-                    Q = hv_fma2(REM, R, Q);
-                    REM = hv_fma2(NZ, Q, A);
-                    Q = hv_fma2(REM, R, Q);
-                    const hv_f2 UV = (Q + C) + hv_splat(0.5f);
-                    const bool in_u = (__float_as_uint(UV.x) - lo_u) < lim_u;
-                    const bool in_v = (__float_as_uint(UV.y) - lo_v) < lim_v;
-                    g.inimg[k] = (int)in_u & (int)in_v;
-                    const uint32_t u = (uint32_t)(int)UV.x, v = (uint32_t)(int)UV.y; // saturating conversions: garbage lanes stay defined
-                    const uint32_t off = __umul24(v, W24) + u; // exact for every in-image pixel; a garbage lane reads 0 or some pixel, unused
-                    g.rec[k] = __builtin_bit_cast(hv_u3, __builtin_amdgcn_raw_buffer_load_b96(rs_px, (int)__umul24(off, 12u), 0, 0));
-                    g.zk[k] = Z;
-                    XY += INC;
-                    Z += inc2;
-                }
-            };
-            auto fold = [&](const Group &g, const int gi) __attribute__((always_inline)) {
+            for (int k = 0; k < GV; ++k) {
+                // (a0, a1) / pc2, correctly rounded, sharing one refined reciprocal (hv_div2's chain on a float2)
+                float r = __builtin_amdgcn_rcpf(Z);
+                const float e = fmaf(-Z, r, 1.0f);
+                r = fmaf(e, r, r);
+                const hv_f2 A = XY * F;
+                const hv_f2 R = hv_splat(r), NZ = hv_splat(-Z);
+                hv_f2 Q = A * R;
+                hv_f2 REM = hv_fma2(NZ, Q, A);
+                Q = hv_fma2(REM, R, Q);
+                REM = hv_fma2(NZ, Q, A);
+                Q = hv_fma2(REM, R, Q);
+                const hv_f2 UV = (Q + C) + hv_splat(0.5f);
+                const bool in_u = (__float_as_uint(UV.x) - lo_u) < lim_u;
+                const bool in_v = (__float_as_uint(UV.y) - lo_v) < lim_v;
+                g.inimg[k] = (int)in_u & (int)in_v;
+                const uint32_t u = (uint32_t)(int)UV.x, v = (uint32_t)(int)UV.y; // saturating conversions: garbage lanes stay defined
+                const uint32_t off = __umul24(v, W24) + u; // exact for every in-image pixel; a garbage lane reads 0 or some pixel, unused
+                g.rec[k] = __builtin_bit_cast(hv_u3, __builtin_amdgcn_raw_buffer_load_b96(rs_px, (int)__umul24(off, 12u), 0, 0));
+                g.zk[k] = Z;
+                XY += INC;
+                Z += inc2;
+            }
+        };
+        auto fold = [&](const Group &g, const int gi) __attribute__((always_inline)) {
 #pragma unroll
-                for (int k = 0; k < GV; ++k) {
-                    const int z = gi * GV + k;
-                    const float sdf = (__uint_as_float(g.rec[k].x) - g.zk[k]) * __uint_as_float(g.rec[k].z);
-                    const bool ok = (int)g.inimg[k] & (int)(sdf > ntrunc);
-                    if (ANYSKIP && !__any(ok)) continue;
-                    const float tk = fminf(sdf * tinv, 1.0f); // == `if (t > 1) t = 1` for the non-NaN t of an accepted voxel
-                    S[z] += ok ? tk : 0.0f;
-                    const uint32_t c = ok ? g.rec[k].y : 0u;
-                    arb[z] += c & 0x00ff00ffu;
-                    agn[z] += c & 0xff00ff00u;
-                }
-            };
-            if (PIPE) {
-                Group ga, gb;
+            for (int k = 0; k < GV; ++k) {
+                const int z = gi * GV + k;
+                const float sdf = (__uint_as_float(g.rec[k].x) - g.zk[k]) * __uint_as_float(g.rec[k].z);
+                const bool ok = (int)g.inimg[k] & (int)(sdf > ntrunc);
+                if (ANYSKIP && !__any(ok)) continue; // no lane of the wave updates its voxel at this z
+                const float tk = fminf(sdf * tinv, 1.0f); // == `if (t > 1) t = 1` for the non-NaN t of an accepted voxel
+                S[z] += ok ? tk : 0.0f;
+                const uint32_t c = ok ? g.rec[k].y : 0u;
+                arb[z] += c & 0x00ff00ffu;
+                agn[z] += c & 0xff00ff00u;
+            }
+        };
+        HvSweepFrameK ka = hv_sweep_frame_k(Ps, __ffsll((long long)mask) - 1), kb = ka;
+        if (PIPE == 2) {
+            // gather groups pipelined ACROSS frames: the first group of frame n+1 is projected (and its gathers issued) before
+            // the last group of frame n is folded
+            static_assert(PIPE != 2 || NG % 2 == 0, "two gather groups alternate");
+            Group ga, gb;
+            {
+                const int f0 = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                begin_frame(ka, f0, kb, mask);
                 project(ga);
+            }
+            // one frame whose group 0 is in flight in ga; K_next: the constants of the frame after it (already requested)
+            auto frame_body = [&](const HvSweepFrameK K_next, HvSweepFrameK &K_after) __attribute__((always_inline)) {
+                bool more = false;
 #pragma unroll
                 for (int gi = 0; gi < NG; gi += 2) {
                     project(gb);
                     __builtin_amdgcn_sched_barrier(0);
                     fold(ga, gi);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (gi + 2 < NG) project(ga);
+                    if (gi + 2 < NG) {
+                        project(ga);
+                    } else {
+                        more = mask != 0ull;
+                        if (more) {
+                            const int fn = __ffsll((long long)mask) - 1;
+                            mask &= mask - 1;
+                            begin_frame(K_next, fn, K_after, mask);
+                            project(ga);
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     fold(gb, gi + 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            } else {
-#pragma unroll
-                for (int gi = 0; gi < NG; ++gi) {
-                    Group ga;
-                    project(ga);
-                    fold(ga, gi);
-                }
+                return more;
+            };
+            while (true) {
+                if (!frame_body(kb, ka)) break;
+                if (!frame_body(ka, kb)) break;
             }
-        };
-        HvSweepFrameK ka = hv_sweep_frame_k(Ps, __ffsll((long long)mask) - 1), kb = ka;
-        while (true) {
-            const int fa = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            fold_frame(ka, fa, kb, mask);
-            if (!mask) break;
-            const int fb = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            fold_frame(kb, fb, ka, mask);
-            if (!mask) break;
+        } else {
+            auto fold_frame = [&](const HvSweepFrameK K, const int f, HvSweepFrameK &Knext, const unsigned long long rest) __attribute__((always_inline)) {
+                begin_frame(K, f, Knext, rest);
+                if (PIPE == 1) {
+                    // the gathers of group g+1 are issued before group g is folded; the pipeline drains at the end of a frame
+                    Group ga, gb;
+                    project(ga);
+#pragma unroll
+                    for (int gi = 0; gi < NG; gi += 2) {
+                        project(gb);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fold(ga, gi);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (gi + 2 < NG) project(ga);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fold(gb, gi + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int gi = 0; gi < NG; ++gi) {
+                        Group ga;
+                        project(ga);
+                        fold(ga, gi);
+                    }
+                }
+            };
+            while (true) {
+                const int fa = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                fold_frame(ka, fa, kb, mask);
+                if (!mask) break;
+                const int fb = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                fold_frame(kb, fb, ka, mask);
+                if (!mask) break;
+            }
         }
         // one running-mean step per voxel for the whole batch, four voxels of the column at a time
 #pragma unroll
@@ -2196,26 +2248,36 @@ int hv_tsdf_integrate(hv_volume *v, const void *depth, int32_t depth_dtype, cons
                               depth_scale, depth_trunc);
 }
 
-int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype, const uint8_t *rgb,
-                            int32_t n_frames, int32_t height, int32_t width, const double *intr,
-                            const double *T_cw, double depth_scale, double depth_trunc, int32_t loc) {
-    int rc = check_tsdf_args(v, depth, rgb, height, width, intr, T_cw, n_frames);
-    if (rc != HV_OK) return rc;
+// depth_ptrs / rgb_ptrs != nullptr: host-resident frames given one pointer per frame (hv_tsdf_integrate_frames); else `depth`
+// / `rgb` hold the frames contiguously at `loc`.
+static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void *const *depth_ptrs, int32_t depth_dtype,
+                                     const uint8_t *rgb, const void *const *rgb_ptrs, int32_t n_frames, int32_t height,
+                                     int32_t width, const double *intr, const double *T_cw, double depth_scale,
+                                     double depth_trunc, int32_t loc) {
+    int rc = HV_OK;
     HV_HIP(hipSetDevice(v->device));
     const size_t npx = (size_t)height * width;
     const size_t dsz = depth_dtype == HV_DEPTH_U16 ? 2 : 4;
     const void *d_depth = nullptr, *d_rgb = nullptr;
-    rc = hv_stage_in(v, depth, npx * dsz * n_frames, loc, 0, &d_depth);
-    if (rc != HV_OK) return rc;
-    rc = hv_stage_in(v, rgb, npx * 3 * n_frames, loc, 1, &d_rgb);
-    if (rc != HV_OK) return rc;
+    int host_set = -1; // device staging set of host-resident frames (hv_stage_frames)
+    if (loc == HV_HOST) {
+        // pageable caller memory -> page-locked slots -> DMA on the copy stream, two device sets: the frames of this call
+        // cross PCIe while the previous batch is still being swept
+        rc = hv_stage_frames(v, depth_ptrs, depth, npx * dsz, rgb_ptrs, rgb, npx * 3, n_frames, &d_depth, &d_rgb, &host_set);
+        if (rc != HV_OK) return rc;
+    } else {
+        d_depth = depth;
+        d_rgb = rgb;
+    }
     if (v->debug_variant != 0 || n_frames == 1) { // ablation variants / trivial batch: frame by frame
+        if (host_set >= 0) HV_HIP(hipStreamWaitEvent(v->stream, v->hs_dev_ready[host_set], 0));
         for (int f = 0; f < n_frames; ++f) {
             rc = tsdf_integrate_one(v, (const char *)d_depth + npx * dsz * f, depth_dtype,
                                     (const uint8_t *)d_rgb + npx * 3 * f, height, width, intr, T_cw + 16 * f,
                                     depth_scale, depth_trunc);
             if (rc != HV_OK) return rc;
         }
+        if (host_set >= 0) return hv_stage_frames_consumed(v, host_set, v->stream);
         return HV_OK;
     }
     // multi-frame sweeps of up to 64 frames (one bit per frame in the per-unit mask)
@@ -2257,7 +2319,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         // one rank - 32.2 k vs 32.3 k frames/s - for one launch more: kept for A/B only)
         const bool list_in_touch = !(getenv("HV_TSDF_LIST") && strcmp(getenv("HV_TSDF_LIST"), "kernel") == 0);
         if (v->cfg.max_blocks != max_before) chain_ok = false; // the pool grew: the stream was drained, start a fresh chain
-        const bool overlap = pipeline_on && chain_ok && !checked && loc == HV_DEVICE && list_in_touch;
+        const bool overlap = pipeline_on && chain_ok && !checked && list_in_touch;
         if (v->stream_aux == nullptr) {
             HV_HIP(hipStreamCreateWithFlags(&v->stream_aux, hipStreamNonBlocking)); // (queue priority high / low against the sweep's: measured, no effect)
             HV_HIP(hipEventCreateWithFlags(&v->ev_prep, hipEventDisableTiming));
@@ -2271,6 +2333,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
         int32_t *d_list = v->touched_list + (size_t)parity * (size_t)v->cfg.max_blocks;
         unsigned long long *d_mask_rw = (unsigned long long *)v->touched_mask + (size_t)parity * (size_t)v->table_capacity;
         if (overlap) HV_HIP(hipStreamWaitEvent(v->stream_aux, v->ev_presweep, 0));
+        if (host_set >= 0) HV_HIP(hipStreamWaitEvent(ps, v->hs_dev_ready[host_set], 0)); // the frames have arrived
         // per-frame constants go through a ring of 4 pinned host buffers: the H2D copy is truly
         // asynchronous and a slot is only rewritten after the copy that last used it has completed,
         // so consecutive calls queue up on the stream without a host synchronisation
@@ -2306,6 +2369,7 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
                 if (ps != v->stream) HV_HIP(hipStreamSynchronize(v->stream_aux)); // nothing of an older batch still reads the old table there
                 ps = v->stream;
                 overlap_this = false;
+                if (host_set >= 0) HV_HIP(hipStreamWaitEvent(ps, v->hs_dev_ready[host_set], 0));
             }
         }
         // scratch: [B frame records of npx uint2][B HvFrameParams]
@@ -2385,22 +2449,26 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
             const int xcd_aware = getenv("HV_TSDF_SWEEP_XCD") ? atoi(getenv("HV_TSDF_SWEEP_XCD")) : 2;
             const int anyskip = getenv("HV_TSDF_SWEEP_ANYSKIP") ? atoi(getenv("HV_TSDF_SWEEP_ANYSKIP")) : 1;
             const int gv = getenv("HV_TSDF_SWEEP_GV") ? atoi(getenv("HV_TSDF_SWEEP_GV")) : 4;
-            const int pipe = getenv("HV_TSDF_SWEEP_PIPE") ? atoi(getenv("HV_TSDF_SWEEP_PIPE")) : 1;
+            const int pipe = getenv("HV_TSDF_SWEEP_PIPE") ? atoi(getenv("HV_TSDF_SWEEP_PIPE")) : 2;
             const int csplit = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : 4;
             if (csplit == 1) {
-                if (wpe >= 5) HV_LAUNCH_COLUMN(1, 5, 2, true, true); else HV_LAUNCH_COLUMN(1, 4, 2, true, true);
+                HV_LAUNCH_COLUMN(1, 4, 4, 1, true);
             } else if (csplit == 2) {
-                if (wpe >= 5) HV_LAUNCH_COLUMN(2, 5, 2, true, true); else HV_LAUNCH_COLUMN(2, 4, 2, true, true);
+                if (pipe == 2) HV_LAUNCH_COLUMN(2, 4, 4, 2, true); else HV_LAUNCH_COLUMN(2, 4, 4, 1, true);
             } else if (!anyskip) {
-                if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 2, true, false); else HV_LAUNCH_COLUMN(4, 4, 2, true, false);
-            } else if (gv == 4) {
-                if (pipe) { if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 4, true, true); else if (wpe == 3) HV_LAUNCH_COLUMN(4, 3, 4, true, true); else HV_LAUNCH_COLUMN(4, 4, 4, true, true); }
-                else { if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 4, false, true); else HV_LAUNCH_COLUMN(4, 4, 4, false, true); }
+                HV_LAUNCH_COLUMN(4, 4, 4, 1, false);
+            } else if (gv == 8) {
+                if (wpe >= 4) HV_LAUNCH_COLUMN(4, 4, 8, 2, true); else if (wpe == 3) HV_LAUNCH_COLUMN(4, 3, 8, 2, true); else HV_LAUNCH_COLUMN(4, 2, 8, 2, true);
+            } else if (gv == 2) {
+                if (pipe == 2) { if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 2, 2, true); else HV_LAUNCH_COLUMN(4, 4, 2, 2, true); }
+                else if (pipe == 1) { if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 2, 1, true); else HV_LAUNCH_COLUMN(4, 4, 2, 1, true); }
+                else HV_LAUNCH_COLUMN(4, 5, 2, 0, true);
             } else if (gv == 1) {
-                if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 1, true, true); else HV_LAUNCH_COLUMN(4, 4, 1, true, true);
+                HV_LAUNCH_COLUMN(4, 5, 1, 1, true);
             } else {
-                if (pipe) { if (wpe >= 6) HV_LAUNCH_COLUMN(4, 6, 2, true, true); else if (wpe == 5) HV_LAUNCH_COLUMN(4, 5, 2, true, true); else if (wpe == 3) HV_LAUNCH_COLUMN(4, 3, 2, true, true); else HV_LAUNCH_COLUMN(4, 4, 2, true, true); }
-                else { if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 2, false, true); else HV_LAUNCH_COLUMN(4, 4, 2, false, true); }
+                if (pipe == 2) { if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 4, 2, true); else if (wpe == 3) HV_LAUNCH_COLUMN(4, 3, 4, 2, true); else HV_LAUNCH_COLUMN(4, 4, 4, 2, true); }
+                else if (pipe == 1) { if (wpe >= 5) HV_LAUNCH_COLUMN(4, 5, 4, 1, true); else if (wpe == 3) HV_LAUNCH_COLUMN(4, 3, 4, 1, true); else HV_LAUNCH_COLUMN(4, 4, 4, 1, true); }
+                else HV_LAUNCH_COLUMN(4, 4, 4, 0, true);
             }
         } else if (d_mult && sweep_form == 3) {
             // fold form (production); HV_TSDF_SWEEP_WPE / _ZH / _ANYSKIP / _REC12 / HV_TSDF_BATCH_SPLIT select the measured alternatives
@@ -2457,7 +2525,30 @@ int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype
     }
     v->pipe_armed = true;
     v->pipe_version = v->content_version;
+    // (every touch + pack launch of this call precedes the point the main stream has reached: it waited for each of them)
+    if (host_set >= 0) return hv_stage_frames_consumed(v, host_set, v->stream);
     return HV_OK;
+}
+
+int hv_tsdf_integrate_batch(hv_volume *v, const void *depth, int32_t depth_dtype, const uint8_t *rgb,
+                            int32_t n_frames, int32_t height, int32_t width, const double *intr,
+                            const double *T_cw, double depth_scale, double depth_trunc, int32_t loc) {
+    int rc = check_tsdf_args(v, depth, rgb, height, width, intr, T_cw, n_frames);
+    if (rc != HV_OK) return rc;
+    return tsdf_integrate_batch_impl(v, depth, nullptr, depth_dtype, rgb, nullptr, n_frames, height, width, intr, T_cw, depth_scale,
+                                     depth_trunc, loc);
+}
+
+int hv_tsdf_integrate_frames(hv_volume *v, const void *const *depth_frames, int32_t depth_dtype, const uint8_t *const *rgb_frames,
+                             int32_t n_frames, int32_t height, int32_t width, const double *intr, const double *T_cw,
+                             double depth_scale, double depth_trunc) {
+    HV_REQUIRE(depth_frames != nullptr && rgb_frames != nullptr && n_frames >= 1, HV_ERR_INVALID, "hv_tsdf_integrate_frames: null argument");
+    for (int f = 0; f < n_frames; ++f)
+        HV_REQUIRE(depth_frames[f] != nullptr && rgb_frames[f] != nullptr, HV_ERR_INVALID, "hv_tsdf_integrate_frames: null frame %d", f);
+    int rc = check_tsdf_args(v, depth_frames[0], rgb_frames[0], height, width, intr, T_cw, n_frames);
+    if (rc != HV_OK) return rc;
+    return tsdf_integrate_batch_impl(v, nullptr, depth_frames, depth_dtype, nullptr, (const void *const *)rgb_frames, n_frames, height,
+                                     width, intr, T_cw, depth_scale, depth_trunc, HV_HOST);
 }
 
 int hv_tsdf_set_tile(hv_volume *v, int32_t u0, int32_t v0, int32_t u1, int32_t v1) {

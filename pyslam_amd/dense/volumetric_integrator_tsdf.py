@@ -90,12 +90,13 @@ class VolumetricIntegratorTsdf(VolumetricIntegratorBase):
                             if depth is not None:
                                 frames.append((color, depth, task.keyframe_data.pose, task.keyframe_data.id))
                         on_host = all(isinstance(f[1], np.ndarray) for f in frames)  # estimator depth may live in HBM
-                        if (on_host and len(frames) > 1 and hasattr(self.volume, "integrate_batch")
+                        if (on_host and len(frames) > 1 and hasattr(self.volume, "integrate_frames")
                                 and len({f[1].shape for f in frames}) == 1):
-                            self.volume.integrate_batch(np.stack([f[1] for f in frames]), np.stack([f[0] for f in frames]),
-                                                        self.o3d_camera, np.stack([f[2] for f in frames]),
-                                                        depth_scale=self.depth_factor,
-                                                        depth_trunc=self.volumetric_integration_depth_trunc)
+                            # one pointer per frame: the library stages the keyframes' own arrays (no np.stack copy)
+                            self.volume.integrate_frames([f[1] for f in frames], [f[0] for f in frames],
+                                                         self.o3d_camera, np.stack([f[2] for f in frames]),
+                                                         depth_scale=self.depth_factor,
+                                                         depth_trunc=self.volumetric_integration_depth_trunc)
                         else:
                             for color, depth, pose, _ in frames:
                                 rgbd = RGBDImage.create_from_color_and_depth(

@@ -610,6 +610,28 @@ class ScalableTSDFVolume(_Volume):
             )
         )
 
+    def integrate_frames(self, depths, colors, intrinsic, extrinsics, depth_scale=1.0, depth_trunc=4.0):
+        """integrate_batch for HOST frames held one numpy array per frame (what the integrator worker has after draining
+        its queue): no np.stack - the library copies every frame straight into page-locked staging slots and sends them
+        over PCIe on a copy stream while the previous batch is swept.  Same result as len(depths) integrate() calls."""
+        F = len(depths)
+        if F == 0:
+            return
+        dkind = L.HV_DEPTH_U16 if str(depths[0].dtype) == "uint16" else L.HV_DEPTH_F32
+        dtype = np.uint16 if dkind == L.HV_DEPTH_U16 else np.float32
+        depths = [np.ascontiguousarray(d, dtype=dtype) for d in depths]
+        colors = [np.ascontiguousarray(c, dtype=np.uint8) for c in colors]
+        H, W = (int(x) for x in depths[0].shape)
+        for d, c in zip(depths, colors):
+            if d.shape != (H, W) or c.shape != (H, W, 3):
+                raise RuntimeError("[ScalableTSDFVolume::Integrate] Unsupported image format.")
+        T = np.ascontiguousarray(np.asarray(extrinsics, dtype=np.float64).reshape(F, 16))
+        intr = intrinsic.as_array()
+        dp = (ctypes.c_void_p * F)(*[d.ctypes.data for d in depths])
+        cp = (ctypes.c_void_p * F)(*[c.ctypes.data for c in colors])
+        L.check(self._lib.hv_tsdf_integrate_frames(self._h, dp, dkind, cp, F, H, W, L.ptr(intr), L.ptr(T), float(depth_scale),
+                                                   float(depth_trunc)))
+
     def set_tile(self, u0, v0, u1, v1):
         """Restrict fusion to the image tile [u0,u1) x [v0,v1) (multi-GPU sharding); zeros = whole image."""
         L.check(self._lib.hv_tsdf_set_tile(self._h, int(u0), int(v0), int(u1), int(v1)))
