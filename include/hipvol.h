@@ -313,21 +313,28 @@ int hv_tsdf_unit_keys(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n);
  * on tile borders (and revisits from other viewpoints) hold PARTIAL running means on several GPUs.  A merge:
  *   1. hv_tsdf_dirty_keys      every rank: the units it stamped since its last merge (sorted, 12 B per key)
  *   2. (caller) all-gather of the key lists
- *   3. hv_merge_halo_plan      every rank, same input -> same output: keys listed by >= 2 ranks, in sorted order, and what
- *                              THIS rank does with each: 0 = does not hold it, 1 = keeps it (lowest listing rank), 2 = zeroes it
+ *   3. hv_merge_halo_plan_held every rank, same input -> same output: the keys that some rank updated since its last merge
+ *                              AND that two ranks or more hold (second all-gather: hv_tsdf_unit_keys), in sorted order, and
+ *                              what THIS rank does with each: 1 = keeps it (the lowest holding rank), 2 = zeroes its copy (a
+ *                              no-op where the rank has none).  (hv_merge_halo_plan: the same from the dirty lists alone -
+ *                              keys listed by >= 2 ranks, lowest listing rank keeps, EVERY other rank zeroes: a unit that is
+ *                              updated by one rank per window is never consolidated by it.)
  *   4. hv_merge_halo_pack      additive numerators {sum w*tsdf, w, sum r, sum g, sum b} of the shared units only, dense
  *                              [K, 16^3, 5] f32 in plan order (zeros where the rank does not hold a unit)
  *   5. (caller) all-reduce(sum) of that buffer - message size = shared units x 81 920 B, not the whole volume
  *   6. hv_merge_halo_unpack    keeper: state := reduced numerators; other holders: unit zeroed (they go on fusing deltas)
  *   7. hv_tsdf_mark_merged
- * Afterwards the sum over ranks of every unit's numerators is still the single-GPU total, and every shared unit is complete
- * on exactly one rank.  The library does the device work; the caller owns the transport (pyslam_amd/distributed.py:
+ * Afterwards the sum over ranks of every unit's numerators is still the single-GPU total, and every unit that went through
+ * the merge is complete on exactly one rank (with the _held plan: every unit two ranks hold).  The library does the device work; the caller owns the transport (pyslam_amd/distributed.py:
  * torch.distributed, backend nccl = RCCL over xGMI). */
 int hv_tsdf_dirty_keys(hv_volume *v, int32_t *keys /* [cap,3] host, may be NULL */, int64_t cap, int64_t *n);
 int hv_tsdf_mark_merged(hv_volume *v);
 /* Host-only.  gathered_keys = the ranks' lists back to back ([sum counts, 3]); shared_keys/action may be NULL to query *n_shared. */
 int hv_merge_halo_plan(const int32_t *gathered_keys, const int64_t *counts, int32_t world_size, int32_t rank,
                        int32_t *shared_keys, uint8_t *action, int64_t cap, int64_t *n_shared);
+int hv_merge_halo_plan_held(const int32_t *dirty_keys, const int64_t *dirty_counts, const int32_t *held_keys,
+                            const int64_t *held_counts, int32_t world_size, int32_t rank, int32_t *shared_keys, uint8_t *action,
+                            int64_t cap, int64_t *n_shared);
 int hv_merge_halo_pack(hv_volume *v, const int32_t *shared_keys, int64_t k, float *payload, int32_t loc);
 int hv_merge_halo_unpack(hv_volume *v, const int32_t *shared_keys, int64_t k, const float *payload, const uint8_t *action,
                          int32_t loc);

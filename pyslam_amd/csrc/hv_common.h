@@ -260,6 +260,7 @@ struct hv_volume {
     int64_t max_new_per_call = 0;  // largest growth of `blocks` seen between two published states
     double avg_new_per_call = 0.0; // running mean of the growth per call (what the calls still in flight are expected to add)
     bool status_exact = false;     // known_blocks was read with the stream idle (after creation / reset / growth: true until the next launch)
+    bool overflow_latched = false; // an unchecked call ran out of pool: every integrate call fails until the pool is rebuilt / reset
 
     // TSDF per-frame state
     int32_t *touched_stamp = nullptr; // [table_capacity] last frame id that touched the slot

@@ -270,6 +270,7 @@ void hv_launch_publish_status(hv_volume *v) {
 }
 
 static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep);
+static int hv_rollback_claims(hv_volume *v, int64_t keep);
 static uint64_t next_pow2(uint64_t x);
 
 static bool hv_auto_grow() { return !(getenv("HV_AUTO_GROW") && atoi(getenv("HV_AUTO_GROW")) == 0); }
@@ -306,7 +307,8 @@ int hv_capacity_gate(hv_volume *v, bool *checked) {
             v->status_seq_seen = seq;
         }
     }
-    HV_REQUIRE(overflow == 0, HV_ERR_CAPACITY,
+    if (overflow != 0) v->overflow_latched = true; // stays set until hv_reserve_blocks / hv_reset repair the pool (a rebuild clears it)
+    HV_REQUIRE(!v->overflow_latched, HV_ERR_CAPACITY,
                "block pool exhausted during an earlier integrate call (max_blocks=%lld): units that did not fit were not fused; "
                "nothing more is fused until hv_reserve_blocks or hv_reset",
                (long long)v->cfg.max_blocks);
@@ -337,9 +339,22 @@ int hv_claims_fit(hv_volume *v) {
     if (rc != HV_OK) {
         // roll the claim pass back: the blocks it did get are released again (nothing was written to them), the failed keys
         // leave the table - the volume is exactly what it was before the call
-        const int64_t before = v->h_status->seq == v->status_seq_issued && v->status_seq_issued > 0 ? v->h_status->blocks : v->known_blocks;
+        // "before" = the larger of the last published occupancy and what the host knows exactly: units that arrived without a
+        // publishing kernel (hv_tsdf_import_numerators on a gather root) are only in known_blocks - they must survive the rollback
+        const int64_t published = v->h_status->seq == v->status_seq_issued && v->status_seq_issued > 0 ? v->h_status->blocks : 0;
+        const int64_t before = std::min<int64_t>(std::max<int64_t>(published, v->known_blocks), v->cfg.max_blocks);
         const int64_t max_blocks = v->cfg.max_blocks;
-        (void)hv_rebuild(v, max_blocks, before);
+        // in place: only the (small) table arrays are re-made - a second full-size pool is exactly what a box that could not
+        // grow does not have
+        const int rb = hv_rollback_claims(v, before);
+        if (rb != HV_OK) {
+            const std::string why = hv_last_error();
+            hv_set_error("block pool exhausted: %lld blocks needed, max_blocks=%lld, the pool cannot grow AND the claim pass could not be "
+                         "rolled back (%s): the frame was NOT fused, but the hash holds keys without a block - hv_reset or "
+                         "hv_reserve_blocks before the volume is used again",
+                         (long long)blocks, (long long)max_blocks, why.c_str());
+            return HV_ERR_CAPACITY;
+        }
         hv_set_error("block pool exhausted: %lld blocks needed, max_blocks=%lld and the pool cannot grow (HV_AUTO_GROW=0, no free HBM, "
                      "or the 32-bit sort keys of the grid modes); the frame was NOT fused, the volume is unchanged",
                      (long long)blocks, (long long)max_blocks);
@@ -560,6 +575,7 @@ int hv_reset(hv_volume *v) {
     v->vg_cap = 0; // the VOXEL_GRID bucket arrays restart clean (list counters were zeroed with the counter block)
     v->last_touch_parity = 0;
     v->touch_counters_clean = true;
+    v->overflow_latched = false;
     return HV_OK;
 }
 
@@ -716,6 +732,75 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
     v->status_seq_seen = v->status_seq_issued;
     v->known_blocks = used;
     v->status_exact = true;
+    v->overflow_latched = false;
+    return HV_OK;
+}
+
+// Undo a claim pass that did not fit, without touching the pool: the table is emptied and re-filled from the keys of the
+// first `keep` blocks (the keys claimed by the failed call - with or without a block - are gone), the TSDF mode's per-slot
+// stamps follow their keys, the counters are repaired.  Blocks beyond `keep` were handed out by the failed call and never
+// written (a claim pass writes no voxel), so they are still zero.  Temporary memory: a copy of the old table (20 B per slot).
+static int hv_rollback_claims(hv_volume *v, int64_t keep) {
+    HV_HIP(hipSetDevice(v->device));
+    HV_HIP(hipStreamSynchronize(v->stream));
+    const uint64_t cap = v->table_capacity;
+    keep = std::max<int64_t>(0, std::min<int64_t>(keep, v->cfg.max_blocks));
+    unsigned long long *old_keys = nullptr;
+    int32_t *old_vals = nullptr, *old_stamp = nullptr;
+    auto release = [&]() {
+        for (void *p : {(void *)old_keys, (void *)old_vals, (void *)old_stamp})
+            if (p) (void)hipFree(p);
+    };
+#define HV_TRY_RB(call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            hv_set_error("%s failed: %s", #call, hipGetErrorString(e_));                           \
+            release();                                                                             \
+            return HV_ERR_DEVICE;                                                                  \
+        }                                                                                          \
+    } while (0)
+    const bool tsdf = v->cfg.mode == HV_MODE_TSDF && v->touched_stamp != nullptr;
+    if (tsdf) {
+        HV_TRY_RB(hipMalloc((void **)&old_keys, sizeof(uint64_t) * cap));
+        HV_TRY_RB(hipMalloc((void **)&old_vals, sizeof(int32_t) * cap));
+        HV_TRY_RB(hipMalloc((void **)&old_stamp, sizeof(int32_t) * cap));
+        HV_TRY_RB(hipMemcpyAsync(old_keys, v->table.keys, sizeof(uint64_t) * cap, hipMemcpyDeviceToDevice, v->stream));
+        HV_TRY_RB(hipMemcpyAsync(old_vals, v->table.vals, sizeof(int32_t) * cap, hipMemcpyDeviceToDevice, v->stream));
+        HV_TRY_RB(hipMemcpyAsync(old_stamp, v->touched_stamp, sizeof(int32_t) * cap, hipMemcpyDeviceToDevice, v->stream));
+    }
+    HV_TRY_RB(hipMemsetAsync(v->table.keys, 0xFF, sizeof(uint64_t) * cap, v->stream));
+    HV_TRY_RB(hipMemsetAsync(v->table.vals, 0xFF, sizeof(int32_t) * cap, v->stream));
+    if (keep > 0) hipLaunchKernelGGL(k_rehash, dim3((unsigned)((keep + 255) / 256)), dim3(256), 0, v->stream, v->table, v->table.block_keys, (int32_t)keep);
+    HV_TRY_RB(hipGetLastError());
+    if (tsdf) {
+        HV_TRY_RB(hipMemsetAsync(v->touched_stamp, 0, sizeof(int32_t) * cap, v->stream));
+        HV_TRY_RB(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * 2 * cap, v->stream));
+        HvTable old_t = v->table;
+        old_t.keys = old_keys;
+        old_t.vals = old_vals;
+        if (keep > 0)
+            hipLaunchKernelGGL(k_restamp, dim3((unsigned)((keep + 255) / 256)), dim3(256), 0, v->stream, old_t, v->table,
+                               (const int32_t *)old_stamp, v->touched_stamp, (int32_t)keep);
+        HV_TRY_RB(hipGetLastError());
+        HV_TRY_RB(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
+        v->touch_counters_clean = true;
+    }
+    const int32_t fixed[2] = {(int32_t)keep, 0};
+    HV_TRY_RB(hipMemcpyAsync(&v->table.counters[HV_CNT_BLOCKS], fixed, sizeof(fixed), hipMemcpyHostToDevice, v->stream));
+    HV_TRY_RB(hipStreamSynchronize(v->stream));
+#undef HV_TRY_RB
+    release();
+    v->h_counters[HV_CNT_BLOCKS] = (int32_t)keep;
+    v->h_counters[HV_CNT_OVERFLOW] = 0;
+    v->h_status->blocks = (int32_t)keep;
+    v->h_status->overflow = 0;
+    v->h_status->seq = v->status_seq_issued;
+    v->status_seq_seen = v->status_seq_issued;
+    v->known_blocks = keep;
+    v->status_exact = true;
+    v->overflow_latched = false;
+    v->vg_cap = 0; // grid modes: the per-slot bucket arrays are keyed by slots that just moved - re-made by the next frame
     return HV_OK;
 }
 

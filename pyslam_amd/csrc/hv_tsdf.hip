@@ -2712,6 +2712,7 @@ int hv_tsdf_import_numerators(hv_volume *v, const int32_t *keys, int64_t k, cons
     hipLaunchKernelGGL(k_tsdf_import, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, v->table,
                        (char *)v->pool, (const int32_t *)d_keys, k, (const float *)d_payload);
     HV_HIP(hipGetLastError());
+    hv_launch_publish_status(v); // the imported units are part of the published occupancy (a later rollback keeps them)
     HV_HIP(hipStreamSynchronize(v->stream));
     return HV_OK;
 }
@@ -2783,7 +2784,74 @@ int hv_merge_halo_plan(const int32_t *gathered_keys, const int64_t *counts, int3
         if (j - i >= 2) { // listed by two ranks or more (a rank lists a key once)
             if (shared_keys != nullptr && action != nullptr && ns < cap) {
                 memcpy(shared_keys + ns * 3, all[i].key.data(), 12);
-                action[ns] = !mine ? 0 : (all[i].rank == rank ? 1 : 2); // the lowest listing rank keeps the unit
+                // the lowest listing rank keeps the unit; EVERY other rank zeroes its copy if it has one - also a rank that holds
+                // the unit from an earlier window without having listed it now: the pack step exports whatever a rank holds,
+                // so a holder that kept its copy would be counted twice (unpack is a no-op where the unit does not exist)
+                action[ns] = all[i].rank == rank ? 1 : 2;
+                (void)mine;
+            }
+            ++ns;
+        }
+        i = j;
+    }
+    *n_shared = ns;
+    return HV_OK;
+}
+
+int hv_merge_halo_plan_held(const int32_t *dirty_keys, const int64_t *dirty_counts, const int32_t *held_keys,
+                            const int64_t *held_counts, int32_t world_size, int32_t rank, int32_t *shared_keys, uint8_t *action,
+                            int64_t cap, int64_t *n_shared) {
+    HV_REQUIRE(dirty_counts != nullptr && held_counts != nullptr && n_shared != nullptr && world_size >= 1 && rank >= 0 && rank < world_size,
+               HV_ERR_INVALID, "hv_merge_halo_plan_held: bad argument");
+    // (key, rank, kind) of every rank's two lists; a key is merged when some rank updated it since its last merge AND two
+    // ranks or more hold it: afterwards the lowest HOLDING rank has the complete unit and every other holder zeros
+    struct Entry { std::array<int32_t, 3> key; int32_t rank; int32_t dirty; };
+    int64_t nd = 0, nh = 0;
+    for (int r = 0; r < world_size; ++r) {
+        nd += dirty_counts[r];
+        nh += held_counts[r];
+    }
+    HV_REQUIRE((nd == 0 || dirty_keys != nullptr) && (nh == 0 || held_keys != nullptr), HV_ERR_INVALID, "hv_merge_halo_plan_held: null key list");
+    std::vector<Entry> all((size_t)(nd + nh));
+    int64_t at = 0, src = 0;
+    for (int r = 0; r < world_size; ++r)
+        for (int64_t i = 0; i < dirty_counts[r]; ++i, ++at, ++src) {
+            memcpy(all[at].key.data(), dirty_keys + src * 3, 12);
+            all[at].rank = r;
+            all[at].dirty = 1;
+        }
+    src = 0;
+    for (int r = 0; r < world_size; ++r)
+        for (int64_t i = 0; i < held_counts[r]; ++i, ++at, ++src) {
+            memcpy(all[at].key.data(), held_keys + src * 3, 12);
+            all[at].rank = r;
+            all[at].dirty = 0;
+        }
+    std::sort(all.begin(), all.end(), [](const Entry &a, const Entry &b) {
+        if (a.key != b.key) return a.key < b.key;
+        if (a.rank != b.rank) return a.rank < b.rank;
+        return a.dirty < b.dirty;
+    });
+    int64_t ns = 0;
+    const int64_t total = nd + nh;
+    for (int64_t i = 0; i < total;) {
+        int64_t j = i;
+        int holders = 0, keeper = -1, last_holder = -1;
+        bool any_dirty = false;
+        while (j < total && all[j].key == all[i].key) {
+            if (all[j].dirty) {
+                any_dirty = true;
+            } else if (all[j].rank != last_holder) {
+                last_holder = all[j].rank;
+                if (keeper < 0) keeper = all[j].rank;
+                ++holders;
+            }
+            ++j;
+        }
+        if (any_dirty && holders >= 2) {
+            if (shared_keys != nullptr && action != nullptr && ns < cap) {
+                memcpy(shared_keys + ns * 3, all[i].key.data(), 12);
+                action[ns] = keeper == rank ? 1 : 2;
             }
             ++ns;
         }

@@ -15,12 +15,14 @@ it is free next to the ~0.5 GB of voxel traffic it causes).  Two ways to split t
     allocated nor swept there.  Units on tile borders (and revisits from other viewpoints) then hold
     *partial* running means on several ranks.  ``merge_halo()`` (BASELINE north star: "RCCL
     all-reduce of overlapping-block TSDF/weight") consolidates exactly those:
-      all-gather of the key lists of the units each rank stamped since its last merge (12 B/key) ->
-      ``hv_merge_halo_plan``: keys listed by >= 2 ranks, identical order everywhere ->
+      all-gather of the key lists of the units each rank stamped since its last merge, and of the units it holds
+      (12 B/key) -> ``hv_merge_halo_plan_held``: the keys some rank updated AND two ranks or more hold, identical order
+      everywhere (the lowest holding rank keeps, every other holder zeroes - also one that did not update the unit in
+      this window: its copy is part of the reduced sum) ->
       ``hv_merge_halo_pack``: additive numerators {sum w*tsdf, w, sum r, sum g, sum b} of THOSE units into one
       dense buffer -> ``all_reduce(SUM)`` in ~64 MB buckets (ring collectives over xGMI are per-link bound,
-      ~153 GB/s: few, large messages) -> ``hv_merge_halo_unpack``: the lowest listing rank keeps the unit with the
-      reduced state, the others zero theirs and go on fusing deltas.
+      ~153 GB/s: few, large messages) -> ``hv_merge_halo_unpack``: the keeper takes the reduced state, the others zero
+      theirs and go on fusing deltas.
     The message is shared units x 81 920 B, not the volume.  The sum over ranks of a unit's numerators stays the
     single-GPU total at all times, so ``gather_to_root()`` (union of all keys, sum-reduce to one rank) yields the
     complete volume whenever a mesh is wanted.
@@ -148,17 +150,23 @@ class ShardedTSDF:
         on_gpu = dist.get_backend(self.group) == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
         mine = np.ascontiguousarray(self.volume.dirty_keys(), dtype=np.int32).reshape(-1, 3)
-        lists = self._gather_keys(mine, dist, torch, dev)
-        counts = np.array([len(x) for x in lists], dtype=np.int64)
-        gathered = np.ascontiguousarray(np.concatenate([x.reshape(-1, 3) for x in lists], axis=0), dtype=np.int32)
+        held = np.ascontiguousarray(self.volume.unit_keys(), dtype=np.int32).reshape(-1, 3)
+
+        def gathered(keys):
+            lists = self._gather_keys(keys, dist, torch, dev)
+            return (np.ascontiguousarray(np.concatenate([x.reshape(-1, 3) for x in lists], axis=0), dtype=np.int32),
+                    np.array([len(x) for x in lists], dtype=np.int64))
+
+        (dk, dc), (hk, hc) = gathered(mine), gathered(held)
         n = ctypes.c_int64()
-        L.check(lib.hv_merge_halo_plan(L.ptr(gathered), L.ptr(counts), self.world_size, self.rank, None, None, 0, ctypes.byref(n)))
+        L.check(lib.hv_merge_halo_plan_held(L.ptr(dk), L.ptr(dc), L.ptr(hk), L.ptr(hc), self.world_size, self.rank, None, None, 0,
+                                            ctypes.byref(n)))
         k = n.value
         shared = np.zeros((k, 3), np.int32)
         action = np.zeros(k, np.uint8)
         if k:
-            L.check(lib.hv_merge_halo_plan(L.ptr(gathered), L.ptr(counts), self.world_size, self.rank, L.ptr(shared), L.ptr(action), k,
-                                           ctypes.byref(n)))
+            L.check(lib.hv_merge_halo_plan_held(L.ptr(dk), L.ptr(dc), L.ptr(hk), L.ptr(hc), self.world_size, self.rank, L.ptr(shared),
+                                                L.ptr(action), k, ctypes.byref(n)))
         self.last_halo = {"shared_keys": shared, "action": action, "dirty": len(mine), "payload_bytes": 0}
         res3 = self.volume.res ** 3
         units_per_bucket = max(1, self.BUCKET_BYTES // (res3 * 5 * 4))

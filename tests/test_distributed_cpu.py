@@ -22,7 +22,7 @@ class OracleBackedVolume:
         import oracle
 
         self.vol = oracle.PortTsdf(0.02, 0.08)
-        self.imported = {}   # key -> numerators that REPLACE the oracle's state of that unit (import / halo unpack)
+        self.imported = {}   # key -> offset that, added to the oracle's own numerators, gives the unit's state (import / halo unpack)
         self.dirty = set()
 
     def set_tile(self, *a):
@@ -44,23 +44,12 @@ class OracleBackedVolume:
     def mark_merged(self):
         self.dirty.clear()
 
-    def halo_unpack(self, keys, payload, action):
-        for j, key in enumerate(keys):
-            if action[j] == 1:
-                self.imported[tuple(key)] = np.array(payload[j])
-            elif action[j] == 2:
-                self.imported[tuple(key)] = np.zeros_like(payload[j])
-
-    def export_numerators(self, keys, out=None):
+    def _numerators(self, keys):
+        """The oracle volume's own additive numerators of `keys` (zeros where it has no such unit)."""
         k, tsdf, w, col = self.vol.dump()
         idx = {tuple(x): i for i, x in enumerate(k)}
-        if out is None:
-            out = np.zeros((len(keys), 4096, 5), np.float32)
-        out[:] = 0
+        out = np.zeros((len(keys), 4096, 5), np.float32)
         for j, key in enumerate(keys):
-            if tuple(key) in self.imported:
-                out[j] = self.imported[tuple(key)]
-                continue
             i = idx.get(tuple(key))
             if i is not None:
                 out[j, :, 0] = tsdf[i] * w[i]
@@ -68,9 +57,32 @@ class OracleBackedVolume:
                 out[j, :, 2:5] = col[i] * w[i][:, None]
         return out
 
-    def import_numerators(self, keys, payload):
+    def _set_state(self, keys, values):
+        """State of a unit := value.  Kept as an offset against the oracle volume, so that frames fused AFTERWARDS still add
+        their deltas (a HIP volume overwrites the unit's planes and goes on fusing into them)."""
+        own = self._numerators(keys)
         for j, key in enumerate(keys):
-            self.imported[tuple(key)] = np.array(payload[j])
+            self.imported[tuple(key)] = np.asarray(values[j], np.float32) - own[j]
+
+    def halo_unpack(self, keys, payload, action):
+        held = {tuple(k) for k in self.unit_keys()} | set(self.imported)
+        sel = [j for j, key in enumerate(keys) if action[j] == 1 or (action[j] == 2 and tuple(key) in held)]
+        if sel:
+            self._set_state([keys[j] for j in sel],
+                            [payload[j] if action[j] == 1 else np.zeros_like(np.asarray(payload[j])) for j in sel])
+
+    def export_numerators(self, keys, out=None):
+        own = self._numerators(keys)
+        if out is None:
+            out = np.zeros((len(keys), 4096, 5), np.float32)
+        out[:] = own
+        for j, key in enumerate(keys):
+            if tuple(key) in self.imported:
+                out[j] += self.imported[tuple(key)]
+        return out
+
+    def import_numerators(self, keys, payload):
+        self._set_state(keys, payload)
 
     def reset(self):
         self.vol.reset()
@@ -98,7 +110,7 @@ def _worker(rank, world, port, tmpdir):
     n = fuser.merge(root=0)
     if rank == 0:
         keys = np.array(sorted(backend.imported))
-        payload = np.stack([backend.imported[tuple(k)] for k in keys])
+        payload = backend.export_numerators(keys)
         np.savez(os.path.join(tmpdir, "merged.npz"), keys=keys, payload=payload, n=n)
     else:
         assert backend.vol.num_units() == 0  # non-root ranks are cleared and keep fusing deltas
@@ -159,7 +171,7 @@ def _halo_worker(rank, world, port, tmpdir):
     n = fuser.gather_to_root(root=0)
     if rank == 0:
         keys = np.array(sorted(backend.imported))
-        np.savez(os.path.join(tmpdir, "gathered.npz"), keys=keys, payload=np.stack([backend.imported[tuple(k)] for k in keys]), n=n)
+        np.savez(os.path.join(tmpdir, "gathered.npz"), keys=keys, payload=backend.export_numerators(keys), n=n)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -201,7 +213,8 @@ def test_two_rank_halo_merge_reduces_only_shared_units(tmp_path):
 
 
 def test_merge_halo_plan_three_ranks():
-    """hv_merge_halo_plan (host-only C): keys listed by >= 2 ranks, sorted; the lowest listing rank keeps."""
+    """hv_merge_halo_plan (host-only C): keys listed by >= 2 ranks, sorted; the lowest listing rank keeps, EVERY other rank
+    zeroes (a rank that did not list the key may still hold a copy from an earlier window, and pack exports it)."""
     import ctypes
 
     from pyslam_amd import _lib as L
@@ -211,13 +224,114 @@ def test_merge_halo_plan_three_ranks():
              np.array([[-3, 0, 1], [1, 0, 0], [9, 9, 9]], np.int32)]
     counts = np.array([len(x) for x in lists], np.int64)
     gathered = np.ascontiguousarray(np.concatenate(lists))
-    want = {0: [0, 1], 1: [1, 2], 2: [2, 2]}  # shared (sorted): [-3,0,1] by ranks 1,2; [1,0,0] by ranks 0,1,2
+    want = {0: [2, 1], 1: [1, 2], 2: [2, 2]}  # shared (sorted): [-3,0,1] by ranks 1,2; [1,0,0] by ranks 0,1,2
     for rank in range(3):
         n = ctypes.c_int64()
         shared, action = np.zeros((4, 3), np.int32), np.zeros(4, np.uint8)
         L.check(lib.hv_merge_halo_plan(L.ptr(gathered), L.ptr(counts), 3, rank, L.ptr(shared), L.ptr(action), 4, ctypes.byref(n)))
         assert n.value == 2 and shared[:2].tolist() == [[-3, 0, 1], [1, 0, 0]]
         assert action[:2].tolist() == want[rank]
+
+
+def test_merge_halo_plan_held_three_ranks():
+    """hv_merge_halo_plan_held: merged = updated by some rank AND held by two or more; the lowest HOLDER keeps."""
+    import ctypes
+
+    from pyslam_amd import _lib as L
+
+    lib = L.load()
+    dirty = [np.array([[1, 0, 0]], np.int32), np.array([[1, 0, 0], [2, 2, 2], [7, 7, 7]], np.int32), np.zeros((0, 3), np.int32)]
+    held = [np.array([[1, 0, 0], [4, 4, 4]], np.int32), np.array([[1, 0, 0], [2, 2, 2], [7, 7, 7]], np.int32),
+            np.array([[1, 0, 0], [2, 2, 2], [4, 4, 4]], np.int32)]
+    # [1,0,0]: dirty on 0 and 1, held by all -> rank 0 keeps, 1 and 2 zero (2 holds a copy it did not update)
+    # [2,2,2]: dirty on 1 only, held by 1 and 2 -> merged, rank 1 keeps;  [4,4,4]: held by 0 and 2 but nobody updated it -> not merged
+    # [7,7,7]: dirty on 1, held by 1 alone -> not merged
+    dk, hk = np.ascontiguousarray(np.concatenate(dirty)), np.ascontiguousarray(np.concatenate(held))
+    dc, hc = np.array([len(x) for x in dirty], np.int64), np.array([len(x) for x in held], np.int64)
+    want = {0: [1, 2], 1: [2, 1], 2: [2, 2]}
+    for rank in range(3):
+        n = ctypes.c_int64()
+        shared, action = np.zeros((4, 3), np.int32), np.zeros(4, np.uint8)
+        L.check(lib.hv_merge_halo_plan_held(L.ptr(dk), L.ptr(dc), L.ptr(hk), L.ptr(hc), 3, rank, L.ptr(shared), L.ptr(action), 4,
+                                            ctypes.byref(n)))
+        assert n.value == 2 and shared[:2].tolist() == [[1, 0, 0], [2, 2, 2]]
+        assert action[:2].tolist() == want[rank]
+
+
+def _three_rank_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from pyslam_amd.distributed import TileShardedTSDF
+    from pyslam_amd.synthetic import SyntheticRGBD
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    K = np.array(s.intrinsics)
+    backend = OracleBackedVolume()
+    fuser = TileShardedTSDF(0.02, 0.08, s.width, s.height, rank=rank, world_size=world, volume=backend)
+    # window 1: only rank 2 fuses (frames 0, 1): nothing is shared, nothing travels, rank 2 keeps its units
+    if rank == 2:
+        for i in (0, 1):
+            backend.integrate(*s[i][:2], K, s[i][2])
+    w1 = fuser.merge_halo()
+    # window 2: ranks 0 and 1 fuse overlapping views of the same place; rank 2 holds those units from window 1 WITHOUT having
+    # updated them now - its copies enter the reduced sum, so it must zero them too (ADVICE r02: A + B + 2C otherwise)
+    if rank == 0:
+        backend.integrate(*s[2][:2], K, s[2][2])
+    if rank == 1:
+        backend.integrate(*s[3][:2], K, s[3][2])
+    w2 = fuser.merge_halo()
+    # window 3: rank 1 alone revisits: units it shares with the keeper are consolidated although only one rank is dirty
+    if rank == 1:
+        backend.integrate(*s[4][:2], K, s[4][2])
+    w3 = fuser.merge_halo()
+    complete = None
+    if rank == 0:  # after the merges rank 0 (lowest holder of everything it touches) holds COMPLETE units, without a gather
+        keys = backend.unit_keys()
+        complete = backend.export_numerators(keys)
+        np.savez(os.path.join(tmpdir, "rank0_units.npz"), keys=keys, payload=complete)
+    n = fuser.gather_to_root(root=0)
+    if rank == 0:
+        keys = np.array(sorted(backend.imported))
+        np.savez(os.path.join(tmpdir, "gathered3.npz"), keys=keys, payload=backend.export_numerators(keys), n=n,
+                 w=np.array([w1[0], w2[0], w3[0]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_halo_merge_with_a_holder_that_is_not_dirty(tmp_path):
+    """World size 3 (where the round-2 plan double-counted): a rank that holds a unit from an earlier window but did not
+    update it in this one takes part in the merge as a zeroer; a unit updated by a single rank in a window is still
+    consolidated when another rank holds it.  The gathered volume equals one volume fusing all five frames, and the
+    units rank 0 holds after the merges are already complete there."""
+    import torch.multiprocessing as mp
+
+    import oracle
+    from pyslam_amd.synthetic import SyntheticRGBD
+
+    port = 29500 + ((os.getpid() + 1234) % 2000)
+    mp.spawn(_three_rank_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    z = np.load(tmp_path / "gathered3.npz")
+    assert z["w"][0] == 0 and z["w"][1] > 0 and z["w"][2] > 0
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    K = np.array(s.intrinsics)
+    full = oracle.PortTsdf(0.02, 0.08)
+    for i in range(5):
+        d, c, T = s[i]
+        full.integrate(d, c, K, T, 1.0, 4.0)
+    k, tsdf, w, col = full.dump()
+    np.testing.assert_array_equal(z["keys"], k)
+    p = z["payload"]
+    np.testing.assert_array_equal(p[..., 1], w)  # nothing counted twice, nothing lost
+    ww = np.maximum(w, 1)
+    assert np.abs(p[..., 0] / ww - tsdf).max() < 1e-4
+    r0 = np.load(tmp_path / "rank0_units.npz")
+    index = {tuple(x): i for i, x in enumerate(k)}
+    rows = [index[tuple(x)] for x in r0["keys"]]
+    np.testing.assert_array_equal(r0["payload"][..., 1], w[rows])  # complete on rank 0 before any gather
 
 
 def test_tile_bounds_partition_the_image():

@@ -113,3 +113,33 @@ def test_pool_that_cannot_grow_fails_before_fusing(monkeypatch):
         probe.integrate(RGBDImage.create_from_color_and_depth(f[1], f[0], 1.0, 4.0, False), K, f[2])
     for a, b in zip(vol.dump(), probe.dump()):
         np.testing.assert_array_equal(a, b)
+
+
+def test_failed_claim_rollback_keeps_imported_units(monkeypatch):
+    """units that arrive through import_numerators (a gather onto the root) are not announced by a publishing
+    kernel; a later integrate call whose claims do not fit - and whose pool cannot grow - must roll back to a state that
+    still contains them.  The rollback works in place (no second pool)."""
+    from pyslam_amd._lib import HipVolError
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+
+    monkeypatch.setenv("HV_AUTO_GROW", "0")
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    src = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 13)
+    d0, c0, T0 = s[0]
+    src.integrate(RGBDImage.create_from_color_and_depth(c0, d0, 1.0, 4.0, False), K, T0)
+    keys = src.unit_keys()
+    payload = src.export_numerators(keys)
+    vol = ScalableTSDFVolume(0.02, 0.08, max_blocks=len(keys) + 8)
+    vol.import_numerators(keys, payload)
+    before = vol.dump()
+    assert len(before[0]) == len(keys)
+    d1, c1, T1 = s[80]  # another view: far more new units than the 8 that are free
+    with pytest.raises(HipVolError, match="NOT fused"):
+        vol.integrate(RGBDImage.create_from_color_and_depth(c1, d1, 1.0, 4.0, False), K, T1)
+    for a, b in zip(vol.dump(), before):
+        np.testing.assert_array_equal(a, b)  # every imported unit is still there, bit for bit
+    vol.reserve_blocks(1 << 13)
+    vol.integrate(RGBDImage.create_from_color_and_depth(c1, d1, 1.0, 4.0, False), K, T1)
+    assert vol.num_blocks() > len(keys)

@@ -292,3 +292,36 @@ def test_touch_pass_paths_open_the_same_units(box_bits, monkeypatch):
             cpu.integrate(depth, rgb, K.as_array(), T, 1.0, 4.0)
         assert gpu.dropped_points() == 0
         assert_same_volume(gpu, cpu, swept=True)
+
+
+@pytest.mark.parametrize("u16", [False, True])
+def test_integrate_frames_host_staging_matches_device_batches(u16, monkeypatch):
+    """hv_tsdf_integrate_frames: host keyframes given one pageable array per frame go through the pipelined staging
+    (worker threads -> two page-locked slots -> copy stream -> two device sets; 1 MB sub-chunks here so that slots and
+    sets are reused several times, back-to-back calls, a call of one frame) and must give exactly the volume of the same
+    frames fused from device-resident batches - and the oracle's."""
+    import torch
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    monkeypatch.setenv("HV_STAGE_CHUNK_MB", "1")
+    s, frames = synthetic_frames("tiny_160x120_2cm", 0, 61)
+    if u16:
+        frames = [((f[0] * 5000.0).astype(np.uint16), f[1], f[2]) for f in frames]
+    scale = 5000.0 if u16 else 1.0
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    a = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 13)
+    b = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 13)
+    cpu = oracle.PortTsdf(0.02, 0.08, threads=8)
+    cuts = [0, 24, 25, 45, 61]  # 24 frames, 1 frame, 20 frames, 16 frames
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = frames[lo:hi]
+        T = np.stack([f[2] for f in part])
+        # separate allocations, deliberately not contiguous with each other
+        a.integrate_frames([np.array(f[0]) for f in part], [np.array(f[1]) for f in part], K, T, depth_scale=scale, depth_trunc=4.0)
+        b.integrate_batch(torch.from_numpy(np.stack([f[0] for f in part])).cuda(), torch.from_numpy(np.stack([f[1] for f in part])).cuda(),
+                          K, T, depth_scale=scale, depth_trunc=4.0)
+        for d, c, Tcw in part:
+            cpu.integrate(d, c, K.as_array(), Tcw, scale, 4.0)
+    for x, y in zip(a.dump(), b.dump()):
+        np.testing.assert_array_equal(x, y)
+    assert_same_volume(a, cpu, swept=True)
