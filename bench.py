@@ -278,6 +278,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-step", type=int, default=32)
+    ap.add_argument("--clock-ramp-steps", type=int, default=60, help="untimed steps before the warm-up steps (device clock ramp, ~40 ms)")
     ap.add_argument("--config", default="synthetic_640x480_5mm")
     ap.add_argument("--window", choices=["sliding", "replay"], default="sliding")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
@@ -348,6 +349,12 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # clock ramp (not a warm-up step, not timed): a fresh box starts the timed region on idle clocks - the 5 warm-up steps of the
+    # driver's default command are 3 ms of work, and the first ~15 ms of sustained load run 10-15 % slower (tools/sweep_variants.py:
+    # first pass of a process 660 us per sweep, every later pass 575-585).  The same step, repeated on the volume the warm-up uses.
+    for k in range(args.clock_ramp_steps):
+        step(k % max(1, n_distinct // B))
+    fence()
     for k in range(args.warmup):
         step(k)
     fence()
@@ -358,8 +365,19 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    merge = None
     if world > 1 and args.sharding == "tile":
-        fuser.merge_halo()  # tile sharding leaves partial means on the units several ranks updated: all-reduce of those units (timed)
+        # tile sharding leaves partial means on the units several ranks updated: all-reduce of those units over RCCL (timed, and
+        # reported on its own so that the first multi-GPU run can be read: fuse time vs merge time vs bytes moved)
+        fence()
+        t_fuse = time.perf_counter() - t0
+        tm = time.perf_counter()
+        n_shared, n_dirty = fuser.merge_halo()
+        fence()
+        merge = {"ms": round((time.perf_counter() - tm) * 1e3, 3), "fuse_ms": round(t_fuse * 1e3, 3), "shared_units": int(n_shared),
+                 "dirty_units_this_rank": int(n_dirty), "bytes_all_reduced": int(fuser.last_halo["payload_bytes"]),
+                 "what": "one merge_halo() after the timed steps: all-gather of dirty / held unit keys, all-reduce(SUM) of the shared units' "
+                         "numerators (81 920 B per unit) in 64 MB buckets, unpack; inside the timed region"}
     fence()
     elapsed = time.perf_counter() - t0
     launch_ms = vol.profile_launches()
@@ -548,6 +566,7 @@ def main():
                     f"units; no collective while fusing" if args.sharding == "owner"
                     else f"{world} vertical image tiles + RCCL merge of the shared units (timed)"),
                 "units_allocated": units_allocated,
+                "clock_ramp_steps": args.clock_ramp_steps,
                 "build_digest": digest,
             },
             "roofline": roofline,
@@ -560,6 +579,8 @@ def main():
         }
         if cpu is not None and world == 1:
             out["speedup_vs_cpu"] = round(fps / cpu["fps"], 1)
+        if merge is not None:
+            out["merge"] = merge
         if online is not None:
             om = {"value": round(online["fps"], 2), "unit": "frames/s",
                   "what": "one hv_tsdf_integrate per frame (pySLAM's online flow), same sliding stream, fresh volume", "roofline": None}

@@ -137,7 +137,23 @@ __device__ __forceinline__ void hv_touch_patch(const HvTable &table, const HvFra
     if (sj < ns_w && si < ns_h) {
         const int i = si * P.stride;
         const int j = sj * P.stride;
-        const float p = hv_convert_depth(P, depth_f, (int64_t)i * P.W + j);
+        float p = hv_convert_depth(P, depth_f, (int64_t)i * P.W + j);
+        if (P.tiled && p > 0.0f) {
+            // Tile-sharded volume: a sample far outside this GPU's image tile cannot open a unit that projects into the tile
+            // (hv_unit_hits_tile would refuse every one of them) - leave before the double-precision back-projection.  The
+            // sample's units lie within rad = unit diagonal + sdf_trunc of its point; for a point q that close, with camera
+            // depth >= zn = p - rad > 0, |u_q - u_s| <= (rad / zn) (fx + |u_s - cx|) (same for v).  Border tiles extend
+            // outwards without bound, as in hv_unit_hits_tile.
+            const float rad = (float)(P.unit_length * 1.7320508075688772 + P.sdf_trunc_d) * 1.001f;
+            const float zn = p - rad;
+            if (zn > 0.05f) {
+                const float k = rad / zn;
+                const float mu = k * (P.fx + fabsf((float)j - P.cx)) + 4.0f, mv = k * (P.fy + fabsf((float)i - P.cy)) + 4.0f;
+                const bool out_u = (P.tile_u0 > 0 && (float)j + mu < (float)P.tile_u0) || (P.tile_u1 < P.W && (float)j - mu >= (float)P.tile_u1);
+                const bool out_v = (P.tile_v0 > 0 && (float)i + mv < (float)P.tile_v0) || (P.tile_v1 < P.H && (float)i - mv >= (float)P.tile_v1);
+                if (out_u || out_v) p = 0.0f;
+            }
+        }
         if (p > 0.0f) {
             const double z = (double)p;
             const double x = ((double)j - P.cx_d) * z / P.fx_d;
@@ -790,6 +806,13 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
         // record stores; every wave access is a contiguous burst (prep blocks cover 1024 pixels each)
         const int64_t i0 = ((int64_t)bx * blockDim.x + threadIdx.x) * 4;
         if (i0 >= npx) return;
+        if (P.tiled && (P.W & 3) == 0) {
+            // tile-sharded volume: only voxels that project into this GPU's tile gather a record (the sweep's image-range test
+            // uses the tile's bounds), so only the tile's columns and rows are packed (+ 4 pixels: a garbage lane may read
+            // outside, its value is never used)
+            const int u = (int)(i0 % P.W), v = (int)(i0 / P.W);
+            if (u + 3 < P.tile_u0 - 4 || u >= P.tile_u1 + 4 || v < P.tile_v0 - 4 || v >= P.tile_v1 + 4) return;
+        }
         uint2 *dst = frame_px + (int64_t)f * npx + i0;
         // mult12 != nullptr: 12-byte records {depth, colour, multiplier} (the fold form of the sweep gathers a voxel's pixel
         // with ONE load; the multiplier comes from the per-pixel table, which is built before this launch)
@@ -1626,8 +1649,8 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep_fold
 // 12-byte frame records only ({depth, colour | 1 << 24, multiplier}: one gather per voxel visit).  Registers: 3 x 16
 // accumulators (sum t, r | b << 16, g << 8 | n << 24) + two gather groups.
 // ================================================================================================
-template <int SPLIT, int WPE, int GV, int PIPE, bool ANYSKIP>
-__global__ __launch_bounds__(64 * 4 / SPLIT, WPE) void k_tsdf_sweep_column(
+template <int SPLIT, int GV, int PIPE, bool ANYSKIP>
+__device__ __forceinline__ void hv_sweep_column_body(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
     char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
     int general, const float *__restrict__ mult, int xcd_aware, int parity) {
@@ -1915,6 +1938,31 @@ __global__ __launch_bounds__(64 * 4 / SPLIT, WPE) void k_tsdf_sweep_column(
         }
     }
 }
+
+// The kernels proper.  WPE = the waves per SIMD the register allocation is capped for (4: 128 VGPRs).  The _v120 / _v112
+// entries cap the allocation at 120 / 112 registers instead (amdgpu_num_vgpr counts half of the unified file on gfx950): four
+// sweep waves then leave 32 / 64 registers of every SIMD free, enough for waves of the NEXT batch's touch + pack launch
+// (56 VGPRs) to be resident beside them - without that, the second queue only gets a wave slot when a sweep wave retires
+// (profiles/r02/pipeline_timeline.txt), which is what an 8-rank share cannot afford.
+template <int SPLIT, int WPE, int GV, int PIPE, bool ANYSKIP>
+__global__ __launch_bounds__(64 * 4 / SPLIT, WPE) void k_tsdf_sweep_column(
+    HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
+    char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
+    int general, const float *__restrict__ mult, int xcd_aware, int parity) {
+    hv_sweep_column_body<SPLIT, GV, PIPE, ANYSKIP>(table, list, frame_mask, pool, frame_px, Ps, n_frames, general, mult, xcd_aware, parity);
+}
+#define HV_SWEEP_COLUMN_CAPPED(NAME, HALF_VGPRS)                                                                        \
+    template <int SPLIT, int GV, int PIPE, bool ANYSKIP>                                                                \
+    __global__ __launch_bounds__(64 * 4 / SPLIT) __attribute__((amdgpu_num_vgpr(HALF_VGPRS))) void NAME(               \
+        HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,             \
+        char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames, \
+        int general, const float *__restrict__ mult, int xcd_aware, int parity) {                                       \
+        hv_sweep_column_body<SPLIT, GV, PIPE, ANYSKIP>(table, list, frame_mask, pool, frame_px, Ps, n_frames, general, mult,  \
+                                                       xcd_aware, parity);                                              \
+    }
+HV_SWEEP_COLUMN_CAPPED(k_tsdf_sweep_column_v120, 60)
+HV_SWEEP_COLUMN_CAPPED(k_tsdf_sweep_column_v112, 56)
+#undef HV_SWEEP_COLUMN_CAPPED
 
 // After the sweep (one workgroup): clear the frame masks of the batch's units and zero the batch's touched-list counter, so
 // that the next batch / online frame starts clean without a memset launch per counter.
@@ -2449,9 +2497,16 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
             const int xcd_aware = getenv("HV_TSDF_SWEEP_XCD") ? atoi(getenv("HV_TSDF_SWEEP_XCD")) : 2;
             const int anyskip = getenv("HV_TSDF_SWEEP_ANYSKIP") ? atoi(getenv("HV_TSDF_SWEEP_ANYSKIP")) : 1;
             const int gv = getenv("HV_TSDF_SWEEP_GV") ? atoi(getenv("HV_TSDF_SWEEP_GV")) : 4;
-            const int pipe = getenv("HV_TSDF_SWEEP_PIPE") ? atoi(getenv("HV_TSDF_SWEEP_PIPE")) : 2;
+            const int pipe = getenv("HV_TSDF_SWEEP_PIPE") ? atoi(getenv("HV_TSDF_SWEEP_PIPE")) : 1;
             const int csplit = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : 4;
-            if (csplit == 1) {
+            const int vcap = getenv("HV_TSDF_SWEEP_VCAP") ? atoi(getenv("HV_TSDF_SWEEP_VCAP")) : 0;
+#define HV_LAUNCH_COLUMN_CAPPED(NAME, S, GV, PIPE)                                                                      \
+    hipLaunchKernelGGL((NAME<S, GV, PIPE, true>), dim3(sweep_grid), dim3(64 * 4 / S), 0, v->stream, v->table, d_list, d_mask, \
+                       (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware, parity)
+            if (vcap == 120 || vcap == 112) {
+                if (vcap == 120) { if (gv == 2) HV_LAUNCH_COLUMN_CAPPED(k_tsdf_sweep_column_v120, 4, 2, 1); else HV_LAUNCH_COLUMN_CAPPED(k_tsdf_sweep_column_v120, 4, 4, 1); }
+                else { if (gv == 2) HV_LAUNCH_COLUMN_CAPPED(k_tsdf_sweep_column_v112, 4, 2, 1); else HV_LAUNCH_COLUMN_CAPPED(k_tsdf_sweep_column_v112, 4, 4, 1); }
+            } else if (csplit == 1) {
                 HV_LAUNCH_COLUMN(1, 4, 4, 1, true);
             } else if (csplit == 2) {
                 if (pipe == 2) HV_LAUNCH_COLUMN(2, 4, 4, 2, true); else HV_LAUNCH_COLUMN(2, 4, 4, 1, true);
@@ -2518,6 +2573,7 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
 #undef HV_LAUNCH_SWEEP
 #undef HV_LAUNCH_FOLD
 #undef HV_LAUNCH_COLUMN
+#undef HV_LAUNCH_COLUMN_CAPPED
         hv_profile_end(v, B);
         hipLaunchKernelGGL(k_tsdf_batch_finish, dim3(1), dim3(1024), 0, v->stream, v->table, d_list, d_mask_rw, parity, v->d_status,
                            hv_next_status_seq(v));

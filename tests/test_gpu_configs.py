@@ -7,7 +7,7 @@ import pytest
 
 import oracle
 from oracle import host_prep as hp
-from tests.conftest import synthetic_frames
+from tests.conftest import FOLD_TSDF_TOL, sweep_is_bitwise, synthetic_frames
 
 pytestmark = pytest.mark.gpu
 
@@ -30,7 +30,7 @@ def test_tsdf_frame_matches_oracle(config, voxel, trunc, max_blocks):
     assert gpu.num_blocks() == cpu.num_units()
     perm = np.arange(4096).reshape(16, 16, 16).transpose(2, 0, 1).reshape(-1)  # internal index z*256+x*16+y -> oracle index x*256+y*16+z
 
-    def compare_sample():
+    def compare_sample(swept=False):
         """A deterministic sample of ~200 units in full (a full dump at 2 mm is several GB on the host): weights exact,
         tsdf bitwise (as the f32 numerator tsdf*w both sides form identically), colour <= 1e-4 on [0, 1]."""
         ka = gpu.unit_keys()
@@ -40,7 +40,10 @@ def test_tsdf_frame_matches_oracle(config, voxel, trunc, max_blocks):
         payload = gpu.export_numerators(kb[sel])
         wb_i, tb_i, cb_i = wb[sel][:, perm], tb[sel][:, perm], cb[sel][:, perm]
         np.testing.assert_array_equal(payload[..., 1], wb_i)
-        np.testing.assert_array_equal(payload[..., 0], tb_i * wb_i)
+        if swept and not sweep_is_bitwise():  # the production sweep folds a batch per voxel: tsdf to FOLD_TSDF_TOL
+            assert np.abs(payload[..., 0] / np.maximum(wb_i, 1.0) - tb_i).max() <= FOLD_TSDF_TOL
+        else:
+            np.testing.assert_array_equal(payload[..., 0], tb_i * wb_i)
         mean = payload[..., 2:5].astype(np.float64) / np.maximum(wb_i, 1.0)[..., None]
         assert np.abs(mean - cb_i).max() / 255.0 <= 1e-4
         return int(wb_i.max())
@@ -53,7 +56,7 @@ def test_tsdf_frame_matches_oracle(config, voxel, trunc, max_blocks):
     for d, c, Tcw in more:
         cpu.integrate(d, c, K.as_array(), Tcw, 1.0, 4.0)
     assert gpu.num_blocks() == cpu.num_units()
-    assert compare_sample() >= 8
+    assert compare_sample(swept=True) >= 8
     assert gpu.dropped_points() == 0
 
 

@@ -74,7 +74,7 @@ def h2d_rate_gbs(n_bytes=256 << 20, reps=5):
     return best
 
 
-def host_leg(s, depth_h, rgb_h, T_h, voxel, sdf_trunc, depth_trunc, B=32, steps=6, front_frames=48):
+def host_leg(s, depth_h, rgb_h, T_h, voxel, sdf_trunc, depth_trunc, B=32, steps=6, front_frames=48, front=True):
     import torch
 
     from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
@@ -136,6 +136,8 @@ def host_leg(s, depth_h, rgb_h, T_h, voxel, sdf_trunc, depth_trunc, B=32, steps=
     out["online_host"] = {"value": round(n_on / (time.perf_counter() - t0), 1), "unit": "frames/s",
                           "call": "one integrate() per keyframe from host arrays (hv_tsdf_integrate, HV_HOST)"}
     del vol
+    if not front:
+        return out
     # the whole front once
     try:
         out["front"] = front_leg(s, depths, colors, T_h, voxel, sdf_trunc, min(front_frames, n))
@@ -165,24 +167,28 @@ def front_leg(s, depths, colors, T_h, voxel, sdf_trunc, n_frames):
         # first keyframe alone: the worker's one-off costs (library load, pool, first output)
         integ.add_keyframe(kfs[0], kfs[0].img, None, kfs[0].depth_img)
         integ.add_update_output_task()
-        first = None
-        t0 = time.time()
-        while first is None and time.time() - t0 < 120:
-            first = integ.pop_output(timeout=0.5)
+        from pyslam_amd.dense import VolumetricIntegrationTaskType
+
+        # both outputs of the first keyframe (its own and the requested one) are consumed before the clock starts
+        seen, t0 = 0, time.time()
+        while seen < 2 and time.time() - t0 < 120:
+            seen += integ.pop_output(timeout=0.5) is not None
         t1 = time.perf_counter()
         for kf in kfs[1:]:
             integ.add_keyframe(kf, kf.img, None, kf.depth_img)
         t_enqueue = time.perf_counter() - t1
         integ.add_update_output_task()
         last = None
+        # (add_task pushes INTEGRATE tasks to the FRONT of the queue, as the reference does - base.py:1216-1232 - so the worker
+        # sees the newest keyframe first; the UPDATE_OUTPUT task sits at the back and is reached when every keyframe is fused)
         while time.perf_counter() - t1 < 300:
             o = integ.pop_output(timeout=0.5)
-            if o is not None and o.id == kfs[-1].id and o.mesh is not None:
+            if o is not None and o.task_type == VolumetricIntegrationTaskType.UPDATE_OUTPUT and o.mesh is not None:
                 last = o
                 break
         dt = time.perf_counter() - t1
         if last is None:
-            raise RuntimeError("no output for the last keyframe")
+            raise RuntimeError("no output after the last keyframe")
         return {"value": round((n_frames - 1) / dt, 1), "unit": "frames/s", "frames": n_frames - 1,
                 "enqueue_s": round(t_enqueue, 3), "total_s": round(dt, 3), "mesh_vertices": int(len(last.mesh.vertices)),
                 "what": "add_keyframe x N (pickled through the multiprocessing queue) -> worker: rectify / BGR->RGB -> integrate_frames -> "
@@ -195,4 +201,7 @@ if __name__ == "__main__":
     import bench
 
     s, d, c, T = bench.load_frames("synthetic_640x480_5mm", 192)
-    print(json.dumps(host_leg(s, d, c, T, bench.VOXEL, bench.SDF_TRUNC, bench.DEPTH_TRUNC)))
+    out = host_leg(s, d, c, T, bench.VOXEL, bench.SDF_TRUNC, bench.DEPTH_TRUNC, front="--no-front" not in sys.argv)
+    out["env"] = {k: v for k, v in os.environ.items() if k.startswith("HV_STAGE")}
+    out["cpus"] = os.cpu_count()
+    print(json.dumps(out))

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=32)
     ap.add_argument("--config", default="synthetic_640x480_5mm")
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--owner", default="", help="rank/world: time one rank's share of the unit-ownership sharding (hv_tsdf_set_owner)")
     ap.add_argument("variants", nargs="*", default=["HV_TSDF_SWEEP=3"])
     args = ap.parse_args()
     import torch
@@ -41,6 +42,9 @@ def main():
     rgb_d = torch.from_numpy(rgb_h[wrap]).cuda()
     T_res = T_h[wrap]
     vol = ScalableTSDFVolume(bench.VOXEL, bench.SDF_TRUNC, max_blocks=1 << 17, max_points=s.width * s.height)
+    if args.owner:
+        r, w = (int(x) for x in args.owner.split("/"))
+        vol.set_owner(r, w)
     results = {}
     out = os.path.join(ROOT, "gpurun_out", "sweep_variants.jsonl")
     os.makedirs(os.path.dirname(out), exist_ok=True)
