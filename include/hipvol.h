@@ -289,6 +289,10 @@ int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, 
                          int64_t *n_triangles);
 /* extract_point_cloud() (volumetric_integrator_tsdf.py:246,267): points/colors f64 [N,3]. */
 int hv_tsdf_extract_points(hv_volume *v, double *points, double *colors, int64_t cap, int64_t *n);
+/* The normals Open3D's extract_point_cloud() attaches to those points (ScalableTSDFVolume::GetNormalAt: central differences of
+ * the trilinearly interpolated tsdf at +/- 0.99 voxel, normalised); o3d.io.write_point_cloud stores them in dense_map.ply
+ * (volumetric_integrator_tsdf.py:246-247).  normals f64 [N,3] in the order of hv_tsdf_extract_points; NULL to query *n. */
+int hv_tsdf_extract_point_normals(hv_volume *v, double *normals, int64_t cap, int64_t *n);
 
 /* Parity/debug export, units sorted by (x,y,z) index: keys [U,3] i32; tsdf, weight [U,R^3] f32;
  * color [U,R^3,3] f64 = running-mean RGB on the 0..255 scale; voxel order = Open3D's IndexOf

@@ -84,6 +84,8 @@ def _load_port():
     L.to_extract_mesh.argtypes = [_vp, _vp, _vp, _i64, _vp, _i64, _vp]
     L.to_extract_points.restype = _i64
     L.to_extract_points.argtypes = [_vp, _vp, _vp, _i64]
+    L.to_point_normals.restype = None
+    L.to_point_normals.argtypes = [_vp, _vp, _i64, _vp]
     L.to_invert4x4.argtypes = [_vp, _vp]
     return L
 
@@ -415,6 +417,13 @@ class PortTsdf:
         cols = np.zeros((n, 3), np.float64)
         self._lib.to_extract_points(self._h, _ptr(pts), _ptr(cols), n)
         return pts, cols
+
+    def point_normals(self, points):
+        """ScalableTSDFVolume::GetNormalAt for each point [N,3] f64 (the normals o3d's extract_point_cloud() carries)."""
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        normals = np.zeros_like(points)
+        self._lib.to_point_normals(self._h, _ptr(points), len(points), _ptr(normals))
+        return normals
 
 
 def invert4x4(T):

@@ -526,8 +526,8 @@ int64_t to_extract_mesh(const to_volume *v, double *vertices, double *vertex_col
     return nv;
 }
 
-/* ScalableTSDFVolume::ExtractPointCloud (points + colours; normals are not consumed by pySLAM's
- * VolumetricIntegrationPointCloud, volumetric_integrator_base.py:159-206, and are not restated). */
+/* ScalableTSDFVolume::ExtractPointCloud: points + colours here, the normals (o3d.io.write_point_cloud stores them in
+ * dense_map.ply, volumetric_integrator_tsdf.py:246-247) in to_point_normals below. */
 int64_t to_extract_points(const to_volume *v, double *points, double *colors, int64_t cap) {
     const int R = v->res;
     const double half_voxel_length = v->voxel_length * 0.5;
@@ -570,4 +570,64 @@ int64_t to_extract_points(const to_volume *v, double *points, double *colors, in
                 }
     }
     return n;
+}
+
+/* ScalableTSDFVolume::GetTSDFAt(p): trilinear interpolation of the tsdf values of the eight voxels around p (weights are
+ * NOT looked at: a voxel that was never observed contributes its initial tsdf 0; a unit that does not exist contributes 0). */
+static double to_tsdf_at(const to_volume *v, const double *p) {
+    const int R = v->res;
+    double p_locate[3];
+    int32_t index0[3];
+    for (int i = 0; i < 3; ++i) {
+        p_locate[i] = p[i] - 0.5 * v->voxel_length;
+        index0[i] = (int32_t)floor(p_locate[i] / v->unit_length);
+    }
+    const int64_t u0 = to_find(v, index0[0], index0[1], index0[2]);
+    if (u0 < 0) return 0.0;
+    int idx0[3];
+    double r[3];
+    for (int i = 0; i < 3; ++i) {
+        const double p_grid = (p_locate[i] - (double)index0[i] * v->unit_length) / v->voxel_length;
+        idx0[i] = (int)floor(p_grid);
+        if (idx0[i] < 0) idx0[i] = 0;
+        if (idx0[i] >= R) idx0[i] = R - 1;
+        r[i] = p_grid - (double)idx0[i];
+    }
+    static const int shift[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+    float f[8];
+    for (int i = 0; i < 8; ++i) {
+        int32_t index1[3] = {index0[0], index0[1], index0[2]};
+        int idx1[3] = {idx0[0] + shift[i][0], idx0[1] + shift[i][1], idx0[2] + shift[i][2]};
+        int64_t u = u0;
+        if (!(idx1[0] < R && idx1[1] < R && idx1[2] < R)) {
+            for (int j = 0; j < 3; ++j)
+                if (idx1[j] >= R) {
+                    idx1[j] -= R;
+                    index1[j] += 1;
+                }
+            u = to_find(v, index1[0], index1[1], index1[2]);
+        }
+        f[i] = u < 0 ? 0.0f : v->units[u].voxels[(idx1[0] * R + idx1[1]) * R + idx1[2]].tsdf;
+    }
+    return (1 - r[0]) * ((1 - r[1]) * ((1 - r[2]) * f[0] + r[2] * f[4]) + r[1] * ((1 - r[2]) * f[3] + r[2] * f[7])) +
+           r[0] * ((1 - r[1]) * ((1 - r[2]) * f[1] + r[2] * f[5]) + r[1] * ((1 - r[2]) * f[2] + r[2] * f[6]));
+}
+
+/* ScalableTSDFVolume::GetNormalAt for every point of an extracted cloud: central differences of GetTSDFAt at +/- 0.99 voxel
+ * along each axis, normalised (Eigen's normalized(): the zero vector stays zero). */
+void to_point_normals(const to_volume *v, const double *points, int64_t n, double *normals) {
+    const double half_gap = 0.99 * v->voxel_length;
+    for (int64_t k = 0; k < n; ++k) {
+        double nn[3];
+        for (int i = 0; i < 3; ++i) {
+            double p0[3] = {points[k * 3], points[k * 3 + 1], points[k * 3 + 2]}, p1[3] = {p0[0], p0[1], p0[2]};
+            p0[i] -= half_gap;
+            p1[i] += half_gap;
+            nn[i] = to_tsdf_at(v, p1) - to_tsdf_at(v, p0);
+        }
+        const double z = nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2];
+        const double s = z > 0.0 ? 1.0 / sqrt(z) : 1.0;
+        for (int i = 0; i < 3; ++i) normals[k * 3 + i] = z > 0.0 ? nn[i] / sqrt(z) : nn[i];
+        (void)s;
+    }
 }

@@ -541,6 +541,80 @@ __global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *_
     }
 }
 
+// ScalableTSDFVolume::GetNormalAt for every extracted point (the normals Open3D's point cloud carries into dense_map.ply,
+// volumetric_integrator_tsdf.py:246-247): central differences, at +/- 0.99 voxel along each axis, of GetTSDFAt = the trilinear
+// interpolation of the eight voxels around a position.  GetTSDFAt does not look at weights (a voxel never observed holds its
+// initial tsdf 0) and a missing unit contributes 0.  One thread per point; the unit of the previous fetch is remembered (most
+// of the 48 fetches of a point fall into one or two units), the arithmetic is Open3D's, in double.
+__device__ __forceinline__ float hv_tsdf_voxel(const HvTable &table, const char *__restrict__ pool, int32_t ux, int32_t uy, int32_t uz,
+                                               int x, int y, int z, unsigned long long &cached_key, int32_t &cached_idx) {
+    if (!hv_key_in_range(ux, uy, uz)) return 0.0f;
+    const unsigned long long key = hv_pack_key(ux, uy, uz);
+    if (key != cached_key) {
+        const int32_t slot = hv_table_find(table, key);
+        cached_key = key;
+        cached_idx = slot >= 0 ? table.vals[slot] : -1;
+    }
+    if (cached_idx < 0) return 0.0f;
+    return ((const float *)(pool + (int64_t)cached_idx * UNIT_BYTES))[voxel_word(x, y, z)];
+}
+
+__device__ inline double hv_tsdf_at(const HvTable &table, const char *__restrict__ pool, double voxel_length, double unit_length,
+                                    const double *p, unsigned long long &ck, int32_t &ci) {
+    int32_t index0[3];
+    int idx0[3];
+    double r[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double p_locate = p[i] - 0.5 * voxel_length;
+        index0[i] = (int32_t)floor(p_locate / unit_length);
+        const double p_grid = (p_locate - (double)index0[i] * unit_length) / voxel_length;
+        int q = (int)floor(p_grid);
+        q = q < 0 ? 0 : (q >= R ? R - 1 : q);
+        idx0[i] = q;
+        r[i] = p_grid - (double)q;
+    }
+    {   // the unit of p itself decides "no such unit -> 0" (GetTSDFAt returns before looking at neighbours)
+        unsigned long long k0 = HV_EMPTY_KEY;
+        int32_t i0 = -1;
+        (void)hv_tsdf_voxel(table, pool, index0[0], index0[1], index0[2], 0, 0, 0, k0, i0);
+        if (i0 < 0) return 0.0;
+        ck = k0;
+        ci = i0;
+    }
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int sx = (i == 1 || i == 2 || i == 5 || i == 6), sy = (i == 2 || i == 3 || i == 6 || i == 7), sz = i >= 4;
+        int x = idx0[0] + sx, y = idx0[1] + sy, z = idx0[2] + sz;
+        const int32_t ux = index0[0] + (x >= R), uy = index0[1] + (y >= R), uz = index0[2] + (z >= R);
+        f[i] = hv_tsdf_voxel(table, pool, ux, uy, uz, x & (R - 1), y & (R - 1), z & (R - 1), ck, ci);
+    }
+    return (1 - r[0]) * ((1 - r[1]) * ((1 - r[2]) * f[0] + r[2] * f[4]) + r[1] * ((1 - r[2]) * f[3] + r[2] * f[7])) +
+           r[0] * ((1 - r[1]) * ((1 - r[2]) * f[1] + r[2] * f[5]) + r[1] * ((1 - r[2]) * f[2] + r[2] * f[6]));
+}
+
+__global__ __launch_bounds__(256) void k_pc_normals(HvTable table, const char *__restrict__ pool, double voxel_length, double unit_length,
+                                                     const double *__restrict__ points, int64_t n, double *__restrict__ normals) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double half_gap = 0.99 * voxel_length;
+    unsigned long long ck = HV_EMPTY_KEY;
+    int32_t ci = -1;
+    double nn[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double p0[3] = {points[k * 3], points[k * 3 + 1], points[k * 3 + 2]}, p1[3] = {p0[0], p0[1], p0[2]};
+        p0[i] -= half_gap;
+        p1[i] += half_gap;
+        nn[i] = hv_tsdf_at(table, pool, voxel_length, unit_length, p1, ck, ci) - hv_tsdf_at(table, pool, voxel_length, unit_length, p0, ck, ci);
+    }
+    const double z = nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2];
+    const double s = sqrt(z);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) normals[k * 3 + i] = z > 0.0 ? nn[i] / s : nn[i]; // Eigen's normalized(): the zero vector stays zero
+}
+
 // ------------------------------------------------------------------------------------------------
 static bool g_tables_uploaded[64] = {false};
 
@@ -727,6 +801,29 @@ int hv_tsdf_extract_points(hv_volume *v, double *points, double *colors, int64_t
         HV_HIP(hipMemcpyAsync(colors, d_cols, sizeof(double) * 3 * m, hipMemcpyDeviceToHost, v->stream));
         HV_HIP(hipStreamSynchronize(v->stream));
     }
+    return HV_OK;
+}
+
+int hv_tsdf_extract_point_normals(hv_volume *v, double *normals, int64_t cap, int64_t *n) {
+    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_tsdf_extract_point_normals: null argument");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_extract_point_normals: volume is not in TSDF mode");
+    HV_HIP(hipSetDevice(v->device));
+    if (v->points_cache_version != v->content_version) {
+        const int rc = points_compute(v);
+        if (rc != HV_OK) return rc;
+    }
+    *n = v->points_cache_n;
+    if (normals == nullptr || cap <= 0 || v->points_cache_n == 0) return HV_OK;
+    const int64_t m = std::min<int64_t>(v->points_cache_n, cap);
+    int rc = hv_ensure_buffer(v, &v->out_b, &v->out_b_bytes, sizeof(double) * 3 * (size_t)m);
+    if (rc != HV_OK) return rc;
+    hv_profile_begin(v);
+    hipLaunchKernelGGL(k_pc_normals, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, v->stream, v->table, (const char *)v->pool,
+                       v->cfg.voxel_size, v->cfg.voxel_size * (double)R, (const double *)v->out_a, m, (double *)v->out_b);
+    hv_profile_end(v, 0);
+    HV_HIP(hipGetLastError());
+    HV_HIP(hipMemcpyAsync(normals, v->out_b, sizeof(double) * 3 * m, hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipStreamSynchronize(v->stream));
     return HV_OK;
 }
 

@@ -8,18 +8,26 @@ def _colors_u8(colors):
     return np.clip(np.rint(np.asarray(colors, dtype=np.float64) * 255.0), 0, 255).astype(np.uint8)
 
 
-def write_ply_points(path, points, colors=None):
+def write_ply_points(path, points, colors=None, normals=None):
+    """Property order as Open3D's WritePointCloudToPLY: x y z, then nx ny nz when the cloud has normals, then the colours."""
     points = np.asarray(points, dtype=np.float64).reshape(-1, 3)
     has_c = colors is not None and len(colors) == len(points)
+    has_n = normals is not None and len(normals) == len(points)
     header = ["ply", "format binary_little_endian 1.0", "comment Created by pyslam_amd", f"element vertex {len(points)}",
               "property double x", "property double y", "property double z"]
     fields = [("x", "<f8"), ("y", "<f8"), ("z", "<f8")]
+    if has_n:
+        header += ["property double nx", "property double ny", "property double nz"]
+        fields += [("nx", "<f8"), ("ny", "<f8"), ("nz", "<f8")]
     if has_c:
         header += ["property uchar red", "property uchar green", "property uchar blue"]
         fields += [("r", "u1"), ("g", "u1"), ("b", "u1")]
     header.append("end_header")
     rec = np.zeros(len(points), dtype=fields)
     rec["x"], rec["y"], rec["z"] = points[:, 0], points[:, 1], points[:, 2]
+    if has_n:
+        nn = np.asarray(normals, dtype=np.float64).reshape(-1, 3)
+        rec["nx"], rec["ny"], rec["nz"] = nn[:, 0], nn[:, 1], nn[:, 2]
     if has_c:
         c = _colors_u8(colors)
         rec["r"], rec["g"], rec["b"] = c[:, 0], c[:, 1], c[:, 2]
@@ -66,7 +74,9 @@ def read_ply(path):
         nf_l = [l for l in lines if l.startswith("element face")]
         nf = int(nf_l[0].split()[-1]) if nf_l else 0
         has_c = any("uchar red" in l for l in lines)
-        fields = [("x", "<f8"), ("y", "<f8"), ("z", "<f8")] + ([("r", "u1"), ("g", "u1"), ("b", "u1")] if has_c else [])
+        has_n = any("double nx" in l for l in lines)
+        fields = ([("x", "<f8"), ("y", "<f8"), ("z", "<f8")] + ([("nx", "<f8"), ("ny", "<f8"), ("nz", "<f8")] if has_n else [])
+                  + ([("r", "u1"), ("g", "u1"), ("b", "u1")] if has_c else []))
         v = np.frombuffer(f.read(nv * np.dtype(fields).itemsize), dtype=fields)
         faces = None
         if nf:
@@ -76,3 +86,21 @@ def read_ply(path):
     pts = np.stack([v["x"], v["y"], v["z"]], axis=1)
     cols = np.stack([v["r"], v["g"], v["b"]], axis=1) if has_c else None
     return pts, cols, faces
+
+
+def read_ply_normals(path):
+    """-> [N,3] normals of a point-cloud PLY written above, or None."""
+    with open(path, "rb") as f:
+        lines = []
+        while True:
+            line = f.readline().decode("ascii").strip()
+            lines.append(line)
+            if line == "end_header":
+                break
+        if not any("double nx" in l for l in lines):
+            return None
+        nv = int([l for l in lines if l.startswith("element vertex")][0].split()[-1])
+        has_c = any("uchar red" in l for l in lines)
+        fields = [("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("nx", "<f8"), ("ny", "<f8"), ("nz", "<f8")] + ([("r", "u1"), ("g", "u1"), ("b", "u1")] if has_c else [])
+        v = np.frombuffer(f.read(nv * np.dtype(fields).itemsize), dtype=fields)
+    return np.stack([v["nx"], v["ny"], v["nz"]], axis=1)

@@ -604,6 +604,6 @@ class VolumetricIntegratorBase:
         write_ply_mesh(path, mesh.vertices, mesh.triangles, mesh.vertex_colors)
 
     @staticmethod
-    def _save_points(path, points, colors):
+    def _save_points(path, points, colors, normals=None):
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        write_ply_points(path, points, colors)
+        write_ply_points(path, points, colors, normals)

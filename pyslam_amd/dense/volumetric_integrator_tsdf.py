@@ -114,8 +114,12 @@ class VolumetricIntegratorTsdf(VolumetricIntegratorBase):
                         if Parameters.kVolumetricIntegrationTsdfExtractMesh:
                             self._save_mesh(save_path, self.volume.extract_triangle_mesh())
                         else:
-                            pc = self.volume.extract_point_cloud()
-                            self._save_points(save_path, pc.points, pc.colors)
+                            # o3d.io.write_point_cloud stores the normals Open3D's extract_point_cloud() attaches (tsdf.py:246-247)
+                            try:
+                                pc = self.volume.extract_point_cloud(normals=True)
+                            except TypeError:  # a volume stand-in without normals (tests)
+                                pc = self.volume.extract_point_cloud()
+                            self._save_points(save_path, pc.points, pc.colors, getattr(pc, "normals", None))
                         last_output = VolumetricIntegrationOutput(ttype)
                     elif ttype == VolumetricIntegrationTaskType.UPDATE_OUTPUT:
                         do_output = True

@@ -549,9 +549,13 @@ class TriangleMesh:
 
 
 class PointCloud:
-    def __init__(self, points, colors):
+    def __init__(self, points, colors, normals=None):
         self.points = points
         self.colors = colors
+        self.normals = normals  # [N,3] f64 when asked for (Open3D's point cloud always carries them), else None
+
+    def has_normals(self):
+        return self.normals is not None and len(self.normals) == len(self.points)
 
 
 class ScalableTSDFVolume(_Volume):
@@ -654,14 +658,21 @@ class ScalableTSDFVolume(_Volume):
             )
         return TriangleMesh(verts, tris, cols)
 
-    def extract_point_cloud(self):
+    def extract_point_cloud(self, normals=False):
+        """o3d's extract_point_cloud().  normals=True also computes the per-point normals Open3D attaches (GetNormalAt: the
+        gradient of the trilinearly interpolated tsdf) - pySLAM's viewer path does not read them, its save path writes them."""
         n = ctypes.c_int64()
         L.check(self._lib.hv_tsdf_extract_points(self._h, None, None, 0, ctypes.byref(n)))
         pts = _result_array((n.value, 3), np.float64)
         cols = _result_array((n.value, 3), np.float64)
+        nrm = None
         if n.value:
             L.check(self._lib.hv_tsdf_extract_points(self._h, L.ptr(pts), L.ptr(cols), n.value, ctypes.byref(n)))
-        return PointCloud(pts, cols)
+        if normals:
+            nrm = np.zeros((n.value, 3), np.float64)
+            if n.value:
+                L.check(self._lib.hv_tsdf_extract_point_normals(self._h, L.ptr(nrm), n.value, ctypes.byref(n)))
+        return PointCloud(pts, cols, nrm)
 
     # -- parity/debug + multi-GPU ------------------------------------------------------------------
     def dump(self):

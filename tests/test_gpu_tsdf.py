@@ -325,3 +325,30 @@ def test_integrate_frames_host_staging_matches_device_batches(u16, monkeypatch):
     for x, y in zip(a.dump(), b.dump()):
         np.testing.assert_array_equal(x, y)
     assert_same_volume(a, cpu, swept=True)
+
+
+def test_point_cloud_normals_match_oracle(tmp_path):
+    """extract_point_cloud(normals=True): Open3D's GetNormalAt on the GPU vs the restatement (same double arithmetic on the same
+    tsdf values: 1e-9), and the PLY the save path writes carries them (x y z nx ny nz r g b, Open3D's property order)."""
+    from pyslam_amd.dense.ply_io import read_ply, read_ply_normals, write_ply_points
+
+    s, frames = synthetic_frames("tiny_160x120_2cm", 0, 5)
+    gpu, cpu = make_pair(0.02, 0.08, max_blocks=1 << 13)
+    integrate_both(gpu, cpu, s, frames)
+    pc = gpu.extract_point_cloud(normals=True)
+    pb, qb = cpu.extract_point_cloud()
+    nb = cpu.point_normals(pb)
+    assert pc.has_normals() and pc.points.shape == pb.shape and len(pb) > 5000
+    key_a, key_b = np.round(pc.points, 9), np.round(pb, 9)
+    ia, ib = np.lexsort(key_a.T[::-1]), np.lexsort(key_b.T[::-1])
+    np.testing.assert_allclose(pc.points[ia], pb[ib], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(pc.normals[ia], nb[ib], rtol=0, atol=1e-9)
+    lens = np.linalg.norm(pc.normals, axis=1)
+    assert ((np.abs(lens - 1.0) < 1e-9) | (lens == 0)).all()
+    assert gpu.extract_point_cloud().normals is None  # not computed unless asked for
+    path = str(tmp_path / "dense_map.ply")
+    write_ply_points(path, pc.points, pc.colors, pc.normals)
+    pts, cols, faces = read_ply(path)
+    np.testing.assert_array_equal(pts, pc.points)
+    np.testing.assert_array_equal(read_ply_normals(path), pc.normals)
+    assert faces is None and cols.shape == (len(pts), 3)
