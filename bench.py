@@ -269,6 +269,26 @@ def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_fr
             "value": round((len(pts) - 1) / dtc, 3), "unit": "frames/s", "cores": 1, "kind": kind,
             "sample": f"{len(pts) - 1} frames, integrate_raw<float,float> on the same float32 world points"
                       + (" (unmodified cpp/volumetric sources compiled by oracle/Makefile, sequential non-TBB branch)" if kind == "reference" else "")}
+    # the reference's INTENDED configuration is its TBB branch (kVolumetricIntegrationTBBThreads, config_parameters.py:314); TBB headers
+    # are not in this image, so the compiled reference above runs its sequential branch.  Beside it: the two-phase algorithm
+    # (thread-local grouping by block, merge, blocks in parallel: voxel_block_grid.hpp:292-456) restated with OpenMP on all cores.
+    try:
+        cores = os.cpu_count() or 1
+        best = None
+        for th in sorted({t for t in (2, 8, 16, 32, 64, cores) if t <= cores}):
+            c = oracle.PortGrid(VOXEL, 8)
+            c.integrate_parallel(*pts[0], threads=th)
+            t0 = time.perf_counter()
+            for p, col in pts[1:]:
+                c.integrate_parallel(p, col, threads=th)
+            fps = (len(pts) - 1) / (time.perf_counter() - t0)
+            if best is None or fps > best[0]:
+                best = (fps, th)
+        out["cpu_parallel"] = {"value": round(best[0], 3), "unit": "frames/s", "cores": best[1], "kind": "port",
+                               "sample": f"restated, {best[1]} threads: {len(pts) - 1} frames, OpenMP restatement of integrate_raw_preorder_no_block_mutex "
+                                         f"(the reference's TBB branch) on the same float32 world points; bit-identical to the sequential branch"}
+    except Exception as e:
+        out["cpu_parallel"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

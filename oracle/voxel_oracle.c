@@ -12,6 +12,9 @@
  *
  * Reference citations are relative to /root/reference/cpp/volumetric/.
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -189,6 +192,165 @@ void vo_integrate(vo_grid *g, const float *pts, int64_t n, const void *cols, int
         }
         v->count = (v->count == 0) ? 1 : v->count + 1;
     }
+}
+
+/* integrate_raw -> integrate_raw_preorder_no_block_mutex (voxel_block_grid.hpp:292-456), the reference's TBB branch, restated
+ * with OpenMP for the all-cores CPU baseline (TBB headers are not available here, so the compiled reference runs its sequential
+ * branch): phase 1 - every thread takes a contiguous range of points, computes their keys and groups the point indices by block
+ * in a thread-local map (:316-328); merge - the thread-local groups are joined per block in thread order (:333-368), which keeps
+ * a block's points in point order; phase 2 - parallel over blocks, each block is found-or-created once (sequentially, the map is
+ * not concurrent) and its points are applied one after the other (:371-456).  Same result as vo_integrate, bit for bit. */
+typedef struct { int32_t key[3]; int64_t first, count; } vo_group;      /* a thread's points of one block */
+typedef struct { int32_t *slot_key; int64_t *slot_grp; int64_t size, used; vo_group *grp; int64_t ngrp, cap; int64_t *next; } vo_local;
+
+static int64_t vo_local_group(vo_local *L, int32_t bx, int32_t by, int32_t bz) {
+    if ((L->used + 1) * 2 > L->size) {
+        const int64_t ns = L->size ? L->size * 2 : 256;
+        int32_t *nk = (int32_t *)malloc(sizeof(int32_t) * 3 * (size_t)ns);
+        int64_t *ng = (int64_t *)malloc(sizeof(int64_t) * (size_t)ns);
+        for (int64_t i = 0; i < ns; ++i) ng[i] = -1;
+        for (int64_t i = 0; i < L->size; ++i)
+            if (L->slot_grp[i] >= 0) {
+                uint64_t s = vo_mix(L->slot_key[i * 3], L->slot_key[i * 3 + 1], L->slot_key[i * 3 + 2]) & (uint64_t)(ns - 1);
+                while (ng[s] >= 0) s = (s + 1) & (uint64_t)(ns - 1);
+                memcpy(nk + s * 3, L->slot_key + i * 3, 12);
+                ng[s] = L->slot_grp[i];
+            }
+        free(L->slot_key);
+        free(L->slot_grp);
+        L->slot_key = nk;
+        L->slot_grp = ng;
+        L->size = ns;
+    }
+    uint64_t s = vo_mix(bx, by, bz) & (uint64_t)(L->size - 1);
+    while (L->slot_grp[s] >= 0) {
+        if (L->slot_key[s * 3] == bx && L->slot_key[s * 3 + 1] == by && L->slot_key[s * 3 + 2] == bz) return L->slot_grp[s];
+        s = (s + 1) & (uint64_t)(L->size - 1);
+    }
+    if (L->ngrp == L->cap) {
+        L->cap = L->cap ? L->cap * 2 : 256;
+        L->grp = (vo_group *)realloc(L->grp, sizeof(vo_group) * (size_t)L->cap);
+    }
+    vo_group *gr = &L->grp[L->ngrp];
+    gr->key[0] = bx; gr->key[1] = by; gr->key[2] = bz;
+    gr->first = -1;
+    gr->count = 0;
+    L->slot_key[s * 3] = bx; L->slot_key[s * 3 + 1] = by; L->slot_key[s * 3 + 2] = bz;
+    L->slot_grp[s] = L->ngrp;
+    L->used++;
+    return L->ngrp++;
+}
+
+void vo_integrate_omp(vo_grid *g, const float *pts, int64_t n, const void *cols, int color_kind, int threads) {
+    if (threads < 1) threads = 1;
+    const int bs = g->block_size;
+    const float inv_255 = 1.0f / 255.0f;
+    vo_local *locals = (vo_local *)calloc((size_t)threads, sizeof(vo_local));
+    int64_t *link = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1)); /* next point of the same (thread, block) group */
+    int64_t *tail = NULL;
+    uint16_t *local_idx = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(n > 0 ? n : 1));
+    /* phase 1 */
+#pragma omp parallel num_threads(threads)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        const int t = 0, nt = 1;
+#endif
+        vo_local *L = &locals[t];
+        int64_t *last = NULL;
+        int64_t last_cap = 0;
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int32_t vx = vo_key_f32(pts[i * 3], g->inv_voxel_size), vy = vo_key_f32(pts[i * 3 + 1], g->inv_voxel_size),
+                          vz = vo_key_f32(pts[i * 3 + 2], g->inv_voxel_size);
+            const int32_t bx = vo_block_of(vx, bs), by = vo_block_of(vy, bs), bz = vo_block_of(vz, bs);
+            local_idx[i] = (uint16_t)(vo_local_of(vx, bx, bs) + vo_local_of(vy, by, bs) * bs + vo_local_of(vz, bz, bs) * bs * bs);
+            const int64_t gi = vo_local_group(L, bx, by, bz);
+            if (gi >= last_cap) {
+                const int64_t nc = last_cap ? last_cap * 2 : 256;
+                last = (int64_t *)realloc(last, sizeof(int64_t) * (size_t)(nc > gi + 1 ? nc : gi + 1));
+                last_cap = nc > gi + 1 ? nc : gi + 1;
+            }
+            link[i] = -1;
+            if (L->grp[gi].count == 0) L->grp[gi].first = i; else link[last[gi]] = i;
+            last[gi] = i;
+            L->grp[gi].count++;
+        }
+        free(last);
+    }
+    (void)tail;
+    /* merge: blocks in first-seen order (thread order, then group order inside a thread); per block the chain of thread groups */
+    typedef struct { vo_block *blk; int64_t first_grp; } vo_work;
+    int64_t total_groups = 0;
+    for (int t = 0; t < threads; ++t) total_groups += locals[t].ngrp;
+    vo_work *work = (vo_work *)malloc(sizeof(vo_work) * (size_t)(total_groups > 0 ? total_groups : 1));
+    int64_t *grp_next = (int64_t *)malloc(sizeof(int64_t) * (size_t)(total_groups > 0 ? total_groups : 1)); /* global group id -> next group of the block */
+    int64_t *grp_first = (int64_t *)malloc(sizeof(int64_t) * (size_t)(total_groups > 0 ? total_groups : 1));
+    /* block index in g->blocks -> (work item, last group): small side tables sized by the block count after insertion */
+    int64_t nwork = 0, base = 0;
+    int64_t *blk_work = NULL, *blk_last = NULL;
+    int64_t blk_cap = 0;
+    for (int t = 0; t < threads; ++t) {
+        for (int64_t k = 0; k < locals[t].ngrp; ++k) {
+            const vo_group *gr = &locals[t].grp[k];
+            vo_block *blk = vo_find_or_create(g, gr->key[0], gr->key[1], gr->key[2], 1);
+            const int64_t bi = blk - g->blocks;
+            if (bi >= blk_cap) {
+                const int64_t nc = blk_cap ? blk_cap * 2 : 1024;
+                const int64_t want = nc > bi + 1 ? nc : bi + 1;
+                blk_work = (int64_t *)realloc(blk_work, sizeof(int64_t) * (size_t)want);
+                blk_last = (int64_t *)realloc(blk_last, sizeof(int64_t) * (size_t)want);
+                for (int64_t q = blk_cap; q < want; ++q) blk_work[q] = -1;
+                blk_cap = want;
+            }
+            const int64_t gid = base + k;
+            grp_first[gid] = gr->first;
+            grp_next[gid] = -1;
+            if (blk_work[bi] < 0) {
+                blk_work[bi] = nwork;
+                work[nwork].first_grp = gid;
+                ++nwork;
+            } else {
+                grp_next[blk_last[bi]] = gid;
+            }
+            blk_last[bi] = gid;
+        }
+        base += locals[t].ngrp;
+    }
+    /* (pointers into g->blocks are taken only now: vo_find_or_create may have moved the array) */
+    for (int64_t bi = 0; bi < blk_cap && bi < g->num_blocks; ++bi)
+        if (blk_work[bi] >= 0) work[blk_work[bi]].blk = &g->blocks[bi];
+    /* phase 2 */
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+    for (int64_t w = 0; w < nwork; ++w) {
+        vo_voxel *data = work[w].blk->data;
+        for (int64_t gid = work[w].first_grp; gid >= 0; gid = grp_next[gid])
+            for (int64_t i = grp_first[gid]; i >= 0; i = link[i]) {
+                vo_voxel *v = &data[local_idx[i]];
+                v->position_sum[0] += pts[i * 3];
+                v->position_sum[1] += pts[i * 3 + 1];
+                v->position_sum[2] += pts[i * 3 + 2];
+                if (color_kind == 1) {
+                    const uint8_t *c = (const uint8_t *)cols + i * 3;
+                    v->color_sum[0] += (float)c[0] * inv_255;
+                    v->color_sum[1] += (float)c[1] * inv_255;
+                    v->color_sum[2] += (float)c[2] * inv_255;
+                } else if (color_kind == 2) {
+                    const float *c = (const float *)cols + i * 3;
+                    v->color_sum[0] += c[0];
+                    v->color_sum[1] += c[1];
+                    v->color_sum[2] += c[2];
+                }
+                v->count = (v->count == 0) ? 1 : v->count + 1;
+            }
+    }
+    for (int t = 0; t < threads; ++t) {
+        free(locals[t].slot_key);
+        free(locals[t].slot_grp);
+        free(locals[t].grp);
+    }
+    free(locals); free(link); free(local_idx); free(work); free(grp_next); free(grp_first); free(blk_work); free(blk_last);
 }
 
 int64_t vo_num_blocks(const vo_grid *g) { return g->num_blocks; }

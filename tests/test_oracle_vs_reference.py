@@ -178,3 +178,23 @@ def test_optimised_reference_build_against_the_portable_oracle_build():
     assert float(np.abs(pa - pb).max()) <= 2e-6 and float(np.abs(ca - cb).max()) <= 1e-6
     if _cpu_has_avx2():
         assert float((pa.view(np.uint32) != pb.view(np.uint32)).mean()) < 0.02
+
+
+def test_openmp_two_phase_restatement_is_bit_identical_to_the_sequential_branch():
+    """oracle.PortGrid.integrate_parallel (the reference's TBB branch, voxel_block_grid.hpp:292-456, restated with OpenMP for the
+    all-cores CPU baseline) against the sequential restatement - which the tests above pin to the compiled reference."""
+    import oracle
+    from oracle import host_prep as hp
+    from pyslam_amd.synthetic import SyntheticRGBD
+
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    a, b = oracle.PortGrid(0.02, 8), oracle.PortGrid(0.02, 8)
+    for i, th in ((0, 1), (5, 3), (9, 8), (5, 16)):
+        d, c, T = s[i]
+        p, col, _ = hp.frame_to_world_f32(d, c, *s.intrinsics, T, 4.0)
+        cols = (col * 255).astype(np.uint8) if i == 9 else col
+        a.integrate(p, cols)
+        b.integrate_parallel(p, cols, threads=th)
+    assert a.num_blocks() == b.num_blocks() > 100
+    for x, y in zip(a.dump(), b.dump()):
+        np.testing.assert_array_equal(x, y)
