@@ -38,6 +38,8 @@ Objects on the JSON line (N = 1):
                 numpy arrays - PCIe INSIDE the timed region (never `value`) - through integrate_frames (page-locked staging slots
                 + copy stream, overlapped with the previous batch's sweep), next to the H2D-bound rate measured in the same
                 process, one integrate() per host frame, and the whole front (add_keyframe -> worker process -> pop_output) once.
+  configs       BASELINE configs[2] / [4] shapes on one GPU: Replica-shaped 1200x680 @ 4 mm with marching cubes every 10 frames,
+                ScanNet-shaped 1296x968 @ 2 mm; frames/s.  semantic_scannet_2mm: the semantic flow at that shape.
   voxel_grid    the cpp/volumetric VOXEL_GRID mode on the same frames: per-frame and batched frames/s, B_vox
                 roofline, and the COMPILED REFERENCE (oracle/_ref, kind "reference") timed beside it.
   semantic      pySLAM's per-keyframe semantic flow (shadow filter, assign_object_ids_to_instance_ids, remap, integrate) for
@@ -207,6 +209,40 @@ def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_fr
         g.profile_enable(False)
         if dt is None or t < dt:
             dt, k_ms, k_launches = t, ms, launches
+    # the order-free single-launch form (HV_VG_PATH=atomic: hardware float atomics; keys / counts exact, sums within 1e-6 of the
+    # point-ordered fold - tests/test_gpu_voxel_grid.py), same frames, fresh grid
+    atomic_mode = None
+    try:
+        os.environ["HV_VG_PATH"] = "atomic"
+        ga = VoxelBlockGrid(VOXEL, 8, max_blocks=1 << 18, max_points=1 << 20)
+
+        def step_a():
+            for f in range(frames):
+                ga.integrate_rgbd(depth_d[f], rgb_d[f], *s.intrinsics, T_h[f], max_depth=DEPTH_TRUNC)
+
+        step_a()
+        ga.synchronize()
+        best_a = None
+        for _ in range(3):
+            ga.profile_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_a()
+            ga.synchronize()
+            t = time.perf_counter() - t0
+            ms_a, launches_a, _ = ga.profile_read()
+            ga.profile_enable(False)
+            if best_a is None or t < best_a[0]:
+                best_a = (t, ms_a, launches_a)
+        atomic_mode = {"value": round(steps * frames / best_a[0], 1), "unit": "frames/s",
+                       "avg_us_per_frame": round(best_a[1] * 1e3 / max(best_a[2], 1), 2),
+                       "what": "HV_VG_PATH=atomic: one launch per frame (unprojection + key + block claim + 7 hardware atomics per point); "
+                               "addition order not the reference's: sums within 1e-6, counts / keys exact"}
+        del ga
+    except Exception as e:
+        atomic_mode = {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        os.environ.pop("HV_VG_PATH", None)
     gb = VoxelBlockGrid(VOXEL, 8, max_blocks=1 << 18, max_points=frames * s.width * s.height)
     gb.integrate_rgbd_batch(depth_d[:frames], rgb_d[:frames], *s.intrinsics, T_h[:frames], max_depth=DEPTH_TRUNC)
     gb.synchronize()
@@ -230,6 +266,7 @@ def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_fr
     out = {"metric": "RGB-D frames/sec fused (640x480, 5 mm, VOXEL_GRID cpp/volumetric semantics)",
            "value": round(steps * frames / dt, 1), "unit": "frames/s",
            "batched_replay": {"value": round(steps * frames / dt_b, 1), "unit": "frames/s", "frames_per_call": frames},
+           "atomic_mode": atomic_mode,
            "blocks": int(g.num_blocks())}
     if k_launches:
         avg_s = k_ms * 1e-3 / k_launches
@@ -289,6 +326,48 @@ def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_fr
                                          f"(the reference's TBB branch) on the same float32 world points; bit-identical to the sequential branch"}
     except Exception as e:
         out["cpu_parallel"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def config_legs():
+    """Secondary: the other single-GPU TSDF shapes of BASELINE.json (parity for them: tests/test_gpu_configs.py, test_gpu_bench_path.py).
+    configs[2]: Replica-shaped 1200x680 @ 4 mm + colour with marching cubes every 10 frames; configs[4]'s image / voxel shape
+    (ScanNet 1296x968 @ 2 mm) on ONE GPU.  Frames resident in HBM; frames/s of fusion alone and with the extraction ticks."""
+    import torch
+
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    out = {}
+    for key, config, voxel, n_frames, B, mesh_every, max_blocks in (("replica_1200x680_4mm", "replica_1200x680_4mm", 0.004, 40, 10, 10, 1 << 17),
+                                                                       ("scannet_1296x968_2mm", "scannet_1296x968_2mm", 0.002, 16, 8, 0, 1 << 18)):
+        s, depth_h, rgb_h, T_h = load_frames(config, n_frames)
+        K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+        depth_d, rgb_d = torch.from_numpy(depth_h).cuda(), torch.from_numpy(rgb_h).cuda()
+        vol = ScalableTSDFVolume(voxel, SDF_TRUNC, max_blocks=max_blocks, max_points=s.width * s.height)
+
+        def run(extract):
+            vol.reset()
+            vol.synchronize()
+            t0 = time.perf_counter()
+            tri = 0
+            for lo in range(0, n_frames, B):
+                vol.integrate_batch(depth_d[lo:lo + B], rgb_d[lo:lo + B], K, T_h[lo:lo + B], depth_scale=1.0, depth_trunc=DEPTH_TRUNC)
+                if extract and mesh_every and (lo + B) % mesh_every == 0:
+                    tri = len(vol.extract_triangle_mesh().triangles)
+            vol.synchronize()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, tri
+
+        run(bool(mesh_every))  # warm-up: units allocated once, result arrays page-locked
+        t_fuse = min(run(False)[0] for _ in range(2))
+        leg = {"frames": n_frames, "frames_per_call": B, "voxel": voxel, "image": f"{s.width}x{s.height}",
+               "fuse_only": {"value": round(n_frames / t_fuse, 1), "unit": "frames/s"}, "units": int(vol.num_blocks())}
+        if mesh_every:
+            t_all, tri = run(True)
+            leg["with_mesh_every_%d_frames" % mesh_every] = {"value": round(n_frames / t_all, 1), "unit": "frames/s", "triangles_last": int(tri),
+                                                              "what": "extract_triangle_mesh (host-visible result, D2H included) after every 10th frame"}
+        out[key] = leg
+        del vol, depth_d, rgb_d
     return out
 
 
@@ -601,6 +680,20 @@ def main():
             out["speedup_vs_cpu"] = round(fps / cpu["fps"], 1)
         if merge is not None:
             out["merge"] = merge
+        if extraction is not None:
+            # HBM traffic of the extraction kernels from the recorded --pmc passes of this command on this build (all launches of
+            # the run extract the same volume)
+            def kernels_traffic(names):
+                tot = 0
+                for nm in names:
+                    t = hbm_traffic(pmc_kernel(pmc, nm, command_key))
+                    if t is None:
+                        return None
+                    tot += t
+                return int(tot)
+
+            extraction["roofline"]["traffic"] = kernels_traffic(("k_mc_classify", "k_mc_prefix", "k_mc_vertices", "k_mc_triangles"))
+            extraction["points_roofline"]["traffic"] = kernels_traffic(("k_pc_extract<false>", "k_pc_extract<true>"))
         if online is not None:
             om = {"value": round(online["fps"], 2), "unit": "frames/s",
                   "what": "one hv_tsdf_integrate per frame (pySLAM's online flow), same sliding stream, fresh volume", "roofline": None}
@@ -624,8 +717,11 @@ def main():
             del vol, fuser
             for key, leg in (("host_mode", lambda: __import__("tools.bench_host", fromlist=["host_leg"]).host_leg(
                                  s, depth_h, rgb_h, T_h, VOXEL, SDF_TRUNC, DEPTH_TRUNC, B=B, steps=min(6, n_distinct // B))),
+                             ("configs", config_legs),
                              ("voxel_grid", lambda: voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, min(B, n_distinct), 5, 6)),
-                             ("semantic", lambda: __import__("tools.bench_semantic", fromlist=["semantic_leg"]).semantic_leg(10, 2, 0.01))):
+                             ("semantic", lambda: __import__("tools.bench_semantic", fromlist=["semantic_leg"]).semantic_leg(10, 2, 0.01)),
+                             ("semantic_scannet_2mm", lambda: __import__("tools.bench_semantic", fromlist=["semantic_leg"]).semantic_leg(
+                                 5, 1, 0.002, "scannet_1296x968_2mm", 2))):
                 try:
                     out[key] = leg()
                 except Exception as e:  # a secondary leg must never cost the headline line

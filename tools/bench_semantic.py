@@ -16,8 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01):
-    """-> dict (bench.py's `semantic` key / this tool's JSON line)."""
+def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x480_5mm", stride=3):
+    """-> dict (bench.py's `semantic` key / this tool's JSON line).  config="scannet_1296x968_2mm", voxel=0.002 is BASELINE
+    configs[4]'s shape (1.25 M points per keyframe, 1.6 cm blocks)."""
     import types
 
     args = types.SimpleNamespace(frames=n_frames, cpu_frames=cpu_frames, voxel=voxel)
@@ -29,13 +30,20 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01):
                                                 remap_instance_ids, set_next_object_id)
     from tests.semantic_helpers import frame_points, semantic_frame
 
-    s = SyntheticRGBD("synthetic_640x480_5mm")
+    s = SyntheticRGBD(config)
     intr = s.intrinsics
-    frames = [semantic_frame(s, 3 * i, shuffle=i) for i in range(args.frames)]
-    out = {"metric": "keyframes/sec, semantic flow (640x480, assign+remap+integrate, cpp/volumetric semantics)", "unit": "keyframes/s",
-           "n_gpus": 1, "voxel": args.voxel, "frames": args.frames}
+    frames = [semantic_frame(s, stride * i, shuffle=i) for i in range(args.frames)]
+    out = {"metric": f"keyframes/sec, semantic flow ({s.width}x{s.height}, assign+remap+integrate, cpp/volumetric semantics)", "unit": "keyframes/s",
+           "n_gpus": 1, "voxel": args.voxel, "frames": args.frames, "config": config}
+    # algorithmic bytes per keyframe (SURVEY 8d shape): every distinct voxel a keyframe touches is read and written once (64 B voting /
+    # 128 B probabilistic record) + the keyframe's inputs (depth f32 + rgb u8x3 + class i32 + instance i32 = 15 B / pixel)
+    v_touched = []
+    for depth, rgb, T, cls_img, inst_img in frames[2:2 + max(1, min(3, len(frames) - 2))]:
+        p = hp.frame_to_world_f32(hp.filter_shadow_points(depth), rgb, *intr, T, 4.0)[0]
+        v_touched.append(len(np.unique(oracle.keys(p, args.voxel, 8, which="port")[0], axis=0)))
+    b_in = s.width * s.height * 15
     for name, cls, kind in (("voting", VoxelBlockSemanticGrid, 0), ("probabilistic", VoxelBlockSemanticProbabilisticGrid, 1)):
-        g = cls(args.voxel, 8, max_blocks=1 << 17, max_points=1 << 20)
+        g = cls(args.voxel, 8, max_blocks=1 << 17, max_points=max(1 << 20, s.width * s.height))
         fr = CameraFrustrum(*intr, s.width, s.height, np.eye(4), depth_max=8.0, depth_min=0.01)
         set_next_object_id(1)
 
@@ -60,7 +68,14 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01):
         t0 = time.perf_counter()
         segs = g.get_object_segments(3, 0.6)
         t_seg = time.perf_counter() - t0
-        res = {"value": round(fps, 1), "get_voxels_ms": round(t_get * 1e3, 2), "voxels_out": int(len(v.points)),
+        rec = 64 if kind == 0 else 128
+        alg = 2 * rec * float(np.mean(v_touched)) + b_in
+        res = {"value": round(fps, 1),
+               "roofline": {"bound": "hbm", "what": "the WHOLE per-keyframe flow (shadow filter, association, remap, integrate), not one kernel: "
+                            f"algorithmic bytes = 2 x {rec} B x distinct voxels touched (oracle keys) + 15 B / pixel of inputs",
+                            "algorithmic_bytes_per_keyframe": int(alg), "achieved": round(alg * fps / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(alg * fps / 1e9 / 8000.0, 5), "traffic": None},
+               "get_voxels_ms": round(t_get * 1e3, 2), "voxels_out": int(len(v.points)),
                "get_object_segments_ms": round(t_seg * 1e3, 2), "objects": len(segs.object_vector), "blocks": int(g.num_blocks()),
                "label_overflows": g.label_overflows()}
         if oracle.ref_available():
@@ -96,8 +111,10 @@ def main():
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--voxel", type=float, default=0.01)
+    ap.add_argument("--config", default="synthetic_640x480_5mm")
+    ap.add_argument("--stride", type=int, default=3)
     args = ap.parse_args()
-    print(json.dumps(semantic_leg(args.frames, args.cpu_frames, args.voxel)))
+    print(json.dumps(semantic_leg(args.frames, args.cpu_frames, args.voxel, args.config, args.stride)))
 
 
 if __name__ == "__main__":

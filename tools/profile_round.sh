@@ -9,19 +9,20 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_round
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-STEPS=${STEPS:-20}; WARM=${WARM:-5}
+STEPS=${STEPS:-20}; WARM=${WARM:-5}; RAMP=${RAMP:-60}   # bench.py runs RAMP clock-ramp steps, then WARM warm-up steps, then the timed STEPS
 KEY="steps=$STEPS warmup=$WARM B=32 window=sliding config=synthetic_640x480_5mm"
-BENCH="python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- $BENCH > $O/kt.log 2>&1
+BENCH="python $R/bench.py --steps $STEPS --warmup $WARM --clock-ramp-steps $RAMP --no-cpu-baseline"
+LO=$((RAMP+WARM)); HI=$((RAMP+WARM+STEPS))
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- $BENCH > $O/kt.log 2>&1
 cp $O/kt/bench_kernel_stats.csv $O/rocprofv3_kernel_stats.csv 2>/dev/null || find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_kernel_stats.csv \;
 cut -c1-200 $O/rocprofv3_kernel_stats.csv
 pmc_pass() { # name, counters...
   local name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$name -o pmc -- $BENCH > $O/pmc_$name.log 2>&1
+  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$name -o pmc -- $BENCH > $O/pmc_$name.log 2>&1
 }
 pmc_pass FETCH_SIZE FETCH_SIZE
 pmc_pass WRITE_SIZE WRITE_SIZE
 pmc_pass sq SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM GRBM_GUI_ACTIVE
 pmc_pass tcp TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum
-python $R/tools/pmc_summary.py --json $O/pmc_summary.json --command-key "$KEY" --range k_tsdf_sweep:$WARM:$((WARM+STEPS)) --range k_tsdf_prep_touch_batch:$WARM:$((WARM+STEPS)) --range k_tsdf_batch_finish:$WARM:$((WARM+STEPS)) $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq $O/pmc_tcp > $O/pmc_summary.txt
+python $R/tools/pmc_summary.py --json $O/pmc_summary.json --command-key "$KEY" --range k_tsdf_sweep:$LO:$HI --range k_tsdf_prep_touch_batch:$LO:$HI --range k_tsdf_batch_finish:$LO:$HI $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq $O/pmc_tcp > $O/pmc_summary.txt
 cat $O/pmc_summary.txt
