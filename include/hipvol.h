@@ -276,6 +276,13 @@ int hv_tsdf_integrate_frames(hv_volume *v, const void *const *depth_frames, int3
  * allocated (so all GPUs agree on the unit set) but not swept.  All zeros = whole image (default). */
 int hv_tsdf_set_tile(hv_volume *v, int32_t u0, int32_t v0, int32_t u1, int32_t v1);
 
+/* The same for the VOXEL_GRID mode: owner(block) = hash(block key) mod world_size; a point whose block another GPU owns is
+ * skipped (not counted as dropped).  The GPUs' voxel sets are disjoint and their union is the single-GPU grid bit for bit
+ * (cpp/volumetric/voxel_block_grid.hpp:371-456 already treats blocks as independent).  hv_block_owner evaluates the ownership
+ * function on the host for block keys [n,3] (-1 for keys outside the supported range). */
+int hv_set_owner(hv_volume *v, int32_t rank, int32_t world_size);
+int hv_block_owner(const int32_t *block_keys, int64_t n, int32_t world_size, int32_t *owner);
+
 /* Multi-GPU unit-ownership sharding (SURVEY §8e "zero reduce" form): every GPU sees every frame but
  * claims, stores and fuses only the units with owner(unit index) == rank (a fixed hash of the
  * index modulo world_size).  Per-frame work and HBM footprint divide by world_size, results are

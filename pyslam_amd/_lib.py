@@ -106,6 +106,8 @@ SIGNATURES = {
     "hv_tsdf_unit_keys": (_i32, [_vp, _vp, _i64, _pi64]),
     "hv_tsdf_dirty_keys": (_i32, [_vp, _vp, _i64, _pi64]),
     "hv_tsdf_mark_merged": (_i32, [_vp]),
+    "hv_set_owner": (_i32, [_vp, _i32, _i32]),
+    "hv_block_owner": (_i32, [_vp, _i64, _i32, _vp]),
     "hv_merge_halo_plan": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _pi64]),
     "hv_merge_halo_plan_held": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _pi64]),
     "hv_merge_halo_pack": (_i32, [_vp, _vp, _i64, _vp, _i32]),

@@ -13,7 +13,14 @@ struct HvGridParams {
     int32_t nvox;         // bs^3
     int32_t local_bits;
     int32_t bs_shift;     // log2(bs) when bs is a power of two (the default 8 and 16), else -1
+    int32_t owner_rank, owner_world; // multi-GPU block ownership (hv_set_owner): this GPU fuses block b iff hv_owner_of(b) % world == rank
 };
+
+// Block-ownership sharding of the grid modes (SURVEY 8e "zero reduce" form): a point whose block another GPU owns is skipped
+// here - it is neither fused nor counted as dropped.
+__host__ __device__ inline bool hv_block_is_foreign(const HvGridParams &G, uint64_t packed_block_key) {
+    return G.owner_world > 1 && hv_owner_of(packed_block_key, G.owner_world) != G.owner_rank;
+}
 
 // floor_div, voxel_hashing.h:139-142
 __host__ __device__ inline int32_t hv_floor_div(int32_t a, int32_t b) {

@@ -664,7 +664,7 @@ int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, in
         Q.kind = 2;
         Q.min_count = 1;
         fill_frustum_query(Q, v, intr_f32, width, height, T_cw, depth_max, depth_min);
-        HvGridParams GP;
+        HvGridParams GP{};
         GP.inv_voxel_size = G.inv_voxel_size;
         GP.bs = G.bs;
         GP.nvox = G.nvox;

@@ -82,16 +82,19 @@ __global__ __launch_bounds__(256) void k_vg_keys(HvTable table, float *__restric
         keyable = hv_point_keyable(x, y, z, G);
         if (keyable) k = hv_point_key(x, y, z, G);
     }
+    bool foreign = false;
     if (keyable) {
         if (hv_key_in_range(k.b[0], k.b[1], k.b[2])) {
-            const int32_t slot = hv_table_insert(table, hv_pack_key(k.b[0], k.b[1], k.b[2]));
+            const unsigned long long bkey = hv_pack_key(k.b[0], k.b[1], k.b[2]);
+            foreign = hv_block_is_foreign(G, bkey);
+            const int32_t slot = foreign ? -1 : hv_table_insert(table, bkey);
             if (slot >= 0) {
                 const uint32_t lidx = (uint32_t)(k.l[0] + k.l[1] * G.bs + k.l[2] * G.bs * G.bs); // voxel_block.h:67-70
                 key = ((uint32_t)slot << G.local_bits) | lidx;
             }
         }
     }
-    if (key == HV_SORT_SENTINEL) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
+    if (key == HV_SORT_SENTINEL && !foreign) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
     keys_out[i] = key;
 }
 
@@ -263,15 +266,18 @@ __global__ __launch_bounds__(256) void k_vgb_count(HvTable table, float *__restr
             }
         }
         if (!masked) {
+            bool foreign = false;
             const bool wide = !FUSED && pts64 != nullptr;
             if (wide ? hv_point_keyable(xd, yd, zd, G) : hv_point_keyable(x, y, z, G)) {
                 const HvPointKey k = wide ? hv_point_key(xd, yd, zd, G) : hv_point_key(x, y, z, G);
                 if (hv_key_in_range(k.b[0], k.b[1], k.b[2])) {
-                    slot = hv_table_insert(table, hv_pack_key(k.b[0], k.b[1], k.b[2]));
+                    const unsigned long long bkey = hv_pack_key(k.b[0], k.b[1], k.b[2]);
+                    foreign = hv_block_is_foreign(G, bkey);
+                    if (!foreign) slot = hv_table_insert(table, bkey);
                     lidx = (uint32_t)(k.l[0] + k.l[1] * G.bs + k.l[2] * G.bs * G.bs); // voxel_block.h:67-70
                 }
             }
-            if (slot < 0) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
+            if (slot < 0 && !foreign) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
         }
         pslot[i] = slot;
         plidx[i] = lidx;
@@ -303,7 +309,9 @@ __global__ __launch_bounds__(256) void k_vg_atomic_frame(HvTable table, HvVoxel 
     if (hv_point_keyable(pt[0], pt[1], pt[2], G)) {
         const HvPointKey k = hv_point_key(pt[0], pt[1], pt[2], G);
         if (hv_key_in_range(k.b[0], k.b[1], k.b[2])) {
-            slot = hv_table_insert(table, hv_pack_key(k.b[0], k.b[1], k.b[2]));
+            const unsigned long long bkey = hv_pack_key(k.b[0], k.b[1], k.b[2]);
+            if (hv_block_is_foreign(G, bkey)) return;
+            slot = hv_table_insert(table, bkey);
             lidx = (uint32_t)(k.l[0] + k.l[1] * G.bs + k.l[2] * G.bs * G.bs);
         }
     }
@@ -828,6 +836,8 @@ static HvGridParams grid_params(const hv_volume *v) {
     G.bs_shift = -1;
     for (int sh = 0; sh <= 4; ++sh)
         if ((1 << sh) == G.bs) G.bs_shift = sh;
+    G.owner_rank = v->owner_rank;
+    G.owner_world = v->owner_world;
     return G;
 }
 
@@ -1163,6 +1173,27 @@ extern "C" int hv_integrate_rgbd_points_batch(hv_volume *v, const void *depth, i
         }
         rc = integrate_device_points(v, v->scratch_points, (int64_t)nf * npx, v->scratch_colors, HV_COLOR_F32, v->sort_keys_out);
         if (rc != HV_OK) return rc;
+    }
+    return HV_OK;
+}
+
+// Multi-GPU block ownership for the VOXEL_GRID mode (the "zero reduce" form: owner(block) = hash(block key) mod world,
+// every GPU sees every point and fuses only the blocks it owns; the union of the GPUs' voxels is the single-GPU grid, bit for
+// bit, and no collective runs while fusing).  hv_block_owner is the same function on the host (tests, planners).
+extern "C" int hv_set_owner(hv_volume *v, int32_t rank, int32_t world_size) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_set_owner: null volume");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_GRID, HV_ERR_MODE, "hv_set_owner: volume is not in VOXEL_GRID mode (TSDF: hv_tsdf_set_owner)");
+    HV_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, HV_ERR_INVALID, "hv_set_owner: bad rank/world");
+    v->owner_rank = rank;
+    v->owner_world = world_size;
+    return HV_OK;
+}
+
+extern "C" int hv_block_owner(const int32_t *block_keys, int64_t n, int32_t world_size, int32_t *owner) {
+    HV_REQUIRE((n == 0 || (block_keys != nullptr && owner != nullptr)) && world_size >= 1, HV_ERR_INVALID, "hv_block_owner: bad argument");
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t x = block_keys[i * 3], y = block_keys[i * 3 + 1], z = block_keys[i * 3 + 2];
+        owner[i] = hv_key_in_range(x, y, z) ? hv_owner_of(hv_pack_key(x, y, z), world_size) : -1;
     }
     return HV_OK;
 }

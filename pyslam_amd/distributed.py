@@ -190,3 +190,59 @@ class TileShardedTSDF(ShardedTSDF):
     def __init__(self, *args, **kwargs):
         kwargs.setdefault("sharding", "tile")
         super().__init__(*args, **kwargs)
+
+
+def block_owner(block_keys, world_size):
+    """Owner rank of each block key [n,3] i32 under the library's ownership function (hv_block_owner, host code)."""
+    from . import _lib as L
+
+    keys = np.ascontiguousarray(block_keys, dtype=np.int32).reshape(-1, 3)
+    out = np.zeros(len(keys), np.int32)
+    L.check(L.load().hv_block_owner(L.ptr(keys), len(keys), int(world_size), L.ptr(out)))
+    return out
+
+
+class ShardedVoxelGrid:
+    """VOXEL_GRID mode on N GPUs ("zero reduce" form): every rank sees every frame / point set and fuses only the blocks
+    it owns (``hv_set_owner``: owner = hash(block key) % N).  The ranks' voxel sets are disjoint and their union is the single-GPU
+    grid bit for bit, so there is no collective while fusing; ``gather_voxels()`` collects what ``get_voxels`` returns on one rank
+    (all-gather of the row counts, then of the padded rows).  The grid object is duck-typed (set_owner / integrate* / get_voxels),
+    so the gather runs on CPU over gloo in tests/."""
+
+    def __init__(self, grid, rank=0, world_size=1, group=None):
+        self.grid, self.rank, self.world_size, self.group = grid, int(rank), int(world_size), group
+        if self.world_size > 1:
+            self.grid.set_owner(self.rank, self.world_size)
+
+    def integrate(self, points, colors=None):
+        self.grid.integrate(points, colors)
+
+    def integrate_rgbd(self, *args, **kwargs):
+        self.grid.integrate_rgbd(*args, **kwargs)
+
+    def gather_voxels(self, min_count=1, min_confidence=0.0, root=0):
+        """-> (points [M,3] f32, colors [M,3] f32) of the whole distributed grid on `root`, None elsewhere."""
+        v = self.grid.get_voxels(min_count, min_confidence)
+        pts, cols = np.ascontiguousarray(v.points, np.float32), np.ascontiguousarray(v.colors, np.float32)
+        if self.world_size == 1:
+            return pts, cols
+        import torch
+        import torch.distributed as dist
+
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+        n_local = torch.tensor([len(pts)], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(n_local) for _ in range(self.world_size)]
+        dist.all_gather(counts, n_local, group=self.group)
+        counts = [int(c.item()) for c in counts]
+        cap = max(max(counts), 1)
+        buf = torch.zeros((cap, 6), dtype=torch.float32, device=dev)
+        if len(pts):
+            buf[: len(pts), :3] = torch.from_numpy(pts).to(dev)
+            buf[: len(pts), 3:] = torch.from_numpy(cols).to(dev)
+        gathered = [torch.zeros_like(buf) for _ in range(self.world_size)]
+        dist.all_gather(gathered, buf, group=self.group)
+        if self.rank != root:
+            return None
+        rows = np.concatenate([g[:c].cpu().numpy() for g, c in zip(gathered, counts)], axis=0)
+        return rows[:, :3], rows[:, 3:]

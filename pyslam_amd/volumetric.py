@@ -389,6 +389,10 @@ class VoxelBlockGrid(_Volume):
             L.check(call(L.ptr(pts), L.ptr(cols), n.value, ctypes.byref(n)))
         return VoxelGridData(pts, cols)
 
+    def set_owner(self, rank, world_size):
+        """Multi-GPU block ownership: fuse only the blocks with hash(block key) % world_size == rank (no collective while fusing)."""
+        L.check(self._lib.hv_set_owner(self._h, int(rank), int(world_size)))
+
     def get_voxels(self, min_count=1, min_confidence=0.0):
         return self._collect(
             lambda p, c, cap, n: self._lib.hv_get_voxels(self._h, int(min_count), float(min_confidence), p, c, cap, n, L.HV_HOST)

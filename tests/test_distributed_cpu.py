@@ -344,3 +344,88 @@ def test_tile_bounds_partition_the_image():
             assert a[2] == b[0]
     u = union_keys([np.array([[1, 2, 3], [0, 0, 0]]), np.zeros((0, 3), np.int32), np.array([[1, 2, 3], [-1, 5, 2]])])
     assert u.tolist() == [[-1, 5, 2], [0, 0, 0], [1, 2, 3]]
+
+
+class OwnerFilteredOracleGrid:
+    """VoxelBlockGrid protocol of ShardedVoxelGrid on top of oracle.PortGrid: set_owner keeps the rank / world, integrate drops the
+    points whose block another rank owns - with the LIBRARY's ownership function (hv_block_owner, host code)."""
+
+    def __init__(self, voxel, bs=8):
+        import oracle
+
+        self.voxel, self.bs = voxel, bs
+        self.grid = oracle.PortGrid(voxel, bs)
+        self.rank, self.world = 0, 1
+
+    def set_owner(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def integrate(self, points, colors=None):
+        import oracle
+        from pyslam_amd.distributed import block_owner
+
+        pts = np.ascontiguousarray(points, np.float32)
+        mine = block_owner(oracle.keys(pts, self.voxel, self.bs, which="port")[1], self.world) == self.rank
+        self.grid.integrate(pts[mine], None if colors is None else np.asarray(colors)[mine])
+
+    def get_voxels(self, min_count=1, min_confidence=0.0):
+        import types
+
+        p, c = self.grid.get_voxels(min_count, min_confidence)
+        return types.SimpleNamespace(points=p, colors=c)
+
+
+def _grid_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from oracle import host_prep as hp
+    from pyslam_amd.distributed import ShardedVoxelGrid
+    from pyslam_amd.synthetic import SyntheticRGBD
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    sharded = ShardedVoxelGrid(OwnerFilteredOracleGrid(0.02), rank=rank, world_size=world)
+    for i in (0, 7, 30):
+        d, c, T = s[i]
+        pts, cols, _ = hp.frame_to_world_f32(d, c, *s.intrinsics, T, 4.0)
+        sharded.integrate(pts, cols)  # every rank sees every point
+    local = len(sharded.grid.get_voxels(1).points)
+    out = sharded.gather_voxels(min_count=1, root=0)
+    np.save(os.path.join(tmpdir, f"grid_local{rank}.npy"), np.array([local, sharded.grid.grid.num_blocks()]))
+    if rank == 0:
+        np.savez(os.path.join(tmpdir, "grid_gathered.npz"), points=out[0], colors=out[1])
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_voxel_grid_ownership_equals_single_grid(tmp_path):
+    """VOXEL_GRID over 2 ranks (gloo): owner(block) = hash(block key) % 2, each rank fuses only its blocks, nothing is reduced;
+    the gathered get_voxels rows are EXACTLY the single grid's (sorted rows bit-identical), each rank holds about half the blocks."""
+    import torch.multiprocessing as mp
+
+    import oracle
+    from oracle import host_prep as hp
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from tests.conftest import sort_rows
+
+    port = 29500 + ((os.getpid() + 333) % 2000)
+    mp.spawn(_grid_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    full = oracle.PortGrid(0.02, 8)
+    for i in (0, 7, 30):
+        d, c, T = s[i]
+        pts, cols, _ = hp.frame_to_world_f32(d, c, *s.intrinsics, T, 4.0)
+        full.integrate(pts, cols)
+    z = np.load(tmp_path / "grid_gathered.npz")
+    pa, ca = sort_rows(z["points"], z["colors"])
+    pb, cb = sort_rows(*full.get_voxels(1))
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(ca, cb)
+    l0, l1 = np.load(tmp_path / "grid_local0.npy"), np.load(tmp_path / "grid_local1.npy")
+    assert l0[0] + l1[0] == len(pb) and l0[1] + l1[1] == full.num_blocks()
+    assert 0.35 * full.num_blocks() < l0[1] < 0.65 * full.num_blocks()  # hash-balanced

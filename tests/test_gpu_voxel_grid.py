@@ -367,3 +367,37 @@ def test_order_free_frame_path_is_within_the_contract_tolerance(monkeypatch):
     n = np.maximum(ca, 1)[..., None].astype(np.float64)
     assert np.abs(sa.astype(np.float64) / n - sb.astype(np.float64) / n).max() <= 1e-6
     assert exact.get_voxels(3).points.shape == fast.get_voxels(3).points.shape
+
+
+def test_block_ownership_sharding_union_is_the_single_grid():
+    """hv_set_owner on HIP grids: three 'ranks' (three grids on this GPU) see the same frames through every integrate entry point
+    (fused RGB-D frame, point array, batched replay); their voxel sets are disjoint, agree with hv_block_owner, and their union is
+    the unsharded grid bit for bit."""
+    from pyslam_amd.distributed import block_owner
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    world = 3
+    full = VoxelBlockGrid(0.02, 8, max_blocks=1 << 13, max_points=1 << 18)
+    parts = [VoxelBlockGrid(0.02, 8, max_blocks=1 << 13, max_points=1 << 18) for _ in range(world)]
+    for r, g in enumerate(parts):
+        g.set_owner(r, world)
+    frames = [s[i] for i in (0, 5, 9, 20)]
+    for g in [full] + parts:
+        d, c, T = frames[0]
+        g.integrate_rgbd(d, c, *s.intrinsics, T, max_depth=4.0)
+        pts, cols, _ = hp.frame_to_world_f32(frames[1][0], frames[1][1], *s.intrinsics, frames[1][2], 4.0)
+        g.integrate(pts, cols)
+        g.integrate_rgbd_batch(np.stack([f[0] for f in frames[2:]]), np.stack([f[1] for f in frames[2:]]), *s.intrinsics,
+                               np.stack([f[2] for f in frames[2:]]), max_depth=4.0)
+        assert g.dropped_points() == 0  # a foreign point is not a dropped point
+    kf, hf, cf, sf = full.dump()
+    dumps = [g.dump() for g in parts]
+    for r, (k, _, _, _) in enumerate(dumps):
+        assert (block_owner(k, world) == r).all() and len(k) > 0.2 * len(kf)
+    keys = np.concatenate([d[0] for d in dumps])
+    order = np.lexsort(keys.T[::-1])
+    np.testing.assert_array_equal(keys[order], kf)
+    np.testing.assert_array_equal(np.concatenate([d[2] for d in dumps])[order], cf)
+    np.testing.assert_array_equal(np.concatenate([d[3] for d in dumps])[order].view(np.uint32), sf.view(np.uint32))
