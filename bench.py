@@ -209,40 +209,6 @@ def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_fr
         g.profile_enable(False)
         if dt is None or t < dt:
             dt, k_ms, k_launches = t, ms, launches
-    # the order-free single-launch form (HV_VG_PATH=atomic: hardware float atomics; keys / counts exact, sums within 1e-6 of the
-    # point-ordered fold - tests/test_gpu_voxel_grid.py), same frames, fresh grid
-    atomic_mode = None
-    try:
-        os.environ["HV_VG_PATH"] = "atomic"
-        ga = VoxelBlockGrid(VOXEL, 8, max_blocks=1 << 18, max_points=1 << 20)
-
-        def step_a():
-            for f in range(frames):
-                ga.integrate_rgbd(depth_d[f], rgb_d[f], *s.intrinsics, T_h[f], max_depth=DEPTH_TRUNC)
-
-        step_a()
-        ga.synchronize()
-        best_a = None
-        for _ in range(3):
-            ga.profile_enable(True)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step_a()
-            ga.synchronize()
-            t = time.perf_counter() - t0
-            ms_a, launches_a, _ = ga.profile_read()
-            ga.profile_enable(False)
-            if best_a is None or t < best_a[0]:
-                best_a = (t, ms_a, launches_a)
-        atomic_mode = {"value": round(steps * frames / best_a[0], 1), "unit": "frames/s",
-                       "avg_us_per_frame": round(best_a[1] * 1e3 / max(best_a[2], 1), 2),
-                       "what": "HV_VG_PATH=atomic: one launch per frame (unprojection + key + block claim + 7 hardware atomics per point); "
-                               "addition order not the reference's: sums within 1e-6, counts / keys exact"}
-        del ga
-    except Exception as e:
-        atomic_mode = {"error": f"{type(e).__name__}: {e}"}
-    finally:
-        os.environ.pop("HV_VG_PATH", None)
     gb = VoxelBlockGrid(VOXEL, 8, max_blocks=1 << 18, max_points=frames * s.width * s.height)
     gb.integrate_rgbd_batch(depth_d[:frames], rgb_d[:frames], *s.intrinsics, T_h[:frames], max_depth=DEPTH_TRUNC)
     gb.synchronize()
@@ -266,7 +232,6 @@ def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_fr
     out = {"metric": "RGB-D frames/sec fused (640x480, 5 mm, VOXEL_GRID cpp/volumetric semantics)",
            "value": round(steps * frames / dt, 1), "unit": "frames/s",
            "batched_replay": {"value": round(steps * frames / dt_b, 1), "unit": "frames/s", "frames_per_call": frames},
-           "atomic_mode": atomic_mode,
            "blocks": int(g.num_blocks())}
     if k_launches:
         avg_s = k_ms * 1e-3 / k_launches

@@ -288,52 +288,10 @@ __global__ __launch_bounds__(256) void k_vgb_count(HvTable table, float *__restr
     if (g.leader) atomicAdd(&cnt[slot], g.size);
 }
 
-// ---- order-free form of a frame (opt-in: HV_VG_PATH=atomic) ---------------------------------------------------------------
-// One launch per RGB-D frame: a thread unprojects its pixel, claims the block and adds its point to the voxel record with
-// seven hardware atomics (count, three position sums, three colour sums).  What it gives up is the ORDER of the float32
-// additions: the reference's sequential branch adds a voxel's points in point order and the bucket path above reproduces that
-// bit for bit; here the order is whatever the memory system makes of it, so sums differ from the reference's in the last bits
-// and from run to run (keys, counts and the set of voxels stay exact).  The contract asks for bit-exact indices / keys and
-// 1e-4 on the values (BASELINE.json north_star); measured against the exact path: <= 1e-6 on positions and colours.
-// A pool slot's index is published after its key (hv_table_insert): a thread that finds a key another wave has just claimed
-// waits for the index (bounded: an overflowing claim never gets one).
-__global__ __launch_bounds__(256) void k_vg_atomic_frame(HvTable table, HvVoxel *__restrict__ pool, int64_t n, HvGridParams G,
-                                                          HvUnprojectParams U, const void *__restrict__ depth_raw,
-                                                          const uint8_t *__restrict__ rgb) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float pt[3], col[3];
-    if (!hv_unproject_pixel(U, depth_raw, rgb, i, pt, col)) return;
-    int32_t slot = -1;
-    uint32_t lidx = 0;
-    if (hv_point_keyable(pt[0], pt[1], pt[2], G)) {
-        const HvPointKey k = hv_point_key(pt[0], pt[1], pt[2], G);
-        if (hv_key_in_range(k.b[0], k.b[1], k.b[2])) {
-            const unsigned long long bkey = hv_pack_key(k.b[0], k.b[1], k.b[2]);
-            if (hv_block_is_foreign(G, bkey)) return;
-            slot = hv_table_insert(table, bkey);
-            lidx = (uint32_t)(k.l[0] + k.l[1] * G.bs + k.l[2] * G.bs * G.bs);
-        }
-    }
-    if (slot < 0) {
-        atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
-        return;
-    }
-    int32_t idx = __hip_atomic_load(&table.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int spin = 0; idx < 0 && spin < (1 << 16); ++spin) {
-        __builtin_amdgcn_s_sleep(1);
-        idx = __hip_atomic_load(&table.vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (idx < 0) return; // the claim overflowed the pool (counted by hv_table_insert)
-    HvVoxel *vx = pool + (int64_t)idx * G.nvox + lidx;
-    atomicAdd(&vx->count, 1);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        unsafeAtomicAdd(&vx->pos[k], pt[k]);
-        unsafeAtomicAdd(&vx->col[k], col[k]);
-    }
-}
-
+// (Measured dead end, round 3: an ORDER-FREE single-launch form - one thread per pixel adding its point to the voxel record with
+// seven hardware atomics, global_atomic_add / global_atomic_add_f32; keys and counts exact, sums within the contract's 1e-4 -
+// runs at 89.9 us per 640x480 frame against 45.4 us for the four launches of the point-ordered bucket path: 2.1 M scattered
+// float atomics per frame are slower than sorting 12 points per block in LDS.  Taken out again.)
 // 1 thread / allocated block: blocks that received points this frame take their bucket range from the global cursor and
 // enter the frame's touched list - both with one atomic per wave (prefix sums inside the wave).
 static constexpr int HV_VGB_WCAP_DECL = 1024; // == HV_VGB_WCAP (defined with the wave fold below)
@@ -892,18 +850,6 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
     int rc = hv_capacity_gate(v, &checked); // may grow the pool: the sort-key width / bucket arrays follow the table
     if (rc != HV_OK) return rc;
     const char *force = getenv("HV_VG_PATH");
-    if (frame && !checked && force && strcmp(force, "atomic") == 0) {
-        // order-free single launch (see k_vg_atomic_frame); the checked mode verifies claims before anything is written, which
-        // one launch cannot: such calls take the exact path below
-        hv_profile_begin(v);
-        hipLaunchKernelGGL(k_vg_atomic_frame, dim3(blocks), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool, n, G, frame->U,
-                           frame->d_depth, frame->d_rgb);
-        hv_launch_publish_status(v);
-        hv_profile_end(v, n);
-        HV_HIP(hipGetLastError());
-        v->frame_counter += 1;
-        return HV_OK;
-    }
     const bool bucket = n < (1ll << HV_VGB_IDX_BITS) && v->local_bits <= 32 - HV_VGB_IDX_BITS && !(force && strcmp(force, "sort") == 0);
     if (bucket) {
         hv_profile_begin(v); // measurement hook: the four launches of one integrate call

@@ -340,35 +340,6 @@ def test_float64_points_take_the_double_overload(path, bs, monkeypatch):
     assert_same_grid(g32, ref32)
 
 
-def test_order_free_frame_path_is_within_the_contract_tolerance(monkeypatch):
-    """HV_VG_PATH=atomic: one launch per RGB-D frame, hardware float atomics instead of the point-ordered fold.  Block keys,
-    the set of voxels and every count stay EXACT; position / colour sums differ from the reference's sequential order only in
-    rounding: means within 1e-6 (contract: 1e-4)."""
-    from oracle import host_prep as hp
-    from pyslam_amd.synthetic import SyntheticRGBD
-    from pyslam_amd.volumetric import VoxelBlockGrid
-
-    s = SyntheticRGBD("synthetic_640x480_5mm")
-    exact = VoxelBlockGrid(0.005, 8, max_blocks=1 << 17, max_points=s.width * s.height)
-    fast = VoxelBlockGrid(0.005, 8, max_blocks=1 << 17, max_points=s.width * s.height)
-    for i in (0, 1, 2, 40):
-        depth, rgb, T = s[i]
-        monkeypatch.delenv("HV_VG_PATH", raising=False)
-        exact.integrate_rgbd(depth, rgb, *s.intrinsics, T, max_depth=4.0)
-        monkeypatch.setenv("HV_VG_PATH", "atomic")
-        fast.integrate_rgbd(depth, rgb, *s.intrinsics, T, max_depth=4.0)
-    monkeypatch.delenv("HV_VG_PATH", raising=False)
-    ka, ha, ca, sa = exact.dump()
-    kb, hb, cb, sb = fast.dump()
-    np.testing.assert_array_equal(ka, kb)
-    np.testing.assert_array_equal(ha, hb)
-    np.testing.assert_array_equal(ca, cb)  # counts exact
-    assert int(ca.max()) >= 4 and (sa.view(np.uint32) != sb.view(np.uint32)).any()  # the order really differs somewhere
-    n = np.maximum(ca, 1)[..., None].astype(np.float64)
-    assert np.abs(sa.astype(np.float64) / n - sb.astype(np.float64) / n).max() <= 1e-6
-    assert exact.get_voxels(3).points.shape == fast.get_voxels(3).points.shape
-
-
 def test_block_ownership_sharding_union_is_the_single_grid():
     """hv_set_owner on HIP grids: three 'ranks' (three grids on this GPU) see the same frames through every integrate entry point
     (fused RGB-D frame, point array, batched replay); their voxel sets are disjoint, agree with hv_block_owner, and their union is
