@@ -1964,6 +1964,11 @@ HV_SWEEP_COLUMN_CAPPED(k_tsdf_sweep_column_v120, 60)
 HV_SWEEP_COLUMN_CAPPED(k_tsdf_sweep_column_v112, 56)
 #undef HV_SWEEP_COLUMN_CAPPED
 
+// n16 16-byte words from device-visible host memory to device memory, one workgroup (see hv_tsdf_integrate_batch: frame constants).
+__global__ __launch_bounds__(256) void k_upload_words(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16) {
+    for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i]; // (one workgroup: 3-4 PCIe round trips for a 32-frame batch)
+}
+
 // After the sweep (one workgroup): clear the frame masks of the batch's units and zero the batch's touched-list counter, so
 // that the next batch / online frame starts clean without a memset launch per counter.
 __global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const int32_t *__restrict__ list,
@@ -2428,7 +2433,14 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
         if (rc != HV_OK) return rc;
         uint2 *d_px = (uint2 *)*bb;
         HvFrameParams *d_params = (HvFrameParams *)((char *)*bb + ((px_bytes + 255) & ~(size_t)255));
-        HV_HIP(hipMemcpyAsync(d_params, params, sizeof(HvFrameParams) * (size_t)B, hipMemcpyHostToDevice, ps));
+        // The 12 KB of frame constants go up with a ONE-WORKGROUP kernel that reads the page-locked ring slot in place (hipHostMalloc
+        // memory is device-visible).  hipMemcpyAsync turns a small pinned copy into the runtime's blit kernel, whose workgroups wait
+        // for wave slots behind the sweep that is running on the other queue: 100-420 us per batch in profiles/r03/
+        // pipeline_timeline.txt (first version), which delayed the touch + pack launch to the end of the sweep it should hide in.
+        {
+            const int n16 = (int)((sizeof(HvFrameParams) * (size_t)B + 15) / 16);
+            hipLaunchKernelGGL(k_upload_words, dim3(1), dim3(256), 0, ps, (const uint4 *)params, (uint4 *)d_params, n16);
+        }
         HV_HIP(hipEventRecord(v->params_ev[ri], ps));
         // the touched-list counters are zero after hv_reset and k_tsdf_batch_finish; an online frame leaves its own
         // parity's count behind
