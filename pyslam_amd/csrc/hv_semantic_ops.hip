@@ -63,11 +63,38 @@ __device__ __forceinline__ bool sem_visit(const HvQuery &Q, const HvTable &table
     return hv_frustum_contains_d(Q, v->pos[0] / c, v->pos[1] / c, v->pos[2] / c, uvd);
 }
 
+// Block-level frustum cull for the per-voxel scans below (a wave = 64 consecutive voxels of ONE block: 64 divides bs^3 for the
+// supported block sizes).  A voxel's averaged position lies in its cell, hence in the block's box; if all eight corners of the
+// box (grown by half a voxel against rounding) are on the outer side of one of the frustum's six planes - depth_min, depth_max,
+// u >= 0, u < W, v >= 0, v < H, each linear in camera coordinates - no voxel of the block can pass CameraFrustrum::contains and
+// the wave leaves without reading a single voxel record (a keyframe sees a fraction of the map; the scan is otherwise
+// bs^3 x 64..128 bytes per allocated block whether it is in view or not).  Lanes 0-7 test one corner each.
+__device__ __forceinline__ bool sem_block_outside_frustum(const HvQuery &Q, const HvTable &table, int64_t b, const HvSemParams &G) {
+    int32_t bk[3];
+    hv_unpack_key(table.block_keys[b], bk[0], bk[1], bk[2]);
+    const int lane = hv_lane_id();
+    const double vs = 1.0 / (double)G.inv_voxel_size, ext = (double)G.bs * vs;
+    double p[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) p[a] = (double)bk[a] * ext + (((lane >> a) & 1) ? ext + 0.5 * vs : -0.5 * vs);
+    double pc[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pc[r] = (Q.R[r * 3 + 0] * p[0] + Q.R[r * 3 + 1] * p[1] + Q.R[r * 3 + 2] * p[2]) + Q.t[r];
+    const double fu = (double)Q.fx * pc[0] + (double)Q.cx * pc[2], fv = (double)Q.fy * pc[1] + (double)Q.cy * pc[2];
+    const unsigned long long corners = 0xffull;
+    const bool out0 = pc[2] < (double)Q.depth_min, out1 = pc[2] > (double)Q.depth_max;
+    const bool out2 = fu < 0.0, out3 = fu - (double)Q.width * pc[2] >= 0.0;
+    const bool out4 = fv < 0.0, out5 = fv - (double)Q.height * pc[2] >= 0.0;
+    return (__ballot(out0) & corners) == corners || (__ballot(out1) & corners) == corners || (__ballot(out2) & corners) == corners ||
+           (__ballot(out3) & corners) == corners || (__ballot(out4) & corners) == corners || (__ballot(out5) & corners) == corners;
+}
+
 template <typename VOX>
 __global__ __launch_bounds__(256) void k_sem_carve(HvTable table, VOX *__restrict__ pool, int64_t n_blocks, HvSemParams G,
                                                     HvQuery Q, const float *__restrict__ depth) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_blocks * G.nvox) return;
+    if ((G.nvox & 63) == 0 && sem_block_outside_frustum(Q, table, gid / G.nvox, G)) return; // wave-uniform
     VOX *v = pool + gid;
     float uvd[3];
     if (!sem_visit(Q, table, v, gid / G.nvox, (int)(gid % G.nvox), G, uvd)) return;
@@ -131,7 +158,9 @@ __global__ __launch_bounds__(256) void k_sem_assoc_vote(HvTable table, VOX *__re
     uint64_t key = HV_VOTE_EMPTY;
     bool is_pending = false;
     int32_t inst = -1;
-    if (gid < n_blocks * G.nvox) {
+    // (total = n_blocks * nvox and nvox % 64 == 0: a wave never straddles the end of the pool or two blocks)
+    const bool culled = gid < n_blocks * G.nvox && (G.nvox & 63) == 0 && sem_block_outside_frustum(Q, table, gid / G.nvox, G);
+    if (gid < n_blocks * G.nvox && !culled) {
         VOX *v = pool + gid;
         float uvd[3];
         if (sem_visit(Q, table, v, gid / G.nvox, (int)(gid % G.nvox), G, uvd)) {

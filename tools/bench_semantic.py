@@ -78,7 +78,7 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
                "get_voxels_ms": round(t_get * 1e3, 2), "voxels_out": int(len(v.points)),
                "get_object_segments_ms": round(t_seg * 1e3, 2), "objects": len(segs.object_vector), "blocks": int(g.num_blocks()),
                "label_overflows": g.label_overflows()}
-        if oracle.ref_available():
+        if oracle.ref_available() and args.cpu_frames > 0:
             from oracle.semantic import RefSemGrid2, ref_remap_instance_ids
 
             r = RefSemGrid2(kind, args.voxel, 8)
