@@ -51,7 +51,9 @@ def _digest():
         path = name if os.path.isabs(name) else os.path.join(CSRC, name)
         with open(path, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(_flags()).encode())
+    # the flags enter with the checkout's root written as "." - the digest names a SOURCE state and must be the same on every
+    # box the tree travels to (the evidence under profiles/ is keyed by it)
+    h.update(" ".join(_flags()).replace(ROOT, ".").encode())
     return h.hexdigest()
 
 
