@@ -7,6 +7,7 @@ step after the rectification runs on the GPU; the last three are one fused call 
 Outputs (reference :517-700): an object list (per-object points + PCA boxes) when instance ids are integrated,
 else one labelled point cloud."""
 import time
+import os
 import traceback
 
 import numpy as np
@@ -154,6 +155,12 @@ class VolumetricIntegratorVoxelSemanticGrid(VolumetricIntegratorBase):
         self.integrate_2d_instance_ids = bool(
             Parameters.kVolumetricSemanticIntegrationUseInstanceIds and semantic_instances is not None
             and np.asarray(semantic_instances).size > 0)
+        if self._device_flow():
+            # One upload per image: the keyframe's depth / colour / label images go to HBM once (torch tensors) and every step
+            # of the body - shadow filter, association, remap, fused integrate - works on them in place, instead of each call
+            # staging its inputs again and the filter / remap results making a round trip through host memory (19 -> 5 copies
+            # per keyframe in profiles/r03/kernel_stats_semantic.csv).
+            return self._integrate_keyframe_on_device(color, depth, pose, semantic_classes, semantic_instances)
         depth_filtered = depth
         if Parameters.kVolumetricIntegrationVoxelGridShadowPointsFilter:
             depth_filtered = self.volume.filter_shadow_points(depth)  # depth.py:103-146 on the GPU
@@ -173,6 +180,48 @@ class VolumetricIntegratorVoxelSemanticGrid(VolumetricIntegratorBase):
         fx, fy, cx, cy = self.get_camera_intrinsics_for_depth()
         self.volume.integrate_rgbd(depth_filtered, color, fx, fy, cx, cy, pose, class_ids_image=semantic_classes,
                                    object_ids_image=object_ids_image, max_depth=self.volumetric_integration_depth_trunc,
+                                   use_depths=Parameters.kVolumetricSemanticProbabilisticIntegrationUseDepth)
+
+    def _device_flow(self):
+        """True when the volume is the HIP one (tests swap in oracle stand-ins that only take numpy) and torch sees a GPU."""
+        if os.environ.get("PYSLAM_AMD_SEMANTIC_DEVICE_FLOW", "1") == "0":
+            return False
+        try:
+            import torch
+
+            from ..volumetric_semantic import _SemanticGridBase
+
+            return isinstance(self.volume, _SemanticGridBase) and torch.cuda.is_available()
+        except Exception:
+            return False
+
+    def _integrate_keyframe_on_device(self, color, depth, pose, semantic_classes, semantic_instances):
+        import torch
+
+        def up(a, dtype):
+            return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+        depth_d = up(depth, np.float32)
+        if Parameters.kVolumetricIntegrationVoxelGridShadowPointsFilter:
+            depth_d = self.volume.filter_shadow_points(depth_d)  # stays in HBM
+        color_d = up(color, np.uint8)
+        cls_d = up(semantic_classes, np.int32) if semantic_classes is not None and np.asarray(semantic_classes).size > 0 else None
+        self.camera_frustrum.set_T_cw(pose)
+        object_ids_d = None
+        if self.integrate_2d_instance_ids and cls_d is not None:
+            inst_d = up(semantic_instances, np.int32)
+            id_map = self.volume.assign_object_ids_to_instance_ids(
+                self.camera_frustrum, cls_d, inst_d, depth_d,
+                depth_threshold=Parameters.kVolumetricIntegrationVoxelGridCarvingDepthThreshold,
+                do_carving=Parameters.kVolumetricIntegrationVoxelGridUseCarving,
+                min_vote_ratio=Parameters.kVolumetricSemanticIntegrationMinVoteRatio,
+                min_votes=Parameters.kVolumetricSemanticIntegrationMinVotes)
+            object_ids_d = self.volume.remap_instance_ids(inst_d, id_map)
+        elif Parameters.kVolumetricIntegrationVoxelGridUseCarving:
+            self.volume.carve(self.camera_frustrum, depth_d, Parameters.kVolumetricIntegrationVoxelGridCarvingDepthThreshold)
+        fx, fy, cx, cy = self.get_camera_intrinsics_for_depth()
+        self.volume.integrate_rgbd(depth_d, color_d, fx, fy, cx, cy, pose, class_ids_image=cls_d, object_ids_image=object_ids_d,
+                                   max_depth=self.volumetric_integration_depth_trunc,
                                    use_depths=Parameters.kVolumetricSemanticProbabilisticIntegrationUseDepth)
 
     def make_output(self, task_type):

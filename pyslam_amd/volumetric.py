@@ -99,6 +99,41 @@ class _Volume:
         """Adopt a caller-owned hipStream_t (e.g. ``torch.cuda.Stream().cuda_stream``)."""
         L.check(self._lib.hv_set_stream(self._h, ctypes.c_void_p(int(stream_handle))))
 
+    # -- torch CUDA tensors handed to / returned by the C ABI ------------------------------------------
+    def _torch_stream(self, device):
+        """The volume's hipStream_t as a torch stream (for event ordering against torch's streams and the caching allocator)."""
+        import torch
+
+        h = int(self._lib.hv_get_stream(self._h) or 0)
+        if getattr(self, "_ts_key", None) != (h, device):
+            self._ts = torch.cuda.ExternalStream(h, device=device) if h else torch.cuda.default_stream(device)
+            self._ts_key = (h, device)
+        return self._ts
+
+    def _torch_in(self, *tensors):
+        """Before a launch that reads / writes torch CUDA tensors on the volume's stream: that stream waits for what torch's
+        current stream has queued (the producers).  No host synchronisation.  -> the volume's torch stream, or None when no
+        tensor is on a GPU.  Always paired with _torch_out() after the launch."""
+        import torch
+
+        for t in tensors:
+            if t is not None and getattr(t, "is_cuda", False):
+                ts = self._torch_stream(t.device)
+                ts.wait_stream(torch.cuda.current_stream(t.device))
+                return ts
+        return None
+
+    def _torch_out(self, ts, device):
+        """After such a launch: torch's current stream waits for the volume's.  Torch ops on the results are ordered after
+        the launch, and so is everything the caching allocator may later place in a block the caller drops (a block freed
+        on torch's stream is only reused by work queued on that stream), so tensors may be released right after the call.
+        (record_stream() on the volume's stream would say the same to the allocator, but leaves it holding events on a stream
+        that hv_destroy() may already have destroyed when the tensor is finally freed.)"""
+        import torch
+
+        if ts is not None:
+            torch.cuda.current_stream(device).wait_stream(ts)
+
     def dropped_points(self):
         n = ctypes.c_int64()
         L.check(self._lib.hv_dropped_points(self._h, ctypes.byref(n)))
@@ -132,8 +167,11 @@ class _Volume:
             d = np.ascontiguousarray(depth, dtype=np.float32)
             out = np.empty_like(d)
         H, W = int(d.shape[0]), int(d.shape[1])
+        ts = self._torch_in(d, out) if L.location(d) == L.HV_DEVICE else None
         L.check(self._lib.hv_filter_shadow_points(self._h, L.ptr(d), H, W, int(delta_x), int(delta_y), float(fill_value),
                                                   L.ptr(out), L.location(d)))
+        if ts is not None:
+            self._torch_out(ts, d.device)
         return out
 
     def remap(self, img, map_x, map_y, linear=False):

@@ -160,9 +160,50 @@ def _i32_image(img, name):
     return np.ascontiguousarray(a, dtype=np.int32)  # convert_image_type_if_needed(..., CV_32S)
 
 
+def _is_device(a):
+    return a is not None and hasattr(a, "is_cuda") and bool(a.is_cuda)
+
+
+def _device_images(*images):
+    """The per-keyframe images of one call, all at ONE location: when any of them is a torch CUDA tensor the numpy ones are
+    uploaded (torch's blocking copy), so that a caller can keep a keyframe's depth / label images in HBM across
+    filter_shadow_points -> assign_object_ids_to_instance_ids -> remap_instance_ids -> integrate_rgbd instead of staging each
+    of them again in every call.  -> (list of images, HV_DEVICE | HV_HOST)."""
+    if not any(_is_device(a) for a in images):
+        return list(images), L.HV_HOST
+    import torch
+
+    out = []
+    for a in images:
+        if a is None or _is_device(a):
+            out.append(None if a is None else a.contiguous())
+        else:
+            out.append(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+    return out, L.HV_DEVICE
+
+
 def remap_instance_ids(instance_ids, instance_id_to_object_id, volume=None):
     """volumetric.remap_instance_ids(image int32 HxW, map) (image_utils.h:69-163, binding image_utils_module.h):
-    ids absent from the map (or an empty map) become -1.  Runs on the GPU of ``volume`` (any volume)."""
+    ids absent from the map (or an empty map) become -1.  Runs on the GPU of ``volume`` (any volume).  A torch CUDA int32
+    image stays on the device (the result is a CUDA tensor)."""
+    if _is_device(instance_ids):
+        import torch
+
+        img = instance_ids.contiguous()
+        if img.dim() != 2:
+            raise RuntimeError("Instance ids must be single-channel")
+        if img.dtype != torch.int32:
+            raise RuntimeError("Instance ids must be int32")
+        if volume is None:
+            volume = _scratch_volume()
+        keys = np.fromiter(instance_id_to_object_id.keys(), np.int32, len(instance_id_to_object_id))
+        vals = np.fromiter(instance_id_to_object_id.values(), np.int32, len(instance_id_to_object_id))
+        out = torch.empty_like(img)
+        ts = volume._torch_in(img, out)
+        L.check(volume._lib.hv_remap_instance_ids(volume._h, L.ptr(img), int(img.shape[0]), int(img.shape[1]), L.ptr(keys), L.ptr(vals),
+                                                  len(keys), L.ptr(out), L.HV_DEVICE))
+        volume._torch_out(ts, img.device)
+        return out
     img = np.ascontiguousarray(instance_ids)
     if img.size == 0:
         return img
@@ -250,21 +291,38 @@ class _SemanticGridBase(_Volume):
                        min_depth=0.0, use_depths=True):
         """Fused per-keyframe prep + integrate (hv_integrate_rgbd_semantic): depth f32 [H,W] metres, rgb u8 [H,W,3]
         (already RGB), label images i32 [H,W] or None, T_cw world->camera."""
-        depth = np.ascontiguousarray(depth, dtype=np.float32)
-        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
-        H, W = depth.shape
-        if rgb.shape[:2] != (H, W):
+        if any(_is_device(a) for a in (depth, rgb, class_ids_image, object_ids_image)):
+            # device-resident keyframe (torch CUDA tensors: depth f32, rgb u8, labels i32): nothing is staged
+            import torch
+
+            (depth, rgb, cls, obj), loc = _device_images(
+                depth if _is_device(depth) else np.ascontiguousarray(depth, dtype=np.float32),
+                rgb if _is_device(rgb) else np.ascontiguousarray(rgb, dtype=np.uint8),
+                class_ids_image if class_ids_image is None or _is_device(class_ids_image) else np.ascontiguousarray(class_ids_image, dtype=np.int32),
+                object_ids_image if object_ids_image is None or _is_device(object_ids_image) else np.ascontiguousarray(object_ids_image, dtype=np.int32))
+            if depth.dtype != torch.float32 or rgb.dtype != torch.uint8 or any(a is not None and a.dtype != torch.int32 for a in (cls, obj)):
+                raise RuntimeError("device images must be float32 depth, uint8 colour, int32 labels")
+            H, W = int(depth.shape[0]), int(depth.shape[1])
+            ts = self._torch_in(depth, rgb, cls, obj)
+        else:
+            loc = L.HV_HOST
+            depth = np.ascontiguousarray(depth, dtype=np.float32)
+            rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+            H, W = depth.shape
+            cls = None if class_ids_image is None else np.ascontiguousarray(class_ids_image, dtype=np.int32)
+            obj = None if object_ids_image is None else np.ascontiguousarray(object_ids_image, dtype=np.int32)
+        if tuple(rgb.shape[:2]) != (H, W):
             raise RuntimeError("depth and colour image sizes differ")
-        cls = None if class_ids_image is None else np.ascontiguousarray(class_ids_image, dtype=np.int32)
-        obj = None if object_ids_image is None else np.ascontiguousarray(object_ids_image, dtype=np.int32)
         for a, name in ((cls, "class_ids"), (obj, "object_ids")):
-            if a is not None and a.shape != (H, W):
+            if a is not None and tuple(a.shape) != (H, W):
                 raise RuntimeError(f"depth and {name} image sizes differ")
         intr = np.array([fx, fy, cx, cy], np.float64)
         T = np.ascontiguousarray(T_cw, dtype=np.float64)
         big = float(np.finfo(np.float32).max)
         L.check(self._lib.hv_integrate_rgbd_semantic(self._h, L.ptr(depth), L.ptr(rgb), L.ptr(cls), L.ptr(obj), H, W, L.ptr(intr), L.ptr(T),
-                                                     float(min_depth), float(min(max_depth, big)), int(bool(use_depths)), L.HV_HOST))
+                                                     float(min_depth), float(min(max_depth, big)), int(bool(use_depths)), loc))
+        if loc == L.HV_DEVICE:
+            self._torch_out(ts, depth.device)
 
     def get_voxels(self, min_count=1, min_confidence=0.0):
         n = ctypes.c_int64()
@@ -354,24 +412,43 @@ class _SemanticGridBase(_Volume):
         f = camera_frustrum
         if class_ids_image is None or semantic_instances_image is None:
             return {}
-        cls, inst = np.asarray(class_ids_image), np.asarray(semantic_instances_image)
-        if cls.size == 0 or inst.size == 0:
-            return {}
-        cls, inst = _i32_image(cls, "Class ids"), _i32_image(inst, "Instance ids")
-        if inst.shape != (f.height, f.width) or cls.shape != (f.height, f.width):
-            return {}  # check_image_size(): message + empty map
-        depth = None
-        if depth_image is not None and np.asarray(depth_image).size > 0:
-            depth = np.ascontiguousarray(depth_image, dtype=np.float32)
-            if depth.shape != (f.height, f.width):
-                depth = None  # use_depth_filter = false
+        loc = L.HV_HOST
+        if any(_is_device(a) for a in (class_ids_image, semantic_instances_image, depth_image)):
+            # device-resident label / depth images (torch CUDA: int32, int32, float32): used in place
+            import torch
+
+            (cls, inst, depth), loc = _device_images(
+                class_ids_image if _is_device(class_ids_image) else _i32_image(np.asarray(class_ids_image), "Class ids"),
+                semantic_instances_image if _is_device(semantic_instances_image) else _i32_image(np.asarray(semantic_instances_image), "Instance ids"),
+                depth_image if depth_image is None or _is_device(depth_image) else np.ascontiguousarray(depth_image, dtype=np.float32))
+            if cls.dim() != 2 or inst.dim() != 2 or cls.dtype != torch.int32 or inst.dtype != torch.int32:
+                raise RuntimeError("Class ids / Instance ids must be single-channel int32")
+            if tuple(inst.shape) != (f.height, f.width) or tuple(cls.shape) != (f.height, f.width):
+                return {}
+            if depth is not None and (depth.dtype != torch.float32 or tuple(depth.shape) != (f.height, f.width)):
+                depth = None
+            ts = self._torch_in(cls, inst, depth)
+        else:
+            cls, inst = np.asarray(class_ids_image), np.asarray(semantic_instances_image)
+            if cls.size == 0 or inst.size == 0:
+                return {}
+            cls, inst = _i32_image(cls, "Class ids"), _i32_image(inst, "Instance ids")
+            if inst.shape != (f.height, f.width) or cls.shape != (f.height, f.width):
+                return {}  # check_image_size(): message + empty map
+            depth = None
+            if depth_image is not None and np.asarray(depth_image).size > 0:
+                depth = np.ascontiguousarray(depth_image, dtype=np.float32)
+                if depth.shape != (f.height, f.width):
+                    depth = None  # use_depth_filter = false
         cap = 1 << 16
         mi, mo = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
         n = ctypes.c_int64()
         L.check(self._lib.hv_assign_object_ids_to_instance_ids(
             self._h, L.ptr(f.intr), f.width, f.height, L.ptr(f.T_cw), f.depth_max, f.depth_min, L.ptr(cls), L.ptr(inst), L.ptr(depth),
             float(depth_threshold), int(bool(do_carving)), float(min_vote_ratio), int(min_votes), L.ptr(mi), L.ptr(mo), cap,
-            ctypes.byref(n), L.HV_HOST))
+            ctypes.byref(n), loc))
+        if loc == L.HV_DEVICE:
+            self._torch_out(ts, cls.device)
         m = min(n.value, cap)
         return {int(k): int(v) for k, v in zip(mi[:m], mo[:m])}
 

@@ -305,3 +305,56 @@ def test_semantic_queries_segments_by_class_and_integrate_segment(kind):
     got = gpu.get_class_segments(1, 0.0)
     assert [(c.class_id, len(c.points)) for c in got] == [tuple(r) for r in ids.tolist()]
     np.testing.assert_allclose([[c.confidence_min, c.confidence_max] for c in got], conf, rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("kind", [VOTE, PROB])
+def test_device_resident_keyframe_flow_equals_host_flow(kind):
+    """filter_shadow_points -> assign_object_ids_to_instance_ids -> remap_instance_ids -> integrate_rgbd on torch CUDA tensors (one
+    upload per image, what the semantic integrator does) against the same calls on numpy arrays: same id maps, id images and
+    voxel states (object ids compared up to the permutation of ids created in the same call)."""
+    import torch
+
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import CameraFrustrum
+    from pyslam_amd.volumetric_semantic import remap_instance_ids, set_next_object_id
+    from tests.semantic_flow import canonical_ids
+
+    s = SyntheticRGBD(CFG, noise=True, invalid_frac=0.02)
+    results = []
+    for device in (False, True):
+        g = gpu_grid(kind, CFG["voxel"])
+        g.set_depth_threshold(2.0)
+        g.set_depth_decay_rate(0.07)
+        fr = CameraFrustrum(*s.intrinsics, s.width, s.height, np.eye(4), depth_max=DEPTH_MAX, depth_min=DEPTH_MIN)
+        set_next_object_id(1)
+        maps, images = [], []
+        for k, i in enumerate((0, 6, 12, 18)):
+            depth, rgb, T, cls_img, inst_img = semantic_frame(s, i, shuffle=k)
+            if device:
+                depth, rgb, cls_img, inst_img = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (depth, rgb, cls_img, inst_img))
+            d = g.filter_shadow_points(depth)
+            assert bool(getattr(d, "is_cuda", False)) == device
+            fr.set_T_cw(T)
+            m = g.assign_object_ids_to_instance_ids(fr, cls_img, inst_img, d, depth_threshold=0.05, do_carving=(k == 2), min_vote_ratio=0.5,
+                                                    min_votes=3)
+            obj = remap_instance_ids(inst_img, m, volume=g)
+            assert bool(getattr(obj, "is_cuda", False)) == device
+            g.integrate_rgbd(d, rgb, *s.intrinsics, T, class_ids_image=cls_img, object_ids_image=obj, max_depth=4.0, use_depths=True)
+            del depth, rgb, cls_img, d  # the launches may still be reading them: the allocator must not hand the blocks out yet
+            maps.append(m)
+            images.append(obj.cpu().numpy() if device else obj)
+        results.append((maps, images, g.dump2()[:5]))
+    (ma, ia, da), (mb, ib, db) = results
+    assert any(v > 0 for m in ma for v in m.values())
+    for x, y in zip(ma, mb):
+        assert set(x) == set(y) and {k_ for k_ in x if x[k_] > 0} == {k_ for k_ in y if y[k_] > 0}
+    for x, y in zip(ia, ib):
+        np.testing.assert_array_equal(x > 0, y > 0)
+        np.testing.assert_array_equal(np.where(x > 0, 0, x), np.where(y > 0, 0, y))
+    (ka, inta, posa, cola, confa), (kb, intb, posb, colb, confb) = da, db
+    np.testing.assert_array_equal(ka, kb)
+    np.testing.assert_array_equal(inta[..., (0, 2, 3)], intb[..., (0, 2, 3)])
+    np.testing.assert_array_equal(canonical_ids(inta[..., 1]), canonical_ids(intb[..., 1]))
+    np.testing.assert_allclose(posa, posb, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(cola, colb, rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(confa, confb, rtol=1e-6, atol=1e-6)

@@ -42,19 +42,30 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
         p = hp.frame_to_world_f32(hp.filter_shadow_points(depth), rgb, *intr, T, 4.0)[0]
         v_touched.append(len(np.unique(oracle.keys(p, args.voxel, 8, which="port")[0], axis=0)))
     b_in = s.width * s.height * 15
+    host_flow = os.environ.get("PYSLAM_AMD_SEMANTIC_DEVICE_FLOW", "1") == "0"  # A/B: every call stages its own host inputs (round 2)
+    out["flow"] = "host images staged by every call" if host_flow else "one upload per image, steps on device tensors (the integrator's flow)"
     for name, cls, kind in (("voting", VoxelBlockSemanticGrid, 0), ("probabilistic", VoxelBlockSemanticProbabilisticGrid, 1)):
         g = cls(args.voxel, 8, max_blocks=1 << 17, max_points=max(1 << 20, s.width * s.height))
         fr = CameraFrustrum(*intr, s.width, s.height, np.eye(4), depth_max=8.0, depth_min=0.01)
         set_next_object_id(1)
 
         def run(frames_):
+            # the body of pyslam_amd/dense/volumetric_integrator_voxel_semantic_grid.py::_integrate_keyframe_on_device: host images in,
+            # one upload each, every step on the device copies
+            import torch
+
             for depth, rgb, T, cls_img, inst_img in frames_:
-                d = g.filter_shadow_points(depth)
+                if host_flow:
+                    d = g.filter_shadow_points(depth)
+                    c, cl, ins = rgb, cls_img, inst_img
+                else:
+                    d = g.filter_shadow_points(torch.from_numpy(depth).cuda())
+                    c, cl, ins = torch.from_numpy(rgb).cuda(), torch.from_numpy(cls_img).cuda(), torch.from_numpy(inst_img).cuda()
                 fr.set_T_cw(T)
-                m = g.assign_object_ids_to_instance_ids(fr, cls_img, inst_img, d, depth_threshold=0.03, do_carving=False,
+                m = g.assign_object_ids_to_instance_ids(fr, cl, ins, d, depth_threshold=0.03, do_carving=False,
                                                         min_vote_ratio=0.5, min_votes=3)
-                obj = remap_instance_ids(inst_img, m, volume=g)
-                g.integrate_rgbd(d, rgb, *intr, T, class_ids_image=cls_img, object_ids_image=obj, max_depth=4.0, use_depths=True)
+                obj = remap_instance_ids(ins, m, volume=g)
+                g.integrate_rgbd(d, c, *intr, T, class_ids_image=cl, object_ids_image=obj, max_depth=4.0, use_depths=True)
 
         run(frames[:2])
         g.synchronize()
