@@ -340,6 +340,11 @@ struct hv_volume {
     uint64_t content_version = 1;
     uint64_t mesh_cache_version = 0, points_cache_version = 0; // content_version the cached results belong to (0: none)
     int64_t mesh_cache_nv = 0, mesh_cache_nt = 0, points_cache_n = 0;
+    // per-unit column masks both extractions start from (hv_extract.hip: k_unit_masks), valid for unit_masks_version
+    void *unit_masks = nullptr;
+    size_t unit_masks_bytes = 0;
+    uint64_t unit_masks_version = 0;
+    int unit_masks_units = 0;
 
     // output scratch (grown on demand)
     void *out_a = nullptr;

@@ -2,18 +2,24 @@
 // (Open3D ScalableTSDFVolume::ExtractTriangleMesh / ExtractPointCloud semantics; reference call
 // sites pyslam/dense/volumetric_integrator_tsdf.py:239-267).
 //
+// Both extractions start from per-unit COLUMN MASKS (k_unit_masks, one pass over the tsdf and weight planes, 256-byte runs,
+// 32 KB read and 2 KB written per unit): marching cubes only asks "observed?" and "negative?" of a voxel, the point cloud
+// "in [-0.98, 0.98)?" and the sign, so a voxel column is four 16-bit masks.  Everything a unit needs of its NEIGHBOURS (the
+// 18^3 neighbourhood of marching cubes, the 17^3 one of the point cloud) is then read from their masks - a few KB - and not
+// from their planes, where a y = 0 / y = 15 face costs one 64-byte line per voxel (round 2: 118 KB fetched per unit for a
+// 32 KB unit, profiles/r02 and r03/pmc_summary.json before this form).
 // Marching cubes, per allocated unit:
-//   k_mc_classify   (workgroup) observed / negative bit masks per voxel column of the unit's 18^3 neighbourhood, straight from
-//                   the tsdf and weight planes; cube cases (kept, one byte each, for the triangle pass), the unit's own edge
-//                   bitmask (3 axes x 4096 bits, keyed by the edge's owning voxel - the GPU analogue of Open3D's
-//                   edgeindex_to_vertexindex map) as wave ballots, per-unit triangle counts.  No float slab, no atomics.
-//   k_mc_prefix     (workgroup) popcount prefix of the edge bitmask (vertex rank inside the unit)
+//   k_mc_classify   (workgroup) the 18 x 18 column masks of the unit's neighbourhood from the published masks; cube cases
+//                   (kept, one byte each, for the triangle pass), the unit's own edge bitmask (3 axes x 4096 bits, keyed by the
+//                   edge's owning voxel - the GPU analogue of Open3D's edgeindex_to_vertexindex map) as wave ballots, its
+//                   popcount prefix (vertex rank inside the unit), per-unit vertex and triangle counts.  No atomics.
 //   rocPRIM scan    unit bases for vertices and triangles
 //   k_mc_vertices   (wave) lane j builds vertices j, j + 64, ... of the unit: interpolated vertex + colour (f64, as Open3D)
 //   k_mc_triangles  (workgroup) reads the stored cube cases and emits triangles whose vertex indices are
 //                   base[unit(edge)] + rank(edge) - no hash map, no atomics in the emit passes; like the vertices and the
 //                   points, the unit's triangles are dealt out evenly over the threads (rank -> column by binary search).
-// Point cloud: k_pc_extract<false> counts per unit over a 17^3 LDS slab, scan, k_pc_extract<true> writes - no atomics either.
+// Point cloud: k_pc_extract<false> counts the unit's crossings from the masks, scan, k_pc_extract<true> finds them again and
+// gathers the values of the crossing voxels only - no slab, no atomics.
 // Vertex/triangle *order* differs from Open3D's unordered_map iteration order (so does Open3D's
 // own from run to run); the vertex and triangle *sets* are identical to the CPU restatement.
 // "Sizes first, data second" (the binding's protocol) costs one computation: the size query does all the device work and
@@ -29,7 +35,6 @@ static constexpr int RR = R * R;
 static constexpr int RRR = R * R * R;
 static constexpr int PLANE_BYTES = RRR * 4;
 static constexpr int UNIT_BYTES = PLANE_BYTES * HV_TSDF_PLANES;
-static constexpr int H = 17; // slab + halo
 static constexpr int MASK_WORDS = 3 * RRR / 64; // 192
 
 __constant__ unsigned short c_edge_table[256];
@@ -56,56 +61,6 @@ __device__ inline void load_neighbours(const HvTable &table, int idx, int *s_nbr
     }
 }
 
-// stage the tsdf of the 17^3 neighbourhood into LDS, NaN where the weight is 0 (and for absent units): marching cubes only
-// asks "observed?" and "negative?", so one 4-byte word per voxel does (19.7 KB per workgroup: 8 resident per CU instead of
-// 4, half the LDS reads per cube).  The loop runs in the order of the planes in memory (word = z*256 + x*16 + y: y fastest),
-// so a wave reads 64-byte runs; the LDS index (x*17 + y)*17 + z has an odd stride in every direction (no bank conflicts on
-// the transposing writes).
-__device__ inline void load_slab(const char *pool, const int *s_nbr, float *s_f) {
-    // two phases so that a thread's ~20 (tsdf, weight) pairs are all in flight together: with the LDS store inside the load
-    // loop every iteration waited for its own pair (a 17^3 slab = 20 dependent round trips per thread: most of the first
-    // version's 1.2 ms per 32 k units)
-    constexpr int PER = (H * H * H + 255) / 256;
-    float t[PER];
-    uint32_t w[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int e = (int)threadIdx.x + k * 256;
-        t[k] = 0.f;
-        w[k] = 0u;
-        if (e < H * H * H) {
-            const int z = e / (H * H), x = (e / H) % H, y = e % H;
-            const int idx = s_nbr[(x >= R ? 1 : 0) | (y >= R ? 2 : 0) | (z >= R ? 4 : 0)];
-            if (idx >= 0) {
-                const char *unit = pool + (int64_t)idx * UNIT_BYTES;
-                const int word = voxel_word(x & (R - 1), y & (R - 1), z & (R - 1));
-                t[k] = ((const float *)unit)[word];
-                w[k] = ((const uint32_t *)(unit + PLANE_BYTES))[word];
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int e = (int)threadIdx.x + k * 256;
-        if (e < H * H * H) {
-            const int z = e / (H * H), x = (e / H) % H, y = e % H;
-            s_f[(x * H + y) * H + z] = w[k] != 0u ? t[k] : __uint_as_float(0x7fc00000u);
-        }
-    }
-}
-
-// Open3D cube loop body: cube_index or 0 if any corner weight is 0
-__device__ __forceinline__ int cube_case(const float *s_f, int x, int y, int z) {
-    int cube = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float f = s_f[((x + hv_mc_shift[i][0]) * H + (y + hv_mc_shift[i][1])) * H + (z + hv_mc_shift[i][2])];
-        if (f != f) return 0;
-        if (f < 0.0f) cube |= 1 << i;
-    }
-    return cube == 255 ? 0 : cube;
-}
-
 // edge i of cube (x,y,z) -> (neighbour selector, axis, bit index inside that unit/axis)
 __device__ __forceinline__ void edge_owner(int x, int y, int z, int i, int &n, int &axis, int &lin) {
     const int ox = x + hv_mc_edge_shift[i][0], oy = y + hv_mc_edge_shift[i][1], oz = z + hv_mc_edge_shift[i][2];
@@ -114,10 +69,41 @@ __device__ __forceinline__ void edge_owner(int x, int y, int z, int i, int &n, i
     lin = voxel_word(ox & (R - 1), oy & (R - 1), oz & (R - 1));
 }
 
+// Column masks of one unit (thread <-> column x * 16 + y; a wave load is one 256-byte run of a plane):
+//   m_on[unit * 256 + column]  bits 0-15: weight != 0 at z;             bits 16-31: observed and tsdf < 0
+//   m_ip[unit * 256 + column]  bits 0-15: observed, -0.98 <= tsdf < 0.98; bits 16-31: that and tsdf > 0
+// (ExtractPointCloud's `f0 * f1 < 0` of two in-range values is "one negative, one positive": the product of two tsdf values
+// cannot underflow to zero - a non-zero tsdf is a ratio of pixel-scale floats, never below 1e-23.)
+__global__ __launch_bounds__(256) void k_unit_masks(const char *__restrict__ pool, int n_units, uint32_t *__restrict__ m_on,
+                                                     uint32_t *__restrict__ m_ip) {
+    const int idx = blockIdx.x;
+    if (idx >= n_units) return;
+    const char *unit = pool + (int64_t)idx * UNIT_BYTES;
+    float t[R];
+    uint32_t w[R];
+#pragma unroll
+    for (int z = 0; z < R; ++z) {
+        t[z] = ((const float *)unit)[z * RR + threadIdx.x];
+        w[z] = ((const uint32_t *)(unit + PLANE_BYTES))[z * RR + threadIdx.x];
+    }
+    uint32_t obs = 0u, neg = 0u, inr = 0u, pos = 0u;
+#pragma unroll
+    for (int z = 0; z < R; ++z) {
+        const bool o = w[z] != 0u;
+        const bool r = o && t[z] < 0.98f && t[z] >= -0.98f;
+        obs |= (o ? 1u : 0u) << z;
+        neg |= (o && t[z] < 0.0f ? 1u : 0u) << z;
+        inr |= (r ? 1u : 0u) << z;
+        pos |= (r && t[z] > 0.0f ? 1u : 0u) << z;
+    }
+    m_on[(int64_t)idx * RR + threadIdx.x] = obs | (neg << 16);
+    m_ip[(int64_t)idx * RR + threadIdx.x] = inr | (pos << 16);
+}
+
 // Classification of one unit from per-COLUMN bit masks.  Marching cubes only asks two things of a voxel - observed (weight
 // != 0) and negative - so a column (cx, cy) of the unit's 18^3 neighbourhood (-1 .. 16 in every direction: the cubes that
 // share this unit's edges reach one voxel back, its own cubes one voxel forward) is two 18-bit masks along z.  A thread
-// assembles the masks of its column straight from the (tsdf, weight) planes - every wave load is one 256-byte run -, the
+// assembles the masks of its column from the published masks of the three units stacked along z (k_unit_masks), the
 // 68 halo columns go to the first 68 threads, and 2.6 KB of LDS hold them all.  Then, per thread and with its 3 x 3
 // neighbouring column masks in registers:
 //   valid cubes of a cube column  V = AND over its four corner columns of (obs & obs >> 1)
@@ -125,13 +111,16 @@ __device__ __forceinline__ void edge_owner(int x, int y, int z, int i, int &n, i
 //   vertex on the +z edge         (neg ^ neg >> 1) & obs-pair & (a valid cube among the four around the edge)
 //   vertex on the +x / +y edge    (neg ^ neg of the next column) & both observed & (a valid cube among the four)
 // which is Open3D's "for every valid cube with a mixed case, every crossing edge gets a vertex".  A unit's 192 mask words are
-// wave ballots (word = z * 4 + wave for each axis) and are all written: no atomics, nothing to clear.  (First form: a 17^3
+// wave ballots (word = z * 4 + wave for each axis) and are all written: no atomics, nothing to clear; the first wave then
+// scans their popcounts (the rank of a vertex inside the unit; round 2 had a kernel of its own for that).  (First form: a 17^3
 // float slab in LDS, 8 LDS reads per cube, one global atomicOr per crossing edge and cube - 0.45 of its 0.87 ms per 24 k
 // units were those atomics, profiles/r02.)
 static constexpr int H2 = 18;
-__global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const char *__restrict__ pool, int n_units,
+__global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32_t *__restrict__ m_on, int n_units,
                                                       unsigned long long *__restrict__ edge_mask,
+                                                      uint32_t *__restrict__ word_prefix, int32_t *__restrict__ vert_count,
                                                       int32_t *__restrict__ tri_count, uint8_t *__restrict__ cases) {
+    __shared__ uint32_t s_cnt[MASK_WORDS]; // popcounts of the unit's mask words
     __shared__ int s_nbr[27]; // pool index of the unit at offset (dx, dy, dz) in {-1, 0, 1}^3: [(dx + 1) + 3 (dy + 1) + 9 (dz + 1)]
     __shared__ uint32_t s_obs[H2 * H2], s_neg[H2 * H2]; // [(cx + 1) * 18 + (cy + 1)], bit k <-> z = k - 1
     __shared__ int s_tris;
@@ -169,27 +158,13 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const char *
         }
         const int nxy = (cx < 0 ? 0 : cx >= R ? 2 : 1) + 3 * (cy < 0 ? 0 : cy >= R ? 2 : 1);
         const int col = (cx & (R - 1)) * R + (cy & (R - 1));
-        float t[H2];
-        uint32_t w[H2];
-#pragma unroll
-        for (int k = 0; k < H2; ++k) {
-            const int z = k - 1;
-            const int nb = s_nbr[nxy + 9 * (z < 0 ? 0 : z >= R ? 2 : 1)];
-            t[k] = 0.f;
-            w[k] = 0u;
-            if (nb >= 0) {
-                const char *unit = pool + (int64_t)nb * UNIT_BYTES;
-                const int word = (z & (R - 1)) * RR + col;
-                t[k] = ((const float *)unit)[word];
-                w[k] = ((const uint32_t *)(unit + PLANE_BYTES))[word];
-            }
-        }
-        uint32_t obs = 0u, neg = 0u;
-#pragma unroll
-        for (int k = 0; k < H2; ++k) {
-            obs |= (w[k] != 0u ? 1u : 0u) << k;
-            neg |= (w[k] != 0u && t[k] < 0.0f ? 1u : 0u) << k;
-        }
+        // bit k <-> z = k - 1: bit 15 of the unit below, the 16 bits of the unit at this level, bit 0 of the unit above
+        const int nl = s_nbr[nxy], nm = s_nbr[nxy + 9], nh = s_nbr[nxy + 18];
+        const uint32_t lo = nl >= 0 ? m_on[(int64_t)nl * RR + col] : 0u;
+        const uint32_t mid = nm >= 0 ? m_on[(int64_t)nm * RR + col] : 0u;
+        const uint32_t hi = nh >= 0 ? m_on[(int64_t)nh * RR + col] : 0u;
+        const uint32_t obs = ((lo >> 15) & 1u) | ((mid & 0xffffu) << 1) | ((hi & 1u) << 17);
+        const uint32_t neg = ((lo >> 31) & 1u) | ((mid >> 16) << 1) | (((hi >> 16) & 1u) << 17);
         s_obs[(cx + 1) * H2 + (cy + 1)] = obs;
         s_neg[(cx + 1) * H2 + (cy + 1)] = neg;
     }
@@ -222,7 +197,11 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const char *
         if (lane == 16 + z) mine = by;
         if (lane == 32 + z) mine = bz;
     }
-    if (lane < 48) edge_mask[(int64_t)idx * MASK_WORDS + (lane >> 4) * (RRR / 64) + (lane & 15) * 4 + wave] = mine;
+    if (lane < 48) {
+        const int word = (lane >> 4) * (RRR / 64) + (lane & 15) * 4 + wave;
+        edge_mask[(int64_t)idx * MASK_WORDS + word] = mine;
+        s_cnt[word] = (uint32_t)__popcll(mine);
+    }
     // cube cases of the column (corner i of hv_mc_shift: columns (x + sx, y + sy), voxel z + sz)
     const uint32_t c0 = g[1][1] >> 1, c1 = g[2][1] >> 1, c2 = g[2][2] >> 1, c3 = g[1][2] >> 1; // bit z <-> voxel z
     int tris = 0;
@@ -240,26 +219,21 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const char *
     if (tris) atomicAdd(&s_tris, tris);
     __syncthreads();
     if (threadIdx.x == 0) tri_count[idx] = s_tris;
-}
-
-// per unit: exclusive popcount prefix over its 192 mask words + total
-__global__ __launch_bounds__(256) void k_mc_prefix(const unsigned long long *__restrict__ edge_mask, int n_units,
-                                                    uint32_t *__restrict__ word_prefix, int32_t *__restrict__ vert_count) {
-    __shared__ uint32_t s[256];
-    const int idx = blockIdx.x;
-    if (idx >= n_units) return;
-    const int t = threadIdx.x;
-    const uint32_t c = t < MASK_WORDS ? (uint32_t)__popcll(edge_mask[(int64_t)idx * MASK_WORDS + t]) : 0u;
-    s[t] = c;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) { // Hillis-Steele inclusive scan
-        const uint32_t add = t >= off ? s[t - off] : 0u;
-        __syncthreads();
-        s[t] += add;
-        __syncthreads();
+    if (wave == 0) { // exclusive popcount prefix over the 192 mask words: three words per lane + a wave scan
+        const uint32_t c0 = s_cnt[lane * 3], c1 = s_cnt[lane * 3 + 1], c2 = s_cnt[lane * 3 + 2];
+        uint32_t incl = c0 + c1 + c2;
+#pragma unroll
+        for (int o = 1; o < HV_WAVE; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const uint32_t before = incl - (c0 + c1 + c2);
+        uint32_t *wp = word_prefix + (int64_t)idx * MASK_WORDS + lane * 3;
+        wp[0] = before;
+        wp[1] = before + c0;
+        wp[2] = before + c0 + c1;
+        if (lane == HV_WAVE - 1) vert_count[idx] = (int32_t)incl;
     }
-    if (t < MASK_WORDS) word_prefix[(int64_t)idx * MASK_WORDS + t] = s[t] - c;
-    if (t == 255) vert_count[idx] = (int32_t)s[255];
 }
 
 struct HvMcParams {
@@ -435,38 +409,49 @@ __global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, int n_units
 }
 
 // ScalableTSDFVolume::ExtractPointCloud: a voxel (weight != 0, tsdf in [-0.98, 0.98)) and its +x / +y / +z neighbour of the
-// same kind with the opposite sign give one interpolated point.  One workgroup per unit over the same 17^3 LDS slab as the
-// mesh passes (NaN = not observed), one thread per (x, y) column.  Pass 1 (FILL = false) counts the unit's points; after an
-// exclusive scan over the units pass 2 stages the slab again and writes every point at its final index - no atomics, and the
-// output order is deterministic (unit, column, z, axis).  (Second form.  The first - one thread per voxel, its neighbours
-// re-read from global memory, a workgroup-aggregated append - cost 1.43 ms per pass over 32 k units, 128 k returning atomics
-// on one counter; profiles/r02.)
+// same kind with the opposite sign give one interpolated point.  One workgroup per unit, one thread per (x, y) column: the
+// crossings of a column follow from its masks and those of the columns (x + 1, y), (x, y + 1) and of the unit above
+// (k_unit_masks) - 16 bits per axis.  Pass 1 (FILL = false) counts the unit's points; after an exclusive scan over the
+// units pass 2 finds them again and writes every point at its final index, fetching tsdf / weight / colour of the two voxels
+// of a crossing only - no atomics, and the output order is deterministic (unit, column, axis, z).  (Second form: both passes
+// staged a 17^3 float slab of the planes, 0.38 + 0.53 ms and 5.6 GB of traffic per 32 k units, profiles/r03 before this
+// form.  First form: one thread per voxel, a workgroup-aggregated append - 1.43 ms per pass, profiles/r02.)
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *__restrict__ pool, int n_units, HvMcParams M,
+__global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *__restrict__ pool, const uint32_t *__restrict__ m_on,
+                                                     const uint32_t *__restrict__ m_ip, int n_units, HvMcParams M,
                                                      double unit_length, int32_t *__restrict__ count,
                                                      const int32_t *__restrict__ base, double *__restrict__ points,
                                                      double *__restrict__ colors, int64_t cap) {
     __shared__ int s_nbr[8];
-    __shared__ float s_f[H * H * H];
     __shared__ int s_wave[4];
     const int idx = blockIdx.x;
     if (idx >= n_units) return;
     load_neighbours(table, idx, s_nbr);
     __syncthreads();
-    load_slab(pool, s_nbr, s_f);
-    __syncthreads();
     const int x = threadIdx.x >> 4, y = threadIdx.x & 15;
-    // hits of this column: bit z * 3 + axis
-    unsigned long long hits = 0ull;
-    for (int z = 0; z < R; ++z) {
-        const float f0 = s_f[(x * H + y) * H + z];
-        if (!(f0 < 0.98f && f0 >= -0.98f)) continue; // also rejects NaN (weight 0)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float f = s_f[((x + (i == 0)) * H + (y + (i == 1))) * H + (z + (i == 2))];
-            if (f < 0.98f && f >= -0.98f && f0 * f < 0) hits |= 1ull << (z * 3 + i);
+    // in-range / negative / positive masks (bit z) of column `col` of neighbour n (bit0 = +x, bit1 = +y, bit2 = +z)
+    auto column = [&](int n, int col, uint32_t &inr, uint32_t &neg, uint32_t &pos) {
+        const int nb = s_nbr[n];
+        uint32_t ip = 0u, on = 0u;
+        if (nb >= 0) {
+            ip = m_ip[(int64_t)nb * RR + col];
+            on = m_on[(int64_t)nb * RR + col];
         }
-    }
+        inr = ip & 0xffffu;
+        pos = ip >> 16;
+        neg = inr & (on >> 16);
+    };
+    uint32_t ia, na, pa, ib, nb_, pb, ic, nc, pc, id, nd, pd;
+    column(0, (int)threadIdx.x, ia, na, pa);
+    column(x == R - 1 ? 1 : 0, ((x + 1) & (R - 1)) * R + y, ib, nb_, pb);
+    column(y == R - 1 ? 2 : 0, x * R + ((y + 1) & (R - 1)), ic, nc, pc);
+    column(4, (int)threadIdx.x, id, nd, pd); // z = 16: bit 0 of the unit above
+    const uint32_t hx = ia & ib & ((na & pb) | (pa & nb_));
+    const uint32_t hy = ia & ic & ((na & pc) | (pa & nc));
+    const uint32_t i17 = ia | ((id & 1u) << 16), n17 = na | ((nd & 1u) << 16), p17 = pa | ((pd & 1u) << 16);
+    const uint32_t hz = i17 & (i17 >> 1) & ((n17 & (p17 >> 1)) | (p17 & (n17 >> 1))) & 0xffffu;
+    // hits of this column: bit axis * 16 + z
+    const unsigned long long hits = (unsigned long long)hx | ((unsigned long long)hy << 16) | ((unsigned long long)hz << 32);
     const int mine = __popcll(hits);
     const int lane = hv_lane_id(), wave = threadIdx.x >> 6;
     int incl = mine;
@@ -509,7 +494,7 @@ __global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *_
         }
         const int x = lo >> 4, y = lo & 15;
         const int bit = hv_nth_set_bit(s_hits[lo], r - s_pre[lo]);
-        const int z = bit / 3, i = bit - z * 3;
+        const int i = bit >> 4, z = bit & 15;
         const int lin = voxel_word(x, y, z);
         const float f0 = ((const float *)u0)[lin];
         const uint32_t w0 = ((const uint32_t *)(u0 + PLANE_BYTES))[lin];
@@ -649,6 +634,24 @@ extern "C" {
 // allocated by the caller).  The call without output pointers does ALL the device work into out_a / out_b and records it
 // under the volume's content_version; the call with pointers then only copies - unless the volume changed in between (or
 // no size query preceded it), in which case it recomputes first.
+// k_unit_masks for the volume's current contents (kept under content_version: a tick that extracts the mesh AND the point
+// cloud of the same contents computes them once)
+static int unit_masks_compute(hv_volume *v, int n, const uint32_t **m_on, const uint32_t **m_ip) {
+    const size_t plane = sizeof(uint32_t) * RR * (size_t)n;
+    int rc = hv_ensure_buffer(v, &v->unit_masks, &v->unit_masks_bytes, 2 * plane);
+    if (rc != HV_OK) return rc;
+    uint32_t *on = (uint32_t *)v->unit_masks, *ip = on + (size_t)RR * n;
+    if (v->unit_masks_version != v->content_version || v->unit_masks_units != n) {
+        hipLaunchKernelGGL(k_unit_masks, dim3(n), dim3(256), 0, v->stream, (const char *)v->pool, n, on, ip);
+        HV_HIP(hipGetLastError());
+        v->unit_masks_version = v->content_version;
+        v->unit_masks_units = n;
+    }
+    *m_on = on;
+    *m_ip = ip;
+    return HV_OK;
+}
+
 static int mesh_compute(hv_volume *v) {
     int rc = upload_tables(v->device);
     if (rc != HV_OK) return rc;
@@ -678,11 +681,13 @@ static int mesh_compute(hv_volume *v) {
     int32_t *vert_base = tri_count + (n + 1);
     int32_t *tri_base = vert_base + (n + 1);
     uint8_t *cases = (uint8_t *)(base + cases_off);
-    hv_profile_begin(v); // measurement hook: classify + prefix + scans
+    hv_profile_begin(v); // measurement hook: column masks + classify + scans
+    const uint32_t *m_on = nullptr, *m_ip = nullptr;
+    rc = unit_masks_compute(v, n, &m_on, &m_ip);
+    if (rc != HV_OK) return rc;
     HV_HIP(hipMemsetAsync(vert_count, 0, 2 * cnt_bytes, v->stream));
-    hipLaunchKernelGGL(k_mc_classify, dim3(n), dim3(256), 0, v->stream, v->table, (const char *)v->pool, n, edge_mask,
+    hipLaunchKernelGGL(k_mc_classify, dim3(n), dim3(256), 0, v->stream, v->table, m_on, n, edge_mask, word_prefix, vert_count,
                        tri_count, cases);
-    hipLaunchKernelGGL(k_mc_prefix, dim3(n), dim3(256), 0, v->stream, edge_mask, n, word_prefix, vert_count);
     HV_HIP(hipGetLastError());
     rc = exclusive_scan_i32(v, vert_count, vert_base, n + 1);
     if (rc != HV_OK) return rc;
@@ -756,10 +761,13 @@ static int points_compute(hv_volume *v) {
     rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, sizeof(int32_t) * 2 * (size_t)(nu + 1));
     if (rc != HV_OK) return rc;
     int32_t *count = (int32_t *)v->out_c, *base = count + (nu + 1);
-    // pass 1 counts per unit (tsdf + weight planes only), the scan places the units, pass 2 writes into a buffer of exactly
+    // pass 1 counts per unit (from the column masks), the scan places the units, pass 2 writes into a buffer of exactly
     // that size
     hv_profile_begin(v);
-    hipLaunchKernelGGL(k_pc_extract<false>, dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, nu, M,
+    const uint32_t *m_on = nullptr, *m_ip = nullptr;
+    rc = unit_masks_compute(v, nu, &m_on, &m_ip);
+    if (rc != HV_OK) return rc;
+    hipLaunchKernelGGL(k_pc_extract<false>, dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, m_on, m_ip, nu, M,
                        v->cfg.voxel_size * (double)R, count, (const int32_t *)nullptr, (double *)nullptr, (double *)nullptr, (int64_t)0);
     HV_HIP(hipGetLastError());
     rc = exclusive_scan_i32(v, count, base, nu + 1);
@@ -774,7 +782,7 @@ static int points_compute(hv_volume *v) {
         if (rc != HV_OK) return rc;
         double *d_pts = (double *)v->out_a, *d_cols = d_pts + 3 * n;
         hv_profile_begin(v);
-        hipLaunchKernelGGL(k_pc_extract<true>, dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, nu, M,
+        hipLaunchKernelGGL(k_pc_extract<true>, dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, m_on, m_ip, nu, M,
                            v->cfg.voxel_size * (double)R, (int32_t *)nullptr, (const int32_t *)base, d_pts, d_cols, n);
         hv_profile_end(v, nb);
         HV_HIP(hipGetLastError());

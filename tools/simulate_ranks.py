@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--mode", default="batch")
     ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--sharding", default="owner", choices=["owner", "tile"],
+                    help="owner: owner(unit) == rank; tile: vertical image tiles (a unit several tiles see is fused by each of them, "
+                         "partial means - what merge_halo() reconciles; not timed here)")
     args = ap.parse_args()
     import torch
 
@@ -36,7 +39,7 @@ def main():
     for world in [int(w) for w in args.worlds.split(",")]:
         per_rank = []
         for rank in range(world):
-            f = ShardedTSDF(VOXEL, SDF_TRUNC, s.width, s.height, device=0, max_blocks=1 << 15, rank=rank, world_size=world, sharding="owner")
+            f = ShardedTSDF(VOXEL, SDF_TRUNC, s.width, s.height, device=0, max_blocks=1 << 15, rank=rank, world_size=world, sharding=args.sharding)
             vol = f.volume
 
             def step():
@@ -57,7 +60,7 @@ def main():
             del f, vol
         ms = max(per_rank)
         base = base or ms
-        print(json.dumps({"world": world, "mode": args.mode, "ms_per_step_slowest_rank": round(ms, 4),
+        print(json.dumps({"world": world, "sharding": args.sharding, "mode": args.mode, "ms_per_step_slowest_rank": round(ms, 4),
                           "ms_per_rank": [round(x, 4) for x in per_rank], "frames_per_s": round(B / ms * 1e3, 1),
                           "speedup_vs_1": round(base / ms, 3), "units_last_rank": int(units)}), flush=True)
 
