@@ -38,7 +38,7 @@ static constexpr int UNIT_BYTES = PLANE_BYTES * HV_TSDF_PLANES;
 static constexpr int MASK_WORDS = 3 * RRR / 64; // 192
 
 __constant__ unsigned short c_edge_table[256];
-__constant__ signed char c_tri_table[256][16];
+__constant__ __attribute__((aligned(16))) signed char c_tri_table[256][16];
 __constant__ unsigned char c_tri_count[256];
 
 __device__ __forceinline__ int voxel_word(int x, int y, int z) { return z * RR + x * R + y; }
@@ -118,15 +118,18 @@ __global__ __launch_bounds__(256) void k_unit_masks(const char *__restrict__ poo
 static constexpr int H2 = 18;
 __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32_t *__restrict__ m_on, int n_units,
                                                       unsigned long long *__restrict__ edge_mask,
-                                                      uint32_t *__restrict__ word_prefix, int32_t *__restrict__ vert_count,
-                                                      int32_t *__restrict__ tri_count, uint8_t *__restrict__ cases) {
+                                                      uint32_t *__restrict__ word_prefix, unsigned long long *__restrict__ counts,
+                                                      uint8_t *__restrict__ cases) {
     __shared__ uint32_t s_cnt[MASK_WORDS]; // popcounts of the unit's mask words
+    __shared__ uint8_t s_tcnt[256];        // triangles per cube case (a per-lane index into constant memory is a vector load)
+    s_tcnt[threadIdx.x] = c_tri_count[threadIdx.x];
     __shared__ int s_nbr[27]; // pool index of the unit at offset (dx, dy, dz) in {-1, 0, 1}^3: [(dx + 1) + 3 (dy + 1) + 9 (dz + 1)]
     __shared__ uint32_t s_obs[H2 * H2], s_neg[H2 * H2]; // [(cx + 1) * 18 + (cy + 1)], bit k <-> z = k - 1
     __shared__ int s_tris;
     const int idx = blockIdx.x;
     if (idx >= n_units) return;
     if (threadIdx.x == 0) s_tris = 0;
+    if (idx == 0 && threadIdx.x == 1) counts[n_units] = 0ull; // the scan's extra element: its output there is the total
     if (threadIdx.x < 27) {
         int32_t ux, uy, uz;
         hv_unpack_key(table.block_keys[idx], ux, uy, uz);
@@ -213,12 +216,11 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32
                          (((c3 >> (z + 1)) & 1u) << 7));
         if (!((V11 >> (z + 1)) & 1u) || cube == 255) cube = 0;
         packed[z >> 2] |= (uint32_t)cube << ((z & 3) * 8);
-        tris += c_tri_count[cube];
+        tris += s_tcnt[cube];
     }
     ((uint4 *)(cases + (int64_t)idx * RRR))[threadIdx.x] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
     if (tris) atomicAdd(&s_tris, tris);
     __syncthreads();
-    if (threadIdx.x == 0) tri_count[idx] = s_tris;
     if (wave == 0) { // exclusive popcount prefix over the 192 mask words: three words per lane + a wave scan
         const uint32_t c0 = s_cnt[lane * 3], c1 = s_cnt[lane * 3 + 1], c2 = s_cnt[lane * 3 + 2];
         uint32_t incl = c0 + c1 + c2;
@@ -232,7 +234,8 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32
         wp[0] = before;
         wp[1] = before + c0;
         wp[2] = before + c0 + c1;
-        if (lane == HV_WAVE - 1) vert_count[idx] = (int32_t)incl;
+        // vertices in the low half, triangles in the high half: ONE 64-bit scan gives both bases
+        if (lane == HV_WAVE - 1) counts[idx] = (unsigned long long)incl | ((unsigned long long)(uint32_t)s_tris << 32);
     }
 }
 
@@ -261,7 +264,7 @@ __device__ __forceinline__ int hv_nth_set_bit(unsigned long long m, int n) { // 
 __global__ __launch_bounds__(64) void k_mc_vertices(HvTable table, const char *__restrict__ pool, int n_units,
                                                      const unsigned long long *__restrict__ edge_mask,
                                                      const uint32_t *__restrict__ word_prefix,
-                                                     const int32_t *__restrict__ vert_base, HvMcParams M,
+                                                     const unsigned long long *__restrict__ bases, HvMcParams M,
                                                      double *__restrict__ vertices, double *__restrict__ colors,
                                                      int64_t cap) {
     __shared__ unsigned long long s_mask[MASK_WORDS];
@@ -269,16 +272,16 @@ __global__ __launch_bounds__(64) void k_mc_vertices(HvTable table, const char *_
     const int idx = blockIdx.x;
     if (idx >= n_units) return;
     const int lane = threadIdx.x;
+    const int64_t vbase = (int64_t)(uint32_t)bases[idx];
+    const int total = (int)((uint32_t)bases[idx + 1] - (uint32_t)vbase);
+    if (total == 0) return; // most allocated units hold no surface
     for (int w = lane; w < MASK_WORDS; w += HV_WAVE) {
         s_mask[w] = edge_mask[(int64_t)idx * MASK_WORDS + w];
         s_prefix[w] = word_prefix[(int64_t)idx * MASK_WORDS + w];
     }
-    const int64_t vbase = vert_base[idx];
-    const int total = (int)(vert_base[idx + 1] - vbase);
     if (lane == 0) s_prefix[MASK_WORDS] = (uint32_t)total;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (total == 0) return;
     int32_t ux, uy, uz;
     hv_unpack_key(table.block_keys[idx], ux, uy, uz);
     const char *u0 = pool + (int64_t)idx * UNIT_BYTES;
@@ -329,23 +332,51 @@ __global__ __launch_bounds__(64) void k_mc_vertices(HvTable table, const char *_
     }
 }
 
-// Reads the cube cases k_mc_classify left (16 bytes per thread: its column) instead of staging the slab again.
+// Reads the cube cases k_mc_classify left (16 bytes per thread: its column) instead of staging the slab again.  Everything a
+// triangle asks for repeatedly sits in LDS: the triangle table and the per-case counts (a per-lane index into constant memory
+// is a vector load), each column's 16 counts as nibbles (the walk to a triangle's cube is register arithmetic), and the
+// unit's own edge masks / prefixes (five of six vertex ids are the unit's own; the rest read the neighbour's words).
 __global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, int n_units, const uint8_t *__restrict__ cases,
                                                        const unsigned long long *__restrict__ edge_mask,
                                                        const uint32_t *__restrict__ word_prefix,
-                                                       const int32_t *__restrict__ vert_base,
-                                                       const int32_t *__restrict__ tri_base,
+                                                       const unsigned long long *__restrict__ bases,
                                                        int32_t *__restrict__ triangles, int64_t cap) {
     __shared__ int s_nbr[8];
+    __shared__ int32_t s_vbase[8];
     __shared__ int s_wave[4];
+    __shared__ uint8_t s_tcnt[256];
+    __shared__ signed char s_tt[256 * 16];
+    __shared__ unsigned long long s_mask[MASK_WORDS];
+    __shared__ uint32_t s_pref[MASK_WORDS];
+    __shared__ uint4 s_cases[256];
+    __shared__ unsigned long long s_nib[256];
+    __shared__ int s_pre[257];
     const int idx = blockIdx.x;
     if (idx >= n_units) return;
+    const int64_t tbase = (int64_t)(bases[idx] >> 32);
+    const int total = (int)((bases[idx + 1] >> 32) - (unsigned long long)tbase);
+    if (total == 0) return; // most allocated units hold no surface
     load_neighbours(table, idx, s_nbr);
+    s_tcnt[threadIdx.x] = c_tri_count[threadIdx.x];
+    ((uint4 *)s_tt)[threadIdx.x] = ((const uint4 *)&c_tri_table[0][0])[threadIdx.x];
+    if (threadIdx.x < MASK_WORDS) {
+        s_mask[threadIdx.x] = edge_mask[(int64_t)idx * MASK_WORDS + threadIdx.x];
+        s_pref[threadIdx.x] = word_prefix[(int64_t)idx * MASK_WORDS + threadIdx.x];
+    }
     const uint4 pk = ((const uint4 *)(cases + (int64_t)idx * RRR))[threadIdx.x];
+    s_cases[threadIdx.x] = pk;
+    __syncthreads();
+    if (threadIdx.x < 8) s_vbase[threadIdx.x] = s_nbr[threadIdx.x] >= 0 ? (int32_t)(uint32_t)bases[s_nbr[threadIdx.x]] : 0;
     const uint32_t packed[4] = {pk.x, pk.y, pk.z, pk.w};
     int tris = 0;
+    unsigned long long nib = 0ull; // nibble z: triangles of the column's cube z (at most 5)
 #pragma unroll
-    for (int z = 0; z < R; ++z) tris += c_tri_count[(packed[z >> 2] >> ((z & 3) * 8)) & 255u];
+    for (int z = 0; z < R; ++z) {
+        const int c = s_tcnt[(packed[z >> 2] >> ((z & 3) * 8)) & 255u];
+        tris += c;
+        nib |= (unsigned long long)c << (4 * z);
+    }
+    s_nib[threadIdx.x] = nib;
     // rank of this thread's triangles inside the unit: wave prefix + the 4 wave totals
     const int lane = hv_lane_id(), wave = threadIdx.x >> 6;
     int incl = tris;
@@ -355,19 +386,14 @@ __global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, int n_units
         if (lane >= o) incl += up;
     }
     if (lane == HV_WAVE - 1) s_wave[wave] = incl;
-    __syncthreads(); // also orders s_nbr
+    __syncthreads();
     int before = 0;
     for (int w = 0; w < wave; ++w) before += s_wave[w];
     // The unit's triangles are dealt out evenly (as the vertices and the points are): triangle r belongs to the column whose
-    // exclusive count is the last one <= r; inside the column it is found by walking the 16 stored cases.
-    __shared__ uint4 s_cases[256];
-    __shared__ int s_pre[257];
-    s_cases[threadIdx.x] = pk;
+    // exclusive count is the last one <= r; inside the column it is found by walking the 16 counts.
     s_pre[threadIdx.x] = before + incl - tris;
     if (threadIdx.x == 255) s_pre[256] = before + incl;
     __syncthreads();
-    const int total = s_pre[256];
-    const int64_t tbase = tri_base[idx];
     for (int r = threadIdx.x; r < total; r += 256) {
         const int64_t at = tbase + r;
         int lo = 0, hi = 256; // s_pre[lo] <= r < s_pre[hi]
@@ -376,34 +402,39 @@ __global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, int n_units
             if (s_pre[mid] <= r) lo = mid; else hi = mid;
         }
         const int x = lo >> 4, y = lo & 15;
-        const uint4 cpk = s_cases[lo];
-        int j = r - s_pre[lo], z = 0, cube = 0;
-        for (; z < R; ++z) {
-            const uint32_t cw = z < 4 ? cpk.x : z < 8 ? cpk.y : z < 12 ? cpk.z : cpk.w;
-            cube = (int)((cw >> ((z & 3) * 8)) & 255u);
-            const int c = c_tri_count[cube];
+        unsigned long long cw = s_nib[lo];
+        int j = r - s_pre[lo], z = 0;
+        for (; z < R - 1; ++z) {
+            const int c = (int)(cw & 15ull);
             if (j < c) break;
             j -= c;
+            cw >>= 4;
         }
-        {
-            const int i = 3 * j;
-            const int order[3] = {i, i + 2, i + 1}; // Open3D emits (e[i], e[i+2], e[i+1])
-            int32_t vid[3];
+        const int cube = ((const uint8_t *)&s_cases[lo])[z];
+        const int i = 3 * j;
+        const int order[3] = {i, i + 2, i + 1}; // Open3D emits (e[i], e[i+2], e[i+1])
+        int32_t vid[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                int n, axis, lin;
-                edge_owner(x, y, z, c_tri_table[cube][order[k]], n, axis, lin);
+        for (int k = 0; k < 3; ++k) {
+            int n, axis, lin;
+            edge_owner(x, y, z, s_tt[cube * 16 + order[k]], n, axis, lin);
+            const int word = axis * (RRR / 64) + (lin >> 6);
+            unsigned long long m;
+            uint32_t pre;
+            if (n == 0) {
+                m = s_mask[word];
+                pre = s_pref[word];
+            } else {
                 const int oidx = s_nbr[n];
-                const int word = axis * (RRR / 64) + (lin >> 6);
-                const unsigned long long m = edge_mask[(int64_t)oidx * MASK_WORDS + word];
-                vid[k] = vert_base[oidx] + (int32_t)word_prefix[(int64_t)oidx * MASK_WORDS + word] +
-                         (int32_t)__popcll(m & ((1ull << (lin & 63)) - 1));
+                m = edge_mask[(int64_t)oidx * MASK_WORDS + word];
+                pre = word_prefix[(int64_t)oidx * MASK_WORDS + word];
             }
-            if (at < cap) {
-                triangles[at * 3 + 0] = vid[0];
-                triangles[at * 3 + 1] = vid[1];
-                triangles[at * 3 + 2] = vid[2];
-            }
+            vid[k] = s_vbase[n] + (int32_t)pre + (int32_t)__popcll(m & ((1ull << (lin & 63)) - 1));
+        }
+        if (at < cap) {
+            triangles[at * 3 + 0] = vid[0];
+            triangles[at * 3 + 1] = vid[1];
+            triangles[at * 3 + 2] = vid[2];
         }
     }
 }
@@ -426,6 +457,7 @@ __global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *_
     __shared__ int s_wave[4];
     const int idx = blockIdx.x;
     if (idx >= n_units) return;
+    if (FILL && base[idx + 1] == base[idx]) return; // most allocated units hold no surface
     load_neighbours(table, idx, s_nbr);
     __syncthreads();
     const int x = threadIdx.x >> 4, y = threadIdx.x & 15;
@@ -628,6 +660,16 @@ static int exclusive_scan_i32(hv_volume *v, int32_t *in, int32_t *out, int n) {
     return HV_OK;
 }
 
+static int exclusive_scan_u64(hv_volume *v, unsigned long long *in, unsigned long long *out, int n) {
+    size_t bytes = 0;
+    HV_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), v->stream));
+    int rc = hv_ensure_buffer(v, &v->sort_tmp, &v->sort_tmp_bytes, bytes);
+    if (rc != HV_OK) return rc;
+    bytes = v->sort_tmp_bytes;
+    HV_HIP(rocprim::exclusive_scan(v->sort_tmp, bytes, in, out, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), v->stream));
+    return HV_OK;
+}
+
 extern "C" {
 
 // Both extraction entry points follow the "sizes first, data second" protocol of the reference binding (numpy arrays are
@@ -666,38 +708,33 @@ static int mesh_compute(hv_volume *v) {
         return HV_OK;
     }
     const int n = (int)nb;
-    // scratch: [edge_mask nb*192 u64][word_prefix nb*192 u32][vert_count n+1][tri_count n+1][vert_base n+1][tri_base n+1][cases nb*4096 u8]
+    // scratch: [edge_mask nb*192 u64][counts n+1 u64][bases n+1 u64][word_prefix nb*192 u32][cases nb*4096 u8]
+    // counts / bases: vertices in the low 32 bits, triangles in the high 32 bits of one word per unit
     const size_t mask_bytes = sizeof(uint64_t) * MASK_WORDS * (size_t)n;
+    const size_t cnt_bytes = sizeof(uint64_t) * (size_t)(n + 1);
     const size_t prefix_bytes = sizeof(uint32_t) * MASK_WORDS * (size_t)n;
-    const size_t cnt_bytes = sizeof(int32_t) * (size_t)(n + 1);
-    const size_t cases_off = (mask_bytes + prefix_bytes + 4 * cnt_bytes + 255) & ~(size_t)255;
+    const size_t cases_off = (mask_bytes + 2 * cnt_bytes + prefix_bytes + 255) & ~(size_t)255;
     rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, cases_off + (size_t)n * RRR + 64);
     if (rc != HV_OK) return rc;
     char *base = (char *)v->out_c;
     unsigned long long *edge_mask = (unsigned long long *)base;
-    uint32_t *word_prefix = (uint32_t *)(base + mask_bytes);
-    int32_t *vert_count = (int32_t *)(base + mask_bytes + prefix_bytes);
-    int32_t *tri_count = vert_count + (n + 1);
-    int32_t *vert_base = tri_count + (n + 1);
-    int32_t *tri_base = vert_base + (n + 1);
+    unsigned long long *counts = (unsigned long long *)(base + mask_bytes);
+    unsigned long long *bases = counts + (n + 1);
+    uint32_t *word_prefix = (uint32_t *)(base + mask_bytes + 2 * cnt_bytes);
     uint8_t *cases = (uint8_t *)(base + cases_off);
-    hv_profile_begin(v); // measurement hook: column masks + classify + scans
+    hv_profile_begin(v); // measurement hook: column masks + classify + scan
     const uint32_t *m_on = nullptr, *m_ip = nullptr;
     rc = unit_masks_compute(v, n, &m_on, &m_ip);
     if (rc != HV_OK) return rc;
-    HV_HIP(hipMemsetAsync(vert_count, 0, 2 * cnt_bytes, v->stream));
-    hipLaunchKernelGGL(k_mc_classify, dim3(n), dim3(256), 0, v->stream, v->table, m_on, n, edge_mask, word_prefix, vert_count,
-                       tri_count, cases);
+    hipLaunchKernelGGL(k_mc_classify, dim3(n), dim3(256), 0, v->stream, v->table, m_on, n, edge_mask, word_prefix, counts, cases);
     HV_HIP(hipGetLastError());
-    rc = exclusive_scan_i32(v, vert_count, vert_base, n + 1);
-    if (rc != HV_OK) return rc;
-    rc = exclusive_scan_i32(v, tri_count, tri_base, n + 1);
+    rc = exclusive_scan_u64(v, counts, bases, n + 1);
     if (rc != HV_OK) return rc;
     hv_profile_end(v, n);
-    int32_t totals[2] = {0, 0};
-    HV_HIP(hipMemcpyAsync(&totals[0], vert_base + n, sizeof(int32_t), hipMemcpyDeviceToHost, v->stream));
-    HV_HIP(hipMemcpyAsync(&totals[1], tri_base + n, sizeof(int32_t), hipMemcpyDeviceToHost, v->stream));
+    unsigned long long total64 = 0ull;
+    HV_HIP(hipMemcpyAsync(&total64, bases + n, sizeof(total64), hipMemcpyDeviceToHost, v->stream));
     HV_HIP(hipStreamSynchronize(v->stream));
+    const int64_t totals[2] = {(int64_t)(uint32_t)total64, (int64_t)(total64 >> 32)};
     const int64_t nv = totals[0], nt = totals[1];
     if (nv > 0 || nt > 0) {
         rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, sizeof(double) * 6 * (size_t)std::max<int64_t>(nv, 1));
@@ -708,9 +745,9 @@ static int mesh_compute(hv_volume *v) {
         HvMcParams M{v->cfg.voxel_size, v->cfg.voxel_size * 0.5};
         hv_profile_begin(v); // vertices + triangles (D2H of the results is outside the bracket)
         hipLaunchKernelGGL(k_mc_vertices, dim3(n), dim3(64), 0, v->stream, v->table,
-                           (const char *)v->pool, n, edge_mask, word_prefix, vert_base, M, d_vert, d_col, nv);
+                           (const char *)v->pool, n, edge_mask, word_prefix, bases, M, d_vert, d_col, nv);
         hipLaunchKernelGGL(k_mc_triangles, dim3(n), dim3(256), 0, v->stream, v->table, n, (const uint8_t *)cases, edge_mask,
-                           word_prefix, vert_base, tri_base, (int32_t *)v->out_b, nt);
+                           word_prefix, bases, (int32_t *)v->out_b, nt);
         hv_profile_end(v, n);
         HV_HIP(hipGetLastError());
     }
