@@ -125,7 +125,9 @@ int hv_remap(hv_volume *v, const void *src, int32_t src_kind, int32_t channels, 
 
 /* filter_shadow_points(depth, delta_depth=None, delta_x=2, delta_y=2, fill_value=-1)
  * (pyslam/utilities/depth.py:103-146): MAD-thresholded depth-discontinuity filter, bit-identical to
- * the numpy reference for float32 depth.  Works on any volume (uses its stream and scratch). */
+ * the numpy reference for float32 depth.  Works on any volume (uses its stream and scratch).  Host images (loc =
+ * HV_HOST) are complete on return; with HV_DEVICE the launches are queued on the volume's stream (hv_get_stream) and the
+ * call returns without waiting, like the integrate entry points. */
 int hv_filter_shadow_points(hv_volume *v, const float *depth, int32_t height, int32_t width, int32_t delta_x,
                             int32_t delta_y, float fill_value, float *out, int32_t loc);
 

@@ -738,35 +738,118 @@ __global__ __launch_bounds__(256) void k_vg_probe_keys(const float *__restrict__
 // ---- filter_shadow_points (pyslam/utilities/depth.py:103-146) -----------------------------------
 // |d(r,c) - d(r-dy,c)| and |d(r,c) - d(r,c-dx)|; threshold = 3 * 1.4826 * median(positive deltas)
 // (float32 arithmetic, as numpy evaluates it for a float32 image); both endpoints of a large jump
-// are replaced by fill_value.  The global median is a device radix sort of the positive deltas'
-// bit patterns (order-preserving for positive floats) + a read of the middle element(s).
-__global__ __launch_bounds__(256) void k_shadow_deltas(const float *__restrict__ depth, int H, int W, int dx, int dy,
-                                                        uint32_t *__restrict__ keys, int32_t *__restrict__ n_pos) {
-    const int64_t n_y = dy > 0 ? (int64_t)(H - dy) * W : 0;
-    const int64_t n_x = dx > 0 ? (int64_t)H * (W - dx) : 0;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool pos = false;
-    if (i < n_y + n_x) {
-        float d;
-        if (i < n_y) {
-            const int64_t r = i / W + dy, c = i % W;
-            d = fabsf(depth[r * W + c] - depth[(r - dy) * W + c]);
+// are replaced by fill_value.  The global median is an exact radix SELECT on the deltas' bit patterns (order-preserving for
+// positive floats): three histogram passes over the image (12 + 12 + 8 bits), each followed by a one-workgroup pick of the
+// bin(s) that hold the two middle ranks; the deltas are recomputed in every pass (two subtractions) instead of being stored,
+// and the threshold stays in device memory for the mask kernel - no sort, no host round trip.  (Round 2: the deltas were
+// written out, radix-sorted (19 launches) and the middle elements copied to the host - 0.33 ms of a 1.2 ms semantic keyframe,
+// profiles/r03/kernel_stats_semantic.csv.)
+// state words: [0] number of positive deltas, [1] [2] remaining ranks of the two middle elements, [3] [4] their key prefixes,
+// [5] the threshold (float bits)
+enum { HV_SH_N = 0, HV_SH_RANK0 = 1, HV_SH_RANK1 = 2, HV_SH_PRE0 = 3, HV_SH_PRE1 = 4, HV_SH_THR = 5, HV_SH_WORDS = 8 };
+static constexpr int HV_SH_BINS01 = 4096, HV_SH_BINS2 = 256;
+static constexpr int HV_SH_HIST_WORDS = HV_SH_BINS01 + 2 * HV_SH_BINS01 + 2 * HV_SH_BINS2;
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_shadow_hist(const float *__restrict__ depth, int H, int W, int dx, int dy,
+                                                      const uint32_t *__restrict__ state, uint32_t *__restrict__ hist) {
+    constexpr int BINS = PASS == 2 ? HV_SH_BINS2 : HV_SH_BINS01;
+    constexpr int NB = (PASS == 0 ? 1 : 2) * BINS;
+    __shared__ uint32_t s_h[NB];
+    for (int i = threadIdx.x; i < NB; i += 256) s_h[i] = 0u;
+    __syncthreads();
+    const uint32_t p0 = PASS > 0 ? state[HV_SH_PRE0] : 0u, p1 = PASS > 0 ? state[HV_SH_PRE1] : 0u;
+    auto add = [&](float v) {
+        if (!(v > 0.0f)) return; // NaN compares false, like numpy's `delta_values > 0`
+        const uint32_t key = __float_as_uint(v);
+        if (PASS == 0) {
+            atomicAdd(&s_h[key >> 20], 1u);
+        } else if (PASS == 1) {
+            if ((key >> 20) == p0) atomicAdd(&s_h[(key >> 8) & 0xfffu], 1u);
+            if ((key >> 20) == p1) atomicAdd(&s_h[BINS + ((key >> 8) & 0xfffu)], 1u);
         } else {
-            const int64_t j = i - n_y;
-            const int64_t r = j / (W - dx), c = j % (W - dx) + dx;
-            d = fabsf(depth[r * W + c] - depth[r * W + c - dx]);
+            if ((key >> 8) == p0) atomicAdd(&s_h[key & 0xffu], 1u);
+            if ((key >> 8) == p1) atomicAdd(&s_h[BINS + (key & 0xffu)], 1u);
         }
-        pos = d > 0.0f; // NaN compares false, like numpy's `delta_values > 0`
-        keys[i] = pos ? __float_as_uint(d) : 0xFFFFFFFFu;
+    };
+    const int npx = H * W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npx; i += gridDim.x * 256) {
+        const int r = i / W, c = i - r * W;
+        const float d = depth[i];
+        if (dy > 0 && r >= dy) add(fabsf(d - depth[i - dy * W]));
+        if (dx > 0 && c >= dx) add(fabsf(d - depth[i - dx]));
     }
-    const unsigned long long m = __ballot(pos);
-    if (m && hv_lane_id() == 0) atomicAdd(n_pos, (int32_t)__popcll(m));
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB; i += 256)
+        if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+
+// one workgroup: the bin holding each of the two ranks, the rank inside it
+template <int PASS>
+__global__ __launch_bounds__(256) void k_shadow_pick(const uint32_t *__restrict__ hist, uint32_t *__restrict__ state) {
+    constexpr int BINS = PASS == 2 ? HV_SH_BINS2 : HV_SH_BINS01;
+    constexpr int PER = BINS / 256;
+    constexpr int BITS = PASS == 2 ? 8 : 12;
+    __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t s_rank[2];
+    const int t = threadIdx.x;
+    for (int target = 0; target < 2; ++target) {
+        const uint32_t *h = hist + (PASS == 0 ? 0 : target * BINS);
+        uint32_t local[PER], sum = 0u;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            local[k] = h[t * PER + k];
+            sum += local[k];
+        }
+        s_scan[t] = sum;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) { // Hillis-Steele inclusive scan
+            const uint32_t addv = t >= off ? s_scan[t - off] : 0u;
+            __syncthreads();
+            s_scan[t] += addv;
+            __syncthreads();
+        }
+        if (PASS == 0 && t == 0) {
+            const uint32_t n = s_scan[255];
+            if (target == 0) state[HV_SH_N] = n;
+            s_rank[target] = n ? (target == 0 ? (n - 1u) / 2u : n / 2u) : 0u; // ranks of np.median's two middle elements
+        }
+        if (PASS > 0 && t == 0) s_rank[target] = state[HV_SH_RANK0 + target];
+        __syncthreads();
+        const uint32_t rank = s_rank[target];
+        const uint32_t incl = s_scan[t];
+        uint32_t before = incl - sum;
+        if (rank >= before && rank < incl) { // exactly one thread when the rank exists
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                if (rank < before + local[k]) {
+                    const uint32_t prefix = PASS == 0 ? 0u : state[HV_SH_PRE0 + target];
+                    state[HV_SH_PRE0 + target] = (prefix << BITS) | (uint32_t)(t * PER + k);
+                    state[HV_SH_RANK0 + target] = rank - before;
+                    break;
+                }
+                before += local[k];
+            }
+        }
+        __syncthreads();
+    }
+    if (PASS == 2 && t == 0) {
+        float thr = __uint_as_float(0x7fc00000u); // np.median of an empty array -> nan -> nothing is masked
+        if (state[HV_SH_N]) {
+            const float a = __uint_as_float(state[HV_SH_PRE0]), b = __uint_as_float(state[HV_SH_PRE1]);
+            const float mad = state[HV_SH_PRE0] == state[HV_SH_PRE1] ? a : (a + b) * 0.5f; // np.median -> np.mean of the two middle float32
+            const float sigma = 1.4826f * mad;
+            thr = 3.0f * sigma;
+        }
+        state[HV_SH_THR] = __float_as_uint(thr);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_shadow_mask(const float *__restrict__ depth, int H, int W, int dx, int dy,
-                                                      float thr, float fill, float *__restrict__ out) {
+                                                      const uint32_t *__restrict__ state, float fill, float *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)H * W) return;
+    const float thr = __uint_as_float(state[HV_SH_THR]);
     const int r = (int)(i / W), c = (int)(i % W);
     const float d = depth[i];
     bool m = false;
@@ -1175,49 +1258,34 @@ int hv_filter_shadow_points(hv_volume *v, const float *depth, int32_t height, in
                HV_ERR_INVALID, "hv_filter_shadow_points: bad image size or deltas");
     HV_HIP(hipSetDevice(v->device));
     const int64_t npx = (int64_t)height * width;
-    const int64_t n_y = delta_y > 0 ? (int64_t)(height - delta_y) * width : 0;
-    const int64_t n_x = delta_x > 0 ? (int64_t)height * (width - delta_x) : 0;
-    const int64_t n = n_y + n_x;
+    HV_REQUIRE(npx < (int64_t)1 << 30, HV_ERR_INVALID, "hv_filter_shadow_points: image too large");
     const void *d_depth = nullptr;
     int rc = hv_stage_in(v, depth, sizeof(float) * npx, loc, 0, &d_depth);
     if (rc != HV_OK) return rc;
-    // scratch: [keys_in n][keys_out n][out npx]
-    rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, sizeof(uint32_t) * 2 * (size_t)std::max<int64_t>(n, 1) + sizeof(float) * npx);
+    // scratch: [histograms][state][out npx]
+    const size_t head = sizeof(uint32_t) * (HV_SH_HIST_WORDS + HV_SH_WORDS);
+    rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, head + sizeof(float) * npx);
     if (rc != HV_OK) return rc;
-    uint32_t *keys_in = (uint32_t *)v->out_c, *keys_out = keys_in + std::max<int64_t>(n, 1);
-    float *d_out = loc == HV_DEVICE ? out : (float *)(keys_out + std::max<int64_t>(n, 1));
-    float thr = NAN; // np.median of an empty array -> nan -> nothing is masked
-    if (n > 0) {
-        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
-        hipLaunchKernelGGL(k_shadow_deltas, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream,
-                           (const float *)d_depth, height, width, delta_x, delta_y, keys_in, &v->table.counters[HV_CNT_OUT]);
-        size_t tmp = 0;
-        HV_HIP(rocprim::radix_sort_keys(nullptr, tmp, keys_in, keys_out, (size_t)n, 0, 32, v->stream));
-        rc = hv_ensure_buffer(v, &v->sort_tmp, &v->sort_tmp_bytes, tmp);
-        if (rc != HV_OK) return rc;
-        tmp = v->sort_tmp_bytes;
-        HV_HIP(rocprim::radix_sort_keys(v->sort_tmp, tmp, keys_in, keys_out, (size_t)n, 0, 32, v->stream));
-        rc = hv_read_counters(v);
-        if (rc != HV_OK) return rc;
-        const int64_t np_ = v->h_counters[HV_CNT_OUT];
-        if (np_ > 0) {
-            uint32_t mid[2] = {0, 0};
-            const int64_t lo = (np_ - 1) / 2, hi = np_ / 2; // equal for odd counts
-            HV_HIP(hipMemcpy(&mid[0], keys_out + lo, sizeof(uint32_t), hipMemcpyDeviceToHost));
-            HV_HIP(hipMemcpy(&mid[1], keys_out + hi, sizeof(uint32_t), hipMemcpyDeviceToHost));
-            float a, b;
-            memcpy(&a, &mid[0], 4);
-            memcpy(&b, &mid[1], 4);
-            const float mad = lo == hi ? a : (a + b) * 0.5f; // np.median -> np.mean of the two middle float32
-            const float sigma = 1.4826f * mad;
-            thr = 3.0f * sigma;
-        }
-    }
+    uint32_t *hist0 = (uint32_t *)v->out_c, *hist1 = hist0 + HV_SH_BINS01, *hist2 = hist1 + 2 * HV_SH_BINS01;
+    uint32_t *state = hist0 + HV_SH_HIST_WORDS;
+    float *d_out = loc == HV_DEVICE ? out : (float *)((char *)v->out_c + head);
+    HV_HIP(hipMemsetAsync(hist0, 0, head, v->stream));
+    const unsigned hist_grid = (unsigned)std::min<int64_t>((npx + 255) / 256, 1024);
+    const float *dd = (const float *)d_depth;
+    hipLaunchKernelGGL(k_shadow_hist<0>, dim3(hist_grid), dim3(256), 0, v->stream, dd, height, width, delta_x, delta_y, state, hist0);
+    hipLaunchKernelGGL(k_shadow_pick<0>, dim3(1), dim3(256), 0, v->stream, hist0, state);
+    hipLaunchKernelGGL(k_shadow_hist<1>, dim3(hist_grid), dim3(256), 0, v->stream, dd, height, width, delta_x, delta_y, state, hist1);
+    hipLaunchKernelGGL(k_shadow_pick<1>, dim3(1), dim3(256), 0, v->stream, hist1, state);
+    hipLaunchKernelGGL(k_shadow_hist<2>, dim3(hist_grid), dim3(256), 0, v->stream, dd, height, width, delta_x, delta_y, state, hist2);
+    hipLaunchKernelGGL(k_shadow_pick<2>, dim3(1), dim3(256), 0, v->stream, hist2, state);
     hipLaunchKernelGGL(k_shadow_mask, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream,
-                       (const float *)d_depth, height, width, delta_x, delta_y, thr, fill_value, d_out);
+                       dd, height, width, delta_x, delta_y, state, fill_value, d_out);
     HV_HIP(hipGetLastError());
-    if (loc == HV_HOST) HV_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * npx, hipMemcpyDeviceToHost, v->stream));
-    HV_HIP(hipStreamSynchronize(v->stream));
+    // host images: copied back and complete on return; device images: queued on the volume's stream like every other launch
+    if (loc == HV_HOST) {
+        HV_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * npx, hipMemcpyDeviceToHost, v->stream));
+        HV_HIP(hipStreamSynchronize(v->stream));
+    }
     return HV_OK;
 }
 

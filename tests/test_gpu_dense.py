@@ -41,6 +41,38 @@ def test_shadow_filter_bit_exact(config):
     np.testing.assert_array_equal(g.filter_shadow_points(flat), hp.filter_shadow_points(flat))
 
 
+def test_shadow_filter_median_select_edge_cases():
+    """The exact median comes from a three-pass radix select on the deltas' bit patterns: images built so that the two
+    middle ranks sit in one histogram bin, in neighbouring bins, in bins that differ in the top digit, with even and odd
+    counts, NaN / inf / zero deltas, non-default strides and one-row / one-column images - each against numpy's median."""
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    g = VoxelBlockGrid(0.02, 8, max_blocks=1 << 10, max_points=1 << 16)
+    rng = np.random.default_rng(11)
+    cases = []
+    for shape in ((5, 7), (1, 9), (9, 1), (33, 20), (64, 48)):
+        cases.append(rng.uniform(0.3, 5.0, shape).astype(np.float32))
+    a = rng.uniform(0.5, 4.0, (40, 40)).astype(np.float32)
+    a[::3, ::5] = np.nan
+    a[7, 9] = np.inf
+    a[10:14, :] = 2.0  # zero deltas
+    cases.append(a)
+    b = np.full((16, 16), 1.0, np.float32)  # two populations of deltas, orders of magnitude apart: the middle ranks straddle them
+    b[:, 8:] += np.float32(1e-4) * np.arange(8, dtype=np.float32)
+    b[8:, :] += np.float32(3.0)
+    cases.append(b)
+    c = np.cumsum(np.full((30, 30), 2.0 ** -12, np.float32), axis=1).astype(np.float32) + 1.0  # many identical deltas
+    cases.append(c)
+    for depth in cases:
+        for kw in ({}, {"delta_x": 1, "delta_y": 3}, {"delta_x": 0, "delta_y": 2}, {"delta_x": 3, "delta_y": 0}):
+            if kw.get("delta_x", 2) >= depth.shape[1] or kw.get("delta_y", 2) >= depth.shape[0]:
+                continue
+            with np.errstate(invalid="ignore"):
+                want = hp.filter_shadow_points(depth, **kw)
+            got = g.filter_shadow_points(depth, **kw)
+            np.testing.assert_array_equal(got, want, err_msg=f"{depth.shape} {kw}")
+
+
 def _params(voxel, trunc):
     from pyslam_amd.dense.parameters import Parameters
 
