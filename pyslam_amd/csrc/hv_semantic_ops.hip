@@ -126,18 +126,61 @@ __device__ inline void vote_add(unsigned long long *__restrict__ vkeys, int32_t 
     atomicAdd(overflow, 1);
 }
 
-// every lane with key != EMPTY votes once; one atomic per distinct key per wave
-__device__ __forceinline__ void vote_wave(unsigned long long *__restrict__ vkeys, int32_t *__restrict__ vcounts,
-                                          int32_t *overflow, uint64_t key) {
+// Workgroup-level vote table in LDS: a keyframe's votes fall on a handful of (instance, object) pairs, so with one global
+// atomic per distinct key per WAVE every wave of the scan queued behind the same few addresses.  The waves of a
+// workgroup add into HV_VOTE_LOCAL LDS slots instead (linear probing; a key that finds no slot goes to the global table
+// directly), and the persistent workgroup flushes its slots once at the end of its share of the scan.
+static constexpr int HV_VOTE_LOCAL = 64;
+struct HvVoteLocal {
+    unsigned long long keys[HV_VOTE_LOCAL];
+    int32_t counts[HV_VOTE_LOCAL];
+};
+
+__device__ __forceinline__ void vote_local_init(HvVoteLocal &L) {
+    for (int i = threadIdx.x; i < HV_VOTE_LOCAL; i += blockDim.x) {
+        L.keys[i] = HV_VOTE_EMPTY;
+        L.counts[i] = 0;
+    }
+    __syncthreads();
+}
+
+__device__ inline void vote_local_add(HvVoteLocal &L, unsigned long long *__restrict__ vkeys, int32_t *__restrict__ vcounts,
+                                      int32_t *overflow, uint64_t key, int32_t n) {
+    uint32_t s = hv_slot_hash(key) & (HV_VOTE_LOCAL - 1);
+    for (int probe = 0; probe < HV_VOTE_LOCAL; ++probe) {
+        unsigned long long k = L.keys[s];
+        if (k == HV_VOTE_EMPTY) {
+            k = atomicCAS(&L.keys[s], HV_VOTE_EMPTY, (unsigned long long)key);
+            if (k == HV_VOTE_EMPTY) k = key;
+        }
+        if (k == key) {
+            atomicAdd(&L.counts[s], n);
+            return;
+        }
+        s = (s + 1) & (HV_VOTE_LOCAL - 1);
+    }
+    vote_add(vkeys, vcounts, overflow, key, n);
+}
+
+// every lane with key != EMPTY votes once; one LDS atomic per distinct key per wave
+__device__ __forceinline__ void vote_wave_local(HvVoteLocal &L, unsigned long long *__restrict__ vkeys, int32_t *__restrict__ vcounts,
+                                                int32_t *overflow, uint64_t key) {
     const int lane = hv_lane_id();
     unsigned long long remaining = __ballot(key != HV_VOTE_EMPTY);
     while (remaining) {
         const int first = __ffsll((long long)remaining) - 1;
         const unsigned long long fkey = __shfl((unsigned long long)key, first);
         const unsigned long long same = __ballot(key == fkey);
-        if (lane == first) vote_add(vkeys, vcounts, overflow, fkey, (int32_t)__popcll(same));
+        if (lane == first) vote_local_add(L, vkeys, vcounts, overflow, fkey, (int32_t)__popcll(same));
         remaining &= ~same;
     }
+}
+
+__device__ __forceinline__ void vote_local_flush(HvVoteLocal &L, unsigned long long *__restrict__ vkeys, int32_t *__restrict__ vcounts,
+                                                 int32_t *overflow) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HV_VOTE_LOCAL; i += blockDim.x)
+        if (L.keys[i] != HV_VOTE_EMPTY) vote_add(vkeys, vcounts, overflow, L.keys[i], L.counts[i]);
 }
 
 struct HvAssocParams {
@@ -154,13 +197,18 @@ __global__ __launch_bounds__(256) void k_sem_assoc_vote(HvTable table, VOX *__re
                                                          const float *__restrict__ depth, HvAssocParams A,
                                                          unsigned long long *__restrict__ vkeys,
                                                          int32_t *__restrict__ vcounts, int2 *__restrict__ pending) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ HvVoteLocal s_votes;
+    vote_local_init(s_votes);
+    const int64_t total = n_blocks * G.nvox;
+    // persistent workgroups: the trip count is the same for every thread of a workgroup (the ballots below need whole waves)
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t gid = base + threadIdx.x;
     uint64_t key = HV_VOTE_EMPTY;
     bool is_pending = false;
     int32_t inst = -1;
     // (total = n_blocks * nvox and nvox % 64 == 0: a wave never straddles the end of the pool or two blocks)
-    const bool culled = gid < n_blocks * G.nvox && (G.nvox & 63) == 0 && sem_block_outside_frustum(Q, table, gid / G.nvox, G);
-    if (gid < n_blocks * G.nvox && !culled) {
+    const bool culled = gid < total && (G.nvox & 63) == 0 && sem_block_outside_frustum(Q, table, gid / G.nvox, G);
+    if (gid < total && !culled) {
         VOX *v = pool + gid;
         float uvd[3];
         if (sem_visit(Q, table, v, gid / G.nvox, (int)(gid % G.nvox), G, uvd)) {
@@ -195,9 +243,11 @@ __global__ __launch_bounds__(256) void k_sem_assoc_vote(HvTable table, VOX *__re
             }
         }
     }
-    vote_wave(vkeys, vcounts, &table.counters[HV_CNT_OUT2], key);
+    vote_wave_local(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2], key);
     const int32_t at = hv_wave_append(&table.counters[HV_CNT_AUX], is_pending);
     if (is_pending && at < A.pending_cap) pending[at] = make_int2((int32_t)gid, inst);
+    }
+    vote_local_flush(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2]);
 }
 
 // the image scan of voxel_semantic_data_association.h:316-331: every instance id with a valid class
@@ -205,13 +255,18 @@ __global__ __launch_bounds__(256) void k_sem_assoc_image(HvTable table, const in
                                                           const int32_t *__restrict__ inst_img, int64_t n_px,
                                                           unsigned long long *__restrict__ vkeys,
                                                           int32_t *__restrict__ vcounts) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t key = HV_VOTE_EMPTY;
-    if (i < n_px) {
-        const int32_t inst = inst_img[i];
-        if (inst >= 0 && cls_img[i] >= 0) key = vote_key(inst, HV_OBJ_SEEN);
+    __shared__ HvVoteLocal s_votes;
+    vote_local_init(s_votes);
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n_px; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        uint64_t key = HV_VOTE_EMPTY;
+        if (i < n_px) {
+            const int32_t inst = inst_img[i];
+            if (inst >= 0 && cls_img[i] >= 0) key = vote_key(inst, HV_OBJ_SEEN);
+        }
+        vote_wave_local(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2], key);
     }
-    vote_wave(vkeys, vcounts, &table.counters[HV_CNT_OUT2], key);
+    vote_local_flush(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2]);
 }
 
 __global__ __launch_bounds__(256) void k_sem_assoc_compact(HvTable table, const unsigned long long *__restrict__ vkeys,
@@ -699,7 +754,7 @@ int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, in
         GP.nvox = G.nvox;
         GP.local_bits = G.local_bits;
         fill_key_range(Q, GP);
-        const dim3 grid((unsigned)((total + 255) / 256));
+        const dim3 grid((unsigned)std::min<int64_t>((total + 255) / 256, 4096)); // persistent: 16 workgroups per CU
         if (prob)
             hipLaunchKernelGGL(k_sem_assoc_vote<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, nb, G,
                                Q, d_cls, d_inst, d_depth, A, vkeys, vcounts, pending);
@@ -707,7 +762,7 @@ int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, in
             hipLaunchKernelGGL(k_sem_assoc_vote<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, nb, G, Q,
                                d_cls, d_inst, d_depth, A, vkeys, vcounts, pending);
     }
-    hipLaunchKernelGGL(k_sem_assoc_image, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, v->stream, v->table, d_cls, d_inst,
+    hipLaunchKernelGGL(k_sem_assoc_image, dim3((unsigned)std::min<int64_t>((n_px + 255) / 256, 512)), dim3(256), 0, v->stream, v->table, d_cls, d_inst,
                        n_px, vkeys, vcounts);
     hipLaunchKernelGGL(k_sem_assoc_compact, dim3(HV_VOTE_CAP / 256), dim3(256), 0, v->stream, v->table, vkeys, vcounts, ckeys,
                        ccounts);
