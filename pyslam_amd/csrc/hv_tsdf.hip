@@ -1649,7 +1649,15 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep_fold
 // 12-byte frame records only ({depth, colour | 1 << 24, multiplier}: one gather per voxel visit).  Registers: 3 x 16
 // accumulators (sum t, r | b << 16, g << 8 | n << 24) + two gather groups.
 // ================================================================================================
-template <int SPLIT, int GV, int PIPE, bool ANYSKIP>
+// ANYSKIP: 0 = every fold step runs, rejected lanes add zeros (selects); 1 = that + a wave-uniform skip of a step no lane
+// accepts; 2 = the accumulation runs under the EXEC mask of the accepting lanes (no selects: 14 instead of 16 vector
+// instructions in a fold step; the compiler's execz branch is the skip).  Measured on the bench stream: 557-558 us (2)
+// against 565-576 us (1).  Measured and dropped with it: the pixel offset as one v_mad_u32_u24 instead of the compiler's
+// v_mad_u64_u32 (561-567 us), the sum of sdf kept in metres with one multiplication by 1 / trunc per batch (one
+// instruction less per visit, 564-568 us: the extra live register costs more), 16-byte records with the colour fields
+// spread 16 bits apart so that the accumulators add the words unmasked (two instructions less, 590-599 us: four registers
+// per gather in flight, 104 B of scratch).  At 128 registers the form is bound by what it keeps live, not by its count.
+template <int SPLIT, int GV, int PIPE, int ANYSKIP>
 __device__ __forceinline__ void hv_sweep_column_body(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
     char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
@@ -1820,8 +1828,17 @@ __device__ __forceinline__ void hv_sweep_column_body(
                 const int z = gi * GV + k;
                 const float sdf = (__uint_as_float(g.rec[k].x) - g.zk[k]) * __uint_as_float(g.rec[k].z);
                 const bool ok = (int)g.inimg[k] & (int)(sdf > ntrunc);
+                if (ANYSKIP == 2) {
+                    if (ok) {
+                        asm volatile("" ::: "memory"); // keeps the branch: if-converted, the body is the select form again
+                        S[z] += fminf(sdf * tinv, 1.0f); // == `if (t > 1) t = 1` for the non-NaN t of an accepted voxel
+                        arb[z] += g.rec[k].y & 0x00ff00ffu;
+                        agn[z] += g.rec[k].y & 0xff00ff00u;
+                    }
+                    continue;
+                }
                 if (ANYSKIP && !__any(ok)) continue; // no lane of the wave updates its voxel at this z
-                const float tk = fminf(sdf * tinv, 1.0f); // == `if (t > 1) t = 1` for the non-NaN t of an accepted voxel
+                const float tk = fminf(sdf * tinv, 1.0f);
                 S[z] += ok ? tk : 0.0f;
                 const uint32_t c = ok ? g.rec[k].y : 0u;
                 arb[z] += c & 0x00ff00ffu;
@@ -1944,7 +1961,7 @@ __device__ __forceinline__ void hv_sweep_column_body(
 // sweep waves then leave 32 / 64 registers of every SIMD free, enough for waves of the NEXT batch's touch + pack launch
 // (56 VGPRs) to be resident beside them - without that, the second queue only gets a wave slot when a sweep wave retires
 // (profiles/r02/pipeline_timeline.txt), which is what an 8-rank share cannot afford.
-template <int SPLIT, int WPE, int GV, int PIPE, bool ANYSKIP>
+template <int SPLIT, int WPE, int GV, int PIPE, int ANYSKIP>
 __global__ __launch_bounds__(64 * 4 / SPLIT, WPE) void k_tsdf_sweep_column(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
     char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
@@ -1952,7 +1969,7 @@ __global__ __launch_bounds__(64 * 4 / SPLIT, WPE) void k_tsdf_sweep_column(
     hv_sweep_column_body<SPLIT, GV, PIPE, ANYSKIP>(table, list, frame_mask, pool, frame_px, Ps, n_frames, general, mult, xcd_aware, parity);
 }
 #define HV_SWEEP_COLUMN_CAPPED(NAME, HALF_VGPRS)                                                                        \
-    template <int SPLIT, int GV, int PIPE, bool ANYSKIP>                                                                \
+    template <int SPLIT, int GV, int PIPE, int ANYSKIP>                                                                 \
     __global__ __launch_bounds__(64 * 4 / SPLIT) __attribute__((amdgpu_num_vgpr(HALF_VGPRS))) void NAME(               \
         HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,             \
         char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames, \
@@ -2507,7 +2524,7 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
             // (next group's gathers before this group's fold), _ANYSKIP, HV_TSDF_BATCH_SPLIT (workgroups per unit: 1 / 2 / 4)
             const int wpe = getenv("HV_TSDF_SWEEP_WPE") ? atoi(getenv("HV_TSDF_SWEEP_WPE")) : 4;
             const int xcd_aware = getenv("HV_TSDF_SWEEP_XCD") ? atoi(getenv("HV_TSDF_SWEEP_XCD")) : 2;
-            const int anyskip = getenv("HV_TSDF_SWEEP_ANYSKIP") ? atoi(getenv("HV_TSDF_SWEEP_ANYSKIP")) : 1;
+            const int anyskip = getenv("HV_TSDF_SWEEP_ANYSKIP") ? atoi(getenv("HV_TSDF_SWEEP_ANYSKIP")) : 2; // 2: exec-masked fold
             const int gv = getenv("HV_TSDF_SWEEP_GV") ? atoi(getenv("HV_TSDF_SWEEP_GV")) : 4;
             const int pipe = getenv("HV_TSDF_SWEEP_PIPE") ? atoi(getenv("HV_TSDF_SWEEP_PIPE")) : 1;
             const int csplit = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : 4;
@@ -2524,6 +2541,8 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
                 if (pipe == 2) HV_LAUNCH_COLUMN(2, 4, 4, 2, true); else HV_LAUNCH_COLUMN(2, 4, 4, 1, true);
             } else if (!anyskip) {
                 HV_LAUNCH_COLUMN(4, 4, 4, 1, false);
+            } else if (anyskip == 2 && gv == 4 && pipe == 1 && wpe == 4) {
+                HV_LAUNCH_COLUMN(4, 4, 4, 1, 2);
             } else if (gv == 8) {
                 if (wpe >= 4) HV_LAUNCH_COLUMN(4, 4, 8, 2, true); else if (wpe == 3) HV_LAUNCH_COLUMN(4, 3, 8, 2, true); else HV_LAUNCH_COLUMN(4, 2, 8, 2, true);
             } else if (gv == 2) {

@@ -39,7 +39,7 @@ cp gpurun_out/pmc_voxel_grid.json profiles/$ROUND/pmc_voxel_grid.json
 timeout 200 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
 timeout 600 python bench.py > gpurun_out/bench_n1.log 2>&1
 grep '^{"metric"' gpurun_out/bench_n1.log > gpurun_out/bench_n1.json; cut -c1-1500 gpurun_out/bench_n1.json
-timeout 250 python tools/sweep_variants.py --steps 18 --warmup 3 --repeat 3 "HV_TSDF_SWEEP=4" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_GV=2" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_GV=2 HV_TSDF_SWEEP_VCAP=112" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_PIPE=0" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_PIPE=2" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_ANYSKIP=0" "HV_TSDF_SWEEP=3" "HV_TSDF_SWEEP=3 HV_TSDF_SWEEP_ANYSKIP=1" "HV_TSDF_SWEEP=3 HV_TSDF_SWEEP_REC12=0" "HV_TSDF_SWEEP=3 HV_TSDF_SWEEP_DBG=2" "HV_TSDF_SWEEP=2" "HV_TSDF_SWEEP=1" 2>/dev/null | tail -12 > gpurun_out/sweep_forms.jsonl; cut -c1-200 gpurun_out/sweep_forms.jsonl
+timeout 250 python tools/sweep_variants.py --steps 18 --warmup 3 --repeat 3 "HV_TSDF_SWEEP=4" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_GV=2" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_GV=2 HV_TSDF_SWEEP_VCAP=112" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_PIPE=0" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_PIPE=2" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_ANYSKIP=1" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_ANYSKIP=0" "HV_TSDF_SWEEP=3" "HV_TSDF_SWEEP=3 HV_TSDF_SWEEP_ANYSKIP=1" "HV_TSDF_SWEEP=3 HV_TSDF_SWEEP_REC12=0" "HV_TSDF_SWEEP=3 HV_TSDF_SWEEP_DBG=2" "HV_TSDF_SWEEP=2" "HV_TSDF_SWEEP=1" 2>/dev/null | tail -13 > gpurun_out/sweep_forms.jsonl; cut -c1-200 gpurun_out/sweep_forms.jsonl
 timeout 250 python tools/simulate_ranks.py --worlds 1,2,4,8 --steps 12 > gpurun_out/simulate_ranks.jsonl 2>/dev/null; cut -c1-200 gpurun_out/simulate_ranks.jsonl
 # the N > 1 code path of bench.py on this one GPU (two ranks share device 0, gloo transport: the kernels, the sharding and the
 # merge logic are what an N-GPU RCCL run executes; NOT a scaling number)
