@@ -103,8 +103,8 @@ enum {
     HV_CNT_TOUCH1 = 4,   // ... parity 1
     HV_CNT_OUT = 5,      // output row counter (compaction kernels)
     HV_CNT_OUT2 = 6,     // second output counter (triangles)
-    HV_CNT_LABEL_OVERFLOW = 7, // probabilistic payload: label observations dropped (voxel already holds HV_PROB_K labels)
-    HV_CNT_AUX = 8,      // scratch counter (association pending list)
+    HV_CNT_AUX = 7,      // scratch counter (association pending list); OUT, OUT2, AUX are cleared by one 12-byte memset
+    HV_CNT_LABEL_OVERFLOW = 8, // probabilistic payload: label observations dropped (voxel already holds HV_PROB_K labels)
     HV_CNT_COUNT = 16
 };
 
@@ -298,6 +298,7 @@ struct hv_volume {
     float sem_depth_threshold = 10.0f;       // VoxelSemanticDataT::kDepthThreshold (hv_set_depth_threshold)
     float sem_depth_decay_rate = 0.07f;      // VoxelSemanticDataProbabilisticT::kDepthDecayRate (hv_set_depth_decay_rate)
     void *assoc_buf = nullptr;               // association vote table + pending list (hv_semantic_ops.hip)
+    void *assoc_clean = nullptr;             // == assoc_buf while its vote table is known to be empty (the compaction kernel clears what it reads)
     size_t assoc_buf_bytes = 0;
     void *segments_cache = nullptr;          // host-side result of hv_object_segments_compute (HvSegmentsCache*)
 

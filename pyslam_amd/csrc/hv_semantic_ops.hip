@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256) void k_sem_assoc_image(HvTable table, const in
     vote_local_flush(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2]);
 }
 
-__global__ __launch_bounds__(256) void k_sem_assoc_compact(HvTable table, const unsigned long long *__restrict__ vkeys,
-                                                            const int32_t *__restrict__ vcounts,
+__global__ __launch_bounds__(256) void k_sem_assoc_compact(HvTable table, unsigned long long *__restrict__ vkeys,
+                                                            int32_t *__restrict__ vcounts,
                                                             unsigned long long *__restrict__ out_keys,
                                                             int32_t *__restrict__ out_counts) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -279,6 +279,8 @@ __global__ __launch_bounds__(256) void k_sem_assoc_compact(HvTable table, const 
     if (pred) {
         out_keys[at] = vkeys[s];
         out_counts[at] = vcounts[s];
+        vkeys[s] = HV_VOTE_EMPTY; // the table is empty again for the next keyframe (no 768 KB of memsets per call)
+        vcounts[s] = 0;
     }
 }
 
@@ -731,10 +733,13 @@ int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, in
         }
     }
 
-    HV_HIP(hipMemsetAsync(vkeys, 0xFF, sizeof(uint64_t) * HV_VOTE_CAP, v->stream));
-    HV_HIP(hipMemsetAsync(vcounts, 0, sizeof(int32_t) * HV_VOTE_CAP, v->stream));
-    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t) * 2, v->stream)); // OUT, OUT2
-    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_AUX], 0, sizeof(int32_t), v->stream));
+    if (v->assoc_clean != v->assoc_buf) { // first use of this buffer, or a call that failed before its compaction
+        HV_HIP(hipMemsetAsync(vkeys, 0xFF, sizeof(uint64_t) * HV_VOTE_CAP, v->stream));
+        HV_HIP(hipMemsetAsync(vcounts, 0, sizeof(int32_t) * HV_VOTE_CAP, v->stream));
+    }
+    v->assoc_clean = nullptr;
+    static_assert(HV_CNT_OUT2 == HV_CNT_OUT + 1 && HV_CNT_AUX == HV_CNT_OUT + 2, "one memset clears OUT, OUT2, AUX");
+    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t) * 3, v->stream));
 
     HvAssocParams A;
     A.use_depth = depth_image != nullptr ? 1 : 0;
@@ -769,6 +774,7 @@ int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, in
     HV_HIP(hipGetLastError());
     rc = hv_read_counters(v);
     if (rc != HV_OK) return rc;
+    v->assoc_clean = v->assoc_buf; // the compaction ran: every slot it found is empty again
     HV_REQUIRE(v->h_counters[HV_CNT_OUT2] == 0, HV_ERR_CAPACITY,
                "hv_assign_object_ids_to_instance_ids: more than %u distinct (instance, object) pairs", HV_VOTE_CAP);
     const int32_t n_pairs = v->h_counters[HV_CNT_OUT];
