@@ -298,7 +298,8 @@ struct hv_volume {
     float sem_depth_threshold = 10.0f;       // VoxelSemanticDataT::kDepthThreshold (hv_set_depth_threshold)
     float sem_depth_decay_rate = 0.07f;      // VoxelSemanticDataProbabilisticT::kDepthDecayRate (hv_set_depth_decay_rate)
     void *assoc_buf = nullptr;               // association vote table + pending list (hv_semantic_ops.hip)
-    void *assoc_clean = nullptr;             // == assoc_buf while its vote table is known to be empty (the compaction kernel clears what it reads)
+    void *assoc_clean = nullptr;             // == assoc_buf (and assoc_clean_bytes == assoc_buf_bytes: a grown buffer may come back at the
+    size_t assoc_clean_bytes = 0;            // same address) while its vote table is known to be empty - the compaction kernel clears what it reads
     size_t assoc_buf_bytes = 0;
     void *segments_cache = nullptr;          // host-side result of hv_object_segments_compute (HvSegmentsCache*)
 

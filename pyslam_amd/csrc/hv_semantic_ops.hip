@@ -733,7 +733,7 @@ int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, in
         }
     }
 
-    if (v->assoc_clean != v->assoc_buf) { // first use of this buffer, or a call that failed before its compaction
+    if (v->assoc_clean != v->assoc_buf || v->assoc_clean_bytes != v->assoc_buf_bytes) { // a new allocation, or a call that failed before its compaction
         HV_HIP(hipMemsetAsync(vkeys, 0xFF, sizeof(uint64_t) * HV_VOTE_CAP, v->stream));
         HV_HIP(hipMemsetAsync(vcounts, 0, sizeof(int32_t) * HV_VOTE_CAP, v->stream));
     }
@@ -775,6 +775,7 @@ int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, in
     rc = hv_read_counters(v);
     if (rc != HV_OK) return rc;
     v->assoc_clean = v->assoc_buf; // the compaction ran: every slot it found is empty again
+    v->assoc_clean_bytes = v->assoc_buf_bytes;
     HV_REQUIRE(v->h_counters[HV_CNT_OUT2] == 0, HV_ERR_CAPACITY,
                "hv_assign_object_ids_to_instance_ids: more than %u distinct (instance, object) pairs", HV_VOTE_CAP);
     const int32_t n_pairs = v->h_counters[HV_CNT_OUT];

@@ -1651,8 +1651,8 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep_fold
 // ================================================================================================
 // ANYSKIP: 0 = every fold step runs, rejected lanes add zeros (selects); 1 = that + a wave-uniform skip of a step no lane
 // accepts; 2 = the accumulation runs under the EXEC mask of the accepting lanes (no selects: 14 instead of 16 vector
-// instructions in a fold step; the compiler's execz branch is the skip).  Measured on the bench stream: 557-558 us (2)
-// against 565-576 us (1).  Measured and dropped with it: the pixel offset as one v_mad_u32_u24 instead of the compiler's
+// instructions in a fold step; the compiler's execz branch is the skip).  Measured on the bench stream in three A/B runs:
+// 557-563 us (2) against 562-576 us (1) - 2 % in two of them, nothing in the third.  Measured and dropped with it: the pixel offset as one v_mad_u32_u24 instead of the compiler's
 // v_mad_u64_u32 (561-567 us), the sum of sdf kept in metres with one multiplication by 1 / trunc per batch (one
 // instruction less per visit, 564-568 us: the extra live register costs more), 16-byte records with the colour fields
 // spread 16 bits apart so that the accumulators add the words unmasked (two instructions less, 590-599 us: four registers
