@@ -89,6 +89,8 @@ def _load_port():
     L.to_point_normals.restype = None
     L.to_point_normals.argtypes = [_vp, _vp, _i64, _vp]
     L.to_invert4x4.argtypes = [_vp, _vp]
+    L.to_load_unit.restype = None
+    L.to_load_unit.argtypes = [_vp, _vp, _vp, _vp, _vp]
     return L
 
 
@@ -410,6 +412,16 @@ class PortTsdf:
         color = np.zeros((nu, nv, 3), np.float64)
         self._lib.to_dump(self._h, _ptr(keys), _ptr(tsdf), _ptr(weight), _ptr(color))
         return keys, tsdf, weight, color
+
+    def load_units(self, keys, tsdf, weight, color):
+        """Test hook: units `keys` [U,3] get the voxel states tsdf / weight [U,R,R,R] (x, y, z) and color [U,R,R,R,3] (0..255)."""
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        for k in range(len(keys)):
+            t = np.ascontiguousarray(tsdf[k], dtype=np.float32).reshape(-1)
+            w = np.ascontiguousarray(weight[k], dtype=np.float32).reshape(-1)
+            c = np.ascontiguousarray(color[k], dtype=np.float64).reshape(-1)
+            assert t.size == self.res ** 3 and w.size == t.size and c.size == 3 * t.size
+            self._lib.to_load_unit(self._h, _ptr(keys[k]), _ptr(t), _ptr(w), _ptr(c))
 
     def extract_triangle_mesh(self):
         nt = _c.c_int64(0)

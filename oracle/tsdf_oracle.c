@@ -406,6 +406,22 @@ int64_t to_dump(const to_volume *v, int32_t *keys, float *tsdf, float *weight, d
     return nu;
 }
 
+/* Test hook (no Open3D counterpart): create unit `key` (or overwrite it) with the given voxel states, IndexOf order
+ * x*res^2 + y*res + z; color = the running mean on the 0..255 scale.  Lets the extraction tests hand both sides voxel states
+ * that no depth image produces (exact zeros, values on the +-0.98 bounds, unobserved voxels inside a surface). */
+void to_load_unit(to_volume *v, const int32_t *key, const float *tsdf, const float *weight, const double *color) {
+    const int64_t u = to_open_unit(v, key[0], key[1], key[2]);
+    const int64_t nv = (int64_t)v->res * v->res * v->res;
+    for (int64_t i = 0; i < nv; ++i) {
+        to_voxel *vx = &v->units[u].voxels[i];
+        vx->tsdf = tsdf[i];
+        vx->weight = weight[i];
+        vx->color[0] = color[i * 3];
+        vx->color[1] = color[i * 3 + 1];
+        vx->color[2] = color[i * 3 + 2];
+    }
+}
+
 /* voxel lookup across unit borders; returns 0 and w=f=0 if the neighbour unit does not exist */
 static int to_fetch(const to_volume *v, const to_unit *unit0, int x, int y, int z, float *w, float *f, double *c) {
     const int R = v->res;

@@ -352,3 +352,77 @@ def test_point_cloud_normals_match_oracle(tmp_path):
     np.testing.assert_array_equal(pts, pc.points)
     np.testing.assert_array_equal(read_ply_normals(path), pc.normals)
     assert faces is None and cols.shape == (len(pts), 3)
+
+
+def _synthetic_unit_states(seed, keys, voxel=0.01, trunc=0.04, R=16):
+    """Voxel states [U, R, R, R] (x, y, z) that no depth image produces: a sphere and a tilted plane crossing unit borders along
+    every axis, with 8 % of the voxels overwritten by values on the decision boundaries of the two extractions (+-0, +-0.98 and
+    their float neighbours, +-1) and 10 % never observed (weight 0, tsdf 0 as in Open3D)."""
+    rng = np.random.default_rng(seed)
+    idx = np.stack(np.meshgrid(np.arange(R), np.arange(R), np.arange(R), indexing="ij"), -1).astype(np.float64)
+    U = len(keys)
+    tsdf = np.zeros((U, R, R, R), np.float32)
+    centre, radius = np.array([-0.07, -0.10, -0.06]), 0.13
+    n = np.array([0.3, -0.5, 0.81]) / np.linalg.norm([0.3, -0.5, 0.81])
+    for k, key in enumerate(keys):
+        p = (np.asarray(key, np.float64)[None, None, None, :] * R + idx + 0.5) * voxel
+        d = np.minimum(np.linalg.norm(p - centre, axis=-1) - radius, p @ n + 0.02)
+        tsdf[k] = np.clip(d / trunc, -1.0, 1.0).astype(np.float32)
+    b = np.float32(0.98)
+    special = np.array([-1.0, -b, np.nextafter(-b, np.float32(0)), np.nextafter(-b, np.float32(-2)), -0.5, -1e-3, -0.0, 0.0, 1e-3, 0.5,
+                        np.nextafter(b, np.float32(0)), b, np.nextafter(b, np.float32(2)), 1.0], np.float32)
+    m = rng.random(tsdf.shape) < 0.08
+    tsdf[m] = rng.choice(special, int(m.sum()))
+    weight = np.ones(tsdf.shape, np.float32)
+    unobserved = rng.random(tsdf.shape) < 0.10
+    weight[unobserved] = 0.0
+    tsdf[unobserved] = 0.0
+    colour = rng.integers(0, 256, tsdf.shape + (3,)).astype(np.float64)
+    return tsdf, weight, colour
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_extraction_of_loaded_voxel_states_matches_oracle(seed):
+    """Both extractions on voxel states handed to both sides directly (hv_tsdf_import_numerators / the oracle's load hook): a
+    3 x 3 x 3 cluster of units with holes, negative unit indices and one isolated unit, values ON the decision boundaries
+    (tsdf = +-0: no sign change; +-0.98: the point cloud's half-open range; unobserved voxels inside the surface; missing
+    neighbour units on every side).  Mesh vertices / triangles / colours, points / colours and normals against the oracle."""
+    import itertools
+
+    rng = np.random.default_rng(100 + seed)
+    R = 16
+    cluster = [k for k in itertools.product(range(-2, 1), repeat=3) if rng.random() > 0.2]
+    keys = np.array(cluster + [(4, 5, -3)], np.int32)
+    tsdf, weight, colour = _synthetic_unit_states(seed, keys)
+    gpu, cpu = make_pair(0.01, 0.04, max_blocks=256)
+    cpu.load_units(keys, tsdf, weight, colour)
+    word = lambda a: a.transpose(0, 3, 1, 2).reshape(len(keys), R ** 3)  # product voxel order: z * 256 + x * 16 + y
+    payload = np.zeros((len(keys), R ** 3, 5), np.float32)
+    payload[..., 0] = word(tsdf * weight)
+    payload[..., 1] = word(weight)
+    for c in range(3):
+        payload[..., 2 + c] = word(colour[..., c].astype(np.float32) * weight)
+    gpu.import_numerators(keys, payload)
+    assert gpu.num_blocks() == len(keys)
+    ka, ta, wa, _ = gpu.dump()
+    kb, tb, wb, _ = cpu.dump()
+    np.testing.assert_array_equal(ka, kb)
+    np.testing.assert_array_equal(ta.view(np.uint32), tb.view(np.uint32))  # incl. the sign of -0
+    np.testing.assert_array_equal(wa, wb)
+    m = gpu.extract_triangle_mesh()
+    vb, tb_, cb = cpu.extract_triangle_mesh()
+    assert m.vertices.shape == vb.shape and m.triangles.shape == tb_.shape and len(tb_) > 2000
+    va, ca, tra = canonical_mesh(m.vertices, m.triangles, m.vertex_colors)
+    vb, cb, trb = canonical_mesh(vb, tb_, cb)
+    np.testing.assert_allclose(va, vb, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(tra, trb, rtol=0, atol=1e-9)
+    # (coincident vertices - an exact 0 on a voxel corner - carry that corner's colour on every edge: ties are harmless)
+    np.testing.assert_allclose(ca, cb, rtol=0, atol=TOL)
+    pc = gpu.extract_point_cloud(normals=True)
+    pb, qb = cpu.extract_point_cloud()
+    nb = cpu.point_normals(pb)
+    assert pc.points.shape == pb.shape and len(pb) > 500
+    ia, ib = np.lexsort(np.round(pc.points, 9).T[::-1]), np.lexsort(np.round(pb, 9).T[::-1])
+    np.testing.assert_allclose(pc.points[ia], pb[ib], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(pc.colors[ia], qb[ib], rtol=0, atol=TOL)
+    np.testing.assert_allclose(pc.normals[ia], nb[ib], rtol=0, atol=1e-9)

@@ -402,3 +402,70 @@ def test_point_cloud_normals_on_a_plane_and_a_sphere():
     radial = (p - centre) / np.linalg.norm(p - centre, axis=1, keepdims=True)
     cos = np.einsum("ij,ij->i", n, radial)
     assert len(p) > 3000 and cos.min() > 0.8 and cos.mean() > 0.98  # (measured: mean 0.986, min 0.85 where unobserved voxels - tsdf 0 - enter the stencil)
+
+
+def test_extraction_decisions_on_loaded_voxel_states():
+    """Hand-placed voxel states through the oracle's load hook (`to_load_unit`), answers from Open3D's rules as SURVEY 8a T5 / T6
+    states them: ExtractPointCloud takes a voxel pair (v, v + e_axis) iff both are observed, both tsdf lie in [-0.98, 0.98) and
+    f0 * f1 < 0, at p0 + |f0| / (|f0| + |f1|) * voxel along the axis; marching cubes puts a vertex on a crossed edge of a cube
+    whose eight corners are all observed (negative means f < 0: an exact 0 is outside)."""
+    R, vl = 16, 0.01
+    vol = oracle.PortTsdf(vl, 0.04)
+    t = np.ones((1, R, R, R), np.float32)
+    w = np.ones((1, R, R, R), np.float32)
+    c = np.zeros((1, R, R, R, 3))
+    pairs = {  # x -> (f at (x, 4, 4), f at (x, 4, 5)): only the z edge of the pair can cross
+        0: (-0.98, 0.5),                                   # lower bound is inside the range: point
+        1: (0.5, -0.98),                                   # ... in either order
+        2: (0.98, -0.5),                                   # upper bound is outside: no point
+        3: (float(np.nextafter(f32(0.98), f32(0))), -0.5),  # just below it: point
+        4: (float(np.nextafter(f32(-0.98), f32(-2))), 0.5),  # just below the lower bound: no point
+        5: (0.0, -0.5),                                    # product is -0: no point
+        6: (-0.0, 0.5),                                    # ... for either zero
+        7: (-0.25, 0.75),                                  # a plain crossing: a quarter of the way along the edge
+    }
+    for x, (f0, f1) in pairs.items():
+        t[0, x, 4, 4], t[0, x, 4, 5] = f0, f1
+    # everything else holds tsdf = +1 (outside the point cloud's range): the only candidate crossings are between pair voxels,
+    # along z inside a pair and along x between neighbouring pairs - the evaluator below enumerates all of them
+    vol.load_units(np.array([[0, 0, 0]], np.int32), t, w, c)
+    pts, _ = vol.extract_point_cloud()
+    got = {tuple(np.round(p / vl - 0.5, 6)) for p in pts}
+    want = set()
+    f = t[0].astype(np.float64)
+    inr = lambda v: -0.98 <= np.float32(v) < np.float32(0.98)
+    for x in range(R):
+        for y in range(R):
+            for z in range(R):
+                for axis, (dx, dy, dz) in enumerate(((1, 0, 0), (0, 1, 0), (0, 0, 1))):
+                    x1, y1, z1 = x + dx, y + dy, z + dz
+                    if x1 >= R or y1 >= R or z1 >= R:
+                        continue  # the neighbouring unit does not exist
+                    f0, f1 = np.float32(f[x, y, z]), np.float32(f[x1, y1, z1])
+                    if inr(f0) and inr(f1) and np.float32(f0 * f1) < 0:
+                        p = [float(x), float(y), float(z)]
+                        r0, r1 = abs(float(f0)), abs(float(f1))
+                        p[axis] = (p[axis] * r1 + (p[axis] + 1.0) * r0) / (r0 + r1)
+                        want.add(tuple(np.round(p, 6)))
+    assert got == want
+    zedge = {x: any(abs(p[0] - x) < 1e-9 and abs(p[1] - 4) < 1e-9 and 4 < p[2] < 5 for p in got) for x in pairs}
+    assert zedge == {0: True, 1: True, 2: False, 3: True, 4: False, 5: False, 6: False, 7: True}
+    assert (7.0, 4.0, 4.25) in got
+    # marching cubes: an unobserved corner removes every cube around it; a 0 corner is "outside"
+    t2 = np.ones((1, R, R, R), np.float32)
+    t2[0, :, :, :8] = -1.0  # surface between z = 7 and z = 8, everywhere
+    w2 = np.ones((1, R, R, R), np.float32)
+    w2[0, 5, 5, 7] = 0.0  # one unobserved voxel on the surface: the 8 cubes touching it are invalid
+    t2[0, 5, 5, 7] = 0.0
+    t2[0, 10, 10, 7] = 0.0  # an exact zero below the surface: its vertical edge crosses between z = 6 and the voxel itself
+    vol = oracle.PortTsdf(vl, 0.04)
+    vol.load_units(np.array([[0, 0, 0]], np.int32), t2, w2, np.zeros((1, R, R, R, 3)))
+    v, tri, _ = vol.extract_triangle_mesh()
+    g = np.round(v / vl - 0.5, 6)
+    # full cube layer: 15 x 15 cubes, two triangles each, minus the four cubes of that layer around the unobserved voxel
+    flat = 2 * (15 * 15 - 4)
+    assert len(tri) >= flat
+    on_edge_above = lambda x, y: any(abs(p[0] - x) < 1e-9 and abs(p[1] - y) < 1e-9 and 7 <= p[2] <= 8 for p in g)
+    assert not on_edge_above(5, 5)  # no vertex on the edge that starts at the unobserved voxel
+    assert on_edge_above(3, 3)
+    assert any(np.allclose(p, (10, 10, 7.0)) for p in g)  # the zero voxel: crossing (z 6 -> 7) lands exactly on it
