@@ -284,6 +284,15 @@ class PortSemGrid2(_Sem2Base):
     def __init__(self, kind, voxel_size, block_size=8):
         super().__init__(port_lib(), "so2_", kind, voxel_size, block_size)
 
+    def label_histogram(self, cap=33):
+        """-> (largest label map of an occupied voxel, hist[k] = occupied voxels holding k (object, class) pairs)."""
+        fn = self._lib.so2_label_histogram
+        fn.restype = _i32
+        fn.argtypes = [_vp, _vp, _i32]
+        hist = np.zeros(cap, np.int64)
+        most = fn(self._h, _ptr(hist), cap)
+        return int(most), hist
+
 
 def port_remap_instance_ids(inst_img, mapping):
     lib = port_lib()

@@ -270,6 +270,21 @@ void so2_destroy(s2_grid *g) {
     free(g);
 }
 int64_t so2_num_blocks(const s2_grid *g) { return g->num_blocks; }
+/* Test hook: hist[k] = occupied voxels whose label map holds k pairs (k >= cap - 1 collected in the last bin); returns the
+ * largest map size.  What the product's 7 inline label slots (hv_semantic.h) are measured against. */
+int32_t so2_label_histogram(const s2_grid *g, int64_t *hist, int32_t cap) {
+    int32_t most = 0;
+    for (int32_t k = 0; k < cap; ++k) hist[k] = 0;
+    for (int64_t b = 0; b < g->num_blocks; ++b)
+        for (int i = 0; i < g->voxels_per_block; ++i) {
+            const s2_voxel *v = &g->blocks[b].data[i];
+            if (v->count <= 0) continue;
+            const int32_t n = v->n_labels;
+            if (n > most) most = n;
+            hist[n < cap - 1 ? n : cap - 1] += 1;
+        }
+    return most;
+}
 void so2_set_depth_threshold(s2_grid *g, float t) {
     if (g->kind == 0) s2_vote_depth_threshold = t;
     else s2_prob_depth_threshold = t;

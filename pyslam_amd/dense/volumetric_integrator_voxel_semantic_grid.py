@@ -208,7 +208,7 @@ class VolumetricIntegratorVoxelSemanticGrid(VolumetricIntegratorBase):
         cls_d = up(semantic_classes, np.int32) if semantic_classes is not None and np.asarray(semantic_classes).size > 0 else None
         self.camera_frustrum.set_T_cw(pose)
         object_ids_d = None
-        if self.integrate_2d_instance_ids and cls_d is not None:
+        if self.integrate_2d_instance_ids:  # same branches as the host flow below (no class image: empty map, every id -> -1)
             inst_d = up(semantic_instances, np.int32)
             id_map = self.volume.assign_object_ids_to_instance_ids(
                 self.camera_frustrum, cls_d, inst_d, depth_d,

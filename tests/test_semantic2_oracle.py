@@ -119,3 +119,33 @@ def test_obb_pca_matches_reference_boxes():
         pts = np.array([[0.5, 1.0, 2.0], [1.5, 1.0, 2.5]])[:n]
         obb = port_compute_obb_pca(pts)
         assert np.allclose(obb[0:3], pts.mean(0))
+
+
+def test_label_map_sizes_the_reference_builds():
+    """How many (object, class) pairs the reference's unbounded per-voxel std::map really holds (the port's map, bit-identical on
+    every flow above), against the product's 7 inline slots (hv_semantic.h: the 8th distinct pair of a voxel is dropped and
+    counted).  On the labelled synthetic stream the largest map has 4 pairs; uniform random label noise - the harshest model:
+    every noisy pixel draws one of 40 x 30 pairs - pushes 1-2 % of the voxels past 7 at a 5 % noise rate.  The cap is exact for
+    consistent labels and a measured, counted divergence of the confidences (never of keys, counts or sums) under noise."""
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from tests.semantic_helpers import CFG, frame_points, semantic_frame
+
+    s = SyntheticRGBD(CFG, noise=True, invalid_frac=0.02)
+    result = {}
+    for p_noise in (0.0, 0.05):
+        g = PortSemGrid2(1, 0.02)
+        rng = np.random.default_rng(3)
+        for k, i in enumerate(range(0, 60, 2)):
+            depth, rgb, T, cls, inst = semantic_frame(s, i, shuffle=k)
+            flip = rng.random(cls.shape) < p_noise
+            cls = np.where(flip, rng.integers(0, 40, cls.shape), cls).astype(np.int32)
+            obj = np.where(flip, rng.integers(0, 30, cls.shape), inst).astype(np.int32)
+            pts, cols, c, o, d = frame_points(depth, rgb, T, cls, obj, s.intrinsics, 4.0)
+            g.integrate(pts, cols, c, o, d)
+        most, hist = g.label_histogram()
+        result[p_noise] = (most, hist)
+    most, hist = result[0.0]
+    assert 1 <= most <= 4 and hist[5:].sum() == 0
+    most, hist = result[0.05]
+    over = hist[8:].sum() / hist.sum()
+    assert most > 7 and 0.005 < over < 0.05  # the cap WOULD bind here: 1-2 % of the occupied voxels
