@@ -105,6 +105,9 @@ class HvCopyPool { // n persistent workers; run(fn) executes fn(i, n) on all of 
     }
     int size() const { return n_; }
     void run(const std::function<void(int, int)> &fn) {
+        // one job at a time: ctypes releases the GIL, so two volumes on two host threads may stage frames concurrently; a second
+        // run() would overwrite job_ / pending_ / gen_ while the first caller waits and both would wake on pending_ == 0
+        std::lock_guard<std::mutex> callers(run_m_);
         std::unique_lock<std::mutex> lk(m_);
         job_ = &fn;
         pending_ = n_;
@@ -134,7 +137,7 @@ class HvCopyPool { // n persistent workers; run(fn) executes fn(i, n) on all of 
     }
     int n_;
     std::vector<std::thread> th_;
-    std::mutex m_;
+    std::mutex m_, run_m_;
     std::condition_variable cv_, done_;
     const std::function<void(int, int)> *job_ = nullptr;
     uint64_t gen_ = 0;
@@ -378,6 +381,7 @@ int hv_claims_fit(hv_volume *v) {
         // grow does not have
         const int rb = hv_rollback_claims(v, before);
         if (rb != HV_OK) {
+            v->overflow_latched = true; // the hash may hold keys without a block: every integrate call fails until hv_reset / hv_reserve_blocks
             const std::string why = hv_last_error();
             hv_set_error("block pool exhausted: %lld blocks needed, max_blocks=%lld, the pool cannot grow AND the claim pass could not be "
                          "rolled back (%s): the frame was NOT fused, but the hash holds keys without a block - hv_reset or "

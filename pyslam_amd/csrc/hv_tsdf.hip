@@ -141,10 +141,11 @@ __device__ __forceinline__ void hv_touch_patch(const HvTable &table, const HvFra
         if (P.tiled && p > 0.0f) {
             // Tile-sharded volume: a sample far outside this GPU's image tile cannot open a unit that projects into the tile
             // (hv_unit_hits_tile would refuse every one of them) - leave before the double-precision back-projection.  The
-            // sample's units lie within rad = unit diagonal + sdf_trunc of its point; for a point q that close, with camera
+            // sample opens units over an L-infinity box of +/- sdf_trunc per axis, so a corner / voxel centre of an opened unit lies
+            // within rad = sqrt(3) (unit_length + sdf_trunc) of its point; for a point q that close, with camera
             // depth >= zn = p - rad > 0, |u_q - u_s| <= (rad / zn) (fx + |u_s - cx|) (same for v).  Border tiles extend
             // outwards without bound, as in hv_unit_hits_tile.
-            const float rad = (float)(P.unit_length * 1.7320508075688772 + P.sdf_trunc_d) * 1.001f;
+            const float rad = (float)((P.unit_length + P.sdf_trunc_d) * 1.7320508075688772) * 1.001f;
             const float zn = p - rad;
             if (zn > 0.05f) {
                 const float k = rad / zn;

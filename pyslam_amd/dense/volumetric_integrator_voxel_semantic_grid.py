@@ -198,8 +198,10 @@ class VolumetricIntegratorVoxelSemanticGrid(VolumetricIntegratorBase):
     def _integrate_keyframe_on_device(self, color, depth, pose, semantic_classes, semantic_instances):
         import torch
 
+        dev = torch.device("cuda", int(self.volume._cfg.device))  # the volume's GPU, not torch's current device
+
         def up(a, dtype):
-            return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+            return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(dev)
 
         depth_d = up(depth, np.float32)
         if Parameters.kVolumetricIntegrationVoxelGridShadowPointsFilter:

@@ -134,6 +134,23 @@ class _Volume:
         if ts is not None:
             torch.cuda.current_stream(device).wait_stream(ts)
 
+    def _carve(self, camera_frustrum, depth_image, depth_threshold):
+        """carve(camera_frustrum, depth f32 HxW, threshold) of every grid type (voxel_grid_carving.h:47-79).  Host array or
+        torch CUDA tensor (used in place, ordered against torch's stream)."""
+        f = camera_frustrum
+        if hasattr(depth_image, "data_ptr"):
+            depth = depth_image.contiguous().float()
+        else:
+            depth = np.ascontiguousarray(depth_image, dtype=np.float32)
+        if depth.ndim != 2 or depth.shape[0] * depth.shape[1] == 0 or depth.shape[0] != f.height or depth.shape[1] != f.width:
+            return  # "Depth image is empty" / check_image_size(): the reference prints a message and returns
+        loc = L.location(depth)
+        ts = self._torch_in(depth) if loc == L.HV_DEVICE else None
+        L.check(self._lib.hv_carve(self._h, L.ptr(f.intr), f.width, f.height, L.ptr(f.T_cw), f.depth_max, f.depth_min, L.ptr(depth),
+                                   float(depth_threshold), loc))
+        if ts is not None:
+            self._torch_out(ts, depth.device)
+
     def dropped_points(self):
         n = ctypes.c_int64()
         L.check(self._lib.hv_dropped_points(self._h, ctypes.byref(n)))
@@ -460,19 +477,7 @@ class VoxelBlockGrid(_Volume):
         )
 
     def carve(self, camera_frustrum, depth_image, depth_threshold=1e-2):
-        f = camera_frustrum
-        if hasattr(depth_image, "data_ptr"):
-            depth = depth_image.contiguous().float()
-        else:
-            depth = np.ascontiguousarray(depth_image, dtype=np.float32)
-        if depth.shape[0] != f.height or depth.shape[1] != f.width:
-            return  # check_image_size(): the reference prints a message and returns
-        L.check(
-            self._lib.hv_carve(
-                self._h, L.ptr(f.intr), f.width, f.height, L.ptr(f.T_cw), f.depth_max, f.depth_min, L.ptr(depth),
-                float(depth_threshold), L.location(depth)
-            )
-        )
+        self._carve(camera_frustrum, depth_image, depth_threshold)
 
     def remove_low_count_voxels(self, min_count):
         L.check(self._lib.hv_remove_low_count_voxels(self._h, int(min_count)))

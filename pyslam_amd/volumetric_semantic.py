@@ -164,21 +164,27 @@ def _is_device(a):
     return a is not None and hasattr(a, "is_cuda") and bool(a.is_cuda)
 
 
-def _device_images(*images):
+def _device_images(*images, device=0):
     """The per-keyframe images of one call, all at ONE location: when any of them is a torch CUDA tensor the numpy ones are
     uploaded (torch's blocking copy), so that a caller can keep a keyframe's depth / label images in HBM across
     filter_shadow_points -> assign_object_ids_to_instance_ids -> remap_instance_ids -> integrate_rgbd instead of staging each
-    of them again in every call.  -> (list of images, HV_DEVICE | HV_HOST)."""
+    of them again in every call.  The images must live on the volume's GPU (`device`: hv_config.device): a tensor of another GPU
+    is an error, not a silent peer access.  -> (list of images, HV_DEVICE | HV_HOST)."""
     if not any(_is_device(a) for a in images):
         return list(images), L.HV_HOST
     import torch
 
+    dev = torch.device("cuda", int(device))
     out = []
     for a in images:
-        if a is None or _is_device(a):
-            out.append(None if a is None else a.contiguous())
+        if a is None:
+            out.append(None)
+        elif _is_device(a):
+            if a.device != dev:
+                raise RuntimeError(f"image tensor lives on {a.device}, the volume on {dev}")
+            out.append(a.contiguous())
         else:
-            out.append(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+            out.append(torch.from_numpy(np.ascontiguousarray(a)).to(dev))
     return out, L.HV_DEVICE
 
 
@@ -299,7 +305,8 @@ class _SemanticGridBase(_Volume):
                 depth if _is_device(depth) else np.ascontiguousarray(depth, dtype=np.float32),
                 rgb if _is_device(rgb) else np.ascontiguousarray(rgb, dtype=np.uint8),
                 class_ids_image if class_ids_image is None or _is_device(class_ids_image) else np.ascontiguousarray(class_ids_image, dtype=np.int32),
-                object_ids_image if object_ids_image is None or _is_device(object_ids_image) else np.ascontiguousarray(object_ids_image, dtype=np.int32))
+                object_ids_image if object_ids_image is None or _is_device(object_ids_image) else np.ascontiguousarray(object_ids_image, dtype=np.int32),
+                device=self._cfg.device)
             if depth.dtype != torch.float32 or rgb.dtype != torch.uint8 or any(a is not None and a.dtype != torch.int32 for a in (cls, obj)):
                 raise RuntimeError("device images must be float32 depth, uint8 colour, int32 labels")
             H, W = int(depth.shape[0]), int(depth.shape[1])
@@ -399,12 +406,7 @@ class _SemanticGridBase(_Volume):
         return vg.class_ids, vg.object_ids
 
     def carve(self, camera_frustrum, depth_image, depth_threshold=1e-2):
-        f = camera_frustrum
-        depth = np.ascontiguousarray(depth_image, dtype=np.float32)
-        if depth.size == 0 or depth.shape[0] != f.height or depth.shape[1] != f.width:
-            return  # "Depth image is empty" / check_image_size(): the reference prints a message and returns
-        L.check(self._lib.hv_carve(self._h, L.ptr(f.intr), f.width, f.height, L.ptr(f.T_cw), f.depth_max, f.depth_min, L.ptr(depth),
-                                   float(depth_threshold), L.HV_HOST))
+        self._carve(camera_frustrum, depth_image, depth_threshold)
 
     def assign_object_ids_to_instance_ids(self, camera_frustrum, class_ids_image, semantic_instances_image, depth_image=None,
                                           depth_threshold=0.1, do_carving=False, min_vote_ratio=0.5, min_votes=3):
@@ -420,7 +422,8 @@ class _SemanticGridBase(_Volume):
             (cls, inst, depth), loc = _device_images(
                 class_ids_image if _is_device(class_ids_image) else _i32_image(np.asarray(class_ids_image), "Class ids"),
                 semantic_instances_image if _is_device(semantic_instances_image) else _i32_image(np.asarray(semantic_instances_image), "Instance ids"),
-                depth_image if depth_image is None or _is_device(depth_image) else np.ascontiguousarray(depth_image, dtype=np.float32))
+                depth_image if depth_image is None or _is_device(depth_image) else np.ascontiguousarray(depth_image, dtype=np.float32),
+                device=self._cfg.device)
             if cls.dim() != 2 or inst.dim() != 2 or cls.dtype != torch.int32 or inst.dtype != torch.int32:
                 raise RuntimeError("Class ids / Instance ids must be single-channel int32")
             if tuple(inst.shape) != (f.height, f.width) or tuple(cls.shape) != (f.height, f.width):

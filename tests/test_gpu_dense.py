@@ -148,10 +148,12 @@ def test_tsdf_integrator_end_to_end(tmp_path):
         integ.quit()
 
 
+@pytest.mark.parametrize("use_instance_ids", [True, False])
 @pytest.mark.parametrize("probabilistic", [False, True])
-def test_semantic_integrator_matches_reference_flow(probabilistic):
+def test_semantic_integrator_matches_reference_flow(probabilistic, use_instance_ids):
     """VolumetricIntegratorVoxelSemanticGrid on the real GPU volume vs the same integrator class driving the
-    compiled reference through the stand-in volume: identical labelled voxels after 3 keyframes."""
+    compiled reference through the stand-in volume: identical labelled voxels after 3 keyframes.  Carving is on: with
+    instance ids it runs inside the association, without them as volume.carve() on the device-resident depth."""
     if not oracle.ref_available():
         pytest.skip("compiled reference not available")
     from pyslam_amd.dense.parameters import Parameters
@@ -164,9 +166,11 @@ def test_semantic_integrator_matches_reference_flow(probabilistic):
     from tests.test_semantic_oracle import srt
 
     P = _params(0.02, 0.08)
-    old = (P.kVolumetricIntegrationVoxelGridMinCount, P.kVolumetricIntegrationVoxelGridMinConfidence, P.kVolumetricIntegrationVoxelGridUseCarving)
+    old = (P.kVolumetricIntegrationVoxelGridMinCount, P.kVolumetricIntegrationVoxelGridMinConfidence, P.kVolumetricIntegrationVoxelGridUseCarving,
+           P.kVolumetricSemanticIntegrationUseInstanceIds)
     P.kVolumetricIntegrationVoxelGridMinCount, P.kVolumetricIntegrationVoxelGridMinConfidence = 1, 0.0
     P.kVolumetricIntegrationVoxelGridUseCarving = True
+    P.kVolumetricSemanticIntegrationUseInstanceIds = use_instance_ids
     try:
         s = SyntheticRGBD(CFG, noise=True)
         cam = dh.FakeCamera(s)
@@ -194,9 +198,13 @@ def test_semantic_integrator_matches_reference_flow(probabilistic):
         assert len({p[0] for p in pairs}) == len(pairs) == len({p[1] for p in pairs})
         np.testing.assert_allclose(ga[4], gb[4], rtol=0, atol=0 if not probabilistic else 2e-6)
         out = gpu.make_output("INTEGRATE")
-        assert out.objects is not None and out.objects.num_objects >= 1
+        if use_instance_ids:
+            assert out.objects is not None and out.objects.num_objects >= 1
+        else:
+            assert out.point_cloud is not None and len(out.point_cloud.points) > 1000
     finally:
-        (P.kVolumetricIntegrationVoxelGridMinCount, P.kVolumetricIntegrationVoxelGridMinConfidence, P.kVolumetricIntegrationVoxelGridUseCarving) = old
+        (P.kVolumetricIntegrationVoxelGridMinCount, P.kVolumetricIntegrationVoxelGridMinConfidence, P.kVolumetricIntegrationVoxelGridUseCarving,
+         P.kVolumetricSemanticIntegrationUseInstanceIds) = old
         RefSemGrid2(0, 0.05).set_depth_threshold(10.0)
         g = RefSemGrid2(1, 0.05)
         g.set_depth_threshold(5.0)
