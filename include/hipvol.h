@@ -273,6 +273,18 @@ int hv_tsdf_integrate_frames(hv_volume *v, const void *const *depth_frames, int3
                              int32_t n_frames, int32_t height, int32_t width, const double *intr, const double *T_cw,
                              double depth_scale, double depth_trunc);
 
+/* Channel order of the colour frames handed to hv_tsdf_integrate*: 0 = R, G, B (Open3D's RGBDImage, the default), 1 = B, G, R -
+ * pySLAM's keyframe.img as OpenCV loads it; the reference converts every keyframe on the host with cv2.cvtColor
+ * (volumetric_integrator_base.py:1054), here the pack kernel swaps the bytes of the record it writes anyway. */
+int hv_tsdf_set_color_order(hv_volume *v, int32_t bgr);
+
+/* Page-lock caller memory for the H2D DMA of hv_tsdf_integrate_frames / hv_integrate_*(HV_HOST): pySLAM's front hands keyframes
+ * over in a shared-memory ring (volumetric_integrator_base.py:401-410 carries them pickled through a Manager queue); once the
+ * ring is registered, frames that lie inside it are DMA'd in place - no staging copy - and the call returns when the DMA has
+ * read them.  Process-wide (any volume of the process sees the range); unregister before the memory is unmapped. */
+int hv_host_register(void *ptr, int64_t bytes);
+int hv_host_unregister(void *ptr);
+
 /* Multi-GPU image-tile sharding (north-star form): this volume fuses only voxels whose
  * projection lands in pixel tile [u0,u1) x [v0,v1); units that cannot project into the tile are
  * allocated (so all GPUs agree on the unit set) but not swept.  All zeros = whole image (default). */

@@ -210,6 +210,7 @@ struct HvFrameParams { // per-frame constants of the TSDF kernels (passed by val
     int32_t tiled;                              // 0: the tile is the whole image (the per-voxel tile test is skipped)
     int32_t owner_rank, owner_world;            // unit ownership sharding: this GPU fuses units with owner(key) == rank
     int32_t touch_box_bits;                     // touch pass: largest unit box enumerated through the LDS bitmap (0: never)
+    int32_t bgr;                                // colour frames are B, G, R (pySLAM's keyframe.img as OpenCV hands it): swapped while packing
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -268,6 +269,7 @@ struct hv_volume {
     uint64_t *touched_mask = nullptr; // [2][table_capacity] per-slot frame bitmask of the multi-frame sweep (ditto)
     void *frame_px = nullptr;         // [max_points] uint2 {depth f32 bits, packed rgb}: the gather target
     int debug_variant = 0;            // env HV_TSDF_DEBUG_VARIANT (roofline ablation only)
+    int color_bgr = 0;                // hv_tsdf_set_color_order
     int touch_box_bits = 2048;        // env HV_TSDF_TOUCH_BOX_BITS (0 forces the touch pass's general path; tests)
     int32_t frame_counter = 0;
     int32_t merge_stamp = 0;          // frame_counter at the last hv_tsdf_mark_merged: units stamped later are "dirty"

@@ -183,6 +183,47 @@ HvCopyPool *hv_copy_pool() {
 }
 } // namespace
 
+// ---- caller memory page-locked with hv_host_register (process-wide) ----
+namespace {
+struct HvHostRange {
+    const char *lo, *hi;
+};
+std::mutex g_host_ranges_m;
+std::vector<HvHostRange> g_host_ranges;
+
+bool hv_host_is_registered(const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_host_ranges_m);
+    for (const HvHostRange &r : g_host_ranges)
+        if ((const char *)p >= r.lo && (const char *)p + bytes <= r.hi) return true;
+    return false;
+}
+} // namespace
+
+extern "C" int hv_host_register(void *ptr, int64_t bytes) {
+    HV_REQUIRE(ptr != nullptr && bytes > 0, HV_ERR_INVALID, "hv_host_register: null pointer or empty range");
+    HV_HIP(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    std::lock_guard<std::mutex> lk(g_host_ranges_m);
+    g_host_ranges.push_back({(const char *)ptr, (const char *)ptr + bytes});
+    return HV_OK;
+}
+
+extern "C" int hv_host_unregister(void *ptr) {
+    HV_REQUIRE(ptr != nullptr, HV_ERR_INVALID, "hv_host_unregister: null pointer");
+    {
+        std::lock_guard<std::mutex> lk(g_host_ranges_m);
+        bool found = false;
+        for (size_t i = 0; i < g_host_ranges.size(); ++i)
+            if (g_host_ranges[i].lo == (const char *)ptr) {
+                g_host_ranges.erase(g_host_ranges.begin() + (long)i);
+                found = true;
+                break;
+            }
+        HV_REQUIRE(found, HV_ERR_INVALID, "hv_host_unregister: the range was not registered with hv_host_register");
+    }
+    HV_HIP(hipHostUnregister(ptr));
+    return HV_OK;
+}
+
 int hv_stage_frames(hv_volume *v, const void *const *depth_ptrs, const void *depth_base, size_t depth_frame_bytes,
                     const void *const *rgb_ptrs, const void *rgb_base, size_t rgb_frame_bytes, int n_frames,
                     const void **d_depth, const void **d_rgb, int *set_out) {
@@ -212,6 +253,28 @@ int hv_stage_frames(hv_volume *v, const void *const *depth_ptrs, const void *dep
         }
     }
     if (v->hs_dev_free_valid[set]) HV_HIP(hipStreamWaitEvent(v->hs_stream, v->hs_dev_free[set], 0));
+    // Frames that already lie in page-locked memory (hv_host_register: the front's shared-memory ring) need no staging copy: the
+    // DMA engine reads each of them in place.  The call returns when the copies have READ the caller's memory (the contract of
+    // hv_tsdf_integrate_frames) - the host waits for the copy stream, not for the sweep that runs beside it.
+    {
+        bool pinned = depth_ptrs != nullptr && rgb_ptrs != nullptr && !(getenv("HV_STAGE_DIRECT") && atoi(getenv("HV_STAGE_DIRECT")) == 0);
+        for (int f = 0; pinned && f < n_frames; ++f)
+            pinned = hv_host_is_registered(depth_ptrs[f], depth_frame_bytes) && hv_host_is_registered(rgb_ptrs[f], rgb_frame_bytes);
+        if (pinned) {
+            for (int f = 0; f < n_frames; ++f) {
+                HV_HIP(hipMemcpyAsync((char *)v->hs_dev[set][0] + depth_frame_bytes * (size_t)f, depth_ptrs[f], depth_frame_bytes,
+                                      hipMemcpyHostToDevice, v->hs_stream));
+                HV_HIP(hipMemcpyAsync((char *)v->hs_dev[set][1] + rgb_frame_bytes * (size_t)f, rgb_ptrs[f], rgb_frame_bytes,
+                                      hipMemcpyHostToDevice, v->hs_stream));
+            }
+            HV_HIP(hipEventRecord(v->hs_dev_ready[set], v->hs_stream));
+            HV_HIP(hipStreamSynchronize(v->hs_stream));
+            *d_depth = v->hs_dev[set][0];
+            *d_rgb = v->hs_dev[set][1];
+            *set_out = set;
+            return HV_OK;
+        }
+    }
     // sub-chunks of about 16 MB: long enough for the DMA engine to reach its rate, short enough that the first one is on its
     // way early
     size_t sub_target = 16u << 20; // (4 / 8 / 16 MB measured: 0.53 / 0.72 / 0.76 of the H2D bound)

@@ -36,6 +36,11 @@ static constexpr int PLANE_BYTES = RRR * 4;
 static constexpr int HV_TOUCH_FAN = 8; // lanes per depth sample in the online touch pass
 static constexpr uint32_t HV_REC_ONE = 1u << 24; // observation count byte of a batch frame record's colour word
 
+// packed colour word {byte0 = R, byte1 = G, byte2 = B}: a B, G, R source swaps bytes 0 and 2 (one v_perm_b32)
+__device__ __forceinline__ uint32_t hv_colour_order(uint32_t c, int bgr) {
+    return bgr ? __builtin_amdgcn_perm(0u, c, 0x03000102u) : c;
+}
+
 // Image::CreateDepthToCameraDistanceMultiplierFloatImage, evaluated per gather instead of tabulated.
 __device__ __forceinline__ float hv_multiplier(const HvFrameParams &P, int u, int v) {
     const float xx = ((float)u - P.cx) * P.ffl_inv_x;
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch(HvTable table, int32_t 
         const uint8_t *c = rgb + i * 3;
         uint2 rec;
         rec.x = __float_as_uint(hv_convert_depth(P, depth_raw, i));
-        rec.y = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+        rec.y = hv_colour_order((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16), P.bgr);
         frame_px[i] = rec;
         return;
     }
@@ -823,8 +828,10 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
             const uint32_t w0 = c4[0], w1 = c4[1], w2 = c4[2];
             // byte 3 of a batch record's colour word is 1: the fold form of the sweep adds accepted records' words into packed
             // accumulators and that byte counts the observations (every other consumer masks the colour bytes out)
-            const uint32_t col[4] = {(w0 & 0xffffffu) | HV_REC_ONE, (w0 >> 24) | ((w1 & 0xffffu) << 8) | HV_REC_ONE,
-                                     (w1 >> 16) | ((w2 & 0xffu) << 16) | HV_REC_ONE, (w2 >> 8) | HV_REC_ONE};
+            const uint32_t col[4] = {hv_colour_order(w0 & 0xffffffu, P.bgr) | HV_REC_ONE,
+                                     hv_colour_order((w0 >> 24) | ((w1 & 0xffffu) << 8), P.bgr) | HV_REC_ONE,
+                                     hv_colour_order((w1 >> 16) | ((w2 & 0xffu) << 16), P.bgr) | HV_REC_ONE,
+                                     hv_colour_order(w2 >> 8, P.bgr) | HV_REC_ONE};
             float d[4];
             if (P.depth_is_u16) {
                 const uint2 raw = *(const uint2 *)((const uint16_t *)depth_f + i0);
@@ -853,7 +860,7 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
                 const uint8_t *c = rgb_f + i * 3;
                 uint2 rec;
                 rec.x = __float_as_uint(hv_convert_depth(P, depth_f, i));
-                rec.y = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | HV_REC_ONE;
+                rec.y = hv_colour_order((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16), P.bgr) | HV_REC_ONE;
                 if (mult12 != nullptr) {
                     uint32_t *r3 = (uint32_t *)frame_px + ((int64_t)f * npx + i) * 3;
                     r3[0] = rec.x;
@@ -2173,6 +2180,7 @@ static int make_frame_params(hv_volume *v, int H, int W, const double *intr, con
     P->W = W;
     P->stride = v->cfg.depth_sampling_stride;
     P->touch_box_bits = v->touch_box_bits;
+    P->bgr = v->color_bgr;
     P->depth_is_u16 = depth_dtype == HV_DEPTH_U16;
     const bool whole = v->tile[0] == 0 && v->tile[1] == 0 && v->tile[2] == 0 && v->tile[3] == 0;
     P->tile_u0 = whole ? 0 : v->tile[0];
@@ -2648,6 +2656,13 @@ int hv_tsdf_set_tile(hv_volume *v, int32_t u0, int32_t v0, int32_t u1, int32_t v
     v->tile[1] = v0;
     v->tile[2] = u1;
     v->tile[3] = v1;
+    return HV_OK;
+}
+
+int hv_tsdf_set_color_order(hv_volume *v, int32_t bgr) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_tsdf_set_color_order: null volume");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_set_color_order: volume is not in TSDF mode");
+    v->color_bgr = bgr ? 1 : 0;
     return HV_OK;
 }
 

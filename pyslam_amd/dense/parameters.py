@@ -59,6 +59,8 @@ class Parameters:
     # GPU-path additions (no reference counterpart)
     kVolumetricIntegrationHipDevice = 0
     kVolumetricIntegrationHipMaxBlocks = None  # None: library default pool size
+    kVolumetricIntegrationUseSharedMemory = True  # keyframe images / output arrays through shared memory, queues carry control only
+    kVolumetricIntegrationSharedMemorySlots = 96  # ring slots (one keyframe each; 5.5 MB at 640x480)
 
 
 def get_parameters():

@@ -4,10 +4,12 @@ keyframe gating, output wrappers (reference lines cited per item).
 Differences that are deliberate (MI355X-first):
 * the worker is always a *spawned* process (the reference already spawns for TSDF, base.py:348-362)
   and owns the HIP context; the volume stays resident in HBM for the life of the worker;
-* queues are plain multiprocessing queues of the spawn context instead of Manager proxies (one
-  pickle instead of two per frame on q_out); the names q_in / q_out / q_management and their semantics
-  (push-to-front for regular tasks, RESET on q_management) are unchanged: q_in and q_management are manager queues
-  like the reference's, because drain-and-refill needs put() to be synchronous;
+* q_in / q_out / q_management keep their names and semantics (push-to-front for regular tasks, RESET on
+  q_management; q_in and q_management are manager queues like the reference's, because drain-and-refill needs put()
+  to be synchronous), but they carry CONTROL only: a keyframe's images travel in a shared-memory ring of slots
+  (one memcpy in add_keyframe, zero-copy views in the worker, page-locked for the H2D DMA), an output's arrays in a
+  shared segment of their own, and push_to_front / the backlog drain are ONE manager round trip each
+  (shared_transport.py; `kVolumetricIntegrationUseSharedMemory = False` restores pickled images);
 * undistortion: the maps are computed by a restatement of OpenCV's getOptimalNewCameraMatrix /
   initUndistortRectifyMap (pyslam_amd/prep.py) and cv2.remap runs on the GPU (hv_remap); cv2 is not
   available here, so parity with OpenCV at that step is unpinned (validated geometrically).
@@ -23,6 +25,7 @@ from enum import Enum
 
 import numpy as np
 
+from . import shared_transport as st
 from .parameters import get_parameters, static_fields_to_dict
 from .ply_io import write_ply_mesh, write_ply_points
 
@@ -123,7 +126,11 @@ class VolumetricIntegrationOutput:  # base.py:308-322
 
 
 def push_to_front(queue, item):
-    """pyslam/utilities/data_management.py:94-114: drain, then refill with `item` first."""
+    """pyslam/utilities/data_management.py:94-114: drain, then refill with `item` first.  A ControlQueue does exactly that
+    inside the manager process (one round trip instead of 2 n + 1)."""
+    if hasattr(queue, "put_front"):
+        queue.put_front(item)
+        return
     items = [item]
     while True:
         try:
@@ -140,12 +147,112 @@ def push_to_front(queue, item):
                 pass
 
 
-def empty_queue(queue):
+def empty_queue(queue, on_drop=None):
+    """Drop everything that is queued; on_drop(item) sees every dropped item (a task gives its ring slot back, an output its
+    shared segment)."""
+    if hasattr(queue, "drain"):
+        try:
+            items = queue.drain()
+        except Exception:
+            items = []
+        if on_drop is not None:
+            for i in items:
+                on_drop(i)
+        return
     try:
         while True:
-            queue.get(block=False)
+            item = queue.get(block=False)
+            if on_drop is not None:
+                on_drop(item)
     except Exception:
         pass
+
+
+def take_integrate_backlog(q_in, limit):
+    """The queued INTEGRATE tasks at the front of q_in (at most `limit`), in queue order; the first task of another kind stays
+    queued where it was.  One manager round trip on a ControlQueue."""
+    if hasattr(q_in, "get_batch"):
+        return q_in.get_batch(limit, VolumetricIntegrationTaskType.INTEGRATE.name)
+    out = []
+    while len(out) < limit:
+        try:
+            nxt = q_in.get_nowait()
+        except Exception:
+            break
+        if nxt is not None and nxt.task_type == VolumetricIntegrationTaskType.INTEGRATE:
+            out.append(nxt)
+        else:
+            push_to_front(q_in, nxt)  # not ours: put it back where it was
+            break
+    return out
+
+
+class _WorkerQueue:
+    """q_in as the worker's volume_integration() sees it: the same queue, but a task that comes out has its images resolved
+    from the shared ring (numpy views, no copy) and its slot noted; the worker loop releases the noted slots when the call that
+    took them has returned."""
+
+    def __init__(self, q, ring):
+        self._q, self._ring, self._slots = q, ring, []
+
+    def _take(self, task):
+        kd = getattr(task, "keyframe_data", None)
+        if kd is not None:
+            slot = st.keyframe_from_ring(self._ring, kd)
+            if slot is not None:
+                self._slots.append(slot)
+        return task
+
+    def get(self, *a, **k):
+        return self._take(self._q.get(*a, **k))
+
+    def get_nowait(self):
+        return self._take(self._q.get_nowait())
+
+    def get_batch(self, limit, task_type_name):
+        """-> list of queued tasks of that type from the front of the queue (possibly empty)."""
+        if hasattr(self._q, "get_batch"):
+            return [self._take(t) for t in self._q.get_batch(limit, task_type_name)]
+        out = []
+        while len(out) < limit:
+            try:
+                nxt = self._q.get_nowait()
+            except Exception:
+                break
+            if nxt is not None and getattr(getattr(nxt, "task_type", None), "name", None) == task_type_name:
+                out.append(self._take(nxt))
+            else:
+                push_to_front(self._q, nxt)  # not ours: put it back where it was
+                break
+        return out
+
+    def release_consumed(self):
+        for slot in self._slots:
+            self._ring.release(slot)
+        self._slots = []
+
+    def __getattr__(self, name):  # put, put_front, empty, qsize, drain, ...
+        return getattr(self._q, name)
+
+
+def _shallow_output_copy(output):
+    """A copy of an output whose containers (output, mesh / point cloud / object list, objects) are new objects sharing the
+    arrays: export_arrays() rewrites the COPY's fields, the worker's last_output stays whole."""
+    import copy
+
+    def cp(o, depth=0):
+        if o is None or depth > 4 or isinstance(o, (np.ndarray, str, bytes, int, float, bool, Enum)):
+            return o
+        if isinstance(o, list):
+            return [cp(x, depth + 1) for x in o]
+        if hasattr(o, "__dict__"):
+            c = copy.copy(o)
+            for k, v in list(c.__dict__.items()):
+                c.__dict__[k] = cp(v, depth + 1)
+            return c
+        return o
+
+    return cp(output)
 
 
 class TimerFps:
@@ -235,10 +342,27 @@ class VolumetricIntegratorBase:
         # thread delivers later (push_to_front then degrades to append, rebuild()'s drain misses in-flight INTEGRATE tasks
         # and their pre-loop-closure poses get fused into the fresh volume).  q_out only ever carries one consumer's
         # outputs (meshes of 100s of MB): it stays a plain mp.Queue to avoid a second pickle of those.
-        self._mp_manager = mp.Manager()
-        self.q_in = self._mp_manager.Queue()          # regular tasks (integrate, update output, save)
-        self.q_out = mp.Queue()                       # outputs (visualise, save)
-        self.q_management = self._mp_manager.Queue()  # management tasks (reset / rebuild)
+        self._mp_manager = st.start_manager(mp)
+        self.q_in = self._mp_manager.ControlQueue()          # regular tasks (integrate, update output, save)
+        self.q_out = mp.Queue()                              # outputs (visualise, save)
+        self.q_management = self._mp_manager.ControlQueue()  # management tasks (reset / rebuild)
+        # keyframe images travel in shared memory, not through the queue: slot = colour + right image + depth + two label images
+        self.frame_ring = None
+        if getattr(Parameters, "kVolumetricIntegrationUseSharedMemory", True) and camera is not None:
+            try:
+                px = int(camera.width) * int(camera.height)
+                slot_bytes = px * (3 + 3 + 4 + 4 + 4) + 8 * 256
+                slots = int(getattr(Parameters, "kVolumetricIntegrationSharedMemorySlots", 96))
+                try:  # a tmpfs that is too small only says so with SIGBUS on the first write: size the ring to what is free
+                    vfs = os.statvfs("/dev/shm")
+                    slots = min(slots, int(vfs.f_bavail * vfs.f_frsize // 4 // slot_bytes))
+                except OSError:
+                    pass
+                if slots >= 2:
+                    self.frame_ring = st.FrameRing(mp, slot_bytes, slots)
+            except Exception:
+                traceback.print_exc()
+                self.frame_ring = None
         self.parameters_dict = static_fields_to_dict(Parameters)  # snapshot for the child, base.py:412-416
         self.q_in_condition = mp.Condition()
         self.q_out_condition = mp.Condition()
@@ -322,10 +446,13 @@ class VolumetricIntegratorBase:
         self.process.join(timeout=2 * Parameters.kMultiprocessingProcessJoinDefaultTimeout)
         if self.process.is_alive():
             self.process.terminate()
+        empty_queue(self.q_out, st.drop_output)
         try:
             self._mp_manager.shutdown()  # the queues' server process
         except Exception:
             pass
+        if self.frame_ring is not None:
+            self.frame_ring.close()
 
     def flush_keyframe_queue(self):  # base.py:1120-1188
         with self.keyframe_queue_lock:
@@ -357,6 +484,14 @@ class VolumetricIntegratorBase:
 
     def add_task(self, task, front=True):  # base.py:1216-1232
         if self.is_running.value == 1:
+            if task is not None and task.task_type == VolumetricIntegrationTaskType.INTEGRATE and self.frame_ring is not None:
+                # one memcpy into a ring slot; the queue carries the slot's name.  A full ring waits briefly for the worker
+                # (back-pressure), then falls back to pickling the images with the task like the reference does.
+                t0 = time.perf_counter()
+                while not st.keyframe_to_ring(self.frame_ring, task.keyframe_data):
+                    if self.frame_ring.held() < self.frame_ring.n_slots or time.perf_counter() - t0 > 0.25 or self.is_running.value != 1:
+                        break  # not a matter of waiting (nothing to move / does not fit), or waited long enough
+                    time.sleep(0.0005)
             with self.q_in_condition:
                 if front:
                     push_to_front(self.q_in, task)
@@ -374,7 +509,7 @@ class VolumetricIntegratorBase:
         if self.is_running.value != 1:
             return
         with self.q_in_condition:
-            empty_queue(self.q_in)
+            empty_queue(self.q_in, self._drop_task)
         with self.q_in_condition:
             self.q_management.put(VolumetricIntegrationTask(task_type=VolumetricIntegrationTaskType.RESET), timeout=1.0)
             self.q_in_condition.notify_all()
@@ -384,7 +519,7 @@ class VolumetricIntegratorBase:
                 break
             time.sleep(0.05)
         with self.q_out_condition:
-            empty_queue(self.q_out)
+            empty_queue(self.q_out, st.drop_output)
             self.q_out.put(VolumetricIntegrationOutput(VolumetricIntegrationTaskType.RESET))
             self.q_out_condition.notify_all()
         with self.keyframe_queue_lock:
@@ -406,9 +541,12 @@ class VolumetricIntegratorBase:
         if self.q_out.empty():
             return None
         try:
-            return self.q_out.get(timeout=timeout)
+            return st.import_arrays(self.q_out.get(timeout=timeout))
         except Exception:
             return None
+
+    def _drop_task(self, task):
+        st.drop_task(self.frame_ring, task)
 
     def draw_output(self, output):  # base.py:1344: forwards to pySLAM's viewer when it exists
         if self.viewer_queue is not None and output is not None:
@@ -495,8 +633,12 @@ class VolumetricIntegratorBase:
             if instances is not None:
                 instances = self.volume.remap(np.ascontiguousarray(instances, dtype=np.int32), m1, m2, linear=False)
         if self.depth_estimator is not None and keyframe_data.id not in self.img_id_to_depth:
-            self.img_id_to_depth[keyframe_data.id] = depth  # base.py:1050-1052
-        color_rgb = np.ascontiguousarray(color[..., ::-1])  # cv2.COLOR_BGR2RGB, base.py:1054
+            # base.py:1050-1052 (a view of a ring slot is copied: the slot is reused after this call)
+            self.img_id_to_depth[keyframe_data.id] = np.array(depth) if isinstance(depth, np.ndarray) and depth.base is not None else depth
+        if getattr(self, "volume_takes_bgr", False):
+            color_rgb = np.ascontiguousarray(color)  # the pack kernel swaps the channels (hv_tsdf_set_color_order): no host pass
+        else:
+            color_rgb = np.ascontiguousarray(color[..., ::-1])  # cv2.COLOR_BGR2RGB, base.py:1054
         if is_dev:  # the fused calls want colour and depth in the same place
             import torch
 
@@ -510,10 +652,10 @@ class VolumetricIntegratorBase:
         with reset_mutex:
             if reset_requested.value == 1:
                 with q_in_condition:
-                    empty_queue(q_in)
+                    empty_queue(q_in, self._drop_task)
                     q_in_condition.notify_all()
                 with q_out_condition:
-                    empty_queue(q_out)
+                    empty_queue(q_out, st.drop_output)
                     q_out_condition.notify_all()
                 try:
                     self.volume.reset()
@@ -543,6 +685,13 @@ class VolumetricIntegratorBase:
             traceback.print_exc()
             is_running.value = 0
             return
+        ring = getattr(self, "frame_ring", None)
+        if ring is not None and hasattr(self.volume, "register_host_memory"):
+            try:  # page-lock the ring: the H2D DMA then reads a keyframe's slot in place (no staging copy)
+                self.volume.register_host_memory(ring.base_address(), ring.slot_bytes * ring.n_slots)
+            except Exception:
+                traceback.print_exc()
+        q_in_w = _WorkerQueue(q_in, ring)
         is_looping.value = 1
         timer_fps = TimerFps("VolumetricIntegratorBase")
         timer_fps.start()
@@ -560,9 +709,12 @@ class VolumetricIntegratorBase:
                     break
                 if has_regular_task or has_management_task:
                     q_in_size = q_in.qsize()
-                    self.volume_integration(q_in, q_out, q_out_condition, q_management, viewer_queue, is_running,
-                                            load_request_completed, load_request_condition, save_request_completed,
-                                            save_request_condition, time_volumetric_integration)
+                    try:
+                        self.volume_integration(q_in_w, q_out, q_out_condition, q_management, viewer_queue, is_running,
+                                                load_request_completed, load_request_condition, save_request_completed,
+                                                save_request_condition, time_volumetric_integration)
+                    finally:
+                        q_in_w.release_consumed()  # the keyframes this call took are fused (or dropped): their slots are free
                     timer_fps.refresh()
                     fps = timer_fps.get_fps()
                     if (Parameters.kVolumetricIntegrationFpsThrottleEnabled
@@ -582,8 +734,8 @@ class VolumetricIntegratorBase:
                         save_request_condition.notify_all()
         is_looping.value = 0
         self._stop_volume_integrator_implementation()
-        empty_queue(q_in)
-        empty_queue(q_out)
+        empty_queue(q_in, self._drop_task)
+        empty_queue(q_out, st.drop_output)
 
     # -- shared tail of every volume_integration(): publish or acknowledge ------------------------
     def _publish(self, last_output, q_out, q_out_condition, is_running, save_request_completed, save_request_condition):
@@ -591,7 +743,12 @@ class VolumetricIntegratorBase:
             if last_output.task_type in (VolumetricIntegrationTaskType.INTEGRATE, VolumetricIntegrationTaskType.UPDATE_OUTPUT):
                 with q_out_condition:
                     last_output.timestamp = time.perf_counter()
-                    q_out.put(last_output)
+                    if getattr(self, "frame_ring", None) is not None:
+                        # big arrays leave through a shared segment (one memcpy here, one in pop_output) instead of a pickle
+                        # through the queue's pipe; self.last_output keeps the arrays (the copy that travels is shallow)
+                        q_out.put(st.export_arrays(_shallow_output_copy(last_output)))
+                    else:
+                        q_out.put(last_output)
                     q_out_condition.notify_all()
             elif last_output.task_type == VolumetricIntegrationTaskType.SAVE:
                 with save_request_condition:

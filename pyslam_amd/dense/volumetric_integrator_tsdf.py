@@ -12,7 +12,7 @@ from .volumetric_integrator_base import (
     VolumetricIntegrationPointCloud,
     VolumetricIntegrationTaskType,
     VolumetricIntegratorBase,
-    push_to_front,
+    take_integrate_backlog,
 )
 from .volumetric_integrator_types import DatasetEnvironmentType
 
@@ -39,6 +39,13 @@ class VolumetricIntegratorTsdf(VolumetricIntegratorBase):
         self.volume = factory(Parameters.kVolumetricIntegrationVoxelLength, Parameters.kVolumetricIntegrationTSdfTrunc,
                               Parameters.kVolumetricIntegrationHipDevice, Parameters.kVolumetricIntegrationHipMaxBlocks,
                               max(camera.width * camera.height, 1 << 16))
+        # keyframes arrive B, G, R (OpenCV); the HIP volume swaps the channels while it packs its frame records, so the
+        # reference's per-keyframe cv2.cvtColor (base.py:1054) - a strided 0.9 MB host copy - disappears and a keyframe's
+        # colour plane can be DMA'd straight from its shared-memory slot
+        self.volume_takes_bgr = False
+        if hasattr(self.volume, "set_color_order"):
+            self.volume.set_color_order(bgr=True)
+            self.volume_takes_bgr = True
         fx, fy, cx, cy = self.get_camera_intrinsics_for_depth()
         self.o3d_camera = PinholeCameraIntrinsic(width=camera.width, height=camera.height, fx=fx, fy=fy, cx=cx, cy=cy)
 
@@ -73,17 +80,7 @@ class VolumetricIntegratorTsdf(VolumetricIntegratorBase):
                         # Backlog (offline reconstruction, rebuild() after loop closure): drain the queued
                         # INTEGRATE tasks and fuse them with one multi-frame sweep (hv_tsdf_integrate_batch);
                         # same result as fusing them one by one in this order.
-                        tasks = [self.last_input_task]
-                        while len(tasks) < 64:
-                            try:
-                                nxt = q_in.get_nowait()
-                            except Exception:
-                                break
-                            if nxt is not None and nxt.task_type == VolumetricIntegrationTaskType.INTEGRATE:
-                                tasks.append(nxt)
-                            else:
-                                push_to_front(q_in, nxt)  # not ours: put it back where it was
-                                break
+                        tasks = [self.last_input_task] + take_integrate_backlog(q_in, 63)
                         frames = []
                         for task in tasks:
                             color, depth, _, _, _ = self.estimate_depth_if_needed_and_rectify(task.keyframe_data)

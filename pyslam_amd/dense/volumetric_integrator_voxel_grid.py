@@ -13,7 +13,7 @@ from .volumetric_integrator_base import (
     VolumetricIntegrationPointCloud,
     VolumetricIntegrationTaskType,
     VolumetricIntegratorBase,
-    push_to_front,
+    take_integrate_backlog,
 )
 from .volumetric_integrator_types import DatasetEnvironmentType
 
@@ -87,16 +87,8 @@ class VolumetricIntegratorVoxelGrid(VolumetricIntegratorBase):
                         # bit-identical to fusing them one by one in this order.  Carving needs the per-frame interleaving.
                         tasks = [self.last_input_task]
                         can_batch = (not Parameters.kVolumetricIntegrationVoxelGridUseCarving) and hasattr(self.volume, "integrate_rgbd_batch")
-                        while can_batch and len(tasks) < 16:
-                            try:
-                                nxt = q_in.get_nowait()
-                            except Exception:
-                                break
-                            if nxt is not None and nxt.task_type == VolumetricIntegrationTaskType.INTEGRATE:
-                                tasks.append(nxt)
-                            else:
-                                push_to_front(q_in, nxt)  # not ours: put it back where it was
-                                break
+                        if can_batch:
+                            tasks += take_integrate_backlog(q_in, 15)
                         frames = []
                         for task in tasks:
                             keyframe_data = task.keyframe_data

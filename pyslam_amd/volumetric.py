@@ -99,6 +99,13 @@ class _Volume:
         """Adopt a caller-owned hipStream_t (e.g. ``torch.cuda.Stream().cuda_stream``)."""
         L.check(self._lib.hv_set_stream(self._h, ctypes.c_void_p(int(stream_handle))))
 
+    def register_host_memory(self, address, nbytes):
+        """Page-lock [address, address + nbytes) (hv_host_register): host frames inside it are DMA'd in place."""
+        L.check(self._lib.hv_host_register(ctypes.c_void_p(int(address)), int(nbytes)))
+
+    def unregister_host_memory(self, address):
+        L.check(self._lib.hv_host_unregister(ctypes.c_void_p(int(address))))
+
     # -- torch CUDA tensors handed to / returned by the C ABI ------------------------------------------
     def _torch_stream(self, device):
         """The volume's hipStream_t as a torch stream (for event ordering against torch's streams and the caching allocator)."""
@@ -682,6 +689,10 @@ class ScalableTSDFVolume(_Volume):
         cp = (ctypes.c_void_p * F)(*[c.ctypes.data for c in colors])
         L.check(self._lib.hv_tsdf_integrate_frames(self._h, dp, dkind, cp, F, H, W, L.ptr(intr), L.ptr(T), float(depth_scale),
                                                    float(depth_trunc)))
+
+    def set_color_order(self, bgr=False):
+        """Colour frames handed to integrate* are R, G, B (Open3D's order, default) or B, G, R (OpenCV's: pySLAM's keyframe.img)."""
+        L.check(self._lib.hv_tsdf_set_color_order(self._h, 1 if bgr else 0))
 
     def set_tile(self, u0, v0, u1, v1):
         """Restrict fusion to the image tile [u0,u1) x [v0,v1) (multi-GPU sharding); zeros = whole image."""

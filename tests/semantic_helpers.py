@@ -82,6 +82,9 @@ def compare_keyframe_flow(kind, config, voxel, frame_ids, max_blocks, max_points
     fr = CameraFrustrum(*intr, s.width, s.height, np.eye(4), depth_max=frustum_depth[0], depth_min=frustum_depth[1])
     obj_map = {}  # reference object id -> GPU object id
     n_new = 0
+    ref_seconds = []  # the reference side of every keyframe on this host's clock (bench: cpu_reference)
+    import time
+
     for k, i in enumerate(frame_ids):
         depth, rgb, T, cls_img, inst_img = semantic_frame(s, i, shuffle=k)
         fr.set_T_cw(T)
@@ -91,12 +94,16 @@ def compare_keyframe_flow(kind, config, voxel, frame_ids, max_blocks, max_points
             c_g, cl_g, in_g = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (rgb, cls_img, inst_img))
         else:
             d_g, c_g, cl_g, in_g = gpu.filter_shadow_points(depth), rgb, cls_img, inst_img
+        t0 = time.perf_counter()
         d_r = hp.filter_shadow_points(depth)
+        t_ref = time.perf_counter() - t0
         np.testing.assert_array_equal(d_g.cpu().numpy() if device_images else d_g, d_r)
         mg = gpu.assign_object_ids_to_instance_ids(fr, cl_g, in_g, d_g, depth_threshold=depth_threshold, do_carving=do_carving,
                                                    min_vote_ratio=0.5, min_votes=3)
+        t0 = time.perf_counter()
         mr = ref.assign_object_ids_to_instance_ids(intr32, s.width, s.height, T, fr.depth_max, fr.depth_min, cls_img, inst_img, d_r,
                                                    depth_threshold, do_carving, 0.5, 3)
+        t_ref += time.perf_counter() - t0
         assert set(mg) == set(mr), (k, mg, mr)
         new_g = sorted(v for v in mg.values() if v > 0 and v not in obj_map.values())
         new_r = sorted(v for v in mr.values() if v > 0 and v not in obj_map)
@@ -108,11 +115,15 @@ def compare_keyframe_flow(kind, config, voxel, frame_ids, max_blocks, max_points
         assert {k_: obj_map.get(v, v) for k_, v in mr.items()} == mg, (k, mg, mr, obj_map)
         assert gpu._lib.hv_peek_next_object_id() == ref.peek_next_object_id()
         og = remap_instance_ids(in_g, mg, volume=gpu)
+        t0 = time.perf_counter()
         orf = ref_remap_instance_ids(inst_img, mr)
+        t_ref += time.perf_counter() - t0
         np.testing.assert_array_equal(og.cpu().numpy() if device_images else og, relabel(orf, obj_map))
         gpu.integrate_rgbd(d_g, c_g, *intr, T, class_ids_image=cl_g, object_ids_image=og, max_depth=4.0, use_depths=True)
+        t0 = time.perf_counter()
         pts, cols, cls, ob, depths = frame_points(d_r, rgb, T, cls_img, orf, intr, 4.0)
         ref.integrate(pts.astype(np.float32), cols, cls, ob, depths)
+        ref_seconds.append(t_ref + time.perf_counter() - t0)
     assert gpu.dropped_points() == 0 and gpu.label_overflows() == 0
     assert gpu.num_blocks() == ref.num_blocks()
     tol = 0.0 if kind == 0 else 2e-6
@@ -147,4 +158,4 @@ def compare_keyframe_flow(kind, config, voxel, frame_ids, max_blocks, max_points
             np.testing.assert_allclose(confg, confr, rtol=0, atol=tol)
     return dict(keyframes=len(frame_ids), blocks=int(gpu.num_blocks()), occupied_voxels=int(len(a[0])), objects=len(seg_r),
                 new_object_ids=n_new, map_sizes=[len(obj_map)], conf_max_abs_diff=float(np.abs(a[4] - b[4]).max()),
-                label_overflows=int(gpu.label_overflows()))
+                label_overflows=int(gpu.label_overflows()), ref_seconds=ref_seconds)

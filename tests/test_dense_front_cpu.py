@@ -214,3 +214,173 @@ def test_result_arrays_fall_back_to_plain_numpy(monkeypatch):
     monkeypatch.setenv("PYSLAM_AMD_PINNED_RESULTS", "0")
     a = _result_array((200_000, 3), np.float64)
     assert a.shape == (200_000, 3) and a.base is None  # an owning numpy array, not a view of a torch tensor
+
+
+# ---- shared-memory transport of the front (pyslam_amd/dense/shared_transport.py) ------------------------------------------------
+def _ring_child(ring, ref, q):
+    """Runs in a spawned process: attach, read through the view, release the slot."""
+    a = ring.view(ref)
+    q.put((float(a.sum()), a.shape, str(a.dtype)))
+    ring.release(0)
+
+
+def test_frame_ring_round_trip_across_processes():
+    import multiprocessing as mp
+
+    from pyslam_amd.dense import shared_transport as st
+
+    ctx = mp.get_context("spawn")
+    ring = st.FrameRing(ctx, 1 << 20, 4)
+    try:
+        slot = ring.acquire()
+        assert slot == 0 and ring.held() == 1
+        a = np.arange(120 * 160, dtype=np.float32).reshape(120, 160)
+        refs = ring.write(slot, {"depth": a, "img": np.full((120, 160, 3), 7, np.uint8)})
+        assert set(refs) == {"depth", "img"} and refs["depth"].offset % 256 == 0 and refs["img"].offset % 256 == 0
+        np.testing.assert_array_equal(ring.view(refs["depth"]), a)
+        assert ring.write(slot, {"big": np.zeros(2 << 20, np.uint8)}) is None  # does not fit a slot
+        q = ctx.Queue()
+        p = ctx.Process(target=_ring_child, args=(ring, refs["depth"], q))
+        p.start()
+        got = q.get(timeout=60)
+        p.join(30)
+        assert got == (float(a.sum()), (120, 160), "float32")
+        assert ring.held() == 0  # released by the other process
+        slots = [ring.acquire() for _ in range(5)]
+        assert slots[:4] == [0, 1, 2, 3] and slots[4] is None  # a full ring says so
+    finally:
+        ring.close()
+
+
+def test_keyframe_images_move_into_the_ring_and_back():
+    import multiprocessing as mp
+
+    from pyslam_amd.dense import shared_transport as st
+    from pyslam_amd.dense.volumetric_integrator_base import VolumetricIntegrationTask
+
+    s = SyntheticRGBD("tiny_160x120_2cm", noise=False)
+    cam = dh.FakeCamera(s)
+    kf = dh.FakeKeyFrame(0, s, cam, semantic=True)
+    ring = st.FrameRing(mp.get_context("spawn"), 160 * 120 * 18 + 2048, 2)
+    try:
+        task = VolumetricIntegrationTask(kf, task_type=VolumetricIntegrationTaskType.INTEGRATE)
+        task.keyframe_data.semantic_instances_img = kf.semantic_instances_img
+        assert st.keyframe_to_ring(ring, task.keyframe_data)
+        kd = task.keyframe_data
+        assert all(isinstance(getattr(kd, f), st.ArrayRef) for f in ("img", "depth", "semantic_img", "semantic_instances_img"))
+        assert kd.img_right is None and kd._ring_slot == 0
+        assert kf.img.dtype == np.uint8  # the keyframe's own arrays are untouched
+        import pickle
+
+        assert len(pickle.dumps(task)) < 8192  # the queue item is control only
+        kd2 = pickle.loads(pickle.dumps(task)).keyframe_data
+        slot = st.keyframe_from_ring(ring, kd2)
+        assert slot == 0
+        np.testing.assert_array_equal(kd2.img, kf.img)
+        np.testing.assert_array_equal(kd2.depth, kf.depth_img)
+        np.testing.assert_array_equal(kd2.semantic_img, kf.semantic_img)
+        assert not kd2.depth.flags.owndata  # a view of the slot, not a copy
+        # a second keyframe takes slot 1, a third finds the ring full and stays as it is (travels pickled, like the reference)
+        t2 = VolumetricIntegrationTask(kf, task_type=VolumetricIntegrationTaskType.INTEGRATE)
+        t3 = VolumetricIntegrationTask(kf, task_type=VolumetricIntegrationTaskType.INTEGRATE)
+        assert st.keyframe_to_ring(ring, t2.keyframe_data) and not st.keyframe_to_ring(ring, t3.keyframe_data)
+        assert isinstance(t3.keyframe_data.depth, np.ndarray)
+        st.drop_task(ring, t2)
+        ring.release(slot)
+        assert ring.held() == 0
+    finally:
+        ring.close()
+
+
+def test_control_queue_put_front_get_batch_drain():
+    import multiprocessing as mp
+
+    from pyslam_amd.dense import shared_transport as st
+    from pyslam_amd.dense.volumetric_integrator_base import (VolumetricIntegrationTask, empty_queue, push_to_front,
+                                                             take_integrate_backlog)
+
+    m = st.start_manager(mp.get_context("spawn"))
+    try:
+        q = m.ControlQueue()
+        for i in range(100):
+            push_to_front(q, i)  # -> put_front: one round trip each
+        assert q.qsize() == 100
+        assert [q.get(block=False) for _ in range(100)] == list(range(99, -1, -1))  # newest first, like drain-and-refill
+        I, U = VolumetricIntegrationTaskType.INTEGRATE, VolumetricIntegrationTaskType.UPDATE_OUTPUT
+        for t in (I, I, I, U, I):
+            q.put(VolumetricIntegrationTask(task_type=t))
+        got = take_integrate_backlog(q, 2)
+        assert [t.task_type for t in got] == [I, I]
+        got = take_integrate_backlog(q, 16)
+        assert [t.task_type for t in got] == [I]  # stops at the UPDATE_OUTPUT task, which stays at the front
+        assert q.get(block=False).task_type == U and q.qsize() == 1
+        q.put(None)
+        dropped = []
+        empty_queue(q, dropped.append)
+        assert q.empty() and len(dropped) == 2 and dropped[1] is None
+        with pytest.raises(Exception):
+            q.get(timeout=0.05)  # queue.Empty through the proxy
+    finally:
+        m.shutdown()
+
+
+def test_output_arrays_travel_through_a_shared_segment():
+    from multiprocessing import shared_memory
+
+    from pyslam_amd.dense import VolumetricIntegrationOutput, VolumetricIntegrationPointCloud
+    from pyslam_amd.dense import shared_transport as st
+    from pyslam_amd.dense.volumetric_integrator_base import _shallow_output_copy
+
+    pts = np.random.default_rng(0).random((50_000, 3)).astype(np.float32)
+    cols = np.random.default_rng(1).random((50_000, 3)).astype(np.float32)
+    out = VolumetricIntegrationOutput(VolumetricIntegrationTaskType.INTEGRATE, 5,
+                                      VolumetricIntegrationPointCloud(points=pts, colors=cols, semantics=np.arange(10, dtype=np.int32)))
+    import pickle
+
+    travelling = st.export_arrays(_shallow_output_copy(out))
+    assert isinstance(out.point_cloud.points, np.ndarray)  # the worker's own last_output is untouched
+    assert isinstance(travelling.point_cloud.points, st.ArrayRef) and isinstance(travelling.point_cloud.semantics, np.ndarray)  # small: inline
+    name = travelling._shm_segment
+    wire = pickle.dumps(travelling)
+    assert len(wire) < 4096
+    got = st.import_arrays(pickle.loads(wire))
+    np.testing.assert_array_equal(got.point_cloud.points, pts)
+    np.testing.assert_array_equal(got.point_cloud.colors, cols)
+    assert got.id == 5 and got.point_cloud.points.flags.writeable  # views of a private mapping of the (already unlinked) segment
+    with pytest.raises(FileNotFoundError):
+        shared_memory.SharedMemory(name=name)  # unlinked by the consumer
+    dropped = st.export_arrays(_shallow_output_copy(out))
+    name2 = dropped._shm_segment
+    st.drop_output(dropped)
+    with pytest.raises(FileNotFoundError):
+        shared_memory.SharedMemory(name=name2)
+
+
+def test_front_moves_keyframes_through_the_ring(small_params):
+    """End to end on the stand-in volume: every keyframe goes through a ring slot, all slots come back, the mesh arrives whole."""
+    s = SyntheticRGBD("tiny_160x120_2cm", noise=False)
+    cam = dh.FakeCamera(s)
+    integ = volumetric_integrator_factory(VolumetricIntegratorType.TSDF, cam, DatasetEnvironmentType.INDOOR, SensorType.RGBD,
+                                          volume_factory=dh.oracle_tsdf_factory)
+    try:
+        assert wait_until(integ.is_ready)
+        assert integ.frame_ring is not None and integ.frame_ring.held() == 0
+        kfs = [dh.FakeKeyFrame(i, s, cam) for i in range(6)]
+        for kf in kfs:
+            integ.add_keyframe(kf, kf.img, None, kf.depth_img)
+        outs = []
+        # (tasks are pushed to the FRONT of q_in and a backlog is fused by one sweep: which keyframe id an output carries depends
+        # on the interleaving; what is fixed is that every keyframe is consumed and every slot comes back)
+        assert wait_until(lambda: integ.q_in.qsize() == 0 and integ.frame_ring.held() == 0, 60.0)
+        assert wait_until(lambda: (outs.append(integ.pop_output(timeout=0.2)) or True) and any(o is not None for o in outs), 30.0)
+        time.sleep(0.5)
+        while (o := integ.pop_output(timeout=0.1)) is not None:
+            outs.append(o)
+        last = [o for o in outs if o is not None][-1]
+        assert {o.id for o in outs if o is not None} <= set(range(6))
+        assert isinstance(last.mesh.vertices, np.ndarray) and len(last.mesh.vertices) > 100 and last.mesh.triangles.max() < len(last.mesh.vertices)
+        # rebuild(): the drained tasks give their slots back too
+        integ.rebuild(dh.FakeMap(kfs))
+        assert wait_until(lambda: integ.frame_ring.held() == 0 and integ.q_in.qsize() == 0, 30.0)
+    finally:
+        integ.quit()

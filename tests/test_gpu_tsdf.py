@@ -327,6 +327,56 @@ def test_integrate_frames_host_staging_matches_device_batches(u16, monkeypatch):
     assert_same_volume(a, cpu, swept=True)
 
 
+def test_registered_host_frames_are_fused_in_place_and_bgr_order():
+    """The front's transport: keyframes lie in ONE page-locked host segment (hv_host_register - the shared-memory ring) in OpenCV's
+    B, G, R order; hv_tsdf_integrate_frames DMAs them in place (no staging copy) and the pack kernel swaps the channels
+    (hv_tsdf_set_color_order).  Must equal the pageable / R, G, B path bit for bit, for the multi-frame sweep and the online path."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+
+    s, frames = synthetic_frames("tiny_160x120_2cm", 0, 40)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    H, W = s.height, s.width
+    slot = (H * W * 7 + 255) // 256 * 256
+    ring = np.zeros(slot * len(frames) + 4096, np.uint8)
+    base = (-ring.ctypes.data) % 4096  # page-aligned start inside the allocation
+    a = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 13)
+    b = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 13)
+    a.set_color_order(bgr=True)
+    a.register_host_memory(ring.ctypes.data + base, slot * len(frames))
+    try:
+        depths, colors = [], []
+        for i, (d, c, T) in enumerate(frames):
+            at = base + i * slot
+            dv = ring[at:at + H * W * 4].view(np.float32).reshape(H, W)
+            cv = ring[at + H * W * 4:at + H * W * 7].reshape(H, W, 3)
+            dv[...] = d
+            cv[...] = c[..., ::-1]  # B, G, R
+            depths.append(dv)
+            colors.append(cv)
+        T = np.stack([f[2] for f in frames])
+        for lo, hi in ((0, 24), (24, 25), (25, 40)):
+            a.integrate_frames(depths[lo:hi], colors[lo:hi], K, T[lo:hi], depth_scale=1.0, depth_trunc=4.0)
+            # the call returned: the slots may be overwritten at once (what the front does when it releases them)
+            saved = [(depths[i].copy(), colors[i].copy()) for i in range(lo, hi)]
+            for i in range(lo, hi):
+                depths[i][...] = 0.0
+                colors[i][...] = 0
+            b.integrate_frames([x[0] for x in saved], [np.ascontiguousarray(x[1][..., ::-1]) for x in saved], K, T[lo:hi], depth_scale=1.0,
+                               depth_trunc=4.0)
+        for x, y in zip(a.dump(), b.dump()):
+            np.testing.assert_array_equal(x, y)
+        # online path, BGR order
+        d, c, Tcw = frames[3]
+        a.integrate(RGBDImage.create_from_color_and_depth(np.ascontiguousarray(c[..., ::-1]), d, depth_scale=1.0, depth_trunc=4.0,
+                                                          convert_rgb_to_intensity=False), K, Tcw)
+        b.integrate(RGBDImage.create_from_color_and_depth(c, d, depth_scale=1.0, depth_trunc=4.0, convert_rgb_to_intensity=False), K, Tcw)
+        for x, y in zip(a.dump(), b.dump()):
+            np.testing.assert_array_equal(x, y)
+    finally:
+        a.synchronize()
+        a.unregister_host_memory(ring.ctypes.data + base)
+
+
 def test_point_cloud_normals_match_oracle(tmp_path):
     """extract_point_cloud(normals=True): Open3D's GetNormalAt on the GPU vs the restatement (same double arithmetic on the same
     tsdf values: 1e-9), and the PLY the save path writes carries them (x y z nx ny nz r g b, Open3D's property order)."""

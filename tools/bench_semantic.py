@@ -90,28 +90,22 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
                "get_object_segments_ms": round(t_seg * 1e3, 2), "objects": len(segs.object_vector), "blocks": int(g.num_blocks()),
                "label_overflows": g.label_overflows()}
         if oracle.ref_available() and args.cpu_frames > 0:
-            from oracle.semantic import RefSemGrid2, ref_remap_instance_ids
+            # The compiled reference runs the same flow on the first cpu_frames + 1 keyframes of the stream - and is COMPARED with a fresh
+            # HIP grid fed the same keyframes (tests/semantic_helpers.py::compare_keyframe_flow: filtered depth, id maps, id images
+            # after every keyframe; block count, every occupied voxel, count distribution, segments at the end).  A mismatch raises:
+            # a semantic number is never printed for a configuration where the flow is not the reference's.
+            from tests.semantic_helpers import compare_keyframe_flow
 
-            r = RefSemGrid2(kind, args.voxel, 8)
-            r.set_next_object_id(1)
-            intr32 = np.array(intr, np.float32)
-
-            def run_ref(frames_):
-                for depth, rgb, T, cls_img, inst_img in frames_:
-                    d = hp.filter_shadow_points(depth)
-                    m = r.assign_object_ids_to_instance_ids(intr32, s.width, s.height, T, 8.0, 0.01, cls_img, inst_img, d, 0.03, False, 0.5, 3)
-                    obj = ref_remap_instance_ids(inst_img, m)
-                    pts, cols, cls, ob, depths = frame_points(d, rgb, T, cls_img, obj, intr, 4.0)
-                    r.integrate(pts.astype(np.float32), cols, cls, ob, depths)
-
-            run_ref(frames[:1])
-            t0 = time.perf_counter()
-            run_ref(frames[1:1 + args.cpu_frames])
-            dt = time.perf_counter() - t0
+            par = compare_keyframe_flow(kind, config, args.voxel, [stride * i for i in range(args.cpu_frames + 1)], max_blocks=1 << 17,
+                                        max_points=max(1 << 20, s.width * s.height), depth_threshold=0.03, frustum_depth=(8.0, 0.01))
+            dt = sum(par["ref_seconds"][1:])
             res["cpu_reference"] = {"value": round(args.cpu_frames / dt, 3), "unit": "keyframes/s", "cores": 1, "kind": "reference",
                                     "sample": f"{args.cpu_frames} keyframes, same flow: numpy shadow filter / depth2pointcloud + compiled "
                                               f"cpp/volumetric (sequential non-TBB branch)"}
             res["speedup_vs_cpu_reference"] = round(fps / res["cpu_reference"]["value"], 1)
+            res["parity"] = {"checked": True, "against": "compiled reference (oracle/_ref), same keyframes", "keyframes": par["keyframes"],
+                             "blocks": par["blocks"], "occupied_voxels": par["occupied_voxels"], "objects": par["objects"],
+                             "conf_max_abs_diff": par["conf_max_abs_diff"], "label_overflows": par["label_overflows"]}
         out[name] = res
         del g
     return out
