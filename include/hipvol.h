@@ -273,6 +273,15 @@ int hv_tsdf_integrate_frames(hv_volume *v, const void *const *depth_frames, int3
                              int32_t n_frames, int32_t height, int32_t width, const double *intr, const double *T_cw,
                              double depth_scale, double depth_trunc);
 
+/* How hv_tsdf_set_owner's N GPUs divide the units of a multi-frame call: 0 = owner(unit) = hash(unit index) % N (static; the GPUs'
+ * unit sets are disjoint for ever, zero merge), 1 = IMAGE-COHERENT: every hv_tsdf_integrate_batch / _frames call plans its
+ * batch on the device - equal work per GPU, a GPU's units contiguous in the image (vertical strips of the batch's middle
+ * frame) - so that a GPU touches, packs and gathers only its own part of every frame; all GPUs derive the same plan from the
+ * same frames without communication.  Ownership then moves with the camera: a unit's additive numerators may live on several
+ * GPUs and are consolidated by hv_merge_halo_* / hv_tsdf_export_numerators like the tile form's.  Single frames
+ * (hv_tsdf_integrate) use the hash in both modes. */
+int hv_tsdf_set_sharding(hv_volume *v, int32_t mode);
+
 /* Channel order of the colour frames handed to hv_tsdf_integrate*: 0 = R, G, B (Open3D's RGBDImage, the default), 1 = B, G, R -
  * pySLAM's keyframe.img as OpenCV loads it; the reference converts every keyframe on the host with cv2.cvtColor
  * (volumetric_integrator_base.py:1054), here the pack kernel swaps the bytes of the record it writes anyway. */

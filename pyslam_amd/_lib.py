@@ -95,6 +95,7 @@ SIGNATURES = {
     "hv_tsdf_integrate_batch": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_tsdf_integrate_frames": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64]),
     "hv_tsdf_set_color_order": (_i32, [_vp, _i32]),
+    "hv_tsdf_set_sharding": (_i32, [_vp, _i32]),
     "hv_host_register": (_i32, [_vp, _i64]),
     "hv_host_unregister": (_i32, [_vp]),
     "hv_tsdf_set_tile": (_i32, [_vp, _i32, _i32, _i32, _i32]),

@@ -297,6 +297,10 @@ struct hv_volume {
     int params_idx = 0;
     int32_t tile[4] = {0, 0, 0, 0}; // u0, v0, u1, v1; all zero = whole image
     int32_t owner_rank = 0, owner_world = 1; // hv_tsdf_set_owner
+    int32_t shard_coherent = 0;              // hv_tsdf_set_sharding: 1 = ownership planned per batch in the image of its middle frame
+    void *plan_buf = nullptr;                // [2 sets] batch table + histogram + per-frame pixel boxes (k_tsdf_touch_plan ...)
+    size_t plan_buf_bytes = 0, plan_cap = 0;
+    bool plan_lists_stale = false;           // coherent batches left their list sizes in the TOUCH counters
     float sem_depth_threshold = 10.0f;       // VoxelSemanticDataT::kDepthThreshold (hv_set_depth_threshold)
     float sem_depth_decay_rate = 0.07f;      // VoxelSemanticDataProbabilisticT::kDepthDecayRate (hv_set_depth_decay_rate)
     void *assoc_buf = nullptr;               // association vote table + pending list (hv_semantic_ops.hip)

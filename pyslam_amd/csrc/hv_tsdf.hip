@@ -34,6 +34,8 @@ static constexpr int RR = R * R;
 static constexpr int RRR = R * R * R;
 static constexpr int PLANE_BYTES = RRR * 4;
 static constexpr int HV_TOUCH_FAN = 8; // lanes per depth sample in the online touch pass
+// image-coherent ownership plan (k_tsdf_touch_plan ...): bins of the middle frame's image, column-major
+static constexpr int HV_PLAN_NU = 64, HV_PLAN_NV = 16, HV_PLAN_BINS = HV_PLAN_NU * HV_PLAN_NV;
 static constexpr uint32_t HV_REC_ONE = 1u << 24; // observation count byte of a batch frame record's colour word
 
 // packed colour word {byte0 = R, byte1 = G, byte2 = B}: a B, G, R source swaps bytes 0 and 2 (one v_perm_b32)
@@ -788,7 +790,15 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
                                                                 uint2 *__restrict__ frame_px,
                                                                 const HvFrameParams *__restrict__ Ps, int n_prep_blocks,
                                                                 int n_touch_blocks, int n_frames, int parity,
-                                                                const float *__restrict__ mult12) {
+                                                                const float *__restrict__ mult12,
+                                                                const int4 *__restrict__ pack_box, uint32_t *__restrict__ plan_hist,
+                                                                HvStatus *status, int32_t status_seq) {
+    if (plan_hist != nullptr && blockIdx.x == 0) {
+        // image-coherent ownership: this is the last launch of the batch's plan chain - k_tsdf_plan_assign has read the histogram
+        // (clean it for this scratch set's next batch) and made its claims (publish the pool's occupancy: hv_capacity_gate)
+        for (int i = threadIdx.x; i < HV_PLAN_BINS; i += blockDim.x) plan_hist[i] = 0u;
+        if (threadIdx.x == 0) hv_publish_status(table, status, status_seq);
+    }
     // block order: the touch blocks of ALL frames first, then the pack blocks.  A touch wave is one chain of dependent
     // memory round trips (depth -> hash probe -> mask / stamp -> atomics; a patch on a long depth discontinuity walks
     // several such chains), the pack blocks are pure streaming: dispatched last they fill the machine while the touch
@@ -812,6 +822,13 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
         // record stores; every wave access is a contiguous burst (prep blocks cover 1024 pixels each)
         const int64_t i0 = ((int64_t)bx * blockDim.x + threadIdx.x) * 4;
         if (i0 >= npx) return;
+        if (pack_box != nullptr && (P.W & 3) == 0) {
+            // image-coherent ownership (k_tsdf_plan_assign): this GPU's units project into pack_box[f] = {u0, v0, u1, v1} of frame
+            // f and nowhere else, so only those pixels' records are ever gathered (the box is conservative and already padded)
+            const int4 bb = pack_box[f];
+            const int u = (int)(i0 % P.W), v = (int)(i0 / P.W);
+            if (u + 3 < bb.x || u >= bb.z || v < bb.y || v >= bb.w) return;
+        }
         if (P.tiled && (P.W & 3) == 0) {
             // tile-sharded volume: only voxels that project into this GPU's tile gather a record (the sweep's image-range test
             // uses the tile's bounds), so only the tile's columns and rows are packed (+ 4 pixels: a garbage lane may read
@@ -919,6 +936,212 @@ __global__ __launch_bounds__(256) void k_tsdf_batch_list(HvTable table, const in
     }
     const int32_t at = hv_wave_append(&table.counters[HV_CNT_TOUCH0], slot >= 0);
     if (slot >= 0) list[at] = slot;
+}
+
+// ================================================================================================
+// Image-coherent unit ownership for N GPUs, decided once per batch with NO communication (hv_tsdf_set_sharding(COHERENT)).
+//
+// Under hash ownership (hv_owner_of) a GPU's units are scattered over the image: every GPU packs every pixel of every frame
+// (187 MB per 32-frame batch at 640x480) and gathers from all of them, so the per-batch replicated work does not shrink with
+// N and bounds the scaling curve (profiles/r03/rank8_timeline.txt).  Here every GPU - they all see every frame - first
+// enumerates the batch's units into a small replicated BATCH TABLE (key -> 64-bit frame mask; no pool claims), then all of
+// them evaluate the same deterministic plan on it:
+//   work(unit) = popcount(frame mask)            (voxel visits ~ frames that see the unit)
+//   bin(unit)  = cell of a PLAN_NU x PLAN_NV grid over the image of the batch's MIDDLE frame that the unit's centre projects
+//                into, numbered column-major (units not in front of that camera: a hash of the key)
+//   owner(bin) = rank whose share [r, r + 1) * total / N of the prefix sum of work over the bins holds the bin's midpoint
+// -> vertical strips of the reference image with ragged edges, equal WORK per GPU, and each GPU's units stay together in
+// every frame of the batch.  A GPU then claims only its own units in its hash (frame masks, union list: what the sweep reads),
+// accumulates the pixel box its units can project into per frame, and packs the records of THOSE pixels only.
+// A (unit, frame) pair is fused by exactly one GPU; ownership moves with the camera from batch to batch, so a unit's additive
+// numerators may live on several GPUs - exactly the state hv_merge_halo_* / gather_to_root() already consolidate (tile form).
+// Integer atomics only: every GPU computes bit-identical histograms, hence identical plans.
+// ================================================================================================
+
+struct HvPlan { // one per scratch set
+    unsigned long long *bt_keys;  // [cap] batch table: packed unit key or HV_EMPTY_KEY (self-cleaning: k_tsdf_plan_assign empties it)
+    unsigned long long *bt_masks; // [cap] frames of the batch that touch the unit
+    uint32_t *hist;               // [HV_PLAN_BINS] work per bin
+    int4 *box;                    // [64] per frame {u0, v0, u1, v1}: pixels this GPU's units can project into
+    uint32_t cap_mask;            // cap - 1
+};
+
+__device__ __forceinline__ int hv_plan_bin(unsigned long long key, const HvFrameParams &Pm) {
+    int32_t ux, uy, uz;
+    hv_unpack_key(key, ux, uy, uz);
+    const float h = 0.5f * (float)Pm.unit_length;
+    const float p0 = (float)((double)ux * Pm.unit_length) + h, p1 = (float)((double)uy * Pm.unit_length) + h,
+                p2 = (float)((double)uz * Pm.unit_length) + h;
+    const float pc0 = ((Pm.ext[0] * p0 + Pm.ext[1] * p1) + Pm.ext[2] * p2) + Pm.ext[3];
+    const float pc1 = ((Pm.ext[4] * p0 + Pm.ext[5] * p1) + Pm.ext[6] * p2) + Pm.ext[7];
+    const float pc2 = ((Pm.ext[8] * p0 + Pm.ext[9] * p1) + Pm.ext[10] * p2) + Pm.ext[11];
+    if (!(pc2 > 0.1f)) return (int)(hv_slot_hash(key ^ 0x5bd1e995ull) % (uint32_t)HV_PLAN_BINS);
+    const float u = pc0 * Pm.fx / pc2 + Pm.cx, v = pc1 * Pm.fy / pc2 + Pm.cy;
+    int ub = (int)floorf(u * ((float)HV_PLAN_NU / (float)Pm.W)), vb = (int)floorf(v * ((float)HV_PLAN_NV / (float)Pm.H));
+    ub = min(max(ub, 0), HV_PLAN_NU - 1);
+    vb = min(max(vb, 0), HV_PLAN_NV - 1);
+    return ub * HV_PLAN_NV + vb;
+}
+
+// Touch role of ALL frames into the batch table (no ownership test: the frame constants carry owner_world = 1, no pool claim).
+// The frame bit an atomicOr newly sets is a new (unit, frame) pair - the plan's measure of work; it is counted in the
+// workgroup's LDS histogram, flushed once per workgroup.  (Measured alone on the GPU, 32 frames of 640x480: patch enumeration
+// without any global access 33 us, with the batch table 46 us; the same pairs counted with global atomics on the 1024 bins:
+// 116 us; a wave taking its patch through 2 / 4 / 8 consecutive frames and merging them in an LDS table first: 68 / 93 / 180 us -
+// the launch is bound by the patch arithmetic and its occupancy, not by the table's atomics.)
+__global__ __launch_bounds__(256) void k_tsdf_touch_plan(HvTable table, HvPlan plan, const char *__restrict__ depth_raw,
+                                                          int64_t depth_stride, const HvFrameParams *__restrict__ Ps,
+                                                          int n_touch_blocks, int n_frames, int parity) {
+    __shared__ HvTouchScratch scratch[4];
+    __shared__ uint32_t s_hist[HV_PLAN_BINS];
+    const int wave = (int)(threadIdx.x / HV_WAVE);
+    for (int i = threadIdx.x; i < HV_PLAN_BINS; i += blockDim.x) s_hist[i] = 0u;
+    if (blockIdx.x == 0) {
+        // this scratch set's last batch is swept (the chain waited for it): its union list restarts, its boxes start empty
+        if (threadIdx.x < 64) plan.box[threadIdx.x] = make_int4(INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN);
+        if (threadIdx.x == 0) table.counters[HV_CNT_TOUCH0 + parity] = 0;
+    }
+    __syncthreads();
+    const int f = (int)blockIdx.x / n_touch_blocks, bx = (int)blockIdx.x % n_touch_blocks;
+    const int patch = bx * 4 + wave;
+    const HvFrameParams &Pm = Ps[n_frames / 2];
+    if (patch < hv_touch_patches(Ps[f])) {
+        const unsigned long long fbit = 1ull << f;
+        hv_touch_patch(table, Ps[f], depth_raw + (int64_t)f * depth_stride, patch, scratch[wave],
+                       [&](unsigned long long key, int32_t, int32_t, int32_t) {
+                           uint32_t s = hv_slot_hash(key) & plan.cap_mask;
+                           for (uint32_t probe = 0; probe <= plan.cap_mask; ++probe) {
+                               unsigned long long k = __hip_atomic_load(&plan.bt_keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                               if (k == HV_EMPTY_KEY) {
+                                   k = atomicCAS(&plan.bt_keys[s], HV_EMPTY_KEY, key);
+                                   if (k == HV_EMPTY_KEY) k = key;
+                               }
+                               if (k == key) {
+                                   const unsigned long long seen = __hip_atomic_load(&plan.bt_masks[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                   if (!(seen & fbit) && !(atomicOr(&plan.bt_masks[s], fbit) & fbit)) atomicAdd(&s_hist[hv_plan_bin(key, Pm)], 1u);
+                                   return;
+                               }
+                               s = (s + 1) & plan.cap_mask;
+                           }
+                           atomicAdd(&table.counters[HV_CNT_OVERFLOW], 1);
+                       });
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HV_PLAN_BINS; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&plan.hist[i], s_hist[i]);
+}
+
+// Every workgroup derives the bin -> owner table from the histogram (1024 bins: an LDS scan), then handles its slots of the
+// batch table: empties them, and for the units this GPU owns claims the unit in the volume's hash, publishes its frame mask,
+// stamps it, appends it to the union list - and adds the pixels the unit can project into to the box of every frame that
+// touches it (the workgroup's owned units are few: a wave takes one of them at a time, lane = frame).
+__global__ __launch_bounds__(256) void k_tsdf_plan_assign(HvTable table, HvPlan plan, int32_t *__restrict__ stamp,
+                                                           unsigned long long *__restrict__ frame_mask, int32_t *__restrict__ list,
+                                                           int batch_stamp, const HvFrameParams *__restrict__ Ps, int n_frames,
+                                                           int parity, int rank, int world) {
+    __shared__ uint32_t s_owner[HV_PLAN_BINS];
+    __shared__ uint32_t s_part[256];
+    __shared__ int s_box[64][4];
+    __shared__ unsigned long long s_mine_key[256], s_mine_mask[256];
+    __shared__ int s_n_mine;
+    static_assert(HV_PLAN_BINS == 4 * 256, "four bins per thread");
+    const int tid = threadIdx.x;
+    // this workgroup's slots first: most workgroups find nothing in theirs and leave before the scan
+    const uint32_t s = blockIdx.x * blockDim.x + tid;
+    unsigned long long key = HV_EMPTY_KEY, mask = 0ull;
+    if (s <= plan.cap_mask) {
+        key = plan.bt_keys[s];
+        if (key != HV_EMPTY_KEY) {
+            mask = plan.bt_masks[s];
+            plan.bt_keys[s] = HV_EMPTY_KEY; // the table is empty again when this launch ends
+            plan.bt_masks[s] = 0ull;
+        }
+    }
+    if (!__syncthreads_or(key != HV_EMPTY_KEY)) return;
+    uint32_t w[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        w[k] = plan.hist[tid * 4 + k];
+        sum += w[k];
+    }
+    s_part[tid] = sum;
+    if (tid < 64) {
+        s_box[tid][0] = INT32_MAX; s_box[tid][1] = INT32_MAX; s_box[tid][2] = INT32_MIN; s_box[tid][3] = INT32_MIN;
+    }
+    if (tid == 0) s_n_mine = 0;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) { // inclusive scan of the per-thread sums
+        const uint32_t add = tid >= o ? s_part[tid - o] : 0u;
+        __syncthreads();
+        s_part[tid] += add;
+        __syncthreads();
+    }
+    const uint32_t total = s_part[255];
+    uint32_t run = s_part[tid] - sum; // exclusive
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // owner of the bin: where the midpoint of its work interval falls (2 * midpoint against 2 * total * r / world, in 64 bits)
+        const unsigned long long mid2 = 2ull * run + w[k];
+        const uint32_t owner = total == 0u ? 0u : (uint32_t)min((unsigned long long)(world - 1), mid2 * (unsigned long long)world / (2ull * total));
+        s_owner[tid * 4 + k] = owner;
+        run += w[k];
+    }
+    __syncthreads();
+    const bool mine = key != HV_EMPTY_KEY && mask != 0ull && (int)s_owner[hv_plan_bin(key, Ps[n_frames / 2])] == rank;
+    int32_t slot = -1;
+    if (mine) {
+        slot = hv_table_insert(table, key);
+        if (slot >= 0) {
+            frame_mask[slot] = mask; // (plain store: the sweep only reads the masks of the units its list names)
+            stamp[slot] = batch_stamp;
+            const int at = atomicAdd(&s_n_mine, 1);
+            s_mine_key[at] = key;
+            s_mine_mask[at] = mask;
+        }
+    }
+    const int32_t at = hv_wave_append(&table.counters[HV_CNT_TOUCH0 + parity], slot >= 0);
+    if (slot >= 0 && at < table.max_blocks) list[at] = slot;
+    __syncthreads();
+    const int n_mine = s_n_mine, wave = tid / HV_WAVE, f = hv_lane_id();
+    for (int m = wave; m < n_mine; m += 4) {
+        if (f >= n_frames || !((s_mine_mask[m] >> f) & 1ull)) continue;
+        const HvFrameParams &P = Ps[f];
+        int32_t ux, uy, uz;
+        hv_unpack_key(s_mine_key[m], ux, uy, uz);
+        const float L = (float)P.unit_length;
+        const float o0 = (float)((double)ux * P.unit_length), o1 = (float)((double)uy * P.unit_length), o2 = (float)((double)uz * P.unit_length);
+        float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+        bool behind = false;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float p0 = o0 + ((c & 1) ? L : 0.f), p1 = o1 + ((c & 2) ? L : 0.f), p2 = o2 + ((c & 4) ? L : 0.f);
+            const float pc0 = ((P.ext[0] * p0 + P.ext[1] * p1) + P.ext[2] * p2) + P.ext[3];
+            const float pc1 = ((P.ext[4] * p0 + P.ext[5] * p1) + P.ext[6] * p2) + P.ext[7];
+            const float pc2 = ((P.ext[8] * p0 + P.ext[9] * p1) + P.ext[10] * p2) + P.ext[11];
+            if (!(pc2 > 0.02f)) behind = true;
+            const float u = pc0 * P.fx / pc2 + P.cx, v = pc1 * P.fy / pc2 + P.cy;
+            umin = fminf(umin, u); umax = fmaxf(umax, u);
+            vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+        }
+        int b0 = 0, b1 = 0, b2 = P.W, b3 = P.H; // a unit that reaches behind the camera plane may project anywhere
+        if (!behind) {
+            // voxel centres lie inside the unit's box, their projections inside the box of the corner projections; +/- 3 pixels
+            // cover the float rounding of either side and the + 0.5 of the reference's pixel choice
+            b0 = (int)fmaxf(fminf(floorf(umin) - 3.f, (float)P.W), 0.f);
+            b1 = (int)fmaxf(fminf(floorf(vmin) - 3.f, (float)P.H), 0.f);
+            b2 = (int)fmaxf(fminf(ceilf(umax) + 4.f, (float)P.W), 0.f);
+            b3 = (int)fmaxf(fminf(ceilf(vmax) + 4.f, (float)P.H), 0.f);
+        }
+        if (b2 > b0 && b3 > b1) {
+            atomicMin(&s_box[f][0], b0); atomicMin(&s_box[f][1], b1);
+            atomicMax(&s_box[f][2], b2); atomicMax(&s_box[f][3], b3);
+        }
+    }
+    __syncthreads();
+    if (tid < 64 && s_box[tid][2] > s_box[tid][0]) {
+        atomicMin(&plan.box[tid].x, s_box[tid][0]); atomicMin(&plan.box[tid].y, s_box[tid][1]);
+        atomicMax(&plan.box[tid].z, s_box[tid][2]); atomicMax(&plan.box[tid].w, s_box[tid][3]);
+    }
 }
 
 // Column mapping: lane -> one (x, y) column of the unit, wave -> 64 consecutive columns (4 x-values: word index
@@ -1665,12 +1888,17 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep_fold
 // instruction less per visit, 564-568 us: the extra live register costs more), 16-byte records with the colour fields
 // spread 16 bits apart so that the accumulators add the words unmasked (two instructions less, 590-599 us: four registers
 // per gather in flight, 104 B of scratch).  At 128 registers the form is bound by what it keeps live, not by its count.
-template <int SPLIT, int GV, int PIPE, int ANYSKIP>
+template <int SPLIT, int GV, int PIPE, int ANYSKIP, int ZS = 1>
 __device__ __forceinline__ void hv_sweep_column_body(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
     char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
     int general, const float *__restrict__ mult, int xcd_aware, int parity) {
-    constexpr int ZH = 16;
+    // ZS = 2: a column is split into two z halves = 8 wave tasks per unit (a GPU that owns few units - multi-GPU sharding - has
+    // ~3 000 column tasks of very different lengths for 4 096 wave slots: nothing evens them out; twice as many, half as long
+    // tasks do).  The upper half replays the reference's 8 repeated float additions along z per frame.
+    static_assert(ZS == 1 || (ZS == 2 && SPLIT == 4), "z halves need one-wave workgroups");
+    constexpr int ZH = 16 / ZS;
+    constexpr int PARTS = SPLIT * ZS; // work items per unit
     constexpr int NG = ZH / GV;
     constexpr int WAVES = 4 / SPLIT; // waves per workgroup
     typedef uint32_t hv_u3 __attribute__((ext_vector_type(3)));
@@ -1692,19 +1920,21 @@ __device__ __forceinline__ void hv_sweep_column_body(
     const float near_z = fmaxf(0.03f, 1.25f * P0.sdf_trunc_f);
     const int G = xcd_aware > 0 ? xcd_aware : 1;
     const int rounds = (n_units + 8 * G - 1) / (8 * G);
-    const int n_items = xcd_aware > 0 ? rounds * 8 * G * SPLIT : n_units * SPLIT;
+    const int n_items = xcd_aware > 0 ? rounds * 8 * G * PARTS : n_units * PARTS;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         int t, part;
         if (xcd_aware > 0) {
             const int xcd = item & 7, j = item >> 3;
-            const int g = j / (G * SPLIT), within = j - g * (G * SPLIT);
-            t = (g * 8 + xcd) * G + within / SPLIT;
-            part = within % SPLIT;
+            const int g = j / (G * PARTS), within = j - g * (G * PARTS);
+            t = (g * 8 + xcd) * G + within / PARTS;
+            part = within % PARTS;
             if (t >= n_units) continue;
         } else {
-            t = item / SPLIT;
-            part = item % SPLIT;
+            t = item / PARTS;
+            part = item % PARTS;
         }
+        const int z0 = ZS == 1 ? 0 : (part >> 2) * ZH; // first z of this task
+        if (ZS == 2) part &= 3;
         const int cg = part * WAVES + wave; // column group: x in [4 cg, 4 cg + 4)
         const int x = cg * 4 + (lane >> 4);
         const int y = lane & 15;
@@ -1726,7 +1956,7 @@ __device__ __forceinline__ void hv_sweep_column_body(
         }
         const bool near_any = __any(near);
         char *unit = pool + (int64_t)idx * (PLANE_BYTES * HV_TSDF_PLANES);
-        const int wordb = cg * 64 + lane;
+        const int wordb = z0 * RR + cg * 64 + lane;
         const float p0 = (float)((double)(hl + vl * (float)x) + o0);
         const float p1 = (float)((double)(hl + vl * (float)y) + o1);
         const float p2 = (float)((double)hl + o2);
@@ -1752,7 +1982,7 @@ __device__ __forceinline__ void hv_sweep_column_body(
                     float pc1 = ((P.ext[4] * p0 + P.ext[5] * p1) + P.ext[6] * p2) + P.ext[7];
                     float pc2 = ((P.ext[8] * p0 + P.ext[9] * p1) + P.ext[10] * p2) + P.ext[11];
 #pragma unroll 1
-                    for (int s = 0; s < zz; ++s) { // the reference's repeated float additions along z, replayed
+                    for (int s = 0; s < z0 + zz; ++s) { // the reference's repeated float additions along z, replayed
                         pc0 += inc0;
                         pc1 += inc1;
                         pc2 += inc2;
@@ -1798,6 +2028,13 @@ __device__ __forceinline__ void hv_sweep_column_body(
             XY = ((K.e04 * p0 + K.e15 * p1) + K.e26 * p2) + K.e37;
             const hv_f2 Z12 = K.e9_10 * hv_f2{p1, p2};
             Z = ((K.e8 * p0 + Z12.x) + Z12.y) + K.e11;
+            if (ZS == 2 && z0 != 0) { // (wave-uniform) the reference's repeated additions up to this task's first voxel
+#pragma unroll
+                for (int sidx = 0; sidx < ZH; ++sidx) {
+                    XY += INC;
+                    Z += inc2;
+                }
+            }
             // K is consumed: only now issue the scalar loads of the next frame's constants (scalar loads return out of order, a
             // wait is always "for all"), so that their latency hides behind this frame's arithmetic
             __builtin_amdgcn_sched_barrier(0);
@@ -1969,12 +2206,12 @@ __device__ __forceinline__ void hv_sweep_column_body(
 // sweep waves then leave 32 / 64 registers of every SIMD free, enough for waves of the NEXT batch's touch + pack launch
 // (56 VGPRs) to be resident beside them - without that, the second queue only gets a wave slot when a sweep wave retires
 // (profiles/r02/pipeline_timeline.txt), which is what an 8-rank share cannot afford.
-template <int SPLIT, int WPE, int GV, int PIPE, int ANYSKIP>
+template <int SPLIT, int WPE, int GV, int PIPE, int ANYSKIP, int ZS = 1>
 __global__ __launch_bounds__(64 * 4 / SPLIT, WPE) void k_tsdf_sweep_column(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
     char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
     int general, const float *__restrict__ mult, int xcd_aware, int parity) {
-    hv_sweep_column_body<SPLIT, GV, PIPE, ANYSKIP>(table, list, frame_mask, pool, frame_px, Ps, n_frames, general, mult, xcd_aware, parity);
+    hv_sweep_column_body<SPLIT, GV, PIPE, ANYSKIP, ZS>(table, list, frame_mask, pool, frame_px, Ps, n_frames, general, mult, xcd_aware, parity);
 }
 #define HV_SWEEP_COLUMN_CAPPED(NAME, HALF_VGPRS)                                                                        \
     template <int SPLIT, int GV, int PIPE, int ANYSKIP>                                                                 \
@@ -2259,6 +2496,12 @@ static int tsdf_launch_integrate(hv_volume *v, const HvFrameParams &P, int parit
 }
 
 static void tsdf_next_frame(hv_volume *v, HvFrameParams &P, int &parity) {
+    if (v->plan_lists_stale) {
+        // coherent batches ran before this frame: their plans leave the list counters behind (the main stream has waited for every
+        // one of those chains, so this memset is ordered after them)
+        (void)hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream);
+        v->plan_lists_stale = false;
+    }
     v->content_version += 1;
     v->frame_counter += 1;
     P.frame_id = v->frame_counter;
@@ -2372,6 +2615,21 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
     // the previous batch (content_version), host-resident frames, the checked capacity mode or HV_TSDF_PIPELINE=0 runs
     // everything on the main stream as before.
     const bool pipeline_on = !(getenv("HV_TSDF_PIPELINE") && atoi(getenv("HV_TSDF_PIPELINE")) == 0);
+    // image-coherent ownership (hv_tsdf_set_sharding): the batch is planned on the device, see k_tsdf_touch_plan
+    const bool coherent = v->owner_world > 1 && v->shard_coherent != 0;
+    if (coherent) {
+        const size_t cap = (size_t)v->table_capacity;
+        const size_t set_bytes = cap * 16 + sizeof(uint32_t) * HV_PLAN_BINS + sizeof(int4) * 64;
+        if (v->plan_buf == nullptr || v->plan_cap != cap) {
+            rc = hv_ensure_buffer(v, &v->plan_buf, &v->plan_buf_bytes, 2 * set_bytes + 512);
+            if (rc != HV_OK) return rc;
+            if (v->stream_aux) HV_HIP(hipStreamSynchronize(v->stream_aux));
+            HV_HIP(hipMemsetAsync(v->plan_buf, 0, v->plan_buf_bytes, v->stream));
+            for (int k = 0; k < 2; ++k) HV_HIP(hipMemsetAsync((char *)v->plan_buf + k * set_bytes, 0xFF, cap * 8, v->stream));
+            HV_HIP(hipStreamSynchronize(v->stream));
+            v->plan_cap = cap;
+        }
+    }
     // sweep form: 4 = k_tsdf_sweep_column (production: the batch folded per voxel, a lane walks a whole voxel column), 3 =
     // k_tsdf_sweep_fold (the fold on 4 voxels per lane), 2 = k_tsdf_sweep (the reference's running mean frame by frame: tsdf
     // bit-identical to it), 1 = first form (A/B, and the only one that runs without the multiplier table).
@@ -2430,6 +2688,7 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
                               &params[f]);
             v->frame_counter += 1;
             params[f].frame_id = v->frame_counter;
+            if (coherent) params[f].owner_world = 1; // the touch enumerates every unit of the batch; k_tsdf_plan_assign decides whose it is
         }
         int batch_stamp = v->frame_counter;
         v->last_touch_parity = parity;
@@ -2473,13 +2732,39 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
         const int n_prep_blocks = (int)((npx + 1023) / 1024); // 4 pixels per thread
         const int n_touch_blocks = (hv_touch_patches(width, height, v->cfg.depth_sampling_stride) + 3) / 4;
         for (int attempt = 0;; ++attempt) {
-            if (!v->touch_counters_clean) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream)); // (never while a chain runs: only an online frame or an aborted claim leaves them dirty)
-            v->touch_counters_clean = true;
+            // (coherent form: the plan restarts its own set's list - k_tsdf_touch_plan - and a memset here, on the main stream, could land
+            // on a list the aux stream is already filling)
+            if (!coherent) {
+                if (!v->touch_counters_clean) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream)); // (never while a chain runs: only an online frame or an aborted claim leaves them dirty)
+                v->touch_counters_clean = true;
+            }
+            if (coherent) {
+                const size_t cap = (size_t)v->table_capacity;
+                const size_t set_bytes = cap * 16 + sizeof(uint32_t) * HV_PLAN_BINS + sizeof(int4) * 64;
+                char *base = (char *)v->plan_buf + (size_t)parity * set_bytes;
+                HvPlan plan;
+                plan.bt_keys = (unsigned long long *)base;
+                plan.bt_masks = (unsigned long long *)(base + cap * 8);
+                plan.hist = (uint32_t *)(base + cap * 16);
+                plan.box = (int4 *)(base + cap * 16 + sizeof(uint32_t) * HV_PLAN_BINS);
+                plan.cap_mask = (uint32_t)(cap - 1);
+                const char *dd = (const char *)d_depth + npx * dsz * (size_t)f0;
+                const unsigned slots_grid = (unsigned)((cap + 255) / 256);
+                hipLaunchKernelGGL(k_tsdf_touch_plan, dim3(n_touch_blocks * B), dim3(256), 0, ps, v->table, plan, dd, (int64_t)(npx * dsz), d_params,
+                                   n_touch_blocks, B, parity);
+                hipLaunchKernelGGL(k_tsdf_plan_assign, dim3(slots_grid), dim3(256), 0, ps, v->table, plan, v->touched_stamp, d_mask_rw, d_list,
+                                   batch_stamp, d_params, B, parity, v->owner_rank, v->owner_world);
+                const bool pack_all = getenv("HV_TSDF_PLAN_PACK_ALL") && atoi(getenv("HV_TSDF_PLAN_PACK_ALL")) != 0; // A/B
+                hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3(n_prep_blocks * B), dim3(256), 0, ps, v->table, v->touched_stamp, d_mask_rw,
+                                   d_list, batch_stamp, dd, (int64_t)(npx * dsz), (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params,
+                                   n_prep_blocks, 0, B, parity, rec12 ? d_mult : nullptr, pack_all ? nullptr : (const int4 *)plan.box, plan.hist,
+                                   v->d_status, hv_next_status_seq(v));
+            } else
             hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3((n_prep_blocks + n_touch_blocks) * B), dim3(256), 0, ps,
                                v->table, v->touched_stamp, d_mask_rw, list_in_touch ? d_list : nullptr,
                                batch_stamp, (const char *)d_depth + npx * dsz * (size_t)f0, (int64_t)(npx * dsz),
                                (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks, n_touch_blocks, B, parity,
-                               rec12 ? d_mult : nullptr);
+                               rec12 ? d_mult : nullptr, nullptr, nullptr, nullptr, 0);
             if (!checked) break;
             // checked mode: nothing is fused before every unit of the batch has its pool slot; if some claims did not fit, the
             // pool has grown (table rebuilt without them, stamps kept) and the touch pass runs again under a fresh stamp
@@ -2538,6 +2823,7 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
             const int pipe = getenv("HV_TSDF_SWEEP_PIPE") ? atoi(getenv("HV_TSDF_SWEEP_PIPE")) : 1;
             const int csplit = getenv("HV_TSDF_BATCH_SPLIT") ? atoi(getenv("HV_TSDF_BATCH_SPLIT")) : 4;
             const int vcap = getenv("HV_TSDF_SWEEP_VCAP") ? atoi(getenv("HV_TSDF_SWEEP_VCAP")) : 0;
+            const int zs = getenv("HV_TSDF_SWEEP_ZS") ? atoi(getenv("HV_TSDF_SWEEP_ZS")) : (v->owner_world >= 4 ? 2 : 1);
 #define HV_LAUNCH_COLUMN_CAPPED(NAME, S, GV, PIPE)                                                                      \
     hipLaunchKernelGGL((NAME<S, GV, PIPE, true>), dim3(sweep_grid), dim3(64 * 4 / S), 0, v->stream, v->table, d_list, d_mask, \
                        (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware, parity)
@@ -2550,6 +2836,14 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
                 if (pipe == 2) HV_LAUNCH_COLUMN(2, 4, 4, 2, true); else HV_LAUNCH_COLUMN(2, 4, 4, 1, true);
             } else if (!anyskip) {
                 HV_LAUNCH_COLUMN(4, 4, 4, 1, false);
+            } else if (zs == 2) {
+                // z halves: 8 tasks per unit (default for a GPU that shares the volume with 3 or more others)
+                if (wpe >= 6) hipLaunchKernelGGL((k_tsdf_sweep_column<4, 6, 4, 1, 2, 2>), dim3(sweep_grid), dim3(64), 0, v->stream, v->table, d_list, d_mask,
+                                                 (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware, parity);
+                else if (wpe == 5) hipLaunchKernelGGL((k_tsdf_sweep_column<4, 5, 4, 1, 2, 2>), dim3(sweep_grid), dim3(64), 0, v->stream, v->table, d_list, d_mask,
+                                                      (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware, parity);
+                else hipLaunchKernelGGL((k_tsdf_sweep_column<4, 4, 4, 1, 2, 2>), dim3(sweep_grid), dim3(64), 0, v->stream, v->table, d_list, d_mask,
+                                        (char *)v->pool, d_px, d_params, B, general, d_mult, xcd_aware, parity);
             } else if (anyskip == 2 && gv == 4 && pipe == 1 && wpe == 4) {
                 HV_LAUNCH_COLUMN(4, 4, 4, 1, 2);
             } else if (gv == 8) {
@@ -2615,8 +2909,13 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
 #undef HV_LAUNCH_COLUMN
 #undef HV_LAUNCH_COLUMN_CAPPED
         hv_profile_end(v, B);
-        hipLaunchKernelGGL(k_tsdf_batch_finish, dim3(1), dim3(1024), 0, v->stream, v->table, d_list, d_mask_rw, parity, v->d_status,
-                           hv_next_status_seq(v));
+        // (image-coherent ownership needs no finish launch: the plan stores the masks of exactly the units it lists, restarts the
+        // set's list itself and publishes the pool status after its claims - sweep k + 1 follows sweep k directly)
+        if (!coherent)
+            hipLaunchKernelGGL(k_tsdf_batch_finish, dim3(1), dim3(1024), 0, v->stream, v->table, d_list, d_mask_rw, parity, v->d_status,
+                               hv_next_status_seq(v));
+        else
+            v->plan_lists_stale = true; // the sets' list counters keep their batches' sizes until their next plan: an online frame clears them first
         HV_HIP(hipGetLastError());
     }
     v->pipe_armed = true;
@@ -2656,6 +2955,23 @@ int hv_tsdf_set_tile(hv_volume *v, int32_t u0, int32_t v0, int32_t u1, int32_t v
     v->tile[1] = v0;
     v->tile[2] = u1;
     v->tile[3] = v1;
+    return HV_OK;
+}
+
+int hv_tsdf_set_sharding(hv_volume *v, int32_t mode) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_tsdf_set_sharding: null volume");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_set_sharding: volume is not in TSDF mode");
+    HV_REQUIRE(mode == 0 || mode == 1, HV_ERR_INVALID, "hv_tsdf_set_sharding: mode must be 0 (hash) or 1 (image-coherent)");
+    if (v->shard_coherent != 0 && mode == 0 && v->touched_mask != nullptr) {
+        // the hash form ORs frame bits into masks that are zero between batches; the coherent form leaves its last masks behind
+        HV_HIP(hipSetDevice(v->device));
+        if (v->stream_aux) HV_HIP(hipStreamSynchronize(v->stream_aux));
+        HV_HIP(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * 2 * v->table_capacity, v->stream));
+        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
+        HV_HIP(hipStreamSynchronize(v->stream));
+        v->pipe_armed = false;
+    }
+    v->shard_coherent = mode;
     return HV_OK;
 }
 

@@ -10,6 +10,15 @@ it is free next to the ~0.5 GB of voxel traffic it causes).  Two ways to split t
     simply distributed over the ranks — no collective while fusing.  ``gather_to_root()`` collects
     it on one rank when a mesh is wanted.
 
+``sharding="coherent"`` (round 4; what ``bench.py --gpus N`` runs) — ownership is PLANNED PER BATCH on the device
+    (``hv_tsdf_set_sharding``, kernels ``k_tsdf_touch_plan / _plan_hist / _plan_assign``): every rank enumerates the batch's
+    units into a small replicated table, all ranks derive the same plan from it without talking — equal WORK per rank, a
+    rank's units contiguous in the image (ragged vertical strips of the batch's middle frame) — and a rank then claims, packs
+    and sweeps only its part of every frame: the per-batch replicated work (pack: 187 MB per 32 frames under hash ownership)
+    shrinks with N.  A (unit, frame) pair is fused by exactly one rank; ownership moves with the camera, so a unit's
+    additive numerators may live on several ranks: ``merge_halo()`` / ``gather_to_root()`` consolidate them like the tile
+    form's (no duplicated sweeps, unlike the tile form).
+
 ``sharding="tile"`` (north-star form) — rank r fuses only the voxels whose projection falls into its
     vertical image tile (``hv_tsdf_set_tile``); a unit that cannot project into a rank's tile is neither
     allocated nor swept there.  Units on tile borders (and revisits from other viewpoints) then hold
@@ -53,7 +62,7 @@ class ShardedTSDF:
 
     def __init__(self, voxel_length, sdf_trunc, width, height, device=0, max_blocks=None, rank=0, world_size=1,
                  process_group=None, volume=None, group=None, sharding="owner"):
-        assert sharding in ("owner", "tile")
+        assert sharding in ("owner", "tile", "coherent")
         self.rank, self.world_size = int(rank), int(world_size)
         self.width, self.height = int(width), int(height)
         self.group = group
@@ -69,6 +78,8 @@ class ShardedTSDF:
         if self.distributed:
             if sharding == "tile":
                 self.volume.set_tile(*self.tile)
+            elif sharding == "coherent":
+                self.volume.set_owner(self.rank, self.world_size, coherent=True)
             else:
                 self.volume.set_owner(self.rank, self.world_size)
 

@@ -698,9 +698,11 @@ class ScalableTSDFVolume(_Volume):
         """Restrict fusion to the image tile [u0,u1) x [v0,v1) (multi-GPU sharding); zeros = whole image."""
         L.check(self._lib.hv_tsdf_set_tile(self._h, int(u0), int(v0), int(u1), int(v1)))
 
-    def set_owner(self, rank, world_size):
-        """Fuse/store only the units owned by `rank` of `world_size` (multi-GPU unit-ownership sharding)."""
+    def set_owner(self, rank, world_size, coherent=False):
+        """Fuse/store only the units owned by `rank` of `world_size` (multi-GPU unit-ownership sharding).  coherent=True: multi-frame
+        calls plan their batch on the device (equal work, image-contiguous units per GPU: hv_tsdf_set_sharding)."""
         L.check(self._lib.hv_tsdf_set_owner(self._h, int(rank), int(world_size)))
+        L.check(self._lib.hv_tsdf_set_sharding(self._h, 1 if coherent else 0))
 
     def extract_triangle_mesh(self):
         nv, nt = ctypes.c_int64(), ctypes.c_int64()

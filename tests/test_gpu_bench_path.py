@@ -201,6 +201,9 @@ SWEEP_FORMS = [
     {"HV_TSDF_SWEEP": "4", "HV_TSDF_BATCH_SPLIT": "2"},
     {"HV_TSDF_SWEEP": "4", "HV_TSDF_BATCH_SPLIT": "1"},
     {"HV_TSDF_SWEEP": "4", "HV_TSDF_BATCH_GENERAL": "1"},
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_ZS": "2"},      # z halves: 8 wave tasks per unit (multi-GPU shares; the upper half replays 8 z steps)
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_ZS": "2", "HV_TSDF_SWEEP_WPE": "5"},
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_ZS": "2", "HV_TSDF_BATCH_GENERAL": "1"},
     {"HV_TSDF_SWEEP": "2"},                              # production: float2 chain, prefetched frame constants, packed colour
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_PIPELINE": "0"},     # every launch of a batch on the one stream (no touch / sweep overlap between batches)
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_XCD": "0"},    # work items in list order instead of one contiguous list eighth per XCD
