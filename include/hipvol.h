@@ -218,6 +218,23 @@ int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, in
                                          const int32_t *instance_ids_image, const float *depth_image, float depth_threshold,
                                          int32_t do_carving, float min_vote_ratio, int32_t min_votes, int32_t *map_inst,
                                          int32_t *map_obj, int64_t cap, int64_t *n_map, int32_t loc);
+/* The same association in stages, none of which waits for the GPU unless it hands data to the host (pySLAM's per-keyframe flow -
+ * assign -> remap -> integrate, volumetric_integrator_voxel_semantic_grid.py:326-461 - then runs without a host round trip):
+ *   hv_assoc_vote      per-voxel votes + the image's instance ids -> (instance << 32 | object, votes) pairs in device memory
+ *   hv_assoc_decide    the reference's winner / min_votes / min_vote_ratio rules on the pairs (voxel_semantic_data_association.h:
+ *                      268-361), new object ids from the process-wide counter (kept in device memory), deferred set_object_id
+ *   hv_assoc_map_fetch the instance -> object map, sorted by instance id (synchronises; reports capacity overflows of the stages)
+ *   hv_remap_instance_ids_last  remap_instance_ids (image_utils.h:69-163) with that map, read where it lies
+ * Multi-GPU (block ownership, hv_set_owner): every GPU votes with its own voxels, hv_assoc_pairs_fetch -> all-gather of the pair
+ * lists -> hv_assoc_pairs_set(concatenation) on every GPU -> hv_assoc_decide: identical maps and object ids everywhere. */
+int hv_assoc_vote(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw, float depth_max,
+                  float depth_min, const int32_t *class_ids_image, const int32_t *instance_ids_image, const float *depth_image,
+                  float depth_threshold, int32_t do_carving, int32_t loc);
+int hv_assoc_pairs_fetch(hv_volume *v, uint64_t *pair_keys, int32_t *pair_counts, int64_t cap, int64_t *n_pairs);
+int hv_assoc_pairs_set(hv_volume *v, const uint64_t *pair_keys, const int32_t *pair_counts, int64_t n_pairs);
+int hv_assoc_decide(hv_volume *v, float min_vote_ratio, int32_t min_votes);
+int hv_assoc_map_fetch(hv_volume *v, int32_t *map_inst, int32_t *map_obj, int64_t cap, int64_t *n_map);
+int hv_remap_instance_ids_last(hv_volume *v, const int32_t *instance_ids, int32_t height, int32_t width, int32_t *out, int32_t loc);
 int32_t hv_peek_next_object_id(void); /* VoxelSemanticSharedData::next_object_id, voxel_semantic_shared_data.h:26-34 */
 void hv_set_next_object_id(int32_t id);
 /* remap_instance_ids(instance_ids i32 HxW, map) (image_utils.h:69-163): ids absent from the map (or an empty map)

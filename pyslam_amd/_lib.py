@@ -81,6 +81,12 @@ SIGNATURES = {
     "hv_label_overflows": (_i32, [_vp, _pi64]),
     "hv_assign_object_ids_to_instance_ids": (_i32, [_vp, _vp, _i32, _i32, _vp, _f32, _f32, _vp, _vp, _vp, _f32, _i32, _f32, _i32,
                                                     _vp, _vp, _i64, _pi64, _i32]),
+    "hv_assoc_vote": (_i32, [_vp, _vp, _i32, _i32, _vp, _f32, _f32, _vp, _vp, _vp, _f32, _i32, _i32]),
+    "hv_assoc_pairs_fetch": (_i32, [_vp, _vp, _vp, _i64, _pi64]),
+    "hv_assoc_pairs_set": (_i32, [_vp, _vp, _vp, _i64]),
+    "hv_assoc_decide": (_i32, [_vp, _f32, _i32]),
+    "hv_assoc_map_fetch": (_i32, [_vp, _vp, _vp, _i64, _pi64]),
+    "hv_remap_instance_ids_last": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32]),
     "hv_peek_next_object_id": (_i32, []),
     "hv_set_next_object_id": (None, [_i32]),
     "hv_remap_instance_ids": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _i32]),

@@ -307,7 +307,14 @@ struct hv_volume {
     void *assoc_clean = nullptr;             // == assoc_buf (and assoc_clean_bytes == assoc_buf_bytes: a grown buffer may come back at the
     size_t assoc_clean_bytes = 0;            // same address) while its vote table is known to be empty - the compaction kernel clears what it reads
     size_t assoc_buf_bytes = 0;
+    int32_t assoc_pending_cap = 0;           // pending-list capacity of the last hv_assoc_vote
+    int assoc_state = 0;                     // 0: no association yet, 1: voted (pairs on the device), 2: decided (map on the device)
     void *segments_cache = nullptr;          // host-side result of hv_object_segments_compute (HvSegmentsCache*)
+    // semantic grids: one bit per voxel of the pool, set when the voxel takes its first point (k_sem_reduce) and never cleared by a
+    // voxel reset (carve / remove_*): "may be occupied".  A surface touches ~7 % of a block's voxels, and every per-voxel scan
+    // (association vote, carve, get_voxels, segments, size) used to read all 64 / 128-byte records to find them; with the bit a
+    // lane reads its record only when the bit is set.  [max_blocks * bs^3 / 64] words, pool order.
+    unsigned long long *occ = nullptr;
 
     // staging for HV_HOST inputs
     void *stage_a = nullptr;

@@ -590,6 +590,11 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
         HV_TRY(hipMalloc(&v->sort_vals_out, sizeof(uint32_t) * cfg->max_points));
         HV_TRY(hipMalloc(&v->scratch_points, sizeof(float) * 3 * cfg->max_points));
         HV_TRY(hipMalloc(&v->scratch_colors, sizeof(float) * 3 * cfg->max_points));
+        if (cfg->mode != HV_MODE_VOXEL_GRID) {
+            const size_t occ_words = ((size_t)cfg->max_blocks * nvox + 63) / 64;
+            HV_TRY(hipMalloc((void **)&v->occ, sizeof(unsigned long long) * occ_words));
+            HV_TRY(hipMemsetAsync(v->occ, 0, sizeof(unsigned long long) * occ_words, v->stream));
+        }
     }
 #undef HV_TRY
     // first reset zeroes the whole pool (later resets only the used prefix)
@@ -619,7 +624,7 @@ void hv_destroy(hv_volume *v) {
                     v->touched_stamp, v->touched_list, v->touched_mask, v->frame_px,
                     v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                     v->sort_vals_out, v->sort_tmp, v->scratch_points, v->scratch_colors, v->out_a,
-                    v->out_b, v->out_c, v->batch_buf, v->assoc_buf, v->mult_table, v->vg_cnt, v->vg_cur, v->vg_touched, v->vg_cursor, v->batch_buf2, v->unit_masks, v->plan_buf};
+                    v->out_b, v->out_c, v->batch_buf, v->assoc_buf, v->mult_table, v->vg_cnt, v->vg_cur, v->vg_touched, v->vg_cursor, v->batch_buf2, v->unit_masks, v->plan_buf, v->occ};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (v->h_counters) (void)hipHostFree(v->h_counters);
@@ -652,6 +657,10 @@ int hv_reset(hv_volume *v) {
         if (used > v->cfg.max_blocks) used = v->cfg.max_blocks;
     }
     if (used > 0) HV_HIP(hipMemsetAsync(v->pool, 0, (size_t)used * v->bytes_per_block, v->stream));
+    if (used > 0 && v->occ) {
+        const int64_t nvox = (int64_t)v->cfg.block_size * v->cfg.block_size * v->cfg.block_size;
+        HV_HIP(hipMemsetAsync(v->occ, 0, sizeof(unsigned long long) * (size_t)((used * nvox + 63) / 64), v->stream));
+    }
     HV_HIP(hipMemsetAsync(v->table.keys, 0xFF, sizeof(uint64_t) * v->table_capacity, v->stream));
     HV_HIP(hipMemsetAsync(v->table.vals, 0xFF, sizeof(int32_t) * v->table_capacity, v->stream));
     HV_HIP(hipMemsetAsync(v->table.counters, 0, sizeof(int32_t) * HV_CNT_COUNT, v->stream));
@@ -745,12 +754,12 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
     HV_REQUIRE(need < free_b, HV_ERR_CAPACITY, "hv_reserve_blocks: %.1f GiB needed, %.1f GiB of HBM free", need / 1073741824.0,
                free_b / 1073741824.0);
     void *pool = nullptr;
-    unsigned long long *keys = nullptr, *block_keys = nullptr;
+    unsigned long long *keys = nullptr, *block_keys = nullptr, *occ = nullptr;
     int32_t *vals = nullptr, *stamp = nullptr, *list = nullptr;
     uint64_t *mask = nullptr;
     // every allocation is released again if a later step fails (HV_HIP returns from the middle)
     auto release = [&]() {
-        for (void *p : {pool, (void *)keys, (void *)vals, (void *)block_keys, (void *)stamp, (void *)list, (void *)mask})
+        for (void *p : {pool, (void *)keys, (void *)vals, (void *)block_keys, (void *)stamp, (void *)list, (void *)mask, (void *)occ})
             if (p) (void)hipFree(p);
     };
 #define HV_TRY_GROW(call)                                                                          \
@@ -770,6 +779,13 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
     HV_TRY_GROW(hipMemsetAsync((char *)pool + (size_t)used * v->bytes_per_block, 0, (size_t)(new_max_blocks - used) * v->bytes_per_block,
                                v->stream));
     HV_TRY_GROW(hipMemcpyAsync(block_keys, v->table.block_keys, sizeof(uint64_t) * used, hipMemcpyDeviceToDevice, v->stream));
+    if (v->occ) { // the occupancy bits follow the pool (pool indices are kept)
+        const int64_t nvox = (int64_t)v->cfg.block_size * v->cfg.block_size * v->cfg.block_size;
+        const size_t new_words = ((size_t)new_max_blocks * nvox + 63) / 64, used_words = ((size_t)used * nvox + 63) / 64;
+        HV_TRY_GROW(hipMalloc((void **)&occ, sizeof(unsigned long long) * new_words));
+        HV_TRY_GROW(hipMemsetAsync(occ, 0, sizeof(unsigned long long) * new_words, v->stream));
+        if (used_words) HV_TRY_GROW(hipMemcpyAsync(occ, v->occ, sizeof(unsigned long long) * used_words, hipMemcpyDeviceToDevice, v->stream));
+    }
     HV_TRY_GROW(hipMemsetAsync(keys, 0xFF, sizeof(uint64_t) * new_cap, v->stream));
     HV_TRY_GROW(hipMemsetAsync(vals, 0xFF, sizeof(int32_t) * new_cap, v->stream));
     HvTable nt = v->table;
@@ -811,6 +827,10 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
         v->touched_stamp = stamp;
         v->touched_list = list;
         v->touched_mask = mask;
+    }
+    if (occ) {
+        (void)hipFree(v->occ);
+        v->occ = occ;
     }
     (void)hipFree(v->pool);
     (void)hipFree(v->table.keys);

@@ -210,6 +210,84 @@ __host__ __device__ inline float prob_observation_log_prob(bool has_depth, float
     return confidence * HV_BASE_LOG_PROB;
 }
 
+// The occupancy bit of voxel `gid` (pool order): false = the voxel never took a point, its record need not be read.  The lanes
+// of a wave ask for 64 consecutive voxels: one 8-byte word.
+__device__ __forceinline__ bool sem_maybe_occupied(const unsigned long long *__restrict__ occ, int64_t gid) {
+    return occ == nullptr || ((occ[gid >> 6] >> (gid & 63)) & 1ull) != 0ull;
+}
+
+#ifdef __HIPCC__
+// r-th (0-based) set bit of a 64-bit word that has more than r bits set
+__device__ __forceinline__ int sem_select_bit(unsigned long long w, int r) {
+    int pos = 0;
+    uint32_t lo = (uint32_t)w;
+    int c = __popc(lo);
+    if (r >= c) {
+        r -= c;
+        pos = 32;
+        lo = (uint32_t)(w >> 32);
+    }
+#pragma unroll
+    for (int s = 16; s > 0; s >>= 1) {
+        c = __popc(lo & ((1u << s) - 1u));
+        if (r >= c) {
+            r -= c;
+            lo >>= s;
+            pos += s;
+        }
+    }
+    return pos;
+}
+
+// One WAVE visits the voxels of pool block b that may be occupied: body(gid, active) is called by all 64 lanes together (so that
+// it may use ballots / wave-aggregated appends), `active` lanes hold a voxel whose occupancy bit is set (pool-order voxel index
+// gid), the others hold nothing.  A surface touches ~34 of a block's 512 voxels: one call instead of eight, and no record of an
+// empty voxel is read.  all_voxels (or occ == nullptr): every voxel of the block is visited, 64 at a time.
+// The visit itself, for a block whose occupancy words are already in registers (lane w holds word w of the block; callers that
+// walk many blocks request the next block's words before they work on this one).  Needs nvox % 64 == 0, nvox / 64 <= 64.
+template <typename F>
+__device__ __forceinline__ void sem_for_occupied_word(unsigned long long word, int64_t b, int nvox, F body) {
+    const int lane = hv_lane_id();
+    const int W = nvox >> 6;
+    const int cnt = __popcll(word);
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < HV_WAVE; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    const int total = __shfl(incl, HV_WAVE - 1);
+    for (int k0 = 0; k0 < total; k0 += HV_WAVE) { // wave-uniform trip count
+        const int k = k0 + lane;
+        const bool active = k < total;
+        int wi = 0;
+        for (int w = 0; w < W - 1; ++w) wi += (__shfl(incl, w) <= k) ? 1 : 0; // word that holds the k-th set bit
+        const unsigned long long ww = __shfl(word, wi);
+        const int before = __shfl(incl, wi) - __shfl(cnt, wi);
+        const int pos = active ? sem_select_bit(ww, k - before) : 0;
+        body(b * nvox + wi * 64 + pos, active);
+    }
+}
+__device__ __forceinline__ bool sem_occ_words_usable(const unsigned long long *occ, int nvox) {
+    return occ != nullptr && (nvox & 63) == 0 && (nvox >> 6) <= HV_WAVE;
+}
+
+template <typename F>
+__device__ __forceinline__ void sem_for_occupied(const unsigned long long *__restrict__ occ, int64_t b, int nvox, bool all_voxels, F body) {
+    const int lane = hv_lane_id();
+    const int W = nvox >> 6;
+    if (all_voxels || !sem_occ_words_usable(occ, nvox)) {
+        for (int l0 = 0; l0 < nvox; l0 += HV_WAVE) {
+            const int l = l0 + lane;
+            const int64_t gid = b * nvox + l;
+            body(gid, l < nvox && (occ == nullptr || all_voxels || sem_maybe_occupied(occ, gid)));
+        }
+        return;
+    }
+    sem_for_occupied_word(lane < W ? occ[b * W + lane] : 0ull, b, nvox, body);
+}
+#endif
+
 static inline HvSemParams sem_params(const hv_volume *v) {
     HvSemParams G;
     G.inv_voxel_size = 1.0f / (float)v->cfg.voxel_size;

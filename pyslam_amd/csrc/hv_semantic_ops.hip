@@ -35,7 +35,24 @@ static constexpr int32_t HV_OBJ_SEEN = INT32_MIN + 1; // "this instance id occur
 static constexpr uint32_t HV_VOTE_CAP = 1u << 16;     // vote-table slots (distinct (instance, object) pairs per frame)
 static constexpr uint64_t HV_VOTE_EMPTY = ~0ull;
 
-static std::atomic<int32_t> g_next_object_id{1}; // VoxelSemanticSharedData::next_object_id
+static std::atomic<int32_t> g_next_object_id{1}; // VoxelSemanticSharedData::next_object_id: the value the device counters start from
+// The counter itself lives in device memory (one per GPU of the process): k_sem_assoc_rules hands the ids out without a host round
+// trip.  hv_peek / hv_set_next_object_id read / write it (synchronising the device).
+static int32_t *g_dev_next_id[64] = {};
+static int g_dev_last = -1; // GPU whose counter was used last (hv_peek_next_object_id reads that one)
+
+static int hv_dev_next_id(int device, int32_t **out) {
+    HV_REQUIRE(device >= 0 && device < 64, HV_ERR_INVALID, "device ordinal out of range");
+    if (g_dev_next_id[device] == nullptr) {
+        HV_HIP(hipSetDevice(device));
+        HV_HIP(hipMalloc((void **)&g_dev_next_id[device], sizeof(int32_t)));
+        const int32_t start = g_next_object_id.load();
+        HV_HIP(hipMemcpy(g_dev_next_id[device], &start, sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    g_dev_last = device;
+    *out = g_dev_next_id[device];
+    return HV_OK;
+}
 
 template <typename VOX> __device__ __forceinline__ void sem_reset(VOX *v) {
     uint4 *q = (uint4 *)v;
@@ -69,9 +86,9 @@ __device__ __forceinline__ bool sem_visit(const HvQuery &Q, const HvTable &table
 // u >= 0, u < W, v >= 0, v < H, each linear in camera coordinates - no voxel of the block can pass CameraFrustrum::contains and
 // the wave leaves without reading a single voxel record (a keyframe sees a fraction of the map; the scan is otherwise
 // bs^3 x 64..128 bytes per allocated block whether it is in view or not).  Lanes 0-7 test one corner each.
-__device__ __forceinline__ bool sem_block_outside_frustum(const HvQuery &Q, const HvTable &table, int64_t b, const HvSemParams &G) {
+__device__ __forceinline__ bool sem_block_outside_frustum_key(const HvQuery &Q, unsigned long long block_key, const HvSemParams &G) {
     int32_t bk[3];
-    hv_unpack_key(table.block_keys[b], bk[0], bk[1], bk[2]);
+    hv_unpack_key(block_key, bk[0], bk[1], bk[2]);
     const int lane = hv_lane_id();
     const double vs = 1.0 / (double)G.inv_voxel_size, ext = (double)G.bs * vs;
     double p[3];
@@ -89,18 +106,27 @@ __device__ __forceinline__ bool sem_block_outside_frustum(const HvQuery &Q, cons
            (__ballot(out3) & corners) == corners || (__ballot(out4) & corners) == corners || (__ballot(out5) & corners) == corners;
 }
 
+__device__ __forceinline__ bool sem_block_outside_frustum(const HvQuery &Q, const HvTable &table, int64_t b, const HvSemParams &G) {
+    return sem_block_outside_frustum_key(Q, table.block_keys[b], G);
+}
+
 template <typename VOX>
 __global__ __launch_bounds__(256) void k_sem_carve(HvTable table, VOX *__restrict__ pool, int64_t n_blocks, HvSemParams G,
-                                                    HvQuery Q, const float *__restrict__ depth) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n_blocks * G.nvox) return;
-    if ((G.nvox & 63) == 0 && sem_block_outside_frustum(Q, table, gid / G.nvox, G)) return; // wave-uniform
-    VOX *v = pool + gid;
-    float uvd[3];
-    if (!sem_visit(Q, table, v, gid / G.nvox, (int)(gid % G.nvox), G, uvd)) return;
-    const float image_depth = depth[(int64_t)(int)uvd[1] * Q.width + (int)uvd[0]];
-    if (image_depth <= 0.0f || !isfinite(image_depth)) return;
-    if (uvd[2] < image_depth - Q.carve_threshold) sem_reset(v);
+                                                    HvQuery Q, const float *__restrict__ depth, const unsigned long long *__restrict__ occ) {
+    // one wave per block, its occupied voxels only (sem_for_occupied)
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / HV_WAVE);
+    for (int64_t b = (int64_t)blockIdx.x * (blockDim.x / HV_WAVE) + threadIdx.x / HV_WAVE; b < n_blocks; b += n_waves) {
+        if ((G.nvox & 63) == 0 && sem_block_outside_frustum(Q, table, b, G)) continue; // wave-uniform
+        sem_for_occupied(occ, b, G.nvox, false, [&](int64_t gid, bool active) {
+            if (!active) return;
+            VOX *v = pool + gid;
+            float uvd[3];
+            if (!sem_visit(Q, table, v, b, (int)(gid - b * G.nvox), G, uvd)) return;
+            const float image_depth = depth[(int64_t)(int)uvd[1] * Q.width + (int)uvd[0]];
+            if (image_depth <= 0.0f || !isfinite(image_depth)) return;
+            if (uvd[2] < image_depth - Q.carve_threshold) sem_reset(v);
+        });
+    }
 }
 
 // ---- association -------------------------------------------------------------------------------
@@ -189,63 +215,83 @@ struct HvAssocParams {
     int32_t pending_cap;
 };
 
-// process_point, voxel_semantic_data_association.h:190-246
+// process_point, voxel_semantic_data_association.h:190-246.  One wave per block of the pool: the block's box is tested against the
+// frustum once, then only the voxels whose occupancy bit is set are visited (a 2 mm ScanNet keyframe faces 120 k blocks = 61 M
+// voxel slots of which 7 % hold a voxel: the thread-per-slot form spent 0.7 - 1.0 ms per keyframe on per-wave overhead - cull,
+// ballots, appends - for 950 k waves of mostly empty slots).
 template <typename VOX>
 __global__ __launch_bounds__(256) void k_sem_assoc_vote(HvTable table, VOX *__restrict__ pool, int64_t n_blocks,
                                                          HvSemParams G, HvQuery Q, const int32_t *__restrict__ cls_img,
                                                          const int32_t *__restrict__ inst_img,
                                                          const float *__restrict__ depth, HvAssocParams A,
                                                          unsigned long long *__restrict__ vkeys,
-                                                         int32_t *__restrict__ vcounts, int2 *__restrict__ pending) {
+                                                         int32_t *__restrict__ vcounts, int2 *__restrict__ pending,
+                                                         const unsigned long long *__restrict__ occ) {
     __shared__ HvVoteLocal s_votes;
     vote_local_init(s_votes);
-    const int64_t total = n_blocks * G.nvox;
-    // persistent workgroups: the trip count is the same for every thread of a workgroup (the ballots below need whole waves)
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t gid = base + threadIdx.x;
-    uint64_t key = HV_VOTE_EMPTY;
-    bool is_pending = false;
-    int32_t inst = -1;
-    // (total = n_blocks * nvox and nvox % 64 == 0: a wave never straddles the end of the pool or two blocks)
-    const bool culled = gid < total && (G.nvox & 63) == 0 && sem_block_outside_frustum(Q, table, gid / G.nvox, G);
-    if (gid < total && !culled) {
-        VOX *v = pool + gid;
-        float uvd[3];
-        if (sem_visit(Q, table, v, gid / G.nvox, (int)(gid % G.nvox), G, uvd)) {
-            const int64_t px = (int64_t)(int)uvd[1] * Q.width + (int)uvd[0];
-            const int32_t image_class = cls_img[px];
-            const int32_t point_class = sem_class_id(v);
-            inst = inst_img[px];
-            bool go = image_class >= 0 && point_class >= 0 && point_class == image_class && inst >= 0;
-            if (go && A.use_depth) {
-                const float image_depth = depth[px];
-                if (image_depth <= 0.0f || !isfinite(image_depth)) {
-                    go = false;
-                } else if (A.do_carving && uvd[2] < image_depth - A.depth_threshold) {
-                    sem_reset(v);
-                    go = false;
-                } else if (uvd[2] > image_depth + A.depth_threshold) {
-                    go = false;
-                }
-            }
-            if (go) {
-                int32_t obj = sem_object_id(v);
-                if (obj < 0) {
-                    if (inst == 0) {
-                        obj = 0;
-                        sem_set_object_id(v, 0);
-                    } else {
-                        obj = HV_OBJ_PENDING;
-                        is_pending = true;
+    if (n_blocks < 0) n_blocks = min(table.counters[HV_CNT_BLOCKS], table.max_blocks); // (the host does not wait to learn it)
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / HV_WAVE);
+    // the key and the occupancy words of the NEXT block are requested before this block is worked on: a block is a chain of
+    // dependent round trips (key -> cull, words -> records -> image pixels) and a wave holds too many registers for the SIMD to
+    // hide them with other waves
+    const bool words = sem_occ_words_usable(occ, G.nvox);
+    const int W = G.nvox >> 6, lane = hv_lane_id();
+    int64_t b = (int64_t)blockIdx.x * (blockDim.x / HV_WAVE) + threadIdx.x / HV_WAVE;
+    unsigned long long next_key = b < n_blocks ? table.block_keys[b] : 0ull;
+    unsigned long long next_word = (words && b < n_blocks && lane < W) ? occ[b * W + lane] : 0ull;
+    for (; b < n_blocks; b += n_waves) {
+        const unsigned long long bkey = next_key, word = next_word;
+        if (b + n_waves < n_blocks) {
+            next_key = table.block_keys[b + n_waves];
+            next_word = (words && lane < W) ? occ[(b + n_waves) * W + lane] : 0ull;
+        }
+        if (words && !__any(word != 0ull)) continue;                                      // nothing ever landed in this block
+        if ((G.nvox & 63) == 0 && sem_block_outside_frustum_key(Q, bkey, G)) continue; // wave-uniform
+        auto visit = [&](int64_t gid, bool active) {
+            uint64_t key = HV_VOTE_EMPTY;
+            bool is_pending = false;
+            int32_t inst = -1;
+            if (active) {
+                VOX *v = pool + gid;
+                float uvd[3];
+                if (sem_visit(Q, table, v, b, (int)(gid - b * G.nvox), G, uvd)) {
+                    const int64_t px = (int64_t)(int)uvd[1] * Q.width + (int)uvd[0];
+                    const int32_t image_class = cls_img[px];
+                    const int32_t point_class = sem_class_id(v);
+                    inst = inst_img[px];
+                    bool go = image_class >= 0 && point_class >= 0 && point_class == image_class && inst >= 0;
+                    if (go && A.use_depth) {
+                        const float image_depth = depth[px];
+                        if (image_depth <= 0.0f || !isfinite(image_depth)) {
+                            go = false;
+                        } else if (A.do_carving && uvd[2] < image_depth - A.depth_threshold) {
+                            sem_reset(v);
+                            go = false;
+                        } else if (uvd[2] > image_depth + A.depth_threshold) {
+                            go = false;
+                        }
+                    }
+                    if (go) {
+                        int32_t obj = sem_object_id(v);
+                        if (obj < 0) {
+                            if (inst == 0) {
+                                obj = 0;
+                                sem_set_object_id(v, 0);
+                            } else {
+                                obj = HV_OBJ_PENDING;
+                                is_pending = true;
+                            }
+                        }
+                        key = vote_key(inst, obj);
                     }
                 }
-                key = vote_key(inst, obj);
             }
-        }
-    }
-    vote_wave_local(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2], key);
-    const int32_t at = hv_wave_append(&table.counters[HV_CNT_AUX], is_pending);
-    if (is_pending && at < A.pending_cap) pending[at] = make_int2((int32_t)gid, inst);
+            vote_wave_local(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2], key);
+            const int32_t at = hv_wave_append(&table.counters[HV_CNT_AUX], is_pending);
+            if (is_pending && at < A.pending_cap) pending[at] = make_int2((int32_t)gid, inst);
+        };
+        if (words) sem_for_occupied_word(word, b, G.nvox, visit);
+        else sem_for_occupied(occ, b, G.nvox, false, visit);
     }
     vote_local_flush(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2]);
 }
@@ -297,45 +343,210 @@ __device__ __forceinline__ int32_t map_lookup(const int32_t *__restrict__ map_in
     return missing;
 }
 
-// deferred set_object_id of the voxels that waited for the vote, voxel_semantic_data_association.h:344-361
-template <typename VOX>
-__global__ __launch_bounds__(256) void k_sem_assoc_apply(VOX *__restrict__ pool, const int2 *__restrict__ pending,
-                                                          int32_t n_pending, const int32_t *__restrict__ map_inst,
-                                                          const int32_t *__restrict__ map_obj, int32_t n_map) {
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pending) return;
-    const int2 p = pending[i];
-    const int32_t final_id = map_lookup(map_inst, map_obj, n_map, p.y, -1);
-    if (final_id >= 0) sem_set_object_id(pool + p.x, final_id);
+// The reference's voting rules (voxel_semantic_data_association.h:268-361) on the compacted (instance, object, votes) pairs of one
+// keyframe, on the device: one workgroup sorts the pairs by (instance, object) in LDS, one thread walks them - a keyframe has a few
+// dozen pairs.  New object ids come from the process-wide counter in device memory, handed out in ascending instance order.
+// map = {inst[HV_VOTE_CAP], obj[HV_VOTE_CAP]} sorted by instance id, *n_map its size; *flags |= 1 when the pairs did not fit the
+// workgroup (the host reports it when the map is fetched).  No host round trip between the vote and the remap / integrate.
+static constexpr int HV_RULES_MAX = 4096;
+__global__ __launch_bounds__(1024) void k_sem_assoc_rules(HvTable table, const unsigned long long *__restrict__ pkeys,
+                                                           const int32_t *__restrict__ pcounts, float min_vote_ratio, int32_t min_votes,
+                                                           int32_t *__restrict__ next_object_id, int32_t *__restrict__ map_inst,
+                                                           int32_t *__restrict__ map_obj, int32_t *__restrict__ n_map_out,
+                                                           int32_t *__restrict__ flags) {
+    __shared__ unsigned long long s_key[HV_RULES_MAX];
+    __shared__ int32_t s_cnt[HV_RULES_MAX];
+    int n = table.counters[HV_CNT_OUT];
+    if (n > HV_RULES_MAX) {
+        if (threadIdx.x == 0) {
+            atomicOr(flags, 1);
+            *n_map_out = 0;
+        }
+        return;
+    }
+    int m2 = 1;
+    while (m2 < n) m2 <<= 1;
+    for (int i = threadIdx.x; i < m2; i += blockDim.x) {
+        if (i < n) {
+            const unsigned long long k = pkeys[i]; // instance << 32 | object (two's complement)
+            s_key[i] = (k & 0xffffffff00000000ull) | (unsigned long long)((uint32_t)k ^ 0x80000000u); // unsigned order == (inst, signed obj)
+            s_cnt[i] = pcounts[i];
+        } else {
+            s_key[i] = ~0ull;
+            s_cnt[i] = 0;
+        }
+    }
+    __syncthreads();
+    for (int k = 2; k <= m2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < m2; t += blockDim.x) {
+                const int x = t ^ j;
+                if (x > t) {
+                    const unsigned long long a = s_key[t], b = s_key[x];
+                    if ((a > b) == ((t & k) == 0)) {
+                        s_key[t] = b;
+                        s_key[x] = a;
+                        const int32_t c = s_cnt[t];
+                        s_cnt[t] = s_cnt[x];
+                        s_cnt[x] = c;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x != 0) return;
+    int32_t next_id = *next_object_id;
+    int n_map = 0;
+    for (int i = 0; i < n;) {
+        const int32_t inst = (int32_t)(uint32_t)(s_key[i] >> 32);
+        int j = i;
+        int32_t pending = 0;
+        bool seen = false;
+        while (j < n && (int32_t)(uint32_t)(s_key[j] >> 32) == inst) { // PENDING and SEEN sort first (the two smallest object values)
+            const int32_t obj = (int32_t)((uint32_t)s_key[j] ^ 0x80000000u);
+            if (obj == HV_OBJ_PENDING) pending += s_cnt[j];
+            else if (obj == HV_OBJ_SEEN) seen = true;
+            else break;
+            ++j;
+        }
+        // the instance's votes in ascending object-id order (std::map), the new id - if voxels wait for one - at its place in that order
+        int32_t new_id = -1;
+        if (pending > 0) new_id = next_id++;
+        int max_votes = 0, winning = -1, total_votes = 0;
+        bool have_votes = pending > 0, new_done = pending <= 0;
+        auto take = [&](int32_t obj, int32_t cnt) {
+            total_votes += cnt;
+            if (cnt > max_votes) {
+                max_votes = cnt;
+                winning = obj;
+            }
+        };
+        while (j < n && (int32_t)(uint32_t)(s_key[j] >> 32) == inst) {
+            const int32_t obj = (int32_t)((uint32_t)s_key[j] ^ 0x80000000u);
+            int32_t cnt = s_cnt[j];
+            ++j;
+            while (j < n && s_key[j] == s_key[j - 1]) cnt += s_cnt[j++]; // (the same pair from several lists: multi-GPU merge)
+            if (!new_done && new_id < obj) {
+                take(new_id, pending);
+                new_done = true;
+            }
+            if (!new_done && new_id == obj) { // (cannot happen with a monotone counter; the reference would add the counts)
+                cnt += pending;
+                new_done = true;
+            }
+            have_votes = true;
+            take(obj, cnt);
+        }
+        if (!new_done) take(new_id, pending);
+        bool present = false;
+        int32_t result = -1;
+        if (have_votes) {
+            present = true;
+            if (total_votes >= min_votes) {
+                const float ratio = (float)max_votes / (float)total_votes;
+                result = ratio < min_vote_ratio ? -1 : winning;
+            }
+        }
+        if (seen) {
+            if (inst == 0) {
+                result = 0;
+                present = true;
+            } else if (!present) {
+                result = -1;
+                present = true;
+            }
+        }
+        if (present) {
+            map_inst[n_map] = inst;
+            map_obj[n_map] = result;
+            ++n_map;
+        }
+        i = j;
+    }
+    *next_object_id = next_id;
+    *n_map_out = n_map;
 }
 
+// deferred set_object_id of the voxels that waited for the vote, voxel_semantic_data_association.h:344-361
+// (the pending count and the map's size are read on the device: nothing of the association goes through the host)
+template <typename VOX>
+__global__ __launch_bounds__(256) void k_sem_assoc_apply(HvTable table, VOX *__restrict__ pool, const int2 *__restrict__ pending,
+                                                          int32_t pending_cap, const int32_t *__restrict__ map_inst,
+                                                          const int32_t *__restrict__ map_obj, const int32_t *__restrict__ n_map_p) {
+    const int32_t n_pending = min(table.counters[HV_CNT_AUX], pending_cap);
+    const int32_t n_map = *n_map_p;
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pending; i += gridDim.x * blockDim.x) {
+        const int2 p = pending[i];
+        const int32_t final_id = map_lookup(map_inst, map_obj, n_map, p.y, -1);
+        if (final_id >= 0) sem_set_object_id(pool + p.x, final_id);
+    }
+}
+
+// n_map_p != nullptr: the map's size lives on the device (the map of the volume's last association)
 __global__ __launch_bounds__(256) void k_remap_instance_ids(const int32_t *__restrict__ in, int64_t n,
                                                              const int32_t *__restrict__ map_inst,
                                                              const int32_t *__restrict__ map_obj, int32_t n_map,
-                                                             int32_t *__restrict__ out) {
+                                                             const int32_t *__restrict__ n_map_p, int32_t *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (n_map_p != nullptr) n_map = *n_map_p;
     out[i] = n_map > 0 ? map_lookup(map_inst, map_obj, n_map, in[i], -1) : -1;
 }
 
 // ---- segments ------------------------------------------------------------------------------------
 template <typename VOX>
-__global__ __launch_bounds__(256) void k_seg_collect(HvTable table, const VOX *__restrict__ pool, int64_t n_voxels,
+__global__ __launch_bounds__(256) void k_seg_collect(HvTable table, const VOX *__restrict__ pool, int64_t n_blocks, int nvox,
                                                       int min_count, float min_confidence,
-                                                      unsigned long long *__restrict__ out_keys, int64_t cap) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool pred = false;
-    int32_t obj = -1;
-    if (gid < n_voxels) {
-        const VOX *v = pool + gid;
-        // NB: strict '>' on the count, voxel_block_semantic_grid.hpp:224
-        if (v->count > min_count && sem_confidence(v) >= min_confidence) {
-            obj = sem_object_id(v);
-            pred = obj >= 0;
-        }
+                                                      unsigned long long *__restrict__ out_keys, int64_t cap,
+                                                      const unsigned long long *__restrict__ occ) {
+    // a wave per block, occupied voxels only; the keys a wave finds wait in its LDS window and take their place in the output with
+    // one returning atomic per ~450 (k_sem_collect has the measurement)
+    constexpr int BUF = 512;
+    __shared__ unsigned long long s_buf[4][BUF];
+    const int wave = threadIdx.x / HV_WAVE, lane = hv_lane_id();
+    unsigned long long *buf = s_buf[wave];
+    int n_buf = 0;
+    int64_t n_found = 0;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    auto flush = [&]() {
+        if (n_buf == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int32_t base = 0;
+        if (lane == 0) base = atomicAdd(&table.counters[HV_CNT_OUT], n_buf);
+        base = __shfl(base, 0);
+        for (int i = lane; i < n_buf; i += HV_WAVE)
+            if ((int64_t)base + i < cap) out_keys[(int64_t)base + i] = buf[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        n_buf = 0;
+    };
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / HV_WAVE);
+    for (int64_t b = (int64_t)blockIdx.x * (blockDim.x / HV_WAVE) + wave; b < n_blocks; b += n_waves) {
+        sem_for_occupied(occ, b, nvox, false, [&](int64_t gid, bool active) {
+            bool pred = false;
+            int32_t obj = -1;
+            if (active) {
+                const VOX *v = pool + gid;
+                // NB: strict '>' on the count, voxel_block_semantic_grid.hpp:224
+                if (v->count > min_count && sem_confidence(v) >= min_confidence) {
+                    obj = sem_object_id(v);
+                    pred = obj >= 0;
+                }
+            }
+            const unsigned long long m = __ballot(pred);
+            if (m == 0ull) return;
+            if (out_keys == nullptr) {
+                n_found += __popcll(m);
+                return;
+            }
+            if (pred) buf[n_buf + __popcll(m & lt)] = ((unsigned long long)(uint32_t)obj << 32) | (unsigned long long)(uint32_t)gid;
+            n_buf += __popcll(m);
+            if (n_buf > BUF - HV_WAVE) flush();
+        });
     }
-    const int32_t at = hv_wave_append(&table.counters[HV_CNT_OUT], pred);
-    if (pred && at < cap && out_keys != nullptr) out_keys[at] = ((unsigned long long)(uint32_t)obj << 32) | (unsigned long long)(uint32_t)gid;
+    if (out_keys != nullptr) flush();
+    else if (lane == 0 && n_found) atomicAdd(&table.counters[HV_CNT_OUT], (int32_t)n_found);
 }
 
 template <typename VOX>
@@ -363,9 +574,10 @@ __global__ __launch_bounds__(256) void k_seg_rows(const VOX *__restrict__ pool, 
 // 3 remove_low_count_voxels(a), 4 remove_low_confidence_voxels(fa)
 template <typename VOX>
 __global__ __launch_bounds__(256) void k_sem_segment_op(VOX *__restrict__ pool, int64_t n_voxels, int op, int32_t a, int32_t b,
-                                                         float fa) {
+                                                         float fa, const unsigned long long *__restrict__ occ) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_voxels) return;
+    if (!sem_maybe_occupied(occ, gid)) return; // a voxel that never took a point: every op leaves its zero record as it is
     VOX *v = pool + gid;
     if (op == 0) {
         if (sem_object_id(v) == b) sem_set_object_id(v, a);
@@ -381,10 +593,13 @@ __global__ __launch_bounds__(256) void k_sem_segment_op(VOX *__restrict__ pool, 
 }
 
 template <typename VOX>
-__global__ __launch_bounds__(256) void k_sem_count_nonempty(HvTable table, const VOX *__restrict__ pool, int64_t n_voxels) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool pred = gid < n_voxels && pool[gid].count > 0;
-    (void)hv_wave_append(&table.counters[HV_CNT_OUT], pred);
+__global__ __launch_bounds__(256) void k_sem_count_nonempty(HvTable table, const VOX *__restrict__ pool, int64_t n_blocks, int nvox,
+                                                             const unsigned long long *__restrict__ occ) {
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / HV_WAVE);
+    for (int64_t b = (int64_t)blockIdx.x * (blockDim.x / HV_WAVE) + threadIdx.x / HV_WAVE; b < n_blocks; b += n_waves)
+        sem_for_occupied(occ, b, nvox, false, [&](int64_t gid, bool active) {
+            (void)hv_wave_append(&table.counters[HV_CNT_OUT], active && pool[gid].count > 0);
+        });
 }
 
 // ---- host: PCA oriented bounding box, bounding_boxes_3d.cpp:373-553 ------------------------------
@@ -571,7 +786,7 @@ template <typename VOX> int sem_launch_segment_op(hv_volume *v, int op, int32_t 
     if (nb == 0) return HV_OK;
     const int64_t total = nb * sem_params(v).nvox;
     hipLaunchKernelGGL(k_sem_segment_op<VOX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, (VOX *)v->pool,
-                       total, op, a, b, fa);
+                       total, op, a, b, fa, (op == 0 && b < 0) ? nullptr : v->occ); // (merging INTO the voxels without an object id reaches empty ones too)
     HV_HIP(hipGetLastError());
     return HV_OK;
 }
@@ -584,12 +799,11 @@ void hv_segments_cache_free(void *cache) { delete static_cast<HvSegmentsCache *>
 
 int hv_sem_carve(hv_volume *v, const HvQuery &Q, const float *d_depth, int64_t nb) {
     const HvSemParams G = sem_params(v);
-    const int64_t total = nb * G.nvox;
-    const dim3 grid((unsigned)((total + 255) / 256));
+    const dim3 grid((unsigned)std::min<int64_t>((nb + 3) / 4, 8192)); // a wave per block, grid-stride
     if (is_prob(v))
-        hipLaunchKernelGGL(k_sem_carve<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, nb, G, Q, d_depth);
+        hipLaunchKernelGGL(k_sem_carve<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, nb, G, Q, d_depth, v->occ);
     else
-        hipLaunchKernelGGL(k_sem_carve<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, nb, G, Q, d_depth);
+        hipLaunchKernelGGL(k_sem_carve<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, nb, G, Q, d_depth, v->occ);
     HV_HIP(hipGetLastError());
     return HV_OK;
 }
@@ -605,13 +819,13 @@ int hv_sem_size(hv_volume *v, int64_t *n) {
     if (rc != HV_OK) return rc;
     *n = 0;
     if (nb == 0) return HV_OK;
-    const int64_t total = nb * sem_params(v).nvox;
+    const int nvox = sem_params(v).nvox;
     HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
-    const dim3 grid((unsigned)((total + 255) / 256));
+    const dim3 grid((unsigned)std::min<int64_t>((nb + 3) / 4, 8192));
     if (is_prob(v))
-        hipLaunchKernelGGL(k_sem_count_nonempty<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvProbVoxel *)v->pool, total);
+        hipLaunchKernelGGL(k_sem_count_nonempty<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvProbVoxel *)v->pool, nb, nvox, v->occ);
     else
-        hipLaunchKernelGGL(k_sem_count_nonempty<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvSemVoxel *)v->pool, total);
+        hipLaunchKernelGGL(k_sem_count_nonempty<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvSemVoxel *)v->pool, nb, nvox, v->occ);
     HV_HIP(hipGetLastError());
     rc = hv_read_counters(v);
     if (rc != HV_OK) return rc;
@@ -621,8 +835,21 @@ int hv_sem_size(hv_volume *v, int64_t *n) {
 
 extern "C" {
 
-int32_t hv_peek_next_object_id(void) { return g_next_object_id.load(); }
-void hv_set_next_object_id(int32_t id) { g_next_object_id.store(id); }
+int32_t hv_peek_next_object_id(void) {
+    if (g_dev_last >= 0 && g_dev_next_id[g_dev_last] != nullptr) {
+        int32_t value = 0;
+        if (hipSetDevice(g_dev_last) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+            hipMemcpy(&value, g_dev_next_id[g_dev_last], sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess)
+            g_next_object_id.store(value);
+    }
+    return g_next_object_id.load();
+}
+void hv_set_next_object_id(int32_t id) {
+    g_next_object_id.store(id);
+    for (int d = 0; d < 64; ++d)
+        if (g_dev_next_id[d] != nullptr && hipSetDevice(d) == hipSuccess && hipDeviceSynchronize() == hipSuccess)
+            (void)hipMemcpy(g_dev_next_id[d], &id, sizeof(int32_t), hipMemcpyHostToDevice);
+}
 
 int hv_merge_segments(hv_volume *v, int32_t instance_id1, int32_t instance_id2) {
     HV_REQUIRE(v != nullptr && hv_is_semantic(v), HV_ERR_MODE, "hv_merge_segments: not a semantic grid");
@@ -671,50 +898,70 @@ int hv_remap_instance_ids(hv_volume *v, const int32_t *instance_ids, int32_t hei
         d_out = (int32_t *)(cursor + img_bytes);
     }
     hipLaunchKernelGGL(k_remap_instance_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, d_in, n, d_map,
-                       d_map + n_map, (int32_t)n_map, d_out);
+                       d_map + n_map, (int32_t)n_map, (const int32_t *)nullptr, d_out);
     HV_HIP(hipGetLastError());
     if (loc == HV_HOST) HV_HIP(hipMemcpyAsync(out, d_out, img_bytes, hipMemcpyDeviceToHost, v->stream));
     HV_HIP(hipStreamSynchronize(v->stream)); // `flat` is host memory
     return HV_OK;
 }
 
-int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw,
-                                         float depth_max, float depth_min, const int32_t *class_ids_image,
-                                         const int32_t *instance_ids_image, const float *depth_image, float depth_threshold,
-                                         int32_t do_carving, float min_vote_ratio, int32_t min_votes, int32_t *map_inst,
-                                         int32_t *map_obj, int64_t cap, int64_t *n_map, int32_t loc) {
-    HV_REQUIRE(v != nullptr && intr_f32 != nullptr && T_cw != nullptr && n_map != nullptr, HV_ERR_INVALID,
-               "hv_assign_object_ids_to_instance_ids: null argument");
-    HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_assign_object_ids_to_instance_ids: not a semantic grid");
-    *n_map = 0;
-    // "class IDs or semantic instances image is empty": the reference returns an empty map
-    if (class_ids_image == nullptr || instance_ids_image == nullptr || width <= 0 || height <= 0) return HV_OK;
-    HV_HIP(hipSetDevice(v->device));
-    int64_t nb = 0;
-    int rc = hv_num_blocks(v, &nb);
-    if (rc != HV_OK) return rc;
-    const HvSemParams G = sem_params(v);
-    const int64_t n_px = (int64_t)width * height;
-    const int64_t total = nb * G.nvox;
-    const int64_t pending_cap = std::max<int64_t>(1, std::min<int64_t>(total, 8 * (int64_t)v->cfg.max_points));
+// ---- association, in stages (all asynchronous on the volume's stream unless they hand data to the host) ------------------------
+namespace {
+struct AssocScratch {
+    unsigned long long *vkeys, *ckeys;
+    int32_t *vcounts, *ccounts, *map_inst, *map_obj, *n_map, *flags;
+    int2 *pending;
+    int64_t pending_cap;
+};
 
-    // device scratch: [vote keys][vote counts][compact keys][compact counts][pending][final map]
+int assoc_scratch(hv_volume *v, AssocScratch *S) {
+    const HvSemParams G = sem_params(v);
+    const int64_t total = (int64_t)v->cfg.max_blocks * G.nvox; // (the pool's size, not its fill: no stage waits for the block count)
+    S->pending_cap = std::max<int64_t>(1, std::min<int64_t>(total, 8 * (int64_t)v->cfg.max_points));
+    // device scratch: [vote keys][vote counts][compact keys][compact counts][final map inst | obj][n_map, flags][pending]
     const size_t off_counts = sizeof(uint64_t) * HV_VOTE_CAP;
     const size_t off_ckeys = off_counts + sizeof(int32_t) * HV_VOTE_CAP;
     const size_t off_ccounts = off_ckeys + sizeof(uint64_t) * HV_VOTE_CAP;
-    const size_t off_pending = off_ccounts + sizeof(int32_t) * HV_VOTE_CAP;
-    const size_t off_map = off_pending + sizeof(int2) * (size_t)pending_cap;
-    const size_t scratch_bytes = off_map + sizeof(int32_t) * 2 * HV_VOTE_CAP;
-    rc = hv_ensure_buffer(v, &v->assoc_buf, &v->assoc_buf_bytes, scratch_bytes);
+    const size_t off_map = off_ccounts + sizeof(int32_t) * HV_VOTE_CAP;
+    const size_t off_misc = off_map + sizeof(int32_t) * 2 * HV_VOTE_CAP;
+    const size_t off_pending = off_misc + 256;
+    const size_t scratch_bytes = off_pending + sizeof(int2) * (size_t)S->pending_cap;
+    int rc = hv_ensure_buffer(v, &v->assoc_buf, &v->assoc_buf_bytes, scratch_bytes);
     if (rc != HV_OK) return rc;
     char *sb = (char *)v->assoc_buf;
-    unsigned long long *vkeys = (unsigned long long *)sb;
-    int32_t *vcounts = (int32_t *)(sb + off_counts);
-    unsigned long long *ckeys = (unsigned long long *)(sb + off_ckeys);
-    int32_t *ccounts = (int32_t *)(sb + off_ccounts);
-    int2 *pending = (int2 *)(sb + off_pending);
-    int32_t *d_map = (int32_t *)(sb + off_map);
+    S->vkeys = (unsigned long long *)sb;
+    S->vcounts = (int32_t *)(sb + off_counts);
+    S->ckeys = (unsigned long long *)(sb + off_ckeys);
+    S->ccounts = (int32_t *)(sb + off_ccounts);
+    S->map_inst = (int32_t *)(sb + off_map);
+    S->map_obj = S->map_inst + HV_VOTE_CAP;
+    S->n_map = (int32_t *)(sb + off_misc);
+    S->flags = S->n_map + 1;
+    S->pending = (int2 *)(sb + off_pending);
+    return HV_OK;
+}
+} // namespace
 
+// Stage 1: the per-voxel votes and the image's instance ids -> compacted (instance << 32 | object, votes) pairs in device memory
+// (how many: counter HV_CNT_OUT; voxels waiting for an object id: the pending list, counter HV_CNT_AUX).
+int hv_assoc_vote(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw, float depth_max,
+                  float depth_min, const int32_t *class_ids_image, const int32_t *instance_ids_image, const float *depth_image,
+                  float depth_threshold, int32_t do_carving, int32_t loc) {
+    HV_REQUIRE(v != nullptr && intr_f32 != nullptr && T_cw != nullptr, HV_ERR_INVALID, "hv_assoc_vote: null argument");
+    HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_assoc_vote: not a semantic grid");
+    HV_REQUIRE(class_ids_image != nullptr && instance_ids_image != nullptr && width > 0 && height > 0, HV_ERR_INVALID,
+               "hv_assoc_vote: empty label images");
+    HV_HIP(hipSetDevice(v->device));
+    bool checked_unused = false;
+    int rc = hv_capacity_gate(v, &checked_unused); // consumes the published pool state (no synchronisation); refuses after an overflow
+    if (rc != HV_OK) return rc;
+    // how many blocks the pool holds is read by the kernel itself; the grid is sized by what the host knows without waiting
+    const int64_t nb = std::min<int64_t>(v->cfg.max_blocks, std::max<int64_t>(v->known_blocks, 1024));
+    const HvSemParams G = sem_params(v);
+    const int64_t n_px = (int64_t)width * height;
+    AssocScratch S;
+    rc = assoc_scratch(v, &S);
+    if (rc != HV_OK) return rc;
     // images: three planes staged back to back when they come from the host
     const int32_t *d_cls = class_ids_image, *d_inst = instance_ids_image;
     const float *d_depth = depth_image;
@@ -732,20 +979,20 @@ int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, in
             d_depth = (const float *)(st + 2 * plane);
         }
     }
-
     if (v->assoc_clean != v->assoc_buf || v->assoc_clean_bytes != v->assoc_buf_bytes) { // a new allocation, or a call that failed before its compaction
-        HV_HIP(hipMemsetAsync(vkeys, 0xFF, sizeof(uint64_t) * HV_VOTE_CAP, v->stream));
-        HV_HIP(hipMemsetAsync(vcounts, 0, sizeof(int32_t) * HV_VOTE_CAP, v->stream));
+        HV_HIP(hipMemsetAsync(S.vkeys, 0xFF, sizeof(uint64_t) * HV_VOTE_CAP, v->stream));
+        HV_HIP(hipMemsetAsync(S.vcounts, 0, sizeof(int32_t) * HV_VOTE_CAP, v->stream));
+        HV_HIP(hipMemsetAsync(S.n_map, 0, 256, v->stream));
     }
     v->assoc_clean = nullptr;
     static_assert(HV_CNT_OUT2 == HV_CNT_OUT + 1 && HV_CNT_AUX == HV_CNT_OUT + 2, "one memset clears OUT, OUT2, AUX");
     HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t) * 3, v->stream));
-
     HvAssocParams A;
     A.use_depth = depth_image != nullptr ? 1 : 0;
     A.do_carving = (do_carving && A.use_depth) ? 1 : 0;
     A.depth_threshold = depth_threshold;
-    A.pending_cap = (int32_t)std::min<int64_t>(pending_cap, INT32_MAX);
+    A.pending_cap = (int32_t)std::min<int64_t>(S.pending_cap, INT32_MAX);
+    v->assoc_pending_cap = A.pending_cap;
     const bool prob = is_prob(v);
     if (nb > 0) {
         HvQuery Q;
@@ -759,106 +1006,168 @@ int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, in
         GP.nvox = G.nvox;
         GP.local_bits = G.local_bits;
         fill_key_range(Q, GP);
-        const dim3 grid((unsigned)std::min<int64_t>((total + 255) / 256, 4096)); // persistent: 16 workgroups per CU
+        const dim3 grid((unsigned)std::min<int64_t>((nb + 3) / 4, 4096)); // a wave per block, persistent: 16 workgroups per CU
         if (prob)
-            hipLaunchKernelGGL(k_sem_assoc_vote<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, nb, G,
-                               Q, d_cls, d_inst, d_depth, A, vkeys, vcounts, pending);
+            hipLaunchKernelGGL(k_sem_assoc_vote<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, (int64_t)-1, G,
+                               Q, d_cls, d_inst, d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ);
         else
-            hipLaunchKernelGGL(k_sem_assoc_vote<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, nb, G, Q,
-                               d_cls, d_inst, d_depth, A, vkeys, vcounts, pending);
+            hipLaunchKernelGGL(k_sem_assoc_vote<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, (int64_t)-1, G, Q,
+                               d_cls, d_inst, d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ);
     }
     hipLaunchKernelGGL(k_sem_assoc_image, dim3((unsigned)std::min<int64_t>((n_px + 255) / 256, 512)), dim3(256), 0, v->stream, v->table, d_cls, d_inst,
-                       n_px, vkeys, vcounts);
-    hipLaunchKernelGGL(k_sem_assoc_compact, dim3(HV_VOTE_CAP / 256), dim3(256), 0, v->stream, v->table, vkeys, vcounts, ckeys,
-                       ccounts);
+                       n_px, S.vkeys, S.vcounts);
+    hipLaunchKernelGGL(k_sem_assoc_compact, dim3(HV_VOTE_CAP / 256), dim3(256), 0, v->stream, v->table, S.vkeys, S.vcounts, S.ckeys,
+                       S.ccounts);
     HV_HIP(hipGetLastError());
-    rc = hv_read_counters(v);
-    if (rc != HV_OK) return rc;
-    v->assoc_clean = v->assoc_buf; // the compaction ran: every slot it found is empty again
+    v->assoc_clean = v->assoc_buf; // the compaction is queued: every slot it finds is empty again
     v->assoc_clean_bytes = v->assoc_buf_bytes;
+    v->assoc_state = 1;
+    return HV_OK;
+}
+
+// Multi-GPU: every GPU votes with the voxels it owns; the pair lists are exchanged (all-gather, a few hundred bytes), concatenated
+// and set on every GPU, which then decides identically (the rules kernel adds the counts of equal pairs).
+int hv_assoc_pairs_fetch(hv_volume *v, uint64_t *pair_keys, int32_t *pair_counts, int64_t cap, int64_t *n_pairs) {
+    HV_REQUIRE(v != nullptr && n_pairs != nullptr, HV_ERR_INVALID, "hv_assoc_pairs_fetch: null argument");
+    HV_REQUIRE(v->assoc_state >= 1, HV_ERR_INVALID, "hv_assoc_pairs_fetch: call hv_assoc_vote first");
+    HV_HIP(hipSetDevice(v->device));
+    int rc = hv_read_counters(v);
+    if (rc != HV_OK) return rc;
+    HV_REQUIRE(v->h_counters[HV_CNT_OUT2] == 0, HV_ERR_CAPACITY, "hv_assoc_vote: more than %u distinct (instance, object) pairs", HV_VOTE_CAP);
+    const int64_t n = v->h_counters[HV_CNT_OUT];
+    *n_pairs = n;
+    if (pair_keys == nullptr || pair_counts == nullptr || n == 0) return HV_OK;
+    AssocScratch S;
+    rc = assoc_scratch(v, &S);
+    if (rc != HV_OK) return rc;
+    const int64_t m = std::min(n, cap);
+    HV_HIP(hipMemcpyAsync(pair_keys, S.ckeys, sizeof(uint64_t) * m, hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipMemcpyAsync(pair_counts, S.ccounts, sizeof(int32_t) * m, hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipStreamSynchronize(v->stream));
+    return HV_OK;
+}
+
+int hv_assoc_pairs_set(hv_volume *v, const uint64_t *pair_keys, const int32_t *pair_counts, int64_t n_pairs) {
+    HV_REQUIRE(v != nullptr && (n_pairs == 0 || (pair_keys != nullptr && pair_counts != nullptr)), HV_ERR_INVALID, "hv_assoc_pairs_set: null argument");
+    HV_REQUIRE(v->assoc_state >= 1, HV_ERR_INVALID, "hv_assoc_pairs_set: call hv_assoc_vote first");
+    HV_REQUIRE(n_pairs >= 0 && n_pairs <= HV_RULES_MAX, HV_ERR_CAPACITY, "hv_assoc_pairs_set: more than %d pairs", HV_RULES_MAX);
+    HV_HIP(hipSetDevice(v->device));
+    AssocScratch S;
+    int rc = assoc_scratch(v, &S);
+    if (rc != HV_OK) return rc;
+    const int32_t n32 = (int32_t)n_pairs;
+    if (n_pairs > 0) {
+        HV_HIP(hipMemcpyAsync(S.ckeys, pair_keys, sizeof(uint64_t) * n_pairs, hipMemcpyHostToDevice, v->stream));
+        HV_HIP(hipMemcpyAsync(S.ccounts, pair_counts, sizeof(int32_t) * n_pairs, hipMemcpyHostToDevice, v->stream));
+    }
+    HV_HIP(hipMemcpyAsync(&v->table.counters[HV_CNT_OUT], &n32, sizeof(int32_t), hipMemcpyHostToDevice, v->stream));
+    HV_HIP(hipStreamSynchronize(v->stream)); // the arguments are host memory
+    return HV_OK;
+}
+
+// Stage 2: the reference's winner / min_votes / min_vote_ratio rules on the pairs, new object ids, the deferred set_object_id of the
+// voxels that waited - all on the device.  The map stays in device memory (hv_remap_instance_ids_last reads it there).
+int hv_assoc_decide(hv_volume *v, float min_vote_ratio, int32_t min_votes) {
+    HV_REQUIRE(v != nullptr && hv_is_semantic(v), HV_ERR_MODE, "hv_assoc_decide: not a semantic grid");
+    HV_REQUIRE(v->assoc_state >= 1, HV_ERR_INVALID, "hv_assoc_decide: call hv_assoc_vote first");
+    HV_HIP(hipSetDevice(v->device));
+    AssocScratch S;
+    int rc = assoc_scratch(v, &S);
+    if (rc != HV_OK) return rc;
+    int32_t *d_next = nullptr;
+    rc = hv_dev_next_id(v->device, &d_next);
+    if (rc != HV_OK) return rc;
+    hipLaunchKernelGGL(k_sem_assoc_rules, dim3(1), dim3(1024), 0, v->stream, v->table, S.ckeys, S.ccounts, min_vote_ratio, min_votes, d_next,
+                       S.map_inst, S.map_obj, S.n_map, S.flags);
+    const dim3 grid(256);
+    if (is_prob(v))
+        hipLaunchKernelGGL(k_sem_assoc_apply<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, S.pending,
+                           v->assoc_pending_cap, S.map_inst, S.map_obj, S.n_map);
+    else
+        hipLaunchKernelGGL(k_sem_assoc_apply<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, S.pending,
+                           v->assoc_pending_cap, S.map_inst, S.map_obj, S.n_map);
+    HV_HIP(hipGetLastError());
+    v->assoc_state = 2;
+    return HV_OK;
+}
+
+// The map of the last association, sorted by instance id (this is where an overflow of the vote table / pending list / rules
+// workgroup is reported).
+int hv_assoc_map_fetch(hv_volume *v, int32_t *map_inst, int32_t *map_obj, int64_t cap, int64_t *n_map) {
+    HV_REQUIRE(v != nullptr && n_map != nullptr, HV_ERR_INVALID, "hv_assoc_map_fetch: null argument");
+    HV_REQUIRE(v->assoc_state == 2, HV_ERR_INVALID, "hv_assoc_map_fetch: call hv_assoc_decide first");
+    HV_HIP(hipSetDevice(v->device));
+    AssocScratch S;
+    int rc = assoc_scratch(v, &S);
+    if (rc != HV_OK) return rc;
+    int32_t misc[2] = {0, 0};
+    HV_HIP(hipMemcpyAsync(misc, S.n_map, sizeof(misc), hipMemcpyDeviceToHost, v->stream));
+    rc = hv_read_counters(v); // synchronises the stream
+    if (rc != HV_OK) return rc;
     HV_REQUIRE(v->h_counters[HV_CNT_OUT2] == 0, HV_ERR_CAPACITY,
                "hv_assign_object_ids_to_instance_ids: more than %u distinct (instance, object) pairs", HV_VOTE_CAP);
-    const int32_t n_pairs = v->h_counters[HV_CNT_OUT];
-    const int32_t n_pending = v->h_counters[HV_CNT_AUX];
-    HV_REQUIRE(n_pending <= A.pending_cap, HV_ERR_CAPACITY, "hv_assign_object_ids_to_instance_ids: pending list overflow (%d)",
-               n_pending);
-    std::vector<uint64_t> hk((size_t)n_pairs);
-    std::vector<int32_t> hc((size_t)n_pairs);
-    if (n_pairs > 0) {
-        HV_HIP(hipMemcpyAsync(hk.data(), ckeys, sizeof(uint64_t) * n_pairs, hipMemcpyDeviceToHost, v->stream));
-        HV_HIP(hipMemcpyAsync(hc.data(), ccounts, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, v->stream));
+    HV_REQUIRE(v->h_counters[HV_CNT_AUX] <= v->assoc_pending_cap, HV_ERR_CAPACITY,
+               "hv_assign_object_ids_to_instance_ids: pending list overflow (%d)", v->h_counters[HV_CNT_AUX]);
+    HV_REQUIRE((misc[1] & 1) == 0, HV_ERR_CAPACITY, "hv_assign_object_ids_to_instance_ids: more than %d (instance, object) pairs in one keyframe",
+               HV_RULES_MAX);
+    *n_map = misc[0];
+    const int64_t m = std::min<int64_t>(misc[0], cap);
+    if (m > 0 && map_inst != nullptr && map_obj != nullptr) {
+        HV_HIP(hipMemcpyAsync(map_inst, S.map_inst, sizeof(int32_t) * m, hipMemcpyDeviceToHost, v->stream));
+        HV_HIP(hipMemcpyAsync(map_obj, S.map_obj, sizeof(int32_t) * m, hipMemcpyDeviceToHost, v->stream));
         HV_HIP(hipStreamSynchronize(v->stream));
     }
+    return HV_OK;
+}
 
-    // ---- host: the reference's voting rules, voxel_semantic_data_association.h:268-361 ----
-    std::map<int32_t, std::map<int32_t, int32_t>> votes; // instance -> (object -> count), objects ascending like std::map
-    std::map<int32_t, int32_t> pending_votes;            // instance -> votes of voxels waiting for a new object id
-    std::vector<int32_t> seen;
-    for (int32_t i = 0; i < n_pairs; ++i) {
-        const int32_t inst = (int32_t)(uint32_t)(hk[i] >> 32);
-        const int32_t obj = (int32_t)(uint32_t)(hk[i] & 0xffffffffull);
-        if (obj == HV_OBJ_SEEN) seen.push_back(inst);
-        else if (obj == HV_OBJ_PENDING) pending_votes[inst] += hc[i];
-        else votes[inst][obj] += hc[i];
+// remap_instance_ids with the map of the volume's last association, straight from device memory (no dict, no upload)
+int hv_remap_instance_ids_last(hv_volume *v, const int32_t *instance_ids, int32_t height, int32_t width, int32_t *out, int32_t loc) {
+    HV_REQUIRE(v != nullptr && instance_ids != nullptr && out != nullptr, HV_ERR_INVALID, "hv_remap_instance_ids_last: null argument");
+    HV_REQUIRE(v->assoc_state == 2, HV_ERR_INVALID, "hv_remap_instance_ids_last: call hv_assoc_decide first");
+    HV_HIP(hipSetDevice(v->device));
+    const int64_t n = (int64_t)height * width;
+    if (n == 0) return HV_OK;
+    AssocScratch S;
+    int rc = assoc_scratch(v, &S);
+    if (rc != HV_OK) return rc;
+    const int32_t *d_in = instance_ids;
+    int32_t *d_out = out;
+    const size_t img_bytes = sizeof(int32_t) * (size_t)n;
+    if (loc == HV_HOST) {
+        rc = hv_ensure_buffer(v, &v->stage_b, &v->stage_b_bytes, 2 * img_bytes + 512);
+        if (rc != HV_OK) return rc;
+        HV_HIP(hipMemcpyAsync(v->stage_b, instance_ids, img_bytes, hipMemcpyHostToDevice, v->stream));
+        d_in = (const int32_t *)v->stage_b;
+        d_out = (int32_t *)((char *)v->stage_b + img_bytes);
     }
-    for (const auto &[inst, cnt] : pending_votes) { // ascending instance id
-        const int32_t new_id = g_next_object_id.fetch_add(1);
-        votes[inst][new_id] += cnt;
-    }
-    std::map<int32_t, int32_t> result;
-    for (const auto &[inst, object_votes] : votes) {
-        int max_votes = 0, winning = -1, total_votes = 0;
-        for (const auto &[obj, cnt] : object_votes) {
-            total_votes += cnt;
-            if (cnt > max_votes) {
-                max_votes = cnt;
-                winning = obj;
-            }
-        }
-        if (total_votes < min_votes) {
-            result[inst] = -1;
-            continue;
-        }
-        const float ratio = (float)max_votes / (float)total_votes;
-        result[inst] = ratio < min_vote_ratio ? -1 : winning;
-    }
-    for (const int32_t inst : seen) {
-        if (inst == 0) result[0] = 0;
-        else if (result.find(inst) == result.end()) result[inst] = -1;
-    }
-
-    // ---- deferred assignments ----
-    if (n_pending > 0 && !result.empty()) {
-        std::vector<int32_t> flat(result.size() * 2);
-        size_t i = 0;
-        for (const auto &[inst, obj] : result) {
-            flat[i] = inst;
-            flat[result.size() + i] = obj;
-            ++i;
-        }
-        HV_REQUIRE(result.size() <= HV_VOTE_CAP, HV_ERR_CAPACITY, "hv_assign_object_ids_to_instance_ids: map too large");
-        HV_HIP(hipMemcpyAsync(d_map, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice, v->stream));
-        const dim3 grid((unsigned)((n_pending + 255) / 256));
-        if (prob)
-            hipLaunchKernelGGL(k_sem_assoc_apply<HvProbVoxel>, grid, dim3(256), 0, v->stream, (HvProbVoxel *)v->pool, pending, n_pending,
-                               d_map, d_map + result.size(), (int32_t)result.size());
-        else
-            hipLaunchKernelGGL(k_sem_assoc_apply<HvSemVoxel>, grid, dim3(256), 0, v->stream, (HvSemVoxel *)v->pool, pending, n_pending,
-                               d_map, d_map + result.size(), (int32_t)result.size());
-        HV_HIP(hipGetLastError());
-        HV_HIP(hipStreamSynchronize(v->stream)); // `flat` is host memory
-    }
-    *n_map = (int64_t)result.size();
-    if (map_inst != nullptr && map_obj != nullptr) {
-        int64_t i = 0;
-        for (const auto &[inst, obj] : result) {
-            if (i >= cap) break;
-            map_inst[i] = inst;
-            map_obj[i] = obj;
-            ++i;
-        }
+    hipLaunchKernelGGL(k_remap_instance_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, d_in, n, S.map_inst, S.map_obj, 0,
+                       (const int32_t *)S.n_map, d_out);
+    HV_HIP(hipGetLastError());
+    if (loc == HV_HOST) {
+        HV_HIP(hipMemcpyAsync(out, d_out, img_bytes, hipMemcpyDeviceToHost, v->stream));
+        HV_HIP(hipStreamSynchronize(v->stream));
     }
     return HV_OK;
+}
+
+// The reference's one call = vote + decide + fetch.
+int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw,
+                                         float depth_max, float depth_min, const int32_t *class_ids_image,
+                                         const int32_t *instance_ids_image, const float *depth_image, float depth_threshold,
+                                         int32_t do_carving, float min_vote_ratio, int32_t min_votes, int32_t *map_inst,
+                                         int32_t *map_obj, int64_t cap, int64_t *n_map, int32_t loc) {
+    HV_REQUIRE(v != nullptr && intr_f32 != nullptr && T_cw != nullptr && n_map != nullptr, HV_ERR_INVALID,
+               "hv_assign_object_ids_to_instance_ids: null argument");
+    HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_assign_object_ids_to_instance_ids: not a semantic grid");
+    *n_map = 0;
+    // "class IDs or semantic instances image is empty": the reference returns an empty map
+    if (class_ids_image == nullptr || instance_ids_image == nullptr || width <= 0 || height <= 0) return HV_OK;
+    int rc = hv_assoc_vote(v, intr_f32, width, height, T_cw, depth_max, depth_min, class_ids_image, instance_ids_image, depth_image,
+                           depth_threshold, do_carving, loc);
+    if (rc != HV_OK) return rc;
+    rc = hv_assoc_decide(v, min_vote_ratio, min_votes);
+    if (rc != HV_OK) return rc;
+    return hv_assoc_map_fetch(v, map_inst, map_obj, cap, n_map);
 }
 
 int hv_object_segments_compute(hv_volume *v, int32_t min_count, float min_confidence, int64_t *n_rows, int64_t *n_objects) {
@@ -875,8 +1184,8 @@ int hv_object_segments_compute(hv_volume *v, int32_t min_count, float min_confid
     if (rc != HV_OK) return rc;
     if (nb == 0) return HV_OK;
     const bool prob = is_prob(v);
-    const int64_t total = nb * sem_params(v).nvox;
-    const dim3 grid((unsigned)((total + 255) / 256));
+    const int nvox = sem_params(v).nvox;
+    const dim3 grid((unsigned)std::min<int64_t>((nb + 3) / 4, 8192));
     // pass 1: count; pass 2: emit (object id, voxel index) keys
     int64_t m = 0;
     for (int pass = 0; pass < 2; ++pass) {
@@ -887,12 +1196,13 @@ int hv_object_segments_compute(hv_volume *v, int32_t min_count, float min_confid
             d_keys = (unsigned long long *)v->out_b;
         }
         HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
+        // (min_count < 0 would admit voxels that never took a point: no occupancy bits then)
         if (prob)
-            hipLaunchKernelGGL(k_seg_collect<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvProbVoxel *)v->pool, total,
-                               min_count, min_confidence, d_keys, m);
+            hipLaunchKernelGGL(k_seg_collect<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvProbVoxel *)v->pool, nb, nvox,
+                               min_count, min_confidence, d_keys, m, min_count >= 0 ? v->occ : nullptr);
         else
-            hipLaunchKernelGGL(k_seg_collect<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvSemVoxel *)v->pool, total,
-                               min_count, min_confidence, d_keys, m);
+            hipLaunchKernelGGL(k_seg_collect<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvSemVoxel *)v->pool, nb, nvox,
+                               min_count, min_confidence, d_keys, m, min_count >= 0 ? v->occ : nullptr);
         HV_HIP(hipGetLastError());
         rc = hv_read_counters(v);
         if (rc != HV_OK) return rc;

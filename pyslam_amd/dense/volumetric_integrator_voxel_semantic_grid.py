@@ -198,20 +198,31 @@ class VolumetricIntegratorVoxelSemanticGrid(VolumetricIntegratorBase):
     def _integrate_keyframe_on_device(self, color, depth, pose, semantic_classes, semantic_instances):
         import torch
 
+        # one queue for torch's uploads and the volume's kernels: no cross-stream event waits between the steps
+        with torch.cuda.stream(self.volume.adopt_torch_stream()):
+            self._integrate_keyframe_on_device_body(color, depth, pose, semantic_classes, semantic_instances)
+
+    def _integrate_keyframe_on_device_body(self, color, depth, pose, semantic_classes, semantic_instances):
+        import torch
+
         dev = torch.device("cuda", int(self.volume._cfg.device))  # the volume's GPU, not torch's current device
 
         def up(a, dtype):
-            return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(dev)
+            # keyframes arrive in the front's shared-memory ring, which the worker page-locks (hv_host_register): the copy is a DMA
+            # that returns at once; pageable sources fall back to torch's blocking copy by themselves
+            return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(dev, non_blocking=True)
 
         depth_d = up(depth, np.float32)
         if Parameters.kVolumetricIntegrationVoxelGridShadowPointsFilter:
             depth_d = self.volume.filter_shadow_points(depth_d)  # stays in HBM
         color_d = up(color, np.uint8)
         cls_d = up(semantic_classes, np.int32) if semantic_classes is not None and np.asarray(semantic_classes).size > 0 else None
+        inst_d = up(semantic_instances, np.int32) if self.integrate_2d_instance_ids else None
+        uploads_done = torch.cuda.Event()
+        uploads_done.record(torch.cuda.current_stream(dev))
         self.camera_frustrum.set_T_cw(pose)
         object_ids_d = None
         if self.integrate_2d_instance_ids:  # same branches as the host flow below (no class image: empty map, every id -> -1)
-            inst_d = up(semantic_instances, np.int32)
             id_map = self.volume.assign_object_ids_to_instance_ids(
                 self.camera_frustrum, cls_d, inst_d, depth_d,
                 depth_threshold=Parameters.kVolumetricIntegrationVoxelGridCarvingDepthThreshold,
@@ -225,6 +236,9 @@ class VolumetricIntegratorVoxelSemanticGrid(VolumetricIntegratorBase):
         self.volume.integrate_rgbd(depth_d, color_d, fx, fy, cx, cy, pose, class_ids_image=cls_d, object_ids_image=object_ids_d,
                                    max_depth=self.volumetric_integration_depth_trunc,
                                    use_depths=Parameters.kVolumetricSemanticProbabilisticIntegrationUseDepth)
+        # the keyframe's host images (ring slots) are handed back when this call returns: the uploads - first in stream order, long
+        # done by now - must have read them
+        uploads_done.synchronize()
 
     def make_output(self, task_type):
         """The output block, reference :511-700."""

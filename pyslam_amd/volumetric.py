@@ -117,6 +117,18 @@ class _Volume:
             self._ts_key = (h, device)
         return self._ts
 
+    def adopt_torch_stream(self):
+        """Run this volume's launches on a torch stream of its own device and hand that stream back: inside
+        ``with torch.cuda.stream(s)`` torch ops (uploads, allocations) and the volume's kernels are ordered by the one queue, and
+        _torch_in / _torch_out need no cross-stream event waits (eight per semantic keyframe otherwise)."""
+        import torch
+
+        if getattr(self, "_adopted", None) is None:
+            dev = torch.device("cuda", int(self._cfg.device))
+            self._adopted = torch.cuda.Stream(dev)
+            self.set_stream(self._adopted.cuda_stream)
+        return self._adopted
+
     def _torch_in(self, *tensors):
         """Before a launch that reads / writes torch CUDA tensors on the volume's stream: that stream waits for what torch's
         current stream has queued (the producers).  No host synchronisation.  -> the volume's torch stream, or None when no
@@ -125,8 +137,11 @@ class _Volume:
 
         for t in tensors:
             if t is not None and getattr(t, "is_cuda", False):
+                cur = torch.cuda.current_stream(t.device)
+                if int(cur.cuda_stream) == int(self._lib.hv_get_stream(self._h) or 0) and int(cur.cuda_stream) != 0:
+                    return None  # the volume runs on torch's current stream (adopt_torch_stream): already ordered
                 ts = self._torch_stream(t.device)
-                ts.wait_stream(torch.cuda.current_stream(t.device))
+                ts.wait_stream(cur)
                 return ts
         return None
 

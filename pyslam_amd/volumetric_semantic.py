@@ -13,6 +13,8 @@ set_depth_threshold, set_depth_decay_rate, clear/reset, size, num_blocks; module
 Also: get_voxels_in_bb / get_voxels_in_camera_frustrum (include_semantics), integrate_segment, get_class_segments.
 Not provided: the *2 payload variants (voxel_data_semantic2.h)."""
 import ctypes
+import weakref
+from collections.abc import Mapping
 
 import numpy as np
 
@@ -188,10 +190,78 @@ def _device_images(*images, device=0):
     return out, L.HV_DEVICE
 
 
+class LazyIdMap(Mapping):
+    """The instance -> object map of an association whose result is still in device memory.  A read-only dict: the first access
+    fetches it (one synchronisation); remap_instance_ids on the same volume uses the device copy without fetching."""
+
+    def __init__(self, volume, serial):
+        self._volume, self._serial, self._d = volume, serial, None
+
+    def on_device_of(self, volume):
+        """True while `volume` still holds this map as its last association."""
+        return volume is self._volume and getattr(volume, "_assoc_serial", None) == self._serial
+
+    def _get(self):
+        if self._d is None:
+            if not self.on_device_of(self._volume):
+                raise RuntimeError("the id map of an earlier association was not read before the next one replaced it")
+            v = self._volume
+            cap = 1 << 16
+            mi, mo = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+            n = ctypes.c_int64()
+            L.check(v._lib.hv_assoc_map_fetch(v._h, L.ptr(mi), L.ptr(mo), cap, ctypes.byref(n)))
+            m = min(n.value, cap)
+            self._d = {int(k): int(o) for k, o in zip(mi[:m], mo[:m])}
+        return self._d
+
+    def __getitem__(self, k):
+        return self._get()[k]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __len__(self):
+        return len(self._get())
+
+    def __repr__(self):
+        return repr(self._get())
+
+
+def _remap_with_last_map(instance_ids, id_map, volume):
+    """remap_instance_ids with the device-resident map of the volume's last association (hv_remap_instance_ids_last)."""
+    v = volume
+    if _is_device(instance_ids):
+        import torch
+
+        img = instance_ids.contiguous()
+        if img.dim() != 2:
+            raise RuntimeError("Instance ids must be single-channel")
+        if img.dtype != torch.int32:
+            raise RuntimeError("Instance ids must be int32")
+        out = torch.empty_like(img)
+        ts = v._torch_in(img, out)
+        L.check(v._lib.hv_remap_instance_ids_last(v._h, L.ptr(img), int(img.shape[0]), int(img.shape[1]), L.ptr(out), L.HV_DEVICE))
+        v._torch_out(ts, img.device)
+        return out
+    img = np.ascontiguousarray(instance_ids)
+    if img.size == 0:
+        return img
+    if img.ndim != 2:
+        raise RuntimeError("Instance ids must be single-channel")
+    if img.dtype != np.int32:
+        raise RuntimeError("Instance ids must be int32")
+    out = np.empty_like(img)
+    L.check(v._lib.hv_remap_instance_ids_last(v._h, L.ptr(img), img.shape[0], img.shape[1], L.ptr(out), L.HV_HOST))
+    return out
+
+
 def remap_instance_ids(instance_ids, instance_id_to_object_id, volume=None):
     """volumetric.remap_instance_ids(image int32 HxW, map) (image_utils.h:69-163, binding image_utils_module.h):
     ids absent from the map (or an empty map) become -1.  Runs on the GPU of ``volume`` (any volume).  A torch CUDA int32
-    image stays on the device (the result is a CUDA tensor)."""
+    image stays on the device (the result is a CUDA tensor).  The map an association on ``volume`` just returned is used where it
+    lies, in device memory."""
+    if isinstance(instance_id_to_object_id, LazyIdMap) and volume is not None and instance_id_to_object_id.on_device_of(volume):
+        return _remap_with_last_map(instance_ids, instance_id_to_object_id, volume)
     if _is_device(instance_ids):
         import torch
 
@@ -443,17 +513,36 @@ class _SemanticGridBase(_Volume):
                 depth = np.ascontiguousarray(depth_image, dtype=np.float32)
                 if depth.shape != (f.height, f.width):
                     depth = None  # use_depth_filter = false
-        cap = 1 << 16
-        mi, mo = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
-        n = ctypes.c_int64()
-        L.check(self._lib.hv_assign_object_ids_to_instance_ids(
+        # vote -> (multi-GPU: exchange of the pair lists) -> decide: queued on the volume's stream, nothing waits; the map stays in
+        # device memory until somebody reads it (remap_instance_ids on this volume uses it there)
+        prev = getattr(self, "_last_map_ref", None)
+        prev = prev() if prev is not None else None
+        if prev is not None and prev._d is None:
+            prev._get()  # somebody still holds the previous association's map and has not read it: fetch it before it is replaced
+        L.check(self._lib.hv_assoc_vote(
             self._h, L.ptr(f.intr), f.width, f.height, L.ptr(f.T_cw), f.depth_max, f.depth_min, L.ptr(cls), L.ptr(inst), L.ptr(depth),
-            float(depth_threshold), int(bool(do_carving)), float(min_vote_ratio), int(min_votes), L.ptr(mi), L.ptr(mo), cap,
-            ctypes.byref(n), loc))
+            float(depth_threshold), int(bool(do_carving)), loc))
+        if self._pair_exchange is not None:
+            self._exchange_pairs()
+        L.check(self._lib.hv_assoc_decide(self._h, float(min_vote_ratio), int(min_votes)))
         if loc == L.HV_DEVICE:
             self._torch_out(ts, cls.device)
-        m = min(n.value, cap)
-        return {int(k): int(v) for k, v in zip(mi[:m], mo[:m])}
+        self._assoc_serial = getattr(self, "_assoc_serial", 0) + 1
+        m = LazyIdMap(self, self._assoc_serial)
+        self._last_map_ref = weakref.ref(m)
+        return m
+
+    _pair_exchange = None  # multi-GPU: callable(keys u64[n], counts i32[n]) -> (keys, counts) of all ranks, concatenated (ShardedSemanticGrid)
+
+    def _exchange_pairs(self):
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_assoc_pairs_fetch(self._h, None, None, 0, ctypes.byref(n)))
+        keys, counts = np.zeros(n.value, np.uint64), np.zeros(n.value, np.int32)
+        if n.value:
+            L.check(self._lib.hv_assoc_pairs_fetch(self._h, L.ptr(keys), L.ptr(counts), n.value, ctypes.byref(n)))
+        keys, counts = self._pair_exchange(keys, counts)
+        keys, counts = np.ascontiguousarray(keys, np.uint64), np.ascontiguousarray(counts, np.int32)
+        L.check(self._lib.hv_assoc_pairs_set(self._h, L.ptr(keys), L.ptr(counts), len(keys)))
 
     def remap_instance_ids(self, instance_ids, instance_id_to_object_id):
         return remap_instance_ids(instance_ids, instance_id_to_object_id, volume=self)

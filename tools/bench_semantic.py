@@ -5,6 +5,7 @@ transform -> integrate, volumetric_integrator_voxel_semantic_grid.py:322-461) on
 next to the *compiled reference* (oracle/_ref: unmodified cpp/volumetric sources, sequential non-TBB branch, 1 core)
 running the same flow with numpy host prep.  Also times get_voxels and get_object_segments.  One JSON line."""
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -33,6 +34,18 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
     s = SyntheticRGBD(config)
     intr = s.intrinsics
     frames = [semantic_frame(s, stride * i, shuffle=i) for i in range(args.frames)]
+    try:  # the keyframes as the worker sees them: in page-locked host memory (the front's registered shared-memory ring)
+        import torch
+
+        def pinned(a):
+            t = torch.empty(a.shape, dtype=torch.from_numpy(a[:0] if a.ndim else a).dtype, pin_memory=True)
+            t.numpy()[...] = a
+            return t.numpy()
+
+        frames = [tuple(pinned(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) and a.ndim >= 2 and a.shape[0] > 4 else a for a in f) for f in frames]
+        out_pinned = True
+    except Exception:
+        out_pinned = False
     out = {"metric": f"keyframes/sec, semantic flow ({s.width}x{s.height}, assign+remap+integrate, cpp/volumetric semantics)", "unit": "keyframes/s",
            "n_gpus": 1, "voxel": args.voxel, "frames": args.frames, "config": config}
     # algorithmic bytes per keyframe (SURVEY 8d shape): every distinct voxel a keyframe touches is read and written once (64 B voting /
@@ -44,6 +57,7 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
     b_in = s.width * s.height * 15
     host_flow = os.environ.get("PYSLAM_AMD_SEMANTIC_DEVICE_FLOW", "1") == "0"  # A/B: every call stages its own host inputs (round 2)
     out["flow"] = "host images staged by every call" if host_flow else "one upload per image, steps on device tensors (the integrator's flow)"
+    out["host_images"] = "page-locked (as in the front's registered ring), asynchronous uploads" if out_pinned else "pageable"
     for name, cls, kind in (("voting", VoxelBlockSemanticGrid, 0), ("probabilistic", VoxelBlockSemanticProbabilisticGrid, 1)):
         g = cls(args.voxel, 8, max_blocks=1 << 17, max_points=max(1 << 20, s.width * s.height))
         fr = CameraFrustrum(*intr, s.width, s.height, np.eye(4), depth_max=8.0, depth_min=0.01)
@@ -54,13 +68,20 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
             # one upload each, every step on the device copies
             import torch
 
+            ctx = torch.cuda.stream(g.adopt_torch_stream()) if not host_flow else contextlib.nullcontext()
+            with ctx:
+                run_body(frames_)
+
+        def run_body(frames_):
+            import torch
+
             for depth, rgb, T, cls_img, inst_img in frames_:
                 if host_flow:
                     d = g.filter_shadow_points(depth)
                     c, cl, ins = rgb, cls_img, inst_img
                 else:
-                    d = g.filter_shadow_points(torch.from_numpy(depth).cuda())
-                    c, cl, ins = torch.from_numpy(rgb).cuda(), torch.from_numpy(cls_img).cuda(), torch.from_numpy(inst_img).cuda()
+                    d = g.filter_shadow_points(torch.from_numpy(depth).cuda(non_blocking=True))
+                    c, cl, ins = (torch.from_numpy(a).cuda(non_blocking=True) for a in (rgb, cls_img, inst_img))
                 fr.set_T_cw(T)
                 m = g.assign_object_ids_to_instance_ids(fr, cl, ins, d, depth_threshold=0.03, do_carving=False,
                                                         min_vote_ratio=0.5, min_votes=3)
