@@ -315,6 +315,8 @@ struct hv_volume {
     // (association vote, carve, get_voxels, segments, size) used to read all 64 / 128-byte records to find them; with the bit a
     // lane reads its record only when the bit is set.  [max_blocks * bs^3 / 64] words, pool order.
     unsigned long long *occ = nullptr;
+    void *semb_tasks = nullptr;              // semantic bucket path: the big buckets' (block, voxel range) tasks
+    size_t semb_tasks_bytes = 0;
 
     // staging for HV_HOST inputs
     void *stage_a = nullptr;

@@ -51,6 +51,7 @@ struct HvSemParams {
     int32_t bs, nvox, local_bits;
     float depth_threshold;  // kDepthThreshold
     float depth_decay_rate; // kDepthDecayRate (probabilistic payload only)
+    int32_t owner_rank, owner_world; // multi-GPU block ownership (hv_set_owner): points of blocks another GPU owns are skipped
 };
 
 // The reference calls std::exp / std::log on floats (glibc expf/logf, < 1 ulp and correctly rounded
@@ -296,6 +297,8 @@ static inline HvSemParams sem_params(const hv_volume *v) {
     G.local_bits = v->local_bits;
     G.depth_threshold = v->sem_depth_threshold;
     G.depth_decay_rate = v->sem_depth_decay_rate;
+    G.owner_rank = v->owner_rank;
+    G.owner_world = v->owner_world;
     return G;
 }
 static inline bool hv_is_semantic(const hv_volume *v) {

@@ -21,6 +21,7 @@
 #include "hv_common.h"
 #include "hv_query.h"
 #include "hv_semantic.h"
+#include "hv_bucket.h"
 #include <rocprim/device/device_radix_sort.hpp>
 
 static constexpr uint32_t HV_SORT_SENTINEL = 0xFFFFFFFFu;
@@ -60,7 +61,12 @@ __global__ __launch_bounds__(256) void k_sem_keys(HvTable table, const PT *__res
             l[a] = (int32_t)((int64_t)v - (int64_t)b[a] * G.bs);
         }
         if (hv_key_in_range(b[0], b[1], b[2])) {
-            const int32_t slot = hv_table_insert(table, hv_pack_key(b[0], b[1], b[2]));
+            const unsigned long long bkey = hv_pack_key(b[0], b[1], b[2]);
+            if (G.owner_world > 1 && hv_owner_of(bkey, G.owner_world) != G.owner_rank) { // another GPU's block: not this GPU's point
+                keys_out[i] = HV_SORT_SENTINEL;
+                return;
+            }
+            const int32_t slot = hv_table_insert(table, bkey);
             if (slot >= 0) key = ((uint32_t)slot << G.local_bits) | (uint32_t)(l[0] + l[1] * G.bs + l[2] * G.bs * G.bs);
         }
     }
@@ -68,51 +74,43 @@ __global__ __launch_bounds__(256) void k_sem_keys(HvTable table, const PT *__res
     keys_out[i] = key;
 }
 
-// update_voxel_direct (voxel_block_grid.hpp:524-614) for a SemanticVoxelWithDepth payload, folded over
-// one voxel's run in point-index order.  VOX = HvSemVoxel (voting) or HvProbVoxel (probabilistic).
-template <typename VOX, typename PT, int COLOR_KIND>
-__global__ __launch_bounds__(256) void k_sem_reduce(HvTable table, VOX *__restrict__ pool,
-                                                     const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                     int64_t n, HvSemParams G, const PT *__restrict__ pts,
-                                                     const void *__restrict__ cols, const int32_t *__restrict__ class_ids,
-                                                     const int32_t *__restrict__ instance_ids,
-                                                     const float *__restrict__ depths, unsigned long long *__restrict__ occ) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t key = keys[i];
-    if (key == HV_SORT_SENTINEL) return;
-    if (i > 0 && keys[i - 1] == key) return;
-    const int32_t idx = table.vals[(int32_t)(key >> G.local_bits)];
-    if (idx < 0) return;
-    const int64_t vid = (int64_t)idx * G.nvox + (key & ((1u << G.local_bits) - 1u));
-    VOX *vx = pool + vid;
-    int32_t count = vx->count;
+// update_voxel_direct (voxel_block_grid.hpp:524-614) for a SemanticVoxelWithDepth payload: one voxel's points folded in
+// point-index order.  `next(j)` yields the point index of the run's j-th entry, or -1 at its end.  VOX = HvSemVoxel (voting) or
+// HvProbVoxel (probabilistic).
+template <typename VOX, typename PT, int COLOR_KIND, typename Next>
+__device__ __forceinline__ void sem_fold_run(const HvTable &table, VOX *__restrict__ pool, int64_t vid, const HvSemParams &G,
+                                             const PT *__restrict__ pts, const void *__restrict__ cols,
+                                             const int32_t *__restrict__ class_ids, const int32_t *__restrict__ instance_ids,
+                                             const float *__restrict__ depths, unsigned long long *__restrict__ occ, Next next) {
+    // the voxel is read once, folded in registers and written once: with the label state updated in memory point by point the
+    // loads of the next point could not be issued before the stores of this one (they may alias): one memory round trip per point
+    VOX acc = pool[vid];
+    int32_t count = acc.count;
     if (count == 0) atomicOr(&occ[vid >> 6], 1ull << (vid & 63)); // first point of this voxel (or the first after a reset)
-    double pos[3] = {vx->pos[0], vx->pos[1], vx->pos[2]};
-    float col[3] = {vx->col[0], vx->col[1], vx->col[2]};
     const float inv_255 = 1.0f / 255.0f;
-    int64_t j = i;
-    do {
-        const int64_t p = vals[j];
-        pos[0] += (double)pts[p * 3 + 0];
-        pos[1] += (double)pts[p * 3 + 1];
-        pos[2] += (double)pts[p * 3 + 2];
+    int overflowed = 0;
+    for (int j = 0;; ++j) {
+        const int64_t p = next(j);
+        if (p < 0) break;
+        acc.pos[0] += (double)pts[p * 3 + 0];
+        acc.pos[1] += (double)pts[p * 3 + 1];
+        acc.pos[2] += (double)pts[p * 3 + 2];
         if (COLOR_KIND == HV_COLOR_U8) {
             const uint8_t *c = (const uint8_t *)cols + p * 3;
-            col[0] += (float)c[0] * inv_255;
-            col[1] += (float)c[1] * inv_255;
-            col[2] += (float)c[2] * inv_255;
+            acc.col[0] += (float)c[0] * inv_255;
+            acc.col[1] += (float)c[1] * inv_255;
+            acc.col[2] += (float)c[2] * inv_255;
         } else if (COLOR_KIND == HV_COLOR_F32) {
             const float *c = (const float *)cols + p * 3;
-            col[0] += c[0];
-            col[1] += c[1];
-            col[2] += c[2];
+            acc.col[0] += c[0];
+            acc.col[1] += c[1];
+            acc.col[2] += c[2];
         }
         if (class_ids != nullptr) {
             const int32_t obj = instance_ids ? instance_ids[p] : 0;
             const int32_t cls = class_ids[p];
             if constexpr (sizeof(VOX) == sizeof(HvSemVoxel)) {
-                HvSemVoxel *sv = (HvSemVoxel *)vx;
+                HvSemVoxel *sv = (HvSemVoxel *)&acc;
                 const bool gate = depths ? (depths[p] < G.depth_threshold) : true; // *_with_depth, voxel_data_semantic.h:168-198
                 if (count == 0) {
                     if (gate) { // initialize_semantics
@@ -134,19 +132,319 @@ __global__ __launch_bounds__(256) void k_sem_reduce(HvTable table, VOX *__restri
                 }
             } else {
                 const float lp = prob_observation_log_prob(depths != nullptr, depths ? depths[p] : 0.0f, G);
-                if (!prob_fold((HvProbVoxel *)vx, count == 0, obj, cls, lp)) atomicAdd(&table.counters[HV_CNT_LABEL_OVERFLOW], 1);
+                if (!prob_fold((HvProbVoxel *)&acc, count == 0, obj, cls, lp)) ++overflowed;
             }
         }
         count = count == 0 ? 1 : count + 1;
-        ++j;
-    } while (j < n && keys[j] == key);
-    vx->count = count;
-    vx->pos[0] = pos[0];
-    vx->pos[1] = pos[1];
-    vx->pos[2] = pos[2];
-    vx->col[0] = col[0];
-    vx->col[1] = col[1];
-    vx->col[2] = col[2];
+    }
+    acc.count = count;
+    pool[vid] = acc;
+    if (overflowed) atomicAdd(&table.counters[HV_CNT_LABEL_OVERFLOW], overflowed);
+}
+
+// radix path: the run of sorted key i (head thread only)
+template <typename VOX, typename PT, int COLOR_KIND>
+__global__ __launch_bounds__(256) void k_sem_reduce(HvTable table, VOX *__restrict__ pool,
+                                                     const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                     int64_t n, HvSemParams G, const PT *__restrict__ pts,
+                                                     const void *__restrict__ cols, const int32_t *__restrict__ class_ids,
+                                                     const int32_t *__restrict__ instance_ids,
+                                                     const float *__restrict__ depths, unsigned long long *__restrict__ occ) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t key = keys[i];
+    if (key == HV_SORT_SENTINEL) return;
+    if (i > 0 && keys[i - 1] == key) return;
+    const int32_t idx = table.vals[(int32_t)(key >> G.local_bits)];
+    if (idx < 0) return;
+    const int64_t vid = (int64_t)idx * G.nvox + (key & ((1u << G.local_bits) - 1u));
+    sem_fold_run<VOX, PT, COLOR_KIND>(table, pool, vid, G, pts, cols, class_ids, instance_ids, depths, occ,
+                                      [&](int j) -> int64_t { return (i + j < n && keys[i + j] == key) ? (int64_t)vals[i + j] : -1; });
+}
+
+// ---- per-keyframe bucket path (hv_bucket.h): count -> offsets -> scatter -> fold (+ the big buckets' ranges), 5 launches instead of the radix sort's ~20 ----
+// entries are (local voxel index << IB | point index) with IB = 32 - local_bits (23 for 8^3 blocks: 8 M points per call)
+template <typename PT>
+__global__ __launch_bounds__(256) void k_semb_count(HvTable table, const PT *__restrict__ pts, int64_t n, HvSemParams G,
+                                                     int32_t *__restrict__ pslot, uint32_t *__restrict__ plidx,
+                                                     const uint32_t *__restrict__ valid_mask_keys, int32_t *__restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t slot = -1;
+    uint32_t lidx = 0;
+    if (i < n && !(valid_mask_keys != nullptr && valid_mask_keys[i] == HV_SORT_SENTINEL)) {
+        const PT p[3] = {pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]};
+        bool ok = true, foreign = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ok = ok && isfinite((double)p[a]) && fabs((double)p[a] * (double)G.inv_voxel_size) < 1.0e9;
+        if (ok) {
+            int32_t b[3], l[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int32_t v = sem_voxel_coord(p[a], G.inv_voxel_size);
+                b[a] = sem_floor_div(v, G.bs);
+                l[a] = (int32_t)((int64_t)v - (int64_t)b[a] * G.bs);
+            }
+            if (hv_key_in_range(b[0], b[1], b[2])) {
+                const unsigned long long bkey = hv_pack_key(b[0], b[1], b[2]);
+                foreign = G.owner_world > 1 && hv_owner_of(bkey, G.owner_world) != G.owner_rank;
+                if (!foreign) slot = hv_table_insert(table, bkey);
+                lidx = (uint32_t)(l[0] + l[1] * G.bs + l[2] * G.bs * G.bs);
+            }
+        }
+        if (slot < 0 && !foreign) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
+    }
+    if (i < n) {
+        pslot[i] = slot;
+        plidx[i] = lidx;
+    }
+    const HvWaveGroup g = hv_wave_group_by(slot);
+    if (g.leader) atomicAdd(&cnt[slot], g.size);
+}
+
+__global__ __launch_bounds__(256) void k_semb_scatter(const int32_t *__restrict__ pslot, const uint32_t *__restrict__ plidx, int64_t n,
+                                                       int32_t *__restrict__ cur, uint32_t *__restrict__ entries, int idx_bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t slot = i < n ? pslot[i] : -1;
+    const HvWaveGroup g = hv_wave_group_by(slot);
+    int32_t base = 0;
+    if (g.leader) base = atomicAdd(&cur[slot], g.size);
+    base = __shfl(base, g.leader_lane);
+    if (slot >= 0) entries[base + g.rank] = (plidx[i] << idx_bits) | (uint32_t)i;
+}
+
+// Entries s_src[0 .. m) of ONE block into (voxel, point index) order, by a wave, in its LDS window: counting sort by voxel
+// (histogram, prefix, scatter) and a rank inside each voxel's short run - a handful of passes over m entries instead of the
+// O(log^2) passes of a bitonic sort with a wave barrier each (which cost 9 us for a 256-entry bucket).  Runs longer than 48 (coarse
+// voxels) take the bitonic sort.  off[] needs nvox + 1 words; the sorted entries end up in s_src.
+__device__ __forceinline__ void semb_sort_window(uint32_t *s_src, uint32_t *s_dst, uint32_t *off, int m, int idx_bits, int nvox) {
+    const int lane = hv_lane_id();
+    for (int v = lane; v <= nvox; v += HV_WAVE) off[v] = 0u;
+    hv_wave_lds_sync();
+    for (int e = lane; e < m; e += HV_WAVE) atomicAdd(&off[s_src[e] >> idx_bits], 1u);
+    hv_wave_lds_sync();
+    // exclusive prefix over the voxels (lane l: voxels [l * per, (l + 1) * per)), the longest run on the way
+    const int per = (nvox + HV_WAVE - 1) / HV_WAVE;
+    uint32_t sum = 0, longest = 0;
+    for (int k = 0; k < per; ++k) {
+        const int v = lane * per + k;
+        const uint32_t c = v < nvox ? off[v] : 0u;
+        sum += c;
+        longest = max(longest, c);
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < HV_WAVE; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
+    if (longest > 48u) { // long runs: the rank pass below is quadratic in the run length
+        int m2 = HV_WAVE;
+        while (m2 < m) m2 <<= 1;
+        for (int e = m + lane; e < m2; e += HV_WAVE) s_src[e] = 0xFFFFFFFFu;
+        hv_wave_lds_sync();
+        hv_vgb_bitonic_wave(s_src, m2);
+        return;
+    }
+    uint32_t run = incl - sum;
+    hv_wave_lds_sync();
+    for (int k = 0; k < per; ++k) {
+        const int v = lane * per + k;
+        if (v < nvox) {
+            const uint32_t c = off[v];
+            off[v] = run; // start of voxel v's run (the scatter advances it to the run's end = the next run's start)
+            run += c;
+        }
+    }
+    hv_wave_lds_sync();
+    for (int e = lane; e < m; e += HV_WAVE) {
+        const uint32_t ent = s_src[e];
+        s_dst[atomicAdd(&off[ent >> idx_bits], 1u)] = ent;
+    }
+    hv_wave_lds_sync();
+    for (int q = lane; q < m; q += HV_WAVE) {
+        const uint32_t ent = s_dst[q];
+        const uint32_t v = ent >> idx_bits;
+        const int a0 = v == 0u ? 0 : (int)off[v - 1], b0 = (int)off[v];
+        int rank = 0;
+        for (int r = a0; r < b0; ++r) rank += s_dst[r] < ent;
+        s_src[a0 + rank] = ent;
+    }
+    hv_wave_lds_sync();
+}
+
+// One wave per touched block: its bucket is brought into (voxel, point index) order in the wave's LDS window (semb_sort_window)
+// and the head lane of every voxel run folds the run in point order - the reference's sequential order, bit-identical to the radix
+// path.  Buckets beyond the window go to k_semb_fold_tasks (or, without a task list, through voxel ranges / point windows here).
+template <typename VOX, typename PT, int COLOR_KIND>
+__global__ __launch_bounds__(256) void k_semb_fold_wave(HvTable table, VOX *__restrict__ pool, const int32_t *__restrict__ touched, int parity,
+                                                         unsigned long long *__restrict__ cursor_and_len, int32_t *__restrict__ cnt,
+                                                         const int32_t *__restrict__ cur, const uint32_t *__restrict__ entries,
+                                                         HvSemParams G, const PT *__restrict__ pts, const void *__restrict__ cols,
+                                                         const int32_t *__restrict__ class_ids, const int32_t *__restrict__ instance_ids,
+                                                         const float *__restrict__ depths, unsigned long long *__restrict__ occ,
+                                                         int64_t n_points, int idx_bits, HvStatus *status, int32_t status_seq,
+                                                         int32_t *__restrict__ task_count, int4 *__restrict__ tasks, int task_cap) {
+    extern __shared__ uint32_t s_dyn[]; // per wave: [WCAP src][WCAP dst][nvox + 64 offsets]
+    const int n_touched = (int)(cursor_and_len[parity] >> 32);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        task_count[parity ^ 1] = 0;        // the next call's task list
+        cursor_and_len[parity ^ 1] = 0ull; // the next call's bucket cursor and list length
+        table.counters[HV_CNT_OUT2] = 0;   // (k_vgb_offsets' largest-bucket mark: the association uses this counter too)
+        hv_publish_status(table, status, status_seq);
+    }
+    const int wave = threadIdx.x >> 6, lane = hv_lane_id();
+    const int per_wave = 2 * HV_VGB_WCAP + G.nvox + 64;
+    uint32_t *s = s_dyn + wave * per_wave, *s_dst = s + HV_VGB_WCAP, *off = s + 2 * HV_VGB_WCAP;
+    const uint32_t idx_mask = (1u << idx_bits) - 1u;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    auto fold_sorted = [&](int m, int64_t block_base) {
+        for (int e = lane; e < m; e += HV_WAVE) {
+            const uint32_t lidx = s[e] >> idx_bits;
+            if (e > 0 && (s[e - 1] >> idx_bits) == lidx) continue; // not the head of its voxel's run
+            sem_fold_run<VOX, PT, COLOR_KIND>(table, pool, block_base + lidx, G, pts, cols, class_ids, instance_ids, depths, occ,
+                                              [&](int j) -> int64_t { return (e + j < m && (s[e + j] >> idx_bits) == lidx) ? (int64_t)(s[e + j] & idx_mask) : -1; });
+        }
+    };
+    for (int t = blockIdx.x * 4 + wave; t < n_touched; t += gridDim.x * 4) {
+        const int32_t slot = touched[t];
+        const int32_t nb = cnt[slot];
+        const int32_t start = cur[slot] - nb;
+        const int32_t idx = table.vals[slot];
+        hv_wave_lds_sync(); // the window of the previous bucket is no longer read
+        if (lane == 0) cnt[slot] = 0; // clean for the next call
+        if (idx < 0) continue;        // (the block did not get a pool slot: overflow, reported by the caller)
+        const int64_t block_base = (int64_t)idx * G.nvox;
+        if (nb <= HV_VGB_WCAP) {
+            for (int e = lane; e < nb; e += HV_WAVE) s[e] = entries[start + e];
+            hv_wave_lds_sync();
+            semb_sort_window(s, s_dst, off, nb, idx_bits, G.nvox);
+            fold_sorted(nb, block_base);
+            continue;
+        }
+        if (tasks != nullptr) {
+            // A bucket beyond the window (a wall at 0.7 m puts ~3 000 points of a 640x480 keyframe into one 8 cm block) would be a
+            // long serial job for this wave while the other waves of the launch have long left: it is cut into its voxel-index
+            // ranges of 64 and handed to k_semb_fold_tasks, one wave per range.
+            const int n_ranges = (G.nvox + 63) / 64;
+            int32_t at = 0;
+            if (lane == 0) at = atomicAdd(&task_count[parity], n_ranges);
+            at = __shfl(at, 0);
+            if (at + n_ranges <= task_cap) {
+                if (lane < n_ranges) tasks[at + lane] = make_int4(idx, lane, nb, start);
+                continue;
+            }
+            if (lane == 0) atomicSub(&task_count[parity], n_ranges); // (no room: this wave does it itself, below)
+        }
+        // voxel-index ranges narrow enough for a range's entries to fit the window; a range that still overflows (very many points
+        // in few voxels) is folded in point-index windows (a voxel's points still arrive in order)
+        int parts = 2;
+        while (nb / parts > HV_VGB_WCAP / 2 && parts < G.nvox) parts <<= 1;
+        const int width = (G.nvox + parts - 1) / parts;
+        for (int lo = 0; lo < G.nvox; lo += width) {
+            const uint32_t hi = (uint32_t)(lo + width);
+            for (int64_t w = -1; w < n_points; w += HV_VGB_WCAP) { // w = -1: the whole range at once
+                hv_wave_lds_sync();
+                int m = 0;
+                bool overflow = false;
+                for (int e0 = 0; e0 < nb; e0 += HV_WAVE) {
+                    const int e = e0 + lane;
+                    const uint32_t ent = e < nb ? entries[start + e] : 0u;
+                    const uint32_t li = ent >> idx_bits;
+                    const int64_t p = ent & idx_mask;
+                    const bool in = e < nb && li >= (uint32_t)lo && li < hi && (w < 0 || (p >= w && p < w + HV_VGB_WCAP));
+                    const unsigned long long bm = __ballot(in);
+                    if (m + __popcll(bm) > HV_VGB_WCAP) {
+                        overflow = true;
+                        break;
+                    }
+                    if (in) s[m + __popcll(bm & lt)] = ent;
+                    m += __popcll(bm);
+                }
+                if (overflow) {
+                    w = -(int64_t)HV_VGB_WCAP; // next: w = 0
+                    continue;
+                }
+                if (m > 0) {
+                    hv_wave_lds_sync();
+                    semb_sort_window(s, s_dst, off, m, idx_bits, G.nvox);
+                    fold_sorted(m, block_base);
+                }
+                if (w < 0) break;
+            }
+        }
+    }
+}
+
+// The deferred big buckets: one wave per (block, range of 64 voxel indices).  The range's entries are picked out of the bucket
+// (ballot compaction, four loads in flight), sorted and folded like a small bucket; a range that overflows the window goes through
+// point-index windows.
+template <typename VOX, typename PT, int COLOR_KIND>
+__global__ __launch_bounds__(256) void k_semb_fold_tasks(HvTable table, VOX *__restrict__ pool, const int32_t *__restrict__ task_count,
+                                                          const int4 *__restrict__ tasks, int parity, int task_cap,
+                                                          const uint32_t *__restrict__ entries, HvSemParams G, const PT *__restrict__ pts,
+                                                          const void *__restrict__ cols, const int32_t *__restrict__ class_ids,
+                                                          const int32_t *__restrict__ instance_ids, const float *__restrict__ depths,
+                                                          unsigned long long *__restrict__ occ, int64_t n_points, int idx_bits) {
+    extern __shared__ uint32_t s_dyn[];
+    const int n_tasks = min(task_count[parity], task_cap);
+    const int wave = threadIdx.x >> 6, lane = hv_lane_id();
+    const int per_wave = 2 * HV_VGB_WCAP + G.nvox + 64;
+    uint32_t *s = s_dyn + wave * per_wave, *s_dst = s + HV_VGB_WCAP, *off = s + 2 * HV_VGB_WCAP;
+    const uint32_t idx_mask = (1u << idx_bits) - 1u;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int t = blockIdx.x * 4 + wave; t < n_tasks; t += gridDim.x * 4) {
+        const int4 task = tasks[t];
+        const int64_t block_base = (int64_t)task.x * G.nvox;
+        const uint32_t lo = (uint32_t)task.y * 64u, hi = lo + 64u;
+        const int nb = task.z, start = task.w;
+        auto fold_sorted = [&](int m) {
+            for (int e = lane; e < m; e += HV_WAVE) {
+                const uint32_t lidx = s[e] >> idx_bits;
+                if (e > 0 && (s[e - 1] >> idx_bits) == lidx) continue;
+                sem_fold_run<VOX, PT, COLOR_KIND>(table, pool, block_base + lidx, G, pts, cols, class_ids, instance_ids, depths, occ,
+                                                  [&](int j) -> int64_t { return (e + j < m && (s[e + j] >> idx_bits) == lidx) ? (int64_t)(s[e + j] & idx_mask) : -1; });
+            }
+        };
+        for (int64_t w = -1; w < n_points; w += HV_VGB_WCAP) { // w = -1: the whole range at once; on overflow: point-index windows
+            hv_wave_lds_sync();
+            int m = 0;
+            bool overflow = false;
+            for (int e0 = 0; e0 < nb && !overflow; e0 += 4 * HV_WAVE) {
+                uint32_t ent[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { // four independent loads in flight
+                    const int e = e0 + k * HV_WAVE + lane;
+                    ent[k] = e < nb ? entries[start + e] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = e0 + k * HV_WAVE + lane;
+                    const uint32_t li = ent[k] >> idx_bits;
+                    const int64_t p = ent[k] & idx_mask;
+                    const bool in = e < nb && li >= lo && li < hi && (w < 0 || (p >= w && p < w + HV_VGB_WCAP));
+                    const unsigned long long bm = __ballot(in);
+                    if (m + __popcll(bm) > HV_VGB_WCAP) {
+                        overflow = true;
+                        break;
+                    }
+                    if (in) s[m + __popcll(bm & lt)] = ent[k];
+                    m += __popcll(bm);
+                }
+            }
+            if (overflow) { // (only possible for w = -1: a window holds at most WCAP distinct point indices)
+                w = -(int64_t)HV_VGB_WCAP; // next iteration: w = 0
+                continue;
+            }
+            if (m > 0) {
+                hv_wave_lds_sync();
+                semb_sort_window(s, s_dst, off, m, idx_bits, G.nvox);
+                fold_sorted(m);
+            }
+            if (w < 0) break; // the range fitted: done
+        }
+    }
 }
 
 // get_voxels(min_count, min_confidence) (voxel_block_grid.hpp:785-817, semantic branch) and, with Q.kind 1 / 2,
@@ -262,6 +560,66 @@ static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d
     bool checked = false;
     int rc = hv_capacity_gate(v, &checked); // may grow the pool: the sort-key width follows the table
     if (rc != HV_OK) return rc;
+    // Per-keyframe bucket path (round 4; HV_SEM_PATH=sort keeps the device-wide radix sort: A/B, tests): needs the point index
+    // and the local voxel index in one 32-bit entry.
+    const int idx_bits = 32 - v->local_bits;
+    const char *force = getenv("HV_SEM_PATH");
+    const size_t fold_lds = 4 * sizeof(uint32_t) * (size_t)(2 * HV_VGB_WCAP + G.nvox + 64); // the fold's LDS: two windows + per-voxel offsets per wave
+    if (n < (1ll << idx_bits) && n <= (int64_t)v->cfg.max_points && fold_lds <= 64 * 1024 && !(force && strcmp(force, "sort") == 0)) {
+        int parity = 0;
+        for (int attempt = 0;; ++attempt) {
+            rc = ensure_bucket_buffers(v);
+            if (rc != HV_OK) return rc;
+            parity = v->vg_parity;
+            hipLaunchKernelGGL(k_semb_count<PT>, dim3(blocks), dim3(256), 0, v->stream, v->table, d_pts, n, G, (int32_t *)v->sort_vals_in,
+                               v->sort_keys_out, valid_mask_keys, v->vg_cnt);
+            if (!checked) break;
+            rc = hv_claims_fit(v); // blocks that did not fit: grow and claim again (the counts restart from clean arrays)
+            if (rc == HV_OK) break;
+            v->vg_cap = 0;
+            if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
+        }
+        v->vg_parity ^= 1;
+        const unsigned list_blocks = (unsigned)((v->cfg.max_blocks + 255) / 256);
+        hipLaunchKernelGGL(k_vgb_offsets, dim3(list_blocks), dim3(256), 0, v->stream, v->table, v->vg_touched, v->vg_cursor + parity,
+                           (const int32_t *)v->vg_cnt, v->vg_cur);
+        hipLaunchKernelGGL(k_semb_scatter, dim3(blocks), dim3(256), 0, v->stream, (const int32_t *)v->sort_vals_in,
+                           (const uint32_t *)v->sort_keys_out, n, v->vg_cur, v->sort_keys_in, idx_bits);
+        const int32_t seq = hv_next_status_seq(v);
+        const unsigned fold_grid = (unsigned)std::min<int64_t>(std::max<int64_t>(n / 128, 256), 16384);
+        VOX *bpool = (VOX *)v->pool;
+        // task list of the big buckets: [2 counters (one per parity)][tasks]; at most n / HV_SEMB_BIG buckets are big
+        const int task_cap = (int)std::min<int64_t>((n / HV_VGB_WCAP + 1) * ((G.nvox + 63) / 64), 1 << 22);
+        const size_t task_bytes = 256 + sizeof(int4) * (size_t)task_cap;
+        if (v->semb_tasks == nullptr || v->semb_tasks_bytes < task_bytes) {
+            rc = hv_ensure_buffer(v, &v->semb_tasks, &v->semb_tasks_bytes, task_bytes);
+            if (rc != HV_OK) return rc;
+            HV_HIP(hipMemsetAsync(v->semb_tasks, 0, 256, v->stream));
+        }
+        int32_t *task_count = (int32_t *)v->semb_tasks;
+        int4 *tasks = (int4 *)((char *)v->semb_tasks + 256);
+        const bool use_tasks = !(getenv("HV_SEM_TASKS") && atoi(getenv("HV_SEM_TASKS")) == 0);
+        const size_t lds_bytes = 4 * sizeof(uint32_t) * (size_t)(2 * HV_VGB_WCAP + G.nvox + 64); // per wave: two windows + per-voxel offsets
+#define HV_LAUNCH_SEM_FOLD(CK)                                                                                           \
+    do {                                                                                                                 \
+        hipLaunchKernelGGL((k_semb_fold_wave<VOX, PT, CK>), dim3(fold_grid), dim3(256), lds_bytes, v->stream, v->table, bpool, \
+                           (const int32_t *)v->vg_touched, parity, v->vg_cursor, v->vg_cnt, (const int32_t *)v->vg_cur,   \
+                           (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, d_cls, d_inst, d_depths, v->occ, n,       \
+                           idx_bits, v->d_status, seq, task_count, use_tasks ? tasks : (int4 *)nullptr, task_cap);        \
+        if (use_tasks)                                                                                                   \
+            hipLaunchKernelGGL((k_semb_fold_tasks<VOX, PT, CK>), dim3(1024), dim3(256), lds_bytes, v->stream, v->table, bpool, \
+                               (const int32_t *)task_count, (const int4 *)tasks, parity, task_cap,                        \
+                               (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, d_cls, d_inst, d_depths, v->occ, n,   \
+                               idx_bits);                                                                                \
+    } while (0)
+        if (color_kind == HV_COLOR_U8) HV_LAUNCH_SEM_FOLD(HV_COLOR_U8);
+        else if (color_kind == HV_COLOR_F32) HV_LAUNCH_SEM_FOLD(HV_COLOR_F32);
+        else HV_LAUNCH_SEM_FOLD(HV_COLOR_NONE);
+#undef HV_LAUNCH_SEM_FOLD
+        HV_HIP(hipGetLastError());
+        v->frame_counter += 1;
+        return HV_OK;
+    }
     size_t bytes = 0;
     HV_HIP(rocprim::radix_sort_pairs(nullptr, bytes, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in, v->sort_vals_out,
                                      (size_t)n, 0, sem_sort_bits(v), v->stream));

@@ -20,6 +20,7 @@
 
 #include "hv_common.h"
 #include "hv_query.h"
+#include "hv_bucket.h"
 #include <rocprim/device/device_radix_sort.hpp>
 
 static constexpr uint32_t HV_SORT_SENTINEL = 0xFFFFFFFFu;
@@ -197,36 +198,6 @@ __global__ __launch_bounds__(256) void k_vg_unproject(const void *__restrict__ d
 //                  frame: coarse voxels / very close surfaces) are folded in point-index windows of 4096, still exact.
 // 4 launches instead of ~20.  Needs point indices < 2^20 and local_bits <= 12; larger inputs take the radix path.
 // ================================================================================================
-static constexpr int HV_VGB_IDX_BITS = 20;
-static constexpr int HV_VGB_CAP = 4096; // entries of one bucket sorted in LDS at a time
-
-// Lanes of a wave that hold the same slot form a group (neighbouring pixels fall into the same block: a wave of 64 points
-// meets a handful of distinct slots).  One lane per group - the leader - talks to memory; every member learns the group's
-// size and its own rank.  Ballot + shuffle only.
-struct HvWaveGroup {
-    bool leader;
-    int leader_lane, size, rank;
-};
-__device__ __forceinline__ HvWaveGroup hv_wave_group_by(int32_t slot) {
-    HvWaveGroup g{false, 0, 0, 0};
-    const int lane = hv_lane_id();
-    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    unsigned long long remaining = __ballot(slot >= 0);
-    while (remaining) {
-        const int first = __ffsll((long long)remaining) - 1;
-        const int32_t fslot = __shfl(slot, first);
-        const unsigned long long same = __ballot(slot == fslot) & remaining;
-        if (slot == fslot) {
-            g.leader = lane == first;
-            g.leader_lane = first;
-            g.size = __popcll(same);
-            g.rank = __popcll(same & lt);
-        }
-        remaining &= ~same;
-    }
-    return g;
-}
-
 // FUSED: the points do not exist yet - the thread unprojects its pixel (k_vg_unproject's arithmetic), stores point and colour
 // for the fold and goes on with the key: one launch and one pass over the points less per RGB-D frame.
 template <bool FUSED>
@@ -292,54 +263,6 @@ __global__ __launch_bounds__(256) void k_vgb_count(HvTable table, float *__restr
 // seven hardware atomics, global_atomic_add / global_atomic_add_f32; keys and counts exact, sums within the contract's 1e-4 -
 // runs at 89.9 us per 640x480 frame against 45.4 us for the four launches of the point-ordered bucket path: 2.1 M scattered
 // float atomics per frame are slower than sorting 12 points per block in LDS.  Taken out again.)
-// 1 thread / allocated block: blocks that received points this frame take their bucket range from the global cursor and
-// enter the frame's touched list - both with one atomic per wave (prefix sums inside the wave).
-static constexpr int HV_VGB_WCAP_DECL = 1024; // == HV_VGB_WCAP (defined with the wave fold below)
-__global__ __launch_bounds__(256) void k_vgb_offsets(HvTable table, int32_t *__restrict__ touched, unsigned long long *__restrict__ cursor_and_len,
-                                                      const int32_t *__restrict__ cnt, int32_t *__restrict__ cur) {
-    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    int32_t n_blocks = table.counters[HV_CNT_BLOCKS];
-    if (n_blocks > table.max_blocks) n_blocks = table.max_blocks;
-    int32_t slot = -1, c = 0;
-    if (b < n_blocks) {
-        slot = hv_table_find(table, table.block_keys[b]);
-        c = slot >= 0 ? cnt[slot] : 0;
-    }
-    const bool live = c > 0;
-    const int lane = hv_lane_id();
-    int32_t incl = c;
-#pragma unroll
-    for (int o = 1; o < HV_WAVE; o <<= 1) {
-        const int32_t up = __shfl_up(incl, o);
-        if (lane >= o) incl += up;
-    }
-    const int32_t total = __shfl(incl, HV_WAVE - 1);
-    const unsigned long long lm = __ballot(live);
-    // bucket cursor (low 32 bits) and list length (high 32 bits) move together: ONE returning atomic per wave
-    unsigned long long got = 0ull;
-    if (lane == HV_WAVE - 1 && total > 0)
-        got = atomicAdd(cursor_and_len, (unsigned long long)(uint32_t)total | ((unsigned long long)__popcll(lm) << 32));
-    got = __shfl(got, HV_WAVE - 1);
-    if (live) {
-        cur[slot] = (int32_t)(uint32_t)got + incl - c;
-        const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-        touched[(int32_t)(got >> 32) + __popcll(lm & lt)] = slot;
-    }
-    // a bucket beyond a wave's LDS window: tell the host (it picks the fold kernel of the NEXT frame by it)
-    if (c > HV_VGB_WCAP_DECL) atomicMax(&table.counters[HV_CNT_OUT2], c);
-}
-
-__global__ __launch_bounds__(256) void k_vgb_scatter(const int32_t *__restrict__ pslot, const uint32_t *__restrict__ plidx, int64_t n,
-                                                      int32_t *__restrict__ cur, uint32_t *__restrict__ entries) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int32_t slot = i < n ? pslot[i] : -1;
-    const HvWaveGroup g = hv_wave_group_by(slot);
-    int32_t base = 0;
-    if (g.leader) base = atomicAdd(&cur[slot], g.size);
-    base = __shfl(base, g.leader_lane);
-    if (slot >= 0) entries[base + g.rank] = (plidx[i] << HV_VGB_IDX_BITS) | (uint32_t)i;
-}
-
 // update_voxel_direct (voxel_block_grid.hpp:524-614) folded over the sorted entries s[0 .. m) of one block
 template <int COLOR_KIND>
 __device__ __forceinline__ void hv_vgb_fold_sorted(const uint32_t *s, int m, HvVoxel *__restrict__ block, const float *__restrict__ pts,
@@ -393,30 +316,6 @@ __device__ __forceinline__ void hv_vgb_bitonic(uint32_t *s, int m2) { // ascendi
     }
 }
 
-// Wave-level counterparts of the two helpers above: a wave owns its LDS window, lanes synchronise with wave barriers only.
-__device__ __forceinline__ void hv_wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ void hv_vgb_bitonic_wave(uint32_t *s, int m2) { // ascending, m2 a power of two >= 64
-    const int lane = hv_lane_id();
-    for (int k = 2; k <= m2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = lane; t < m2; t += HV_WAVE) {
-                const int x = t ^ j;
-                if (x > t) {
-                    const uint32_t a = s[t], b = s[x];
-                    const bool up = (t & k) == 0;
-                    if ((a > b) == up) {
-                        s[t] = b;
-                        s[x] = a;
-                    }
-                }
-            }
-            hv_wave_lds_sync();
-        }
-    }
-}
 template <int COLOR_KIND>
 __device__ __forceinline__ void hv_vgb_fold_sorted_wave(const uint32_t *s, int m, HvVoxel *__restrict__ block, const float *__restrict__ pts,
                                                         const void *__restrict__ cols) {
@@ -454,7 +353,6 @@ __device__ __forceinline__ void hv_vgb_fold_sorted_wave(const uint32_t *s, int m
 // spends its time in barriers).  Buckets of up to HV_VGB_WCAP entries are sorted in the wave's LDS window at once, larger ones
 // in point-index windows of HV_VGB_WCAP (correct for any size; when the previous frame had such buckets the host launches the
 // workgroup form k_vgb_fold instead).
-static constexpr int HV_VGB_WCAP = HV_VGB_WCAP_DECL;
 static constexpr int HV_VGB_RANK = 256; // buckets up to this size are rank-sorted (<= 4 entries per lane)
 static constexpr int HV_VGB_STAGE = 128; // ... and up to this size their points are staged in the window's spare 3 KB (24 B each)
 template <int COLOR_KIND>
@@ -895,25 +793,6 @@ static int ensure_sort_tmp(hv_volume *v, int64_t n) {
     return hv_ensure_buffer(v, &v->sort_tmp, &v->sort_tmp_bytes, bytes);
 }
 
-static int ensure_bucket_buffers(hv_volume *v) {
-    if (v->vg_cap == v->table_capacity && v->vg_cnt != nullptr) return HV_OK;
-    HV_HIP(hipStreamSynchronize(v->stream));
-    for (int32_t **p : {&v->vg_cnt, &v->vg_cur, &v->vg_touched}) {
-        if (*p) (void)hipFree(*p);
-        *p = nullptr;
-    }
-    if (v->vg_cursor == nullptr) HV_HIP(hipMalloc((void **)&v->vg_cursor, 2 * sizeof(unsigned long long)));
-    HV_HIP(hipMemsetAsync(v->vg_cursor, 0, 2 * sizeof(unsigned long long), v->stream));
-    HV_HIP(hipMalloc((void **)&v->vg_cnt, sizeof(int32_t) * v->table_capacity));
-    HV_HIP(hipMalloc((void **)&v->vg_cur, sizeof(int32_t) * v->table_capacity));
-    HV_HIP(hipMalloc((void **)&v->vg_touched, sizeof(int32_t) * v->table_capacity));
-    HV_HIP(hipMemsetAsync(v->vg_cnt, 0, sizeof(int32_t) * v->table_capacity, v->stream));
-    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT2], 0, sizeof(int32_t), v->stream));
-    v->vg_cap = v->table_capacity;
-    v->vg_parity = 0;
-    return HV_OK;
-}
-
 // keys -> group -> ordered reduce over device-resident points/colours.  Single frames (n < 2^20 points) take the bucket path
 // (4 launches), larger inputs - the batched replay - the device-wide radix sort; HV_VG_PATH=sort forces the latter (A/B, tests).
 // `frame` != nullptr: the points do not exist yet - they are one posed RGB-D frame (device pointers + unprojection constants);
@@ -1211,7 +1090,7 @@ extern "C" int hv_integrate_rgbd_points_batch(hv_volume *v, const void *depth, i
 // bit, and no collective runs while fusing).  hv_block_owner is the same function on the host (tests, planners).
 extern "C" int hv_set_owner(hv_volume *v, int32_t rank, int32_t world_size) {
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_set_owner: null volume");
-    HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_GRID, HV_ERR_MODE, "hv_set_owner: volume is not in VOXEL_GRID mode (TSDF: hv_tsdf_set_owner)");
+    HV_REQUIRE(v->cfg.mode != HV_MODE_TSDF, HV_ERR_MODE, "hv_set_owner: grid modes only (TSDF: hv_tsdf_set_owner)");
     HV_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, HV_ERR_INVALID, "hv_set_owner: bad rank/world");
     v->owner_rank = rank;
     v->owner_world = world_size;

@@ -19,6 +19,7 @@ from .volumetric_integrator_base import (
     VolumetricIntegrationPointCloud,
     VolumetricIntegrationTaskType,
     VolumetricIntegratorBase,
+    take_integrate_backlog,
 )
 from .volumetric_integrator_types import DatasetEnvironmentType
 
@@ -195,34 +196,39 @@ class VolumetricIntegratorVoxelSemanticGrid(VolumetricIntegratorBase):
         except Exception:
             return False
 
+    def _keyframe_arrays(self, color, depth, semantic_classes, semantic_instances):
+        """What a keyframe uploads: name -> (host array | None, dtype)."""
+        has_cls = semantic_classes is not None and np.asarray(semantic_classes).size > 0
+        use_inst = bool(Parameters.kVolumetricSemanticIntegrationUseInstanceIds and semantic_instances is not None
+                        and np.asarray(semantic_instances).size > 0)
+        return {"depth": (depth, np.float32), "color": (color, np.uint8), "cls": (semantic_classes if has_cls else None, np.int32),
+                "inst": (semantic_instances if use_inst else None, np.int32)}
+
     def _integrate_keyframe_on_device(self, color, depth, pose, semantic_classes, semantic_instances):
-        import torch
+        self.integrate_keyframes_on_device([(color, depth, pose, semantic_classes, semantic_instances)])
 
-        # one queue for torch's uploads and the volume's kernels: no cross-stream event waits between the steps
-        with torch.cuda.stream(self.volume.adopt_torch_stream()):
-            self._integrate_keyframe_on_device_body(color, depth, pose, semantic_classes, semantic_instances)
+    def integrate_keyframes_on_device(self, keyframes):
+        """keyframes: list of (color RGB u8, depth f32, T_cw, class image | None, instance image | None), fused in this order; the
+        images of keyframe k + 1 cross PCIe while keyframe k is fused (device_pipeline.KeyframeUploader)."""
+        from .device_pipeline import KeyframeUploader
 
-    def _integrate_keyframe_on_device_body(self, color, depth, pose, semantic_classes, semantic_instances):
-        import torch
+        if getattr(self, "_uploader", None) is None:
+            self._uploader = KeyframeUploader(self.volume)
 
-        dev = torch.device("cuda", int(self.volume._cfg.device))  # the volume's GPU, not torch's current device
+        def body(kf, t):
+            _, _, pose, _, _ = kf
+            self.integrate_2d_instance_ids = t["inst"] is not None
+            self._fuse_device_keyframe(t["color"], t["depth"], pose, t["cls"], t["inst"])
 
-        def up(a, dtype):
-            # keyframes arrive in the front's shared-memory ring, which the worker page-locks (hv_host_register): the copy is a DMA
-            # that returns at once; pageable sources fall back to torch's blocking copy by themselves
-            return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(dev, non_blocking=True)
+        self._uploader.run(keyframes, lambda kf: self._keyframe_arrays(kf[0], kf[1], kf[3], kf[4]), body)
 
-        depth_d = up(depth, np.float32)
+    def _fuse_device_keyframe(self, color_d, depth_d, pose, cls_d, inst_d):
+        """The INTEGRATE body on device-resident images (torch CUDA tensors on the volume's stream): nothing waits for the GPU."""
         if Parameters.kVolumetricIntegrationVoxelGridShadowPointsFilter:
             depth_d = self.volume.filter_shadow_points(depth_d)  # stays in HBM
-        color_d = up(color, np.uint8)
-        cls_d = up(semantic_classes, np.int32) if semantic_classes is not None and np.asarray(semantic_classes).size > 0 else None
-        inst_d = up(semantic_instances, np.int32) if self.integrate_2d_instance_ids else None
-        uploads_done = torch.cuda.Event()
-        uploads_done.record(torch.cuda.current_stream(dev))
         self.camera_frustrum.set_T_cw(pose)
         object_ids_d = None
-        if self.integrate_2d_instance_ids:  # same branches as the host flow below (no class image: empty map, every id -> -1)
+        if inst_d is not None:  # same branches as the host flow (no class image: empty map, every id -> -1)
             id_map = self.volume.assign_object_ids_to_instance_ids(
                 self.camera_frustrum, cls_d, inst_d, depth_d,
                 depth_threshold=Parameters.kVolumetricIntegrationVoxelGridCarvingDepthThreshold,
@@ -236,9 +242,6 @@ class VolumetricIntegratorVoxelSemanticGrid(VolumetricIntegratorBase):
         self.volume.integrate_rgbd(depth_d, color_d, fx, fy, cx, cy, pose, class_ids_image=cls_d, object_ids_image=object_ids_d,
                                    max_depth=self.volumetric_integration_depth_trunc,
                                    use_depths=Parameters.kVolumetricSemanticProbabilisticIntegrationUseDepth)
-        # the keyframe's host images (ring slots) are handed back when this call returns: the uploads - first in stream order, long
-        # done by now - must have read them
-        uploads_done.synchronize()
 
     def make_output(self, task_type):
         """The output block, reference :511-700."""
@@ -288,13 +291,26 @@ class VolumetricIntegratorVoxelSemanticGrid(VolumetricIntegratorBase):
                 else:
                     ttype = self.last_input_task.task_type
                     if ttype == VolumetricIntegrationTaskType.INTEGRATE:
-                        keyframe_data = self.last_input_task.keyframe_data
-                        if not Parameters.kVolumetricSemanticIntegrationUseInstanceIds:
-                            keyframe_data.semantic_instances_img = None
-                        color, depth, _, sem_cls, sem_inst = self.estimate_depth_if_needed_and_rectify(keyframe_data)
-                        if color is not None and depth is not None:
-                            self.integrate_keyframe(color, depth, keyframe_data.pose, sem_cls, sem_inst)
-                            self.last_integrated_id = keyframe_data.id
+                        # a backlog (offline reconstruction, rebuild()) is fused in queue order with the uploads of keyframe k + 1
+                        # beside the kernels of keyframe k; a single keyframe takes the same path
+                        tasks = [self.last_input_task]
+                        if self._device_flow():
+                            tasks += take_integrate_backlog(q_in, 7)
+                        ready = []
+                        for task in tasks:
+                            keyframe_data = task.keyframe_data
+                            if not Parameters.kVolumetricSemanticIntegrationUseInstanceIds:
+                                keyframe_data.semantic_instances_img = None
+                            color, depth, _, sem_cls, sem_inst = self.estimate_depth_if_needed_and_rectify(keyframe_data)
+                            if color is not None and depth is not None:
+                                ready.append((color, depth, keyframe_data.pose, sem_cls, sem_inst, keyframe_data.id))
+                        if ready and self._device_flow():
+                            self.integrate_keyframes_on_device([r[:5] for r in ready])
+                        else:
+                            for color, depth, pose, sem_cls, sem_inst, _ in ready:
+                                self.integrate_keyframe(color, depth, pose, sem_cls, sem_inst)
+                        if ready:
+                            self.last_integrated_id = ready[-1][5]
                             do_output = True
                             if self.last_output is not None:
                                 if time.perf_counter() - self.last_output.timestamp < Parameters.kVolumetricIntegrationOutputTimeInterval:

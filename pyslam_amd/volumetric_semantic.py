@@ -315,6 +315,10 @@ class _SemanticGridBase(_Volume):
         super().__init__(self._MODE, voxel_size, 0.0, block_size, 1, device, max_blocks, max_points)
         self.voxel_size, self.block_size = voxel_size, int(block_size)
 
+    def set_owner(self, rank, world_size):
+        """Multi-GPU block ownership (hv_set_owner): this grid fuses and stores only the blocks owner(block key) == rank."""
+        L.check(self._lib.hv_set_owner(self._h, int(rank), int(world_size)))
+
     def set_depth_threshold(self, depth_threshold):
         L.check(self._lib.hv_set_depth_threshold(self._h, float(depth_threshold)))
 

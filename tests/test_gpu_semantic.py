@@ -71,3 +71,21 @@ def test_depth_threshold_and_errors():
         gpu.integrate(pts, cols, None, inst)
     with pytest.raises(RuntimeError, match="same size"):
         gpu.integrate(pts, cols, cls[:-1])
+
+
+@pytest.mark.parametrize("voxel", [0.1, 0.25, 0.5])
+@pytest.mark.parametrize("pos_dtype", [np.float32, np.float64])
+def test_big_buckets_bit_exact(voxel, pos_dtype):
+    """The per-keyframe bucket path with buckets far beyond a wave's LDS window: 60 000 points in a 2 m cube with 0.8 / 2 / 4 m
+    blocks = 2 000 ... 60 000 points per block (voxel-index ranges; at 0.5 m a range still overflows -> point-index windows)."""
+    from pyslam_amd.volumetric_semantic import VoxelBlockSemanticGrid
+
+    gpu = VoxelBlockSemanticGrid(voxel, 8, max_blocks=1 << 10, max_points=1 << 17)
+    cpu = make_oracle(voxel)
+    for it in range(2):
+        pts, cols, cls, inst, dep = stream(900 + it, 60000, pos_dtype)
+        for g in (gpu, cpu):
+            g.integrate(pts, cols, cls, inst, dep)
+    assert gpu.dropped_points() == 0
+    for a, b in zip(gpu.dump(), cpu.dump()):
+        np.testing.assert_array_equal(a, b)

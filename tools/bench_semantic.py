@@ -29,6 +29,7 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
     from pyslam_amd.volumetric import CameraFrustrum
     from pyslam_amd.volumetric_semantic import (VoxelBlockSemanticGrid, VoxelBlockSemanticProbabilisticGrid,
                                                 remap_instance_ids, set_next_object_id)
+    from pyslam_amd.dense.device_pipeline import KeyframeUploader
     from tests.semantic_helpers import frame_points, semantic_frame
 
     s = SyntheticRGBD(config)
@@ -59,34 +60,31 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
     out["flow"] = "host images staged by every call" if host_flow else "one upload per image, steps on device tensors (the integrator's flow)"
     out["host_images"] = "page-locked (as in the front's registered ring), asynchronous uploads" if out_pinned else "pageable"
     for name, cls, kind in (("voting", VoxelBlockSemanticGrid, 0), ("probabilistic", VoxelBlockSemanticProbabilisticGrid, 1)):
-        g = cls(args.voxel, 8, max_blocks=1 << 17, max_points=max(1 << 20, s.width * s.height))
+        g = cls(args.voxel, 8, max_blocks=1 << (19 if args.voxel < 0.004 else 17), max_points=max(1 << 20, s.width * s.height))  # (a pool that does not have to grow inside the timed keyframes)
         fr = CameraFrustrum(*intr, s.width, s.height, np.eye(4), depth_max=8.0, depth_min=0.01)
         set_next_object_id(1)
 
+        def fuse(frame, t):
+            depth, rgb, T, cls_img, inst_img = frame
+            d = g.filter_shadow_points(t["depth"] if t is not None else depth)
+            c, cl, ins = (t["color"], t["cls"], t["inst"]) if t is not None else (rgb, cls_img, inst_img)
+            fr.set_T_cw(T)
+            m = g.assign_object_ids_to_instance_ids(fr, cl, ins, d, depth_threshold=0.03, do_carving=False, min_vote_ratio=0.5, min_votes=3)
+            obj = remap_instance_ids(ins, m, volume=g)
+            g.integrate_rgbd(d, c, *intr, T, class_ids_image=cl, object_ids_image=obj, max_depth=4.0, use_depths=True)
+
+        uploader = None if host_flow else KeyframeUploader(g)
+
         def run(frames_):
-            # the body of pyslam_amd/dense/volumetric_integrator_voxel_semantic_grid.py::_integrate_keyframe_on_device: host images in,
-            # one upload each, every step on the device copies
-            import torch
-
-            ctx = torch.cuda.stream(g.adopt_torch_stream()) if not host_flow else contextlib.nullcontext()
-            with ctx:
-                run_body(frames_)
-
-        def run_body(frames_):
-            import torch
-
-            for depth, rgb, T, cls_img, inst_img in frames_:
-                if host_flow:
-                    d = g.filter_shadow_points(depth)
-                    c, cl, ins = rgb, cls_img, inst_img
-                else:
-                    d = g.filter_shadow_points(torch.from_numpy(depth).cuda(non_blocking=True))
-                    c, cl, ins = (torch.from_numpy(a).cuda(non_blocking=True) for a in (rgb, cls_img, inst_img))
-                fr.set_T_cw(T)
-                m = g.assign_object_ids_to_instance_ids(fr, cl, ins, d, depth_threshold=0.03, do_carving=False,
-                                                        min_vote_ratio=0.5, min_votes=3)
-                obj = remap_instance_ids(ins, m, volume=g)
-                g.integrate_rgbd(d, c, *intr, T, class_ids_image=cl, object_ids_image=obj, max_depth=4.0, use_depths=True)
+            # what pyslam_amd/dense/volumetric_integrator_voxel_semantic_grid.py::integrate_keyframes_on_device does with a backlog of
+            # keyframes: host images in, one upload each on the copy stream (keyframe k + 1 beside the kernels of keyframe k), every
+            # step on the device copies, no host round trip inside a keyframe
+            if host_flow:
+                for f in frames_:
+                    fuse(f, None)
+                return
+            uploader.run(frames_, lambda f: {"depth": (f[0], np.float32), "color": (f[1], np.uint8), "cls": (f[3], np.int32),
+                                             "inst": (f[4], np.int32)}, fuse)
 
         run(frames[:2])
         g.synchronize()
