@@ -257,3 +257,82 @@ class ShardedVoxelGrid:
             return None
         rows = np.concatenate([g[:c].cpu().numpy() for g, c in zip(gathered, counts)], axis=0)
         return rows[:, :3], rows[:, 3:]
+
+
+class ShardedSemanticGrid:
+    """The semantic block grids on N GPUs (BASELINE configs[4]: "2 mm TSDF + semantic labels, 8 x MI355X").  Block ownership as for the
+    VOXEL_GRID (``hv_set_owner``: a rank fuses and stores the blocks owner(block key) == rank; the union of the ranks' grids is the
+    single grid bit for bit) - plus the ONE real exchange step of the semantic path: the per-keyframe association
+    (assign_object_ids_to_instance_ids, voxel_semantic_data_association.h:70-373) is a global vote.  Every rank votes with the voxels
+    it owns (``hv_assoc_vote``), the compacted (instance, object, votes) pair lists - a few hundred bytes - are all-gathered, every
+    rank decides on the concatenation with the reference's rules (``hv_assoc_decide``: the rules kernel adds the counts of equal
+    pairs) and so arrives at the same map and the same new object ids (the process-wide counters advance in lock step).
+    The grid is duck-typed (set_owner / _pair_exchange / integrate* / get_voxels ...): the exchange runs on CPU over gloo in tests/."""
+
+    def __init__(self, grid, rank=0, world_size=1, group=None):
+        self.grid, self.rank, self.world_size, self.group = grid, int(rank), int(world_size), group
+        self.last_exchange = None
+        if self.world_size > 1:
+            self.grid.set_owner(self.rank, self.world_size)
+            self.grid._pair_exchange = self.all_gather_pairs
+
+    def all_gather_pairs(self, keys, counts):
+        """-> the ranks' (keys u64, votes i32) lists concatenated in rank order - identical on every rank."""
+        import torch
+        import torch.distributed as dist
+
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+        keys = np.ascontiguousarray(keys, np.uint64)
+        counts = np.ascontiguousarray(counts, np.int32)
+        n_local = torch.tensor([len(keys)], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(n_local) for _ in range(self.world_size)]
+        dist.all_gather(sizes, n_local, group=self.group)
+        sizes = [int(x.item()) for x in sizes]
+        cap = max(max(sizes), 1)
+        # one message per rank: [cap] int64 keys followed by [cap] votes widened to int64
+        buf = torch.zeros(2 * cap, dtype=torch.int64, device=dev)
+        if len(keys):
+            buf[: len(keys)] = torch.from_numpy(keys.view(np.int64)).to(dev)
+            buf[cap : cap + len(keys)] = torch.from_numpy(counts.astype(np.int64)).to(dev)
+        gathered = [torch.zeros_like(buf) for _ in range(self.world_size)]
+        dist.all_gather(gathered, buf, group=self.group)
+        ks, cs = [], []
+        for g, m in zip(gathered, sizes):
+            g = g.cpu().numpy()
+            ks.append(g[:m].view(np.uint64))
+            cs.append(g[cap : cap + m].astype(np.int32))
+        out = np.concatenate(ks), np.concatenate(cs)
+        self.last_exchange = {"sizes": sizes, "bytes": int(2 * cap * 8 * self.world_size)}
+        return out
+
+    def __getattr__(self, name):  # integrate, integrate_rgbd, assign_object_ids_to_instance_ids, remap_instance_ids, get_voxels, ...
+        return getattr(self.grid, name)
+
+    def gather_voxels(self, min_count=1, min_confidence=0.0, root=0):
+        """-> (points f64 [M,3], colors f32, class_ids, object_ids, confidences) of the whole distributed grid on `root`, None elsewhere."""
+        v = self.grid.get_voxels(min_count, min_confidence)
+        rows = np.concatenate([np.asarray(v.points, np.float64), np.asarray(v.colors, np.float64), np.asarray(v.class_ids, np.float64)[:, None],
+                               np.asarray(v.object_ids, np.float64)[:, None], np.asarray(v.confidences, np.float64)[:, None]], axis=1) \
+            if len(v.points) else np.zeros((0, 9), np.float64)
+        if self.world_size > 1:
+            import torch
+            import torch.distributed as dist
+
+            on_gpu = dist.get_backend(self.group) == "nccl"
+            dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+            n_local = torch.tensor([len(rows)], dtype=torch.int64, device=dev)
+            sizes = [torch.zeros_like(n_local) for _ in range(self.world_size)]
+            dist.all_gather(sizes, n_local, group=self.group)
+            sizes = [int(x.item()) for x in sizes]
+            cap = max(max(sizes), 1)
+            buf = torch.zeros((cap, 9), dtype=torch.float64, device=dev)
+            if len(rows):
+                buf[: len(rows)] = torch.from_numpy(rows).to(dev)
+            gathered = [torch.zeros_like(buf) for _ in range(self.world_size)]
+            dist.all_gather(gathered, buf, group=self.group)
+            if self.rank != root:
+                return None
+            rows = np.concatenate([g[:m].cpu().numpy() for g, m in zip(gathered, sizes)], axis=0)
+        return (rows[:, 0:3], rows[:, 3:6].astype(np.float32), rows[:, 6].astype(np.int32), rows[:, 7].astype(np.int32),
+                rows[:, 8].astype(np.float32))

@@ -484,11 +484,27 @@ class _SemanticGridBase(_Volume):
 
     def assign_object_ids_to_instance_ids(self, camera_frustrum, class_ids_image, semantic_instances_image, depth_image=None,
                                           depth_threshold=0.1, do_carving=False, min_vote_ratio=0.5, min_votes=3):
-        """-> dict instance_id -> object_id (voxel_semantic_data_association.h:70-373)."""
+        """-> dict instance_id -> object_id (voxel_semantic_data_association.h:70-373), as a LazyIdMap: vote -> (multi-GPU: exchange
+        of the pair lists) -> decide are queued on the volume's stream and nothing waits; the map stays in device memory until
+        somebody reads it (remap_instance_ids on this volume uses it there)."""
+        if not self.assoc_vote(camera_frustrum, class_ids_image, semantic_instances_image, depth_image, depth_threshold, do_carving):
+            return {}
+        if self._pair_exchange is not None:
+            self.assoc_set_pairs(*self._pair_exchange(*self.assoc_pairs()))
+        return self.assoc_decide(min_vote_ratio, min_votes)
+
+    _pair_exchange = None  # multi-GPU: callable(keys u64[n], counts i32[n]) -> (keys, counts) of all ranks, concatenated (ShardedSemanticGrid)
+
+    # -- the association in stages (hv_assoc_*): what a multi-GPU driver interleaves with its exchange ----------------------------
+    def assoc_vote(self, camera_frustrum, class_ids_image, semantic_instances_image, depth_image=None, depth_threshold=0.1,
+                   do_carving=False):
+        """Stage 1: this grid's voxels vote (instance, object) pairs.  -> False where the reference returns an empty map without
+        looking at the grid (missing / mis-sized label images)."""
         f = camera_frustrum
         if class_ids_image is None or semantic_instances_image is None:
-            return {}
+            return False
         loc = L.HV_HOST
+        ts = None
         if any(_is_device(a) for a in (class_ids_image, semantic_instances_image, depth_image)):
             # device-resident label / depth images (torch CUDA: int32, int32, float32): used in place
             import torch
@@ -501,24 +517,22 @@ class _SemanticGridBase(_Volume):
             if cls.dim() != 2 or inst.dim() != 2 or cls.dtype != torch.int32 or inst.dtype != torch.int32:
                 raise RuntimeError("Class ids / Instance ids must be single-channel int32")
             if tuple(inst.shape) != (f.height, f.width) or tuple(cls.shape) != (f.height, f.width):
-                return {}
+                return False
             if depth is not None and (depth.dtype != torch.float32 or tuple(depth.shape) != (f.height, f.width)):
                 depth = None
             ts = self._torch_in(cls, inst, depth)
         else:
             cls, inst = np.asarray(class_ids_image), np.asarray(semantic_instances_image)
             if cls.size == 0 or inst.size == 0:
-                return {}
+                return False
             cls, inst = _i32_image(cls, "Class ids"), _i32_image(inst, "Instance ids")
             if inst.shape != (f.height, f.width) or cls.shape != (f.height, f.width):
-                return {}  # check_image_size(): message + empty map
+                return False  # check_image_size(): message + empty map
             depth = None
             if depth_image is not None and np.asarray(depth_image).size > 0:
                 depth = np.ascontiguousarray(depth_image, dtype=np.float32)
                 if depth.shape != (f.height, f.width):
                     depth = None  # use_depth_filter = false
-        # vote -> (multi-GPU: exchange of the pair lists) -> decide: queued on the volume's stream, nothing waits; the map stays in
-        # device memory until somebody reads it (remap_instance_ids on this volume uses it there)
         prev = getattr(self, "_last_map_ref", None)
         prev = prev() if prev is not None else None
         if prev is not None and prev._d is None:
@@ -526,27 +540,31 @@ class _SemanticGridBase(_Volume):
         L.check(self._lib.hv_assoc_vote(
             self._h, L.ptr(f.intr), f.width, f.height, L.ptr(f.T_cw), f.depth_max, f.depth_min, L.ptr(cls), L.ptr(inst), L.ptr(depth),
             float(depth_threshold), int(bool(do_carving)), loc))
-        if self._pair_exchange is not None:
-            self._exchange_pairs()
-        L.check(self._lib.hv_assoc_decide(self._h, float(min_vote_ratio), int(min_votes)))
         if loc == L.HV_DEVICE:
             self._torch_out(ts, cls.device)
-        self._assoc_serial = getattr(self, "_assoc_serial", 0) + 1
-        m = LazyIdMap(self, self._assoc_serial)
-        self._last_map_ref = weakref.ref(m)
-        return m
+        return True
 
-    _pair_exchange = None  # multi-GPU: callable(keys u64[n], counts i32[n]) -> (keys, counts) of all ranks, concatenated (ShardedSemanticGrid)
-
-    def _exchange_pairs(self):
+    def assoc_pairs(self):
+        """-> (keys u64 [n] = instance << 32 | object, votes i32 [n]) of stage 1 (synchronises)."""
         n = ctypes.c_int64()
         L.check(self._lib.hv_assoc_pairs_fetch(self._h, None, None, 0, ctypes.byref(n)))
         keys, counts = np.zeros(n.value, np.uint64), np.zeros(n.value, np.int32)
         if n.value:
             L.check(self._lib.hv_assoc_pairs_fetch(self._h, L.ptr(keys), L.ptr(counts), n.value, ctypes.byref(n)))
-        keys, counts = self._pair_exchange(keys, counts)
+        return keys, counts
+
+    def assoc_set_pairs(self, keys, counts):
+        """Replace the pairs stage 2 decides on (multi-GPU: the concatenation of every rank's list; equal pairs are added up)."""
         keys, counts = np.ascontiguousarray(keys, np.uint64), np.ascontiguousarray(counts, np.int32)
         L.check(self._lib.hv_assoc_pairs_set(self._h, L.ptr(keys), L.ptr(counts), len(keys)))
+
+    def assoc_decide(self, min_vote_ratio=0.5, min_votes=3):
+        """Stage 2: the reference's rules, new object ids, deferred assignments - on the device.  -> LazyIdMap."""
+        L.check(self._lib.hv_assoc_decide(self._h, float(min_vote_ratio), int(min_votes)))
+        self._assoc_serial = getattr(self, "_assoc_serial", 0) + 1
+        m = LazyIdMap(self, self._assoc_serial)
+        self._last_map_ref = weakref.ref(m)
+        return m
 
     def remap_instance_ids(self, instance_ids, instance_id_to_object_id):
         return remap_instance_ids(instance_ids, instance_id_to_object_id, volume=self)

@@ -429,3 +429,75 @@ def test_two_rank_voxel_grid_ownership_equals_single_grid(tmp_path):
     l0, l1 = np.load(tmp_path / "grid_local0.npy"), np.load(tmp_path / "grid_local1.npy")
     assert l0[0] + l1[0] == len(pb) and l0[1] + l1[1] == full.num_blocks()
     assert 0.35 * full.num_blocks() < l0[1] < 0.65 * full.num_blocks()  # hash-balanced
+
+
+# ---- semantic grids: the association's pair-list exchange ------------------------------------------------------------------------
+class _FakeSemanticGrid:
+    """What ShardedSemanticGrid needs of a grid: set_owner, the _pair_exchange hook, get_voxels."""
+
+    def __init__(self, rank):
+        self.rank, self.owner = rank, None
+        self._pair_exchange = None
+
+    def set_owner(self, rank, world):
+        self.owner = (rank, world)
+
+    def local_pairs(self):
+        rng = np.random.default_rng(100 + self.rank)
+        n = 0 if self.rank == 1 else 3 + 2 * self.rank  # one rank has nothing in view
+        inst = rng.integers(0, 5, n).astype(np.uint64)
+        obj = rng.integers(-3, 9, n).astype(np.int32)
+        return (inst << np.uint64(32)) | obj.view(np.uint32).astype(np.uint64), rng.integers(1, 50, n).astype(np.int32)
+
+    def get_voxels(self, min_count=1, min_confidence=0.0):
+        import types
+
+        n = 4 + self.rank
+        return types.SimpleNamespace(points=np.full((n, 3), float(self.rank)), colors=np.full((n, 3), 0.5, np.float32),
+                                     class_ids=np.full(n, self.rank, np.int32), object_ids=np.arange(n, dtype=np.int32),
+                                     confidences=np.full(n, 0.25, np.float32))
+
+
+def _sem_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from pyslam_amd.distributed import ShardedSemanticGrid
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = _FakeSemanticGrid(rank)
+    sh = ShardedSemanticGrid(g, rank=rank, world_size=world)
+    assert g.owner == (rank, world) and g._pair_exchange is not None
+    keys, counts = g._pair_exchange(*g.local_pairs())  # what assign_object_ids_to_instance_ids calls between vote and decide
+    assert keys.dtype == np.uint64 and counts.dtype == np.int32
+    np.savez(os.path.join(tmpdir, f"pairs{rank}.npz"), keys=keys, counts=counts, sizes=np.array(sh.last_exchange["sizes"]))
+    rows = sh.gather_voxels(1, 0.0, root=0)
+    if rank == 0:
+        np.savez(os.path.join(tmpdir, "sem_rows.npz"), points=rows[0], cls=rows[2], obj=rows[3], conf=rows[4])
+    else:
+        assert rows is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_semantic_pair_lists_are_all_gathered_in_rank_order(tmp_path, world):
+    """The one collective of the semantic path: every rank ends up with the SAME concatenation of the ranks' (instance << 32 | object,
+    votes) lists, in rank order, bit for bit (negative object markers included), also when a rank has no pairs; get_voxels rows are
+    gathered on the root."""
+    import torch.multiprocessing as mp
+
+    port = 29500 + ((os.getpid() + 777 + world) % 2000)
+    mp.spawn(_sem_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    want_k = np.concatenate([_FakeSemanticGrid(r).local_pairs()[0] for r in range(world)])
+    want_c = np.concatenate([_FakeSemanticGrid(r).local_pairs()[1] for r in range(world)])
+    for r in range(world):
+        z = np.load(tmp_path / f"pairs{r}.npz")
+        np.testing.assert_array_equal(z["keys"], want_k)
+        np.testing.assert_array_equal(z["counts"], want_c)
+        assert z["sizes"].tolist() == [len(_FakeSemanticGrid(q).local_pairs()[0]) for q in range(world)]
+    z = np.load(tmp_path / "sem_rows.npz")
+    assert len(z["points"]) == sum(4 + r for r in range(world))
+    assert sorted(z["cls"].tolist()) == sorted(sum(([r] * (4 + r) for r in range(world)), []))

@@ -358,3 +358,58 @@ def test_device_resident_keyframe_flow_equals_host_flow(kind):
     np.testing.assert_allclose(posa, posb, rtol=1e-12, atol=1e-9)
     np.testing.assert_allclose(cola, colb, rtol=1e-6, atol=1e-4)
     np.testing.assert_allclose(confa, confb, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", [VOTE, PROB])
+@pytest.mark.parametrize("world", [2, 3])
+def test_block_ownership_sharding_with_exchanged_votes_equals_the_single_grid(kind, world):
+    """Semantic grids on `world` GPUs (here: `world` grids in one process play the ranks): hv_set_owner splits the blocks, every rank
+    votes with its own voxels (assoc_vote), the pair lists are concatenated - what ShardedSemanticGrid all-gathers - and set on every
+    rank, every rank decides.  All ranks must arrive at the single grid's map and object ids (the counter is process-wide here: the
+    ranks' decisions are replayed from the same start value), and the union of their voxels must be the single grid's."""
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import CameraFrustrum
+    from pyslam_amd.volumetric_semantic import get_next_object_id_peek, remap_instance_ids, set_next_object_id
+
+    s = SyntheticRGBD(CFG, noise=True, invalid_frac=0.02)
+    intr = s.intrinsics
+    single = gpu_grid(kind, CFG["voxel"])
+    ranks = [gpu_grid(kind, CFG["voxel"]) for _ in range(world)]
+    for r, g in enumerate(ranks):
+        g.set_owner(r, world)
+    for g in [single] + ranks:
+        g.set_depth_threshold(2.0)
+        g.set_depth_decay_rate(0.07)
+    fr = CameraFrustrum(*intr, s.width, s.height, np.eye(4), depth_max=DEPTH_MAX, depth_min=DEPTH_MIN)
+    set_next_object_id(1)
+    for k, i in enumerate((0, 6, 12, 18)):
+        depth, rgb, T, cls_img, inst_img = semantic_frame(s, i, shuffle=k)
+        fr.set_T_cw(T)
+        start = get_next_object_id_peek()
+        want = dict(single.assign_object_ids_to_instance_ids(fr, cls_img, inst_img, depth, depth_threshold=0.05, do_carving=(k == 2),
+                                                             min_vote_ratio=0.5, min_votes=3))
+        after = get_next_object_id_peek()
+        for g in ranks:
+            assert g.assoc_vote(fr, cls_img, inst_img, depth, 0.05, k == 2)
+        lists = [g.assoc_pairs() for g in ranks]
+        keys, counts = np.concatenate([x[0] for x in lists]), np.concatenate([x[1] for x in lists])
+        maps = []
+        for g in ranks:
+            set_next_object_id(start)  # every rank's counter stands where the single grid's stood
+            g.assoc_set_pairs(keys, counts)
+            maps.append(dict(g.assoc_decide(0.5, 3)))
+            assert get_next_object_id_peek() == after
+        assert all(m == want for m in maps), (k, want, maps)
+        obj_img = remap_instance_ids(inst_img, want, volume=single)
+        pts, cols, cls, obj, depths = frame_points(depth, rgb, T, cls_img, obj_img, intr, 4.0)
+        for g in [single] + ranks:
+            g.integrate(pts, cols, cls, obj, depths)
+    assert any(v > 0 for v in want.values())
+    a = single.get_voxels(1, -1.0)
+    rows = [g.get_voxels(1, -1.0) for g in ranks]
+    assert sum(len(r.points) for r in rows) == len(a.points) and min(len(r.points) for r in rows) > 0.15 * len(a.points)
+    got = srt(tuple(np.concatenate([getattr(r, f) for r in rows]) for f in ("points", "colors", "class_ids", "object_ids", "confidences")))
+    exp = srt((a.points, a.colors, a.class_ids, a.object_ids, a.confidences))
+    for x, y in zip(got, exp):
+        np.testing.assert_array_equal(x, y)
+    assert sum(g.num_blocks() for g in ranks) == single.num_blocks()
