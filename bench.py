@@ -68,7 +68,7 @@ UNIT_BYTES = 4096 * BYTES_PER_VOXEL
 VALU_PEAK_GINSTR_2CYC = 1024 * 2.4 / 2.0  # MI355X_MICROARCH.md lists wave64 v_fma_f32 at 2 cycles: 1228.8 G wave-instr/s
 VECTOR_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector (non-MFMA) fp32
 FLOP_PER_VISIT = 40  # "TSDF ~ 40 flop / voxel visited"
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 PMC_SUMMARY = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_summary.json")
 
 
@@ -132,6 +132,48 @@ def hbm_traffic(pk):
     if not pk or "FETCH_SIZE" not in pk or "WRITE_SIZE" not in pk:
         return None
     return int((2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024)
+
+
+def live_pmc(args, B, kernel_substr="k_tsdf_sweep"):
+    """HBM traffic of the dominant kernel measured IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE: separate
+    passes with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes) of this very command without its secondary
+    legs; mean over the launches of the timed steps.  -> {"FETCH_SIZE": KB, "WRITE_SIZE": KB, "launches": n} or None (no rocprofv3
+    on the box, BENCH_LIVE_PMC=0, a pass failed or timed out)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if os.environ.get("BENCH_LIVE_PMC", "1") == "0" or shutil.which("rocprofv3") is None:
+        return None
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(args.steps), "--warmup", str(args.warmup), "--clock-ramp-steps",
+             str(args.clock_ramp_steps), "--frames-per-step", str(B), "--window", args.window, "--config", args.config, "--no-cpu-baseline",
+             "--no-secondary"]
+    cold = (args.warmup + args.steps) if args.clock_ramp_steps > 0 else 0  # the cold-clock pass comes first
+    lo = cold + args.clock_ramp_steps + args.warmup
+    hi = lo + args.steps
+    env = dict(os.environ, BENCH_LIVE_PMC="0", TMPDIR="/tmp")
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        try:
+            subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child,
+                           cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+            vals = []
+            for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r.get("Dispatch_Id", 0)))
+                vals += [float(r["Counter_Value"]) for r in rows if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            vals = vals[lo:hi]
+            if not vals:
+                return None
+            out[counter] = sum(vals) / len(vals)
+            out["launches"] = len(vals)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 def cpu_baseline_and_counts(s, depth, rgb, T, B, max_steps, budget_s, threads, window):
@@ -333,7 +375,54 @@ def config_legs():
                                                               "what": "extract_triangle_mesh (host-visible result, D2H included) after every 10th frame"}
         out[key] = leg
         del vol, depth_d, rgb_d
+    try:
+        out["euroc_752x480_10mm"] = euroc_leg()
+    except Exception as e:
+        out["euroc_752x480_10mm"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+def euroc_leg(n_frames=48):
+    """BASELINE configs[3]'s single-GPU half: EuRoC-shaped stereo keyframes (752x480, f = 435.2 px, bf = 47.9 px m: settings/
+    EuRoC_stereo.yaml:18-35), depth from a torch stereo module on the device (no RAFT-Stereo weights offline: the deterministic stub
+    of pyslam_amd/depth_estimation.py stands in for it - a 5x5 conv, so the figure is the HAND-OFF and the fusion, not a depth
+    network), shadow-point filter on the device (volumetric_integrator_base.py:989-1004), 1 cm TSDF, one integrate per keyframe:
+    depth never visits the host.  Parity of this shape: tests/test_gpu_configs.py, tests/test_gpu_dense.py."""
+    import types
+
+    import torch
+
+    from pyslam_amd.depth_estimation import DepthEstimatorStereoTorch, make_stub_stereo_net
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+
+    s, depth_h, rgb_h, T_h = load_frames("euroc_752x480_10mm", n_frames)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    cam = types.SimpleNamespace(bf=47.9, width=s.width, height=s.height)
+    est = DepthEstimatorStereoTorch(make_stub_stereo_net(), cam, device="cuda", keep_on_device=True, max_depth=10.0)
+    left = [np.ascontiguousarray(rgb_h[i]) for i in range(n_frames)]
+    right = [np.ascontiguousarray(np.roll(rgb_h[i], -8, axis=1)) for i in range(n_frames)]
+    vol = ScalableTSDFVolume(0.010, SDF_TRUNC, max_blocks=1 << 15, max_points=s.width * s.height)
+
+    def run():
+        vol.reset()
+        vol.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_frames):
+            depth_d, _ = est.infer(left[i], right[i])                 # torch, device-resident
+            depth_d = vol.filter_shadow_points(depth_d)                # radix-select median on the device
+            color_d = torch.from_numpy(left[i]).cuda(non_blocking=True)
+            vol.integrate(RGBDImage(color_d, depth_d, 1.0, DEPTH_TRUNC), K, T_h[i])
+        vol.synchronize()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run()
+    dt = min(run() for _ in range(2))
+    return {"value": round(n_frames / dt, 1), "unit": "frames/s", "frames": n_frames, "voxel": 0.010, "image": f"{s.width}x{s.height}",
+            "units": int(vol.num_blocks()),
+            "what": "stereo keyframes: uploads of the pair, stub stereo module (torch) -> disparity -> depth = bf / |d| on the device, shadow-point "
+                    "filter, hv_tsdf_integrate from device pointers; one keyframe per call; the 2-GPU tile-sharded half of configs[3] "
+                    "needs a second GPU (tests/test_gpu_distributed.py runs that code path with two ranks on one GPU)"}
 
 
 def main():
@@ -352,8 +441,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--all-on-device0", action="store_true",
                     help="testing only: every rank uses GPU 0 (multi-rank code path on a 1-GPU box, with --backend gloo)")
-    ap.add_argument("--sharding", choices=["owner", "tile"], default="owner",
-                    help="N > 1: owner = unit-ownership sharding, no collective while fusing (default); "
+    ap.add_argument("--sharding", choices=["owner", "tile", "coherent"], default="owner",
+                    help="N > 1: owner = unit-ownership sharding by hash, no collective while fusing (default); "
+                         "coherent = ownership planned per batch on the device (equal work, image-contiguous units per GPU; units may end up "
+                         "on several GPUs: consolidated by merge_halo / gather_to_root); "
                          "tile = image tiles + RCCL merge of the shared units at the end")
     ap.add_argument("--mode", choices=["batch", "online"], default="batch",
                     help="batch: one multi-frame sweep per step (replay/rebuild path); online: one integrate() per frame")
@@ -416,6 +507,25 @@ def main():
     # clock ramp (not a warm-up step, not timed): a fresh box starts the timed region on idle clocks - the 5 warm-up steps of the
     # driver's default command are 3 ms of work, and the first ~15 ms of sustained load run 10-15 % slower (tools/sweep_variants.py:
     # first pass of a process 660 us per sweep, every later pass 575-585).  The same step, repeated on the volume the warm-up uses.
+    # the same K steps on COLD clocks first (reported beside the headline as `cold_clock`: what a rebuild() after a loop closure sees
+    # when the GPU was idle before it): the driver's W warm-up steps, then K timed steps, before any clock ramp
+    cold = None
+    if args.clock_ramp_steps > 0 and args.mode == "batch":
+        for k in range(args.warmup):
+            step(k)
+        fence()
+        if args.window == "sliding":
+            vol.reset()
+            fence()
+        tc = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+        fence()
+        cold = time.perf_counter() - tc
+        if dist is not None:
+            t = torch.tensor([cold], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            cold = float(t.item())
     for k in range(args.clock_ramp_steps):
         step(k % max(1, n_distinct // B))
     fence()
@@ -447,7 +557,19 @@ def main():
     launch_ms = vol.profile_launches()
     vol.profile_read()
     vol.profile_enable(False)
+    per_rank = None
     if dist is not None:
+        # every rank's own clock, its mean sweep launch (HIP events) and the units it holds: how to read the first real N-GPU run
+        mine = torch.tensor([elapsed / args.steps * 1e3, float(np.mean(launch_ms)) if len(launch_ms) else 0.0, float(vol.num_blocks()),
+                             merge["ms"] if merge else 0.0], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        rows = [e.cpu().tolist() for e in everyone]
+        per_rank = {"ms_per_step": [round(r[0], 4) for r in rows], "sweep_ms_per_step": [round(r[1], 4) for r in rows],
+                    "units_held": [int(r[2]) for r in rows], "merge_ms": [round(r[3], 3) for r in rows],
+                    "what": "per rank: wall ms per step on the rank's own clock, mean duration of its sweep launch (HIP events on the kernel's "
+                            "stream; the touch + pack launch of the next batch runs beside it on a second stream), units in its pool, "
+                            "merge_halo() ms (tile sharding)"}
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -574,6 +696,14 @@ def main():
             visits = sum(sum(st["touched"]) for st in cpu["steps"][:n_cov]) * 4096 / world
             pk = pmc_kernel(pmc, "k_tsdf_sweep", command_key) if world == 1 else None
             traffic = hbm_traffic(pk)
+            traffic_source = (f"replayed: profiles/{PROFILE_ROUND}/pmc_summary.json, rocprofv3 --pmc passes the builder recorded of this command "
+                              f"on this library build") if traffic else None
+            if world == 1 and not args.no_secondary:
+                live = live_pmc(args, B)
+                if live is not None:
+                    traffic = hbm_traffic(live)
+                    traffic_source = (f"live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of this command inside this "
+                                      f"run, mean over the {live['launches']} sweep launches of the timed steps")
             hbm = {"algorithmic_bytes_per_launch": int(alg / n_cov), "achieved": round(alg / t_cov / 1e9, 1), "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": round(alg / t_cov / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                    "what": "BATCH-level algorithmic bytes (oracle): distinct units touched by the batch x 81 920 B read + distinct "
@@ -586,6 +716,7 @@ def main():
                         "algorithmic_bytes_per_launch": hbm["algorithmic_bytes_per_launch"], "what": hbm["what"],
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(n_cov), "frames_per_launch": B,
                         "voxel_visits_per_launch": int(visits / n_cov)}
+            roofline["traffic_source"] = traffic_source
             if traffic:
                 roofline["traffic_GBs"] = hbm["traffic_GBs"]
                 roofline["traffic_over_algorithmic"] = hbm["traffic_over_algorithmic"]
@@ -634,7 +765,9 @@ def main():
                 "sharding": "single spatial tile" if world == 1 else (
                     f"unit ownership: unit -> GPU hash(index) % {world}; every GPU sees every frame, fuses and stores only its "
                     f"units; no collective while fusing" if args.sharding == "owner"
-                    else f"{world} vertical image tiles + RCCL merge of the shared units (timed)"),
+                    else (f"ownership planned per batch on the device: equal work per GPU, a GPU's units contiguous in the image of the batch's "
+                          f"middle frame; every GPU sees every frame, no collective while fusing" if args.sharding == "coherent"
+                          else f"{world} vertical image tiles + RCCL merge of the shared units (timed)")),
                 "units_allocated": units_allocated,
                 "clock_ramp_steps": args.clock_ramp_steps,
                 "build_digest": digest,
@@ -647,6 +780,12 @@ def main():
                           f"gcc -O3 -march=native on this host; open3d itself is not installed), OpenMP over touched units",
             },
         }
+        if cold is not None:
+            out["cold_clock"] = {"value": round(args.steps * B / cold, 2), "unit": "frames/s", "ms_per_step": round(cold / args.steps * 1e3, 4),
+                                 "what": f"the same {args.steps} steps after the same {args.warmup} warm-up steps BEFORE the {args.clock_ramp_steps} "
+                                         f"untimed clock-ramp steps: a fresh process on idle clocks (value above: after the ramp)"}
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if cpu is not None and world == 1:
             out["speedup_vs_cpu"] = round(fps / cpu["fps"], 1)
         if merge is not None:
