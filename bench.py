@@ -617,6 +617,15 @@ def main():
             t1 = time.perf_counter()
             mesh = vol.extract_triangle_mesh()
             t_mesh_fetch = time.perf_counter() - t1
+            # ... and a tick whose consumer lives on the GPU (device=True: torch CUDA tensors, nothing crosses PCIe)
+            del mesh
+            vol.integrate(RGBDImage(rgb_d[2], depth_d[2], 1.0, DEPTH_TRUNC), Kcam, T_res[2])
+            fence()
+            t1 = time.perf_counter()
+            mesh = vol.extract_triangle_mesh(device=True)
+            torch.cuda.synchronize()
+            t_mesh_dev = time.perf_counter() - t1
+            assert mesh.vertices.is_cuda and len(mesh.vertices) > 0
             b_mc_in = units_allocated * 4096 * 8
             b_mesh_out = nv * 48 + nt * 12
             b_pc_out = npts * 48
@@ -626,6 +635,7 @@ def main():
                         "running reconstruction, *_first_call_ms = the first tick, which also page-locks the result arrays)",
                 "units": units_allocated, "vertices": nv, "triangles": nt, "points": npts,
                 "mesh_wall_ms": round(t_mesh * 1e3, 2), "mesh_kernel_ms": round(k_mesh, 3), "mesh_fetch_only_ms": round(t_mesh_fetch * 1e3, 2),
+                "mesh_device_resident_wall_ms": round(t_mesh_dev * 1e3, 2),
                 "mesh_first_call_ms": round(t_mesh_cold * 1e3, 2), "points_first_call_ms": round(t_pc_cold * 1e3, 2),
                 "points_wall_ms": round(t_pc * 1e3, 2), "points_kernel_ms": round(k_pc, 3),
                 "roofline": {"bound": "hbm", "kernel": "k_unit_masks + k_mc_classify + scans + k_mc_vertices + k_mc_triangles (once: the size query computes, the fetch copies)",

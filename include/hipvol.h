@@ -330,7 +330,9 @@ int hv_block_owner(const int32_t *block_keys, int64_t n, int32_t world_size, int
 int hv_tsdf_set_owner(hv_volume *v, int32_t rank, int32_t world_size);
 
 /* extract_triangle_mesh() (volumetric_integrator_tsdf.py:239,260).  vertices/vertex_colors f64
- * [V,3] (colours in [0,1]); triangles i32 [T,3].  NULL arrays = size query.  Host pointers. */
+ * [V,3] (colours in [0,1]); triangles i32 [T,3].  NULL arrays = size query.  The destination arrays may be host memory
+ * (pySLAM's viewer / PLY writer) or device memory of the volume's GPU (a GPU consumer: the 272 MB device-to-host copy of a
+ * 32 k-unit mesh is the whole wall time of an output tick); the same holds for hv_tsdf_extract_points / _point_normals. */
 int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, int64_t cap_vertices,
                          int32_t *triangles, int64_t cap_triangles, int64_t *n_vertices,
                          int64_t *n_triangles);

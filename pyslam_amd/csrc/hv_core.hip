@@ -546,7 +546,22 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
         }                                                                                          \
     } while (0)
 
-    HV_TRY(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+    {
+        // HV_TSDF_AUX_CUS=n with HV_TSDF_MAIN_EXCLUDE=1 (experiment): the main stream stays OFF the n CUs the
+        // touch + pack stream gets (hv_tsdf.hip), i.e. the two launches run on disjoint CU sets
+        const int aux_cus = getenv("HV_TSDF_AUX_CUS") ? atoi(getenv("HV_TSDF_AUX_CUS")) : 0;
+        if (cfg->mode == HV_MODE_TSDF && aux_cus > 0 && aux_cus < 256 && getenv("HV_TSDF_MAIN_EXCLUDE") && atoi(getenv("HV_TSDF_MAIN_EXCLUDE")) != 0) {
+            uint32_t mask[8];
+            for (int i = 0; i < 8; ++i) mask[i] = 0xffffffffu;
+            for (int i = 0; i < aux_cus; ++i) {
+                const int bit = (int)((int64_t)i * 256 / aux_cus);
+                mask[bit >> 5] &= ~(1u << (bit & 31));
+            }
+            HV_TRY(hipExtStreamCreateWithCUMask(&v->stream, 8, mask));
+        } else {
+            HV_TRY(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+        }
+    }
     v->own_stream = true;
 
     const int64_t nvox = (int64_t)cfg->block_size * cfg->block_size * cfg->block_size;

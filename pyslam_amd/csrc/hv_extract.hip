@@ -773,10 +773,10 @@ int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, 
     const int64_t nv = std::min<int64_t>(v->mesh_cache_nv, cap_vertices), nt = std::min<int64_t>(v->mesh_cache_nt, cap_triangles);
     const double *d_vert = (const double *)v->out_a, *d_col = d_vert + 3 * v->mesh_cache_nv;
     if (nv > 0) {
-        HV_HIP(hipMemcpyAsync(vertices, d_vert, sizeof(double) * 3 * nv, hipMemcpyDeviceToHost, v->stream));
-        HV_HIP(hipMemcpyAsync(vertex_colors, d_col, sizeof(double) * 3 * nv, hipMemcpyDeviceToHost, v->stream));
+        HV_HIP(hipMemcpyAsync(vertices, d_vert, sizeof(double) * 3 * nv, hipMemcpyDefault /* the destination may be host or device memory (a GPU consumer) */, v->stream));
+        HV_HIP(hipMemcpyAsync(vertex_colors, d_col, sizeof(double) * 3 * nv, hipMemcpyDefault, v->stream));
     }
-    if (nt > 0) HV_HIP(hipMemcpyAsync(triangles, v->out_b, sizeof(int32_t) * 3 * nt, hipMemcpyDeviceToHost, v->stream));
+    if (nt > 0) HV_HIP(hipMemcpyAsync(triangles, v->out_b, sizeof(int32_t) * 3 * nt, hipMemcpyDefault, v->stream));
     HV_HIP(hipStreamSynchronize(v->stream));
     return HV_OK;
 }
@@ -842,8 +842,8 @@ int hv_tsdf_extract_points(hv_volume *v, double *points, double *colors, int64_t
     const int64_t m = std::min<int64_t>(v->points_cache_n, cap);
     if (m > 0) {
         const double *d_pts = (const double *)v->out_a, *d_cols = d_pts + 3 * v->points_cache_n;
-        HV_HIP(hipMemcpyAsync(points, d_pts, sizeof(double) * 3 * m, hipMemcpyDeviceToHost, v->stream));
-        HV_HIP(hipMemcpyAsync(colors, d_cols, sizeof(double) * 3 * m, hipMemcpyDeviceToHost, v->stream));
+        HV_HIP(hipMemcpyAsync(points, d_pts, sizeof(double) * 3 * m, hipMemcpyDefault, v->stream));
+        HV_HIP(hipMemcpyAsync(colors, d_cols, sizeof(double) * 3 * m, hipMemcpyDefault, v->stream));
         HV_HIP(hipStreamSynchronize(v->stream));
     }
     return HV_OK;
@@ -867,7 +867,7 @@ int hv_tsdf_extract_point_normals(hv_volume *v, double *normals, int64_t cap, in
                        v->cfg.voxel_size, v->cfg.voxel_size * (double)R, (const double *)v->out_a, m, (double *)v->out_b);
     hv_profile_end(v, 0);
     HV_HIP(hipGetLastError());
-    HV_HIP(hipMemcpyAsync(normals, v->out_b, sizeof(double) * 3 * m, hipMemcpyDeviceToHost, v->stream));
+    HV_HIP(hipMemcpyAsync(normals, v->out_b, sizeof(double) * 3 * m, hipMemcpyDefault, v->stream));
     HV_HIP(hipStreamSynchronize(v->stream));
     return HV_OK;
 }

@@ -2658,6 +2658,17 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
         if (v->cfg.max_blocks != max_before) chain_ok = false; // the pool grew: the stream was drained, start a fresh chain
         const bool overlap = pipeline_on && chain_ok && !checked && list_in_touch;
         if (v->stream_aux == nullptr) {
+            // HV_TSDF_AUX_CUS=n: the touch + pack stream gets n CUs of its own (hipExtStreamCreateWithCUMask, bits spread evenly over
+            // the 256) so that its workgroups do not wait for retiring sweep waves (VERDICT r03 Next #5a; measured in DESIGN section 4)
+            const int aux_cus = getenv("HV_TSDF_AUX_CUS") ? atoi(getenv("HV_TSDF_AUX_CUS")) : 0;
+            if (aux_cus > 0 && aux_cus < 256) {
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < aux_cus; ++i) {
+                    const int bit = (int)((int64_t)i * 256 / aux_cus);
+                    mask[bit >> 5] |= 1u << (bit & 31);
+                }
+                HV_HIP(hipExtStreamCreateWithCUMask(&v->stream_aux, 8, mask));
+            } else
             HV_HIP(hipStreamCreateWithFlags(&v->stream_aux, hipStreamNonBlocking)); // (queue priority high / low against the sweep's: measured, no effect)
             HV_HIP(hipEventCreateWithFlags(&v->ev_prep, hipEventDisableTiming));
             HV_HIP(hipEventCreateWithFlags(&v->ev_presweep, hipEventDisableTiming));

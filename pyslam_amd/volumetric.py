@@ -719,12 +719,23 @@ class ScalableTSDFVolume(_Volume):
         L.check(self._lib.hv_tsdf_set_owner(self._h, int(rank), int(world_size)))
         L.check(self._lib.hv_tsdf_set_sharding(self._h, 1 if coherent else 0))
 
-    def extract_triangle_mesh(self):
+    def extract_triangle_mesh(self, device=False):
+        """o3d's extract_triangle_mesh().  device=True: vertices / vertex_colors / triangles are torch CUDA tensors on the volume's GPU
+        (nothing crosses PCIe: for consumers that render or post-process on the GPU); default: host arrays like Open3D's."""
         nv, nt = ctypes.c_int64(), ctypes.c_int64()
         L.check(self._lib.hv_tsdf_extract_mesh(self._h, None, None, 0, None, 0, ctypes.byref(nv), ctypes.byref(nt)))
-        verts = _result_array((nv.value, 3), np.float64)
-        cols = _result_array((nv.value, 3), np.float64)
-        tris = _result_array((nt.value, 3), np.int32)
+        if device:
+            import torch
+
+            dev = torch.device("cuda", int(self._cfg.device))
+            verts = torch.empty((nv.value, 3), dtype=torch.float64, device=dev)
+            cols = torch.empty((nv.value, 3), dtype=torch.float64, device=dev)
+            tris = torch.empty((nt.value, 3), dtype=torch.int32, device=dev)
+            torch.cuda.current_stream(dev).synchronize()  # (the allocator may hand out blocks with work pending on torch's stream)
+        else:
+            verts = _result_array((nv.value, 3), np.float64)
+            cols = _result_array((nv.value, 3), np.float64)
+            tris = _result_array((nt.value, 3), np.int32)
         if nv.value or nt.value:
             L.check(
                 self._lib.hv_tsdf_extract_mesh(
@@ -733,18 +744,27 @@ class ScalableTSDFVolume(_Volume):
             )
         return TriangleMesh(verts, tris, cols)
 
-    def extract_point_cloud(self, normals=False):
+    def extract_point_cloud(self, normals=False, device=False):
         """o3d's extract_point_cloud().  normals=True also computes the per-point normals Open3D attaches (GetNormalAt: the
-        gradient of the trilinearly interpolated tsdf) - pySLAM's viewer path does not read them, its save path writes them."""
+        gradient of the trilinearly interpolated tsdf) - pySLAM's viewer path does not read them, its save path writes them.
+        device=True: torch CUDA tensors on the volume's GPU instead of host arrays."""
         n = ctypes.c_int64()
         L.check(self._lib.hv_tsdf_extract_points(self._h, None, None, 0, ctypes.byref(n)))
-        pts = _result_array((n.value, 3), np.float64)
-        cols = _result_array((n.value, 3), np.float64)
+        if device:
+            import torch
+
+            dev = torch.device("cuda", int(self._cfg.device))
+            pts = torch.empty((n.value, 3), dtype=torch.float64, device=dev)
+            cols = torch.empty((n.value, 3), dtype=torch.float64, device=dev)
+            torch.cuda.current_stream(dev).synchronize()
+        else:
+            pts = _result_array((n.value, 3), np.float64)
+            cols = _result_array((n.value, 3), np.float64)
         nrm = None
         if n.value:
             L.check(self._lib.hv_tsdf_extract_points(self._h, L.ptr(pts), L.ptr(cols), n.value, ctypes.byref(n)))
         if normals:
-            nrm = np.zeros((n.value, 3), np.float64)
+            nrm = torch.zeros((n.value, 3), dtype=torch.float64, device=dev) if device else np.zeros((n.value, 3), np.float64)
             if n.value:
                 L.check(self._lib.hv_tsdf_extract_point_normals(self._h, L.ptr(nrm), n.value, ctypes.byref(n)))
         return PointCloud(pts, cols, nrm)

@@ -476,3 +476,25 @@ def test_extraction_of_loaded_voxel_states_matches_oracle(seed):
     np.testing.assert_allclose(pc.points[ia], pb[ib], rtol=0, atol=1e-9)
     np.testing.assert_allclose(pc.colors[ia], qb[ib], rtol=0, atol=TOL)
     np.testing.assert_allclose(pc.normals[ia], nb[ib], rtol=0, atol=1e-9)
+
+
+def test_device_resident_extraction_equals_host_extraction():
+    """extract_triangle_mesh / extract_point_cloud(device=True): the same arrays as torch CUDA tensors (no PCIe copy)."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+
+    s, frames = synthetic_frames("tiny_160x120_2cm", 0, 4)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    vol = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 12)
+    for d, c, T in frames:
+        vol.integrate(RGBDImage.create_from_color_and_depth(c, d, 1.0, 4.0, False), K, T)
+    host = vol.extract_triangle_mesh()
+    dev = vol.extract_triangle_mesh(device=True)
+    assert dev.vertices.is_cuda and dev.triangles.is_cuda and len(host.vertices) > 100
+    np.testing.assert_array_equal(dev.vertices.cpu().numpy(), host.vertices)
+    np.testing.assert_array_equal(dev.vertex_colors.cpu().numpy(), host.vertex_colors)
+    np.testing.assert_array_equal(dev.triangles.cpu().numpy(), host.triangles)
+    ph = vol.extract_point_cloud(normals=True)
+    pd = vol.extract_point_cloud(normals=True, device=True)
+    np.testing.assert_array_equal(pd.points.cpu().numpy(), ph.points)
+    np.testing.assert_array_equal(pd.colors.cpu().numpy(), ph.colors)
+    np.testing.assert_array_equal(pd.normals.cpu().numpy(), ph.normals)
