@@ -173,8 +173,9 @@ int hv_keys_from_points(hv_volume *v, const float *points, int64_t n, int32_t *v
  *   (volumetric_grid_module.h:131-467 -> integrate_raw -> update_voxel_direct, voxel_block_grid.hpp:524-614).
  *   point_dtype: 0 float32, 1 float64 (keys follow get_voxel_key_inv<Tpos,Tpos>).  Labels, confidence
  *   counters / log-probabilities, counts and float64 position sums are bit-identical to the reference's
- *   sequential (point-index) order.  The probabilistic payload keeps at most 7 distinct (object, class) labels per
- *   voxel; further labels are dropped and counted (hv_label_overflows). */
+ *   sequential (point-index) order.  The probabilistic payload's per-voxel label map (std::map in the reference) holds
+ *   6 pairs in the voxel record and chains 10-pair nodes from a per-volume pool beyond them; a pair is dropped, and
+ *   counted (hv_label_overflows), only past 254 pairs in one voxel or when the node pool is exhausted. */
 int hv_integrate_points_semantic(hv_volume *v, const void *points, int32_t point_dtype, int64_t n, const void *colors,
                                  int32_t color_dtype, const int32_t *class_ids, const int32_t *instance_ids,
                                  const float *depths, int32_t loc);
@@ -260,11 +261,13 @@ int hv_remove_low_confidence_segments(hv_volume *v, int32_t min_confidence);
 int hv_remove_low_confidence_voxels(hv_volume *v, float min_confidence);
 /* Parity/debug export, key-sorted: keys [B,3]; ints [B,bs^3,4] {count, object_id, class_id, confidence_counter};
  * pos_sums [B,bs^3,3] f64; col_sums [B,bs^3,3] f32.  The second form adds conf [B,bs^3] f32 and, for the
- * probabilistic payload, label_counts [B,bs^3], labels [B,bs^3,7,2] {object, class} and log_probs [B,bs^3,7]. */
+ * probabilistic payload, label_counts [B,bs^3] (the size of each voxel's label map), labels [B,bs^3,max_labels,2]
+ * {object, class} and log_probs [B,bs^3,max_labels]: each map's first max_labels pairs in insertion order. */
 int hv_dump_blocks_semantic(hv_volume *v, int32_t *keys, int32_t *ints, double *pos_sums, float *col_sums,
                             int64_t *n_blocks);
 int hv_dump_blocks_semantic2(hv_volume *v, int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums,
-                             int32_t *label_counts, int32_t *labels, float *log_probs, int64_t *n_blocks);
+                             int32_t *label_counts, int32_t *labels, float *log_probs, int32_t max_labels,
+                             int64_t *n_blocks);
 
 /* ---- TSDF mode ---------------------------------------------------------------------------------
  * hv_tsdf_integrate == RGBDImage.create_from_color_and_depth(color, depth, depth_scale,

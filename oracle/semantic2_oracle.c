@@ -271,7 +271,7 @@ void so2_destroy(s2_grid *g) {
 }
 int64_t so2_num_blocks(const s2_grid *g) { return g->num_blocks; }
 /* Test hook: hist[k] = occupied voxels whose label map holds k pairs (k >= cap - 1 collected in the last bin); returns the
- * largest map size.  What the product's 7 inline label slots (hv_semantic.h) are measured against. */
+ * largest map size.  What the product's 6 inline label slots + overflow nodes (hv_semantic.h) are sized against. */
 int32_t so2_label_histogram(const s2_grid *g, int64_t *hist, int32_t cap) {
     int32_t most = 0;
     for (int32_t k = 0; k < cap; ++k) hist[k] = 0;

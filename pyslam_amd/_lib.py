@@ -75,7 +75,7 @@ SIGNATURES = {
     "hv_get_voxels_semantic_in_frustum": (_i32, [_vp, _vp, _i32, _i32, _vp, _f32, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _pi64]),
     "hv_set_depth_threshold": (_i32, [_vp, _f32]),
     "hv_dump_blocks_semantic": (_i32, [_vp, _vp, _vp, _vp, _vp, _pi64]),
-    "hv_dump_blocks_semantic2": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi64]),
+    "hv_dump_blocks_semantic2": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _pi64]),
     "hv_set_depth_decay_rate": (_i32, [_vp, _f32]),
     "hv_integrate_rgbd_semantic": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _f64, _i32, _i32]),
     "hv_label_overflows": (_i32, [_vp, _pi64]),

@@ -93,6 +93,8 @@ struct HvTable {
     int32_t *counters; // [HV_CNT_*]
     uint32_t mask;     // capacity - 1
     int32_t max_blocks;
+    void *prob_nodes;       // probabilistic semantic payload: overflow nodes of the per-voxel label maps (HvProbNode[prob_node_cap])
+    int32_t prob_node_cap;  // (0 / nullptr in every other mode)
 };
 
 enum {
@@ -104,7 +106,8 @@ enum {
     HV_CNT_OUT = 5,      // output row counter (compaction kernels)
     HV_CNT_OUT2 = 6,     // second output counter (triangles)
     HV_CNT_AUX = 7,      // scratch counter (association pending list); OUT, OUT2, AUX are cleared by one 12-byte memset
-    HV_CNT_LABEL_OVERFLOW = 8, // probabilistic payload: label observations dropped (voxel already holds HV_PROB_K labels)
+    HV_CNT_LABEL_OVERFLOW = 8, // probabilistic payload: label observations dropped (the overflow-node pool is exhausted / > 254 labels)
+    HV_CNT_PROB_NODES = 9,     // probabilistic payload: overflow nodes handed out
     HV_CNT_COUNT = 16
 };
 

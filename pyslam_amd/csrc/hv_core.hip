@@ -610,6 +610,15 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
             HV_TRY(hipMalloc((void **)&v->occ, sizeof(unsigned long long) * occ_words));
             HV_TRY(hipMemsetAsync(v->occ, 0, sizeof(unsigned long long) * occ_words, v->stream));
         }
+        if (cfg->mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID) {
+            // overflow nodes of the per-voxel label maps (hv_semantic.h): 4 per block of the pool - measured need under 5 % uniform
+            // label noise: about one node per 100 occupied voxels.  HV_PROB_NODE_CAP overrides (tests of the exhausted pool).
+            int64_t cap = std::max<int64_t>(1 << 16, (int64_t)cfg->max_blocks * 4);
+            if (const char *e = getenv("HV_PROB_NODE_CAP")) cap = std::max<int64_t>(atoll(e), 1);
+            cap = std::min<int64_t>(cap, INT32_MAX / 2);
+            HV_TRY(hipMalloc(&v->table.prob_nodes, (size_t)cap * 128));
+            v->table.prob_node_cap = (int32_t)cap;
+        }
     }
 #undef HV_TRY
     // first reset zeroes the whole pool (later resets only the used prefix)
@@ -639,7 +648,7 @@ void hv_destroy(hv_volume *v) {
                     v->touched_stamp, v->touched_list, v->touched_mask, v->frame_px,
                     v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                     v->sort_vals_out, v->sort_tmp, v->scratch_points, v->scratch_colors, v->out_a,
-                    v->out_b, v->out_c, v->batch_buf, v->assoc_buf, v->mult_table, v->vg_cnt, v->vg_cur, v->vg_touched, v->vg_cursor, v->batch_buf2, v->unit_masks, v->plan_buf, v->occ, v->semb_tasks};
+                    v->out_b, v->out_c, v->batch_buf, v->assoc_buf, v->mult_table, v->vg_cnt, v->vg_cur, v->vg_touched, v->vg_cursor, v->batch_buf2, v->unit_masks, v->plan_buf, v->occ, v->semb_tasks, v->table.prob_nodes};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (v->h_counters) (void)hipHostFree(v->h_counters);

@@ -12,7 +12,7 @@
 // position sums come out bit-identical to the reference's sequential branch.
 //
 // Records: voting 64 B {count, object_id+1, class_id+1, confidence_counter, position_sum f64[3],
-// color_sum f32[3], pad}; probabilistic 128 B with 7 inline label slots (hv_semantic.h).
+// color_sum f32[3], pad}; probabilistic 128 B with 6 inline label slots + a chain of overflow nodes (hv_semantic.h).
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -132,7 +132,7 @@ __device__ __forceinline__ void sem_fold_run(const HvTable &table, VOX *__restri
                 }
             } else {
                 const float lp = prob_observation_log_prob(depths != nullptr, depths ? depths[p] : 0.0f, G);
-                if (!prob_fold((HvProbVoxel *)&acc, count == 0, obj, cls, lp)) ++overflowed;
+                if (!prob_fold((HvProbVoxel *)&acc, table, count == 0, obj, cls, lp)) ++overflowed;
             }
         }
         count = count == 0 ? 1 : count + 1;
@@ -485,9 +485,9 @@ __global__ __launch_bounds__(256) void k_sem_collect(HvTable table, const VOX *_
                 out_pts[at * 3 + k] = v->pos[k] / c;
                 out_cols[at * 3 + k] = v->col[k] / cf;
             }
-            out_cls[at] = sem_class_id(v);
-            out_obj[at] = sem_object_id(v);
-            out_conf[at] = sem_confidence(v);
+            out_cls[at] = sem_class_id(v, table.prob_nodes);
+            out_obj[at] = sem_object_id(v, table.prob_nodes);
+            out_conf[at] = sem_confidence(v, table.prob_nodes);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_sem_collect(HvTable table, const VOX *_
             if (active) {
                 const VOX *v = pool + gid;
                 const int32_t count = v->count;
-                pred = count >= min_count && sem_confidence(v) >= min_confidence;
+                pred = count >= min_count && sem_confidence(v, table.prob_nodes) >= min_confidence;
                 if (pred && Q.kind != 0) {
                     const int l = (int)(gid - b * G.nvox);
                     const int32_t lc[3] = {l % G.bs, (l / G.bs) % G.bs, l / (G.bs * G.bs)};
@@ -676,10 +676,18 @@ static int sem_stage(hv_volume *v, const void *src, size_t bytes, int32_t loc, c
 template <typename VOX>
 static int sem_dump(hv_volume *v, int64_t nb, const std::vector<int64_t> &order, const std::vector<std::array<int32_t, 3>> &xyz,
                     int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums, int32_t *label_counts,
-                    int32_t *labels, float *log_probs) {
+                    int32_t *labels, float *log_probs, int32_t max_labels) {
     const int nvox = sem_params(v).nvox;
     std::vector<VOX> host((size_t)nb * nvox);
     HV_HIP(hipMemcpy(host.data(), v->pool, sizeof(VOX) * host.size(), hipMemcpyDeviceToHost));
+    std::vector<HvProbNode> host_nodes; // the label maps' overflow nodes handed out so far
+    if (v->table.prob_nodes != nullptr) {
+        int32_t used = 0;
+        HV_HIP(hipMemcpy(&used, v->table.counters + HV_CNT_PROB_NODES, sizeof(int32_t), hipMemcpyDeviceToHost));
+        host_nodes.resize((size_t)std::min(std::max(used, 0), v->table.prob_node_cap) + 1);
+        HV_HIP(hipMemcpy(host_nodes.data(), v->table.prob_nodes, sizeof(HvProbNode) * (host_nodes.size() - 1), hipMemcpyDeviceToHost));
+    }
+    const HvProbNode *nodes = host_nodes.empty() ? nullptr : host_nodes.data();
     for (int64_t o = 0; o < nb; ++o) {
         const int64_t i = order[o];
         if (keys) memcpy(keys + o * 3, xyz[i].data(), 12);
@@ -688,21 +696,22 @@ static int sem_dump(hv_volume *v, int64_t nb, const std::vector<int64_t> &order,
             const size_t at = (size_t)o * nvox + l;
             if (ints) {
                 int32_t *d = ints + at * 4;
-                d[0] = x->count; d[1] = sem_object_id(x); d[2] = sem_class_id(x); d[3] = sem_confidence_counter(x);
+                d[0] = x->count; d[1] = sem_object_id(x, nodes); d[2] = sem_class_id(x, nodes); d[3] = sem_confidence_counter(x, nodes);
             }
-            if (conf) conf[at] = sem_confidence(x);
+            if (conf) conf[at] = sem_confidence(x, nodes);
             if (pos_sums) memcpy(pos_sums + at * 3, x->pos, 24);
             if (col_sums) memcpy(col_sums + at * 3, x->col, 12);
             if constexpr (sizeof(VOX) == sizeof(HvProbVoxel)) {
                 const HvProbVoxel *p = (const HvProbVoxel *)x;
                 const int nlab = prob_nlab(p->meta);
                 if (label_counts) label_counts[at] = nlab;
-                for (int k = 0; k < HV_PROB_K; ++k) {
+                for (int k = 0; k < max_labels; ++k) { // (insertion order; the first max_labels pairs of longer maps)
+                    const HvProbPair q = k < nlab ? prob_get(p, nodes, k) : HvProbPair{-1, -1, 0.0f};
                     if (labels) {
-                        labels[(at * HV_PROB_K + k) * 2 + 0] = k < nlab ? p->obj[k] : -1;
-                        labels[(at * HV_PROB_K + k) * 2 + 1] = k < nlab ? p->cls[k] : -1;
+                        labels[(at * max_labels + k) * 2 + 0] = q.obj;
+                        labels[(at * max_labels + k) * 2 + 1] = q.cls;
                     }
-                    if (log_probs) log_probs[at * HV_PROB_K + k] = k < nlab ? p->logp[k] : 0.0f;
+                    if (log_probs) log_probs[at * max_labels + k] = q.logp;
                 }
             } else if (label_counts) {
                 label_counts[at] = 0;
@@ -905,8 +914,8 @@ int hv_get_voxels_semantic_in_frustum(hv_volume *v, const float *intr_f32, int32
 }
 
 int hv_dump_blocks_semantic2(hv_volume *v, int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums,
-                             int32_t *label_counts, int32_t *labels, float *log_probs, int64_t *n_blocks) {
-    HV_REQUIRE(v != nullptr && n_blocks != nullptr, HV_ERR_INVALID, "hv_dump_blocks_semantic: null argument");
+                             int32_t *label_counts, int32_t *labels, float *log_probs, int32_t max_labels, int64_t *n_blocks) {
+    HV_REQUIRE(v != nullptr && n_blocks != nullptr && max_labels >= 0, HV_ERR_INVALID, "hv_dump_blocks_semantic: null argument");
     HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_dump_blocks_semantic: wrong mode");
     int64_t nb = 0;
     int rc = hv_num_blocks(v, &nb);
@@ -921,13 +930,13 @@ int hv_dump_blocks_semantic2(hv_volume *v, int32_t *keys, int32_t *ints, float *
     std::iota(order.begin(), order.end(), 0);
     std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return xyz[a] < xyz[b]; });
     if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID)
-        return sem_dump<HvProbVoxel>(v, nb, order, xyz, keys, ints, conf, pos_sums, col_sums, label_counts, labels, log_probs);
-    return sem_dump<HvSemVoxel>(v, nb, order, xyz, keys, ints, conf, pos_sums, col_sums, label_counts, labels, log_probs);
+        return sem_dump<HvProbVoxel>(v, nb, order, xyz, keys, ints, conf, pos_sums, col_sums, label_counts, labels, log_probs, max_labels);
+    return sem_dump<HvSemVoxel>(v, nb, order, xyz, keys, ints, conf, pos_sums, col_sums, label_counts, labels, log_probs, max_labels);
 }
 
 int hv_dump_blocks_semantic(hv_volume *v, int32_t *keys, int32_t *ints, double *pos_sums, float *col_sums,
                             int64_t *n_blocks) {
-    return hv_dump_blocks_semantic2(v, keys, ints, nullptr, pos_sums, col_sums, nullptr, nullptr, nullptr, n_blocks);
+    return hv_dump_blocks_semantic2(v, keys, ints, nullptr, pos_sums, col_sums, nullptr, nullptr, nullptr, 0, n_blocks);
 }
 
 } // extern "C"

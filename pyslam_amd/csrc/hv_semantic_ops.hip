@@ -56,8 +56,13 @@ static int hv_dev_next_id(int device, int32_t **out) {
 
 template <typename VOX> __device__ __forceinline__ void sem_reset(VOX *v) {
     uint4 *q = (uint4 *)v;
+    uint32_t chain = 0u; // a probabilistic voxel keeps its overflow nodes for the label map it grows next
+    if constexpr (sizeof(VOX) == sizeof(HvProbVoxel)) chain = ((const HvProbVoxel *)v)->next;
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(VOX) / 16); ++i) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (sizeof(VOX) == sizeof(HvProbVoxel)) {
+        if (chain != 0u) ((HvProbVoxel *)v)->next = chain;
+    }
 }
 
 // The visit predicate of iterate_voxels_in_camera_frustrum (min_count = 1, min_confidence = 0).
@@ -66,7 +71,7 @@ __device__ __forceinline__ bool sem_visit(const HvQuery &Q, const HvTable &table
                                           const HvSemParams &G, float *uvd) {
     const int32_t count = v->count;
     if (count < 1) return false;
-    if (!(sem_confidence(v) >= 0.0f)) return false;
+    if (!(sem_confidence(v, table.prob_nodes) >= 0.0f)) return false;
     int32_t bk[3];
     hv_unpack_key(table.block_keys[b], bk[0], bk[1], bk[2]);
     const int32_t lc[3] = {l % G.bs, (l / G.bs) % G.bs, l / (G.bs * G.bs)};
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256) void k_sem_assoc_vote(HvTable table, VOX *__re
                 if (sem_visit(Q, table, v, b, (int)(gid - b * G.nvox), G, uvd)) {
                     const int64_t px = (int64_t)(int)uvd[1] * Q.width + (int)uvd[0];
                     const int32_t image_class = cls_img[px];
-                    const int32_t point_class = sem_class_id(v);
+                    const int32_t point_class = sem_class_id(v, table.prob_nodes);
                     inst = inst_img[px];
                     bool go = image_class >= 0 && point_class >= 0 && point_class == image_class && inst >= 0;
                     if (go && A.use_depth) {
@@ -272,11 +277,11 @@ __global__ __launch_bounds__(256) void k_sem_assoc_vote(HvTable table, VOX *__re
                         }
                     }
                     if (go) {
-                        int32_t obj = sem_object_id(v);
+                        int32_t obj = sem_object_id(v, table.prob_nodes);
                         if (obj < 0) {
                             if (inst == 0) {
                                 obj = 0;
-                                sem_set_object_id(v, 0);
+                                sem_set_object_id(v, table.prob_nodes, 0);
                             } else {
                                 obj = HV_OBJ_PENDING;
                                 is_pending = true;
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(256) void k_sem_assoc_apply(HvTable table, VOX *__r
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pending; i += gridDim.x * blockDim.x) {
         const int2 p = pending[i];
         const int32_t final_id = map_lookup(map_inst, map_obj, n_map, p.y, -1);
-        if (final_id >= 0) sem_set_object_id(pool + p.x, final_id);
+        if (final_id >= 0) sem_set_object_id(pool + p.x, table.prob_nodes, final_id);
     }
 }
 
@@ -529,8 +534,8 @@ __global__ __launch_bounds__(256) void k_seg_collect(HvTable table, const VOX *_
             if (active) {
                 const VOX *v = pool + gid;
                 // NB: strict '>' on the count, voxel_block_semantic_grid.hpp:224
-                if (v->count > min_count && sem_confidence(v) >= min_confidence) {
-                    obj = sem_object_id(v);
+                if (v->count > min_count && sem_confidence(v, table.prob_nodes) >= min_confidence) {
+                    obj = sem_object_id(v, table.prob_nodes);
                     pred = obj >= 0;
                 }
             }
@@ -553,7 +558,7 @@ template <typename VOX>
 __global__ __launch_bounds__(256) void k_seg_rows(const VOX *__restrict__ pool, const unsigned long long *__restrict__ keys,
                                                    int64_t n, double *__restrict__ out_pts, float *__restrict__ out_cols,
                                                    int32_t *__restrict__ out_obj, int32_t *__restrict__ out_cls,
-                                                   float *__restrict__ out_conf) {
+                                                   float *__restrict__ out_conf, const void *__restrict__ nodes) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned long long k = keys[i];
@@ -566,29 +571,29 @@ __global__ __launch_bounds__(256) void k_seg_rows(const VOX *__restrict__ pool, 
         out_cols[i * 3 + a] = v->col[a] / cf;
     }
     out_obj[i] = (int32_t)(k >> 32);
-    out_cls[i] = sem_class_id(v);
-    out_conf[i] = sem_confidence(v);
+    out_cls[i] = sem_class_id(v, nodes);
+    out_conf[i] = sem_confidence(v, nodes);
 }
 
 // op 0 merge_segments(a <- b), 1 remove_segment(a), 2 remove_low_confidence_segments(int a),
 // 3 remove_low_count_voxels(a), 4 remove_low_confidence_voxels(fa)
 template <typename VOX>
 __global__ __launch_bounds__(256) void k_sem_segment_op(VOX *__restrict__ pool, int64_t n_voxels, int op, int32_t a, int32_t b,
-                                                         float fa, const unsigned long long *__restrict__ occ) {
+                                                         float fa, const unsigned long long *__restrict__ occ, const void *__restrict__ nodes) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_voxels) return;
     if (!sem_maybe_occupied(occ, gid)) return; // a voxel that never took a point: every op leaves its zero record as it is
     VOX *v = pool + gid;
     if (op == 0) {
-        if (sem_object_id(v) == b) sem_set_object_id(v, a);
+        if (sem_object_id(v, nodes) == b) sem_set_object_id(v, nodes, a);
     } else if (op == 1) {
-        if (sem_object_id(v) == a) sem_reset(v);
+        if (sem_object_id(v, nodes) == a) sem_reset(v);
     } else if (op == 2) {
-        if (sem_confidence(v) < (float)a) sem_reset(v);
+        if (sem_confidence(v, nodes) < (float)a) sem_reset(v);
     } else if (op == 3) {
         if (v->count < a) sem_reset(v);
     } else if (op == 4) {
-        if (sem_confidence(v) < fa) sem_reset(v);
+        if (sem_confidence(v, nodes) < fa) sem_reset(v);
     }
 }
 
@@ -786,7 +791,7 @@ template <typename VOX> int sem_launch_segment_op(hv_volume *v, int op, int32_t 
     if (nb == 0) return HV_OK;
     const int64_t total = nb * sem_params(v).nvox;
     hipLaunchKernelGGL(k_sem_segment_op<VOX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, (VOX *)v->pool,
-                       total, op, a, b, fa, (op == 0 && b < 0) ? nullptr : v->occ); // (merging INTO the voxels without an object id reaches empty ones too)
+                       total, op, a, b, fa, (op == 0 && b < 0) ? nullptr : v->occ, (const void *)v->table.prob_nodes); // (merging INTO the voxels without an object id reaches empty ones too)
     HV_HIP(hipGetLastError());
     return HV_OK;
 }
@@ -1226,10 +1231,10 @@ int hv_object_segments_compute(hv_volume *v, int32_t min_count, float min_confid
     const dim3 rgrid((unsigned)((m + 255) / 256));
     if (prob)
         hipLaunchKernelGGL(k_seg_rows<HvProbVoxel>, rgrid, dim3(256), 0, v->stream, (const HvProbVoxel *)v->pool, d_sorted, m, d_pts,
-                           d_cols, d_obj, d_cls, d_conf);
+                           d_cols, d_obj, d_cls, d_conf, (const void *)v->table.prob_nodes);
     else
         hipLaunchKernelGGL(k_seg_rows<HvSemVoxel>, rgrid, dim3(256), 0, v->stream, (const HvSemVoxel *)v->pool, d_sorted, m, d_pts,
-                           d_cols, d_obj, d_cls, d_conf);
+                           d_cols, d_obj, d_cls, d_conf, (const void *)nullptr);
     HV_HIP(hipGetLastError());
     C.pts.resize((size_t)m * 3);
     C.cols.resize((size_t)m * 3);

@@ -629,8 +629,9 @@ class _SemanticGridBase(_Volume):
         """-> keys [B,3], ints [B,bs^3,4] {count, object_id, class_id, confidence_counter}, pos_sums f64, col_sums f32."""
         return self.dump2()[:4]
 
-    def dump2(self):
-        """dump() + conf [B,bs^3] f32, label_counts [B,bs^3], labels [B,bs^3,7,2], log_probs [B,bs^3,7]."""
+    def dump2(self, max_labels=7):
+        """dump() + conf [B,bs^3] f32, label_counts [B,bs^3] (each voxel's map size), labels [B,bs^3,max_labels,2] and
+        log_probs [B,bs^3,max_labels] (each map's first max_labels pairs, insertion order)."""
         nb, nv = self.num_blocks(), self.block_size ** 3
         keys = np.zeros((nb, 3), np.int32)
         ints = np.zeros((nb, nv, 4), np.int32)
@@ -638,11 +639,11 @@ class _SemanticGridBase(_Volume):
         pos = np.zeros((nb, nv, 3), np.float64)
         col = np.zeros((nb, nv, 3), np.float32)
         nlab = np.zeros((nb, nv), np.int32)
-        labels = np.zeros((nb, nv, 7, 2), np.int32)
-        logp = np.zeros((nb, nv, 7), np.float32)
+        labels = np.zeros((nb, nv, max_labels, 2), np.int32)
+        logp = np.zeros((nb, nv, max_labels), np.float32)
         n = ctypes.c_int64()
         L.check(self._lib.hv_dump_blocks_semantic2(self._h, L.ptr(keys), L.ptr(ints), L.ptr(conf), L.ptr(pos), L.ptr(col), L.ptr(nlab),
-                                                   L.ptr(labels), L.ptr(logp), ctypes.byref(n)))
+                                                   L.ptr(labels), L.ptr(logp), int(max_labels), ctypes.byref(n)))
         return keys, ints, pos, col, conf, nlab, labels, logp
 
 

@@ -60,7 +60,7 @@ def test_probabilistic_stream(pos_dtype, use_inst, use_depth):
         g.set_depth_decay_rate(0.07)
     for it in range(4):
         pts, cols, cls, inst, dep = stream(500 + it, 60000, pos_dtype)
-        cls, inst = cls % 3, inst % 2  # <= 6 distinct (object, class) pairs per voxel: inside the 7 inline label slots
+        cls, inst = cls % 3, inst % 2  # <= 6 distinct (object, class) pairs per voxel: inside the 6 inline label slots
         c = cols if it != 1 else (cols / 255.0).astype(np.float32)
         for g in (gpu, ref):
             g.integrate(pts, c, cls, inst if use_inst else None, dep if use_depth else None)
@@ -77,13 +77,65 @@ def test_probabilistic_stream(pos_dtype, use_inst, use_depth):
             np.testing.assert_allclose(got[4], exp[4], rtol=0, atol=2e-6)
 
 
-def test_probabilistic_label_overflow_is_counted():
-    gpu = gpu_grid(PROB, 0.1, max_blocks=1 << 8, max_points=1 << 12)
-    n = 12
-    gpu.integrate(np.zeros((n, 3), np.float32), np.zeros((n, 3), np.uint8), np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32))
-    assert gpu.label_overflows() == n - 7
-    v = gpu.get_voxels(1, 0.0)
+def _many_label_stream(seed, n, n_cls, n_inst):
+    pts, cols, _, _, dep = stream(seed, n)
+    rng = np.random.default_rng(seed + 77)
+    return pts, cols, rng.integers(0, n_cls, n).astype(np.int32), rng.integers(0, n_inst, n).astype(np.int32), dep
+
+
+def test_probabilistic_label_maps_grow_past_the_inline_slots_like_the_reference():
+    """Up to 63 distinct (object, class) pairs per voxel (the reference's std::map is unbounded; here 6 inline slots + chained
+    10-pair nodes): every count, sum, arg-max label and confidence as the compiled reference's, nothing dropped.  A segment removal
+    resets voxels whose maps had grown chains; the maps they grow afterwards reuse the chains and stay the reference's."""
+    gpu, ref = gpu_grid(PROB, 0.2), RefSemGrid2(PROB, 0.2)
+    for g in (gpu, ref):
+        g.set_depth_threshold(5.0)
+        g.set_depth_decay_rate(0.07)
+    for it in range(3):
+        pts, cols, cls, inst, dep = _many_label_stream(900 + it, 60000, 7, 9)
+        for g in (gpu, ref):
+            g.integrate(pts, cols, cls, inst, dep if it != 1 else None)
+    assert gpu.dropped_points() == 0 and gpu.label_overflows() == 0
+    nlab = gpu.dump2(max_labels=64)[5]
+    assert nlab.max() > 26  # maps of three nodes and more
+    assert_state_equal(gpu, ref, PROB)
+    labels = gpu.dump2(max_labels=64)[6]
+    v = np.unravel_index(np.argmax(nlab), nlab.shape)
+    pairs = labels[v][: nlab[v]]
+    assert len({tuple(p) for p in pairs}) == nlab[v] and (pairs >= 0).all()  # a map holds each pair once
+    for g in (gpu, ref):
+        g.remove_segment(3)
+        g.merge_segments(1, 2)
+    assert_state_equal(gpu, ref, PROB)
+    pts, cols, cls, inst, dep = _many_label_stream(990, 60000, 7, 9)
+    for g in (gpu, ref):
+        g.integrate(pts, cols, cls, inst, dep)
+    assert gpu.label_overflows() == 0
+    assert_state_equal(gpu, ref, PROB)
+    v = gpu.get_voxels(2, 0.05)
+    got, exp = srt((v.points, v.colors, v.class_ids, v.object_ids, v.confidences)), srt(ref.get_voxels(2, 0.05))
+    if len(got[0]) == len(exp[0]):  # (confidences within 1 ulp of the threshold may flip)
+        for a, b in zip(got[:4], exp[:4]):
+            np.testing.assert_array_equal(a, b)
+    assert abs(len(got[0]) - len(exp[0])) <= 2
+
+
+def test_probabilistic_label_overflow_is_counted(monkeypatch):
+    """A label observation is dropped only past 254 pairs in one voxel or with the node pool exhausted - and then counted."""
+    def one_voxel(n):
+        g = gpu_grid(PROB, 0.1, max_blocks=1 << 8, max_points=1 << 12)
+        g.integrate(np.zeros((n, 3), np.float32), np.zeros((n, 3), np.uint8), np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32))
+        return g
+
+    g = one_voxel(12)
+    assert g.label_overflows() == 0 and g.dump2()[5].max() == 12
+    v = g.get_voxels(1, 0.0)
     assert len(v.points) == 1 and v.object_ids[0] == 0  # first label keeps the arg-max (ties keep the incumbent)
+    g = one_voxel(300)
+    assert g.label_overflows() == 300 - 254 and g.dump2()[5].max() == 254
+    monkeypatch.setenv("HV_PROB_NODE_CAP", "1")
+    g = one_voxel(30)
+    assert g.label_overflows() == 30 - 16 and g.dump2()[5].max() == 16  # 6 inline + the pool's only node
 
 
 @pytest.mark.parametrize("kind", [VOTE, PROB])

@@ -123,10 +123,11 @@ def test_obb_pca_matches_reference_boxes():
 
 def test_label_map_sizes_the_reference_builds():
     """How many (object, class) pairs the reference's unbounded per-voxel std::map really holds (the port's map, bit-identical on
-    every flow above), against the product's 7 inline slots (hv_semantic.h: the 8th distinct pair of a voxel is dropped and
-    counted).  On the labelled synthetic stream the largest map has 4 pairs; uniform random label noise - the harshest model:
-    every noisy pixel draws one of 40 x 30 pairs - pushes 1-2 % of the voxels past 7 at a 5 % noise rate.  The cap is exact for
-    consistent labels and a measured, counted divergence of the confidences (never of keys, counts or sums) under noise."""
+    every flow above): what the product's layout is sized by (hv_semantic.h: 6 pairs in the voxel record, 10-pair overflow nodes
+    chained beyond them).  On the labelled synthetic stream the largest map has 4 pairs; uniform random label noise - the harshest
+    model: every noisy pixel draws one of 40 x 30 pairs - pushes 1-2 % of the voxels past 7 pairs at a 5 % noise rate (rounds 1-3
+    dropped those pairs; tests/test_gpu_semantic_ops.py::test_probabilistic_label_maps_grow_past_the_inline_slots_like_the_reference
+    is the parity test of the chained maps)."""
     from pyslam_amd.synthetic import SyntheticRGBD
     from tests.semantic_helpers import CFG, frame_points, semantic_frame
 
@@ -148,4 +149,4 @@ def test_label_map_sizes_the_reference_builds():
     assert 1 <= most <= 4 and hist[5:].sum() == 0
     most, hist = result[0.05]
     over = hist[8:].sum() / hist.sum()
-    assert most > 7 and 0.005 < over < 0.05  # the cap WOULD bind here: 1-2 % of the occupied voxels
+    assert most > 7 and 0.005 < over < 0.05  # 1-2 % of the occupied voxels need an overflow node

@@ -41,8 +41,9 @@ python $R/tools/timeline.py $R/gpurun_out/rank1_kt 16 > $R/gpurun_out/pipeline_t
 popd > /dev/null
 python tools/pmc_summary.py --json gpurun_out/pmc_voxel_grid.json --command-key "tools/bench_voxel_grid.py --steps 3" gpurun_out/vg_pmc_FETCH_SIZE gpurun_out/vg_pmc_WRITE_SIZE > gpurun_out/vg_pmc_summary.txt 2>&1; grep -E "vgb|vg_" gpurun_out/vg_pmc_summary.txt | cut -c1-200
 cp gpurun_out/pmc_voxel_grid.json profiles/$ROUND/pmc_voxel_grid.json
-python tools/pmc_summary.py --json profiles/$ROUND/pmc_semantic.json --command-key "tools/bench_semantic.py --frames 10 --cpu-frames 0" gpurun_out/sem_pmc_FETCH_SIZE gpurun_out/sem_pmc_WRITE_SIZE > gpurun_out/sem_pmc_summary.txt 2>&1
-python tools/pmc_summary.py --json profiles/$ROUND/pmc_semantic_scannet_2mm.json --command-key "tools/bench_semantic.py --frames 5 --cpu-frames 0 --voxel 0.002 --config scannet_1296x968_2mm --stride 2" gpurun_out/sem2_pmc_FETCH_SIZE gpurun_out/sem2_pmc_WRITE_SIZE > gpurun_out/sem2_pmc_summary.txt 2>&1
+python tools/pmc_summary.py --json gpurun_out/pmc_semantic.json --command-key "tools/bench_semantic.py --frames 10 --cpu-frames 0" gpurun_out/sem_pmc_FETCH_SIZE gpurun_out/sem_pmc_WRITE_SIZE > gpurun_out/sem_pmc_summary.txt 2>&1
+python tools/pmc_summary.py --json gpurun_out/pmc_semantic_scannet_2mm.json --command-key "tools/bench_semantic.py --frames 5 --cpu-frames 0 --voxel 0.002 --config scannet_1296x968_2mm --stride 2" gpurun_out/sem2_pmc_FETCH_SIZE gpurun_out/sem2_pmc_WRITE_SIZE > gpurun_out/sem2_pmc_summary.txt 2>&1
+cp gpurun_out/pmc_semantic.json gpurun_out/pmc_semantic_scannet_2mm.json profiles/$ROUND/
 grep -E "sem|shadow" gpurun_out/sem2_pmc_summary.txt | cut -c1-200 | head -12
 timeout 200 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
 timeout 600 python bench.py > gpurun_out/bench_n1.log 2>&1

@@ -17,6 +17,47 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+_FLOW_KERNELS = ("k_shadow_", "k_sem_assoc_", "k_remap_instance_ids", "k_vg_unproject", "k_semb_", "k_vgb_offsets", "k_sem_keys",
+                 "k_sem_reduce", "k_sem_carve")
+
+
+def flow_traffic(pmc_file, payload_tag):
+    """HBM bytes of one keyframe's flow from the recorded --pmc passes of this tool on THIS build (tools/_final.sh; two separate
+    passes, FETCH_SIZE then WRITE_SIZE, MI355X_MICROARCH.md's HBM section): sum over the flow's kernels of (2 x FETCH_SIZE +
+    WRITE_SIZE) x 1024 x launches per keyframe.  A kernel instantiated per payload counts for its payload; the others ran for both
+    payloads of the recorded command, half of their launches each.  -> (bytes, per-kernel dict) or (None, None)."""
+    from bench import PROFILE_ROUND, current_build_digest, hbm_traffic
+
+    try:
+        with open(os.path.join(ROOT, "profiles", PROFILE_ROUND, pmc_file)) as f:
+            z = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    if z.get("build_digest") != current_build_digest():
+        return None, None
+    frames = None
+    for tok in z.get("command_key", "").split("--frames")[1:]:
+        frames = int(tok.split()[0])
+    if not frames:
+        return None, None
+    per = {}
+    for name, pk in z.get("kernels", {}).items():
+        if not any(k in name for k in _FLOW_KERNELS):
+            continue
+        t = hbm_traffic(pk)
+        if t is None:
+            continue
+        if "HvSemVoxel" in name or "HvProbVoxel" in name:
+            if payload_tag not in name:
+                continue
+            share = pk["launches"] / frames
+        else:
+            share = pk["launches"] / (2.0 * frames)
+        short = name.replace("void ", "").split("<")[0]
+        per[short] = per.get(short, 0) + int(t * share)
+    return (int(sum(per.values())), per) if per else (None, None)
+
+
 def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x480_5mm", stride=3):
     """-> dict (bench.py's `semantic` key / this tool's JSON line).  config="scannet_1296x968_2mm", voxel=0.002 is BASELINE
     configs[4]'s shape (1.25 M points per keyframe, 1.6 cm blocks)."""
@@ -108,6 +149,11 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
                "get_voxels_ms": round(t_get * 1e3, 2), "voxels_out": int(len(v.points)),
                "get_object_segments_ms": round(t_seg * 1e3, 2), "objects": len(segs.object_vector), "blocks": int(g.num_blocks()),
                "label_overflows": g.label_overflows()}
+        traffic, per = flow_traffic("pmc_semantic_scannet_2mm.json" if args.voxel < 0.004 else "pmc_semantic.json", "HvSemVoxel" if kind == 0 else "HvProbVoxel")
+        if traffic is not None:
+            res["roofline"]["traffic"] = traffic
+            res["roofline"]["traffic_per_kernel"] = per
+            res["roofline"]["traffic_source"] = "recorded rocprofv3 --pmc passes of tools/bench_semantic.py on this build (profiles/, build digest checked)"
         if oracle.ref_available() and args.cpu_frames > 0:
             # The compiled reference runs the same flow on the first cpu_frames + 1 keyframes of the stream - and is COMPARED with a fresh
             # HIP grid fed the same keyframes (tests/semantic_helpers.py::compare_keyframe_flow: filtered depth, id maps, id images
