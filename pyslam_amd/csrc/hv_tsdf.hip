@@ -2794,11 +2794,18 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
             hipLaunchKernelGGL(k_tsdf_batch_list, dim3((unsigned)((v->cfg.max_blocks + 255) / 256)), dim3(256), 0, v->stream, v->table,
                                (const int32_t *)v->touched_stamp, batch_stamp, d_list);
         }
+        // What the NEXT batch's touch + pack launch waits for: everything the main stream holds up to here, i.e. the finish of the
+        // batch that last used the next batch's scratch set.  Recorded BEFORE the main stream waits for this batch's own touch + pack
+        // launch (round 4; HV_TSDF_PRESWEEP_LATE=1: after it, as rounds 2-3 did): the aux stream is in order, so the next launch
+        // follows this batch's there anyway, and with the late form every touch + pack launch also waited for the cross-queue
+        // hand-off into the sweep before it (~23 us + the upload: profiles/r04/rank8_timeline.txt, the critical loop of a 1/8 share).
+        const bool presweep_late = getenv("HV_TSDF_PRESWEEP_LATE") && atoi(getenv("HV_TSDF_PRESWEEP_LATE")) != 0;
+        if (!presweep_late) HV_HIP(hipEventRecord(v->ev_presweep, v->stream));
         if (overlap_this) {
             HV_HIP(hipEventRecord(v->ev_prep, v->stream_aux));
             HV_HIP(hipStreamWaitEvent(v->stream, v->ev_prep, 0));
         }
-        HV_HIP(hipEventRecord(v->ev_presweep, v->stream)); // what the NEXT batch's touch + pack launch waits for
+        if (presweep_late) HV_HIP(hipEventRecord(v->ev_presweep, v->stream));
         chain_ok = true;                                   // (the next chunk of this call may follow this one directly)
         hv_profile_begin(v);
         const int sweep_zh = getenv("HV_TSDF_SWEEP_ZH") ? atoi(getenv("HV_TSDF_SWEEP_ZH")) : 4;
