@@ -207,6 +207,8 @@ int hv_get_voxels_semantic_in_frustum(hv_volume *v, const float *intr_f32, int32
 int hv_set_depth_threshold(hv_volume *v, float depth_threshold);
 /* set_depth_decay_rate() (voxel_block_semantic_grid.hpp:32-37), probabilistic payload; default 0.07 1/m. */
 int hv_set_depth_decay_rate(hv_volume *v, float depth_decay_rate);
+/* Label observations the probabilistic payload could not store (a voxel's map past 254 pairs, or the overflow-node pool exhausted):
+ * 0 in every test and bench run; never silent. */
 int hv_label_overflows(hv_volume *v, int64_t *n);
 /* assign_object_ids_to_instance_ids(camera_frustrum, class_ids_image i32 HxW, semantic_instances_image i32 HxW,
  * depth_image f32 HxW | NULL, depth_threshold, do_carving, min_vote_ratio, min_votes)

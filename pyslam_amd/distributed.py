@@ -10,14 +10,15 @@ it is free next to the ~0.5 GB of voxel traffic it causes).  Two ways to split t
     simply distributed over the ranks — no collective while fusing.  ``gather_to_root()`` collects
     it on one rank when a mesh is wanted.
 
-``sharding="coherent"`` (round 4; what ``bench.py --gpus N`` runs) — ownership is PLANNED PER BATCH on the device
-    (``hv_tsdf_set_sharding``, kernels ``k_tsdf_touch_plan / _plan_hist / _plan_assign``): every rank enumerates the batch's
+``sharding="coherent"`` (round 4, optional: ``bench.py --gpus N --sharding coherent``) — ownership is PLANNED PER BATCH on the
+    device (``hv_tsdf_set_sharding``, kernels ``k_tsdf_touch_plan`` / ``k_tsdf_plan_assign``): every rank enumerates the batch's
     units into a small replicated table, all ranks derive the same plan from it without talking — equal WORK per rank, a
-    rank's units contiguous in the image (ragged vertical strips of the batch's middle frame) — and a rank then claims, packs
-    and sweeps only its part of every frame: the per-batch replicated work (pack: 187 MB per 32 frames under hash ownership)
-    shrinks with N.  A (unit, frame) pair is fused by exactly one rank; ownership moves with the camera, so a unit's
-    additive numerators may live on several ranks: ``merge_halo()`` / ``gather_to_root()`` consolidate them like the tile
-    form's (no duplicated sweeps, unlike the tile form).
+    rank's units contiguous in the image (cells of the batch's middle frame) — and a rank then claims, packs and sweeps only
+    its part of every frame: the per-batch replicated pack (206 MB per 32 frames under hash ownership) shrinks with N.  A
+    (unit, frame) pair is fused by exactly one rank; ownership moves with the camera, so a unit's additive numerators may live
+    on several ranks: ``merge_halo()`` / ``gather_to_root()`` consolidate them like the tile form's (no duplicated sweeps,
+    unlike the tile form).  Measured SLOWER than the hash form on one GPU's projection (deciding costs more than the smaller
+    pack saves: DESIGN section 6, profiles/r04/touch_plan_ablation.txt), which is why it is not the default.
 
 ``sharding="tile"`` (north-star form) — rank r fuses only the voxels whose projection falls into its
     vertical image tile (``hv_tsdf_set_tile``); a unit that cannot project into a rank's tile is neither

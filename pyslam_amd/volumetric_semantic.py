@@ -602,6 +602,7 @@ class _SemanticGridBase(_Volume):
         L.check(self._lib.hv_remove_low_confidence_voxels(self._h, float(min_confidence)))
 
     def label_overflows(self):
+        """Label observations the probabilistic payload dropped (a map past 254 pairs / the overflow-node pool exhausted); 0 otherwise."""
         n = ctypes.c_int64()
         L.check(self._lib.hv_label_overflows(self._h, ctypes.byref(n)))
         return n.value
