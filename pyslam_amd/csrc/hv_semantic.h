@@ -110,13 +110,16 @@ __host__ __device__ inline const HvProbNode *prob_node_of(const HvProbVoxel *v, 
     }
     return &nodes[n - 1];
 }
+// CHAIN = false: the caller knows that the map has no pair beyond the inline slots (the common case: the node walk is compiled out)
+template <bool CHAIN = true>
 __host__ __device__ inline HvProbPair prob_get(const HvProbVoxel *v, const HvProbNode *nodes, int i) {
-    if (i < HV_PROB_K) return {v->obj[i], v->cls[i], v->logp[i]};
+    if (!CHAIN || i < HV_PROB_K) return {v->obj[i], v->cls[i], v->logp[i]};
     const HvProbNode *nd = prob_node_of(v, nodes, i);
     return {nd->obj[i], nd->cls[i], nd->logp[i]};
 }
+template <bool CHAIN = true>
 __host__ __device__ inline void prob_set_logp(HvProbVoxel *v, HvProbNode *nodes, int i, float lp) {
-    if (i < HV_PROB_K) {
+    if (!CHAIN || i < HV_PROB_K) {
         v->logp[i] = lp;
         return;
     }
@@ -124,11 +127,12 @@ __host__ __device__ inline void prob_set_logp(HvProbVoxel *v, HvProbNode *nodes,
     nd->logp[i] = lp;
 }
 // update_cache(), voxel_data_semantic.h:575-601: the first maximum in map (key) order
+template <bool CHAIN = true>
 __host__ __device__ inline int prob_argmax(const HvProbVoxel *v, const HvProbNode *nodes, int nlab) {
     int best = -1;
     HvProbPair bp{0, 0, 0.f};
     for (int i = 0; i < nlab; ++i) {
-        const HvProbPair p = prob_get(v, nodes, i);
+        const HvProbPair p = prob_get<CHAIN>(v, nodes, i);
         if (best < 0 || p.logp > bp.logp || (p.logp == bp.logp && prob_key(p.obj, p.cls) < prob_key(bp.obj, bp.cls))) {
             best = i;
             bp = p;
@@ -213,19 +217,20 @@ __host__ __device__ inline void sem_set_object_id(HvProbVoxel *v, const void *no
 // One semantic observation folded into a probabilistic voxel: initialize_semantics_log_prob
 // (count == 0, voxel_data_semantic.h:311-324) or update_semantics_log_prob (:358-417).  Returns false when the pair is new and
 // cannot be stored (254 pairs, or the node pool is exhausted): the observation is dropped and counted.
-__device__ inline bool prob_fold(HvProbVoxel *v, const HvTable &table, bool first, int32_t obj, int32_t cls, float lp) {
+template <bool CHAIN>
+__device__ inline bool prob_fold_t(HvProbVoxel *v, const HvTable &table, bool first, int32_t obj, int32_t cls, float lp) {
     HvProbNode *nodes = (HvProbNode *)table.prob_nodes;
     int nlab = prob_nlab(v->meta), best = prob_best(v->meta);
     int idx = -1;
     for (int i = 0; i < nlab; ++i) {
-        const HvProbPair p = prob_get(v, nodes, i);
+        const HvProbPair p = prob_get<CHAIN>(v, nodes, i);
         if (p.obj == obj && p.cls == cls) idx = i;
     }
-    float best_lp = best >= 0 ? prob_get(v, nodes, best).logp : 0.f;
+    float best_lp = best >= 0 ? prob_get<CHAIN>(v, nodes, best).logp : 0.f;
     if (idx < 0) {
         // a new pair goes to index nlab: inline, or in the chain's node (nlab - K) / NK, which may have to be linked in first
         if (nlab >= HV_PROB_MAX) return false;
-        if (nlab >= HV_PROB_K && (nlab - HV_PROB_K) % HV_PROB_NK == 0) {
+        if (CHAIN && nlab >= HV_PROB_K && (nlab - HV_PROB_K) % HV_PROB_NK == 0) {
             uint32_t *link = &v->next;
             for (int hop = (nlab - HV_PROB_K) / HV_PROB_NK; hop > 0; --hop) link = &nodes[*link - 1].next;
             if (*link == 0u) { // (a chain left behind by a collapsed map is taken up again)
@@ -237,7 +242,7 @@ __device__ inline bool prob_fold(HvProbVoxel *v, const HvTable &table, bool firs
             }
         }
         idx = nlab++;
-        if (idx < HV_PROB_K) {
+        if (!CHAIN || idx < HV_PROB_K) {
             v->obj[idx] = obj;
             v->cls[idx] = cls;
             v->logp[idx] = lp;
@@ -253,27 +258,31 @@ __device__ inline bool prob_fold(HvProbVoxel *v, const HvTable &table, bool firs
         } else if (best >= 0) {
             if (lp > best_lp) best = idx;
         } else {
-            best = prob_argmax(v, nodes, nlab);
+            best = prob_argmax<CHAIN>(v, nodes, nlab);
         }
     } else if (first) {
-        prob_set_logp(v, nodes, idx, lp);
+        prob_set_logp<CHAIN>(v, nodes, idx, lp);
         best = idx;
     } else {
-        const float old = prob_get(v, nodes, idx).logp;
+        const float old = prob_get<CHAIN>(v, nodes, idx).logp;
         const float now = old + lp;
-        prob_set_logp(v, nodes, idx, now);
+        prob_set_logp<CHAIN>(v, nodes, idx, now);
         if (best >= 0) {
             if (idx == best) {
-                if (now < old) best = prob_argmax(v, nodes, nlab);
+                if (now < old) best = prob_argmax<CHAIN>(v, nodes, nlab);
             } else if (now > best_lp) {
                 best = idx;
             }
         } else {
-            best = prob_argmax(v, nodes, nlab);
+            best = prob_argmax<CHAIN>(v, nodes, nlab);
         }
     }
     v->meta = prob_meta(nlab, best);
     return true;
+}
+// (a map that stays inside the inline slots after this observation takes the version without the node walk)
+__device__ inline bool prob_fold(HvProbVoxel *v, const HvTable &table, bool first, int32_t obj, int32_t cls, float lp) {
+    return prob_nlab(v->meta) < HV_PROB_K ? prob_fold_t<false>(v, table, first, obj, cls, lp) : prob_fold_t<true>(v, table, first, obj, cls, lp);
 }
 #endif
 

@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256) void k_semb_fold_wave(HvTable table, VOX *__re
                                                          const int32_t *__restrict__ class_ids, const int32_t *__restrict__ instance_ids,
                                                          const float *__restrict__ depths, unsigned long long *__restrict__ occ,
                                                          int64_t n_points, int idx_bits, HvStatus *status, int32_t status_seq,
-                                                         int32_t *__restrict__ task_count, int4 *__restrict__ tasks, int task_cap) {
-    extern __shared__ uint32_t s_dyn[]; // per wave: [WCAP src][WCAP dst][nvox + 64 offsets]
+                                                         int32_t *__restrict__ task_count, int4 *__restrict__ tasks, int task_cap, int wcap) {
+    extern __shared__ uint32_t s_dyn[]; // per wave: [wcap src][wcap dst][nvox + 64 offsets]; wcap = the window, a power of two (HV_SEM_WCAP)
     const int n_touched = (int)(cursor_and_len[parity] >> 32);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         task_count[parity ^ 1] = 0;        // the next call's task list
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(256) void k_semb_fold_wave(HvTable table, VOX *__re
         hv_publish_status(table, status, status_seq);
     }
     const int wave = threadIdx.x >> 6, lane = hv_lane_id();
-    const int per_wave = 2 * HV_VGB_WCAP + G.nvox + 64;
-    uint32_t *s = s_dyn + wave * per_wave, *s_dst = s + HV_VGB_WCAP, *off = s + 2 * HV_VGB_WCAP;
+    const int per_wave = 2 * wcap + G.nvox + 64;
+    uint32_t *s = s_dyn + wave * per_wave, *s_dst = s + wcap, *off = s + 2 * wcap;
     const uint32_t idx_mask = (1u << idx_bits) - 1u;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     auto fold_sorted = [&](int m, int64_t block_base) {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_semb_fold_wave(HvTable table, VOX *__re
         if (lane == 0) cnt[slot] = 0; // clean for the next call
         if (idx < 0) continue;        // (the block did not get a pool slot: overflow, reported by the caller)
         const int64_t block_base = (int64_t)idx * G.nvox;
-        if (nb <= HV_VGB_WCAP) {
+        if (nb <= wcap) {
             for (int e = lane; e < nb; e += HV_WAVE) s[e] = entries[start + e];
             hv_wave_lds_sync();
             semb_sort_window(s, s_dst, off, nb, idx_bits, G.nvox);
@@ -340,11 +340,11 @@ __global__ __launch_bounds__(256) void k_semb_fold_wave(HvTable table, VOX *__re
         // voxel-index ranges narrow enough for a range's entries to fit the window; a range that still overflows (very many points
         // in few voxels) is folded in point-index windows (a voxel's points still arrive in order)
         int parts = 2;
-        while (nb / parts > HV_VGB_WCAP / 2 && parts < G.nvox) parts <<= 1;
+        while (nb / parts > wcap / 2 && parts < G.nvox) parts <<= 1;
         const int width = (G.nvox + parts - 1) / parts;
         for (int lo = 0; lo < G.nvox; lo += width) {
             const uint32_t hi = (uint32_t)(lo + width);
-            for (int64_t w = -1; w < n_points; w += HV_VGB_WCAP) { // w = -1: the whole range at once
+            for (int64_t w = -1; w < n_points; w += wcap) { // w = -1: the whole range at once
                 hv_wave_lds_sync();
                 int m = 0;
                 bool overflow = false;
@@ -353,9 +353,9 @@ __global__ __launch_bounds__(256) void k_semb_fold_wave(HvTable table, VOX *__re
                     const uint32_t ent = e < nb ? entries[start + e] : 0u;
                     const uint32_t li = ent >> idx_bits;
                     const int64_t p = ent & idx_mask;
-                    const bool in = e < nb && li >= (uint32_t)lo && li < hi && (w < 0 || (p >= w && p < w + HV_VGB_WCAP));
+                    const bool in = e < nb && li >= (uint32_t)lo && li < hi && (w < 0 || (p >= w && p < w + wcap));
                     const unsigned long long bm = __ballot(in);
-                    if (m + __popcll(bm) > HV_VGB_WCAP) {
+                    if (m + __popcll(bm) > wcap) {
                         overflow = true;
                         break;
                     }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_semb_fold_wave(HvTable table, VOX *__re
                     m += __popcll(bm);
                 }
                 if (overflow) {
-                    w = -(int64_t)HV_VGB_WCAP; // next: w = 0
+                    w = -(int64_t)wcap; // next: w = 0
                     continue;
                 }
                 if (m > 0) {
@@ -386,12 +386,12 @@ __global__ __launch_bounds__(256) void k_semb_fold_tasks(HvTable table, VOX *__r
                                                           const uint32_t *__restrict__ entries, HvSemParams G, const PT *__restrict__ pts,
                                                           const void *__restrict__ cols, const int32_t *__restrict__ class_ids,
                                                           const int32_t *__restrict__ instance_ids, const float *__restrict__ depths,
-                                                          unsigned long long *__restrict__ occ, int64_t n_points, int idx_bits) {
+                                                          unsigned long long *__restrict__ occ, int64_t n_points, int idx_bits, int wcap) {
     extern __shared__ uint32_t s_dyn[];
     const int n_tasks = min(task_count[parity], task_cap);
     const int wave = threadIdx.x >> 6, lane = hv_lane_id();
-    const int per_wave = 2 * HV_VGB_WCAP + G.nvox + 64;
-    uint32_t *s = s_dyn + wave * per_wave, *s_dst = s + HV_VGB_WCAP, *off = s + 2 * HV_VGB_WCAP;
+    const int per_wave = 2 * wcap + G.nvox + 64;
+    uint32_t *s = s_dyn + wave * per_wave, *s_dst = s + wcap, *off = s + 2 * wcap;
     const uint32_t idx_mask = (1u << idx_bits) - 1u;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (int t = blockIdx.x * 4 + wave; t < n_tasks; t += gridDim.x * 4) {
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void k_semb_fold_tasks(HvTable table, VOX *__r
                                                   [&](int j) -> int64_t { return (e + j < m && (s[e + j] >> idx_bits) == lidx) ? (int64_t)(s[e + j] & idx_mask) : -1; });
             }
         };
-        for (int64_t w = -1; w < n_points; w += HV_VGB_WCAP) { // w = -1: the whole range at once; on overflow: point-index windows
+        for (int64_t w = -1; w < n_points; w += wcap) { // w = -1: the whole range at once; on overflow: point-index windows
             hv_wave_lds_sync();
             int m = 0;
             bool overflow = false;
@@ -423,9 +423,9 @@ __global__ __launch_bounds__(256) void k_semb_fold_tasks(HvTable table, VOX *__r
                     const int e = e0 + k * HV_WAVE + lane;
                     const uint32_t li = ent[k] >> idx_bits;
                     const int64_t p = ent[k] & idx_mask;
-                    const bool in = e < nb && li >= lo && li < hi && (w < 0 || (p >= w && p < w + HV_VGB_WCAP));
+                    const bool in = e < nb && li >= lo && li < hi && (w < 0 || (p >= w && p < w + wcap));
                     const unsigned long long bm = __ballot(in);
-                    if (m + __popcll(bm) > HV_VGB_WCAP) {
+                    if (m + __popcll(bm) > wcap) {
                         overflow = true;
                         break;
                     }
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_semb_fold_tasks(HvTable table, VOX *__r
                 }
             }
             if (overflow) { // (only possible for w = -1: a window holds at most WCAP distinct point indices)
-                w = -(int64_t)HV_VGB_WCAP; // next iteration: w = 0
+                w = -(int64_t)wcap; // next iteration: w = 0
                 continue;
             }
             if (m > 0) {
@@ -564,7 +564,11 @@ static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d
     // and the local voxel index in one 32-bit entry.
     const int idx_bits = 32 - v->local_bits;
     const char *force = getenv("HV_SEM_PATH");
-    const size_t fold_lds = 4 * sizeof(uint32_t) * (size_t)(2 * HV_VGB_WCAP + G.nvox + 64); // the fold's LDS: two windows + per-voxel offsets per wave
+    // The fold's LDS window per wave (entries): buckets beyond it go to the task kernel as voxel ranges.  512 (HV_SEM_WCAP) leaves
+    // room for the 16 waves per CU the kernel's registers allow (1024: 12 waves)
+    int wcap = getenv("HV_SEM_WCAP") ? atoi(getenv("HV_SEM_WCAP")) : 512;
+    if (wcap != 256 && wcap != 512 && wcap != 1024) wcap = 512;
+    const size_t fold_lds = 4 * sizeof(uint32_t) * (size_t)(2 * wcap + G.nvox + 64); // two windows + per-voxel offsets per wave
     if (n < (1ll << idx_bits) && n <= (int64_t)v->cfg.max_points && fold_lds <= 64 * 1024 && !(force && strcmp(force, "sort") == 0)) {
         int parity = 0;
         for (int attempt = 0;; ++attempt) {
@@ -589,7 +593,7 @@ static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d
         const unsigned fold_grid = (unsigned)std::min<int64_t>(std::max<int64_t>(n / 128, 256), 16384);
         VOX *bpool = (VOX *)v->pool;
         // task list of the big buckets: [2 counters (one per parity)][tasks]; at most n / HV_SEMB_BIG buckets are big
-        const int task_cap = (int)std::min<int64_t>((n / HV_VGB_WCAP + 1) * ((G.nvox + 63) / 64), 1 << 22);
+        const int task_cap = (int)std::min<int64_t>((n / wcap + 1) * ((G.nvox + 63) / 64), 1 << 22);
         const size_t task_bytes = 256 + sizeof(int4) * (size_t)task_cap;
         if (v->semb_tasks == nullptr || v->semb_tasks_bytes < task_bytes) {
             rc = hv_ensure_buffer(v, &v->semb_tasks, &v->semb_tasks_bytes, task_bytes);
@@ -599,18 +603,18 @@ static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d
         int32_t *task_count = (int32_t *)v->semb_tasks;
         int4 *tasks = (int4 *)((char *)v->semb_tasks + 256);
         const bool use_tasks = !(getenv("HV_SEM_TASKS") && atoi(getenv("HV_SEM_TASKS")) == 0);
-        const size_t lds_bytes = 4 * sizeof(uint32_t) * (size_t)(2 * HV_VGB_WCAP + G.nvox + 64); // per wave: two windows + per-voxel offsets
+        const size_t lds_bytes = fold_lds;
 #define HV_LAUNCH_SEM_FOLD(CK)                                                                                           \
     do {                                                                                                                 \
         hipLaunchKernelGGL((k_semb_fold_wave<VOX, PT, CK>), dim3(fold_grid), dim3(256), lds_bytes, v->stream, v->table, bpool, \
                            (const int32_t *)v->vg_touched, parity, v->vg_cursor, v->vg_cnt, (const int32_t *)v->vg_cur,   \
                            (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, d_cls, d_inst, d_depths, v->occ, n,       \
-                           idx_bits, v->d_status, seq, task_count, use_tasks ? tasks : (int4 *)nullptr, task_cap);        \
+                           idx_bits, v->d_status, seq, task_count, use_tasks ? tasks : (int4 *)nullptr, task_cap, wcap);  \
         if (use_tasks)                                                                                                   \
             hipLaunchKernelGGL((k_semb_fold_tasks<VOX, PT, CK>), dim3(1024), dim3(256), lds_bytes, v->stream, v->table, bpool, \
                                (const int32_t *)task_count, (const int4 *)tasks, parity, task_cap,                        \
                                (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, d_cls, d_inst, d_depths, v->occ, n,   \
-                               idx_bits);                                                                                \
+                               idx_bits, wcap);                                                                          \
     } while (0)
         if (color_kind == HV_COLOR_U8) HV_LAUNCH_SEM_FOLD(HV_COLOR_U8);
         else if (color_kind == HV_COLOR_F32) HV_LAUNCH_SEM_FOLD(HV_COLOR_F32);
