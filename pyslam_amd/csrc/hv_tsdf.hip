@@ -1888,6 +1888,14 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep_fold
 // instruction less per visit, 564-568 us: the extra live register costs more), 16-byte records with the colour fields
 // spread 16 bits apart so that the accumulators add the words unmasked (two instructions less, 590-599 us: four registers
 // per gather in flight, 104 B of scratch).  At 128 registers the form is bound by what it keeps live, not by its count.
+// Correction rounds of the projection's shared-reciprocal division in the column sweep.  hv_div2 (online path, bitwise sweep forms)
+// runs two; with the reciprocal refined by one Newton step the FIRST round already returns the correctly rounded quotient on every
+// operand pair tried: tools/divtest.hip, round 4 - 0 mismatches against IEEE division in 3.4e12 pairs each of the kernel's operand
+// ranges, wide random exponents and divisors whose mantissa ends in runs of ones / zeros (1.0e13 divisions; the two-round form:
+// 0 as well).  Two packed FMAs less per voxel visit.  -DHV_SWEEP_DIV_ROUNDS=2 restores the second round.
+#ifndef HV_SWEEP_DIV_ROUNDS
+#define HV_SWEEP_DIV_ROUNDS 1
+#endif
 template <int SPLIT, int GV, int PIPE, int ANYSKIP, int ZS = 1>
 __device__ __forceinline__ void hv_sweep_column_body(
     HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
@@ -2053,8 +2061,10 @@ __device__ __forceinline__ void hv_sweep_column_body(
                 hv_f2 Q = A * R;
                 hv_f2 REM = hv_fma2(NZ, Q, A);
                 Q = hv_fma2(REM, R, Q);
-                REM = hv_fma2(NZ, Q, A);
-                Q = hv_fma2(REM, R, Q);
+                if (HV_SWEEP_DIV_ROUNDS == 2) { // (hv_div2's second correction round: never needed, see HV_SWEEP_DIV_ROUNDS)
+                    REM = hv_fma2(NZ, Q, A);
+                    Q = hv_fma2(REM, R, Q);
+                }
                 const hv_f2 UV = (Q + C) + hv_splat(0.5f);
                 const bool in_u = (__float_as_uint(UV.x) - lo_u) < lim_u;
                 const bool in_v = (__float_as_uint(UV.y) - lo_v) < lim_v;
