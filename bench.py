@@ -421,8 +421,70 @@ def euroc_leg(n_frames=48):
     return {"value": round(n_frames / dt, 1), "unit": "frames/s", "frames": n_frames, "voxel": 0.010, "image": f"{s.width}x{s.height}",
             "units": int(vol.num_blocks()),
             "what": "stereo keyframes: uploads of the pair, stub stereo module (torch) -> disparity -> depth = bf / |d| on the device, shadow-point "
-                    "filter, hv_tsdf_integrate from device pointers; one keyframe per call; the 2-GPU tile-sharded half of configs[3] "
-                    "needs a second GPU (tests/test_gpu_distributed.py runs that code path with two ranks on one GPU)"}
+                    "filter, hv_tsdf_integrate from device pointers; one keyframe per call; the 2-GPU tile-sharded form of configs[3]: "
+                    "`bench.py --gpus 2 --sharding tile` -> configs.euroc_752x480_10mm (euroc_sharded_leg)"}
+
+
+def euroc_sharded_leg(rank, world, local_rank, dist, backend, sharding, n_frames=32):
+    """BASELINE configs[3] as it is written: EuRoC-shaped stereo keyframes on `world` GPUs, tile-sharded (every rank sees every keyframe
+    pair, estimates the depth on its own GPU and fuses the voxels that project into its image tile; one merge_halo() at the end
+    consolidates the units several ranks hold).  Runs on ALL ranks of an N > 1 run with --sharding tile; on a 1-GPU box the ranks
+    share the GPU over gloo (tools/_final.sh), which exercises the code path and is not a scaling number."""
+    import types
+
+    import torch
+
+    from pyslam_amd.depth_estimation import DepthEstimatorStereoTorch, make_stub_stereo_net
+    from pyslam_amd.distributed import ShardedTSDF
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage
+
+    s, depth_h, rgb_h, T_h = load_frames("euroc_752x480_10mm", n_frames, rank=rank, barrier=dist.barrier)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    cam = types.SimpleNamespace(bf=47.9, width=s.width, height=s.height)
+    est = DepthEstimatorStereoTorch(make_stub_stereo_net(), cam, device="cuda", keep_on_device=True, max_depth=10.0)
+    left = [np.ascontiguousarray(rgb_h[i]) for i in range(n_frames)]
+    right = [np.ascontiguousarray(np.roll(rgb_h[i], -8, axis=1)) for i in range(n_frames)]
+    fuser = ShardedTSDF(0.010, SDF_TRUNC, s.width, s.height, device=local_rank, max_blocks=1 << 15, rank=rank, world_size=world,
+                        sharding=sharding)
+    vol = fuser.volume
+    on_gpu = backend == "nccl"
+
+    def fence():
+        vol.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    def run():
+        vol.reset()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n_frames):
+            depth_d, _ = est.infer(left[i], right[i])
+            depth_d = vol.filter_shadow_points(depth_d)
+            color_d = torch.from_numpy(left[i]).cuda(non_blocking=True)
+            fuser.integrate(RGBDImage(color_d, depth_d, 1.0, DEPTH_TRUNC), K, T_h[i])
+        fence()
+        t_fuse = time.perf_counter() - t0
+        shared = 0
+        if sharding != "owner":
+            shared, _ = fuser.merge_halo()
+            fence()
+        t_all = time.perf_counter() - t0
+        t = torch.tensor([t_fuse, t_all], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0]), float(t[1]), int(shared)
+
+    run()
+    t_fuse, t_all, shared = run()
+    units = torch.tensor([float(vol.num_blocks())], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+    everyone = [torch.zeros_like(units) for _ in range(world)]
+    dist.all_gather(everyone, units)
+    return {"value": round(n_frames / t_all, 1), "unit": "frames/s", "n_gpus": world, "sharding": sharding, "frames": n_frames, "voxel": 0.010,
+            "image": f"{s.width}x{s.height}", "fuse_only": round(n_frames / t_fuse, 1), "merge_ms": round((t_all - t_fuse) * 1e3, 3),
+            "shared_units": shared, "units_held": [int(e.item()) for e in everyone],
+            "what": "stereo keyframes on every rank: stub stereo module (torch) -> depth on the device -> shadow-point filter -> hv_tsdf_integrate "
+                    "of the rank's image tile; one merge_halo() (all-gather of key lists, all-reduce of the shared units' numerators) inside "
+                    "the clock; slowest rank"}
 
 
 def main():
@@ -576,6 +638,15 @@ def main():
     frames = args.steps * B
     fps = frames / elapsed
     units_allocated = int(vol.num_blocks())
+    euroc_sharded = None
+    if dist is not None and args.sharding == "tile" and not args.no_secondary:
+        try:  # (every rank takes part: collectives inside)
+            euroc_sharded = euroc_sharded_leg(rank, world, local_rank, dist, args.backend, args.sharding)
+        except Exception as e:  # a secondary leg must never cost the headline line
+            import traceback
+
+            traceback.print_exc()
+            euroc_sharded = {"error": f"{type(e).__name__}: {e}"}
     secondary = world == 1 and args.mode == "batch" and not args.no_secondary
 
     # ---- secondary legs (single GPU): extraction of the volume just built, replay figure, online mode ----
@@ -800,6 +871,8 @@ def main():
             out["speedup_vs_cpu"] = round(fps / cpu["fps"], 1)
         if merge is not None:
             out["merge"] = merge
+        if euroc_sharded is not None:
+            out["configs"] = {"euroc_752x480_10mm": euroc_sharded}
         if extraction is not None:
             # HBM traffic of the extraction kernels from the recorded --pmc passes of this command on this build (all launches of
             # the run extract the same volume)
