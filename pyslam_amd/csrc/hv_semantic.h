@@ -195,6 +195,21 @@ __host__ __device__ inline float sem_confidence(const HvProbVoxel *v, const void
     if (bp.obj == -1 || bp.cls == -1) return 0.0f;
     return hv_expf_cr(bp.logp - prob_log_normalization(v, nodes, nlab));
 }
+// `confidence >= 0` - the visit predicate of iterate_voxels_in_camera_frustrum with min_confidence = 0 (association vote, carve) -
+// without evaluating the confidence where its sign is known: the confidence of a map whose log-probabilities are all finite is
+// exp(best - log sum exp) in (0, 1] (or 0 for an empty / unlabelled best pair), so only a map holding a NaN or an infinity (a NaN
+// depth handed to the integrate) takes the exp / log chain; the answer is the reference's in every case.
+__host__ __device__ inline bool sem_confidence_not_negative(const HvSemVoxel *v, const void * = nullptr) { return sem_confidence(v) >= 0.0f; }
+__host__ __device__ inline bool sem_confidence_not_negative(const HvProbVoxel *v, const void *nodes_) {
+    const HvProbNode *nodes = (const HvProbNode *)nodes_;
+    const int nlab = prob_nlab(v->meta);
+    bool finite = true;
+    for (int i = 0; i < nlab; ++i) {
+        const float lp = prob_get(v, nodes, i).logp;
+        finite = finite && (lp - lp == 0.0f); // false for NaN and +-inf
+    }
+    return finite ? true : sem_confidence(v, nodes_) >= 0.0f;
+}
 // get_confidence_counter(), voxel_data_semantic.h:505-511
 __host__ __device__ inline int32_t sem_confidence_counter(const HvProbVoxel *v, const void *nodes) {
     return (int32_t)(sem_confidence(v, nodes) * (float)v->count);

@@ -71,7 +71,7 @@ __device__ __forceinline__ bool sem_visit(const HvQuery &Q, const HvTable &table
                                           const HvSemParams &G, float *uvd) {
     const int32_t count = v->count;
     if (count < 1) return false;
-    if (!(sem_confidence(v, table.prob_nodes) >= 0.0f)) return false;
+    if (!sem_confidence_not_negative(v, table.prob_nodes)) return false; // (confidence >= 0)
     int32_t bk[3];
     hv_unpack_key(table.block_keys[b], bk[0], bk[1], bk[2]);
     const int32_t lc[3] = {l % G.bs, (l / G.bs) % G.bs, l / (G.bs * G.bs)};
