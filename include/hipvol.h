@@ -312,7 +312,10 @@ int hv_tsdf_set_color_order(hv_volume *v, int32_t bgr);
 /* Page-lock caller memory for the H2D DMA of hv_tsdf_integrate_frames / hv_integrate_*(HV_HOST): pySLAM's front hands keyframes
  * over in a shared-memory ring (volumetric_integrator_base.py:401-410 carries them pickled through a Manager queue); once the
  * ring is registered, frames that lie inside it are DMA'd in place - no staging copy - and the call returns when the DMA has
- * read them.  Process-wide (any volume of the process sees the range); unregister before the memory is unmapped. */
+ * read them.  This holds for EVERY entry point that takes HV_HOST arrays: a page-locked source (registered here, or any other
+ * pinned allocation) is read by the DMA engine when the stream gets to the copy, so those calls wait for their copies before they
+ * return (hv_core.hip: hv_h2d); the kernels behind the copies stay asynchronous.  Process-wide (any volume of the process sees the
+ * range); unregister before the memory is unmapped. */
 int hv_host_register(void *ptr, int64_t bytes);
 int hv_host_unregister(void *ptr);
 

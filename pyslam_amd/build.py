@@ -19,7 +19,21 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpyslam_hipvol.so")
 SOURCES = ["hv_core.hip", "hv_tsdf.hip", "hv_voxel_grid.hip", "hv_semantic.hip", "hv_semantic_ops.hip", "hv_extract.hip", "hv_prep.hip"]
-HEADERS = ["hv_common.h", "mc_tables.h", os.path.join(ROOT, "include", "hipvol.h")]
+INCLUDE = os.path.join(ROOT, "include")
+
+
+def _digest_files():
+    """Every file the library is compiled from: all of csrc/ and include/ (a list of names went stale - three
+    headers included by four translation units were not hashed, so a header-only edit reused the old .so)."""
+    files = []
+    for d in (CSRC, INCLUDE):
+        for name in sorted(os.listdir(d)):
+            path = os.path.join(d, name)
+            if os.path.isfile(path) and name.endswith((".hip", ".h", ".hpp", ".inc")):
+                files.append(path)
+    return files
+
+
 ARCH = "gfx950"
 
 
@@ -40,15 +54,15 @@ def _flags():
         "-fno-fast-math",
         "-Wall",
         "-Wno-unused-function",
-        "-I" + os.path.join(ROOT, "include"),
+        "-I" + INCLUDE,
         "-I" + CSRC,
     ]
 
 
 def _digest():
     h = hashlib.sha256()
-    for name in SOURCES + HEADERS:
-        path = name if os.path.isabs(name) else os.path.join(CSRC, name)
+    for path in _digest_files():
+        h.update(os.path.relpath(path, ROOT).encode())
         with open(path, "rb") as f:
             h.update(f.read())
     # the flags enter with the checkout's root written as "." - the digest names a SOURCE state and must be the same on every

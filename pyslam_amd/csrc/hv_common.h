@@ -225,7 +225,9 @@ struct HvStatus {
     int32_t blocks;
     int32_t overflow;
     int32_t seq;
-    int32_t pad;
+    int32_t pad;         // VOXEL_GRID bucket path: the largest bucket of the last frame
+    int32_t assoc_flags; // capacity flags of the semantic association, OR-ed in by k_sem_assoc_apply, reported and cleared by the host
+    int32_t reserved[3];
 };
 
 #ifdef __HIPCC__
@@ -393,6 +395,12 @@ int32_t hv_next_status_seq(hv_volume *v); // sequence number for the call's publ
 void hv_launch_publish_status(hv_volume *v); // modes whose last kernel does not publish by itself
 int hv_read_counters(hv_volume *v); // D2H of the counter block (synchronises the stream)
 int hv_stage_in(hv_volume *v, const void *src, size_t bytes, int32_t loc, int which, const void **dev);
+// hipMemcpyAsync(H2D) of a caller's array on the volume's stream; waits for the copy when the source is page-locked (the DMA would
+// otherwise read it after the call has returned: the ABI borrows host arrays for the duration of the call only)
+int hv_h2d(hv_volume *v, void *dst, const void *src, size_t bytes);
+// several arrays of one call: queue them with hv_h2d_lazy (sets *pending when a source is page-locked), then ONE hv_h2d_fence
+int hv_h2d_lazy(hv_volume *v, void *dst, const void *src, size_t bytes, bool *pending);
+int hv_h2d_fence(hv_volume *v, bool pending);
 // Host-resident frames -> device (pipelined, see hv_volume::hs_*).  Frame f's depth is depth_ptrs[f] when depth_ptrs is given,
 // else depth_base + f * depth_frame_bytes (same for colour).  Returns the device arrays (frames contiguous) and the set whose
 // hs_dev_ready event the consuming stream has to wait for; hv_stage_frames_consumed records hs_dev_free on that stream after

@@ -84,9 +84,44 @@ int hv_stage_in(hv_volume *v, const void *src, size_t bytes, int32_t loc, int wh
     size_t *cur = which == 0 ? &v->stage_a_bytes : &v->stage_b_bytes;
     int rc = hv_ensure_buffer(v, buf, cur, bytes);
     if (rc != HV_OK) return rc;
-    HV_HIP(hipMemcpyAsync(*buf, src, bytes, hipMemcpyHostToDevice, v->stream));
+    rc = hv_h2d(v, *buf, src, bytes);
+    if (rc != HV_OK) return rc;
     *dev = *buf;
     return HV_OK;
+}
+
+// Host -> device copy of a caller's array on the volume's stream.  The C ABI borrows HV_HOST arrays "for the duration of the call":
+// a pageable source is read by the runtime before hipMemcpyAsync returns, but a PAGE-LOCKED source (the front's shared-memory ring
+// after hv_host_register, a torch pinned tensor, hipHostMalloc memory) is read by the DMA engine later, when the stream gets there -
+// the caller may have refilled the memory by then (a ring slot released while its copy was still queued).  So the
+// host waits for the copy when the source is page-locked; the kernels behind it stay asynchronous.
+static bool hv_host_is_registered(const void *p, size_t bytes);
+static bool hv_host_is_pinned(const void *p, size_t bytes) {
+    if (hv_host_is_registered(p, bytes)) return true;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError(); // plain malloc / numpy memory: "invalid value", not an error of ours
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+int hv_h2d_lazy(hv_volume *v, void *dst, const void *src, size_t bytes, bool *pending) {
+    if (bytes == 0) return HV_OK;
+    HV_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, v->stream));
+    if (hv_host_is_pinned(src, bytes)) *pending = true;
+    return HV_OK;
+}
+
+int hv_h2d_fence(hv_volume *v, bool pending) {
+    if (pending) HV_HIP(hipStreamSynchronize(v->stream));
+    return HV_OK;
+}
+
+int hv_h2d(hv_volume *v, void *dst, const void *src, size_t bytes) {
+    bool pending = false;
+    const int rc = hv_h2d_lazy(v, dst, src, bytes, &pending);
+    return rc != HV_OK ? rc : hv_h2d_fence(v, pending);
 }
 
 // ---- pipelined staging of host-resident frames ------------------------------------------------------------------------
@@ -191,13 +226,13 @@ struct HvHostRange {
 std::mutex g_host_ranges_m;
 std::vector<HvHostRange> g_host_ranges;
 
-bool hv_host_is_registered(const void *p, size_t bytes) {
+} // namespace
+static bool hv_host_is_registered(const void *p, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_host_ranges_m);
     for (const HvHostRange &r : g_host_ranges)
         if ((const char *)p >= r.lo && (const char *)p + bytes <= r.hi) return true;
     return false;
 }
-} // namespace
 
 extern "C" int hv_host_register(void *ptr, int64_t bytes) {
     HV_REQUIRE(ptr != nullptr && bytes > 0, HV_ERR_INVALID, "hv_host_register: null pointer or empty range");
@@ -402,6 +437,15 @@ int hv_capacity_gate(hv_volume *v, bool *checked) {
             v->known_blocks = std::max<int64_t>(v->known_blocks, std::min<int64_t>(blocks, v->cfg.max_blocks));
             v->status_seq_seen = seq;
         }
+    }
+    // an earlier association (hv_assoc_vote / _decide in the device flow, which never fetches the map) dropped votes or voxels: say so
+    // ONCE, at the first call that can - the volume itself is consistent, the caller decides whether to go on
+    if (const int32_t af = st->assoc_flags) {
+        v->h_status->assoc_flags = 0;
+        HV_REQUIRE(false, HV_ERR_CAPACITY,
+                   "an earlier assign_object_ids_to_instance_ids overflowed (%s%s%s): some voxels did not receive their object id; "
+                   "the volume is otherwise unchanged",
+                   (af & 2) ? "vote table full " : "", (af & 4) ? "pending list full " : "", (af & 1) ? "more than 4096 (instance, object) pairs" : "");
     }
     if (overflow != 0) v->overflow_latched = true; // stays set until hv_reserve_blocks / hv_reset repair the pool (a rebuild clears it)
     HV_REQUIRE(!v->overflow_latched, HV_ERR_CAPACITY,

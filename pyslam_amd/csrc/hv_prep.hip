@@ -80,9 +80,11 @@ extern "C" int hv_remap(hv_volume *v, const void *src, int32_t src_kind, int32_t
         char *s = (char *)(my + npx);
         s += (256 - ((uintptr_t)s & 255)) & 255;
         char *d = s + ((img_bytes + 255) & ~(size_t)255);
-        HV_HIP(hipMemcpyAsync(mx, map_x, map_bytes, hipMemcpyHostToDevice, v->stream));
-        HV_HIP(hipMemcpyAsync(my, map_y, map_bytes, hipMemcpyHostToDevice, v->stream));
-        HV_HIP(hipMemcpyAsync(s, src, img_bytes, hipMemcpyHostToDevice, v->stream));
+        bool pinned_src = false; // (page-locked sources are read by the DMA engine after hipMemcpyAsync returns: hv_h2d)
+        if ((rc = hv_h2d_lazy(v, mx, map_x, map_bytes, &pinned_src)) != HV_OK) return rc;
+        if ((rc = hv_h2d_lazy(v, my, map_y, map_bytes, &pinned_src)) != HV_OK) return rc;
+        if ((rc = hv_h2d_lazy(v, s, src, img_bytes, &pinned_src)) != HV_OK) return rc;
+        if ((rc = hv_h2d_fence(v, pinned_src)) != HV_OK) return rc;
         d_src = s; d_mx = mx; d_my = my; d_dst = d;
     }
     const dim3 grid((unsigned)((npx + 255) / 256)), block(256);

@@ -671,7 +671,8 @@ static int sem_stage(hv_volume *v, const void *src, size_t bytes, int32_t loc, c
         *dev = src;
         return HV_OK;
     }
-    HV_HIP(hipMemcpyAsync(cursor, src, bytes, hipMemcpyHostToDevice, v->stream));
+    const int rc = hv_h2d(v, cursor, src, bytes); // (waits for the copy when the source is page-locked)
+    if (rc != HV_OK) return rc;
     *dev = cursor;
     cursor += (bytes + 255) & ~(size_t)255;
     return HV_OK;
@@ -865,12 +866,14 @@ int hv_integrate_rgbd_semantic(hv_volume *v, const float *depth, const uint8_t *
         rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, 2 * plane);
         if (rc != HV_OK) return rc;
         char *st = (char *)v->out_c;
-        HV_HIP(hipMemcpyAsync(st, class_ids_image, sizeof(int32_t) * npx, hipMemcpyHostToDevice, v->stream));
+        bool pinned_src = false;
+        if ((rc = hv_h2d_lazy(v, st, class_ids_image, sizeof(int32_t) * npx, &pinned_src)) != HV_OK) return rc;
         d_cls = (const int32_t *)st;
         if (object_ids_image != nullptr) {
-            HV_HIP(hipMemcpyAsync(st + plane, object_ids_image, sizeof(int32_t) * npx, hipMemcpyHostToDevice, v->stream));
+            if ((rc = hv_h2d_lazy(v, st + plane, object_ids_image, sizeof(int32_t) * npx, &pinned_src)) != HV_OK) return rc;
             d_obj = (const int32_t *)(st + plane);
         }
+        if ((rc = hv_h2d_fence(v, pinned_src)) != HV_OK) return rc;
     }
     // depths = camera z of the point = the pixel's depth (…voxel_semantic_grid.py:418-424)
     const float *d_depths = use_depths ? (const float *)d_depth : nullptr;

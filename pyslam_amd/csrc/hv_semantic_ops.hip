@@ -354,6 +354,8 @@ __device__ __forceinline__ int32_t map_lookup(const int32_t *__restrict__ map_in
 // map = {inst[HV_VOTE_CAP], obj[HV_VOTE_CAP]} sorted by instance id, *n_map its size; *flags |= 1 when the pairs did not fit the
 // workgroup (the host reports it when the map is fetched).  No host round trip between the vote and the remap / integrate.
 static constexpr int HV_RULES_MAX = 4096;
+// capacity flags of one association (S.flags; latched into HvStatus::assoc_flags by k_sem_assoc_apply, reported by the next call)
+static constexpr int32_t HV_ASSOC_TOO_MANY_PAIRS = 1, HV_ASSOC_VOTE_TABLE_FULL = 2, HV_ASSOC_PENDING_FULL = 4;
 __global__ __launch_bounds__(1024) void k_sem_assoc_rules(HvTable table, const unsigned long long *__restrict__ pkeys,
                                                            const int32_t *__restrict__ pcounts, float min_vote_ratio, int32_t min_votes,
                                                            int32_t *__restrict__ next_object_id, int32_t *__restrict__ map_inst,
@@ -364,11 +366,12 @@ __global__ __launch_bounds__(1024) void k_sem_assoc_rules(HvTable table, const u
     int n = table.counters[HV_CNT_OUT];
     if (n > HV_RULES_MAX) {
         if (threadIdx.x == 0) {
-            atomicOr(flags, 1);
+            *flags = HV_ASSOC_TOO_MANY_PAIRS; // (this call's flags: k_sem_assoc_apply adds the vote's and latches them into the status word)
             *n_map_out = 0;
         }
         return;
     }
+    if (threadIdx.x == 0) *flags = 0;
     int m2 = 1;
     while (m2 < n) m2 <<= 1;
     for (int i = threadIdx.x; i < m2; i += blockDim.x) {
@@ -477,9 +480,24 @@ __global__ __launch_bounds__(1024) void k_sem_assoc_rules(HvTable table, const u
 template <typename VOX>
 __global__ __launch_bounds__(256) void k_sem_assoc_apply(HvTable table, VOX *__restrict__ pool, const int2 *__restrict__ pending,
                                                           int32_t pending_cap, const int32_t *__restrict__ map_inst,
-                                                          const int32_t *__restrict__ map_obj, const int32_t *__restrict__ n_map_p) {
+                                                          const int32_t *__restrict__ map_obj, const int32_t *__restrict__ n_map_p,
+                                                          int32_t *__restrict__ flags, HvStatus *status) {
     const int32_t n_pending = min(table.counters[HV_CNT_AUX], pending_cap);
     const int32_t n_map = *n_map_p;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the device flow (assign -> remap_instance_ids -> integrate) never fetches the map, and the next vote / fold clear
+        // the shared counters - so what overflowed in THIS association is folded into its flags word here and latched into the pinned
+        // status word, which the next call's gate reads without a synchronisation
+        int32_t f = *flags;
+        if (table.counters[HV_CNT_OUT2] != 0) f |= HV_ASSOC_VOTE_TABLE_FULL;
+        if (table.counters[HV_CNT_AUX] > pending_cap) f |= HV_ASSOC_PENDING_FULL;
+        *flags = f;
+        if (f != 0) {
+            volatile HvStatus *s = status;
+            s->assoc_flags = s->assoc_flags | f;
+            __threadfence_system();
+        }
+    }
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pending; i += gridDim.x * blockDim.x) {
         const int2 p = pending[i];
         const int32_t final_id = map_lookup(map_inst, map_obj, n_map, p.y, -1);
@@ -975,14 +993,16 @@ int hv_assoc_vote(hv_volume *v, const float *intr_f32, int32_t width, int32_t he
         rc = hv_ensure_buffer(v, &v->stage_b, &v->stage_b_bytes, 3 * plane);
         if (rc != HV_OK) return rc;
         char *st = (char *)v->stage_b;
-        HV_HIP(hipMemcpyAsync(st, class_ids_image, sizeof(int32_t) * n_px, hipMemcpyHostToDevice, v->stream));
-        HV_HIP(hipMemcpyAsync(st + plane, instance_ids_image, sizeof(int32_t) * n_px, hipMemcpyHostToDevice, v->stream));
+        bool pinned_src = false; // (page-locked sources - the front's registered ring - are read by the DMA engine later: hv_h2d)
+        if ((rc = hv_h2d_lazy(v, st, class_ids_image, sizeof(int32_t) * n_px, &pinned_src)) != HV_OK) return rc;
+        if ((rc = hv_h2d_lazy(v, st + plane, instance_ids_image, sizeof(int32_t) * n_px, &pinned_src)) != HV_OK) return rc;
         d_cls = (const int32_t *)st;
         d_inst = (const int32_t *)(st + plane);
         if (depth_image != nullptr) {
-            HV_HIP(hipMemcpyAsync(st + 2 * plane, depth_image, sizeof(float) * n_px, hipMemcpyHostToDevice, v->stream));
+            if ((rc = hv_h2d_lazy(v, st + 2 * plane, depth_image, sizeof(float) * n_px, &pinned_src)) != HV_OK) return rc;
             d_depth = (const float *)(st + 2 * plane);
         }
+        if ((rc = hv_h2d_fence(v, pinned_src)) != HV_OK) return rc;
     }
     if (v->assoc_clean != v->assoc_buf || v->assoc_clean_bytes != v->assoc_buf_bytes) { // a new allocation, or a call that failed before its compaction
         HV_HIP(hipMemsetAsync(S.vkeys, 0xFF, sizeof(uint64_t) * HV_VOTE_CAP, v->stream));
@@ -1087,10 +1107,10 @@ int hv_assoc_decide(hv_volume *v, float min_vote_ratio, int32_t min_votes) {
     const dim3 grid(256);
     if (is_prob(v))
         hipLaunchKernelGGL(k_sem_assoc_apply<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, S.pending,
-                           v->assoc_pending_cap, S.map_inst, S.map_obj, S.n_map);
+                           v->assoc_pending_cap, S.map_inst, S.map_obj, S.n_map, S.flags, v->d_status);
     else
         hipLaunchKernelGGL(k_sem_assoc_apply<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, S.pending,
-                           v->assoc_pending_cap, S.map_inst, S.map_obj, S.n_map);
+                           v->assoc_pending_cap, S.map_inst, S.map_obj, S.n_map, S.flags, v->d_status);
     HV_HIP(hipGetLastError());
     v->assoc_state = 2;
     return HV_OK;
@@ -1109,11 +1129,14 @@ int hv_assoc_map_fetch(hv_volume *v, int32_t *map_inst, int32_t *map_obj, int64_
     HV_HIP(hipMemcpyAsync(misc, S.n_map, sizeof(misc), hipMemcpyDeviceToHost, v->stream));
     rc = hv_read_counters(v); // synchronises the stream
     if (rc != HV_OK) return rc;
-    HV_REQUIRE(v->h_counters[HV_CNT_OUT2] == 0, HV_ERR_CAPACITY,
+    // misc[1] = the flags of the association whose map this is (k_sem_assoc_rules + k_sem_assoc_apply; the shared counters may belong
+    // to a later fold by now).  Reported here, so the latch of the status word is cleared: the caller has been told.
+    if (misc[1] != 0) v->h_status->assoc_flags = 0;
+    HV_REQUIRE((misc[1] & HV_ASSOC_VOTE_TABLE_FULL) == 0, HV_ERR_CAPACITY,
                "hv_assign_object_ids_to_instance_ids: more than %u distinct (instance, object) pairs", HV_VOTE_CAP);
-    HV_REQUIRE(v->h_counters[HV_CNT_AUX] <= v->assoc_pending_cap, HV_ERR_CAPACITY,
-               "hv_assign_object_ids_to_instance_ids: pending list overflow (%d)", v->h_counters[HV_CNT_AUX]);
-    HV_REQUIRE((misc[1] & 1) == 0, HV_ERR_CAPACITY, "hv_assign_object_ids_to_instance_ids: more than %d (instance, object) pairs in one keyframe",
+    HV_REQUIRE((misc[1] & HV_ASSOC_PENDING_FULL) == 0, HV_ERR_CAPACITY,
+               "hv_assign_object_ids_to_instance_ids: pending list overflow (capacity %d)", v->assoc_pending_cap);
+    HV_REQUIRE((misc[1] & HV_ASSOC_TOO_MANY_PAIRS) == 0, HV_ERR_CAPACITY, "hv_assign_object_ids_to_instance_ids: more than %d (instance, object) pairs in one keyframe",
                HV_RULES_MAX);
     *n_map = misc[0];
     const int64_t m = std::min<int64_t>(misc[0], cap);

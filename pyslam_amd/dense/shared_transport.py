@@ -55,12 +55,13 @@ class FrameRing:
         self._shm = shared_memory.SharedMemory(create=True, size=self.slot_bytes * self.n_slots)
         self.name = self._shm.name
         self._flags = ctx.Array("b", self.n_slots, lock=True)
+        self._next = ctx.Value("i", 0, lock=False)  # round-robin cursor, guarded by the flags' lock
         self._owner = True
         self._registered = False
 
     # -- pickling: the child attaches to the same segment ---------------------------------------
     def __getstate__(self):
-        return dict(slot_bytes=self.slot_bytes, n_slots=self.n_slots, name=self.name, _flags=self._flags)
+        return dict(slot_bytes=self.slot_bytes, n_slots=self.n_slots, name=self.name, _flags=self._flags, _next=self._next)
 
     def __setstate__(self, s):
         self.__dict__.update(s)
@@ -76,11 +77,16 @@ class FrameRing:
         return np.frombuffer(self._shm.buf, dtype=np.uint8).ctypes.data
 
     def acquire(self):
-        """-> a free slot index, or None."""
+        """-> a free slot index, or None.  Slots are handed out ROUND-ROBIN: the slot released last is reused last (with
+        lowest-index-first a just-released slot was refilled at once - defence in depth behind the library's own rule that a
+        page-locked source has been read when an HV_HOST call returns, hv_h2d)."""
         with self._flags.get_lock():
-            for i in range(self.n_slots):
+            start = self._next.value % self.n_slots
+            for k in range(self.n_slots):
+                i = (start + k) % self.n_slots
                 if self._flags[i] == 0:
                     self._flags[i] = 1
+                    self._next.value = (i + 1) % self.n_slots
                     return i
         return None
 
@@ -243,9 +249,9 @@ def import_arrays(output, copy=False):
             mm = mmap.mmap(fd, os.fstat(fd).st_size)
         finally:
             os.close(fd)
-    except OSError:
-        output._shm_segment = None
-        return output
+    except OSError as e:
+        # never hand ArrayRefs downstream where ndarrays are expected: the output is unusable without its segment
+        raise RuntimeError(f"shared output segment {name!r} cannot be opened ({e}): the output's arrays are lost") from e
 
     def resolve(container, key, v):
         if isinstance(v, ArrayRef) and v.segment == name:

@@ -71,3 +71,35 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
     out = subprocess.run(["ldd", os.path.join(ROOT, "pyslam_amd", "lib", "libpyslam_hipvol.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_build_digest_covers_every_source_and_header(tmp_path, monkeypatch):
+    """a header-only edit (hv_semantic.h, hv_bucket.h, hv_query.h were not hashed) must change the digest the
+    .so and every profile under profiles/ are keyed by."""
+    import shutil
+
+    from pyslam_amd import build
+
+    hashed = {os.path.basename(p) for p in build._digest_files()}
+    for name in os.listdir(build.CSRC):
+        if name.endswith((".hip", ".h")):
+            assert name in hashed, name
+    assert "hipvol.h" in hashed
+    # the same tree copied elsewhere hashes the same (the digest names a source state, not a path) ...
+    csrc, inc = tmp_path / "pkg" / "csrc", tmp_path / "include"
+    shutil.copytree(build.CSRC, csrc)
+    shutil.copytree(build.INCLUDE, inc)
+    before = build._digest()
+    monkeypatch.setattr(build, "CSRC", str(csrc))
+    monkeypatch.setattr(build, "INCLUDE", str(inc))
+    monkeypatch.setattr(build, "ROOT", str(tmp_path))
+    monkeypatch.setattr(build, "HERE", str(tmp_path / "pkg"))
+    same = build._digest()
+    # ... and touching one header that only other headers' users include changes it
+    for header in ("hv_semantic.h", "hv_bucket.h", "hv_query.h"):
+        with open(csrc / header, "a") as f:
+            f.write("\n// touched\n")
+        after = build._digest()
+        assert after != same, header
+        same = after
+    assert before != same

@@ -247,7 +247,11 @@ def test_frame_ring_round_trip_across_processes():
         assert got == (float(a.sum()), (120, 160), "float32")
         assert ring.held() == 0  # released by the other process
         slots = [ring.acquire() for _ in range(5)]
-        assert slots[:4] == [0, 1, 2, 3] and slots[4] is None  # a full ring says so
+        # round-robin: the slot released last (0) is reused LAST, and a full ring says so
+        assert slots[:4] == [1, 2, 3, 0] and slots[4] is None
+        ring.release(2)
+        ring.release(1)
+        assert ring.acquire() == 1 and ring.acquire() == 2 and ring.acquire() is None
     finally:
         ring.close()
 
