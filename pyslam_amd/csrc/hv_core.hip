@@ -63,6 +63,7 @@ int hv_ensure_buffer(hv_volume *v, void **buf, size_t *cur, size_t want) {
 }
 
 int hv_read_counters(hv_volume *v) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_HIP(hipMemcpyAsync(v->h_counters, v->table.counters, sizeof(int32_t) * HV_CNT_COUNT,
                           hipMemcpyDeviceToHost, v->stream));
     HV_HIP(hipStreamSynchronize(v->stream));
@@ -637,8 +638,9 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
 
     if (cfg->mode == HV_MODE_TSDF) {
         HV_TRY(hipMalloc(&v->touched_stamp, sizeof(int32_t) * v->table_capacity));
-        HV_TRY(hipMalloc(&v->touched_list, sizeof(int32_t) * 2 * cfg->max_blocks));
-        HV_TRY(hipMalloc(&v->touched_mask, sizeof(uint64_t) * 2 * v->table_capacity));
+        HV_TRY(hipMalloc(&v->touched_list, sizeof(int32_t) * HV_TSDF_SETS * cfg->max_blocks));
+        HV_TRY(hipMalloc(&v->touched_mask, sizeof(uint64_t) * HV_TSDF_SETS * v->table_capacity));
+        HV_TRY(hipMalloc((void **)&v->sweep_done, sizeof(int32_t) * v->table_capacity));
         HV_TRY(hipMalloc(&v->frame_px, 8 * (size_t)cfg->max_points));
         if (const char *dv = getenv("HV_TSDF_DEBUG_VARIANT")) v->debug_variant = atoi(dv);
         if (const char *tb = getenv("HV_TSDF_TOUCH_BOX_BITS")) v->touch_box_bits = std::min(std::max(atoi(tb), 0), 2048);
@@ -676,7 +678,9 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
 void hv_destroy(hv_volume *v) {
     if (!v) return;
     (void)hipSetDevice(v->device);
+    v->pending.valid = false; // (a deferred sweep dies with the volume)
     if (v->stream_aux) (void)hipStreamSynchronize(v->stream_aux);
+    if (v->stream_up) (void)hipStreamSynchronize(v->stream_up);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     if (v->hs_stream) (void)hipStreamSynchronize(v->hs_stream);
     for (int i = 0; i < 2; ++i) {
@@ -692,7 +696,7 @@ void hv_destroy(hv_volume *v) {
                     v->touched_stamp, v->touched_list, v->touched_mask, v->frame_px,
                     v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                     v->sort_vals_out, v->sort_tmp, v->scratch_points, v->scratch_colors, v->out_a,
-                    v->out_b, v->out_c, v->batch_buf, v->assoc_buf, v->mult_table, v->vg_cnt, v->vg_cur, v->vg_touched, v->vg_cursor, v->batch_buf2, v->unit_masks, v->plan_buf, v->occ, v->semb_tasks, v->table.prob_nodes};
+                    v->out_b, v->out_c, v->sweep_done, v->params_ring, v->list_sorted, v->batch_buf, v->assoc_buf, v->mult_table, v->vg_cnt, v->vg_cur, v->vg_touched, v->vg_cursor, v->batch_buf2, v->batch_buf3, v->unit_masks, v->plan_buf, v->occ, v->semb_tasks, v->table.prob_nodes};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (v->h_counters) (void)hipHostFree(v->h_counters);
@@ -706,6 +710,13 @@ void hv_destroy(hv_volume *v) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);
     }
+    for (int i = 0; i < 4; ++i)
+        if (v->ev_swept[i]) (void)hipEventDestroy(v->ev_swept[i]);
+    if (v->stream_up) (void)hipStreamDestroy(v->stream_up);
+    for (int i = 0; i < HV_TSDF_SETS; ++i) {
+        if (v->ev_set_prep[i]) (void)hipEventDestroy(v->ev_set_prep[i]);
+        if (v->ev_set_free[i]) (void)hipEventDestroy(v->ev_set_free[i]);
+    }
     if (v->ev_prep) (void)hipEventDestroy(v->ev_prep);
     if (v->ev_presweep) (void)hipEventDestroy(v->ev_presweep);
     if (v->stream_aux) (void)hipStreamDestroy(v->stream_aux);
@@ -714,6 +725,7 @@ void hv_destroy(hv_volume *v) {
 }
 
 int hv_reset(hv_volume *v) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_reset: null volume");
     HV_HIP(hipSetDevice(v->device));
     // zero only the used pool prefix (pool was fully zeroed at creation)
@@ -733,7 +745,8 @@ int hv_reset(hv_volume *v) {
     HV_HIP(hipMemsetAsync(v->table.vals, 0xFF, sizeof(int32_t) * v->table_capacity, v->stream));
     HV_HIP(hipMemsetAsync(v->table.counters, 0, sizeof(int32_t) * HV_CNT_COUNT, v->stream));
     if (v->touched_stamp) HV_HIP(hipMemsetAsync(v->touched_stamp, 0, sizeof(int32_t) * v->table_capacity, v->stream));
-    if (v->touched_mask) HV_HIP(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * 2 * v->table_capacity, v->stream));
+    if (v->touched_mask) HV_HIP(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * HV_TSDF_SETS * v->table_capacity, v->stream));
+    if (v->sweep_done) HV_HIP(hipMemsetAsync(v->sweep_done, 0, sizeof(int32_t) * v->table_capacity, v->stream));
     memset(v->h_counters, 0, sizeof(int32_t) * HV_CNT_COUNT);
     v->content_version += 1;
     v->frame_counter = 0;
@@ -754,12 +767,14 @@ int hv_reset(hv_volume *v) {
 }
 
 int hv_synchronize(hv_volume *v) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_synchronize: null volume");
     HV_HIP(hipStreamSynchronize(v->stream));
     return HV_OK;
 }
 
 int hv_set_stream(hv_volume *v, void *hip_stream) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_set_stream: null volume");
     HV_HIP(hipStreamSynchronize(v->stream));
     if (v->own_stream && v->stream) HV_HIP(hipStreamDestroy(v->stream));
@@ -800,6 +815,7 @@ __global__ void k_restamp(HvTable old_t, HvTable new_t, const int32_t *__restric
 static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep);
 
 int hv_reserve_blocks(hv_volume *v, int64_t new_max_blocks) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_reserve_blocks: null volume");
     if (new_max_blocks <= v->cfg.max_blocks) return HV_OK;
     return hv_rebuild(v, new_max_blocks, -1);
@@ -823,11 +839,11 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
                free_b / 1073741824.0);
     void *pool = nullptr;
     unsigned long long *keys = nullptr, *block_keys = nullptr, *occ = nullptr;
-    int32_t *vals = nullptr, *stamp = nullptr, *list = nullptr;
+    int32_t *vals = nullptr, *stamp = nullptr, *list = nullptr, *done = nullptr;
     uint64_t *mask = nullptr;
     // every allocation is released again if a later step fails (HV_HIP returns from the middle)
     auto release = [&]() {
-        for (void *p : {pool, (void *)keys, (void *)vals, (void *)block_keys, (void *)stamp, (void *)list, (void *)mask, (void *)occ})
+        for (void *p : {pool, (void *)keys, (void *)vals, (void *)block_keys, (void *)stamp, (void *)list, (void *)mask, (void *)occ, (void *)done})
             if (p) (void)hipFree(p);
     };
 #define HV_TRY_GROW(call)                                                                          \
@@ -868,10 +884,12 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
     HV_TRY_GROW(hipGetLastError());
     if (v->cfg.mode == HV_MODE_TSDF) { // per-slot frame stamps / masks and the touched list follow the table
         HV_TRY_GROW(hipMalloc((void **)&stamp, sizeof(int32_t) * new_cap));
-        HV_TRY_GROW(hipMalloc((void **)&list, sizeof(int32_t) * 2 * new_max_blocks));
-        HV_TRY_GROW(hipMalloc((void **)&mask, sizeof(uint64_t) * 2 * new_cap));
+        HV_TRY_GROW(hipMalloc((void **)&list, sizeof(int32_t) * HV_TSDF_SETS * new_max_blocks));
+        HV_TRY_GROW(hipMalloc((void **)&mask, sizeof(uint64_t) * HV_TSDF_SETS * new_cap));
         HV_TRY_GROW(hipMemsetAsync(stamp, 0, sizeof(int32_t) * new_cap, v->stream));
-        HV_TRY_GROW(hipMemsetAsync(mask, 0, sizeof(uint64_t) * 2 * new_cap, v->stream));
+        HV_TRY_GROW(hipMemsetAsync(mask, 0, sizeof(uint64_t) * HV_TSDF_SETS * new_cap, v->stream));
+        HV_TRY_GROW(hipMalloc((void **)&done, sizeof(int32_t) * new_cap));
+        HV_TRY_GROW(hipMemsetAsync(done, 0, sizeof(int32_t) * new_cap, v->stream));
         // stamps carry "touched since the last merge": re-stamp the surviving blocks' slots in the new table
         if (used > 0 && v->touched_stamp != nullptr)
             hipLaunchKernelGGL(k_restamp, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, v->stream, v->table, nt,
@@ -883,7 +901,7 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
     const int32_t fixed[2] = {(int32_t)used, 0};
     HV_TRY_GROW(hipMemcpyAsync(&v->table.counters[HV_CNT_BLOCKS], fixed, sizeof(fixed), hipMemcpyHostToDevice, v->stream));
     if (v->cfg.mode == HV_MODE_TSDF) {
-        HV_TRY_GROW(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream)); // lists are void now
+        HV_TRY_GROW(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, HV_CNT_TOUCH_SPAN_BYTES, v->stream)); // lists are void now
         v->touch_counters_clean = true;
     }
     HV_TRY_GROW(hipStreamSynchronize(v->stream));
@@ -895,6 +913,8 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
         v->touched_stamp = stamp;
         v->touched_list = list;
         v->touched_mask = mask;
+        (void)hipFree(v->sweep_done);
+        v->sweep_done = done;
     }
     if (occ) {
         (void)hipFree(v->occ);
@@ -960,7 +980,7 @@ static int hv_rollback_claims(hv_volume *v, int64_t keep) {
     HV_TRY_RB(hipGetLastError());
     if (tsdf) {
         HV_TRY_RB(hipMemsetAsync(v->touched_stamp, 0, sizeof(int32_t) * cap, v->stream));
-        HV_TRY_RB(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * 2 * cap, v->stream));
+        HV_TRY_RB(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * HV_TSDF_SETS * cap, v->stream));
         HvTable old_t = v->table;
         old_t.keys = old_keys;
         old_t.vals = old_vals;
@@ -968,7 +988,7 @@ static int hv_rollback_claims(hv_volume *v, int64_t keep) {
             hipLaunchKernelGGL(k_restamp, dim3((unsigned)((keep + 255) / 256)), dim3(256), 0, v->stream, old_t, v->table,
                                (const int32_t *)old_stamp, v->touched_stamp, (int32_t)keep);
         HV_TRY_RB(hipGetLastError());
-        HV_TRY_RB(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
+        HV_TRY_RB(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, HV_CNT_TOUCH_SPAN_BYTES, v->stream));
         v->touch_counters_clean = true;
     }
     const int32_t fixed[2] = {(int32_t)keep, 0};
@@ -1045,6 +1065,7 @@ int hv_profile_enable(hv_volume *v, int32_t on) {
 }
 
 int hv_profile_read(hv_volume *v, double *kernel_ms_total, int64_t *kernel_launches, int64_t *units_processed) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_profile_read: null volume");
     HV_HIP(hipStreamSynchronize(v->stream));
     double total = 0.0;
@@ -1062,6 +1083,7 @@ int hv_profile_read(hv_volume *v, double *kernel_ms_total, int64_t *kernel_launc
 }
 
 int hv_profile_read_launches(hv_volume *v, float *launch_ms, int64_t cap, int64_t *n) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_profile_read_launches: null argument");
     HV_HIP(hipStreamSynchronize(v->stream));
     *n = (int64_t)v->events_used;

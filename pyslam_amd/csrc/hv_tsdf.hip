@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch(HvTable table, int32_t 
                 if (__hip_atomic_load(&stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != P.frame_id) {
                     const int32_t old = atomicExch(&stamp[slot], P.frame_id);
                     if (old != P.frame_id) {
-                        const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0 + parity], 1);
+                        const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH(parity)], 1);
                         if (at < table.max_blocks) list[at] = slot;
                     }
                 }
@@ -661,12 +661,12 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int
                                                          int parity, char *__restrict__ pool,
                                                          const uint2 *__restrict__ frame_px, HvFrameParams P,
                                                          const float *__restrict__ mult, HvStatus *status, int32_t status_seq) {
-    int n_touched = table.counters[HV_CNT_TOUCH0 + parity];
+    int n_touched = table.counters[HV_CNT_TOUCH(parity)];
     if (n_touched > table.max_blocks) n_touched = table.max_blocks;
     // the next frame's touch pass appends to the other parity's counter: zero it here (stream order); the pool occupancy
     // this frame's touch pass left goes to the host-visible status word (hv_capacity_gate reads it before the next call)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        table.counters[HV_CNT_TOUCH0 + (parity ^ 1)] = 0;
+        table.counters[HV_CNT_TOUCH(parity ^ 1)] = 0;
         hv_publish_status(table, status, status_seq);
     }
     const int wave = threadIdx.x >> 6;
@@ -767,6 +767,116 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(HvTable table, const int
     }
 }
 
+// Pack role of the multi-frame paths: pixels [i0, i0 + 4) of frame f -> frame records (4 pixels per thread: one 16-byte depth load -
+// 8 for uint16 -, three dwords of RGB, two / three 16-byte record stores).  Shared by k_tsdf_prep_touch_batch and k_tsdf_fused.
+__device__ __forceinline__ void hv_pack_px4(const HvFrameParams &P, const int f, const int64_t i0, const void *depth_f,
+                                            const uint8_t *rgb_f, uint2 *__restrict__ frame_px, const float *__restrict__ mult12,
+                                            const int4 *__restrict__ pack_box) {
+    const int64_t npx = (int64_t)P.H * P.W;
+    if (i0 >= npx) return;
+    if (pack_box != nullptr && (P.W & 3) == 0) {
+        // image-coherent ownership (k_tsdf_plan_assign): this GPU's units project into pack_box[f] = {u0, v0, u1, v1} of frame
+        // f and nowhere else, so only those pixels' records are ever gathered (the box is conservative and already padded)
+        const int4 bb = pack_box[f];
+        const int u = (int)(i0 % P.W), v = (int)(i0 / P.W);
+        if (u + 3 < bb.x || u >= bb.z || v < bb.y || v >= bb.w) return;
+    }
+    if (P.tiled && (P.W & 3) == 0) {
+        // tile-sharded volume: only voxels that project into this GPU's tile gather a record (the sweep's image-range test
+        // uses the tile's bounds), so only the tile's columns and rows are packed (+ 4 pixels: a garbage lane may read
+        // outside, its value is never used)
+        const int u = (int)(i0 % P.W), v = (int)(i0 / P.W);
+        if (u + 3 < P.tile_u0 - 4 || u >= P.tile_u1 + 4 || v < P.tile_v0 - 4 || v >= P.tile_v1 + 4) return;
+    }
+    uint2 *dst = frame_px + (int64_t)f * npx + i0;
+    // mult12 != nullptr: 12-byte records {depth, colour, multiplier} (the fold form of the sweep gathers a voxel's pixel
+    // with ONE load; the multiplier comes from the per-pixel table, which is built before this launch)
+    uint32_t *dst12 = (uint32_t *)frame_px + ((int64_t)f * npx + i0) * 3;
+    if (i0 + 4 <= npx && (npx & 3) == 0) {
+        const uint32_t *c4 = (const uint32_t *)(rgb_f + i0 * 3); // i0 % 4 == 0 -> 12-byte multiple: dword aligned
+        const uint32_t w0 = c4[0], w1 = c4[1], w2 = c4[2];
+        // byte 3 of a batch record's colour word is 1: the fold form of the sweep adds accepted records' words into packed
+        // accumulators and that byte counts the observations (every other consumer masks the colour bytes out)
+        const uint32_t col[4] = {hv_colour_order(w0 & 0xffffffu, P.bgr) | HV_REC_ONE,
+                                 hv_colour_order((w0 >> 24) | ((w1 & 0xffffu) << 8), P.bgr) | HV_REC_ONE,
+                                 hv_colour_order((w1 >> 16) | ((w2 & 0xffu) << 16), P.bgr) | HV_REC_ONE,
+                                 hv_colour_order(w2 >> 8, P.bgr) | HV_REC_ONE};
+        float d[4];
+        if (P.depth_is_u16) {
+            const uint2 raw = *(const uint2 *)((const uint16_t *)depth_f + i0);
+            d[0] = (float)(raw.x & 0xffffu); d[1] = (float)(raw.x >> 16);
+            d[2] = (float)(raw.y & 0xffffu); d[3] = (float)(raw.y >> 16);
+        } else {
+            const float4 raw = *(const float4 *)((const float *)depth_f + i0);
+            d[0] = raw.x; d[1] = raw.y; d[2] = raw.z; d[3] = raw.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { // hv_convert_depth
+            d[k] = d[k] / P.depth_scale_f;
+            if ((double)d[k] >= P.depth_trunc_d) d[k] = 0.0f;
+        }
+        if (mult12 != nullptr) {
+            const float4 m4 = *(const float4 *)(mult12 + i0);
+            ((uint4 *)dst12)[0] = make_uint4(__float_as_uint(d[0]), col[0], __float_as_uint(m4.x), __float_as_uint(d[1]));
+            ((uint4 *)dst12)[1] = make_uint4(col[1], __float_as_uint(m4.y), __float_as_uint(d[2]), col[2]);
+            ((uint4 *)dst12)[2] = make_uint4(__float_as_uint(m4.z), __float_as_uint(d[3]), col[3], __float_as_uint(m4.w));
+        } else {
+            ((uint4 *)dst)[0] = make_uint4(__float_as_uint(d[0]), col[0], __float_as_uint(d[1]), col[1]);
+            ((uint4 *)dst)[1] = make_uint4(__float_as_uint(d[2]), col[2], __float_as_uint(d[3]), col[3]);
+        }
+    } else {
+        for (int64_t i = i0; i < npx && i < i0 + 4; ++i) {
+            const uint8_t *c = rgb_f + i * 3;
+            uint2 rec;
+            rec.x = __float_as_uint(hv_convert_depth(P, depth_f, i));
+            rec.y = hv_colour_order((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16), P.bgr) | HV_REC_ONE;
+            if (mult12 != nullptr) {
+                uint32_t *r3 = (uint32_t *)frame_px + ((int64_t)f * npx + i) * 3;
+                r3[0] = rec.x;
+                r3[1] = rec.y;
+                r3[2] = __float_as_uint(mult12[i]);
+            } else {
+                frame_px[(int64_t)f * npx + i] = rec;
+            }
+        }
+    }
+}
+
+// Touch role of the multi-frame paths: one wave = one 8x8 patch of frame f's depth samples; every distinct unit the patch opens gets
+// bit f of its frame mask and - at its first touch in the batch - its place in the batch's union list.  Shared by
+// k_tsdf_prep_touch_batch and k_tsdf_fused.
+__device__ __forceinline__ void hv_touch_batch_patch(const HvTable &table, const HvFrameParams &P, const void *depth_f, const int patch,
+                                                     HvTouchScratch &scratch, const int f, unsigned long long *__restrict__ frame_mask,
+                                                     int32_t *__restrict__ stamp, int32_t *__restrict__ list, const int batch_stamp,
+                                                     const int parity) {
+    const unsigned long long fbit = 1ull << f;
+    hv_touch_patch(table, P, depth_f, patch, scratch,
+                   [&](unsigned long long key, int32_t ux, int32_t uy, int32_t uz) {
+                       // image-tile sharding: units that cannot project into this GPU's tile are not allocated here
+                       if (!hv_unit_hits_tile(P, ux, uy, uz)) return;
+                       const int32_t slot = hv_table_insert(table, key);
+                       if (slot < 0) return;
+                       // both L1-bypassing pre-checks in flight together
+                       const unsigned long long seen = __hip_atomic_load(&frame_mask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                       const int32_t stamped = __hip_atomic_load(&stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                       // frame bit (skip the atomic when another wave of this frame already set it)
+                       if (!(seen & fbit)) atomicOr(&frame_mask[slot], fbit);
+                       if (stamped != batch_stamp) {
+                           if (list == nullptr) {
+                               // the union list is built afterwards from the allocated units (k_tsdf_batch_list): an append here
+                               // is one returning atomic on a single counter per first touch - thousands per batch, serialised
+                               __hip_atomic_store(&stamp[slot], batch_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                           } else {
+                               const int32_t old = atomicExch(&stamp[slot], batch_stamp);
+                               if (old != batch_stamp) {
+                                   const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH(parity)], 1);
+                                   if (at < table.max_blocks) list[at] = slot;
+                               }
+                           }
+                       }
+                   });
+}
+
 // ================================================================================================
 // Multi-frame sweep (hv_tsdf_integrate_batch; the rebuild()/offline-replay use case,
 // volumetric_integrator_base.py:1242-1318).  B <= 64 posed frames are resident in HBM:
@@ -818,108 +928,15 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
     const void *depth_f = depth_raw + (int64_t)f * depth_stride;
     const uint8_t *rgb_f = rgb + (int64_t)f * npx * 3;
     if (!touch_role) {
-        // pack role: 4 pixels per thread — one 16-byte depth load (8 for uint16), three dwords of RGB, two 16-byte
-        // record stores; every wave access is a contiguous burst (prep blocks cover 1024 pixels each)
-        const int64_t i0 = ((int64_t)bx * blockDim.x + threadIdx.x) * 4;
-        if (i0 >= npx) return;
-        if (pack_box != nullptr && (P.W & 3) == 0) {
-            // image-coherent ownership (k_tsdf_plan_assign): this GPU's units project into pack_box[f] = {u0, v0, u1, v1} of frame
-            // f and nowhere else, so only those pixels' records are ever gathered (the box is conservative and already padded)
-            const int4 bb = pack_box[f];
-            const int u = (int)(i0 % P.W), v = (int)(i0 / P.W);
-            if (u + 3 < bb.x || u >= bb.z || v < bb.y || v >= bb.w) return;
-        }
-        if (P.tiled && (P.W & 3) == 0) {
-            // tile-sharded volume: only voxels that project into this GPU's tile gather a record (the sweep's image-range test
-            // uses the tile's bounds), so only the tile's columns and rows are packed (+ 4 pixels: a garbage lane may read
-            // outside, its value is never used)
-            const int u = (int)(i0 % P.W), v = (int)(i0 / P.W);
-            if (u + 3 < P.tile_u0 - 4 || u >= P.tile_u1 + 4 || v < P.tile_v0 - 4 || v >= P.tile_v1 + 4) return;
-        }
-        uint2 *dst = frame_px + (int64_t)f * npx + i0;
-        // mult12 != nullptr: 12-byte records {depth, colour, multiplier} (the fold form of the sweep gathers a voxel's pixel
-        // with ONE load; the multiplier comes from the per-pixel table, which is built before this launch)
-        uint32_t *dst12 = (uint32_t *)frame_px + ((int64_t)f * npx + i0) * 3;
-        if (i0 + 4 <= npx && (npx & 3) == 0) {
-            const uint32_t *c4 = (const uint32_t *)(rgb_f + i0 * 3); // i0 % 4 == 0 -> 12-byte multiple: dword aligned
-            const uint32_t w0 = c4[0], w1 = c4[1], w2 = c4[2];
-            // byte 3 of a batch record's colour word is 1: the fold form of the sweep adds accepted records' words into packed
-            // accumulators and that byte counts the observations (every other consumer masks the colour bytes out)
-            const uint32_t col[4] = {hv_colour_order(w0 & 0xffffffu, P.bgr) | HV_REC_ONE,
-                                     hv_colour_order((w0 >> 24) | ((w1 & 0xffffu) << 8), P.bgr) | HV_REC_ONE,
-                                     hv_colour_order((w1 >> 16) | ((w2 & 0xffu) << 16), P.bgr) | HV_REC_ONE,
-                                     hv_colour_order(w2 >> 8, P.bgr) | HV_REC_ONE};
-            float d[4];
-            if (P.depth_is_u16) {
-                const uint2 raw = *(const uint2 *)((const uint16_t *)depth_f + i0);
-                d[0] = (float)(raw.x & 0xffffu); d[1] = (float)(raw.x >> 16);
-                d[2] = (float)(raw.y & 0xffffu); d[3] = (float)(raw.y >> 16);
-            } else {
-                const float4 raw = *(const float4 *)((const float *)depth_f + i0);
-                d[0] = raw.x; d[1] = raw.y; d[2] = raw.z; d[3] = raw.w;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { // hv_convert_depth
-                d[k] = d[k] / P.depth_scale_f;
-                if ((double)d[k] >= P.depth_trunc_d) d[k] = 0.0f;
-            }
-            if (mult12 != nullptr) {
-                const float4 m4 = *(const float4 *)(mult12 + i0);
-                ((uint4 *)dst12)[0] = make_uint4(__float_as_uint(d[0]), col[0], __float_as_uint(m4.x), __float_as_uint(d[1]));
-                ((uint4 *)dst12)[1] = make_uint4(col[1], __float_as_uint(m4.y), __float_as_uint(d[2]), col[2]);
-                ((uint4 *)dst12)[2] = make_uint4(__float_as_uint(m4.z), __float_as_uint(d[3]), col[3], __float_as_uint(m4.w));
-            } else {
-                ((uint4 *)dst)[0] = make_uint4(__float_as_uint(d[0]), col[0], __float_as_uint(d[1]), col[1]);
-                ((uint4 *)dst)[1] = make_uint4(__float_as_uint(d[2]), col[2], __float_as_uint(d[3]), col[3]);
-            }
-        } else {
-            for (int64_t i = i0; i < npx && i < i0 + 4; ++i) {
-                const uint8_t *c = rgb_f + i * 3;
-                uint2 rec;
-                rec.x = __float_as_uint(hv_convert_depth(P, depth_f, i));
-                rec.y = hv_colour_order((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16), P.bgr) | HV_REC_ONE;
-                if (mult12 != nullptr) {
-                    uint32_t *r3 = (uint32_t *)frame_px + ((int64_t)f * npx + i) * 3;
-                    r3[0] = rec.x;
-                    r3[1] = rec.y;
-                    r3[2] = __float_as_uint(mult12[i]);
-                } else {
-                    frame_px[(int64_t)f * npx + i] = rec;
-                }
-            }
-        }
+        // pack role: 4 pixels per thread - every wave access is a contiguous burst (prep blocks cover 1024 pixels each)
+        hv_pack_px4(P, f, ((int64_t)bx * blockDim.x + threadIdx.x) * 4, depth_f, rgb_f, frame_px, mult12, pack_box);
         return;
     }
     // ---- touch role: one wave per 8x8 sample patch (hv_touch_patch) ----
     __shared__ HvTouchScratch scratch[4];
-    const int patch = bx * 4 + (int)(threadIdx.x / HV_WAVE);
+    const int patch = bx * (int)(blockDim.x / HV_WAVE) + (int)(threadIdx.x / HV_WAVE); // (blocks of 256 or - HV_TSDF_AUX_W64 - 64 threads)
     if (patch >= hv_touch_patches(P)) return;
-    const unsigned long long fbit = 1ull << f;
-    hv_touch_patch(table, P, depth_f, patch, scratch[threadIdx.x / HV_WAVE],
-                   [&](unsigned long long key, int32_t ux, int32_t uy, int32_t uz) {
-                       // image-tile sharding: units that cannot project into this GPU's tile are not allocated here
-                       if (!hv_unit_hits_tile(P, ux, uy, uz)) return;
-                       const int32_t slot = hv_table_insert(table, key);
-                       if (slot < 0) return;
-                       // both L1-bypassing pre-checks in flight together
-                       const unsigned long long seen = __hip_atomic_load(&frame_mask[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                       const int32_t stamped = __hip_atomic_load(&stamp[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                       // frame bit (skip the atomic when another wave of this frame already set it)
-                       if (!(seen & fbit)) atomicOr(&frame_mask[slot], fbit);
-                       if (stamped != batch_stamp) {
-                           if (list == nullptr) {
-                               // the union list is built afterwards from the allocated units (k_tsdf_batch_list): an append here
-                               // is one returning atomic on a single counter per first touch - thousands per batch, serialised
-                               __hip_atomic_store(&stamp[slot], batch_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                           } else {
-                               const int32_t old = atomicExch(&stamp[slot], batch_stamp);
-                               if (old != batch_stamp) {
-                                   const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH0 + parity], 1);
-                                   if (at < table.max_blocks) list[at] = slot;
-                               }
-                           }
-                       }
-                   });
+    hv_touch_batch_patch(table, P, depth_f, patch, scratch[threadIdx.x / HV_WAVE], f, frame_mask, stamp, list, batch_stamp, parity);
 }
 
 // Union list of a batch from the allocated units: unit b belongs to it iff its slot carries the batch's stamp.  One thread per
@@ -999,7 +1016,7 @@ __global__ __launch_bounds__(256) void k_tsdf_touch_plan(HvTable table, HvPlan p
     if (blockIdx.x == 0) {
         // this scratch set's last batch is swept (the chain waited for it): its union list restarts, its boxes start empty
         if (threadIdx.x < 64) plan.box[threadIdx.x] = make_int4(INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN);
-        if (threadIdx.x == 0) table.counters[HV_CNT_TOUCH0 + parity] = 0;
+        if (threadIdx.x == 0) table.counters[HV_CNT_TOUCH(parity)] = 0;
     }
     __syncthreads();
     const int f = (int)blockIdx.x / n_touch_blocks, bx = (int)blockIdx.x % n_touch_blocks;
@@ -1099,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_tsdf_plan_assign(HvTable table, HvPlan 
             s_mine_mask[at] = mask;
         }
     }
-    const int32_t at = hv_wave_append(&table.counters[HV_CNT_TOUCH0 + parity], slot >= 0);
+    const int32_t at = hv_wave_append(&table.counters[HV_CNT_TOUCH(parity)], slot >= 0);
     if (slot >= 0 && at < table.max_blocks) list[at] = slot;
     __syncthreads();
     const int n_mine = s_n_mine, wave = tid / HV_WAVE, f = hv_lane_id();
@@ -1162,7 +1179,7 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_integrate_
     constexpr int G = ZH < 4 ? ZH : 4; // voxels of a lane evaluated together (G gathers in flight), then folded
     constexpr int TASKS = 64 / ZH;          // wave tasks per unit
     constexpr int WAVES = TASKS / SPLIT;    // waves per workgroup
-    int n_units = table.counters[HV_CNT_TOUCH0 + parity];
+    int n_units = table.counters[HV_CNT_TOUCH(parity)];
     if (n_units > table.max_blocks) n_units = table.max_blocks;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: keeps the z-walk replay loop scalar
     const int lane = threadIdx.x & 63;
@@ -1365,7 +1382,7 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep(
     static_assert(ZH % 2 == 0, "voxels are folded in pairs");
     constexpr int TASKS = 64 / ZH;          // wave tasks per unit
     constexpr int WAVES = TASKS / SPLIT;    // waves per workgroup
-    int n_units = table.counters[HV_CNT_TOUCH0 + parity];
+    int n_units = table.counters[HV_CNT_TOUCH(parity)];
     if (n_units > table.max_blocks) n_units = table.max_blocks;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1643,7 +1660,7 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep_fold
     int general, const float *__restrict__ mult, int xcd_aware, int parity) {
     constexpr int TASKS = 64 / ZH;          // wave tasks per unit
     constexpr int WAVES = TASKS / SPLIT;    // waves per workgroup
-    int n_units = table.counters[HV_CNT_TOUCH0 + parity];
+    int n_units = table.counters[HV_CNT_TOUCH(parity)];
     if (n_units > table.max_blocks) n_units = table.max_blocks;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1896,22 +1913,22 @@ __global__ __launch_bounds__(64 * (64 / ZH) / SPLIT, WPE) void k_tsdf_sweep_fold
 #ifndef HV_SWEEP_DIV_ROUNDS
 #define HV_SWEEP_DIV_ROUNDS 1
 #endif
-template <int SPLIT, int GV, int PIPE, int ANYSKIP, int ZS = 1>
-__device__ __forceinline__ void hv_sweep_column_body(
-    HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
-    char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
-    int general, const float *__restrict__ mult, int xcd_aware, int parity) {
+// hv_sweep_column_core: the sweep of ONE work item (unit slot, part) as the callable `run_item(slot, part)`, handed to `drive`, which
+// decides what items this workgroup runs (k_tsdf_sweep_column: the grid-stride loop over the batch's union list; k_tsdf_fused: the
+// same items interleaved with the touch + pack items of the NEXT batch).  Everything inlines: one copy of the code per kernel.
+template <int SPLIT, int GV, int PIPE, int ANYSKIP, int ZS, class Drive>
+__device__ __forceinline__ void hv_sweep_column_core(
+    const HvTable &table, const unsigned long long *__restrict__ frame_mask,
+    char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, const int n_frames,
+    const int general, const float *__restrict__ mult, Drive drive) {
     // ZS = 2: a column is split into two z halves = 8 wave tasks per unit (a GPU that owns few units - multi-GPU sharding - has
     // ~3 000 column tasks of very different lengths for 4 096 wave slots: nothing evens them out; twice as many, half as long
     // tasks do).  The upper half replays the reference's 8 repeated float additions along z per frame.
     static_assert(ZS == 1 || (ZS == 2 && SPLIT == 4), "z halves need one-wave workgroups");
     constexpr int ZH = 16 / ZS;
-    constexpr int PARTS = SPLIT * ZS; // work items per unit
     constexpr int NG = ZH / GV;
     constexpr int WAVES = 4 / SPLIT; // waves per workgroup
     typedef uint32_t hv_u3 __attribute__((ext_vector_type(3)));
-    int n_units = table.counters[HV_CNT_TOUCH0 + parity];
-    if (n_units > table.max_blocks) n_units = table.max_blocks;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const HvFrameParams &P0 = Ps[0];
@@ -1926,30 +1943,15 @@ __device__ __forceinline__ void hv_sweep_column_body(
     const uint32_t W24 = (uint32_t)P0.W;
     const float ntrunc = -P0.sdf_trunc_f, tinv = P0.sdf_trunc_inv_f;
     const float near_z = fmaxf(0.03f, 1.25f * P0.sdf_trunc_f);
-    const int G = xcd_aware > 0 ? xcd_aware : 1;
-    const int rounds = (n_units + 8 * G - 1) / (8 * G);
-    const int n_items = xcd_aware > 0 ? rounds * 8 * G * PARTS : n_units * PARTS;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        int t, part;
-        if (xcd_aware > 0) {
-            const int xcd = item & 7, j = item >> 3;
-            const int g = j / (G * PARTS), within = j - g * (G * PARTS);
-            t = (g * 8 + xcd) * G + within / PARTS;
-            part = within % PARTS;
-            if (t >= n_units) continue;
-        } else {
-            t = item / PARTS;
-            part = item % PARTS;
-        }
+    auto run_item = [&](const int32_t slot, int part) __attribute__((always_inline)) {
         const int z0 = ZS == 1 ? 0 : (part >> 2) * ZH; // first z of this task
         if (ZS == 2) part &= 3;
         const int cg = part * WAVES + wave; // column group: x in [4 cg, 4 cg + 4)
         const int x = cg * 4 + (lane >> 4);
         const int y = lane & 15;
-        const int32_t slot = list[t];
         const int32_t idx = table.vals[slot];
         unsigned long long mask = frame_mask[slot];
-        if (idx < 0 || mask == 0ull) continue;
+        if (idx < 0 || mask == 0ull) return;
         int32_t ux, uy, uz;
         hv_unpack_key(table.keys[slot], ux, uy, uz);
         const double o0 = (double)ux * unit_length, o1 = (double)uy * unit_length, o2 = (double)uz * unit_length;
@@ -2010,7 +2012,7 @@ __device__ __forceinline__ void hv_sweep_column_body(
                     ((uint32_t *)(unit + 4 * PLANE_BYTES))[q] = vb;
                 }
             }
-            continue;
+            return;
         }
         float S[ZH];               // sum of the accepted frames' t
         uint32_t arb[ZH], agn[ZH]; // r | b << 16 and g << 8 | n << 24 of the accepted frames
@@ -2208,7 +2210,38 @@ __device__ __forceinline__ void hv_sweep_column_body(
                 }
             }
         }
-    }
+    };
+    drive(run_item);
+}
+
+// The column sweep on its own: a grid-stride loop over the batch's union list.
+template <int SPLIT, int GV, int PIPE, int ANYSKIP, int ZS = 1>
+__device__ __forceinline__ void hv_sweep_column_body(
+    HvTable table, const int32_t *__restrict__ list, const unsigned long long *__restrict__ frame_mask,
+    char *__restrict__ pool, const uint2 *__restrict__ frame_px, const HvFrameParams *__restrict__ Ps, int n_frames,
+    int general, const float *__restrict__ mult, int xcd_aware, int parity) {
+    constexpr int PARTS = SPLIT * ZS; // work items per unit
+    int n_units = table.counters[HV_CNT_TOUCH(parity)];
+    if (n_units > table.max_blocks) n_units = table.max_blocks;
+    hv_sweep_column_core<SPLIT, GV, PIPE, ANYSKIP, ZS>(table, frame_mask, pool, frame_px, Ps, n_frames, general, mult, [&](auto &&run_item) __attribute__((always_inline)) {
+        const int G = xcd_aware > 0 ? xcd_aware : 1;
+        const int rounds = (n_units + 8 * G - 1) / (8 * G);
+        const int n_items = xcd_aware > 0 ? rounds * 8 * G * PARTS : n_units * PARTS;
+        for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+            int t, part;
+            if (xcd_aware > 0) {
+                const int xcd = item & 7, j = item >> 3;
+                const int g = j / (G * PARTS), within = j - g * (G * PARTS);
+                t = (g * 8 + xcd) * G + within / PARTS;
+                part = within % PARTS;
+                if (t >= n_units) continue;
+            } else {
+                t = item / PARTS;
+                part = item % PARTS;
+            }
+            run_item(list[t], part);
+        }
+    });
 }
 
 // The kernels proper.  WPE = the waves per SIMD the register allocation is capped for (4: 128 VGPRs).  The _v120 / _v112
@@ -2236,6 +2269,312 @@ HV_SWEEP_COLUMN_CAPPED(k_tsdf_sweep_column_v120, 60)
 HV_SWEEP_COLUMN_CAPPED(k_tsdf_sweep_column_v112, 56)
 #undef HV_SWEEP_COLUMN_CAPPED
 
+// ================================================================================================
+// k_tsdf_fused (round 5): the column sweep of batch k-1 AND the touch + pack pass of batch k in ONE launch.
+//
+// Rounds 2-4 ran the touch + pack launch of the next batch on a second stream beside the sweep.  The sweep's waves hold every VGPR
+// of a SIMD (4 x 128), so the other queue only got a wave slot when a sweep wave retired: the launch took the whole sweep to finish,
+// ended ~37 us AFTER it (profiles/r04/pipeline_timeline.txt), and at an 8-GPU share (sweep 85 us, touch + pack 60 us) a step was
+// the SUM of the two launches (profiles/r04/rank8_timeline.txt: 153 us), which is what kept the projected scaling at 4.5x.  Here
+// both kinds of work are items of one grid, interleaved evenly (Bresenham) in dispatch order: the streaming / latency-chain waves
+// of the next batch take their slots among the VALU-bound sweep waves by construction, not by the dispatcher's mercy.
+//   item kinds (one 64-lane workgroup each): sweep (unit, part) of batch k-1 | touch: one 8x8 sample patch of a frame of batch k |
+//   pack: 1024 pixels of a frame of batch k.
+//   XCD-aware as the sweep was: workgroup b runs on XCD b & 7; all parts of a unit and G list neighbours share an XCD's L2.
+// What used to be k_tsdf_batch_finish (a launch + two dependent-launch gaps per batch) is the sweep's epilogue: the LAST part of
+// a unit to finish clears the unit's frame mask (per-slot counter `done`), and the last item of the launch that matters for it
+// (sweep items: the union list is consumed; touch items: the pool claims are made) zeroes the batch's list counter and
+// publishes the pool status.  Frame constants: Ps_sweep / Ps_aux live in a device ring filled by k_upload_words on a stream of
+// its own, a batch ahead (hv_tsdf.hip: tsdf_integrate_batch_impl).  Host side: the sweep of the batch handed over by call k is
+// launched by call k+1 (with that call's touch + pack) or by hv_tsdf_flush - which every other entry point runs first.
+// ================================================================================================
+struct HvFusedSweep {             // batch k-1 (n_frames == 0: no sweep in this launch)
+    const int32_t *list;          // union list of the batch (scratch set `parity`)
+    unsigned long long *mask;     // [table capacity] frame masks of that set: read, then cleared by the unit's last part
+    int32_t *done;                // [table capacity] parts of the unit finished in this launch (back to 0 with the last one)
+    const uint2 *px;              // 12-byte frame records of the batch
+    const HvFrameParams *Ps;
+    int32_t n_frames, parity;
+};
+struct HvFusedAux {               // batch k (n_frames == 0: no touch + pack in this launch)
+    unsigned long long *mask;     // frame masks of the batch's scratch set
+    int32_t *stamp, *list;
+    const char *depth;            // frames back to back, depth_stride bytes apart
+    const uint8_t *rgb;
+    uint2 *px;                    // records to write
+    const HvFrameParams *Ps;
+    const float *mult;            // per-pixel multiplier table (copied into the records)
+    int64_t depth_stride;
+    int32_t n_frames, parity, batch_stamp;
+    int32_t touch_per_frame, pack_per_frame; // items per frame: 8x8 sample patches / 1024-pixel chunks
+};
+
+// The kernel's arguments are passed ONE BY ONE, not as this struct (with a struct argument the sweep's register allocation loses
+// 30 accumulators to scratch: the compiler then reads the fields through a reference into the kernarg segment instead of preloading
+// them).  The struct MIRRORS the argument list - same order, same natural alignment = the layout of the kernarg segment - so that
+// the epilogue and the touch + pack role can re-read arguments from the segment (hv_fused_kernarg) instead of keeping them live.
+struct HvFusedArgs {
+    HvTable table;
+    char *pool;
+    HvFusedSweep S;
+    HvFusedAux A;
+    HvStatus *status;
+    int32_t status_seq, general, xcd_g, lead;
+};
+#define HV_FUSED_PARAMS                                                                                                            \
+    HvTable table, char *__restrict__ pool, const int32_t *__restrict__ s_list, unsigned long long *__restrict__ s_mask,           \
+        int32_t *__restrict__ s_done, const uint2 *__restrict__ s_px, const HvFrameParams *__restrict__ s_Ps, int32_t s_n_frames,  \
+        int32_t s_parity, HvFusedAux A, HvStatus *status, int32_t status_seq, int32_t general, int32_t xcd_g, int32_t lead
+#define HV_FUSED_ARGS(K)                                                                                                           \
+    (K).table, (K).pool, (K).S.list, (K).S.mask, (K).S.done, (K).S.px, (K).S.Ps, (K).S.n_frames, (K).S.parity, (K).A, (K).status,  \
+        (K).status_seq, (K).general, (K).xcd_g, (K).lead
+static_assert(offsetof(HvFusedArgs, S) == sizeof(HvTable) + 8 && sizeof(HvFusedSweep) == 48 && offsetof(HvFusedArgs, A) % 8 == 0 &&
+                  offsetof(HvFusedArgs, status) == offsetof(HvFusedArgs, A) + sizeof(HvFusedAux),
+              "HvFusedArgs must have the layout of the kernel's argument list");
+
+// What k_tsdf_batch_finish did, by whichever item of the launch finishes last (lane 0 of the item's wave calls this).  The
+// launch's arguments are read AGAIN from the kernarg segment, through a pointer laundered by an empty asm so that the scalar loads
+// are not merged with the kernel's own: nothing this needs stays live in registers over a sweep item (the sweep sits at the 128
+// VGPRs / 102 SGPRs of 4 waves per SIMD; spilled SGPRs take a VGPR for their lanes, and that one register costs the sweep its
+// accumulators).
+typedef const __attribute__((address_space(4))) HvFusedArgs *HvFusedKernargPtr;
+__device__ __forceinline__ HvFusedKernargPtr hv_fused_kernarg() {
+    HvFusedKernargPtr kp = (HvFusedKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+
+// items of XCD x the epilogue waits for: the parts of its units (unit t belongs to XCD (t / G) & 7) + its touch items (a & 7 == x)
+template <int PARTS>
+__device__ __forceinline__ int hv_fused_expected_xcd(const int n_units, const int G, const int n_touch, const int x) {
+    const int full = n_units / (8 * G), rem = n_units - full * 8 * G;
+    const int units_x = full * G + min(max(rem - x * G, 0), G);
+    const int touch_x = n_touch > x ? (n_touch - x + 7) >> 3 : 0;
+    return units_x * PARTS + touch_x;
+}
+
+// Completion is counted per XCD first (one counter line per XCD, HV_CNT_SWEEP_DONE_XCD), then over the XCDs: 50 k returning atomics
+// per launch on ONE address were the launch's critical path.
+template <int PARTS>
+__device__ __forceinline__ void hv_fused_item_done(const int xcd) {
+    HvFusedKernargPtr kp = hv_fused_kernarg();
+    int32_t *counters = kp->table.counters;
+    const int32_t s_frames = kp->S.n_frames, s_parity = kp->S.parity;
+    int n_units = 0;
+    if (s_frames > 0) n_units = min(counters[HV_CNT_TOUCH(s_parity)], kp->table.max_blocks); // (stable during the launch, on a line nobody writes)
+    const int n_touch = kp->A.touch_per_frame * kp->A.n_frames;
+    const int xg = kp->xcd_g;
+    const int G = xg > 0 ? xg : 1;
+    const int32_t gx = atomicAdd(&counters[HV_CNT_SWEEP_DONE_XCD + 32 * xcd], 1);
+    if (gx != hv_fused_expected_xcd<PARTS>(n_units, G, n_touch, xcd) - 1) return;
+    counters[HV_CNT_SWEEP_DONE_XCD + 32 * xcd] = 0;
+    int live = 0; // XCDs that have items at all
+#pragma unroll
+    for (int x = 0; x < 8; ++x) live += hv_fused_expected_xcd<PARTS>(n_units, G, n_touch, x) > 0 ? 1 : 0;
+    const int32_t g = atomicAdd(&counters[HV_CNT_SWEEP_DONE], 1);
+    if (g != live - 1) return;
+    counters[HV_CNT_SWEEP_DONE] = 0;
+    if (s_frames > 0) counters[HV_CNT_TOUCH(s_parity)] = 0; // the list is consumed (the other set's may be filling)
+    // pool occupancy after this launch's claims, for hv_capacity_gate.  L1-bypassing loads: the claims were made by atomics of
+    // other workgroups
+    volatile HvStatus *st = kp->status;
+    if (st == nullptr) return; // (a claim pass that is verified synchronously: hv_claims_fit reads the counters itself)
+    st->blocks = __hip_atomic_load(&counters[HV_CNT_BLOCKS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st->overflow = __hip_atomic_load(&counters[HV_CNT_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    st->seq = kp->status_seq;
+}
+
+// the unit's last part clears its frame mask for the scratch set's next batch (every part read the mask before it came here)
+template <int PARTS>
+__device__ __forceinline__ void hv_fused_unit_part_done(const int32_t slot) {
+    HvFusedKernargPtr kp = hv_fused_kernarg();
+    int32_t *done = kp->S.done;
+    const int32_t before = atomicAdd(&done[slot], 1);
+    if (before == PARTS - 1) {
+        done[slot] = 0;
+        kp->S.mask[slot] = 0ull;
+    }
+}
+
+// The touch + pack role of a k_tsdf_fused workgroup: aux items q, q + naw, ... of this XCD (item a = q * 8 + xcd; touch items
+// first - latency chains: hash probes, atomics - then the pack items).  Reads the launch's arguments from the kernarg segment.
+template <int PARTS>
+__device__ __forceinline__ void hv_fused_aux_role(int q0, const int naw, const int na, const int xcd, const int n_touch, const int n_pack) {
+    __shared__ HvTouchScratch scratch;
+    // The frame constants are read with VECTOR loads (the index goes through a VGPR the compiler cannot see through): as scalars
+    // the touch role's 40-odd doubles do not fit beside the kernel's own, and spilled scalars take a VGPR of the WHOLE kernel for
+    // their lanes - the one register the sweep's accumulators cannot spare at 128.
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    // (the launch's arguments, field by field through the kernarg pointer: scalar loads)
+    HvFusedKernargPtr kp = hv_fused_kernarg();
+    struct {
+        HvTable table;
+    } K;
+    K.table.keys = kp->table.keys;
+    K.table.vals = kp->table.vals;
+    K.table.block_keys = kp->table.block_keys;
+    K.table.counters = kp->table.counters;
+    K.table.mask = kp->table.mask;
+    K.table.max_blocks = kp->table.max_blocks;
+    K.table.prob_nodes = nullptr;
+    K.table.prob_node_cap = 0;
+    HvFusedAux A;
+    A.mask = kp->A.mask;
+    A.stamp = kp->A.stamp;
+    A.list = kp->A.list;
+    A.depth = kp->A.depth;
+    A.rgb = kp->A.rgb;
+    A.px = kp->A.px;
+    A.Ps = kp->A.Ps;
+    A.mult = kp->A.mult;
+    A.depth_stride = kp->A.depth_stride;
+    A.n_frames = kp->A.n_frames;
+    A.parity = kp->A.parity;
+    A.batch_stamp = kp->A.batch_stamp;
+    A.touch_per_frame = kp->A.touch_per_frame;
+    A.pack_per_frame = kp->A.pack_per_frame;
+    const int lane = threadIdx.x & 63;
+    for (int q = q0; q < na; q += naw) {
+        const int a = q * 8 + xcd;
+        if (a < n_touch) {
+            const int f = a / A.touch_per_frame, patch = a - f * A.touch_per_frame;
+            const HvFrameParams &P = A.Ps[f + vzero];
+            if (patch < hv_touch_patches(P))
+                hv_touch_batch_patch(K.table, P, A.depth + (int64_t)f * A.depth_stride, patch, scratch, f, A.mask, A.stamp, A.list,
+                                     A.batch_stamp, A.parity);
+            // (the claims of this wave's lanes are returning atomics: performed before this one is issued)
+            if (lane == 0) hv_fused_item_done<PARTS>(xcd);
+        } else if (a < n_touch + n_pack) {
+            const int c = a - n_touch;
+            const int f = c / A.pack_per_frame, chunk = c - f * A.pack_per_frame;
+            const HvFrameParams &P = A.Ps[f + vzero];
+            const int64_t npx = (int64_t)P.H * P.W;
+            const void *depth_f = A.depth + (int64_t)f * A.depth_stride;
+            const uint8_t *rgb_f = A.rgb + (int64_t)f * npx * 3;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) // (unrolled: the four sub-chunks' loads are in flight together - a pack wave holds a 128-VGPR slot)
+                hv_pack_px4(P, f, ((int64_t)chunk * 1024 + it * 256 + lane * 4), depth_f, rgb_f, A.px, A.mult, nullptr);
+        }
+    }
+}
+
+// Which items a workgroup of k_tsdf_fused runs.  A workgroup has ONE role for its whole life (the register allocation of the sweep
+// then is the stand-alone kernel's: in a loop that switched roles per item the touch + pack code's live values pushed the sweep's
+// accumulators into scratch).  The first Lw workgroups of an XCD are dealt the roles in the proportion ns : na, evenly interleaved
+// in dispatch order (Bresenham); each class then strides over its own items.
+struct HvFusedRole {
+    int n_units, ns, na, n_touch, n_pack; // sweep / aux items per XCD, touch / pack items of the launch
+    int G, xcd, rank, stride;             // this workgroup: its first item and stride inside its class
+    bool active, sweep;
+};
+template <int PARTS>
+__device__ __forceinline__ HvFusedRole hv_fused_role(const HvTable &table, const int s_n_frames, const int s_parity, const HvFusedAux &A, const int xcd_g,
+                                                     const int lead) {
+    HvFusedRole r;
+    r.n_units = 0;
+    if (s_n_frames > 0) r.n_units = min(table.counters[HV_CNT_TOUCH(s_parity)], table.max_blocks);
+    r.G = xcd_g > 0 ? xcd_g : 1;
+    const int rounds = (r.n_units + 8 * r.G - 1) / (8 * r.G);
+    r.ns = rounds * r.G * PARTS; // (the list padded to whole rounds of 8 XCDs x G units)
+    r.n_touch = A.touch_per_frame * A.n_frames;
+    r.n_pack = A.pack_per_frame * A.n_frames;
+    r.na = (r.n_touch + r.n_pack + 7) >> 3;
+    const int per = r.ns + r.na;
+    r.xcd = blockIdx.x & 7;
+    const int l = blockIdx.x >> 3;
+    const int Lw = min(per, (int)(gridDim.x >> 3));
+    r.active = l < Lw;
+    r.sweep = false;
+    r.rank = r.stride = 0;
+    if (!r.active) return r;
+    // sweep workgroups of this XCD: the share ns / per of the Lw (any split serves; float arithmetic and 32-bit divisions only -
+    // a 64-bit division is expanded on the vector unit and leaves these wave-uniform values, and with them the list index, the unit's
+    // slot and address and the frame mask of every sweep item, in VECTOR registers: 60 of the sweep's accumulators went to scratch)
+    int nsw = r.ns > 0 ? max(1, (int)((float)Lw * ((float)r.ns / (float)per))) : 0;
+    if (nsw > Lw) nsw = Lw;
+    if (r.na > 0 && nsw >= Lw) nsw = Lw - 1;
+    // `lead`: the first workgroups of an XCD are ALL sweep items (a sweep item lives ~10x as long as a touch / pack item: dealt evenly
+    // from the start, the sweep items trickle into the machine behind short-lived neighbours and the launch ends on the sweep's
+    // second wave; with the machine's 512 wave slots per XCD filled by sweep items first, the touch + pack items fill what the
+    // later sweep items leave free)
+    const int ld = min(max(lead, 0), nsw);
+    int rank_s;
+    if (l < ld) {
+        rank_s = l;
+        r.sweep = true;
+    } else {
+        const uint32_t l2 = (uint32_t)(l - ld), n2 = (uint32_t)(nsw - ld), L2 = (uint32_t)(Lw - ld); // < 2^13 each (gridDim.x >> 3 <= 8192 by launch)
+        const int q = (int)((l2 * n2) / L2);
+        r.sweep = (int)(((l2 + 1) * n2) / L2) > q;
+        rank_s = ld + q;
+    }
+    r.rank = __builtin_amdgcn_readfirstlane(r.sweep ? rank_s : l - rank_s);
+    r.stride = __builtin_amdgcn_readfirstlane(r.sweep ? nsw : Lw - nsw);
+    r.ns = __builtin_amdgcn_readfirstlane(r.ns);
+    r.na = __builtin_amdgcn_readfirstlane(r.na);
+    r.n_units = __builtin_amdgcn_readfirstlane(r.n_units);
+    return r;
+}
+
+template <int ZS>
+__global__ __launch_bounds__(64, 4) void k_tsdf_fused(HV_FUSED_PARAMS) {
+    constexpr int PARTS = 4 * ZS;
+    const int lane = threadIdx.x & 63;
+    const HvFusedRole r = hv_fused_role<PARTS>(table, s_n_frames, s_parity, A, xcd_g, lead);
+    if (r.n_units * PARTS + r.n_touch == 0) { // (nothing the epilogue would wait for: an empty sweep without a next batch)
+        if (blockIdx.x == 0 && lane == 0 && status != nullptr) hv_publish_status(table, status, status_seq);
+    }
+    if (!r.active) return;
+    if (!r.sweep) {
+        hv_fused_aux_role<PARTS>(r.rank, r.stride, r.na, r.xcd, r.n_touch, r.n_pack);
+        return;
+    }
+    hv_sweep_column_core<4, 4, 1, 2, ZS>(table, s_mask, pool, s_px, s_Ps, s_n_frames, general, (const float *)nullptr, [&](auto &&run_item) __attribute__((always_inline)) {
+        for (int j = r.rank; j < r.ns; j += r.stride) {
+            const int g = j / (r.G * PARTS), within = j - g * (r.G * PARTS);
+            const int t = (g * 8 + r.xcd) * r.G + within / PARTS;
+            if (t >= r.n_units) continue;
+            const int32_t slot = s_list[t];
+            run_item(slot, within % PARTS);
+            if (lane == 0) {
+                hv_fused_unit_part_done<PARTS>(slot);
+                hv_fused_item_done<PARTS>(r.xcd);
+            }
+        }
+    });
+}
+
+// The batch's union list in order of DECREASING work (frames that see the unit = set bits of its frame mask): a counting sort by one
+// workgroup between the touch pass and the sweep, on the touch pass's stream.  The sweep deals its items out in list order; a unit seen
+// by all 32 frames is a wave task 10 - 30 x as long as one seen by a single frame, and with the long ones first the short ones fill
+// the launch's tail (longest-processing-time-first: what matters at an 8-GPU share, where 6 800 tasks meet 4 096 wave slots).
+__global__ __launch_bounds__(1024) void k_tsdf_list_by_work(HvTable table, const int32_t *__restrict__ list,
+                                                            const unsigned long long *__restrict__ frame_mask,
+                                                            int32_t *__restrict__ sorted, int parity) {
+    __shared__ int32_t s_bin[65]; // bin b = 64 - popcount: the longest tasks first
+    int n = table.counters[HV_CNT_TOUCH(parity)];
+    if (n > table.max_blocks) n = table.max_blocks;
+    for (int i = threadIdx.x; i < 65; i += blockDim.x) s_bin[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_bin[64 - __popcll(frame_mask[list[i]])], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int at = 0;
+        for (int b = 0; b < 65; ++b) {
+            const int c = s_bin[b];
+            s_bin[b] = at;
+            at += c;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int32_t slot = list[i];
+        sorted[atomicAdd(&s_bin[64 - __popcll(frame_mask[slot])], 1)] = slot;
+    }
+}
+
 // n16 16-byte words from device-visible host memory to device memory, one workgroup (see hv_tsdf_integrate_batch: frame constants).
 __global__ __launch_bounds__(256) void k_upload_words(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16) {
     for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i]; // (one workgroup: 3-4 PCIe round trips for a 32-frame batch)
@@ -2246,7 +2585,7 @@ __global__ __launch_bounds__(256) void k_upload_words(const uint4 *__restrict__ 
 __global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const int32_t *__restrict__ list,
                                                              unsigned long long *__restrict__ frame_mask, int parity,
                                                              HvStatus *status, int32_t status_seq) {
-    int n_units = table.counters[HV_CNT_TOUCH0 + parity];
+    int n_units = table.counters[HV_CNT_TOUCH(parity)];
     if (n_units > table.max_blocks) n_units = table.max_blocks;
     __syncthreads(); // every thread holds n_units before the counters are reset
     // 8 independent list loads in flight per thread, then the 8 stores: two memory latencies per 8192 units instead
@@ -2263,7 +2602,7 @@ __global__ __launch_bounds__(1024) void k_tsdf_batch_finish(HvTable table, const
             if (slot[k] >= 0) frame_mask[slot[k]] = 0ull;
     }
     if (threadIdx.x == 0) {
-        table.counters[HV_CNT_TOUCH0 + parity] = 0; // (the other set's counter may be filling: the next batch's touch pass)
+        table.counters[HV_CNT_TOUCH(parity)] = 0; // (the other set's counter may be filling: the next batch's touch pass)
         hv_publish_status(table, status, status_seq); // pool occupancy after this batch, for hv_capacity_gate
     }
 }
@@ -2509,7 +2848,7 @@ static void tsdf_next_frame(hv_volume *v, HvFrameParams &P, int &parity) {
     if (v->plan_lists_stale) {
         // coherent batches ran before this frame: their plans leave the list counters behind (the main stream has waited for every
         // one of those chains, so this memset is ordered after them)
-        (void)hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream);
+        (void)hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, HV_CNT_TOUCH_SPAN_BYTES, v->stream);
         v->plan_lists_stale = false;
     }
     v->content_version += 1;
@@ -2527,14 +2866,16 @@ static int tsdf_integrate_one(hv_volume *v, const void *d_depth, int depth_dtype
                               int H, int W, const double *intr, const double *T_cw, double depth_scale,
                               double depth_trunc) {
     bool checked = false;
-    int rc = hv_capacity_gate(v, &checked);
+    int rc = hv_tsdf_flush(v); // a deferred multi-frame sweep goes first (frames are fused in order)
+    if (rc != HV_OK) return rc;
+    rc = hv_capacity_gate(v, &checked);
     if (rc != HV_OK) return rc;
     HvFrameParams P;
     make_frame_params(v, H, W, intr, T_cw, depth_scale, depth_trunc, depth_dtype, &P);
     int parity = 0;
     for (int attempt = 0;; ++attempt) {
         tsdf_next_frame(v, P, parity);
-        if (attempt > 0) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
+        if (attempt > 0) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, HV_CNT_TOUCH_SPAN_BYTES, v->stream));
         rc = tsdf_launch_touch(v, v->stream, P, parity, d_depth, d_rgb);
         if (rc != HV_OK) return rc;
         if (!checked) break;
@@ -2548,6 +2889,193 @@ static int tsdf_integrate_one(hv_volume *v, const void *d_depth, int depth_dtype
         if (rc != HV_OK) return rc;
     }
     return tsdf_launch_integrate(v, P, parity);
+}
+
+// ---- fused form: host side (see k_tsdf_fused) ---------------------------------------------------------------------------------
+static constexpr int HV_BATCH_MAX = 64; // frames per sweep (one bit per frame in a unit's mask)
+
+static int tsdf_fused_resources(hv_volume *v) {
+    if (v->stream_up == nullptr) {
+        HV_HIP(hipStreamCreateWithFlags(&v->stream_up, hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) HV_HIP(hipEventCreateWithFlags(&v->ev_swept[i], hipEventDisableTiming));
+    }
+    if (v->params_ring == nullptr) HV_HIP(hipMalloc(&v->params_ring, sizeof(HvFrameParams) * HV_BATCH_MAX * 4));
+    return HV_OK;
+}
+
+// One launch: the sweep of `sweep` (the pending batch, or nullptr) + the touch + pack pass described by `aux` (or nullptr).
+static int tsdf_launch_fused(hv_volume *v, bool with_sweep, const HvFusedAux *aux, bool publish = true, const HvFusedSweep *explicit_sweep = nullptr) {
+    HvFusedSweep S;
+    memset(&S, 0, sizeof(S));
+    HvFusedAux A;
+    memset(&A, 0, sizeof(A));
+    if (aux) A = *aux;
+    if (explicit_sweep) { // (the two-stream form's sweep with the finish as its epilogue: not the pending batch)
+        S = *explicit_sweep;
+    } else if (with_sweep) {
+        const int sp = v->pending.parity;
+        S.list = v->touched_list + (size_t)sp * (size_t)v->cfg.max_blocks;
+        S.mask = (unsigned long long *)v->touched_mask + (size_t)sp * (size_t)v->table_capacity;
+        S.px = (const uint2 *)v->pending.px;
+        S.Ps = v->pending.params;
+        S.n_frames = v->pending.n_frames;
+        S.parity = sp;
+    } else {
+        S.Ps = A.Ps; // (the sweep's frame-independent constants are read at kernel entry: any valid frame will do)
+        S.mask = A.mask;
+    }
+    S.done = v->sweep_done;
+    const int general = getenv("HV_TSDF_BATCH_GENERAL") ? atoi(getenv("HV_TSDF_BATCH_GENERAL")) : 0;
+    const int xcd_g = getenv("HV_TSDF_SWEEP_XCD") ? atoi(getenv("HV_TSDF_SWEEP_XCD")) : 2;
+    const int grid = getenv("HV_TSDF_BATCH_GRID") ? atoi(getenv("HV_TSDF_BATCH_GRID")) : 65536;
+    // z halves (8 tasks per unit) when this GPU shares the volume with 3 or more others: DESIGN section 4
+    const int zs = getenv("HV_TSDF_SWEEP_ZS") ? atoi(getenv("HV_TSDF_SWEEP_ZS")) : (v->owner_world >= 4 ? 2 : 1);
+    HvFusedArgs K;
+    memset(&K, 0, sizeof(K));
+    K.table = v->table;
+    K.pool = (char *)v->pool;
+    K.S = S;
+    K.A = A;
+    // (publish = false: a claim pass whose claims are verified before anything else happens - a published block count that ran past
+    // the pool would be taken for the state to roll back to)
+    K.status = publish ? v->d_status : nullptr;
+    K.status_seq = publish ? hv_next_status_seq(v) : 0;
+    K.general = general;
+    K.xcd_g = xcd_g;
+    K.lead = getenv("HV_TSDF_FUSED_LEAD") ? atoi(getenv("HV_TSDF_FUSED_LEAD")) : 512; // sweep items dealt first per XCD (512 = its wave slots at 4 / SIMD)
+    if (with_sweep || explicit_sweep) hv_profile_begin(v);
+    if (zs == 2)
+        hipLaunchKernelGGL(k_tsdf_fused<2>, dim3(grid), dim3(64), 0, v->stream, HV_FUSED_ARGS(K));
+    else
+        hipLaunchKernelGGL(k_tsdf_fused<1>, dim3(grid), dim3(64), 0, v->stream, HV_FUSED_ARGS(K));
+    if (explicit_sweep) {
+        hv_profile_end(v, S.n_frames);
+    } else if (with_sweep) {
+        hv_profile_end(v, v->pending.n_frames);
+        // the frame constants of the swept batch may be overwritten once this launch is done
+        HV_HIP(hipEventRecord(v->ev_swept[v->pending.ring], v->stream));
+        v->ev_swept_valid[v->pending.ring] = true;
+        v->pending.valid = false;
+    }
+    HV_HIP(hipGetLastError());
+    return HV_OK;
+}
+
+int hv_tsdf_flush(hv_volume *v) {
+    if (v == nullptr || !v->pending.valid) return HV_OK;
+    HV_HIP(hipSetDevice(v->device));
+    return tsdf_launch_fused(v, true, nullptr);
+}
+
+// One chunk (B <= 64 frames resident in HBM) of a multi-frame call in the fused form: its touch + pack pass goes out now, together
+// with the sweep of the batch before it; its own sweep is left pending.
+static int tsdf_fused_chunk(hv_volume *v, const char *d_depth, size_t depth_frame_bytes, const uint8_t *d_rgb, int B, int height, int width,
+                            const double *intr, const double *T_cw, double depth_scale, double depth_trunc, int depth_dtype, int host_set) {
+    const size_t npx = (size_t)height * width;
+    bool checked = false;
+    int rc = hv_capacity_gate(v, &checked); // (a pool that has to grow flushes the pending sweep first: hv_reserve_blocks)
+    if (rc != HV_OK) return rc;
+    rc = tsdf_fused_resources(v);
+    if (rc != HV_OK) return rc;
+    // frame constants: pinned ring slot -> device ring slot, uploaded on a stream of its own so that it does not queue behind the
+    // launch that is running (the host is usually several batches ahead of the GPU)
+    const int ri = v->params_idx;
+    v->params_idx = (ri + 1) & 3;
+    if (v->pinned_params[ri] == nullptr) {
+        HV_HIP(hipHostMalloc(&v->pinned_params[ri], sizeof(HvFrameParams) * HV_BATCH_MAX));
+        HV_HIP(hipEventCreateWithFlags(&v->params_ev[ri], hipEventDisableTiming));
+    } else {
+        HV_HIP(hipEventSynchronize(v->params_ev[ri]));
+    }
+    HvFrameParams *params = (HvFrameParams *)v->pinned_params[ri];
+    for (int f = 0; f < B; ++f) {
+        make_frame_params(v, height, width, intr, T_cw + 16 * (size_t)f, depth_scale, depth_trunc, depth_dtype, &params[f]);
+        v->frame_counter += 1;
+        params[f].frame_id = v->frame_counter;
+    }
+    int batch_stamp = v->frame_counter;
+    {
+        // the multiplier table of these intrinsics.  When it has to be (re)built, the pending sweep goes first: its records carry
+        // their own multipliers, but a re-allocation of the table synchronises the stream anyway
+        const float key[4] = {params[0].cx, params[0].cy, params[0].ffl_inv_x, params[0].ffl_inv_y};
+        if (!(v->mult_table != nullptr && v->mult_W == width && v->mult_H == height && memcmp(key, v->mult_key, sizeof(key)) == 0)) {
+            rc = hv_tsdf_flush(v);
+            if (rc != HV_OK) return rc;
+        }
+        rc = tsdf_multiplier_table(v, params[0]);
+        if (rc != HV_OK) return rc;
+    }
+    const int parity = v->batch_parity & 1; // (the fused form alternates between two sets)
+    v->batch_parity = parity ^ 1;
+    v->last_touch_parity = parity;
+    // this scratch set's records (its last reader, the sweep of two batches ago, was launched by the previous call; a
+    // re-allocation waits for the stream)
+    const size_t px_bytes = 12 * npx * (size_t)B;
+    void **bb = parity ? &v->batch_buf2 : &v->batch_buf;
+    size_t *bb_bytes = parity ? &v->batch_buf2_bytes : &v->batch_buf_bytes;
+    rc = hv_ensure_buffer(v, bb, bb_bytes, px_bytes + sizeof(HvFrameParams) * (size_t)B + 256); // (sized as the unfused form's: the forms may alternate)
+    if (rc != HV_OK) return rc;
+    HvFrameParams *d_params = (HvFrameParams *)v->params_ring + (size_t)ri * HV_BATCH_MAX;
+    if (v->ev_swept_valid[ri]) HV_HIP(hipStreamWaitEvent(v->stream_up, v->ev_swept[ri], 0));
+    {
+        const int n16 = (int)((sizeof(HvFrameParams) * (size_t)B + 15) / 16);
+        hipLaunchKernelGGL(k_upload_words, dim3(1), dim3(256), 0, v->stream_up, (const uint4 *)params, (uint4 *)d_params, n16);
+    }
+    HV_HIP(hipEventRecord(v->params_ev[ri], v->stream_up));
+    HV_HIP(hipStreamWaitEvent(v->stream, v->params_ev[ri], 0));
+    if (host_set >= 0) HV_HIP(hipStreamWaitEvent(v->stream, v->hs_dev_ready[host_set], 0)); // the frames have arrived
+    if (!v->pending.valid && (!v->touch_counters_clean || v->plan_lists_stale)) {
+        // (an online frame / a coherent batch left its list length behind; never while a sweep is pending - its list is live)
+        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, HV_CNT_TOUCH_SPAN_BYTES, v->stream));
+        v->touch_counters_clean = true;
+        v->plan_lists_stale = false;
+    }
+    HvFusedAux A;
+    memset(&A, 0, sizeof(A));
+    auto fill = [&]() {
+        A.mask = (unsigned long long *)v->touched_mask + (size_t)parity * (size_t)v->table_capacity;
+        A.stamp = v->touched_stamp;
+        A.list = v->touched_list + (size_t)parity * (size_t)v->cfg.max_blocks;
+        A.depth = d_depth;
+        A.rgb = d_rgb;
+        A.px = (uint2 *)*bb;
+        A.Ps = d_params;
+        A.mult = v->mult_table;
+        A.depth_stride = (int64_t)depth_frame_bytes;
+        A.n_frames = B;
+        A.parity = parity;
+        A.batch_stamp = batch_stamp;
+        A.touch_per_frame = hv_touch_patches(width, height, v->cfg.depth_sampling_stride);
+        A.pack_per_frame = (int)((npx + 1023) / 1024);
+    };
+    fill();
+    if (!checked) {
+        rc = tsdf_launch_fused(v, v->pending.valid, &A);
+        if (rc != HV_OK) return rc;
+    } else {
+        // checked mode (the pool's headroom is not known to cover this batch): nothing is fused before every unit of the batch has
+        // its pool slot.  The pending sweep goes first, then the touch + pack pass alone, verified; if some claims did not fit the
+        // pool has grown (tables rebuilt, stamps kept) and the pass runs again under a fresh stamp.
+        rc = hv_tsdf_flush(v);
+        if (rc != HV_OK) return rc;
+        for (int attempt = 0;; ++attempt) {
+            rc = tsdf_launch_fused(v, false, &A, false);
+            if (rc != HV_OK) return rc;
+            rc = hv_claims_fit(v);
+            if (rc == HV_OK) break;
+            if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
+            v->frame_counter += 1;
+            batch_stamp = v->frame_counter;
+            fill(); // the tables were rebuilt: the scratch set's arrays moved (their list counters were zeroed)
+        }
+    }
+    v->pending.valid = true;
+    v->pending.parity = parity;
+    v->pending.n_frames = B;
+    v->pending.ring = ri;
+    v->pending.px = *bb;
+    v->pending.params = d_params;
+    return HV_OK;
 }
 
 static int check_tsdf_args(hv_volume *v, const void *depth, const uint8_t *rgb, int H, int W,
@@ -2654,6 +3182,29 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
     bool chain_ok = v->pipe_armed && v->pipe_version == v->content_version; // nothing but batches since ev_presweep was recorded
     v->content_version += 1;
     const int BMAX = 64;
+    // Fused form (round 5, the default for the production sweep): one launch = the sweep of the previous batch + this batch's touch +
+    // pack pass (k_tsdf_fused); this batch's sweep stays pending until the next call or hv_tsdf_flush.  HV_TSDF_FUSED=0 and every
+    // A/B variant of the sweep (other forms, register caps, gather groups ...) take the unfused path below, which starts by flushing.
+    auto env_is = [](const char *name, int dflt) { return !getenv(name) || atoi(getenv(name)) == dflt; };
+    const bool fused = sweep_form == 4 && use_mult && rec12 && !coherent && pipeline_on && getenv("HV_TSDF_FUSED") && atoi(getenv("HV_TSDF_FUSED")) == 1 &&
+                       env_is("HV_TSDF_SWEEP_WPE", 4) && env_is("HV_TSDF_SWEEP_ANYSKIP", 2) && env_is("HV_TSDF_SWEEP_GV", 4) &&
+                       env_is("HV_TSDF_SWEEP_PIPE", 1) && env_is("HV_TSDF_BATCH_SPLIT", 4) && env_is("HV_TSDF_SWEEP_VCAP", 0) &&
+                       !(getenv("HV_TSDF_LIST") && strcmp(getenv("HV_TSDF_LIST"), "kernel") == 0);
+    if (fused) {
+        if (v->stream_aux) HV_HIP(hipStreamSynchronize(v->stream_aux)); // (a chain of the unfused form may still run its touch + pack launch there)
+        v->pipe_armed = false;
+        for (int f0 = 0; f0 < n_frames; f0 += BMAX) {
+            const int B = std::min(BMAX, n_frames - f0);
+            rc = tsdf_fused_chunk(v, (const char *)d_depth + npx * dsz * (size_t)f0, npx * dsz, (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, B, height, width,
+                                  intr, T_cw + 16 * (size_t)f0, depth_scale, depth_trunc, depth_dtype, host_set);
+            if (rc != HV_OK) return rc;
+        }
+        // (the touch + pack pass of every chunk - the only reader of the frames - is queued on the main stream by now)
+        if (host_set >= 0) return hv_stage_frames_consumed(v, host_set, v->stream);
+        return HV_OK;
+    }
+    rc = hv_tsdf_flush(v);
+    if (rc != HV_OK) return rc;
     for (int f0 = 0; f0 < n_frames; f0 += BMAX) {
         const int B = std::min(BMAX, n_frames - f0);
         // pool headroom (grows here when more than half is known to be used; see hv_capacity_gate)
@@ -2678,6 +3229,10 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
                     mask[bit >> 5] |= 1u << (bit & 31);
                 }
                 HV_HIP(hipExtStreamCreateWithCUMask(&v->stream_aux, 8, mask));
+            } else if (getenv("HV_TSDF_AUX_PRIO") && atoi(getenv("HV_TSDF_AUX_PRIO")) != 0) {
+                int lo_p = 0, hi_p = 0; // (A/B, round 5: with one-wave workgroups a priority has something to act on)
+                HV_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+                HV_HIP(hipStreamCreateWithPriority(&v->stream_aux, hipStreamNonBlocking, hi_p));
             } else
             HV_HIP(hipStreamCreateWithFlags(&v->stream_aux, hipStreamNonBlocking)); // (queue priority high / low against the sweep's: measured, no effect)
             HV_HIP(hipEventCreateWithFlags(&v->ev_prep, hipEventDisableTiming));
@@ -2686,11 +3241,30 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
         hipStream_t ps = overlap ? v->stream_aux : v->stream; // where this batch's touch + pack launch goes
         bool overlap_this = overlap;
         // scratch set
-        const int parity = list_in_touch ? v->batch_parity : 0;
-        if (list_in_touch) v->batch_parity ^= 1;
+        // Three sets (round 5, HV_TSDF_SETS=3): with two, the touch + pack launch of batch k + 1 had to wait for the finish
+        // of batch k - 1 and ran beside sweep k, where it only gets wave slots as sweep waves retire - it ended ~37 us AFTER that
+        // sweep, and sweep k + 1 waited for it (profiles/r04/pipeline_timeline.txt).  With three, batch k + 2's launch is already
+        // queued behind it on the aux stream and soaks up the same tail, so that by the time sweep k + 1 could start, ITS touch + pack
+        // launch (and the list sort) finished a whole sweep ago: consecutive sweeps are separated by the finish launch only.
+        // Measured (profiles/r05/pipeline_experiments.md): no gain - the aux stream is in order and EVERY touch + pack launch is starved
+        // of wave slots for the length of a sweep, so it cannot get further ahead than one batch however many sets there are.  Default 2.
+        const int n_sets = (!coherent && getenv("HV_TSDF_SETS") && atoi(getenv("HV_TSDF_SETS")) == 3) ? 3 : 2; // (the per-batch plan keeps two sets)
+        const int parity = list_in_touch ? v->batch_parity % n_sets : 0;
+        if (list_in_touch) v->batch_parity = (parity + 1) % n_sets;
         int32_t *d_list = v->touched_list + (size_t)parity * (size_t)v->cfg.max_blocks;
         unsigned long long *d_mask_rw = (unsigned long long *)v->touched_mask + (size_t)parity * (size_t)v->table_capacity;
-        if (overlap) HV_HIP(hipStreamWaitEvent(v->stream_aux, v->ev_presweep, 0));
+        if (v->ev_set_free[0] == nullptr)
+            for (int i = 0; i < HV_TSDF_SETS; ++i) HV_HIP(hipEventCreateWithFlags(&v->ev_set_free[i], hipEventDisableTiming));
+        if (overlap) {
+            // what this batch's touch + pack launch waits for: the batch that last used its scratch set is swept and finished.  Two
+            // sets: ev_presweep = the main stream up to just before the previous sweep.  Three sets: ev_presweep = the main stream
+            // where this chain of batches began (everything older - a reset, an extraction ... - lives on the main stream) + the
+            // set's own "free" event when a batch of this chain has used the set.
+            HV_HIP(hipStreamWaitEvent(v->stream_aux, v->ev_presweep, 0));
+            if (n_sets != 2 && v->ev_set_free_valid[parity]) HV_HIP(hipStreamWaitEvent(v->stream_aux, v->ev_set_free[parity], 0));
+        } else {
+            for (int i = 0; i < HV_TSDF_SETS; ++i) v->ev_set_free_valid[i] = false; // a chain (re)starts with this batch
+        }
         if (host_set >= 0) HV_HIP(hipStreamWaitEvent(ps, v->hs_dev_ready[host_set], 0)); // the frames have arrived
         // per-frame constants go through a ring of 4 pinned host buffers: the H2D copy is truly
         // asynchronous and a slot is only rewritten after the copy that last used it has completed,
@@ -2733,8 +3307,9 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
         }
         // scratch: [B frame records of npx uint2][B HvFrameParams]
         const size_t px_bytes = rec_bytes * npx * (size_t)B;
-        void **bb = parity ? &v->batch_buf2 : &v->batch_buf;
-        size_t *bb_bytes = parity ? &v->batch_buf2_bytes : &v->batch_buf_bytes;
+        void **bb = parity == 2 ? &v->batch_buf3 : parity ? &v->batch_buf2 : &v->batch_buf;
+        size_t *bb_bytes = parity == 2 ? &v->batch_buf3_bytes : parity ? &v->batch_buf2_bytes : &v->batch_buf_bytes;
+        if (*bb_bytes < px_bytes + sizeof(HvFrameParams) * (size_t)B + 256 && v->stream_aux) HV_HIP(hipStreamSynchronize(v->stream_aux)); // (a launch two batches back may still write the old buffer)
         rc = hv_ensure_buffer(v, bb, bb_bytes, px_bytes + sizeof(HvFrameParams) * (size_t)B + 256); // (re-allocation drains the main stream, and with it every batch whose touch pass it waited for)
         if (rc != HV_OK) return rc;
         uint2 *d_px = (uint2 *)*bb;
@@ -2750,13 +3325,16 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
         HV_HIP(hipEventRecord(v->params_ev[ri], ps));
         // the touched-list counters are zero after hv_reset and k_tsdf_batch_finish; an online frame leaves its own
         // parity's count behind
-        const int n_prep_blocks = (int)((npx + 1023) / 1024); // 4 pixels per thread
-        const int n_touch_blocks = (hv_touch_patches(width, height, v->cfg.depth_sampling_stride) + 3) / 4;
+        // HV_TSDF_AUX_W64=1 (A/B): one-wave workgroups - a 4-wave workgroup of this launch only fits a CU when four sweep waves retire
+        // close together, a one-wave workgroup fits wherever ONE sweep wave retires
+        const int aux_threads = (!coherent && getenv("HV_TSDF_AUX_W64") && atoi(getenv("HV_TSDF_AUX_W64")) != 0) ? 64 : 256;
+        const int n_prep_blocks = (int)((npx + 4 * aux_threads - 1) / (4 * aux_threads)); // 4 pixels per thread
+        const int n_touch_blocks = (hv_touch_patches(width, height, v->cfg.depth_sampling_stride) + aux_threads / 64 - 1) / (aux_threads / 64);
         for (int attempt = 0;; ++attempt) {
             // (coherent form: the plan restarts its own set's list - k_tsdf_touch_plan - and a memset here, on the main stream, could land
             // on a list the aux stream is already filling)
             if (!coherent) {
-                if (!v->touch_counters_clean) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream)); // (never while a chain runs: only an online frame or an aborted claim leaves them dirty)
+                if (!v->touch_counters_clean) HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, HV_CNT_TOUCH_SPAN_BYTES, v->stream)); // (never while a chain runs: only an online frame or an aborted claim leaves them dirty)
                 v->touch_counters_clean = true;
             }
             if (coherent) {
@@ -2781,7 +3359,7 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
                                    n_prep_blocks, 0, B, parity, rec12 ? d_mult : nullptr, pack_all ? nullptr : (const int4 *)plan.box, plan.hist,
                                    v->d_status, hv_next_status_seq(v));
             } else
-            hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3((n_prep_blocks + n_touch_blocks) * B), dim3(256), 0, ps,
+            hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3((n_prep_blocks + n_touch_blocks) * B), dim3(aux_threads), 0, ps,
                                v->table, v->touched_stamp, d_mask_rw, list_in_touch ? d_list : nullptr,
                                batch_stamp, (const char *)d_depth + npx * dsz * (size_t)f0, (int64_t)(npx * dsz),
                                (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks, n_touch_blocks, B, parity,
@@ -2804,19 +3382,53 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
             hipLaunchKernelGGL(k_tsdf_batch_list, dim3((unsigned)((v->cfg.max_blocks + 255) / 256)), dim3(256), 0, v->stream, v->table,
                                (const int32_t *)v->touched_stamp, batch_stamp, d_list);
         }
+        // HV_TSDF_LPT=1: the sweep (and the finish) read the list sorted by decreasing work (k_tsdf_list_by_work), queued behind the
+        // touch pass on its stream
+        if (list_in_touch && !coherent && getenv("HV_TSDF_LPT") && atoi(getenv("HV_TSDF_LPT")) != 0) {
+            const size_t want_sorted = sizeof(int32_t) * HV_TSDF_SETS * (size_t)v->cfg.max_blocks;
+            if (v->list_sorted_bytes < want_sorted && v->stream_aux) HV_HIP(hipStreamSynchronize(v->stream_aux)); // (a sort may still write the old array)
+            rc = hv_ensure_buffer(v, &v->list_sorted, &v->list_sorted_bytes, want_sorted);
+            if (rc != HV_OK) return rc;
+            int32_t *d_sorted = (int32_t *)v->list_sorted + (size_t)parity * (size_t)v->cfg.max_blocks;
+            hipLaunchKernelGGL(k_tsdf_list_by_work, dim3(1), dim3(1024), 0, ps, v->table, (const int32_t *)d_list, (const unsigned long long *)d_mask_rw,
+                               d_sorted, parity);
+            d_list = d_sorted;
+        }
         // What the NEXT batch's touch + pack launch waits for: everything the main stream holds up to here, i.e. the finish of the
         // batch that last used the next batch's scratch set.  Recorded BEFORE the main stream waits for this batch's own touch + pack
         // launch (round 4; HV_TSDF_PRESWEEP_LATE=1: after it, as rounds 2-3 did): the aux stream is in order, so the next launch
         // follows this batch's there anyway, and with the late form every touch + pack launch also waited for the cross-queue
         // hand-off into the sweep before it (~23 us + the upload: profiles/r04/rank8_timeline.txt, the critical loop of a 1/8 share).
         const bool presweep_late = getenv("HV_TSDF_PRESWEEP_LATE") && atoi(getenv("HV_TSDF_PRESWEEP_LATE")) != 0;
-        if (!presweep_late) HV_HIP(hipEventRecord(v->ev_presweep, v->stream));
+        if (!presweep_late && (n_sets == 2 || !overlap)) HV_HIP(hipEventRecord(v->ev_presweep, v->stream));
         if (overlap_this) {
             HV_HIP(hipEventRecord(v->ev_prep, v->stream_aux));
             HV_HIP(hipStreamWaitEvent(v->stream, v->ev_prep, 0));
         }
         if (presweep_late) HV_HIP(hipEventRecord(v->ev_presweep, v->stream));
         chain_ok = true;                                   // (the next chunk of this call may follow this one directly)
+        // HV_TSDF_FINISH=epilogue (round 5): the production sweep is launched through k_tsdf_fused without a touch + pack part - the same
+        // sweep, whose epilogue does what k_tsdf_batch_finish did (the unit's last part clears its frame mask, the launch's last
+        // item zeroes the list counter and publishes the pool status): one launch and one dependent-launch gap less per batch
+        const bool epilogue_sweep = d_mult && sweep_form == 4 && rec12 && !coherent && list_in_touch && getenv("HV_TSDF_FINISH") &&
+                                    strcmp(getenv("HV_TSDF_FINISH"), "epilogue") == 0 && env_is("HV_TSDF_SWEEP_WPE", 4) &&
+                                    env_is("HV_TSDF_SWEEP_ANYSKIP", 2) && env_is("HV_TSDF_SWEEP_GV", 4) && env_is("HV_TSDF_SWEEP_PIPE", 1) &&
+                                    env_is("HV_TSDF_BATCH_SPLIT", 4) && env_is("HV_TSDF_SWEEP_VCAP", 0);
+        if (epilogue_sweep) {
+            HvFusedSweep ES;
+            memset(&ES, 0, sizeof(ES));
+            ES.list = d_list;
+            ES.mask = d_mask_rw;
+            ES.px = d_px;
+            ES.Ps = d_params;
+            ES.n_frames = B;
+            ES.parity = parity;
+            rc = tsdf_launch_fused(v, false, nullptr, true, &ES);
+            if (rc != HV_OK) return rc;
+            HV_HIP(hipEventRecord(v->ev_set_free[parity], v->stream));
+            v->ev_set_free_valid[parity] = true;
+            continue;
+        }
         hv_profile_begin(v);
         const int sweep_zh = getenv("HV_TSDF_SWEEP_ZH") ? atoi(getenv("HV_TSDF_SWEEP_ZH")) : 4;
         // workgroups per unit (2 / 4 / 8).  Second form: 8 (two waves per workgroup; 32.7 k frames/s against 31.6 k at 4 and
@@ -2945,6 +3557,8 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
         else
             v->plan_lists_stale = true; // the sets' list counters keep their batches' sizes until their next plan: an online frame clears them first
         HV_HIP(hipGetLastError());
+        HV_HIP(hipEventRecord(v->ev_set_free[parity], v->stream));
+        v->ev_set_free_valid[parity] = true;
     }
     v->pipe_armed = true;
     v->pipe_version = v->content_version;
@@ -2975,6 +3589,7 @@ int hv_tsdf_integrate_frames(hv_volume *v, const void *const *depth_frames, int3
 }
 
 int hv_tsdf_set_tile(hv_volume *v, int32_t u0, int32_t v0, int32_t u1, int32_t v1) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_tsdf_set_tile: null volume");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_set_tile: volume is not in TSDF mode");
     HV_REQUIRE((u0 == 0 && v0 == 0 && u1 == 0 && v1 == 0) || (u0 >= 0 && v0 >= 0 && u1 > u0 && v1 > v0), HV_ERR_INVALID,
@@ -2987,6 +3602,7 @@ int hv_tsdf_set_tile(hv_volume *v, int32_t u0, int32_t v0, int32_t u1, int32_t v
 }
 
 int hv_tsdf_set_sharding(hv_volume *v, int32_t mode) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_tsdf_set_sharding: null volume");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_set_sharding: volume is not in TSDF mode");
     HV_REQUIRE(mode == 0 || mode == 1, HV_ERR_INVALID, "hv_tsdf_set_sharding: mode must be 0 (hash) or 1 (image-coherent)");
@@ -2995,7 +3611,7 @@ int hv_tsdf_set_sharding(hv_volume *v, int32_t mode) {
         HV_HIP(hipSetDevice(v->device));
         if (v->stream_aux) HV_HIP(hipStreamSynchronize(v->stream_aux));
         HV_HIP(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * 2 * v->table_capacity, v->stream));
-        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, 2 * sizeof(int32_t), v->stream));
+        HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_TOUCH0], 0, HV_CNT_TOUCH_SPAN_BYTES, v->stream));
         HV_HIP(hipStreamSynchronize(v->stream));
         v->pipe_armed = false;
     }
@@ -3004,6 +3620,7 @@ int hv_tsdf_set_sharding(hv_volume *v, int32_t mode) {
 }
 
 int hv_tsdf_set_color_order(hv_volume *v, int32_t bgr) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_tsdf_set_color_order: null volume");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_set_color_order: volume is not in TSDF mode");
     v->color_bgr = bgr ? 1 : 0;
@@ -3011,6 +3628,7 @@ int hv_tsdf_set_color_order(hv_volume *v, int32_t bgr) {
 }
 
 int hv_tsdf_set_owner(hv_volume *v, int32_t rank, int32_t world_size) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_tsdf_set_owner: null volume");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_set_owner: volume is not in TSDF mode");
     HV_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, HV_ERR_INVALID, "hv_tsdf_set_owner: bad rank/world");
@@ -3020,6 +3638,7 @@ int hv_tsdf_set_owner(hv_volume *v, int32_t rank, int32_t world_size) {
 }
 
 int hv_tsdf_dump(hv_volume *v, int32_t *keys, float *tsdf, float *weight, double *color, int64_t *n_units) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr && n_units != nullptr, HV_ERR_INVALID, "hv_tsdf_dump: null argument");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_dump: volume is not in TSDF mode");
     int64_t nb = 0;
@@ -3068,11 +3687,12 @@ int hv_tsdf_dump(hv_volume *v, int32_t *keys, float *tsdf, float *weight, double
 }
 
 int hv_tsdf_touched(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_tsdf_touched: null argument");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_touched: volume is not in TSDF mode");
     int rc = hv_read_counters(v);
     if (rc != HV_OK) return rc;
-    int64_t nt = v->h_counters[HV_CNT_TOUCH0 + v->last_touch_parity];
+    int64_t nt = v->h_counters[HV_CNT_TOUCH(v->last_touch_parity)];
     if (nt > v->cfg.max_blocks) nt = v->cfg.max_blocks;
     *n = nt;
     if (keys == nullptr || nt == 0) return HV_OK;
@@ -3089,6 +3709,7 @@ int hv_tsdf_touched(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n) {
 }
 
 int hv_tsdf_unit_keys(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_tsdf_unit_keys: null argument");
     int64_t nb = 0;
     int rc = hv_num_blocks(v, &nb);
@@ -3103,6 +3724,7 @@ int hv_tsdf_unit_keys(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n) {
 }
 
 int hv_tsdf_export_numerators(hv_volume *v, const int32_t *keys, int64_t k, float *payload, int32_t loc) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr && (k == 0 || (keys != nullptr && payload != nullptr)), HV_ERR_INVALID,
                "hv_tsdf_export_numerators: null argument");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_export_numerators: not a TSDF volume");
@@ -3131,6 +3753,7 @@ int hv_tsdf_export_numerators(hv_volume *v, const int32_t *keys, int64_t k, floa
 }
 
 int hv_tsdf_import_numerators(hv_volume *v, const int32_t *keys, int64_t k, const float *payload, int32_t loc) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr && (k == 0 || (keys != nullptr && payload != nullptr)), HV_ERR_INVALID,
                "hv_tsdf_import_numerators: null argument");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_import_numerators: not a TSDF volume");
@@ -3168,6 +3791,7 @@ int hv_tsdf_import_numerators(hv_volume *v, const int32_t *keys, int64_t k, cons
 // the two collectives (all-gather of key lists, all-reduce of the dense buffer) with whatever transport it has -
 // torch.distributed over RCCL in pyslam_amd/distributed.py ----
 int hv_tsdf_dirty_keys(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_tsdf_dirty_keys: null argument");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_dirty_keys: not a TSDF volume");
     HV_HIP(hipSetDevice(v->device));
@@ -3197,6 +3821,7 @@ int hv_tsdf_dirty_keys(hv_volume *v, int32_t *keys, int64_t cap, int64_t *n) {
 }
 
 int hv_tsdf_mark_merged(hv_volume *v) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_tsdf_mark_merged: null volume");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_mark_merged: not a TSDF volume");
     v->merge_stamp = v->frame_counter;
@@ -3314,6 +3939,7 @@ int hv_merge_halo_pack(hv_volume *v, const int32_t *shared_keys, int64_t k, floa
 
 int hv_merge_halo_unpack(hv_volume *v, const int32_t *shared_keys, int64_t k, const float *payload, const uint8_t *action,
                          int32_t loc) {
+    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr && (k == 0 || (shared_keys != nullptr && payload != nullptr && action != nullptr)), HV_ERR_INVALID,
                "hv_merge_halo_unpack: null argument");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_merge_halo_unpack: not a TSDF volume");
