@@ -235,6 +235,12 @@ int hv_assoc_vote(hv_volume *v, const float *intr_f32, int32_t width, int32_t he
                   float depth_threshold, int32_t do_carving, int32_t loc);
 int hv_assoc_pairs_fetch(hv_volume *v, uint64_t *pair_keys, int32_t *pair_counts, int64_t cap, int64_t *n_pairs);
 int hv_assoc_pairs_set(hv_volume *v, const uint64_t *pair_keys, const int32_t *pair_counts, int64_t n_pairs);
+/* Multi-GPU exchange with the pair lists staying in device memory (no host round trip per keyframe): d_msg / d_msgs are DEVICE
+ * buffers of the caller (torch tensors), int64 words: one GPU's message = [n, keys[cap], votes[cap]] (1 + 2 cap words, cap <= 4096);
+ * hv_assoc_pairs_import takes `world` messages back to back - the output of an all-gather - and adds equal pairs up.  Both are
+ * queued on the volume's stream and return at once. */
+int hv_assoc_pairs_export(hv_volume *v, int64_t *d_msg, int64_t cap);
+int hv_assoc_pairs_import(hv_volume *v, const int64_t *d_msgs, int32_t world, int64_t cap);
 int hv_assoc_decide(hv_volume *v, float min_vote_ratio, int32_t min_votes);
 int hv_assoc_map_fetch(hv_volume *v, int32_t *map_inst, int32_t *map_obj, int64_t cap, int64_t *n_map);
 int hv_remap_instance_ids_last(hv_volume *v, const int32_t *instance_ids, int32_t height, int32_t width, int32_t *out, int32_t loc);

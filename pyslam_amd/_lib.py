@@ -84,6 +84,8 @@ SIGNATURES = {
     "hv_assoc_vote": (_i32, [_vp, _vp, _i32, _i32, _vp, _f32, _f32, _vp, _vp, _vp, _f32, _i32, _i32]),
     "hv_assoc_pairs_fetch": (_i32, [_vp, _vp, _vp, _i64, _pi64]),
     "hv_assoc_pairs_set": (_i32, [_vp, _vp, _vp, _i64]),
+    "hv_assoc_pairs_export": (_i32, [_vp, _vp, _i64]),
+    "hv_assoc_pairs_import": (_i32, [_vp, _vp, _i32, _i64]),
     "hv_assoc_decide": (_i32, [_vp, _f32, _i32]),
     "hv_assoc_map_fetch": (_i32, [_vp, _vp, _vp, _i64, _pi64]),
     "hv_remap_instance_ids_last": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32]),

@@ -335,6 +335,36 @@ __global__ __launch_bounds__(256) void k_sem_assoc_compact(HvTable table, unsign
     }
 }
 
+// Multi-GPU, device-resident exchange of the pair lists (hv_assoc_pairs_export / _import).  Message of one GPU, int64 words:
+// [0] = number of pairs n (<= cap), [1 .. cap] = keys, [1 + cap .. 2 cap] = votes.
+__global__ __launch_bounds__(256) void k_assoc_pairs_export(HvTable table, const unsigned long long *__restrict__ ckeys,
+                                                             const int32_t *__restrict__ ccounts, long long *__restrict__ msg, int cap,
+                                                             int32_t *__restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_all = table.counters[HV_CNT_OUT];
+    const int n = min(n_all, cap);
+    if (i == 0) {
+        msg[0] = n;
+        if (n_all > cap) atomicOr(flags, 1); // HV_ASSOC_TOO_MANY_PAIRS: latched by the decide stage's last kernel
+    }
+    if (i < n) {
+        msg[1 + i] = (long long)ckeys[i];
+        msg[1 + cap + i] = ccounts[i];
+    }
+}
+
+// every GPU's pairs into the (empty) vote table: equal (instance, object) pairs of different GPUs - and the image markers every GPU
+// contributes - add up to ONE pair, so that the merged list is as long as a single GPU's would be
+__global__ __launch_bounds__(256) void k_assoc_pairs_import(HvTable table, const long long *__restrict__ msgs, int world, int cap,
+                                                             unsigned long long *__restrict__ vkeys, int32_t *__restrict__ vcounts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (r >= world) return;
+    const long long *msg = msgs + (size_t)r * (1 + 2 * (size_t)cap);
+    const int n = (int)min((long long)cap, max(0ll, msg[0]));
+    if (i < n) vote_add(vkeys, vcounts, &table.counters[HV_CNT_OUT2], (uint64_t)msg[1 + i], (int32_t)msg[1 + cap + i]);
+}
+
 __device__ __forceinline__ int32_t map_lookup(const int32_t *__restrict__ map_inst, const int32_t *__restrict__ map_obj,
                                               int32_t n_map, int32_t inst, int32_t missing) {
     int lo = 0, hi = n_map - 1;
@@ -488,7 +518,8 @@ __global__ __launch_bounds__(256) void k_sem_assoc_apply(HvTable table, VOX *__r
         // the device flow (assign -> remap_instance_ids -> integrate) never fetches the map, and the next vote / fold clear
         // the shared counters - so what overflowed in THIS association is folded into its flags word here and latched into the pinned
         // status word, which the next call's gate reads without a synchronisation
-        int32_t f = *flags;
+        int32_t f = *flags | flags[1]; // flags[1]: what the stages before the rules kernel found (hv_assoc_pairs_export)
+        flags[1] = 0;
         if (table.counters[HV_CNT_OUT2] != 0) f |= HV_ASSOC_VOTE_TABLE_FULL;
         if (table.counters[HV_CNT_AUX] > pending_cap) f |= HV_ASSOC_PENDING_FULL;
         *flags = f;
@@ -932,7 +963,7 @@ int hv_remap_instance_ids(hv_volume *v, const int32_t *instance_ids, int32_t hei
 namespace {
 struct AssocScratch {
     unsigned long long *vkeys, *ckeys;
-    int32_t *vcounts, *ccounts, *map_inst, *map_obj, *n_map, *flags;
+    int32_t *vcounts, *ccounts, *map_inst, *map_obj, *n_map, *flags, *flags_vote;
     int2 *pending;
     int64_t pending_cap;
 };
@@ -960,6 +991,7 @@ int assoc_scratch(hv_volume *v, AssocScratch *S) {
     S->map_obj = S->map_inst + HV_VOTE_CAP;
     S->n_map = (int32_t *)(sb + off_misc);
     S->flags = S->n_map + 1;
+    S->flags_vote = S->n_map + 2; // set by stages before the rules kernel (which writes `flags` afresh), folded in by k_sem_assoc_apply
     S->pending = (int2 *)(sb + off_pending);
     return HV_OK;
 }
@@ -1087,6 +1119,40 @@ int hv_assoc_pairs_set(hv_volume *v, const uint64_t *pair_keys, const int32_t *p
     }
     HV_HIP(hipMemcpyAsync(&v->table.counters[HV_CNT_OUT], &n32, sizeof(int32_t), hipMemcpyHostToDevice, v->stream));
     HV_HIP(hipStreamSynchronize(v->stream)); // the arguments are host memory
+    return HV_OK;
+}
+
+// The same exchange with the lists staying in device memory (round 5; the host forms above cost two synchronisations and four
+// copies per keyframe, which the single-GPU flow no longer has): export this GPU's pairs as a fixed-size message into a device
+// buffer of the caller (int64 [1 + 2 cap]), all-gather the messages (RCCL, on the device), import all of them.  Asynchronous on the
+// volume's stream.  Equal pairs of different GPUs are added up on the way in (the vote table de-duplicates), so the merged list is
+// no longer than a single GPU's - an 8-GPU keyframe cannot overflow the decide stage by repetition.
+int hv_assoc_pairs_export(hv_volume *v, int64_t *d_msg, int64_t cap) {
+    HV_REQUIRE(v != nullptr && d_msg != nullptr && cap > 0 && cap <= HV_RULES_MAX, HV_ERR_INVALID, "hv_assoc_pairs_export: bad argument (cap <= %d)", HV_RULES_MAX);
+    HV_REQUIRE(v->assoc_state >= 1, HV_ERR_INVALID, "hv_assoc_pairs_export: call hv_assoc_vote first");
+    HV_HIP(hipSetDevice(v->device));
+    AssocScratch S;
+    int rc = assoc_scratch(v, &S);
+    if (rc != HV_OK) return rc;
+    hipLaunchKernelGGL(k_assoc_pairs_export, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, v->stream, v->table, S.ckeys, S.ccounts,
+                       (long long *)d_msg, (int)cap, S.flags_vote);
+    HV_HIP(hipGetLastError());
+    return HV_OK;
+}
+
+int hv_assoc_pairs_import(hv_volume *v, const int64_t *d_msgs, int32_t world, int64_t cap) {
+    HV_REQUIRE(v != nullptr && d_msgs != nullptr && world > 0 && cap > 0 && cap <= HV_RULES_MAX, HV_ERR_INVALID, "hv_assoc_pairs_import: bad argument");
+    HV_REQUIRE(v->assoc_state >= 1, HV_ERR_INVALID, "hv_assoc_pairs_import: call hv_assoc_vote first");
+    HV_HIP(hipSetDevice(v->device));
+    AssocScratch S;
+    int rc = assoc_scratch(v, &S);
+    if (rc != HV_OK) return rc;
+    // (the vote table is empty: the vote stage's compaction clears what it reads)
+    HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
+    hipLaunchKernelGGL(k_assoc_pairs_import, dim3((unsigned)((cap + 255) / 256), (unsigned)world), dim3(256), 0, v->stream, v->table,
+                       (const long long *)d_msgs, (int)world, (int)cap, S.vkeys, S.vcounts);
+    hipLaunchKernelGGL(k_sem_assoc_compact, dim3(HV_VOTE_CAP / 256), dim3(256), 0, v->stream, v->table, S.vkeys, S.vcounts, S.ckeys, S.ccounts);
+    HV_HIP(hipGetLastError());
     return HV_OK;
 }
 

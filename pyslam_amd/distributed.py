@@ -62,13 +62,19 @@ class ShardedTSDF:
     BUCKET_BYTES = 64 << 20
 
     def __init__(self, voxel_length, sdf_trunc, width, height, device=0, max_blocks=None, rank=0, world_size=1,
-                 process_group=None, volume=None, group=None, sharding="owner"):
+                 process_group=None, volume=None, group=None, sharding="owner", force_collectives=False):
+        """force_collectives: run every collective (and the pack / reduce / unpack around it) even with world_size == 1 - RCCL
+        accepts a one-rank group, so the `nccl` branches (CUDA key buffers, CUDA payloads into export_numerators / halo_unpack,
+        the ordering of RCCL's stream against the volume's) can be executed on a one-GPU box (they had never run).
+        With one rank merge_halo() has no shared unit to find: every dirty unit is then taken through pack -> all-reduce -> unpack
+        as its own keeper, which leaves the volume as it was (up to the export / import round trip)."""
         assert sharding in ("owner", "tile", "coherent")
         self.rank, self.world_size = int(rank), int(world_size)
         self.width, self.height = int(width), int(height)
         self.group = group
         self.sharding = sharding
-        self.distributed = self.world_size > 1
+        self.force_collectives = bool(force_collectives)
+        self.distributed = self.world_size > 1 or self.force_collectives
         if volume is None:
             from .volumetric import ScalableTSDFVolume
 
@@ -76,7 +82,7 @@ class ShardedTSDF:
                                         max_points=max(width * height, 1 << 16))
         self.volume = volume
         self.tile = tile_bounds(self.rank, self.world_size, self.width, self.height)
-        if self.distributed:
+        if self.world_size > 1:
             if sharding == "tile":
                 self.volume.set_tile(*self.tile)
             elif sharding == "coherent":
@@ -93,17 +99,21 @@ class ShardedTSDF:
 
     # -- merge -----------------------------------------------------------------------------------
     def _gather_keys(self, keys, dist, torch, dev):
+        """All ranks' key lists ([n_i, 3] int32) -> list of host arrays.  The plan that consumes them is host code
+        (hv_merge_halo_plan_held), so this is where the keys are meant to end; over RCCL they make ONE device round trip:
+        counts (one all-gather), then one [world, cap, 3] buffer gathered in place and downloaded once."""
         n_local = torch.tensor([keys.shape[0]], dtype=torch.int64, device=dev)
-        counts = [torch.zeros_like(n_local) for _ in range(self.world_size)]
-        dist.all_gather(counts, n_local, group=self.group)
-        counts = [int(c.item()) for c in counts]
+        counts_t = torch.zeros(self.world_size, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(counts_t, n_local, group=self.group)
+        counts = [int(c) for c in counts_t.cpu().tolist()]
         cap = max(max(counts), 1)
         buf = torch.zeros((cap, 3), dtype=torch.int32, device=dev)
         if keys.shape[0]:
-            buf[: keys.shape[0]] = torch.from_numpy(np.ascontiguousarray(keys)).to(dev)
-        gathered = [torch.zeros_like(buf) for _ in range(self.world_size)]
-        dist.all_gather(gathered, buf, group=self.group)
-        return [g[:c].cpu().numpy() for g, c in zip(gathered, counts)]
+            buf[: keys.shape[0]].copy_(torch.from_numpy(np.ascontiguousarray(keys)), non_blocking=False)
+        gathered = torch.empty((self.world_size, cap, 3), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(gathered.view(-1), buf.view(-1), group=self.group)
+        host = gathered.cpu().numpy()
+        return [host[r, :c] for r, c in enumerate(counts)]
 
     def merge(self, root=0):
         """Sum-reduce all ranks' volumes into rank `root`; the other ranks are cleared.
@@ -179,6 +189,11 @@ class ShardedTSDF:
         if k:
             L.check(lib.hv_merge_halo_plan_held(L.ptr(dk), L.ptr(dc), L.ptr(hk), L.ptr(hc), self.world_size, self.rank, L.ptr(shared),
                                                 L.ptr(action), k, ctypes.byref(n)))
+        if self.force_collectives and self.world_size == 1 and len(mine):
+            # one rank has nothing to share: take its dirty units through pack -> all-reduce -> unpack as their own keeper (see __init__)
+            shared = np.ascontiguousarray(mine[np.lexsort((mine[:, 2], mine[:, 1], mine[:, 0]))])
+            k = len(shared)
+            action = np.ones(k, np.uint8)
         self.last_halo = {"shared_keys": shared, "action": action, "dirty": len(mine), "payload_bytes": 0}
         res3 = self.volume.res ** 3
         units_per_bucket = max(1, self.BUCKET_BYTES // (res3 * 5 * 4))
@@ -221,8 +236,9 @@ class ShardedVoxelGrid:
     (all-gather of the row counts, then of the padded rows).  The grid object is duck-typed (set_owner / integrate* / get_voxels),
     so the gather runs on CPU over gloo in tests/."""
 
-    def __init__(self, grid, rank=0, world_size=1, group=None):
+    def __init__(self, grid, rank=0, world_size=1, group=None, force_collectives=False):
         self.grid, self.rank, self.world_size, self.group = grid, int(rank), int(world_size), group
+        self.force_collectives = bool(force_collectives)  # run the all-gathers with one rank too (ShardedTSDF.__init__)
         if self.world_size > 1:
             self.grid.set_owner(self.rank, self.world_size)
 
@@ -236,7 +252,7 @@ class ShardedVoxelGrid:
         """-> (points [M,3] f32, colors [M,3] f32) of the whole distributed grid on `root`, None elsewhere."""
         v = self.grid.get_voxels(min_count, min_confidence)
         pts, cols = np.ascontiguousarray(v.points, np.float32), np.ascontiguousarray(v.colors, np.float32)
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force_collectives:
             return pts, cols
         import torch
         import torch.distributed as dist
@@ -270,15 +286,41 @@ class ShardedSemanticGrid:
     pairs) and so arrives at the same map and the same new object ids (the process-wide counters advance in lock step).
     The grid is duck-typed (set_owner / _pair_exchange / integrate* / get_voxels ...): the exchange runs on CPU over gloo in tests/."""
 
-    def __init__(self, grid, rank=0, world_size=1, group=None):
+    def __init__(self, grid, rank=0, world_size=1, group=None, force_collectives=False):
         self.grid, self.rank, self.world_size, self.group = grid, int(rank), int(world_size), group
+        self.force_collectives = bool(force_collectives)  # run the exchange with one rank too (ShardedTSDF.__init__)
         self.last_exchange = None
         if self.world_size > 1:
             self.grid.set_owner(self.rank, self.world_size)
-            self.grid._pair_exchange = self.all_gather_pairs
+        if self.world_size > 1 or self.force_collectives:
+            import torch.distributed as dist
+
+            if dist.is_initialized() and dist.get_backend(self.group) == "nccl":
+                self.grid._pair_exchange_device = self.all_gather_pairs_device
+            else:
+                self.grid._pair_exchange = self.all_gather_pairs
+
+    def all_gather_pairs_device(self, grid):
+        """RCCL form of the exchange: export -> all_gather_into_tensor -> import, the lists never leave the GPU and the host never
+        waits (round 4's form did device -> host -> device -> all-gather -> host -> device per keyframe).  One message per rank:
+        int64 [1 + 2 cap] = [n, keys, votes]; equal pairs of different ranks are added up on the way in."""
+        import torch
+        import torch.distributed as dist
+
+        dev = torch.device("cuda", torch.cuda.current_device())
+        words = 1 + 2 * grid.ASSOC_PAIRS_CAP
+        if getattr(self, "_msg", None) is None or self._msg.device != dev:
+            self._msg = torch.empty(words, dtype=torch.int64, device=dev)
+            self._msgs = torch.empty(words * self.world_size, dtype=torch.int64, device=dev)
+        grid.assoc_pairs_export(self._msg)
+        dist.all_gather_into_tensor(self._msgs, self._msg, group=self.group)  # (RCCL's stream is ordered against torch's current one)
+        grid.assoc_pairs_import(self._msgs, self.world_size)
+        self.last_exchange = {"sizes": None, "bytes": int(words * 8 * self.world_size), "device_resident": True}
 
     def all_gather_pairs(self, keys, counts):
-        """-> the ranks' (keys u64, votes i32) lists concatenated in rank order - identical on every rank."""
+        """-> the ranks' (keys u64, votes i32) lists merged - identical on every rank: equal pairs (the image's 'instance seen' markers
+        are contributed by every rank, and an object's voxels live on several) are added up, so the merged list is no longer than a
+        single GPU's would be and the decide stage's 4096-pair limit is not reached by repetition."""
         import torch
         import torch.distributed as dist
 
@@ -303,9 +345,12 @@ class ShardedSemanticGrid:
             g = g.cpu().numpy()
             ks.append(g[:m].view(np.uint64))
             cs.append(g[cap : cap + m].astype(np.int32))
-        out = np.concatenate(ks), np.concatenate(cs)
-        self.last_exchange = {"sizes": sizes, "bytes": int(2 * cap * 8 * self.world_size)}
-        return out
+        all_k, all_c = np.concatenate(ks), np.concatenate(cs)
+        uk, inv = np.unique(all_k, return_inverse=True)  # (sorted: the same order on every rank)
+        uc = np.zeros(len(uk), np.int64)
+        np.add.at(uc, inv, all_c.astype(np.int64))
+        self.last_exchange = {"sizes": sizes, "bytes": int(2 * cap * 8 * self.world_size), "merged": int(len(uk))}
+        return uk, uc.astype(np.int32)
 
     def __getattr__(self, name):  # integrate, integrate_rgbd, assign_object_ids_to_instance_ids, remap_instance_ids, get_voxels, ...
         return getattr(self.grid, name)
@@ -316,7 +361,7 @@ class ShardedSemanticGrid:
         rows = np.concatenate([np.asarray(v.points, np.float64), np.asarray(v.colors, np.float64), np.asarray(v.class_ids, np.float64)[:, None],
                                np.asarray(v.object_ids, np.float64)[:, None], np.asarray(v.confidences, np.float64)[:, None]], axis=1) \
             if len(v.points) else np.zeros((0, 9), np.float64)
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force_collectives:
             import torch
             import torch.distributed as dist
 

@@ -489,11 +489,30 @@ class _SemanticGridBase(_Volume):
         somebody reads it (remap_instance_ids on this volume uses it there)."""
         if not self.assoc_vote(camera_frustrum, class_ids_image, semantic_instances_image, depth_image, depth_threshold, do_carving):
             return {}
-        if self._pair_exchange is not None:
+        if self._pair_exchange_device is not None:
+            self._pair_exchange_device(self)  # RCCL: the lists never leave the device (hv_assoc_pairs_export / _import)
+        elif self._pair_exchange is not None:
             self.assoc_set_pairs(*self._pair_exchange(*self.assoc_pairs()))
         return self.assoc_decide(min_vote_ratio, min_votes)
 
     _pair_exchange = None  # multi-GPU: callable(keys u64[n], counts i32[n]) -> (keys, counts) of all ranks, concatenated (ShardedSemanticGrid)
+    _pair_exchange_device = None  # multi-GPU over RCCL: callable(grid) that runs assoc_pairs_export -> all-gather -> assoc_pairs_import
+    ASSOC_PAIRS_CAP = 4096  # pairs in one GPU's exchange message (HV_RULES_MAX)
+
+    def assoc_pairs_export(self, msg):
+        """This GPU's pair list of stage 1 into `msg`, a torch CUDA int64 tensor of 1 + 2 * ASSOC_PAIRS_CAP words ([n, keys, votes]);
+        queued on the volume's stream, ordered against torch's current stream - no host synchronisation."""
+        cap = (msg.numel() - 1) // 2
+        ts = self._torch_in(msg)
+        L.check(self._lib.hv_assoc_pairs_export(self._h, L.ptr(msg), cap))
+        self._torch_out(ts, msg.device)
+
+    def assoc_pairs_import(self, msgs, world):
+        """The ranks' messages back to back (the all-gather's output) become the pair list stage 2 decides on; equal pairs add up."""
+        cap = (msgs.numel() // int(world) - 1) // 2
+        ts = self._torch_in(msgs)
+        L.check(self._lib.hv_assoc_pairs_import(self._h, L.ptr(msgs), int(world), cap))
+        self._torch_out(ts, msgs.device)
 
     # -- the association in stages (hv_assoc_*): what a multi-GPU driver interleaves with its exchange ----------------------------
     def assoc_vote(self, camera_frustrum, class_ids_image, semantic_instances_image, depth_image=None, depth_threshold=0.1,

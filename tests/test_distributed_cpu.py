@@ -438,6 +438,7 @@ class _FakeSemanticGrid:
     def __init__(self, rank):
         self.rank, self.owner = rank, None
         self._pair_exchange = None
+        self._pair_exchange_device = None
 
     def set_owner(self, rank, world):
         self.owner = (rank, world)
@@ -484,15 +485,22 @@ def _sem_worker(rank, world, port, tmpdir):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_semantic_pair_lists_are_all_gathered_in_rank_order(tmp_path, world):
-    """The one collective of the semantic path: every rank ends up with the SAME concatenation of the ranks' (instance << 32 | object,
-    votes) lists, in rank order, bit for bit (negative object markers included), also when a rank has no pairs; get_voxels rows are
-    gathered on the root."""
+    """The one collective of the semantic path: every rank ends up with the SAME merged list of the ranks' (instance << 32 | object,
+    votes) pairs - equal pairs of different ranks added up (plain concatenation repeated the image's markers N times and
+    could overflow the decide stage on 8 ranks), sorted by key, bit for bit (negative object markers included), also when a rank has
+    no pairs; get_voxels rows are gathered on the root."""
     import torch.multiprocessing as mp
 
     port = 29500 + ((os.getpid() + 777 + world) % 2000)
     mp.spawn(_sem_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    want_k = np.concatenate([_FakeSemanticGrid(r).local_pairs()[0] for r in range(world)])
-    want_c = np.concatenate([_FakeSemanticGrid(r).local_pairs()[1] for r in range(world)])
+    cat_k = np.concatenate([_FakeSemanticGrid(r).local_pairs()[0] for r in range(world)])
+    cat_c = np.concatenate([_FakeSemanticGrid(r).local_pairs()[1] for r in range(world)])
+    merged = {}
+    for k, c in zip(cat_k.tolist(), cat_c.tolist()):
+        merged[k] = merged.get(k, 0) + c
+    want_k = np.array(sorted(merged), np.uint64)
+    want_c = np.array([merged[k] for k in sorted(merged)], np.int32)
+    assert want_c.sum() == cat_c.sum() and len(want_k) <= len(cat_k)
     for r in range(world):
         z = np.load(tmp_path / f"pairs{r}.npz")
         np.testing.assert_array_equal(z["keys"], want_k)
