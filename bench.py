@@ -186,21 +186,21 @@ def cpu_baseline_and_counts(s, depth, rgb, T, B, max_steps, budget_s, threads, w
     K = np.array(s.intrinsics, dtype=np.float64)
     n_res = len(depth)
     if threads <= 0:
-        # the OpenMP width that is actually fastest on this host (oversubscribing a 256-thread box is slower than
-        # 32 threads for ~4k independent units)
-        cores = os.cpu_count() or 1
-        best = (0.0, 1)
-        for cand in sorted({c for c in (1, 8, 32, 96, cores) if c <= cores}):
-            probe = oracle.PortTsdf(VOXEL, SDF_TRUNC, threads=cand)
-            probe.integrate(depth[0], rgb[0], K, T[0], 1.0, DEPTH_TRUNC)
-            t0 = time.perf_counter()
-            for i in range(1, 4):
-                probe.integrate(depth[i % n_res], rgb[i % n_res], K, T[i % n_res], 1.0, DEPTH_TRUNC)
-            fps = 3.0 / (time.perf_counter() - t0)
-            if fps > best[0]:
-                best = (fps, cand)
-            del probe
-        threads = best[1]
+        # ONE stated policy (a probe picked 8 threads on one box and 32 on another): every hardware thread
+        # the box has (os.cpu_count()), and the same restatement on ONE core beside it (`single_core`)
+        threads = os.cpu_count() or 1
+    single = None
+    if budget_s > 0:
+        one = oracle.PortTsdf(VOXEL, SDF_TRUNC, threads=1)
+        one.integrate(depth[0], rgb[0], K, T[0], 1.0, DEPTH_TRUNC)
+        t0 = time.perf_counter()
+        n1 = 0
+        while n1 < 16 and time.perf_counter() - t0 < 0.2 * budget_s:
+            i = (1 + n1) % n_res
+            one.integrate(depth[i], rgb[i], K, T[i], 1.0, DEPTH_TRUNC)
+            n1 += 1
+        single = {"value": round(n1 / (time.perf_counter() - t0), 3), "unit": "frames/s", "cores": 1, "frames": n1}
+        del one
     vol = oracle.PortTsdf(VOXEL, SDF_TRUNC, threads=threads)
     steps = []
     t_begin = time.perf_counter()
@@ -221,7 +221,7 @@ def cpu_baseline_and_counts(s, depth, rgb, T, B, max_steps, budget_s, threads, w
             break
     n = len(steps) * B
     return {"threads": threads, "fps": n / t_frames, "frames": n, "seconds": t_frames, "steps": steps,
-            "units": vol.num_units()}
+            "units": vol.num_units(), "single_core": single}
 
 
 def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_frames):
@@ -497,10 +497,13 @@ def main():
     ap.add_argument("--config", default="synthetic_640x480_5mm")
     ap.add_argument("--window", choices=["sliding", "replay"], default="sliding")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = pick the fastest OpenMP width on this host")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline; 0 = os.cpu_count() (the stated policy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the replay / online / extraction / voxel-grid legs (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group (and run every barrier / all-reduce / all-gather of the N > 1 line) with ONE rank: "
+                         "RCCL accepts a one-rank group, so the N > 1 code path of this file can be executed on a one-GPU box")
     ap.add_argument("--all-on-device0", action="store_true",
                     help="testing only: every rank uses GPU 0 (multi-rank code path on a 1-GPU box, with --backend gloo)")
     ap.add_argument("--sharding", choices=["owner", "tile", "coherent"], default="owner",
@@ -523,10 +526,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -549,7 +555,7 @@ def main():
     T_res = T_h[wrap]
 
     fuser = ShardedTSDF(VOXEL, SDF_TRUNC, s.width, s.height, device=local_rank, max_blocks=1 << 17,
-                        rank=rank, world_size=world, sharding=args.sharding)
+                        rank=rank, world_size=world, sharding=args.sharding, force_collectives=args.force_dist)
     vol = fuser.volume
 
     def step(k, mode=None, window=None):
@@ -602,7 +608,7 @@ def main():
     for k in range(args.steps):
         step(k)
     merge = None
-    if world > 1 and args.sharding == "tile":
+    if (world > 1 or args.force_dist) and args.sharding == "tile":
         # tile sharding leaves partial means on the units several ranks updated: all-reduce of those units over RCCL (timed, and
         # reported on its own so that the first multi-GPU run can be read: fuse time vs merge time vs bytes moved)
         fence()
@@ -762,7 +768,7 @@ def main():
         if not args.no_cpu_baseline:
             # the timed CPU baseline belongs to the N=1 line; at N>1 a two-step oracle pass still provides the counts
             budget = args.cpu_budget_s if world == 1 else 0.0
-            cpu = cpu_baseline_and_counts(s, depth_h, rgb_h, T_h, B, args.steps, budget, args.cpu_threads if world == 1 else 8, args.window)
+            cpu = cpu_baseline_and_counts(s, depth_h, rgb_h, T_h, B, args.steps, budget, args.cpu_threads if world == 1 else min(32, os.cpu_count() or 1), args.window)
         digest = current_build_digest()
         pmc = pmc_summary(digest)
         command_key = f"steps={args.steps} warmup={args.warmup} B={B} window={args.window} config={args.config}"
@@ -858,7 +864,9 @@ def main():
                 "value": round(cpu["fps"], 3), "unit": "frames/s", "cores": cpu["threads"], "kind": "port",
                 "sample": f"the first {cpu['frames']} frames of the same sliding stream ({cpu['seconds']:.1f} s of integrate calls, allocation "
                           f"included), oracle/tsdf_oracle.c (Open3D-semantics restatement, per-frame multiplier image as Open3D, "
-                          f"gcc -O3 -march=native on this host; open3d itself is not installed), OpenMP over touched units",
+                          f"gcc -O3 -march=native on this host; open3d itself is not installed), OpenMP over touched units; "
+                          f"thread policy: cores = os.cpu_count() of this box (--cpu-threads overrides), the same code on one core in `single_core`",
+                "single_core": cpu.get("single_core"),
             },
         }
         if cold is not None:

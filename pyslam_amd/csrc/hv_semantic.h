@@ -251,7 +251,10 @@ __device__ inline bool prob_fold_t(HvProbVoxel *v, const HvTable &table, bool fi
             if (*link == 0u) { // (a chain left behind by a collapsed map is taken up again)
                 if (nodes == nullptr) return false;
                 const int32_t id = atomicAdd(&table.counters[HV_CNT_PROB_NODES], 1);
-                if (id >= table.prob_node_cap) return false;
+                if (id >= table.prob_node_cap) {
+                    atomicSub(&table.counters[HV_CNT_PROB_NODES], 1); // (the counter stays the number of nodes handed out)
+                    return false;
+                }
                 nodes[id].next = 0u;
                 *link = (uint32_t)id + 1u;
             }
