@@ -316,6 +316,7 @@ struct hv_volume {
     } pending;
     void *list_sorted = nullptr;      // [2][max_blocks] a batch's union list by decreasing work (k_tsdf_list_by_work; HV_TSDF_LPT)
     size_t list_sorted_bytes = 0;
+    uint32_t *touch_ticket = nullptr; // touch workgroups of the running touch + pack launch that have finished (back to 0 with the last one)
     int32_t *sweep_done = nullptr;    // [table_capacity] parts of a unit finished by the running fused launch (zero between launches)
     void *params_ring = nullptr;      // device: 4 x 64 HvFrameParams, filled a batch ahead by k_upload_words on stream_up
     hipStream_t stream_up = nullptr;

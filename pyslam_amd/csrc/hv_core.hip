@@ -696,7 +696,7 @@ void hv_destroy(hv_volume *v) {
                     v->touched_stamp, v->touched_list, v->touched_mask, v->frame_px,
                     v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                     v->sort_vals_out, v->sort_tmp, v->scratch_points, v->scratch_colors, v->out_a,
-                    v->out_b, v->out_c, v->sweep_done, v->params_ring, v->list_sorted, v->batch_buf, v->assoc_buf, v->mult_table, v->vg_cnt, v->vg_cur, v->vg_touched, v->vg_cursor, v->batch_buf2, v->batch_buf3, v->unit_masks, v->plan_buf, v->occ, v->semb_tasks, v->table.prob_nodes};
+                    v->out_b, v->out_c, v->sweep_done, v->params_ring, v->list_sorted, v->touch_ticket, v->batch_buf, v->assoc_buf, v->mult_table, v->vg_cnt, v->vg_cur, v->vg_touched, v->vg_cursor, v->batch_buf2, v->batch_buf3, v->unit_masks, v->plan_buf, v->occ, v->semb_tasks, v->table.prob_nodes};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (v->h_counters) (void)hipHostFree(v->h_counters);

@@ -870,7 +870,8 @@ __device__ __forceinline__ void hv_touch_batch_patch(const HvTable &table, const
                                const int32_t old = atomicExch(&stamp[slot], batch_stamp);
                                if (old != batch_stamp) {
                                    const int32_t at = atomicAdd(&table.counters[HV_CNT_TOUCH(parity)], 1);
-                                   if (at < table.max_blocks) list[at] = slot;
+                                   // (an L2-level store: the launch's last touch workgroup may read the list back - hv_list_by_work_tail)
+                                   if (at < table.max_blocks) __hip_atomic_store(&list[at], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                }
                            }
                        }
@@ -892,6 +893,70 @@ __device__ __forceinline__ void hv_touch_batch_patch(const HvTable &table, const
 // union of 32 consecutive frames' units is ~1.6x one frame's); what remains is the per-voxel math
 // and the 8-byte frame gathers.
 // ================================================================================================
+// Longest-processing-time-first order for the sweep, WITHOUT a launch of its own (round 5): the last touch workgroup of the touch + pack
+// launch to finish counting-sorts the batch's union list by decreasing work (set bits of the unit's frame mask) while the launch's pack
+// workgroups are still streaming.  As a kernel of its own (k_tsdf_list_by_work) the sort sat in the dependency chain between two
+// sweeps and cost the step what the better order saved the sweep (profiles/r05/pipeline_experiments.md).  `lds`: >= 16 384 bytes of
+// the workgroup's LDS (the touch role's scratch, free by now) holds one byte of work per list entry; longer lists are copied as they
+// are.  List entries and masks were written with L2-level atomics by every workgroup: read back the same way.
+__device__ __forceinline__ void hv_list_by_work_tail(const HvTable &table, const int32_t *list, const unsigned long long *frame_mask,
+                                                     int32_t *__restrict__ sorted, const int parity, uint8_t *lds) {
+    __shared__ int32_t s_bin[65];
+    constexpr int CAP = 16384;
+    int n = __hip_atomic_load(&table.counters[HV_CNT_TOUCH(parity)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n > table.max_blocks) n = table.max_blocks;
+    const int nt = (int)blockDim.x;
+    if (n > CAP) {
+        for (int i = threadIdx.x; i < n; i += nt) sorted[i] = __hip_atomic_load(&list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    for (int i = threadIdx.x; i < 65; i += nt) s_bin[i] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 8 * nt) { // eight list entries, then their eight masks, in flight per thread
+        int32_t slot[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * nt + (int)threadIdx.x;
+            slot[k] = i < n ? __hip_atomic_load(&list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        }
+        unsigned long long m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = slot[k] >= 0 ? __hip_atomic_load(&frame_mask[slot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * nt + (int)threadIdx.x;
+            if (i < n) {
+                const int b = 64 - __popcll(m[k]); // bin 0 = all 64 frames: the longest tasks first
+                lds[i] = (uint8_t)b;
+                atomicAdd(&s_bin[b], 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int at = 0;
+        for (int b = 0; b < 65; ++b) {
+            const int c = s_bin[b];
+            s_bin[b] = at;
+            at += c;
+        }
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 8 * nt) {
+        int32_t slot[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * nt + (int)threadIdx.x;
+            slot[k] = i < n ? __hip_atomic_load(&list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * nt + (int)threadIdx.x;
+            if (i < n) sorted[atomicAdd(&s_bin[lds[i]], 1)] = slot[k];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, int32_t *__restrict__ stamp,
                                                                 unsigned long long *__restrict__ frame_mask,
                                                                 int32_t *__restrict__ list, int batch_stamp,
@@ -902,7 +967,8 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
                                                                 int n_touch_blocks, int n_frames, int parity,
                                                                 const float *__restrict__ mult12,
                                                                 const int4 *__restrict__ pack_box, uint32_t *__restrict__ plan_hist,
-                                                                HvStatus *status, int32_t status_seq) {
+                                                                HvStatus *status, int32_t status_seq, int32_t *__restrict__ sorted,
+                                                                uint32_t *__restrict__ touch_ticket) {
     if (plan_hist != nullptr && blockIdx.x == 0) {
         // image-coherent ownership: this is the last launch of the batch's plan chain - k_tsdf_plan_assign has read the histogram
         // (clean it for this scratch set's next batch) and made its claims (publish the pool's occupancy: hv_capacity_gate)
@@ -935,8 +1001,20 @@ __global__ __launch_bounds__(256) void k_tsdf_prep_touch_batch(HvTable table, in
     // ---- touch role: one wave per 8x8 sample patch (hv_touch_patch) ----
     __shared__ HvTouchScratch scratch[4];
     const int patch = bx * (int)(blockDim.x / HV_WAVE) + (int)(threadIdx.x / HV_WAVE); // (blocks of 256 or - HV_TSDF_AUX_W64 - 64 threads)
-    if (patch >= hv_touch_patches(P)) return;
-    hv_touch_batch_patch(table, P, depth_f, patch, scratch[threadIdx.x / HV_WAVE], f, frame_mask, stamp, list, batch_stamp, parity);
+    if (patch < hv_touch_patches(P))
+        hv_touch_batch_patch(table, P, depth_f, patch, scratch[threadIdx.x / HV_WAVE], f, frame_mask, stamp, list, batch_stamp, parity);
+    if (sorted == nullptr) return;
+    // the launch's LAST touch workgroup sorts the union list by decreasing work (hv_list_by_work_tail); every workgroup's list entries
+    // and mask bits are L2-level atomics, acknowledged (vmcnt = 0) before its ticket is taken
+    __shared__ uint32_t s_last;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(touch_ticket, 1u) == (uint32_t)(n_touch_blocks * n_frames) - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) *touch_ticket = 0u;
+    static_assert(sizeof(scratch) >= 16384, "the sort keeps one byte of work per list entry in the touch role's scratch");
+    hv_list_by_work_tail(table, list, frame_mask, sorted, parity, (uint8_t *)scratch);
 }
 
 // Union list of a batch from the allocated units: unit b belongs to it iff its slot carries the batch's stamp.  One thread per
@@ -3330,6 +3408,25 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
         const int aux_threads = (!coherent && getenv("HV_TSDF_AUX_W64") && atoi(getenv("HV_TSDF_AUX_W64")) != 0) ? 64 : 256;
         const int n_prep_blocks = (int)((npx + 4 * aux_threads - 1) / (4 * aux_threads)); // 4 pixels per thread
         const int n_touch_blocks = (hv_touch_patches(width, height, v->cfg.depth_sampling_stride) + aux_threads / 64 - 1) / (aux_threads / 64);
+        // HV_TSDF_LPT: 2 = the union list is sorted by decreasing work by the touch + pack launch's last touch workgroup, 1 = by a launch
+        // of its own behind it (k_tsdf_list_by_work), 0 (default) = list order.  Measured: the sorted order takes 6 % (one rank) / 17 %
+        // (an 8-rank share) off the SWEEP and nothing off the STEP - sweep and touch + pack share the machine's wave slots, the sum of
+        // their work is what a step costs, and the idle tail the sort removes from the sweep was where the next batch's touch + pack
+        // launch ran for free (profiles/r05/pipeline_experiments.md).
+        const int lpt = (list_in_touch && !coherent && aux_threads == 256) ? (getenv("HV_TSDF_LPT") ? atoi(getenv("HV_TSDF_LPT")) : 0) : 0;
+        int32_t *d_sorted_tail = nullptr;
+        if (lpt != 0) {
+            const size_t want_sorted = sizeof(int32_t) * HV_TSDF_SETS * (size_t)v->cfg.max_blocks;
+            if (v->list_sorted_bytes < want_sorted && v->stream_aux) HV_HIP(hipStreamSynchronize(v->stream_aux)); // (a sort may still write the old array)
+            rc = hv_ensure_buffer(v, &v->list_sorted, &v->list_sorted_bytes, want_sorted);
+            if (rc != HV_OK) return rc;
+            if (v->touch_ticket == nullptr) {
+                HV_HIP(hipMalloc((void **)&v->touch_ticket, 256));
+                HV_HIP(hipMemsetAsync(v->touch_ticket, 0, 256, v->stream));
+                HV_HIP(hipStreamSynchronize(v->stream));
+            }
+            if (lpt == 2) d_sorted_tail = (int32_t *)v->list_sorted + (size_t)parity * (size_t)v->cfg.max_blocks;
+        }
         for (int attempt = 0;; ++attempt) {
             // (coherent form: the plan restarts its own set's list - k_tsdf_touch_plan - and a memset here, on the main stream, could land
             // on a list the aux stream is already filling)
@@ -3357,13 +3454,13 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
                 hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3(n_prep_blocks * B), dim3(256), 0, ps, v->table, v->touched_stamp, d_mask_rw,
                                    d_list, batch_stamp, dd, (int64_t)(npx * dsz), (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params,
                                    n_prep_blocks, 0, B, parity, rec12 ? d_mult : nullptr, pack_all ? nullptr : (const int4 *)plan.box, plan.hist,
-                                   v->d_status, hv_next_status_seq(v));
+                                   v->d_status, hv_next_status_seq(v), (int32_t *)nullptr, (uint32_t *)nullptr);
             } else
             hipLaunchKernelGGL(k_tsdf_prep_touch_batch, dim3((n_prep_blocks + n_touch_blocks) * B), dim3(aux_threads), 0, ps,
                                v->table, v->touched_stamp, d_mask_rw, list_in_touch ? d_list : nullptr,
                                batch_stamp, (const char *)d_depth + npx * dsz * (size_t)f0, (int64_t)(npx * dsz),
                                (const uint8_t *)d_rgb + npx * 3 * (size_t)f0, d_px, d_params, n_prep_blocks, n_touch_blocks, B, parity,
-                               rec12 ? d_mult : nullptr, nullptr, nullptr, nullptr, 0);
+                               rec12 ? d_mult : nullptr, nullptr, nullptr, nullptr, 0, d_sorted_tail, d_sorted_tail ? v->touch_ticket : nullptr);
             if (!checked) break;
             // checked mode: nothing is fused before every unit of the batch has its pool slot; if some claims did not fit, the
             // pool has grown (table rebuilt without them, stamps kept) and the touch pass runs again under a fresh stamp
@@ -3376,6 +3473,11 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
             // the tables were rebuilt: the scratch set's arrays moved
             d_list = v->touched_list + (size_t)parity * (size_t)v->cfg.max_blocks;
             d_mask_rw = (unsigned long long *)v->touched_mask + (size_t)parity * (size_t)v->table_capacity;
+            if (lpt != 0) { // (the sorted lists are laid out by max_blocks, which has just grown)
+                rc = hv_ensure_buffer(v, &v->list_sorted, &v->list_sorted_bytes, sizeof(int32_t) * HV_TSDF_SETS * (size_t)v->cfg.max_blocks);
+                if (rc != HV_OK) return rc;
+                if (lpt == 2) d_sorted_tail = (int32_t *)v->list_sorted + (size_t)parity * (size_t)v->cfg.max_blocks;
+            }
         }
         if (!list_in_touch) {
             // one thread per pool slot (how many are allocated is only known on the device; threads beyond leave at once)
@@ -3384,15 +3486,13 @@ static int tsdf_integrate_batch_impl(hv_volume *v, const void *depth, const void
         }
         // HV_TSDF_LPT=1: the sweep (and the finish) read the list sorted by decreasing work (k_tsdf_list_by_work), queued behind the
         // touch pass on its stream
-        if (list_in_touch && !coherent && getenv("HV_TSDF_LPT") && atoi(getenv("HV_TSDF_LPT")) != 0) {
-            const size_t want_sorted = sizeof(int32_t) * HV_TSDF_SETS * (size_t)v->cfg.max_blocks;
-            if (v->list_sorted_bytes < want_sorted && v->stream_aux) HV_HIP(hipStreamSynchronize(v->stream_aux)); // (a sort may still write the old array)
-            rc = hv_ensure_buffer(v, &v->list_sorted, &v->list_sorted_bytes, want_sorted);
-            if (rc != HV_OK) return rc;
+        if (lpt == 1) {
             int32_t *d_sorted = (int32_t *)v->list_sorted + (size_t)parity * (size_t)v->cfg.max_blocks;
             hipLaunchKernelGGL(k_tsdf_list_by_work, dim3(1), dim3(1024), 0, ps, v->table, (const int32_t *)d_list, (const unsigned long long *)d_mask_rw,
                                d_sorted, parity);
             d_list = d_sorted;
+        } else if (lpt == 2) {
+            d_list = (int32_t *)v->list_sorted + (size_t)parity * (size_t)v->cfg.max_blocks; // (sorted by the touch + pack launch itself)
         }
         // What the NEXT batch's touch + pack launch waits for: everything the main stream holds up to here, i.e. the finish of the
         // batch that last used the next batch's scratch set.  Recorded BEFORE the main stream waits for this batch's own touch + pack

@@ -183,6 +183,72 @@ __global__ __launch_bounds__(256) void k_vg_unproject(const void *__restrict__ d
     }
 }
 
+// NS1 (the north star's "MFMA only for the 3xN point-transform GEMM"), measured instead of argued (HV_VG_UNPROJECT=mfma, radix path
+// only; tools/ns1_mfma.py, profiles/r05/ns1_mfma.txt): the same unprojection with the rigid transform of a wave's 64 points as four
+// v_mfma_f64_16x16x4_f64 (D = [R | t] (16x4, rows 0..2 used) x [x; y; z; 1] (4x16 points)).  The operands have to be gathered across
+// lanes (B[k][j] = coordinate k of point j lives in lane j's registers) and the results - rows 0..2 land in lanes 0..15 - scattered
+// back: 48 ds_bpermute per wave around 4 MFMAs, against 18 scalar-f64 VALU operations per lane.  The matrix core also FUSES the
+// four multiply-adds of a row (one rounding per step instead of two), so its points are not the numpy-order points the parity
+// contract names (section 2: ((r0 x + r1 y) + r2 z) + t, every product and sum rounded): NOT the default.
+__global__ __launch_bounds__(256) void k_vg_unproject_mfma(const void *__restrict__ depth_raw, const uint8_t *__restrict__ rgb,
+                                                            HvUnprojectParams U, float *__restrict__ pts_out,
+                                                            float *__restrict__ cols_out, uint32_t *__restrict__ valid_out) {
+    typedef double hv_d4 __attribute__((ext_vector_type(4)));
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = hv_lane_id();
+    const int64_t npx = (int64_t)U.H * U.W;
+    bool valid = false;
+    double x = 0.0, y = 0.0, z = 0.0;
+    if (i < npx) {
+        float d = U.depth_is_u16 ? (float)((const uint16_t *)depth_raw)[i] : ((const float *)depth_raw)[i];
+        if (U.depth_scale_f != 1.0f) d = d / U.depth_scale_f;
+        valid = (d > U.min_depth) && (d < U.max_depth);
+        const int row = (int)((uint32_t)i / (uint32_t)U.W), col_px = (int)((uint32_t)i - (uint32_t)row * (uint32_t)U.W);
+        z = (double)d;
+        x = ((double)col_px - U.cx) * z * U.inv_fx;
+        y = ((double)row - U.cy) * z * U.inv_fy;
+    }
+    // A[i][k]: lane l holds i = l & 15, k = l >> 4
+    const int ai = lane & 15, ak = lane >> 4;
+    const double a = ai < 3 ? (ak < 3 ? U.Rwc[ai * 3 + ak] : U.twc[ai]) : 0.0;
+    double wx = 0.0, wy = 0.0, wz = 0.0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        // B[k][j]: lane l holds k = l >> 4, j = l & 15 = coordinate k of point 16 g + j
+        const int src = 16 * g + (lane & 15);
+        const double bx = __shfl(x, src), by = __shfl(y, src), bz = __shfl(z, src);
+        const double b = ak == 0 ? bx : ak == 1 ? by : ak == 2 ? bz : 1.0;
+        const hv_d4 c = {0.0, 0.0, 0.0, 0.0};
+        const hv_d4 dres = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        // D[i][j] sits in lane (i & 3) * 16 + j, register i >> 2 (tools/mfma_f64_layout.hip, found by one-hot operands): rows 0..2 of
+        // point 16 g + j are register 0 of lanes j, 16 + j, 32 + j
+        const double rx = __shfl(dres[0], lane & 15), ry = __shfl(dres[0], 16 + (lane & 15)), rz = __shfl(dres[0], 32 + (lane & 15));
+        if ((lane >> 4) == g) {
+            wx = rx;
+            wy = ry;
+            wz = rz;
+        }
+    }
+    if (i >= npx) return;
+    valid_out[i] = valid ? 0u : HV_SORT_SENTINEL;
+    if (!valid) return;
+    pts_out[i * 3 + 0] = (float)wx;
+    pts_out[i * 3 + 1] = (float)wy;
+    pts_out[i * 3 + 2] = (float)wz;
+    const uint8_t *cpx = rgb + i * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cols_out[i * 3 + k] = (float)((double)cpx[k] / 255.0);
+}
+
+static void hv_launch_unproject(hipStream_t s, int64_t npx, const void *d_depth, const uint8_t *d_rgb, const HvUnprojectParams &U, float *pts,
+                                float *cols, uint32_t *valid) {
+    const bool mfma = getenv("HV_VG_UNPROJECT") && strcmp(getenv("HV_VG_UNPROJECT"), "mfma") == 0;
+    if (mfma)
+        hipLaunchKernelGGL(k_vg_unproject_mfma, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, d_depth, d_rgb, U, pts, cols, valid);
+    else
+        hipLaunchKernelGGL(k_vg_unproject, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, s, d_depth, d_rgb, U, pts, cols, valid);
+}
+
 // ================================================================================================
 // Per-frame bucket path (production for single frames).  The device-wide radix sort above is 18 small launches and 115 of
 // the 140 us a 640x480 frame takes (profiles/r01): a frame's points only have to be grouped per BLOCK (a few thousand
@@ -644,47 +710,15 @@ __global__ __launch_bounds__(256) void k_vg_probe_keys(const float *__restrict__
 // profiles/r03/kernel_stats_semantic.csv.)
 // state words: [0] number of positive deltas, [1] [2] remaining ranks of the two middle elements, [3] [4] their key prefixes,
 // [5] the threshold (float bits)
-enum { HV_SH_N = 0, HV_SH_RANK0 = 1, HV_SH_RANK1 = 2, HV_SH_PRE0 = 3, HV_SH_PRE1 = 4, HV_SH_THR = 5, HV_SH_WORDS = 8 };
+enum { HV_SH_N = 0, HV_SH_RANK0 = 1, HV_SH_RANK1 = 2, HV_SH_PRE0 = 3, HV_SH_PRE1 = 4, HV_SH_THR = 5, HV_SH_TICKET = 8 /* + pass */, HV_SH_WORDS = 16 };
 static constexpr int HV_SH_BINS01 = 4096, HV_SH_BINS2 = 256;
 static constexpr int HV_SH_HIST_WORDS = HV_SH_BINS01 + 2 * HV_SH_BINS01 + 2 * HV_SH_BINS2;
 
+// one workgroup (all 256 threads call this): the bin holding each of the two ranks, the rank inside it.  Round 5: no longer a launch of
+// its own - the LAST workgroup of the pass's histogram kernel to finish runs it (three dependent launches less per keyframe); the
+// histogram was accumulated with device-scope atomics by every workgroup, so it is read back with L2-level (agent-scope) loads.
 template <int PASS>
-__global__ __launch_bounds__(256) void k_shadow_hist(const float *__restrict__ depth, int H, int W, int dx, int dy,
-                                                      const uint32_t *__restrict__ state, uint32_t *__restrict__ hist) {
-    constexpr int BINS = PASS == 2 ? HV_SH_BINS2 : HV_SH_BINS01;
-    constexpr int NB = (PASS == 0 ? 1 : 2) * BINS;
-    __shared__ uint32_t s_h[NB];
-    for (int i = threadIdx.x; i < NB; i += 256) s_h[i] = 0u;
-    __syncthreads();
-    const uint32_t p0 = PASS > 0 ? state[HV_SH_PRE0] : 0u, p1 = PASS > 0 ? state[HV_SH_PRE1] : 0u;
-    auto add = [&](float v) {
-        if (!(v > 0.0f)) return; // NaN compares false, like numpy's `delta_values > 0`
-        const uint32_t key = __float_as_uint(v);
-        if (PASS == 0) {
-            atomicAdd(&s_h[key >> 20], 1u);
-        } else if (PASS == 1) {
-            if ((key >> 20) == p0) atomicAdd(&s_h[(key >> 8) & 0xfffu], 1u);
-            if ((key >> 20) == p1) atomicAdd(&s_h[BINS + ((key >> 8) & 0xfffu)], 1u);
-        } else {
-            if ((key >> 8) == p0) atomicAdd(&s_h[key & 0xffu], 1u);
-            if ((key >> 8) == p1) atomicAdd(&s_h[BINS + (key & 0xffu)], 1u);
-        }
-    };
-    const int npx = H * W;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < npx; i += gridDim.x * 256) {
-        const int r = i / W, c = i - r * W;
-        const float d = depth[i];
-        if (dy > 0 && r >= dy) add(fabsf(d - depth[i - dy * W]));
-        if (dx > 0 && c >= dx) add(fabsf(d - depth[i - dx]));
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < NB; i += 256)
-        if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
-}
-
-// one workgroup: the bin holding each of the two ranks, the rank inside it
-template <int PASS>
-__global__ __launch_bounds__(256) void k_shadow_pick(const uint32_t *__restrict__ hist, uint32_t *__restrict__ state) {
+__device__ __forceinline__ void hv_shadow_pick(const uint32_t *__restrict__ hist, uint32_t *__restrict__ state) {
     constexpr int BINS = PASS == 2 ? HV_SH_BINS2 : HV_SH_BINS01;
     constexpr int PER = BINS / 256;
     constexpr int BITS = PASS == 2 ? 8 : 12;
@@ -696,7 +730,7 @@ __global__ __launch_bounds__(256) void k_shadow_pick(const uint32_t *__restrict_
         uint32_t local[PER], sum = 0u;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            local[k] = h[t * PER + k];
+            local[k] = __hip_atomic_load(&h[t * PER + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sum += local[k];
         }
         s_scan[t] = sum;
@@ -741,6 +775,47 @@ __global__ __launch_bounds__(256) void k_shadow_pick(const uint32_t *__restrict_
         }
         state[HV_SH_THR] = __float_as_uint(thr);
     }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_shadow_hist(const float *__restrict__ depth, int H, int W, int dx, int dy,
+                                                      uint32_t *__restrict__ state, uint32_t *__restrict__ hist) {
+    constexpr int BINS = PASS == 2 ? HV_SH_BINS2 : HV_SH_BINS01;
+    constexpr int NB = (PASS == 0 ? 1 : 2) * BINS;
+    __shared__ uint32_t s_h[NB];
+    for (int i = threadIdx.x; i < NB; i += 256) s_h[i] = 0u;
+    __syncthreads();
+    const uint32_t p0 = PASS > 0 ? state[HV_SH_PRE0] : 0u, p1 = PASS > 0 ? state[HV_SH_PRE1] : 0u;
+    auto add = [&](float v) {
+        if (!(v > 0.0f)) return; // NaN compares false, like numpy's `delta_values > 0`
+        const uint32_t key = __float_as_uint(v);
+        if (PASS == 0) {
+            atomicAdd(&s_h[key >> 20], 1u);
+        } else if (PASS == 1) {
+            if ((key >> 20) == p0) atomicAdd(&s_h[(key >> 8) & 0xfffu], 1u);
+            if ((key >> 20) == p1) atomicAdd(&s_h[BINS + ((key >> 8) & 0xfffu)], 1u);
+        } else {
+            if ((key >> 8) == p0) atomicAdd(&s_h[key & 0xffu], 1u);
+            if ((key >> 8) == p1) atomicAdd(&s_h[BINS + (key & 0xffu)], 1u);
+        }
+    };
+    const int npx = H * W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npx; i += gridDim.x * 256) {
+        const int r = i / W, c = i - r * W;
+        const float d = depth[i];
+        if (dy > 0 && r >= dy) add(fabsf(d - depth[i - dy * W]));
+        if (dx > 0 && c >= dx) add(fabsf(d - depth[i - dx]));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB; i += 256)
+        if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+    // the last workgroup to get here picks the bins (its own atomics above are performed before it takes its ticket)
+    __shared__ uint32_t s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&state[HV_SH_TICKET + PASS], 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last) hv_shadow_pick<PASS>(hist, state);
 }
 
 __global__ __launch_bounds__(256) void k_shadow_mask(const float *__restrict__ depth, int H, int W, int dx, int dy,
@@ -865,8 +940,7 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
         return HV_OK;
     }
     if (frame) { // radix path on a frame: unproject first (validity flags go straight into the sort-key input buffer)
-        hipLaunchKernelGGL(k_vg_unproject, dim3(blocks), dim3(256), 0, v->stream, frame->d_depth, frame->d_rgb, frame->U, (float *)d_pts,
-                           (float *)d_cols, v->sort_keys_out);
+        hv_launch_unproject(v->stream, n, frame->d_depth, frame->d_rgb, frame->U, (float *)d_pts, (float *)d_cols, v->sort_keys_out);
         d_valid = v->sort_keys_out;
     }
     rc = ensure_sort_tmp(v, n);
@@ -1029,8 +1103,8 @@ static int unproject_device(hv_volume *v, const void *d_depth, int32_t depth_dty
     const int64_t npx = (int64_t)height * width;
     const HvUnprojectParams U = unproject_params(depth_dtype, depth_scale, height, width, intr, T_cw, min_depth, max_depth);
     // the unprojection's validity flags go straight into the sort-key input buffer
-    hipLaunchKernelGGL(k_vg_unproject, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream, d_depth, d_rgb, U,
-                       v->scratch_points + 3 * out_offset, v->scratch_colors + 3 * out_offset, v->sort_keys_out + out_offset);
+    hv_launch_unproject(v->stream, npx, d_depth, d_rgb, U, v->scratch_points + 3 * out_offset, v->scratch_colors + 3 * out_offset,
+                        v->sort_keys_out + out_offset);
     HV_HIP(hipGetLastError());
     return HV_OK;
 }
@@ -1151,12 +1225,10 @@ int hv_filter_shadow_points(hv_volume *v, const float *depth, int32_t height, in
     HV_HIP(hipMemsetAsync(hist0, 0, head, v->stream));
     const unsigned hist_grid = (unsigned)std::min<int64_t>((npx + 255) / 256, 1024);
     const float *dd = (const float *)d_depth;
+    // (each histogram pass ends with its own pick: the last workgroup of the launch, hv_shadow_pick)
     hipLaunchKernelGGL(k_shadow_hist<0>, dim3(hist_grid), dim3(256), 0, v->stream, dd, height, width, delta_x, delta_y, state, hist0);
-    hipLaunchKernelGGL(k_shadow_pick<0>, dim3(1), dim3(256), 0, v->stream, hist0, state);
     hipLaunchKernelGGL(k_shadow_hist<1>, dim3(hist_grid), dim3(256), 0, v->stream, dd, height, width, delta_x, delta_y, state, hist1);
-    hipLaunchKernelGGL(k_shadow_pick<1>, dim3(1), dim3(256), 0, v->stream, hist1, state);
     hipLaunchKernelGGL(k_shadow_hist<2>, dim3(hist_grid), dim3(256), 0, v->stream, dd, height, width, delta_x, delta_y, state, hist2);
-    hipLaunchKernelGGL(k_shadow_pick<2>, dim3(1), dim3(256), 0, v->stream, hist2, state);
     hipLaunchKernelGGL(k_shadow_mask, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream,
                        dd, height, width, delta_x, delta_y, state, fill_value, d_out);
     HV_HIP(hipGetLastError());

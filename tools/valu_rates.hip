@@ -14,10 +14,17 @@ constexpr int ITER = 4096;
 #define REP8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 #define BODY4(S) REP8(S) REP8(S) REP8(S) REP8(S)
 
+// Round 5: the table no longer depends on the NOMINAL clock.  Wave 0 of block 0 reads the shader-clock counter
+// (s_memtime) and the constant 100 MHz counter (s_memrealtime) around its loop: the clock the GPU really ran at = shader cycles / real
+// time, and the SUSTAINED rate per SIMD = launch duration (HIP events) x that clock / (8 waves x ITER x 32 instructions).  The last
+// column is wave 0's own view (its loop's shader cycles / its own instructions): the waves of a SIMD do not all run side by side.
 #define KERNEL(NAME, DECL, ASM)                                                                        \
-    __global__ __launch_bounds__(256) void NAME(float *out, float seed) {                               \
+    __global__ __launch_bounds__(256) void NAME(float *out, float seed, unsigned long long *ticks) {    \
         DECL;                                                                                           \
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime(); \
         for (int i = 0; i < ITER; ++i) { BODY4(ASM) }                                                   \
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime(); \
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ticks[0] = c1 - c0; ticks[1] = r1 - r0; }            \
         float acc = 0.f;                                                                                \
         for (int k = 0; k < 8; ++k) acc += __uint_as_float((unsigned)(unsigned long long)a[k]) + __uint_as_float((unsigned)((unsigned long long)a[k] >> 16)); \
         if (acc == 1234.5f) out[threadIdx.x] = acc;                                                     \
@@ -107,7 +114,7 @@ KERNEL(k_lshl_add_u64, DECL64, A_LSHLADD64)
 KERNEL(k_fma_f64, DECL64, A_FMA64)
 KERNEL(k_mov_b64, DECL64, A_MOV64)
 
-struct Entry { const char *name; void (*fn)(float *, float); };
+struct Entry { const char *name; void (*fn)(float *, float, unsigned long long *); };
 
 int main() {
     float *out;
@@ -129,21 +136,25 @@ int main() {
                              {"v_lshl_add_u32", k_lshl_add_u32}, {"v_pk_fma_f32", k_pk_fma}, {"v_pk_add_f32", k_pk_add}, {"v_pk_mul_f32", k_pk_mul},
                              {"v_mad_u64_u32", k_mad_u64_u32}, {"v_lshl_add_u64", k_lshl_add_u64}, {"v_fma_f64", k_fma_f64}, {"v_mov_b64", k_mov_b64}};
     const int blocks = cus * 8; // 8 blocks of 4 waves per CU = 8 waves per SIMD
+    unsigned long long *ticks;
+    CHECK(hipHostMalloc((void **)&ticks, 16));
     printf("device %s, %d CUs, nominal clock %.0f MHz; %d blocks x 256 threads, %d x 32 instructions per wave\n", prop.gcnArchName, cus, clk / 1e6,
            blocks, ITER);
-    printf("%-22s %10s %28s\n", "instruction", "ms", "cycles / wave-instr / SIMD");
+    printf("%-28s %9s %12s %30s %34s\n", "instruction", "ms", "clock MHz", "cycles / wave-instr / SIMD", "wave 0: cycles per OWN instruction");
     for (auto &e : es) {
-        hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, out, 1.5f);
+        hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, out, 1.5f, ticks);
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, out, 1.5f);
+        hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, out, 1.5f, ticks);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
+        CHECK(hipDeviceSynchronize());
         float ms = 0;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         // per SIMD: 8 waves x ITER x 32 instructions
         const double instr_per_simd = 8.0 * ITER * 32.0;
-        printf("%-22s %10.3f %28.2f\n", e.name, ms, ms * 1e-3 * clk / instr_per_simd);
+        const double mhz = ticks[1] ? (double)ticks[0] / (double)ticks[1] * 100.0 : 0.0; // s_memrealtime counts at 100 MHz
+        printf("%-28s %9.3f %12.0f %30.2f %34.2f\n", e.name, ms, mhz, ms * 1e-3 * mhz * 1e6 / instr_per_simd, (double)ticks[0] / (ITER * 32.0));
     }
     return 0;
 }
