@@ -370,6 +370,38 @@ __device__ __forceinline__ void sem_for_occupied_word(unsigned long long word, i
         body(b * nvox + wi * 64 + pos, active);
     }
 }
+// FOUR blocks per wave (round 5): a block of a 2 mm map holds ~15 occupied voxels, so the one-block-per-wave walk above keeps 15 of 64
+// lanes busy per dependent round trip (record -> image pixels).  Here every 16-lane group owns one block: lane (lane & 15) < W of a group
+// holds word (lane & 15) of ITS block (zero: nothing to visit), the group's k-th set bit goes to its lane k, groups with more than 16
+// occupied voxels take more trips (the trip count is the wave's maximum).  body(gid, active, group's block) is called by every lane of
+// the wave in every trip.  Needs nvox / 64 <= 8 (8^3 blocks).
+template <typename F>
+__device__ __forceinline__ void sem_for_occupied_quad(unsigned long long word, int64_t bg, int nvox, F body) {
+    const int lane = hv_lane_id();
+    const int g16 = lane & ~15, gl = lane & 15;
+    const int W = nvox >> 6;
+    const int cnt = __popcll(word);
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (gl >= o) incl += up;
+    }
+    const int total = __shfl(incl, g16 + 15);
+    int trips = (total + 15) >> 4;
+#pragma unroll
+    for (int o = 32; o >= 16; o >>= 1) trips = max(trips, __shfl_xor(trips, o));
+    for (int it = 0; it < trips; ++it) { // wave-uniform trip count
+        const int k = it * 16 + gl;
+        const bool active = k < total;
+        int wi = 0;
+        for (int w = 0; w < W - 1; ++w) wi += (__shfl(incl, g16 + w) <= k) ? 1 : 0; // word of the group's block that holds its k-th set bit
+        const unsigned long long ww = __shfl(word, g16 + wi);
+        const int before = __shfl(incl, g16 + wi) - __shfl(cnt, g16 + wi);
+        const int pos = active ? sem_select_bit(ww, k - before) : 0;
+        body(bg * nvox + wi * 64 + pos, active, bg);
+    }
+}
 __device__ __forceinline__ bool sem_occ_words_usable(const unsigned long long *occ, int nvox) {
     return occ != nullptr && (nvox & 63) == 0 && (nvox >> 6) <= HV_WAVE;
 }

@@ -372,3 +372,31 @@ def test_block_ownership_sharding_union_is_the_single_grid():
     np.testing.assert_array_equal(keys[order], kf)
     np.testing.assert_array_equal(np.concatenate([d[2] for d in dumps])[order], cf)
     np.testing.assert_array_equal(np.concatenate([d[3] for d in dumps])[order].view(np.uint32), sf.view(np.uint32))
+
+
+def test_mfma_unprojection_variant_fills_the_same_voxels(monkeypatch):
+    """NS1 (tools/ns1_mfma.py): the unprojection with its rigid transform on the matrix cores (HV_VG_UNPROJECT=mfma, four
+    v_mfma_f64_16x16x4_f64 per wave, radix path) against the default VALU form on posed synthetic frames: the same blocks, the same
+    per-voxel counts; position sums within float32 rounding of a fused multiply-add (the matrix core rounds a row's four steps once
+    each) - which is why it is NOT the default: the parity contract names the unfused order."""
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    monkeypatch.setenv("HV_VG_PATH", "sort")
+    dumps = {}
+    for form in ("valu", "mfma"):
+        monkeypatch.setenv("HV_VG_UNPROJECT", form)
+        g = VoxelBlockGrid(0.02, 8, max_blocks=1 << 13, max_points=1 << 16)
+        for i in (0, 7, 19):
+            d, c, T = s[i]
+            g.integrate_rgbd(d, c, *s.intrinsics, T, max_depth=4.0)
+        dumps[form] = g.dump()
+    ka, _, ca, sa = dumps["valu"]
+    kb, _, cb, sb = dumps["mfma"]
+    np.testing.assert_array_equal(ka, kb)
+    moved = int(np.abs(ca.astype(np.int64) - cb).sum()) // 2
+    assert moved <= 2, moved  # a point exactly on a voxel face may move with the last bit of its coordinate; none does on these frames
+    same = ca == cb
+    np.testing.assert_allclose(sa[same][:, :3], sb[same][:, :3], rtol=0, atol=2e-6 * max(1, int(ca.max())))
+    assert ca.sum() > 30000
