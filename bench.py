@@ -68,7 +68,7 @@ UNIT_BYTES = 4096 * BYTES_PER_VOXEL
 VALU_PEAK_GINSTR_2CYC = 1024 * 2.4 / 2.0  # MI355X_MICROARCH.md lists wave64 v_fma_f32 at 2 cycles: 1228.8 G wave-instr/s
 VECTOR_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector (non-MFMA) fp32
 FLOP_PER_VISIT = 40  # "TSDF ~ 40 flop / voxel visited"
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 PMC_SUMMARY = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_summary.json")
 
 

@@ -3,7 +3,7 @@
 # (tools/profile_round.sh), the VOXEL_GRID and semantic kernel tables + traffic passes, then the default bench line (which parses
 # the summaries), the sweep A/B table, the ownership-sharding projection.  Every profiler run sits under its own `timeout`.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 export GRAFT_GIT_HEAD=$(cat $R/.final_head 2>/dev/null)
 cd $R
 mkdir -p gpurun_out profiles/$ROUND
@@ -48,7 +48,18 @@ grep -E "sem|shadow" gpurun_out/sem2_pmc_summary.txt | cut -c1-200 | head -12
 timeout 200 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
 timeout 600 python bench.py > gpurun_out/bench_n1.log 2>&1
 grep '^{"metric"' gpurun_out/bench_n1.log > gpurun_out/bench_n1.json; cut -c1-1500 gpurun_out/bench_n1.json
-timeout 250 python tools/sweep_variants.py --steps 18 --warmup 3 --repeat 3 "HV_TSDF_SWEEP=4" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_GV=2" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_GV=2 HV_TSDF_SWEEP_VCAP=112" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_PIPE=0" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_PIPE=2" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_ANYSKIP=1" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_ANYSKIP=0" "HV_TSDF_SWEEP=3" "HV_TSDF_SWEEP=3 HV_TSDF_SWEEP_ANYSKIP=1" "HV_TSDF_SWEEP=3 HV_TSDF_SWEEP_REC12=0" "HV_TSDF_SWEEP=3 HV_TSDF_SWEEP_DBG=2" "HV_TSDF_SWEEP=2" "HV_TSDF_SWEEP=1" 2>/dev/null | tail -13 > gpurun_out/sweep_forms.jsonl; cut -c1-200 gpurun_out/sweep_forms.jsonl
+timeout 250 python tools/sweep_variants.py --steps 18 --warmup 3 --repeat 3 "HV_TSDF_SWEEP=4" "HV_TSDF_SWEEP=4 HV_TSDF_LPT=2" "HV_TSDF_SWEEP=4 HV_TSDF_FUSED=1" "HV_TSDF_SWEEP=4 HV_TSDF_FINISH=epilogue" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_ANYSKIP=0" "HV_TSDF_SWEEP=3" "HV_TSDF_SWEEP=2" "HV_TSDF_SWEEP=1" 2>/dev/null | tail -8 > gpurun_out/sweep_forms.jsonl; cut -c1-200 gpurun_out/sweep_forms.jsonl
+# round 5: issue-rate table on measured clocks, NS1 (MFMA unprojection) beside the VALU form, the N > 1 line of bench.py over RCCL with one rank
+hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rates tools/valu_rates.hip > /dev/null 2>&1 && timeout 120 /tmp/valu_rates > gpurun_out/valu_issue_rates.txt 2>&1; head -4 gpurun_out/valu_issue_rates.txt
+pushd /tmp > /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ns1_kt -o ns1 -- python $R/tools/ns1_mfma.py > $R/gpurun_out/ns1_mfma.json 2>/dev/null
+popd > /dev/null
+find gpurun_out/ns1_kt -name "*kernel_stats.csv" -exec cp {} gpurun_out/ns1_kernel_stats.csv \;; grep -i unproject gpurun_out/ns1_kernel_stats.csv | cut -c1-160
+for SH in owner tile; do
+  BENCH_LIVE_PMC=0 timeout 300 python bench.py --force-dist --sharding $SH --steps 6 --warmup 2 --clock-ramp-steps 4 --no-secondary --no-cpu-baseline > gpurun_out/bench_nccl1_$SH.log 2>&1
+  grep '^{"metric"' gpurun_out/bench_nccl1_$SH.log > gpurun_out/bench_nccl1_$SH.json; python -c "
+import json; z=json.load(open('gpurun_out/bench_nccl1_$SH.json')); print('nccl world 1 $SH', z['value'], z.get('merge'))" 2>&1 | tail -1 | cut -c1-300
+done
 timeout 250 python tools/simulate_ranks.py --worlds 1,2,4,8 --steps 12 > gpurun_out/simulate_ranks.jsonl 2>/dev/null; cut -c1-200 gpurun_out/simulate_ranks.jsonl
 timeout 250 python tools/simulate_ranks.py --worlds 1,2,4,8 --steps 12 --sharding coherent > gpurun_out/simulate_ranks_coherent.jsonl 2>/dev/null; cut -c1-200 gpurun_out/simulate_ranks_coherent.jsonl
 # the N > 1 code path of bench.py on this one GPU (two ranks share device 0, gloo transport: the kernels, the sharding and the

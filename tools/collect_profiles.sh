@@ -1,6 +1,6 @@
 #!/bin/bash
 # After tools/_final.sh has run on the GPU box: copy the summaries it left under gpurun_out/ (scratch) into profiles/$ROUND (tracked).
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 cd "$(dirname "$0")/.."
 P=profiles/$ROUND
 mkdir -p $P
@@ -20,4 +20,10 @@ cp gpurun_out/sem_pmc_summary.txt $P/pmc_semantic.txt
 cp gpurun_out/sem2_pmc_summary.txt $P/pmc_semantic_scannet_2mm.txt
 cp gpurun_out/bench_semantic_profiled.json $P/bench_semantic.json
 cp gpurun_out/bench_semantic_scannet_profiled.json $P/bench_semantic_scannet_2mm.json
+ls -la $P
+# round 5 additions
+cp gpurun_out/valu_issue_rates.txt $P/valu_issue_rates.txt 2>/dev/null
+cp gpurun_out/ns1_mfma.json $P/ns1_mfma.json 2>/dev/null
+cp gpurun_out/ns1_kernel_stats.csv $P/kernel_stats_ns1.csv 2>/dev/null
+cp gpurun_out/bench_nccl1_owner.json gpurun_out/bench_nccl1_tile.json $P/ 2>/dev/null
 ls -la $P
