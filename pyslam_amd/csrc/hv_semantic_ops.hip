@@ -246,7 +246,7 @@ struct HvAssocParams {
 // frustum once, then only the voxels whose occupancy bit is set are visited (a 2 mm ScanNet keyframe faces 120 k blocks = 61 M
 // voxel slots of which 7 % hold a voxel: the thread-per-slot form spent 0.7 - 1.0 ms per keyframe on per-wave overhead - cull,
 // ballots, appends - for 950 k waves of mostly empty slots).
-template <typename VOX>
+template <typename VOX, bool QUAD>
 __global__ __launch_bounds__(256) void k_sem_assoc_vote(HvTable table, VOX *__restrict__ pool, int64_t n_blocks,
                                                          HvSemParams G, HvQuery Q, const int32_t *__restrict__ cls_img,
                                                          const int32_t *__restrict__ inst_img,
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_sem_assoc_vote(HvTable table, VOX *__re
         const int32_t at = hv_wave_append(&table.counters[HV_CNT_AUX], is_pending);
         if (is_pending && at < A.pending_cap) pending[at] = make_int2((int32_t)gid, inst);
     };
-    if (quad && sem_occ_words_usable(occ, G.nvox) && (G.nvox >> 6) <= 8) {
+    if (QUAD && quad && sem_occ_words_usable(occ, G.nvox) && (G.nvox >> 6) <= 8) { // (QUAD: an instantiation of its own - the one-block form keeps its registers)
         // four blocks per wave, one per 16-lane group (sem_for_occupied_quad); the next quad's keys and words are requested before this
         // one is worked on
         const int lane = hv_lane_id(), g = lane >> 4, gl = lane & 15, W = G.nvox >> 6;
@@ -1135,15 +1135,17 @@ int hv_assoc_vote(hv_volume *v, const float *intr_f32, int32_t width, int32_t he
         GP.nvox = G.nvox;
         GP.local_bits = G.local_bits;
         fill_key_range(Q, GP);
-        // HV_SEM_VOTE_QUAD=0: one block per wave (round 4); default: four blocks per wave, one per 16-lane group
-        const int vote_quad = getenv("HV_SEM_VOTE_QUAD") ? atoi(getenv("HV_SEM_VOTE_QUAD")) : 1;
+        // HV_SEM_VOTE_QUAD=1: four blocks per wave, one per 16-lane group, where that takes fewer trips.  Measured (profiles/r05/README.md):
+        // +2-3 % keyframes/s at 1296x968 / 2 mm (~15 occupied voxels per block), -11 % at 640x480 / 1 cm (~60 per block: the per-quad
+        // decision and the larger kernel cost more than the trips it saves).  Default 0 = one block per wave, as in round 4.
+        const int vote_quad = getenv("HV_SEM_VOTE_QUAD") ? atoi(getenv("HV_SEM_VOTE_QUAD")) : 0;
         const dim3 grid((unsigned)std::min<int64_t>(((vote_quad ? (nb + 3) / 4 : nb) + 3) / 4, 4096)); // persistent: 16 workgroups per CU
-        if (prob)
-            hipLaunchKernelGGL(k_sem_assoc_vote<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, (int64_t)-1, G,
-                               Q, d_cls, d_inst, d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ, vote_quad);
-        else
-            hipLaunchKernelGGL(k_sem_assoc_vote<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, (int64_t)-1, G, Q,
-                               d_cls, d_inst, d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ, vote_quad);
+#define HV_LAUNCH_VOTE(VOX, QUAD)                                                                                                  \
+    hipLaunchKernelGGL((k_sem_assoc_vote<VOX, QUAD>), grid, dim3(256), 0, v->stream, v->table, (VOX *)v->pool, (int64_t)-1, G, Q, d_cls, d_inst, \
+                       d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ, vote_quad)
+        if (prob) { if (vote_quad) HV_LAUNCH_VOTE(HvProbVoxel, true); else HV_LAUNCH_VOTE(HvProbVoxel, false); }
+        else { if (vote_quad) HV_LAUNCH_VOTE(HvSemVoxel, true); else HV_LAUNCH_VOTE(HvSemVoxel, false); }
+#undef HV_LAUNCH_VOTE
     }
     hipLaunchKernelGGL(k_sem_assoc_image, dim3((unsigned)std::min<int64_t>((n_px + 255) / 256, 512)), dim3(256), 0, v->stream, v->table, d_cls, d_inst,
                        n_px, S.vkeys, S.vcounts);

@@ -714,9 +714,9 @@ enum { HV_SH_N = 0, HV_SH_RANK0 = 1, HV_SH_RANK1 = 2, HV_SH_PRE0 = 3, HV_SH_PRE1
 static constexpr int HV_SH_BINS01 = 4096, HV_SH_BINS2 = 256;
 static constexpr int HV_SH_HIST_WORDS = HV_SH_BINS01 + 2 * HV_SH_BINS01 + 2 * HV_SH_BINS2;
 
-// one workgroup (all 256 threads call this): the bin holding each of the two ranks, the rank inside it.  Round 5: no longer a launch of
-// its own - the LAST workgroup of the pass's histogram kernel to finish runs it (three dependent launches less per keyframe); the
-// histogram was accumulated with device-scope atomics by every workgroup, so it is read back with L2-level (agent-scope) loads.
+// one workgroup: the bin holding each of the two ranks, the rank inside it.  (Round 5 tried the pick as the tail of the histogram
+// launch - run by its last workgroup to finish, the histogram read back with L2-level loads -: three launches less per keyframe and
+// 18 us MORE, 69.6 us for the three passes against 51.5: the 4096 bypassing loads of one workgroup cost more than a 5 us launch.)
 template <int PASS>
 __device__ __forceinline__ void hv_shadow_pick(const uint32_t *__restrict__ hist, uint32_t *__restrict__ state) {
     constexpr int BINS = PASS == 2 ? HV_SH_BINS2 : HV_SH_BINS01;
@@ -730,7 +730,7 @@ __device__ __forceinline__ void hv_shadow_pick(const uint32_t *__restrict__ hist
         uint32_t local[PER], sum = 0u;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            local[k] = __hip_atomic_load(&h[t * PER + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            local[k] = h[t * PER + k];
             sum += local[k];
         }
         s_scan[t] = sum;
@@ -809,13 +809,11 @@ __global__ __launch_bounds__(256) void k_shadow_hist(const float *__restrict__ d
     __syncthreads();
     for (int i = threadIdx.x; i < NB; i += 256)
         if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
-    // the last workgroup to get here picks the bins (its own atomics above are performed before it takes its ticket)
-    __shared__ uint32_t s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&state[HV_SH_TICKET + PASS], 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (s_last) hv_shadow_pick<PASS>(hist, state);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_shadow_pick(const uint32_t *__restrict__ hist, uint32_t *__restrict__ state) {
+    hv_shadow_pick<PASS>(hist, state);
 }
 
 __global__ __launch_bounds__(256) void k_shadow_mask(const float *__restrict__ depth, int H, int W, int dx, int dy,
@@ -1225,10 +1223,12 @@ int hv_filter_shadow_points(hv_volume *v, const float *depth, int32_t height, in
     HV_HIP(hipMemsetAsync(hist0, 0, head, v->stream));
     const unsigned hist_grid = (unsigned)std::min<int64_t>((npx + 255) / 256, 1024);
     const float *dd = (const float *)d_depth;
-    // (each histogram pass ends with its own pick: the last workgroup of the launch, hv_shadow_pick)
     hipLaunchKernelGGL(k_shadow_hist<0>, dim3(hist_grid), dim3(256), 0, v->stream, dd, height, width, delta_x, delta_y, state, hist0);
+    hipLaunchKernelGGL(k_shadow_pick<0>, dim3(1), dim3(256), 0, v->stream, hist0, state);
     hipLaunchKernelGGL(k_shadow_hist<1>, dim3(hist_grid), dim3(256), 0, v->stream, dd, height, width, delta_x, delta_y, state, hist1);
+    hipLaunchKernelGGL(k_shadow_pick<1>, dim3(1), dim3(256), 0, v->stream, hist1, state);
     hipLaunchKernelGGL(k_shadow_hist<2>, dim3(hist_grid), dim3(256), 0, v->stream, dd, height, width, delta_x, delta_y, state, hist2);
+    hipLaunchKernelGGL(k_shadow_pick<2>, dim3(1), dim3(256), 0, v->stream, hist2, state);
     hipLaunchKernelGGL(k_shadow_mask, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream,
                        dd, height, width, delta_x, delta_y, state, fill_value, d_out);
     HV_HIP(hipGetLastError());
