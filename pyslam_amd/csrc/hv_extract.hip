@@ -74,10 +74,14 @@ __device__ __forceinline__ void edge_owner(int x, int y, int z, int i, int &n, i
 //   m_ip[unit * 256 + column]  bits 0-15: observed, -0.98 <= tsdf < 0.98; bits 16-31: that and tsdf > 0
 // (ExtractPointCloud's `f0 * f1 < 0` of two in-range values is "one negative, one positive": the product of two tsdf values
 // cannot underflow to zero - a non-zero tsdf is a ratio of pixel-scale floats, never below 1e-23.)
+//   unit_signs[unit]           bit 0: the unit holds an observed negative voxel, bit 1: an observed non-negative one
 __global__ __launch_bounds__(256) void k_unit_masks(const char *__restrict__ pool, int n_units, uint32_t *__restrict__ m_on,
-                                                     uint32_t *__restrict__ m_ip) {
+                                                     uint32_t *__restrict__ m_ip, uint32_t *__restrict__ unit_signs) {
+    __shared__ uint32_t s_signs;
     const int idx = blockIdx.x;
     if (idx >= n_units) return;
+    if (threadIdx.x == 0) s_signs = 0u;
+    __syncthreads();
     const char *unit = pool + (int64_t)idx * UNIT_BYTES;
     float t[R];
     uint32_t w[R];
@@ -98,6 +102,10 @@ __global__ __launch_bounds__(256) void k_unit_masks(const char *__restrict__ poo
     }
     m_on[(int64_t)idx * RR + threadIdx.x] = obs | (neg << 16);
     m_ip[(int64_t)idx * RR + threadIdx.x] = inr | (pos << 16);
+    const uint32_t wave_signs = (__any(neg != 0u) ? 1u : 0u) | (__any((obs & ~neg) != 0u) ? 2u : 0u);
+    if (hv_lane_id() == 0 && wave_signs) atomicOr(&s_signs, wave_signs);
+    __syncthreads();
+    if (threadIdx.x == 0) unit_signs[idx] = s_signs;
 }
 
 // Classification of one unit from per-COLUMN bit masks.  Marching cubes only asks two things of a voxel - observed (weight
@@ -116,7 +124,8 @@ __global__ __launch_bounds__(256) void k_unit_masks(const char *__restrict__ poo
 // float slab in LDS, 8 LDS reads per cube, one global atomicOr per crossing edge and cube - 0.45 of its 0.87 ms per 24 k
 // units were those atomics, profiles/r02.)
 static constexpr int H2 = 18;
-__global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32_t *__restrict__ m_on, int n_units,
+__global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32_t *__restrict__ m_on,
+                                                      const uint32_t *__restrict__ unit_signs, int n_units,
                                                       unsigned long long *__restrict__ edge_mask,
                                                       uint32_t *__restrict__ word_prefix, unsigned long long *__restrict__ counts,
                                                       uint8_t *__restrict__ cases) {
@@ -126,9 +135,14 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32
     __shared__ int s_nbr[27]; // pool index of the unit at offset (dx, dy, dz) in {-1, 0, 1}^3: [(dx + 1) + 3 (dy + 1) + 9 (dz + 1)]
     __shared__ uint32_t s_obs[H2 * H2], s_neg[H2 * H2]; // [(cx + 1) * 18 + (cy + 1)], bit k <-> z = k - 1
     __shared__ int s_tris;
+    __shared__ uint32_t s_signs; // bit 0: an observed negative voxel in the 18 x 18 x 18 neighbourhood, bit 1: an observed non-negative one
+    __shared__ uint32_t s_coarse; // the same for the 27 units around (k_unit_masks' summaries)
     const int idx = blockIdx.x;
     if (idx >= n_units) return;
-    if (threadIdx.x == 0) s_tris = 0;
+    if (threadIdx.x == 0) {
+        s_tris = 0;
+        s_signs = 0u;
+    }
     if (idx == 0 && threadIdx.x == 1) counts[n_units] = 0ull; // the scan's extra element: its output there is the total
     if (threadIdx.x < 27) {
         int32_t ux, uy, uz;
@@ -143,8 +157,21 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32
             if (slot >= 0) r = table.vals[slot];
         }
         s_nbr[n] = r;
+        // (coarse) the signs the 27 units hold between them
+        const uint32_t sg = r >= 0 ? unit_signs[r] : 0u;
+        const uint32_t all = (__any(sg & 1u) ? 1u : 0u) | (__any(sg & 2u) ? 2u : 0u);
+        if (n == 0) s_coarse = all;
     }
     __syncthreads();
+    // A crossing edge and a mixed cube both need an observed negative AND an observed non-negative voxel in the unit's 18 x 18 x 18
+    // neighbourhood.  Most allocated units (free space in front of the surface, the far side of the band) see one kind only: no vertex,
+    // no triangle, and nothing of their masks / prefixes / cases is ever read (the emit passes return on a zero count; a neighbour asks
+    // for this unit's words only for an edge that crosses).  They end here - before the 324 column masks are fetched if the 27 units'
+    // summaries say so already, after assembling them otherwise: counts = 0, 7 KB of scratch not written.
+    if (s_coarse != 3u) {
+        if (threadIdx.x == 0) counts[idx] = 0ull;
+        return;
+    }
     // ---- column masks ----
     for (int pass = 0; pass < 2; ++pass) {
         int cx, cy;
@@ -170,8 +197,15 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32
         const uint32_t neg = ((lo >> 31) & 1u) | ((mid >> 16) << 1) | (((hi >> 16) & 1u) << 17);
         s_obs[(cx + 1) * H2 + (cy + 1)] = obs;
         s_neg[(cx + 1) * H2 + (cy + 1)] = neg;
+        const uint32_t signs = (neg ? 1u : 0u) | ((obs & ~neg) ? 2u : 0u);
+        const uint32_t wave_signs = (__any(signs & 1u) ? 1u : 0u) | (__any(signs & 2u) ? 2u : 0u);
+        if (hv_lane_id() == 0 && wave_signs) atomicOr(&s_signs, wave_signs);
     }
     __syncthreads();
+    if (s_signs != 3u) { // (fine) the neighbourhood itself
+        if (threadIdx.x == 0) counts[idx] = 0ull;
+        return;
+    }
     // ---- classification of column (x, y) ----
     const int x = threadIdx.x >> 4, y = threadIdx.x & 15;
     uint32_t o[3][3], g[3][3]; // [dx + 1][dy + 1]
@@ -680,11 +714,11 @@ extern "C" {
 // cloud of the same contents computes them once)
 static int unit_masks_compute(hv_volume *v, int n, const uint32_t **m_on, const uint32_t **m_ip) {
     const size_t plane = sizeof(uint32_t) * RR * (size_t)n;
-    int rc = hv_ensure_buffer(v, &v->unit_masks, &v->unit_masks_bytes, 2 * plane);
+    int rc = hv_ensure_buffer(v, &v->unit_masks, &v->unit_masks_bytes, 2 * plane + sizeof(uint32_t) * (size_t)n);
     if (rc != HV_OK) return rc;
-    uint32_t *on = (uint32_t *)v->unit_masks, *ip = on + (size_t)RR * n;
+    uint32_t *on = (uint32_t *)v->unit_masks, *ip = on + (size_t)RR * n; // [m_on n * 256][m_ip n * 256][unit_signs n]
     if (v->unit_masks_version != v->content_version || v->unit_masks_units != n) {
-        hipLaunchKernelGGL(k_unit_masks, dim3(n), dim3(256), 0, v->stream, (const char *)v->pool, n, on, ip);
+        hipLaunchKernelGGL(k_unit_masks, dim3(n), dim3(256), 0, v->stream, (const char *)v->pool, n, on, ip, ip + (size_t)RR * n);
         HV_HIP(hipGetLastError());
         v->unit_masks_version = v->content_version;
         v->unit_masks_units = n;
@@ -726,7 +760,7 @@ static int mesh_compute(hv_volume *v) {
     const uint32_t *m_on = nullptr, *m_ip = nullptr;
     rc = unit_masks_compute(v, n, &m_on, &m_ip);
     if (rc != HV_OK) return rc;
-    hipLaunchKernelGGL(k_mc_classify, dim3(n), dim3(256), 0, v->stream, v->table, m_on, n, edge_mask, word_prefix, counts, cases);
+    hipLaunchKernelGGL(k_mc_classify, dim3(n), dim3(256), 0, v->stream, v->table, m_on, m_ip + (size_t)RR * n /* unit_signs */, n, edge_mask, word_prefix, counts, cases);
     HV_HIP(hipGetLastError());
     rc = exclusive_scan_u64(v, counts, bases, n + 1);
     if (rc != HV_OK) return rc;

@@ -229,6 +229,81 @@ __host__ __device__ inline void sem_set_object_id(HvProbVoxel *v, const void *no
 }
 
 #ifdef __HIPCC__
+// The fold keeps the voxel it works on as a LOCAL copy (sem_fold_run: read once, folded, written once).  An inline slot reached with
+// a run-time index (`v->logp[i]`) forces that copy into scratch memory - the probabilistic fold kernels carried 144 bytes of it per
+// lane and paid a memory round trip for every slot they looked at (round 5).  The helpers below reach the six inline slots through
+// constant indices only (a select chain over the slots), so the copy lives in registers; pairs beyond the inline slots are in the
+// node pool (global memory) either way.  Only the fold uses them: on a voxel in GLOBAL memory one indexed load beats six.
+// (all six slots are read, unconditionally, and the VALUES are selected: loads in the arms of a branch are merged by the optimiser
+// into one load through a selected address)
+__device__ __forceinline__ HvProbPair prob_slot_get(const HvProbVoxel *v, int i) {
+    HvProbPair p{v->obj[0], v->cls[0], v->logp[0]};
+#pragma unroll
+    for (int k = 1; k < HV_PROB_K; ++k) {
+        const int32_t ok = v->obj[k], ck = v->cls[k];
+        const float lk = v->logp[k];
+        p.obj = i == k ? ok : p.obj;
+        p.cls = i == k ? ck : p.cls;
+        p.logp = i == k ? lk : p.logp;
+    }
+    return p;
+}
+// (every slot is stored, with its old or its new value: a conditional store per slot is merged by the optimiser into ONE store through
+// a pointer picked from the six slots - a run-time address again)
+__device__ __forceinline__ void prob_slot_set(HvProbVoxel *v, int i, int32_t obj, int32_t cls, float lp) {
+#pragma unroll
+    for (int k = 0; k < HV_PROB_K; ++k) {
+        v->obj[k] = i == k ? obj : v->obj[k];
+        v->cls[k] = i == k ? cls : v->cls[k];
+        v->logp[k] = i == k ? lp : v->logp[k];
+    }
+}
+__device__ __forceinline__ void prob_slot_set_logp(HvProbVoxel *v, int i, float lp) {
+#pragma unroll
+    for (int k = 0; k < HV_PROB_K; ++k) v->logp[k] = i == k ? lp : v->logp[k];
+}
+template <bool CHAIN>
+__device__ __forceinline__ HvProbPair prob_get_r(const HvProbVoxel *v, const HvProbNode *nodes, int i) {
+    HvProbPair p = prob_slot_get(v, i); // (for i >= HV_PROB_K: slot 0, replaced below)
+    if (CHAIN && i >= HV_PROB_K) {
+        const HvProbNode *nd = prob_node_of(v, nodes, i);
+        p = HvProbPair{nd->obj[i], nd->cls[i], nd->logp[i]};
+    }
+    return p;
+}
+template <bool CHAIN>
+__device__ __forceinline__ void prob_set_logp_r(HvProbVoxel *v, HvProbNode *nodes, int i, float lp) {
+    if (!CHAIN || i < HV_PROB_K) {
+        prob_slot_set_logp(v, i, lp);
+        return;
+    }
+    HvProbNode *nd = (HvProbNode *)prob_node_of(v, nodes, i);
+    nd->logp[i] = lp;
+}
+// prob_argmax for the local copy: the same scan in slot order (inline slots first, then the chain)
+template <bool CHAIN>
+__device__ __forceinline__ int prob_argmax_r(const HvProbVoxel *v, const HvProbNode *nodes, int nlab) {
+    int best = -1;
+    HvProbPair bp{0, 0, 0.f};
+    auto take = [&](int i, const HvProbPair p) {
+        if (best < 0 || p.logp > bp.logp || (p.logp == bp.logp && prob_key(p.obj, p.cls) < prob_key(bp.obj, bp.cls))) {
+            best = i;
+            bp = p;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < HV_PROB_K; ++i) {
+        const HvProbPair p{v->obj[i], v->cls[i], v->logp[i]};
+        if (i < nlab) take(i, p);
+    }
+    if (CHAIN)
+        for (int i = HV_PROB_K; i < nlab; ++i) {
+            int j = i;
+            const HvProbNode *nd = prob_node_of(v, nodes, j);
+            take(i, HvProbPair{nd->obj[j], nd->cls[j], nd->logp[j]});
+        }
+    return best;
+}
 // One semantic observation folded into a probabilistic voxel: initialize_semantics_log_prob
 // (count == 0, voxel_data_semantic.h:311-324) or update_semantics_log_prob (:358-417).  Returns false when the pair is new and
 // cannot be stored (254 pairs, or the node pool is exhausted): the observation is dropped and counted.
@@ -237,18 +312,33 @@ __device__ inline bool prob_fold_t(HvProbVoxel *v, const HvTable &table, bool fi
     HvProbNode *nodes = (HvProbNode *)table.prob_nodes;
     int nlab = prob_nlab(v->meta), best = prob_best(v->meta);
     int idx = -1;
-    for (int i = 0; i < nlab; ++i) {
-        const HvProbPair p = prob_get<CHAIN>(v, nodes, i);
-        if (p.obj == obj && p.cls == cls) idx = i;
+#pragma unroll
+    for (int i = 0; i < HV_PROB_K; ++i) {
+        const bool hit = (int)(v->obj[i] == obj) & (int)(v->cls[i] == cls) & (int)(i < nlab);
+        idx = hit ? i : idx;
     }
-    float best_lp = best >= 0 ? prob_get<CHAIN>(v, nodes, best).logp : 0.f;
+    if (CHAIN)
+        for (int i = HV_PROB_K; i < nlab; ++i) {
+            int j = i;
+            const HvProbNode *nd = prob_node_of(v, nodes, j);
+            if (nd->obj[j] == obj && nd->cls[j] == cls) idx = i;
+        }
+    float best_lp = best >= 0 ? prob_get_r<CHAIN>(v, nodes, best).logp : 0.f;
     if (idx < 0) {
         // a new pair goes to index nlab: inline, or in the chain's node (nlab - K) / NK, which may have to be linked in first
         if (nlab >= HV_PROB_MAX) return false;
         if (CHAIN && nlab >= HV_PROB_K && (nlab - HV_PROB_K) % HV_PROB_NK == 0) {
-            uint32_t *link = &v->next;
-            for (int hop = (nlab - HV_PROB_K) / HV_PROB_NK; hop > 0; --hop) link = &nodes[*link - 1].next;
-            if (*link == 0u) { // (a chain left behind by a collapsed map is taken up again)
+            // the link the new node hangs on: the voxel's own `next`, or the last node's (no pointer into the local voxel is formed:
+            // one that may point there or into the node pool would pin the copy in memory)
+            const int hops = (nlab - HV_PROB_K) / HV_PROB_NK;
+            HvProbNode *tail = nullptr;
+            if (hops > 0) {
+                uint32_t n = v->next;
+                for (int hop = hops - 1; hop > 0; --hop) n = nodes[n - 1].next;
+                tail = &nodes[n - 1];
+            }
+            const uint32_t own_next = v->next;
+            if ((tail ? tail->next : own_next) == 0u) { // (a chain left behind by a collapsed map is taken up again)
                 if (nodes == nullptr) return false;
                 const int32_t id = atomicAdd(&table.counters[HV_CNT_PROB_NODES], 1);
                 if (id >= table.prob_node_cap) {
@@ -256,14 +346,13 @@ __device__ inline bool prob_fold_t(HvProbVoxel *v, const HvTable &table, bool fi
                     return false;
                 }
                 nodes[id].next = 0u;
-                *link = (uint32_t)id + 1u;
+                if (tail) tail->next = (uint32_t)id + 1u;
+                v->next = tail ? own_next : (uint32_t)id + 1u;
             }
         }
         idx = nlab++;
         if (!CHAIN || idx < HV_PROB_K) {
-            v->obj[idx] = obj;
-            v->cls[idx] = cls;
-            v->logp[idx] = lp;
+            prob_slot_set(v, idx, obj, cls, lp);
         } else {
             int j = idx;
             HvProbNode *nd = (HvProbNode *)prob_node_of(v, nodes, j);
@@ -276,23 +365,23 @@ __device__ inline bool prob_fold_t(HvProbVoxel *v, const HvTable &table, bool fi
         } else if (best >= 0) {
             if (lp > best_lp) best = idx;
         } else {
-            best = prob_argmax<CHAIN>(v, nodes, nlab);
+            best = prob_argmax_r<CHAIN>(v, nodes, nlab);
         }
     } else if (first) {
-        prob_set_logp<CHAIN>(v, nodes, idx, lp);
+        prob_set_logp_r<CHAIN>(v, nodes, idx, lp);
         best = idx;
     } else {
-        const float old = prob_get<CHAIN>(v, nodes, idx).logp;
+        const float old = prob_get_r<CHAIN>(v, nodes, idx).logp;
         const float now = old + lp;
-        prob_set_logp<CHAIN>(v, nodes, idx, now);
+        prob_set_logp_r<CHAIN>(v, nodes, idx, now);
         if (best >= 0) {
             if (idx == best) {
-                if (now < old) best = prob_argmax<CHAIN>(v, nodes, nlab);
+                if (now < old) best = prob_argmax_r<CHAIN>(v, nodes, nlab);
             } else if (now > best_lp) {
                 best = idx;
             }
         } else {
-            best = prob_argmax<CHAIN>(v, nodes, nlab);
+            best = prob_argmax_r<CHAIN>(v, nodes, nlab);
         }
     }
     v->meta = prob_meta(nlab, best);

@@ -274,11 +274,16 @@ __device__ __forceinline__ void semb_sort_window(uint32_t *s_src, uint32_t *s_ds
     hv_wave_lds_sync();
 }
 
+// (register budget of the two fold kernels: 4 waves per SIMD = 128 registers.  With the probabilistic voxel held in registers - round
+// 5, hv_semantic.h - the allocator would take 130-134 and drop to 3 waves)
+#ifndef HV_SEMB_FOLD_MIN_WAVES
+#define HV_SEMB_FOLD_MIN_WAVES 4
+#endif
 // One wave per touched block: its bucket is brought into (voxel, point index) order in the wave's LDS window (semb_sort_window)
 // and the head lane of every voxel run folds the run in point order - the reference's sequential order, bit-identical to the radix
 // path.  Buckets beyond the window go to k_semb_fold_tasks (or, without a task list, through voxel ranges / point windows here).
 template <typename VOX, typename PT, int COLOR_KIND>
-__global__ __launch_bounds__(256) void k_semb_fold_wave(HvTable table, VOX *__restrict__ pool, const int32_t *__restrict__ touched, int parity,
+__global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_wave(HvTable table, VOX *__restrict__ pool, const int32_t *__restrict__ touched, int parity,
                                                          unsigned long long *__restrict__ cursor_and_len, int32_t *__restrict__ cnt,
                                                          const int32_t *__restrict__ cur, const uint32_t *__restrict__ entries,
                                                          HvSemParams G, const PT *__restrict__ pts, const void *__restrict__ cols,
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(256) void k_semb_fold_wave(HvTable table, VOX *__re
 // (ballot compaction, four loads in flight), sorted and folded like a small bucket; a range that overflows the window goes through
 // point-index windows.
 template <typename VOX, typename PT, int COLOR_KIND>
-__global__ __launch_bounds__(256) void k_semb_fold_tasks(HvTable table, VOX *__restrict__ pool, const int32_t *__restrict__ task_count,
+__global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_tasks(HvTable table, VOX *__restrict__ pool, const int32_t *__restrict__ task_count,
                                                           const int4 *__restrict__ tasks, int parity, int task_cap,
                                                           const uint32_t *__restrict__ entries, HvSemParams G, const PT *__restrict__ pts,
                                                           const void *__restrict__ cols, const int32_t *__restrict__ class_ids,
