@@ -247,7 +247,7 @@ struct HvAssocParams {
 // voxel slots of which 7 % hold a voxel: the thread-per-slot form spent 0.7 - 1.0 ms per keyframe on per-wave overhead - cull,
 // ballots, appends - for 950 k waves of mostly empty slots).
 template <typename VOX, bool QUAD>
-__global__ __launch_bounds__(256) void k_sem_assoc_vote(HvTable table, VOX *__restrict__ pool, int64_t n_blocks,
+__global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *__restrict__ pool, int64_t n_blocks,
                                                          HvSemParams G, HvQuery Q, const int32_t *__restrict__ cls_img,
                                                          const int32_t *__restrict__ inst_img,
                                                          const float *__restrict__ depth, HvAssocParams A,
