@@ -28,6 +28,10 @@ cut -c1-120 $R/gpurun_out/sem_kernel_stats.csv | head -14
 timeout 250 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/sem2_kt -o sem -- python $R/tools/bench_semantic.py --frames 5 --cpu-frames 0 --voxel 0.002 --config scannet_1296x968_2mm --stride 2 > $R/gpurun_out/bench_semantic_scannet_profiled.json 2>/dev/null
 find $R/gpurun_out/sem2_kt -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/sem_scannet_kernel_stats.csv \;
 cut -c1-120 $R/gpurun_out/sem_scannet_kernel_stats.csv | head -10
+# the fills of those two profiles, split into per-keyframe ones and one-off set-up
+python $R/tools/memset_split.py $R/gpurun_out/sem_kt > $R/gpurun_out/memset_split_semantic.json 2>/dev/null
+python $R/tools/memset_split.py $R/gpurun_out/sem2_kt > $R/gpurun_out/memset_split_semantic_scannet_2mm.json 2>/dev/null
+cut -c1-400 $R/gpurun_out/memset_split_semantic_scannet_2mm.json
 # semantic flow: HBM traffic per kernel (two --pmc passes each, counters only)
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/sem_pmc_$C -o pmc -- python $R/tools/bench_semantic.py --frames 10 --cpu-frames 0 > /dev/null 2>&1

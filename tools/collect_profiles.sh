@@ -26,4 +26,5 @@ cp gpurun_out/valu_issue_rates.txt $P/valu_issue_rates.txt 2>/dev/null
 cp gpurun_out/ns1_mfma.json $P/ns1_mfma.json 2>/dev/null
 cp gpurun_out/ns1_kernel_stats.csv $P/kernel_stats_ns1.csv 2>/dev/null
 cp gpurun_out/bench_nccl1_owner.json gpurun_out/bench_nccl1_tile.json $P/ 2>/dev/null
+cp gpurun_out/memset_split_semantic.json gpurun_out/memset_split_semantic_scannet_2mm.json $P/ 2>/dev/null
 ls -la $P
