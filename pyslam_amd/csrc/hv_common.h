@@ -97,6 +97,21 @@ struct HvTable {
     int32_t prob_node_cap;  // (0 / nullptr in every other mode)
 };
 
+// Device view of a call's point bins (grid modes; hv_bins.h).
+struct HvBins {
+    int32_t *cnt;                // [table_capacity] points of this call per slot; zero between calls (the fold clears what it reads)
+    uint32_t *inl;               // [table_capacity][HV_BIN_K0]
+    int32_t *touched;            // [HV_BIN_LISTS][touched_cap] slots that took points in this call
+    int32_t *len;                // [2 parities][HV_BIN_LISTS * HV_BIN_LEN_STRIDE] list lengths
+    unsigned long long *pg_keys; // [pg_mask + 1]  epoch << 40 | slot << 16 | page number
+    uint32_t *pg_data;           // [pg_mask + 1][HV_BIN_PG]
+    uint32_t pg_mask;
+    uint32_t epoch;              // this call's (1 .. HV_BIN_EPOCHS)
+    int32_t touched_cap;
+    int32_t idx_bits;            // entry = local voxel index << idx_bits | point index
+    int32_t parity;              // which set of list lengths this call appends to (the fold zeroes the other one)
+};
+
 enum {
     HV_CNT_BLOCKS = 0,   // allocated blocks
     HV_CNT_OVERFLOW = 1, // pool/table overflow events
@@ -376,12 +391,14 @@ struct hv_volume {
     uint32_t *sort_vals_in = nullptr, *sort_vals_out = nullptr;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
-    // per-frame bucket path of the VOXEL_GRID mode (hv_voxel_grid.hip): per-slot point counts / bucket cursors, the list of
-    // slots a frame touches; sized by the table, re-allocated when it grows
-    int32_t *vg_cnt = nullptr, *vg_cur = nullptr, *vg_touched = nullptr;
-    unsigned long long *vg_cursor = nullptr; // [2] per frame parity: bucket cursor (low 32 bits) | touched-list length (high 32 bits)
-    uint64_t vg_cap = 0;
-    int vg_parity = 0;               // which of the two touched-list counters the next frame appends to
+    // per-call point bins of the grid modes (hv_bins.h): per-slot counts and inline entries sized by the table (re-made when it
+    // moves), overflow pages and records sized by max_points
+    HvBins bins{};
+    uint64_t bins_cap = 0;           // table capacity the per-slot arrays were made for
+    bool bins_clean = false;         // counts and list lengths are zero (false after a reset / rebuild / aborted claim pass)
+    uint32_t bins_epoch = 0;
+    void *bin_rec = nullptr;         // [max_points] packed per-point records the bin pass leaves for the fold (16 or 32 bytes each)
+    size_t bin_rec_bytes = 0;
     float *scratch_points = nullptr; // [max_points*3]
     float *scratch_colors = nullptr; // [max_points*3]
     int local_bits = 9;

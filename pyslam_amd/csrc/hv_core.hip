@@ -696,7 +696,7 @@ void hv_destroy(hv_volume *v) {
                     v->touched_stamp, v->touched_list, v->touched_mask, v->frame_px,
                     v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                     v->sort_vals_out, v->sort_tmp, v->scratch_points, v->scratch_colors, v->out_a,
-                    v->out_b, v->out_c, v->sweep_done, v->params_ring, v->list_sorted, v->touch_ticket, v->batch_buf, v->assoc_buf, v->mult_table, v->vg_cnt, v->vg_cur, v->vg_touched, v->vg_cursor, v->batch_buf2, v->batch_buf3, v->unit_masks, v->plan_buf, v->occ, v->semb_tasks, v->table.prob_nodes};
+                    v->out_b, v->out_c, v->sweep_done, v->params_ring, v->list_sorted, v->touch_ticket, v->batch_buf, v->assoc_buf, v->mult_table, v->bins.cnt, v->bins.inl, v->bins.touched, v->bins.len, v->bins.pg_keys, v->bins.pg_data, v->bin_rec, v->batch_buf2, v->batch_buf3, v->unit_masks, v->plan_buf, v->occ, v->semb_tasks, v->table.prob_nodes};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (v->h_counters) (void)hipHostFree(v->h_counters);
@@ -759,7 +759,7 @@ int hv_reset(hv_volume *v) {
     v->max_new_per_call = 0;
     v->avg_new_per_call = 0.0;
     v->status_exact = true;
-    v->vg_cap = 0; // the VOXEL_GRID bucket arrays restart clean (list counters were zeroed with the counter block)
+    v->bins_clean = false; // the grid modes' per-call bins restart clean (hv_bins_ensure)
     v->last_touch_parity = 0;
     v->touch_counters_clean = true;
     v->overflow_latched = false;
@@ -938,6 +938,7 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
     v->known_blocks = used;
     v->status_exact = true;
     v->overflow_latched = false;
+    v->bins_clean = false; // grid modes: the per-slot bin arrays follow the table (hv_bins_ensure re-makes / clears them)
     return HV_OK;
 }
 
@@ -1005,7 +1006,7 @@ static int hv_rollback_claims(hv_volume *v, int64_t keep) {
     v->known_blocks = keep;
     v->status_exact = true;
     v->overflow_latched = false;
-    v->vg_cap = 0; // grid modes: the per-slot bucket arrays are keyed by slots that just moved - re-made by the next frame
+    v->bins_clean = false; // grid modes: the per-slot bin arrays are keyed by slots that just moved - re-made / cleared by the next call
     return HV_OK;
 }
 

@@ -21,7 +21,8 @@
 #include "hv_common.h"
 #include "hv_query.h"
 #include "hv_semantic.h"
-#include "hv_bucket.h"
+#include "hv_bins.h"
+#include "hv_unproject.h"
 #include <rocprim/device/device_radix_sort.hpp>
 
 static constexpr uint32_t HV_SORT_SENTINEL = 0xFFFFFFFFu;
@@ -74,44 +75,104 @@ __global__ __launch_bounds__(256) void k_sem_keys(HvTable table, const PT *__res
     keys_out[i] = key;
 }
 
+// What the fold learns about one point.  Two sources: the caller's arrays (points float32 | float64, colours none | uint8 | float32,
+// class / instance ids, depths - the binding's integrate overloads, volumetric_grid_module.h:131-467), or the packed 32-byte record
+// the frame entry point's bin pass leaves per pixel (round 6: two 16-byte loads per point where the arrays take seven scalar ones).
+struct HvSemPoint {
+    double x, y, z;
+    float c0, c1, c2;
+    int32_t cls, obj;
+    float depth;
+};
+template <typename PT, int COLOR_KIND>
+struct HvSemArrays {
+    const PT *__restrict__ pts;
+    const void *__restrict__ cols;
+    const int32_t *__restrict__ class_ids;
+    const int32_t *__restrict__ instance_ids;
+    const float *__restrict__ depths;
+    static constexpr bool kColors = COLOR_KIND != HV_COLOR_NONE;
+    __device__ __forceinline__ bool has_labels() const { return class_ids != nullptr; }
+    __device__ __forceinline__ bool has_depth() const { return depths != nullptr; }
+    __device__ __forceinline__ HvSemPoint get(int64_t p) const {
+        HvSemPoint q;
+        q.x = (double)pts[p * 3 + 0];
+        q.y = (double)pts[p * 3 + 1];
+        q.z = (double)pts[p * 3 + 2];
+        q.c0 = q.c1 = q.c2 = 0.f;
+        const float inv_255 = 1.0f / 255.0f; // voxel_data.h:82
+        if (COLOR_KIND == HV_COLOR_U8) {
+            const uint8_t *c = (const uint8_t *)cols + p * 3;
+            q.c0 = (float)c[0] * inv_255;
+            q.c1 = (float)c[1] * inv_255;
+            q.c2 = (float)c[2] * inv_255;
+        } else if (COLOR_KIND == HV_COLOR_F32) {
+            const float *c = (const float *)cols + p * 3;
+            q.c0 = c[0];
+            q.c1 = c[1];
+            q.c2 = c[2];
+        }
+        q.cls = class_ids ? class_ids[p] : 0;
+        q.obj = instance_ids ? instance_ids[p] : 0;
+        q.depth = depths ? depths[p] : 0.0f;
+        return q;
+    }
+};
+// record: {x, y, z, rgb8 | class, instance, depth, -}; colours through the fold's 256-entry table of (float)(c / 255.0) (depth.py:76)
+struct HvSemRecs {
+    const float4 *__restrict__ rec;
+    const float *lut; // LDS
+    bool labels, depth;
+    static constexpr bool kColors = true;
+    __device__ __forceinline__ bool has_labels() const { return labels; }
+    __device__ __forceinline__ bool has_depth() const { return depth; }
+    __device__ __forceinline__ HvSemPoint get(int64_t p) const {
+        const float4 a = rec[2 * p], b = rec[2 * p + 1];
+        HvSemPoint q;
+        q.x = (double)a.x;
+        q.y = (double)a.y;
+        q.z = (double)a.z;
+        const uint32_t c = __float_as_uint(a.w);
+        q.c0 = lut[c & 255u];
+        q.c1 = lut[(c >> 8) & 255u];
+        q.c2 = lut[(c >> 16) & 255u];
+        q.cls = (int32_t)__float_as_uint(b.x);
+        q.obj = (int32_t)__float_as_uint(b.y);
+        q.depth = b.z;
+        return q;
+    }
+};
+
 // update_voxel_direct (voxel_block_grid.hpp:524-614) for a SemanticVoxelWithDepth payload: one voxel's points folded in
 // point-index order.  `next(j)` yields the point index of the run's j-th entry, or -1 at its end.  VOX = HvSemVoxel (voting) or
 // HvProbVoxel (probabilistic).
-template <typename VOX, typename PT, int COLOR_KIND, typename Next>
+template <typename VOX, typename SRC, typename Next>
 __device__ __forceinline__ void sem_fold_run(const HvTable &table, VOX *__restrict__ pool, int64_t vid, const HvSemParams &G,
-                                             const PT *__restrict__ pts, const void *__restrict__ cols,
-                                             const int32_t *__restrict__ class_ids, const int32_t *__restrict__ instance_ids,
-                                             const float *__restrict__ depths, unsigned long long *__restrict__ occ, Next next) {
+                                             const SRC &src, unsigned long long *__restrict__ occ, Next next) {
     // the voxel is read once, folded in registers and written once: with the label state updated in memory point by point the
     // loads of the next point could not be issued before the stores of this one (they may alias): one memory round trip per point
     VOX acc = pool[vid];
     int32_t count = acc.count;
     if (count == 0) atomicOr(&occ[vid >> 6], 1ull << (vid & 63)); // first point of this voxel (or the first after a reset)
-    const float inv_255 = 1.0f / 255.0f;
     int overflowed = 0;
+    const bool labels = src.has_labels(), with_depth = src.has_depth();
     for (int j = 0;; ++j) {
         const int64_t p = next(j);
         if (p < 0) break;
-        acc.pos[0] += (double)pts[p * 3 + 0];
-        acc.pos[1] += (double)pts[p * 3 + 1];
-        acc.pos[2] += (double)pts[p * 3 + 2];
-        if (COLOR_KIND == HV_COLOR_U8) {
-            const uint8_t *c = (const uint8_t *)cols + p * 3;
-            acc.col[0] += (float)c[0] * inv_255;
-            acc.col[1] += (float)c[1] * inv_255;
-            acc.col[2] += (float)c[2] * inv_255;
-        } else if (COLOR_KIND == HV_COLOR_F32) {
-            const float *c = (const float *)cols + p * 3;
-            acc.col[0] += c[0];
-            acc.col[1] += c[1];
-            acc.col[2] += c[2];
+        const HvSemPoint q = src.get(p);
+        acc.pos[0] += q.x;
+        acc.pos[1] += q.y;
+        acc.pos[2] += q.z;
+        if (SRC::kColors) {
+            acc.col[0] += q.c0;
+            acc.col[1] += q.c1;
+            acc.col[2] += q.c2;
         }
-        if (class_ids != nullptr) {
-            const int32_t obj = instance_ids ? instance_ids[p] : 0;
-            const int32_t cls = class_ids[p];
+        if (labels) {
+            const int32_t obj = q.obj, cls = q.cls;
             if constexpr (sizeof(VOX) == sizeof(HvSemVoxel)) {
                 HvSemVoxel *sv = (HvSemVoxel *)&acc;
-                const bool gate = depths ? (depths[p] < G.depth_threshold) : true; // *_with_depth, voxel_data_semantic.h:168-198
+                const bool gate = with_depth ? (q.depth < G.depth_threshold) : true; // *_with_depth, voxel_data_semantic.h:168-198
                 if (count == 0) {
                     if (gate) { // initialize_semantics
                         sv->obj1 = obj + 1;
@@ -131,7 +192,7 @@ __device__ __forceinline__ void sem_fold_run(const HvTable &table, VOX *__restri
                     }
                 }
             } else {
-                const float lp = prob_observation_log_prob(depths != nullptr, depths ? depths[p] : 0.0f, G);
+                const float lp = prob_observation_log_prob(with_depth, q.depth, G);
                 if (!prob_fold((HvProbVoxel *)&acc, table, count == 0, obj, cls, lp)) ++overflowed;
             }
         }
@@ -158,58 +219,77 @@ __global__ __launch_bounds__(256) void k_sem_reduce(HvTable table, VOX *__restri
     const int32_t idx = table.vals[(int32_t)(key >> G.local_bits)];
     if (idx < 0) return;
     const int64_t vid = (int64_t)idx * G.nvox + (key & ((1u << G.local_bits) - 1u));
-    sem_fold_run<VOX, PT, COLOR_KIND>(table, pool, vid, G, pts, cols, class_ids, instance_ids, depths, occ,
-                                      [&](int j) -> int64_t { return (i + j < n && keys[i + j] == key) ? (int64_t)vals[i + j] : -1; });
+    const HvSemArrays<PT, COLOR_KIND> src{pts, cols, class_ids, instance_ids, depths};
+    sem_fold_run<VOX>(table, pool, vid, G, src, occ,
+                      [&](int j) -> int64_t { return (i + j < n && keys[i + j] == key) ? (int64_t)vals[i + j] : -1; });
 }
 
-// ---- per-keyframe bucket path (hv_bucket.h): count -> offsets -> scatter -> fold (+ the big buckets' ranges), 5 launches instead of the radix sort's ~20 ----
+// ---- per-keyframe bin path (hv_bins.h): bin -> fold (+ the big bins' ranges), 3 launches instead of the radix sort's ~20 (rounds 4-5:
+// count -> offsets -> scatter -> fold + tasks, and a separate unprojection launch in front of them) ----
 // entries are (local voxel index << IB | point index) with IB = 32 - local_bits (23 for 8^3 blocks: 8 M points per call)
+__device__ __forceinline__ bool sem_point_block(const HvSemParams &G, double px, double py, double pz, bool is_f64, unsigned long long &bkey,
+                                                uint32_t &lidx, bool &foreign) {
+    const double p[3] = {px, py, pz};
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) ok = ok && isfinite(p[a]) && fabs(p[a] * (double)G.inv_voxel_size) < 1.0e9;
+    if (!ok) return false;
+    int32_t b[3], l[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int32_t v = is_f64 ? sem_voxel_coord(p[a], G.inv_voxel_size) : sem_voxel_coord((float)p[a], G.inv_voxel_size);
+        b[a] = sem_floor_div(v, G.bs);
+        l[a] = (int32_t)((int64_t)v - (int64_t)b[a] * G.bs);
+    }
+    if (!hv_key_in_range(b[0], b[1], b[2])) return false;
+    bkey = hv_pack_key(b[0], b[1], b[2]);
+    foreign = G.owner_world > 1 && hv_owner_of(bkey, G.owner_world) != G.owner_rank;
+    lidx = (uint32_t)(l[0] + l[1] * G.bs + l[2] * G.bs * G.bs);
+    return !foreign;
+}
+
 template <typename PT>
-__global__ __launch_bounds__(256) void k_semb_count(HvTable table, const PT *__restrict__ pts, int64_t n, HvSemParams G,
-                                                     int32_t *__restrict__ pslot, uint32_t *__restrict__ plidx,
-                                                     const uint32_t *__restrict__ valid_mask_keys, int32_t *__restrict__ cnt) {
+__global__ __launch_bounds__(256) void k_semb_bin(HvTable table, HvBins B, const PT *__restrict__ pts, int64_t n, HvSemParams G,
+                                                   const uint32_t *__restrict__ valid_mask_keys) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int32_t slot = -1;
+    bool has = false;
+    unsigned long long bkey = 0ull;
     uint32_t lidx = 0;
     if (i < n && !(valid_mask_keys != nullptr && valid_mask_keys[i] == HV_SORT_SENTINEL)) {
-        const PT p[3] = {pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]};
-        bool ok = true, foreign = false;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) ok = ok && isfinite((double)p[a]) && fabs((double)p[a] * (double)G.inv_voxel_size) < 1.0e9;
-        if (ok) {
-            int32_t b[3], l[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const int32_t v = sem_voxel_coord(p[a], G.inv_voxel_size);
-                b[a] = sem_floor_div(v, G.bs);
-                l[a] = (int32_t)((int64_t)v - (int64_t)b[a] * G.bs);
-            }
-            if (hv_key_in_range(b[0], b[1], b[2])) {
-                const unsigned long long bkey = hv_pack_key(b[0], b[1], b[2]);
-                foreign = G.owner_world > 1 && hv_owner_of(bkey, G.owner_world) != G.owner_rank;
-                if (!foreign) slot = hv_table_insert(table, bkey);
-                lidx = (uint32_t)(l[0] + l[1] * G.bs + l[2] * G.bs * G.bs);
-            }
-        }
-        if (slot < 0 && !foreign) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
+        bool foreign = false;
+        has = sem_point_block(G, (double)pts[i * 3 + 0], (double)pts[i * 3 + 1], (double)pts[i * 3 + 2], sizeof(PT) == 8, bkey, lidx, foreign);
+        if (!has && !foreign) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
     }
-    if (i < n) {
-        pslot[i] = slot;
-        plidx[i] = lidx;
-    }
-    const HvWaveGroup g = hv_wave_group_by(slot);
-    if (g.leader) atomicAdd(&cnt[slot], g.size);
+    hv_bins_push(table, B, has, bkey, lidx, (uint32_t)i);
 }
 
-__global__ __launch_bounds__(256) void k_semb_scatter(const int32_t *__restrict__ pslot, const uint32_t *__restrict__ plidx, int64_t n,
-                                                       int32_t *__restrict__ cur, uint32_t *__restrict__ entries, int idx_bits) {
+// The frame entry point's bin pass: the thread unprojects its pixel (depth2pointcloud + world transform, hv_unproject.h), packs
+// position, colour, labels and depth into the pixel's 32-byte record and goes on with the key - the unprojection launch, its 24-byte
+// point / colour rows and the fold's seven scalar gathers per point are gone.
+__global__ __launch_bounds__(256) void k_semb_bin_frame(HvTable table, HvBins B, HvSemParams G, HvUnprojectParams U,
+                                                        const void *__restrict__ depth_raw, const uint8_t *__restrict__ rgb,
+                                                        const int32_t *__restrict__ cls_img, const int32_t *__restrict__ obj_img,
+                                                        float4 *__restrict__ rec) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int32_t slot = i < n ? pslot[i] : -1;
-    const HvWaveGroup g = hv_wave_group_by(slot);
-    int32_t base = 0;
-    if (g.leader) base = atomicAdd(&cur[slot], g.size);
-    base = __shfl(base, g.leader_lane);
-    if (slot >= 0) entries[base + g.rank] = (plidx[i] << idx_bits) | (uint32_t)i;
+    bool has = false;
+    unsigned long long bkey = 0ull;
+    uint32_t lidx = 0;
+    float pt[3];
+    if (i < (int64_t)U.H * U.W && hv_unproject_point(U, depth_raw, i, pt)) {
+        bool foreign = false;
+        has = sem_point_block(G, (double)pt[0], (double)pt[1], (double)pt[2], false, bkey, lidx, foreign);
+        if (!has && !foreign) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
+        if (has) {
+            const uint8_t *c = rgb + i * 3;
+            const uint32_t packed = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+            const int32_t cls = cls_img ? cls_img[i] : 0, obj = obj_img ? obj_img[i] : 0;
+            // depths = camera z of the point = the pixel's depth (…voxel_semantic_grid.py:418-424)
+            const float d = U.depth_is_u16 ? (float)((const uint16_t *)depth_raw)[i] : ((const float *)depth_raw)[i];
+            rec[2 * i] = make_float4(pt[0], pt[1], pt[2], __uint_as_float(packed));
+            rec[2 * i + 1] = make_float4(__uint_as_float((uint32_t)cls), __uint_as_float((uint32_t)obj), d, 0.f);
+        }
+    }
+    hv_bins_push(table, B, has, bkey, lidx, (uint32_t)i);
 }
 
 // Entries s_src[0 .. m) of ONE block into (voxel, point index) order, by a wave, in its LDS window: counting sort by voxel
@@ -279,24 +359,33 @@ __device__ __forceinline__ void semb_sort_window(uint32_t *s_src, uint32_t *s_ds
 #ifndef HV_SEMB_FOLD_MIN_WAVES
 #define HV_SEMB_FOLD_MIN_WAVES 4
 #endif
-// One wave per touched block: its bucket is brought into (voxel, point index) order in the wave's LDS window (semb_sort_window)
+// The fold's point source on the device: the arrays as they are, or the records with the workgroup's colour table (by all 256 threads).
+template <typename PT, int COLOR_KIND>
+__device__ __forceinline__ HvSemArrays<PT, COLOR_KIND> sem_src_prepare(const HvSemArrays<PT, COLOR_KIND> &src, float *) { return src; }
+__device__ __forceinline__ HvSemRecs sem_src_prepare(const HvSemRecs &src, float *lut) {
+    lut[threadIdx.x] = (float)((double)threadIdx.x / 255.0); // depth.py:76 (uint8 image / 255.0), cast to float32 by voxel_semantic_grid.py
+    __syncthreads();
+    HvSemRecs r = src;
+    r.lut = lut;
+    return r;
+}
+
+// One wave per touched block: its bin is brought into (voxel, point index) order in the wave's LDS window (semb_sort_window)
 // and the head lane of every voxel run folds the run in point order - the reference's sequential order, bit-identical to the radix
-// path.  Buckets beyond the window go to k_semb_fold_tasks (or, without a task list, through voxel ranges / point windows here).
-template <typename VOX, typename PT, int COLOR_KIND>
-__global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_wave(HvTable table, VOX *__restrict__ pool, const int32_t *__restrict__ touched, int parity,
-                                                         unsigned long long *__restrict__ cursor_and_len, int32_t *__restrict__ cnt,
-                                                         const int32_t *__restrict__ cur, const uint32_t *__restrict__ entries,
-                                                         HvSemParams G, const PT *__restrict__ pts, const void *__restrict__ cols,
-                                                         const int32_t *__restrict__ class_ids, const int32_t *__restrict__ instance_ids,
-                                                         const float *__restrict__ depths, unsigned long long *__restrict__ occ,
-                                                         int64_t n_points, int idx_bits, HvStatus *status, int32_t status_seq,
+// path.  Bins beyond the window go to k_semb_fold_tasks (or, without a task list, through voxel ranges / point windows here).
+template <typename VOX, typename SRC>
+__global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_wave(HvTable table, VOX *__restrict__ pool, HvBins B, HvSemParams G, SRC src_in,
+                                                         unsigned long long *__restrict__ occ, int64_t n_points, HvStatus *status, int32_t status_seq,
                                                          int32_t *__restrict__ task_count, int4 *__restrict__ tasks, int task_cap, int wcap) {
     extern __shared__ uint32_t s_dyn[]; // per wave: [wcap src][wcap dst][nvox + 64 offsets]; wcap = the window, a power of two (HV_SEM_WCAP)
-    const int n_touched = (int)(cursor_and_len[parity] >> 32);
+    __shared__ float s_lut[256];
+    const SRC src = sem_src_prepare(src_in, s_lut);
+    const int idx_bits = B.idx_bits, parity = B.parity;
+    const HvBinLists L = hv_bins_lists(B);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         task_count[parity ^ 1] = 0;        // the next call's task list
-        cursor_and_len[parity ^ 1] = 0ull; // the next call's bucket cursor and list length
-        table.counters[HV_CNT_OUT2] = 0;   // (k_vgb_offsets' largest-bucket mark: the association uses this counter too)
+        hv_bins_clear_next(B);             // the next call's list lengths
+        table.counters[HV_CNT_OUT2] = 0;   // (hv_bins_push's largest-bin mark: the association uses this counter too)
         hv_publish_status(table, status, status_seq);
     }
     const int wave = threadIdx.x >> 6, lane = hv_lane_id();
@@ -308,28 +397,27 @@ __global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_wave(
         for (int e = lane; e < m; e += HV_WAVE) {
             const uint32_t lidx = s[e] >> idx_bits;
             if (e > 0 && (s[e - 1] >> idx_bits) == lidx) continue; // not the head of its voxel's run
-            sem_fold_run<VOX, PT, COLOR_KIND>(table, pool, block_base + lidx, G, pts, cols, class_ids, instance_ids, depths, occ,
-                                              [&](int j) -> int64_t { return (e + j < m && (s[e + j] >> idx_bits) == lidx) ? (int64_t)(s[e + j] & idx_mask) : -1; });
+            sem_fold_run<VOX>(table, pool, block_base + lidx, G, src, occ,
+                              [&](int j) -> int64_t { return (e + j < m && (s[e + j] >> idx_bits) == lidx) ? (int64_t)(s[e + j] & idx_mask) : -1; });
         }
     };
-    for (int t = blockIdx.x * 4 + wave; t < n_touched; t += gridDim.x * 4) {
-        const int32_t slot = touched[t];
-        const int32_t nb = cnt[slot];
-        const int32_t start = cur[slot] - nb;
+    for (int t = blockIdx.x * 4 + wave; t < L.total; t += gridDim.x * 4) {
+        const int32_t slot = hv_bins_touched(B, L, t);
+        const int32_t nb = B.cnt[slot];
         const int32_t idx = table.vals[slot];
-        hv_wave_lds_sync(); // the window of the previous bucket is no longer read
-        if (lane == 0) cnt[slot] = 0; // clean for the next call
-        if (idx < 0) continue;        // (the block did not get a pool slot: overflow, reported by the caller)
+        hv_wave_lds_sync(); // the window of the previous bin is no longer read
+        if (lane == 0) B.cnt[slot] = 0; // clean for the next call
+        if (idx < 0) continue;          // (the block did not get a pool slot: overflow, reported by the caller)
         const int64_t block_base = (int64_t)idx * G.nvox;
         if (nb <= wcap) {
-            for (int e = lane; e < nb; e += HV_WAVE) s[e] = entries[start + e];
+            for (int e = lane; e < nb; e += HV_WAVE) s[e] = hv_bins_entry(B, slot, e);
             hv_wave_lds_sync();
             semb_sort_window(s, s_dst, off, nb, idx_bits, G.nvox);
             fold_sorted(nb, block_base);
             continue;
         }
         if (tasks != nullptr) {
-            // A bucket beyond the window (a wall at 0.7 m puts ~3 000 points of a 640x480 keyframe into one 8 cm block) would be a
+            // A bin beyond the window (a wall at 0.7 m puts ~3 000 points of a 640x480 keyframe into one 8 cm block) would be a
             // long serial job for this wave while the other waves of the launch have long left: it is cut into its voxel-index
             // ranges of 64 and handed to k_semb_fold_tasks, one wave per range.
             const int n_ranges = (G.nvox + 63) / 64;
@@ -337,7 +425,7 @@ __global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_wave(
             if (lane == 0) at = atomicAdd(&task_count[parity], n_ranges);
             at = __shfl(at, 0);
             if (at + n_ranges <= task_cap) {
-                if (lane < n_ranges) tasks[at + lane] = make_int4(idx, lane, nb, start);
+                if (lane < n_ranges) tasks[at + lane] = make_int4(idx, lane, nb, slot);
                 continue;
             }
             if (lane == 0) atomicSub(&task_count[parity], n_ranges); // (no room: this wave does it itself, below)
@@ -355,7 +443,7 @@ __global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_wave(
                 bool overflow = false;
                 for (int e0 = 0; e0 < nb; e0 += HV_WAVE) {
                     const int e = e0 + lane;
-                    const uint32_t ent = e < nb ? entries[start + e] : 0u;
+                    const uint32_t ent = e < nb ? hv_bins_entry(B, slot, e) : 0u;
                     const uint32_t li = ent >> idx_bits;
                     const int64_t p = ent & idx_mask;
                     const bool in = e < nb && li >= (uint32_t)lo && li < hi && (w < 0 || (p >= w && p < w + wcap));
@@ -382,18 +470,18 @@ __global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_wave(
     }
 }
 
-// The deferred big buckets: one wave per (block, range of 64 voxel indices).  The range's entries are picked out of the bucket
-// (ballot compaction, four loads in flight), sorted and folded like a small bucket; a range that overflows the window goes through
+// The deferred big bins: one wave per (block, range of 64 voxel indices).  The range's entries are picked out of the bin
+// (ballot compaction, four loads in flight), sorted and folded like a small bin; a range that overflows the window goes through
 // point-index windows.
-template <typename VOX, typename PT, int COLOR_KIND>
-__global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_tasks(HvTable table, VOX *__restrict__ pool, const int32_t *__restrict__ task_count,
-                                                          const int4 *__restrict__ tasks, int parity, int task_cap,
-                                                          const uint32_t *__restrict__ entries, HvSemParams G, const PT *__restrict__ pts,
-                                                          const void *__restrict__ cols, const int32_t *__restrict__ class_ids,
-                                                          const int32_t *__restrict__ instance_ids, const float *__restrict__ depths,
-                                                          unsigned long long *__restrict__ occ, int64_t n_points, int idx_bits, int wcap) {
+template <typename VOX, typename SRC>
+__global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_tasks(HvTable table, VOX *__restrict__ pool, HvBins B, const int32_t *__restrict__ task_count,
+                                                          const int4 *__restrict__ tasks, int task_cap, HvSemParams G, SRC src_in,
+                                                          unsigned long long *__restrict__ occ, int64_t n_points, int wcap) {
     extern __shared__ uint32_t s_dyn[];
-    const int n_tasks = min(task_count[parity], task_cap);
+    __shared__ float s_lut[256];
+    const SRC src = sem_src_prepare(src_in, s_lut);
+    const int idx_bits = B.idx_bits;
+    const int n_tasks = min(task_count[B.parity], task_cap);
     const int wave = threadIdx.x >> 6, lane = hv_lane_id();
     const int per_wave = 2 * wcap + G.nvox + 64;
     uint32_t *s = s_dyn + wave * per_wave, *s_dst = s + wcap, *off = s + 2 * wcap;
@@ -403,13 +491,13 @@ __global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_tasks
         const int4 task = tasks[t];
         const int64_t block_base = (int64_t)task.x * G.nvox;
         const uint32_t lo = (uint32_t)task.y * 64u, hi = lo + 64u;
-        const int nb = task.z, start = task.w;
+        const int nb = task.z, slot = task.w;
         auto fold_sorted = [&](int m) {
             for (int e = lane; e < m; e += HV_WAVE) {
                 const uint32_t lidx = s[e] >> idx_bits;
                 if (e > 0 && (s[e - 1] >> idx_bits) == lidx) continue;
-                sem_fold_run<VOX, PT, COLOR_KIND>(table, pool, block_base + lidx, G, pts, cols, class_ids, instance_ids, depths, occ,
-                                                  [&](int j) -> int64_t { return (e + j < m && (s[e + j] >> idx_bits) == lidx) ? (int64_t)(s[e + j] & idx_mask) : -1; });
+                sem_fold_run<VOX>(table, pool, block_base + lidx, G, src, occ,
+                                  [&](int j) -> int64_t { return (e + j < m && (s[e + j] >> idx_bits) == lidx) ? (int64_t)(s[e + j] & idx_mask) : -1; });
             }
         };
         for (int64_t w = -1; w < n_points; w += wcap) { // w = -1: the whole range at once; on overflow: point-index windows
@@ -421,7 +509,7 @@ __global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_tasks
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { // four independent loads in flight
                     const int e = e0 + k * HV_WAVE + lane;
-                    ent[k] = e < nb ? entries[start + e] : 0xFFFFFFFFu;
+                    ent[k] = e < nb ? hv_bins_entry(B, slot, e) : 0xFFFFFFFFu;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -556,6 +644,64 @@ static int sem_sort_bits(const hv_volume *v) {
     return std::min(32, slot_bits + v->local_bits + 1);
 }
 
+// The fold's LDS window per wave (entries): bins beyond it go to the task kernel as voxel ranges.  512 (HV_SEM_WCAP) leaves
+// room for the 16 waves per CU the kernel's registers allow (1024: 12 waves)
+static int sem_wcap() {
+    int wcap = getenv("HV_SEM_WCAP") ? atoi(getenv("HV_SEM_WCAP")) : 512;
+    return (wcap != 256 && wcap != 512 && wcap != 1024) ? 512 : wcap;
+}
+static size_t sem_fold_lds(int wcap, int nvox) { return 4 * sizeof(uint32_t) * (size_t)(2 * wcap + nvox + 64); } // two windows + per-voxel offsets per wave
+static bool sem_bins_usable(const hv_volume *v, int64_t n) {
+    const char *force = getenv("HV_SEM_PATH"); // HV_SEM_PATH=sort keeps the device-wide radix sort: A/B, tests
+    const int nvox = v->cfg.block_size * v->cfg.block_size * v->cfg.block_size;
+    return hv_bins_usable(v, n, 32 - v->local_bits) && sem_fold_lds(sem_wcap(), nvox) <= 64 * 1024 && !(force && strcmp(force, "sort") == 0);
+}
+
+// The bin path's launches after the capacity gate: `bin(B)` launches the bin pass (arrays or frame), then the fold over `src`.
+template <typename VOX, typename SRC, typename BinLaunch>
+static int sem_bins_run(hv_volume *v, int64_t n, bool checked, const SRC &src, BinLaunch bin) {
+    const HvSemParams G = sem_params(v);
+    const int idx_bits = 32 - v->local_bits;
+    const int wcap = sem_wcap();
+    const size_t lds_bytes = sem_fold_lds(wcap, G.nvox);
+    int rc = HV_OK;
+    HvBins B{};
+    for (int attempt = 0;; ++attempt) {
+        rc = hv_bins_ensure(v);
+        if (rc != HV_OK) return rc;
+        B = hv_bins_begin(v, idx_bits);
+        bin(B);
+        if (!checked) break;
+        rc = hv_claims_fit(v); // blocks that did not fit: grow and claim again (the bins restart from clean arrays)
+        if (rc == HV_OK) break;
+        v->bins_clean = false;
+        if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
+    }
+    v->bins.parity ^= 1;
+    const int32_t seq = hv_next_status_seq(v);
+    const unsigned fold_grid = (unsigned)std::min<int64_t>(std::max<int64_t>(n / 128, 256), 16384);
+    VOX *bpool = (VOX *)v->pool;
+    // task list of the big bins: [2 counters (one per parity)][tasks]; at most n / wcap bins are big
+    const int task_cap = (int)std::min<int64_t>((n / wcap + 1) * ((G.nvox + 63) / 64), 1 << 22);
+    const size_t task_bytes = 256 + sizeof(int4) * (size_t)task_cap;
+    if (v->semb_tasks == nullptr || v->semb_tasks_bytes < task_bytes) {
+        rc = hv_ensure_buffer(v, &v->semb_tasks, &v->semb_tasks_bytes, task_bytes);
+        if (rc != HV_OK) return rc;
+        HV_HIP(hipMemsetAsync(v->semb_tasks, 0, 256, v->stream));
+    }
+    int32_t *task_count = (int32_t *)v->semb_tasks;
+    int4 *tasks = (int4 *)((char *)v->semb_tasks + 256);
+    const bool use_tasks = !(getenv("HV_SEM_TASKS") && atoi(getenv("HV_SEM_TASKS")) == 0);
+    hipLaunchKernelGGL((k_semb_fold_wave<VOX, SRC>), dim3(fold_grid), dim3(256), lds_bytes, v->stream, v->table, bpool, B, G, src, v->occ, n,
+                       v->d_status, seq, task_count, use_tasks ? tasks : (int4 *)nullptr, task_cap, wcap);
+    if (use_tasks)
+        hipLaunchKernelGGL((k_semb_fold_tasks<VOX, SRC>), dim3(1024), dim3(256), lds_bytes, v->stream, v->table, bpool, B,
+                           (const int32_t *)task_count, (const int4 *)tasks, task_cap, G, src, v->occ, n, wcap);
+    HV_HIP(hipGetLastError());
+    v->frame_counter += 1;
+    return HV_OK;
+}
+
 template <typename VOX, typename PT>
 static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d_cols, int color_kind,
                          const int32_t *d_cls, const int32_t *d_inst, const float *d_depths,
@@ -565,69 +711,16 @@ static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d
     bool checked = false;
     int rc = hv_capacity_gate(v, &checked); // may grow the pool: the sort-key width follows the table
     if (rc != HV_OK) return rc;
-    // Per-keyframe bucket path (round 4; HV_SEM_PATH=sort keeps the device-wide radix sort: A/B, tests): needs the point index
-    // and the local voxel index in one 32-bit entry.
-    const int idx_bits = 32 - v->local_bits;
-    const char *force = getenv("HV_SEM_PATH");
-    // The fold's LDS window per wave (entries): buckets beyond it go to the task kernel as voxel ranges.  512 (HV_SEM_WCAP) leaves
-    // room for the 16 waves per CU the kernel's registers allow (1024: 12 waves)
-    int wcap = getenv("HV_SEM_WCAP") ? atoi(getenv("HV_SEM_WCAP")) : 512;
-    if (wcap != 256 && wcap != 512 && wcap != 1024) wcap = 512;
-    const size_t fold_lds = 4 * sizeof(uint32_t) * (size_t)(2 * wcap + G.nvox + 64); // two windows + per-voxel offsets per wave
-    if (n < (1ll << idx_bits) && n <= (int64_t)v->cfg.max_points && fold_lds <= 64 * 1024 && !(force && strcmp(force, "sort") == 0)) {
-        int parity = 0;
-        for (int attempt = 0;; ++attempt) {
-            rc = ensure_bucket_buffers(v);
-            if (rc != HV_OK) return rc;
-            parity = v->vg_parity;
-            hipLaunchKernelGGL(k_semb_count<PT>, dim3(blocks), dim3(256), 0, v->stream, v->table, d_pts, n, G, (int32_t *)v->sort_vals_in,
-                               v->sort_keys_out, valid_mask_keys, v->vg_cnt);
-            if (!checked) break;
-            rc = hv_claims_fit(v); // blocks that did not fit: grow and claim again (the counts restart from clean arrays)
-            if (rc == HV_OK) break;
-            v->vg_cap = 0;
-            if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
-        }
-        v->vg_parity ^= 1;
-        const unsigned list_blocks = (unsigned)((v->cfg.max_blocks + 255) / 256);
-        hipLaunchKernelGGL(k_vgb_offsets, dim3(list_blocks), dim3(256), 0, v->stream, v->table, v->vg_touched, v->vg_cursor + parity,
-                           (const int32_t *)v->vg_cnt, v->vg_cur);
-        hipLaunchKernelGGL(k_semb_scatter, dim3(blocks), dim3(256), 0, v->stream, (const int32_t *)v->sort_vals_in,
-                           (const uint32_t *)v->sort_keys_out, n, v->vg_cur, v->sort_keys_in, idx_bits);
-        const int32_t seq = hv_next_status_seq(v);
-        const unsigned fold_grid = (unsigned)std::min<int64_t>(std::max<int64_t>(n / 128, 256), 16384);
-        VOX *bpool = (VOX *)v->pool;
-        // task list of the big buckets: [2 counters (one per parity)][tasks]; at most n / HV_SEMB_BIG buckets are big
-        const int task_cap = (int)std::min<int64_t>((n / wcap + 1) * ((G.nvox + 63) / 64), 1 << 22);
-        const size_t task_bytes = 256 + sizeof(int4) * (size_t)task_cap;
-        if (v->semb_tasks == nullptr || v->semb_tasks_bytes < task_bytes) {
-            rc = hv_ensure_buffer(v, &v->semb_tasks, &v->semb_tasks_bytes, task_bytes);
-            if (rc != HV_OK) return rc;
-            HV_HIP(hipMemsetAsync(v->semb_tasks, 0, 256, v->stream));
-        }
-        int32_t *task_count = (int32_t *)v->semb_tasks;
-        int4 *tasks = (int4 *)((char *)v->semb_tasks + 256);
-        const bool use_tasks = !(getenv("HV_SEM_TASKS") && atoi(getenv("HV_SEM_TASKS")) == 0);
-        const size_t lds_bytes = fold_lds;
-#define HV_LAUNCH_SEM_FOLD(CK)                                                                                           \
-    do {                                                                                                                 \
-        hipLaunchKernelGGL((k_semb_fold_wave<VOX, PT, CK>), dim3(fold_grid), dim3(256), lds_bytes, v->stream, v->table, bpool, \
-                           (const int32_t *)v->vg_touched, parity, v->vg_cursor, v->vg_cnt, (const int32_t *)v->vg_cur,   \
-                           (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, d_cls, d_inst, d_depths, v->occ, n,       \
-                           idx_bits, v->d_status, seq, task_count, use_tasks ? tasks : (int4 *)nullptr, task_cap, wcap);  \
-        if (use_tasks)                                                                                                   \
-            hipLaunchKernelGGL((k_semb_fold_tasks<VOX, PT, CK>), dim3(1024), dim3(256), lds_bytes, v->stream, v->table, bpool, \
-                               (const int32_t *)task_count, (const int4 *)tasks, parity, task_cap,                        \
-                               (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, d_cls, d_inst, d_depths, v->occ, n,   \
-                               idx_bits, wcap);                                                                          \
-    } while (0)
-        if (color_kind == HV_COLOR_U8) HV_LAUNCH_SEM_FOLD(HV_COLOR_U8);
-        else if (color_kind == HV_COLOR_F32) HV_LAUNCH_SEM_FOLD(HV_COLOR_F32);
-        else HV_LAUNCH_SEM_FOLD(HV_COLOR_NONE);
-#undef HV_LAUNCH_SEM_FOLD
-        HV_HIP(hipGetLastError());
-        v->frame_counter += 1;
-        return HV_OK;
+    // Per-keyframe bin path (rounds 4-6): needs the point index and the local voxel index in one 32-bit entry.
+    if (sem_bins_usable(v, n)) {
+        auto bin = [&](const HvBins &B) {
+            hipLaunchKernelGGL(k_semb_bin<PT>, dim3(blocks), dim3(256), 0, v->stream, v->table, B, d_pts, n, G, valid_mask_keys);
+        };
+        if (color_kind == HV_COLOR_U8)
+            return sem_bins_run<VOX>(v, n, checked, HvSemArrays<PT, HV_COLOR_U8>{d_pts, d_cols, d_cls, d_inst, d_depths}, bin);
+        if (color_kind == HV_COLOR_F32)
+            return sem_bins_run<VOX>(v, n, checked, HvSemArrays<PT, HV_COLOR_F32>{d_pts, d_cols, d_cls, d_inst, d_depths}, bin);
+        return sem_bins_run<VOX>(v, n, checked, HvSemArrays<PT, HV_COLOR_NONE>{d_pts, d_cols, d_cls, d_inst, d_depths}, bin);
     }
     size_t bytes = 0;
     HV_HIP(rocprim::radix_sort_pairs(nullptr, bytes, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in, v->sort_vals_out,
@@ -861,8 +954,11 @@ int hv_integrate_rgbd_semantic(hv_volume *v, const float *depth, const uint8_t *
     const int64_t npx = (int64_t)height * width;
     HV_REQUIRE(npx <= v->cfg.max_points, HV_ERR_CAPACITY, "hv_integrate_rgbd_semantic: image exceeds max_points");
     HV_HIP(hipSetDevice(v->device));
-    const void *d_depth = nullptr;
-    int rc = hv_unproject_frame(v, depth, HV_DEPTH_F32, 1.0, rgb, height, width, intr, T_cw, min_depth, max_depth, loc, &d_depth);
+    // the frame's depth and colour planes on the device (staged on the volume's stream when they come from the host)
+    const void *d_depth = nullptr, *d_rgb = nullptr;
+    int rc = hv_stage_in(v, depth, (size_t)npx * 4, loc, 0, &d_depth);
+    if (rc != HV_OK) return rc;
+    rc = hv_stage_in(v, rgb, (size_t)npx * 3, loc, 1, &d_rgb);
     if (rc != HV_OK) return rc;
     // label planes: staged behind each other in the output scratch when they come from the host
     const int32_t *d_cls = class_ids_image, *d_obj = object_ids_image;
@@ -880,9 +976,29 @@ int hv_integrate_rgbd_semantic(hv_volume *v, const float *depth, const uint8_t *
         }
         if ((rc = hv_h2d_fence(v, pinned_src)) != HV_OK) return rc;
     }
+    const bool prob = v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID;
+    if (sem_bins_usable(v, npx)) {
+        // production: the bin pass unprojects the pixel itself and leaves a 32-byte record per point for the fold
+        bool checked = false;
+        rc = hv_capacity_gate(v, &checked);
+        if (rc != HV_OK) return rc;
+        rc = hv_ensure_buffer(v, &v->bin_rec, &v->bin_rec_bytes, (size_t)32 * (size_t)v->cfg.max_points);
+        if (rc != HV_OK) return rc;
+        const HvSemParams G = sem_params(v);
+        const HvUnprojectParams U = unproject_params(HV_DEPTH_F32, 1.0, height, width, intr, T_cw, min_depth, max_depth);
+        auto bin = [&](const HvBins &B) {
+            hipLaunchKernelGGL(k_semb_bin_frame, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream, v->table, B, G, U, d_depth,
+                               (const uint8_t *)d_rgb, d_cls, d_obj, (float4 *)v->bin_rec);
+        };
+        const HvSemRecs src{(const float4 *)v->bin_rec, nullptr, d_cls != nullptr, use_depths != 0};
+        return prob ? sem_bins_run<HvProbVoxel>(v, npx, checked, src, bin) : sem_bins_run<HvSemVoxel>(v, npx, checked, src, bin);
+    }
+    // (inputs beyond the bin path's limits: unprojected rows, then the radix path)
+    rc = hv_unproject_frame(v, d_depth, HV_DEPTH_F32, 1.0, (const uint8_t *)d_rgb, height, width, intr, T_cw, min_depth, max_depth, HV_DEVICE, nullptr);
+    if (rc != HV_OK) return rc;
     // depths = camera z of the point = the pixel's depth (…voxel_semantic_grid.py:418-424)
     const float *d_depths = use_depths ? (const float *)d_depth : nullptr;
-    if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID)
+    if (prob)
         return sem_integrate<HvProbVoxel, float>(v, v->scratch_points, npx, v->scratch_colors, HV_COLOR_F32, d_cls, d_obj, d_depths,
                                                  v->sort_keys_out);
     return sem_integrate<HvSemVoxel, float>(v, v->scratch_points, npx, v->scratch_colors, HV_COLOR_F32, d_cls, d_obj, d_depths,

@@ -20,7 +20,8 @@
 
 #include "hv_common.h"
 #include "hv_query.h"
-#include "hv_bucket.h"
+#include "hv_bins.h"
+#include "hv_unproject.h"
 #include <rocprim/device/device_radix_sort.hpp>
 
 static constexpr uint32_t HV_SORT_SENTINEL = 0xFFFFFFFFu;
@@ -140,32 +141,6 @@ __global__ __launch_bounds__(256) void k_vg_reduce(HvTable table, HvVoxel *__res
     *vx = acc;
 }
 
-// depth2pointcloud (pyslam/utilities/depth.py:45-85) + world transform
-// (volumetric_integrator_voxel_grid.py:262-281), f64 arithmetic in a fixed order, rounded to f32.
-struct HvUnprojectParams {
-    double cx, cy, inv_fx, inv_fy;
-    double Rwc[9], twc[3];
-    float min_depth, max_depth, depth_scale_f;
-    int32_t H, W, depth_is_u16;
-};
-
-__device__ __forceinline__ bool hv_unproject_pixel(const HvUnprojectParams &U, const void *__restrict__ depth_raw,
-                                                   const uint8_t *__restrict__ rgb, int64_t i, float pt[3], float col[3]) {
-    float d = U.depth_is_u16 ? (float)((const uint16_t *)depth_raw)[i] : ((const float *)depth_raw)[i];
-    if (U.depth_scale_f != 1.0f) d = d / U.depth_scale_f;
-    if (!((d > U.min_depth) && (d < U.max_depth))) return false;
-    const int row = (int)((uint32_t)i / (uint32_t)U.W), col_px = (int)((uint32_t)i - (uint32_t)row * (uint32_t)U.W); // i < 2^31 (max_points)
-    const double z = (double)d;
-    const double x = ((double)col_px - U.cx) * z * U.inv_fx;
-    const double y = ((double)row - U.cy) * z * U.inv_fy;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) pt[r] = (float)(((U.Rwc[r * 3 + 0] * x + U.Rwc[r * 3 + 1] * y) + U.Rwc[r * 3 + 2] * z) + U.twc[r]);
-    const uint8_t *c = rgb + i * 3;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) col[k] = (float)((double)c[k] / 255.0);
-    return true;
-}
-
 __global__ __launch_bounds__(256) void k_vg_unproject(const void *__restrict__ depth_raw,
                                                        const uint8_t *__restrict__ rgb, HvUnprojectParams U,
                                                        float *__restrict__ pts_out, float *__restrict__ cols_out,
@@ -250,53 +225,73 @@ static void hv_launch_unproject(hipStream_t s, int64_t npx, const void *d_depth,
 }
 
 // ================================================================================================
-// Per-frame bucket path (production for single frames).  The device-wide radix sort above is 18 small launches and 115 of
-// the 140 us a 640x480 frame takes (profiles/r01): a frame's points only have to be grouped per BLOCK (a few thousand
-// buckets of a few dozen to a few hundred points) and ordered inside a block by (voxel, point index) - SURVEY 7.2 K4.
-//   k_vgb_count    1 thread / point: key arithmetic + block claim as k_vg_keys; counts the points per table slot, the
-//                  first point of a slot appends the slot to the frame's touched list
-//   k_vgb_offsets  1 thread / touched slot: takes the slot's bucket range from a global cursor
-//   k_vgb_scatter  1 thread / point: entry (local voxel index << 20 | point index) into its slot's bucket
-//   k_vgb_fold     1 workgroup / touched slot: bucket -> LDS, bitonic sort of the 32-bit entries (= by voxel, then by point
-//                  index), the first thread of every voxel run folds its points in point order into the voxel record -
-//                  exactly the order of the reference's sequential branch, so the result is bit-identical to the radix
-//                  path and to the reference.  Buckets beyond the LDS capacity (a block that catches > 4096 points of one
-//                  frame: coarse voxels / very close surfaces) are folded in point-index windows of 4096, still exact.
-// 4 launches instead of ~20.  Needs point indices < 2^20 and local_bits <= 12; larger inputs take the radix path.
+// Per-call bin path (production for single frames; hv_bins.h).  The device-wide radix sort above is 18 small launches and 115 of
+// the 140 us a 640x480 frame takes (profiles/r01): a frame's points only have to be grouped per BLOCK (a few thousand bins of a
+// few dozen to a few hundred points) and ordered inside a block by (voxel, point index) - SURVEY 7.2 K4.
+//   k_vgb_bin      1 thread / point: (the pixel's unprojection,) key arithmetic + block claim as k_vg_keys; the point's entry
+//                  (local voxel index << 20 | point index) goes straight into its block's bin, its packed record (position +
+//                  colour, 16 or 32 bytes) into the record array in point order; a block's first point of the call appends the
+//                  block to the touched list (hv_bins_push)
+//   k_vgb_fold     1 wave (or workgroup) / touched block: bin -> LDS, the 32-bit entries into ascending order (= by voxel, then by
+//                  point index), the first lane of every voxel run folds its points in point order into the voxel record - exactly
+//                  the order of the reference's sequential branch, so the result is bit-identical to the radix path and to the
+//                  reference.  Bins beyond the LDS capacity (a block that catches > 4096 points of one frame: coarse voxels / very
+//                  close surfaces) are folded in point-index windows, still exact.
+// 2 launches (rounds 3-5: 4 - count, offsets over every allocated block, scatter, fold).  Needs point indices < 2^20 and
+// local_bits <= 12; larger inputs take the radix path.
 // ================================================================================================
-// FUSED: the points do not exist yet - the thread unprojects its pixel (k_vg_unproject's arithmetic), stores point and colour
-// for the fold and goes on with the key: one launch and one pass over the points less per RGB-D frame.
-template <bool FUSED>
-__global__ __launch_bounds__(256) void k_vgb_count(HvTable table, float *__restrict__ pts, int64_t n, HvGridParams G,
-                                                    int32_t *__restrict__ pslot, uint32_t *__restrict__ plidx,
-                                                    const uint32_t *__restrict__ valid_mask_keys, int32_t *__restrict__ cnt,
-                                                    HvUnprojectParams U, const void *__restrict__ depth_raw,
-                                                    const uint8_t *__restrict__ rgb, float *__restrict__ cols_out,
-                                                    const double *__restrict__ pts64) {
+// The records the bin pass leaves for the fold, in point order: ONE 16-byte load per point (f32 colours: two) where the fold used to
+// gather three position and three colour scalars.  8-bit colours stay 8-bit; the fold turns them into the float the reference adds
+// through a 256-entry table in LDS: c * (1/255) in float for the binding's uint8 overload (voxel_data.h:82), (float)(c / 255.0) in
+// double for a frame's pixels (depth.py:76 divides the uint8 image by 255.0, voxel_grid.py:270-281 casts to float32).
+enum { HV_REC_NONE = 0, HV_REC_U8_MUL = 1, HV_REC_U8_DIV = 2, HV_REC_F32 = 3 };
+template <int REC>
+__device__ __forceinline__ void hv_rec_fetch(const void *__restrict__ rec, int64_t p, const float *lut, float out[6]) {
+    if (REC == HV_REC_F32) {
+        const float4 a = ((const float4 *)rec)[2 * p], b = ((const float4 *)rec)[2 * p + 1];
+        out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y;
+    } else {
+        const float4 a = ((const float4 *)rec)[p];
+        out[0] = a.x; out[1] = a.y; out[2] = a.z;
+        if (REC != HV_REC_NONE) {
+            const uint32_t c = __float_as_uint(a.w);
+            out[3] = lut[c & 255u]; out[4] = lut[(c >> 8) & 255u]; out[5] = lut[(c >> 16) & 255u];
+        }
+    }
+}
+template <int REC>
+__device__ __forceinline__ void hv_rec_lut(float *lut) { // by all 256 threads of the workgroup
+    if (REC == HV_REC_U8_MUL) lut[threadIdx.x] = (float)threadIdx.x * (1.0f / 255.0f);
+    if (REC == HV_REC_U8_DIV) lut[threadIdx.x] = (float)((double)threadIdx.x / 255.0);
+    __syncthreads();
+}
+
+// FUSED: the points do not exist yet - the thread unprojects its pixel (k_vg_unproject's arithmetic) and goes on with the key: one
+// launch and one pass over the points less per RGB-D frame.
+template <bool FUSED, int REC>
+__global__ __launch_bounds__(256) void k_vgb_bin(HvTable table, HvBins B, const float *__restrict__ pts, const double *__restrict__ pts64,
+                                                  const void *__restrict__ cols, int64_t n, HvGridParams G,
+                                                  const uint32_t *__restrict__ valid_mask_keys, HvUnprojectParams U,
+                                                  const void *__restrict__ depth_raw, const uint8_t *__restrict__ rgb, void *__restrict__ rec) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int32_t slot = -1;
+    bool has = false;
+    unsigned long long bkey = 0ull;
     uint32_t lidx = 0;
     if (i < n) {
         bool masked;
         float x = 0.f, y = 0.f, z = 0.f;
         double xd = 0.0, yd = 0.0, zd = 0.0; // pts64 != nullptr (never with FUSED): float64 points, see k_vg_keys
+        const bool wide = !FUSED && pts64 != nullptr;
         if (FUSED) {
-            float pt[3], col[3];
-            masked = !hv_unproject_pixel(U, depth_raw, rgb, i, pt, col);
-            if (!masked) {
-                x = pt[0]; y = pt[1]; z = pt[2];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    pts[i * 3 + k] = pt[k];
-                    cols_out[i * 3 + k] = col[k];
-                }
-            }
+            float pt[3];
+            masked = !hv_unproject_point(U, depth_raw, i, pt);
+            x = pt[0]; y = pt[1]; z = pt[2];
         } else {
             masked = valid_mask_keys != nullptr && valid_mask_keys[i] == HV_SORT_SENTINEL; // pixel rejected by the unprojection
             if (!masked) {
-                if (pts64 != nullptr) {
+                if (wide) {
                     xd = pts64[i * 3 + 0]; yd = pts64[i * 3 + 1]; zd = pts64[i * 3 + 2];
-                    pts[i * 3 + 0] = (float)xd; pts[i * 3 + 1] = (float)yd; pts[i * 3 + 2] = (float)zd;
+                    x = (float)xd; y = (float)yd; z = (float)zd; // the narrowing the voxel sums take (voxel_data.h:54-56)
                 } else {
                     x = pts[i * 3 + 0]; y = pts[i * 3 + 1]; z = pts[i * 3 + 2];
                 }
@@ -304,57 +299,60 @@ __global__ __launch_bounds__(256) void k_vgb_count(HvTable table, float *__restr
         }
         if (!masked) {
             bool foreign = false;
-            const bool wide = !FUSED && pts64 != nullptr;
             if (wide ? hv_point_keyable(xd, yd, zd, G) : hv_point_keyable(x, y, z, G)) {
                 const HvPointKey k = wide ? hv_point_key(xd, yd, zd, G) : hv_point_key(x, y, z, G);
                 if (hv_key_in_range(k.b[0], k.b[1], k.b[2])) {
-                    const unsigned long long bkey = hv_pack_key(k.b[0], k.b[1], k.b[2]);
+                    bkey = hv_pack_key(k.b[0], k.b[1], k.b[2]);
                     foreign = hv_block_is_foreign(G, bkey);
-                    if (!foreign) slot = hv_table_insert(table, bkey);
+                    has = !foreign;
                     lidx = (uint32_t)(k.l[0] + k.l[1] * G.bs + k.l[2] * G.bs * G.bs); // voxel_block.h:67-70
                 }
             }
-            if (slot < 0 && !foreign) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
+            if (!has && !foreign) atomicAdd(&table.counters[HV_CNT_DROPPED], 1);
+            if (has) {
+                if (REC == HV_REC_F32) {
+                    const float *c = (const float *)cols + i * 3;
+                    ((float4 *)rec)[2 * i] = make_float4(x, y, z, c[0]);
+                    ((float4 *)rec)[2 * i + 1] = make_float4(c[1], c[2], 0.f, 0.f);
+                } else {
+                    uint32_t packed = 0u;
+                    if (REC != HV_REC_NONE) {
+                        const uint8_t *c = (FUSED ? rgb : (const uint8_t *)cols) + i * 3;
+                        packed = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+                    }
+                    ((float4 *)rec)[i] = make_float4(x, y, z, __uint_as_float(packed));
+                }
+            }
         }
-        pslot[i] = slot;
-        plidx[i] = lidx;
     }
-    // one fire-and-forget atomic per (wave, slot); the list of touched slots is built by k_vgb_offsets from the allocated
-    // blocks (an append here would be ~7000 returning atomics on ONE counter per frame: 20 of this kernel's 29 us)
-    const HvWaveGroup g = hv_wave_group_by(slot);
-    if (g.leader) atomicAdd(&cnt[slot], g.size);
+    hv_bins_push(table, B, has, bkey, lidx, (uint32_t)i);
 }
 
 // (Measured dead end, round 3: an ORDER-FREE single-launch form - one thread per pixel adding its point to the voxel record with
 // seven hardware atomics, global_atomic_add / global_atomic_add_f32; keys and counts exact, sums within the contract's 1e-4 -
 // runs at 89.9 us per 640x480 frame against 45.4 us for the four launches of the point-ordered bucket path: 2.1 M scattered
 // float atomics per frame are slower than sorting 12 points per block in LDS.  Taken out again.)
-// update_voxel_direct (voxel_block_grid.hpp:524-614) folded over the sorted entries s[0 .. m) of one block
-template <int COLOR_KIND>
-__device__ __forceinline__ void hv_vgb_fold_sorted(const uint32_t *s, int m, HvVoxel *__restrict__ block, const float *__restrict__ pts,
-                                                   const void *__restrict__ cols) {
-    const float inv_255 = 1.0f / 255.0f; // voxel_data.h:82
-    for (int e = threadIdx.x; e < m; e += blockDim.x) {
+// update_voxel_direct (voxel_block_grid.hpp:524-614) folded over the sorted entries s[0 .. m) of one block: the head of every voxel
+// run, one per `stride` threads
+template <int REC>
+__device__ __forceinline__ void hv_vgb_fold_sorted(const uint32_t *s, int m, int first, int stride, HvVoxel *__restrict__ block,
+                                                   const void *__restrict__ rec, const float *lut) {
+    for (int e = first; e < m; e += stride) {
         const uint32_t lidx = s[e] >> HV_VGB_IDX_BITS;
         if (e > 0 && (s[e - 1] >> HV_VGB_IDX_BITS) == lidx) continue; // not the head of its voxel's run
         HvVoxel *vx = block + lidx;
         HvVoxel acc = *vx;
         int j = e;
         do {
-            const int64_t p = s[j] & ((1u << HV_VGB_IDX_BITS) - 1u);
-            acc.pos[0] += pts[p * 3 + 0];
-            acc.pos[1] += pts[p * 3 + 1];
-            acc.pos[2] += pts[p * 3 + 2];
-            if (COLOR_KIND == HV_COLOR_U8) {
-                const uint8_t *c = (const uint8_t *)cols + p * 3;
-                acc.col[0] += (float)c[0] * inv_255;
-                acc.col[1] += (float)c[1] * inv_255;
-                acc.col[2] += (float)c[2] * inv_255;
-            } else if (COLOR_KIND == HV_COLOR_F32) {
-                const float *c = (const float *)cols + p * 3;
-                acc.col[0] += c[0];
-                acc.col[1] += c[1];
-                acc.col[2] += c[2];
+            float r[6];
+            hv_rec_fetch<REC>(rec, (int64_t)(s[j] & ((1u << HV_VGB_IDX_BITS) - 1u)), lut, r);
+            acc.pos[0] += r[0];
+            acc.pos[1] += r[1];
+            acc.pos[2] += r[2];
+            if (REC != HV_REC_NONE) {
+                acc.col[0] += r[3];
+                acc.col[1] += r[4];
+                acc.col[2] += r[5];
             }
             acc.count = acc.count == 0 ? 1 : acc.count + 1;
             ++j;
@@ -382,83 +380,68 @@ __device__ __forceinline__ void hv_vgb_bitonic(uint32_t *s, int m2) { // ascendi
     }
 }
 
-template <int COLOR_KIND>
-__device__ __forceinline__ void hv_vgb_fold_sorted_wave(const uint32_t *s, int m, HvVoxel *__restrict__ block, const float *__restrict__ pts,
-                                                        const void *__restrict__ cols) {
-    const float inv_255 = 1.0f / 255.0f; // voxel_data.h:82
-    for (int e = hv_lane_id(); e < m; e += HV_WAVE) {
-        const uint32_t lidx = s[e] >> HV_VGB_IDX_BITS;
-        if (e > 0 && (s[e - 1] >> HV_VGB_IDX_BITS) == lidx) continue; // not the head of its voxel's run
-        HvVoxel *vx = block + lidx;
-        HvVoxel acc = *vx;
-        int j = e;
-        do {
-            const int64_t p = s[j] & ((1u << HV_VGB_IDX_BITS) - 1u);
-            acc.pos[0] += pts[p * 3 + 0];
-            acc.pos[1] += pts[p * 3 + 1];
-            acc.pos[2] += pts[p * 3 + 2];
-            if (COLOR_KIND == HV_COLOR_U8) {
-                const uint8_t *c = (const uint8_t *)cols + p * 3;
-                acc.col[0] += (float)c[0] * inv_255;
-                acc.col[1] += (float)c[1] * inv_255;
-                acc.col[2] += (float)c[2] * inv_255;
-            } else if (COLOR_KIND == HV_COLOR_F32) {
-                const float *c = (const float *)cols + p * 3;
-                acc.col[0] += c[0];
-                acc.col[1] += c[1];
-                acc.col[2] += c[2];
-            }
-            acc.count = acc.count == 0 ? 1 : acc.count + 1;
-            ++j;
-        } while (j < m && (s[j] >> HV_VGB_IDX_BITS) == lidx);
-        *vx = acc;
-    }
-}
-
-// One WAVE per touched slot (a frame's buckets hold a few dozen points: a 256-thread workgroup with block barriers per bucket
-// spends its time in barriers).  Buckets of up to HV_VGB_WCAP entries are sorted in the wave's LDS window at once, larger ones
-// in point-index windows of HV_VGB_WCAP (correct for any size; when the previous frame had such buckets the host launches the
-// workgroup form k_vgb_fold instead).
-static constexpr int HV_VGB_RANK = 256; // buckets up to this size are rank-sorted (<= 4 entries per lane)
+// One WAVE per touched slot (a frame's bins hold a few dozen points: a 256-thread workgroup with block barriers per bin spends its
+// time in barriers).  Bins of up to HV_VGB_WCAP entries are sorted in the wave's LDS window at once, larger ones in point-index
+// windows of HV_VGB_WCAP (correct for any size; when the previous frame had such bins the host launches the workgroup form
+// k_vgb_fold instead).
+static constexpr int HV_VGB_RANK = 256; // bins up to this size are rank-sorted (<= 4 entries per lane)
 static constexpr int HV_VGB_STAGE = 128; // ... and up to this size their points are staged in the window's spare 3 KB (24 B each)
-template <int COLOR_KIND>
-__global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *__restrict__ pool, const int32_t *__restrict__ touched,
-                                                        int parity, unsigned long long *__restrict__ cursor_and_len, int32_t *__restrict__ cnt,
-                                                        const int32_t *__restrict__ cur,
-                                                        const uint32_t *__restrict__ entries, HvGridParams G, const float *__restrict__ pts,
-                                                        const void *__restrict__ cols, int64_t n_points, HvStatus *status, int32_t status_seq) {
+template <int REC>
+__global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *__restrict__ pool, HvBins B, HvGridParams G,
+                                                        const void *__restrict__ rec, int64_t n_points, HvStatus *status, int32_t status_seq) {
     __shared__ uint32_t s_all[4][HV_VGB_WCAP];
-    const int n_touched = (int)(cursor_and_len[parity] >> 32);
+    __shared__ float s_lut[256];
+    hv_rec_lut<REC>(s_lut);
+    const HvBinLists L = hv_bins_lists(B);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        cursor_and_len[parity ^ 1] = 0ull;                // the next frame's bucket cursor and list length
-        status->pad = table.counters[HV_CNT_OUT2];        // largest bucket of this frame
+        hv_bins_clear_next(B);                            // the next call's list lengths
+        status->pad = table.counters[HV_CNT_OUT2];        // largest bin of this frame
         table.counters[HV_CNT_OUT2] = 0;
         hv_publish_status(table, status, status_seq);
     }
     const int wave = threadIdx.x >> 6, lane = hv_lane_id();
     uint32_t *s = s_all[wave];
-    for (int t = blockIdx.x * 4 + wave; t < n_touched; t += gridDim.x * 4) {
-        const int32_t slot = touched[t];
-        const int32_t nb = cnt[slot];
-        const int32_t start = cur[slot] - nb;
+    for (int t = blockIdx.x * 4 + wave; t < L.total; t += gridDim.x * 4) {
+        const int32_t slot = hv_bins_touched(B, L, t);
+        const int32_t nb = B.cnt[slot];
         const int32_t idx = table.vals[slot];
-        hv_wave_lds_sync(); // the window of the previous bucket is no longer read
-        if (lane == 0) cnt[slot] = 0; // clean for the next frame
-        if (idx < 0) continue;        // (the block did not get a pool slot: overflow, reported by the caller)
+        hv_wave_lds_sync(); // the window of the previous bin is no longer read
+        if (lane == 0) B.cnt[slot] = 0; // clean for the next call
+        if (idx < 0) continue;          // (the block did not get a pool slot: overflow, reported by the caller)
         HvVoxel *block = pool + (int64_t)idx * G.nvox;
         if (nb <= HV_VGB_RANK) {
-            // small bucket (the common case: a few dozen points): every lane ranks its <= 4 entries against the whole bucket
+            // small bin (the common case: a few dozen points): every lane ranks its <= 4 entries against the whole bin
             // (LDS broadcast reads, entries are distinct) and drops them at their rank - no passes, one synchronisation
             uint32_t mine[HV_VGB_RANK / HV_WAVE];
             int rank[HV_VGB_RANK / HV_WAVE];
 #pragma unroll
             for (int q = 0; q < HV_VGB_RANK / HV_WAVE; ++q) {
                 const int e = lane + q * HV_WAVE;
-                mine[q] = e < nb ? entries[start + e] : 0xFFFFFFFFu;
+                mine[q] = e < nb ? B.inl[(size_t)slot * HV_BIN_K0 + e] : 0xFFFFFFFFu; // (HV_VGB_RANK <= HV_BIN_K0: inline entries only)
                 rank[q] = 0;
                 if (e < nb) s[e] = mine[q];
             }
             hv_wave_lds_sync();
+            const bool staged = nb <= HV_VGB_STAGE;
+            // the records of this lane's (still unsorted) entries and the lines of their voxels are requested NOW and travel while
+            // the bin is ranked: one memory round trip less on the bin's dependent chain
+            float4 r4[2][2];
+            int32_t warm = 0;
+            if (staged) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (lane + q * HV_WAVE < nb) {
+                        const int64_t p = mine[q] & ((1u << HV_VGB_IDX_BITS) - 1u);
+                        if (REC == HV_REC_F32) {
+                            r4[q][0] = ((const float4 *)rec)[2 * p];
+                            r4[q][1] = ((const float4 *)rec)[2 * p + 1];
+                        } else {
+                            r4[q][0] = ((const float4 *)rec)[p];
+                        }
+                        warm += block[mine[q] >> HV_VGB_IDX_BITS].count;
+                    }
+                }
+            }
             for (int j = 0; j < nb; ++j) {
                 const uint32_t o = s[j];
 #pragma unroll
@@ -468,28 +451,24 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
 #pragma unroll
             for (int q = 0; q < HV_VGB_RANK / HV_WAVE; ++q)
                 if (lane + q * HV_WAVE < nb) s[rank[q]] = mine[q];
-            hv_wave_lds_sync();
-            if (nb <= HV_VGB_STAGE) {
-                // every lane fetches ITS sorted entries' point and colour (all gathers of the bucket in flight at once) into the
-                // rest of the wave's LDS window; the run heads then add from LDS instead of chasing one global load per point
+            if (staged) {
+                // ... and land at their entry's rank in the rest of the wave's LDS window; the run heads then add from LDS instead
+                // of chasing one global load per point
                 float *stage = (float *)(s + HV_VGB_RANK);
-                for (int e = lane; e < nb; e += HV_WAVE) {
-                    const int64_t p = s[e] & ((1u << HV_VGB_IDX_BITS) - 1u);
-                    stage[e * 6 + 0] = pts[p * 3 + 0];
-                    stage[e * 6 + 1] = pts[p * 3 + 1];
-                    stage[e * 6 + 2] = pts[p * 3 + 2];
-                    if (COLOR_KIND == HV_COLOR_U8) {
-                        const uint8_t *c = (const uint8_t *)cols + p * 3;
-                        stage[e * 6 + 3] = (float)c[0] * (1.0f / 255.0f); // voxel_data.h:82
-                        stage[e * 6 + 4] = (float)c[1] * (1.0f / 255.0f);
-                        stage[e * 6 + 5] = (float)c[2] * (1.0f / 255.0f);
-                    } else if (COLOR_KIND == HV_COLOR_F32) {
-                        const float *c = (const float *)cols + p * 3;
-                        stage[e * 6 + 3] = c[0];
-                        stage[e * 6 + 4] = c[1];
-                        stage[e * 6 + 5] = c[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (lane + q * HV_WAVE < nb) {
+                        float *d = stage + rank[q] * 6;
+                        d[0] = r4[q][0].x; d[1] = r4[q][0].y; d[2] = r4[q][0].z;
+                        if (REC == HV_REC_F32) {
+                            d[3] = r4[q][0].w; d[4] = r4[q][1].x; d[5] = r4[q][1].y;
+                        } else if (REC != HV_REC_NONE) {
+                            const uint32_t c = __float_as_uint(r4[q][0].w);
+                            d[3] = s_lut[c & 255u]; d[4] = s_lut[(c >> 8) & 255u]; d[5] = s_lut[(c >> 16) & 255u];
+                        }
                     }
                 }
+                asm volatile("" ::"v"(warm)); // (the voxel lines have arrived)
                 hv_wave_lds_sync();
                 for (int e = lane; e < nb; e += HV_WAVE) {
                     const uint32_t lidx = s[e] >> HV_VGB_IDX_BITS;
@@ -501,7 +480,7 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
                         acc.pos[0] += stage[j * 6 + 0];
                         acc.pos[1] += stage[j * 6 + 1];
                         acc.pos[2] += stage[j * 6 + 2];
-                        if (COLOR_KIND != HV_COLOR_NONE) {
+                        if (REC != HV_REC_NONE) {
                             acc.col[0] += stage[j * 6 + 3];
                             acc.col[1] += stage[j * 6 + 4];
                             acc.col[2] += stage[j * 6 + 5];
@@ -513,16 +492,17 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
                 }
                 continue;
             }
-            hv_vgb_fold_sorted_wave<COLOR_KIND>(s, nb, block, pts, cols);
+            hv_wave_lds_sync();
+            hv_vgb_fold_sorted<REC>(s, nb, lane, HV_WAVE, block, rec, s_lut);
             continue;
         }
         if (nb <= HV_VGB_WCAP) {
             int m2 = HV_WAVE;
             while (m2 < nb) m2 <<= 1;
-            for (int e = lane; e < m2; e += HV_WAVE) s[e] = e < nb ? entries[start + e] : 0xFFFFFFFFu;
+            for (int e = lane; e < m2; e += HV_WAVE) s[e] = e < nb ? hv_bins_entry(B, slot, e) : 0xFFFFFFFFu;
             hv_wave_lds_sync();
             hv_vgb_bitonic_wave(s, m2);
-            hv_vgb_fold_sorted_wave<COLOR_KIND>(s, nb, block, pts, cols);
+            hv_vgb_fold_sorted<REC>(s, nb, lane, HV_WAVE, block, rec, s_lut);
             continue;
         }
         for (int64_t w = 0; w < n_points; w += HV_VGB_WCAP) { // point-index windows, ascending: a voxel's points stay in order
@@ -530,7 +510,7 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
             int m = 0;
             for (int e0 = 0; e0 < nb; e0 += HV_WAVE) {
                 const int e = e0 + lane;
-                const uint32_t ent = e < nb ? entries[start + e] : 0u;
+                const uint32_t ent = e < nb ? hv_bins_entry(B, slot, e) : 0u;
                 const int64_t p = ent & ((1u << HV_VGB_IDX_BITS) - 1u);
                 const bool in = e < nb && p >= w && p < w + HV_VGB_WCAP;
                 const unsigned long long bm = __ballot(in);
@@ -544,52 +524,50 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
             for (int e = m + lane; e < m2; e += HV_WAVE) s[e] = 0xFFFFFFFFu;
             hv_wave_lds_sync();
             hv_vgb_bitonic_wave(s, m2);
-            hv_vgb_fold_sorted_wave<COLOR_KIND>(s, m, block, pts, cols);
+            hv_vgb_fold_sorted<REC>(s, m, lane, HV_WAVE, block, rec, s_lut);
         }
     }
 }
 
-template <int COLOR_KIND>
-__global__ __launch_bounds__(256) void k_vgb_fold(HvTable table, HvVoxel *__restrict__ pool, const int32_t *__restrict__ touched,
-                                                   int parity, unsigned long long *__restrict__ cursor_and_len, int32_t *__restrict__ cnt,
-                                                   const int32_t *__restrict__ cur,
-                                                   const uint32_t *__restrict__ entries, HvGridParams G, const float *__restrict__ pts,
-                                                   const void *__restrict__ cols, int64_t n_points, HvStatus *status, int32_t status_seq) {
+template <int REC>
+__global__ __launch_bounds__(256) void k_vgb_fold(HvTable table, HvVoxel *__restrict__ pool, HvBins B, HvGridParams G,
+                                                   const void *__restrict__ rec, int64_t n_points, HvStatus *status, int32_t status_seq) {
     __shared__ uint32_t s[HV_VGB_CAP];
+    __shared__ float s_lut[256];
     __shared__ int s_m;
-    const int n_touched = (int)(cursor_and_len[parity] >> 32);
+    hv_rec_lut<REC>(s_lut);
+    const HvBinLists L = hv_bins_lists(B);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        cursor_and_len[parity ^ 1] = 0ull;                // the next frame's bucket cursor and list length
-        status->pad = table.counters[HV_CNT_OUT2];        // largest bucket of this frame
+        hv_bins_clear_next(B);                            // the next call's list lengths
+        status->pad = table.counters[HV_CNT_OUT2];        // largest bin of this frame
         table.counters[HV_CNT_OUT2] = 0;
         hv_publish_status(table, status, status_seq);
     }
-    for (int t = blockIdx.x; t < n_touched; t += gridDim.x) {
-        const int32_t slot = touched[t];
-        const int32_t nb = cnt[slot];
-        const int32_t start = cur[slot] - nb;
+    for (int t = blockIdx.x; t < L.total; t += gridDim.x) {
+        const int32_t slot = hv_bins_touched(B, L, t);
+        const int32_t nb = B.cnt[slot];
         const int32_t idx = table.vals[slot];
-        __syncthreads(); // s[] of the previous iteration is no longer read
-        if (threadIdx.x == 0) cnt[slot] = 0; // clean for the next frame
-        if (idx < 0) continue;               // (the block did not get a pool slot: overflow, reported by the caller)
+        __syncthreads(); // s[] of the previous iteration is no longer read (and every thread has read cnt[slot])
+        if (threadIdx.x == 0) B.cnt[slot] = 0; // clean for the next call
+        if (idx < 0) continue;                 // (the block did not get a pool slot: overflow, reported by the caller)
         HvVoxel *block = pool + (int64_t)idx * G.nvox;
         if (nb <= HV_VGB_CAP) {
             int m2 = 1;
             while (m2 < nb) m2 <<= 1;
-            for (int e = threadIdx.x; e < m2; e += blockDim.x) s[e] = e < nb ? entries[start + e] : 0xFFFFFFFFu;
+            for (int e = threadIdx.x; e < m2; e += blockDim.x) s[e] = e < nb ? hv_bins_entry(B, slot, e) : 0xFFFFFFFFu;
             __syncthreads();
             hv_vgb_bitonic(s, m2);
-            hv_vgb_fold_sorted<COLOR_KIND>(s, nb, block, pts, cols);
+            hv_vgb_fold_sorted<REC>(s, nb, threadIdx.x, blockDim.x, block, rec, s_lut);
             continue;
         }
-        // a bucket larger than the LDS window: fold the points of index window [w, w + CAP) at a time, windows ascending - a
+        // a bin larger than the LDS window: fold the points of index window [w, w + CAP) at a time, windows ascending - a
         // voxel's points still arrive in point order (a window holds <= CAP entries: point indices are distinct)
         for (int64_t w = 0; w < n_points; w += HV_VGB_CAP) {
             __syncthreads();
             if (threadIdx.x == 0) s_m = 0;
             __syncthreads();
             for (int e = threadIdx.x; e < nb; e += blockDim.x) {
-                const uint32_t ent = entries[start + e];
+                const uint32_t ent = hv_bins_entry(B, slot, e);
                 const int64_t p = ent & ((1u << HV_VGB_IDX_BITS) - 1u);
                 if (p >= w && p < w + HV_VGB_CAP) s[atomicAdd(&s_m, 1)] = ent;
             }
@@ -601,7 +579,7 @@ __global__ __launch_bounds__(256) void k_vgb_fold(HvTable table, HvVoxel *__rest
             for (int e = m + threadIdx.x; e < m2; e += blockDim.x) s[e] = 0xFFFFFFFFu;
             __syncthreads();
             hv_vgb_bitonic(s, m2);
-            hv_vgb_fold_sorted<COLOR_KIND>(s, m, block, pts, cols);
+            hv_vgb_fold_sorted<REC>(s, m, threadIdx.x, blockDim.x, block, rec, s_lut);
         }
     }
 }
@@ -866,10 +844,10 @@ static int ensure_sort_tmp(hv_volume *v, int64_t n) {
     return hv_ensure_buffer(v, &v->sort_tmp, &v->sort_tmp_bytes, bytes);
 }
 
-// keys -> group -> ordered reduce over device-resident points/colours.  Single frames (n < 2^20 points) take the bucket path
-// (4 launches), larger inputs - the batched replay - the device-wide radix sort; HV_VG_PATH=sort forces the latter (A/B, tests).
+// keys -> group -> ordered reduce over device-resident points/colours.  Single frames (n < 2^20 points) take the bin path
+// (2 launches), larger inputs - the batched replay - the device-wide radix sort; HV_VG_PATH=sort forces the latter (A/B, tests).
 // `frame` != nullptr: the points do not exist yet - they are one posed RGB-D frame (device pointers + unprojection constants);
-// the bucket path unprojects inside its count kernel, the radix path launches k_vg_unproject first.
+// the bin path unprojects inside its bin kernel, the radix path launches k_vg_unproject first.
 struct HvFrameSource {
     HvUnprojectParams U;
     const void *d_depth;
@@ -885,52 +863,51 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
     int rc = hv_capacity_gate(v, &checked); // may grow the pool: the sort-key width / bucket arrays follow the table
     if (rc != HV_OK) return rc;
     const char *force = getenv("HV_VG_PATH");
-    const bool bucket = n < (1ll << HV_VGB_IDX_BITS) && v->local_bits <= 32 - HV_VGB_IDX_BITS && !(force && strcmp(force, "sort") == 0);
-    if (bucket) {
-        hv_profile_begin(v); // measurement hook: the four launches of one integrate call
-        int parity = 0;
+    const bool bins = hv_bins_usable(v, n, HV_VGB_IDX_BITS) && v->local_bits <= 32 - HV_VGB_IDX_BITS && !(force && strcmp(force, "sort") == 0);
+    if (bins) {
+        const int rec_kind = frame ? HV_REC_U8_DIV : color_kind == HV_COLOR_U8 ? HV_REC_U8_MUL : color_kind == HV_COLOR_F32 ? HV_REC_F32 : HV_REC_NONE;
+        rc = hv_ensure_buffer(v, &v->bin_rec, &v->bin_rec_bytes, (size_t)32 * (size_t)std::min<int64_t>(v->cfg.max_points, 1ll << HV_VGB_IDX_BITS));
+        if (rc != HV_OK) return rc;
+        hv_profile_begin(v); // measurement hook: the two launches of one integrate call
+        HvBins B{};
         for (int attempt = 0;; ++attempt) {
-            rc = ensure_bucket_buffers(v);
+            rc = hv_bins_ensure(v);
             if (rc != HV_OK) return rc;
-            parity = v->vg_parity;
-            if (frame)
-                hipLaunchKernelGGL(k_vgb_count<true>, dim3(blocks), dim3(256), 0, v->stream, v->table, (float *)d_pts, n, G,
-                                   (int32_t *)v->sort_vals_in, v->sort_keys_out, (const uint32_t *)nullptr, v->vg_cnt, frame->U,
-                                   frame->d_depth, frame->d_rgb, (float *)d_cols, (const double *)nullptr);
-            else
-                hipLaunchKernelGGL(k_vgb_count<false>, dim3(blocks), dim3(256), 0, v->stream, v->table, (float *)d_pts, n, G,
-                                   (int32_t *)v->sort_vals_in, v->sort_keys_out, d_valid, v->vg_cnt, HvUnprojectParams{},
-                                   (const void *)nullptr, (const uint8_t *)nullptr, (float *)nullptr, d_pts64);
+            B = hv_bins_begin(v, HV_VGB_IDX_BITS);
+#define HV_LAUNCH_BIN(FUSED, REC)                                                                                      \
+    hipLaunchKernelGGL((k_vgb_bin<FUSED, REC>), dim3(blocks), dim3(256), 0, v->stream, v->table, B, d_pts, d_pts64, d_cols, n, G, \
+                       d_valid, frame ? frame->U : HvUnprojectParams{}, frame ? frame->d_depth : (const void *)nullptr,  \
+                       frame ? frame->d_rgb : (const uint8_t *)nullptr, v->bin_rec)
+            if (frame) HV_LAUNCH_BIN(true, HV_REC_U8_DIV);
+            else if (rec_kind == HV_REC_U8_MUL) HV_LAUNCH_BIN(false, HV_REC_U8_MUL);
+            else if (rec_kind == HV_REC_F32) HV_LAUNCH_BIN(false, HV_REC_F32);
+            else HV_LAUNCH_BIN(false, HV_REC_NONE);
+#undef HV_LAUNCH_BIN
             if (!checked) break;
-            rc = hv_claims_fit(v); // blocks that did not fit: grow and claim again (the counts restart from clean arrays)
+            rc = hv_claims_fit(v); // blocks that did not fit: grow and claim again (the bins restart from clean arrays)
             if (rc == HV_OK) break;
-            v->vg_cap = 0; // counts / list of the aborted claim pass are void (and the table may have moved): fresh arrays next time
+            v->bins_clean = false; // counts / lists of the aborted claim pass are void (and the table may have moved)
             if (rc != HV_RETRY_CLAIM || attempt >= 8) return rc == HV_RETRY_CLAIM ? HV_ERR_CAPACITY : rc;
         }
-        v->vg_parity ^= 1;
-        // one thread per pool slot (how many are allocated is only known on the device; threads beyond leave at once)
-        const unsigned list_blocks = (unsigned)((v->cfg.max_blocks + 255) / 256);
-        hipLaunchKernelGGL(k_vgb_offsets, dim3(list_blocks), dim3(256), 0, v->stream, v->table, v->vg_touched, v->vg_cursor + parity,
-                           (const int32_t *)v->vg_cnt, v->vg_cur);
-        hipLaunchKernelGGL(k_vgb_scatter, dim3(blocks), dim3(256), 0, v->stream, (const int32_t *)v->sort_vals_in,
-                           (const uint32_t *)v->sort_keys_out, n, v->vg_cur, v->sort_keys_in);
+        v->bins.parity ^= 1;
         const int32_t seq = hv_next_status_seq(v);
-        // one wave per bucket, or - when the last finished frame had buckets beyond a wave's LDS window (coarse voxels, very
-        // close surfaces) - one workgroup per bucket; both are exact for any bucket size
+        // one wave per bin, or - when the last finished frame had bins beyond a wave's LDS window (coarse voxels, very
+        // close surfaces) - one workgroup per bin; both are exact for any bin size
         const bool big = v->h_status->pad > HV_VGB_WCAP;
         const unsigned fold_grid = (unsigned)std::min<int64_t>(std::max<int64_t>(n / (big ? 32 : 128), 256), 16384);
-#define HV_LAUNCH_FOLD(CK)                                                                                             \
+#define HV_LAUNCH_FOLD(REC)                                                                                            \
     do {                                                                                                               \
         if (big)                                                                                                       \
-            hipLaunchKernelGGL(k_vgb_fold<CK>, dim3(fold_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool,  \
-                               (const int32_t *)v->vg_touched, parity, v->vg_cursor, v->vg_cnt, (const int32_t *)v->vg_cur, \
-                               (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, n, v->d_status, seq);               \
+            hipLaunchKernelGGL(k_vgb_fold<REC>, dim3(fold_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool, B, G, \
+                               (const void *)v->bin_rec, n, v->d_status, seq);                                          \
         else                                                                                                           \
-            hipLaunchKernelGGL(k_vgb_fold_wave<CK>, dim3(fold_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool, \
-                               (const int32_t *)v->vg_touched, parity, v->vg_cursor, v->vg_cnt, (const int32_t *)v->vg_cur, \
-                               (const uint32_t *)v->sort_keys_in, G, d_pts, d_cols, n, v->d_status, seq);               \
+            hipLaunchKernelGGL(k_vgb_fold_wave<REC>, dim3(fold_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool, B, G, \
+                               (const void *)v->bin_rec, n, v->d_status, seq);                                          \
     } while (0)
-        if (color_kind == HV_COLOR_U8) HV_LAUNCH_FOLD(HV_COLOR_U8); else if (color_kind == HV_COLOR_F32) HV_LAUNCH_FOLD(HV_COLOR_F32); else HV_LAUNCH_FOLD(HV_COLOR_NONE);
+        if (rec_kind == HV_REC_U8_DIV) HV_LAUNCH_FOLD(HV_REC_U8_DIV);
+        else if (rec_kind == HV_REC_U8_MUL) HV_LAUNCH_FOLD(HV_REC_U8_MUL);
+        else if (rec_kind == HV_REC_F32) HV_LAUNCH_FOLD(HV_REC_F32);
+        else HV_LAUNCH_FOLD(HV_REC_NONE);
 #undef HV_LAUNCH_FOLD
         hv_profile_end(v, n);
         HV_HIP(hipGetLastError());
@@ -1074,27 +1051,6 @@ int hv_integrate_points_f64(hv_volume *v, const double *points, int64_t n, const
 // v->scratch_points / v->scratch_colors (float32) with the per-pixel validity flags in v->sort_keys_out.
 // d_depth_out receives the device address of the (staged) depth image.
 // k_vg_unproject of one frame already in HBM into slice [out_offset, out_offset + H*W) of the scratch arrays.
-static HvUnprojectParams unproject_params(int32_t depth_dtype, double depth_scale, int32_t height, int32_t width, const double *intr,
-                                          const double *T_cw, double min_depth, double max_depth) {
-    HvUnprojectParams U;
-    U.cx = intr[2];
-    U.cy = intr[3];
-    U.inv_fx = 1.0 / intr[0]; // depth.py:67-68
-    U.inv_fy = 1.0 / intr[1];
-    // inv_T, pyslam/utilities/geometry.py:98-104
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) U.Rwc[r * 3 + c] = T_cw[c * 4 + r];
-    for (int r = 0; r < 3; ++r)
-        U.twc[r] = -((U.Rwc[r * 3 + 0] * T_cw[3] + U.Rwc[r * 3 + 1] * T_cw[7]) + U.Rwc[r * 3 + 2] * T_cw[11]);
-    U.min_depth = (float)min_depth;
-    U.max_depth = (float)max_depth;
-    U.depth_scale_f = (float)depth_scale;
-    U.H = height;
-    U.W = width;
-    U.depth_is_u16 = depth_dtype == HV_DEPTH_U16;
-    return U;
-}
-
 static int unproject_device(hv_volume *v, const void *d_depth, int32_t depth_dtype, double depth_scale, const uint8_t *d_rgb,
                             int32_t height, int32_t width, const double *intr, const double *T_cw, double min_depth,
                             double max_depth, int64_t out_offset) {
