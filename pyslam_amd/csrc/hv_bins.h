@@ -99,25 +99,32 @@ __device__ __forceinline__ uint32_t hv_bins_entry(const HvBins &B, int32_t slot,
     return 0xFFFFFFFFu; // (its write failed and was counted)
 }
 
-// The bin pass's common half, called by ALL 256 threads of the workgroup (it synchronises): `has` = this thread holds a point of
-// block `bkey` (packed key, in range, this GPU's), local voxel index lidx, point index i.
+// The bin pass's common half, called by ALL threads of the workgroup (HV_BIN_THREADS; it synchronises): `has` = this thread holds a
+// point of block `bkey` (packed key, in range, this GPU's), local voxel index lidx, point index i.
+// Two single-word counters are touched ONCE per workgroup, both between the same two barriers: this XCD's touched-list length and
+// the pool's block counter (a workgroup's new blocks take consecutive pool indices).  Workgroups of 1024 threads: 1 225 of them for a
+// 1296x968 keyframe - that many returning atomics per word are ~13 us of serialised time, spread over the launch.
+static constexpr int HV_BIN_THREADS = 1024;
 __device__ __forceinline__ void hv_bins_push(const HvTable &table, const HvBins &B, bool has, unsigned long long bkey, uint32_t lidx, uint32_t i) {
-    __shared__ int32_t s_first[256];
-    __shared__ int32_t s_n, s_base;
-    if (threadIdx.x == 0) s_n = 0;
+    __shared__ int32_t s_first[HV_BIN_THREADS];
+    __shared__ int32_t s_new_slot[HV_BIN_THREADS];
+    __shared__ unsigned long long s_new_key[HV_BIN_THREADS];
+    __shared__ int32_t s_n, s_nn, s_base, s_nbase;
+    if (threadIdx.x == 0) s_n = s_nn = 0;
     __syncthreads();
     const int lane = hv_lane_id();
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const HvWaveGroup g = hv_wave_group_by_key(has, bkey);
     int32_t slot = -1, old = 0;
+    bool is_new = false;
     if (g.leader) {
-        slot = hv_table_insert(table, bkey);
+        slot = hv_table_claim(table, bkey, &is_new);
         if (slot >= 0) {
             old = atomicAdd(&B.cnt[slot], g.size);
             // a bin beyond a wave's LDS window: tell the host (it picks the fold kernel of the NEXT call by it)
             if (old + g.size > HV_VGB_WCAP) atomicMax(&table.counters[HV_CNT_OUT2], old + g.size);
         } else {
-            atomicAdd(&table.counters[HV_CNT_DROPPED], g.size); // (no room in the table / pool: reported by the caller's capacity checks)
+            atomicAdd(&table.counters[HV_CNT_DROPPED], g.size); // (the table is full: reported by the caller's capacity checks)
         }
     }
     slot = __shfl(slot, g.leader_lane);
@@ -126,9 +133,9 @@ __device__ __forceinline__ void hv_bins_push(const HvTable &table, const HvBins 
         uint32_t *at = hv_bins_place(table, B, slot, old + g.rank);
         if (at) *at = (lidx << B.idx_bits) | i;
     }
-    // the block's first points of this call: its slot enters the touched list (workgroup-aggregated, one atomic on this XCD's length)
+    // the block's first points of this call: its slot enters the touched list; a key this lane put into the table: it needs a block
     const bool first = g.leader && slot >= 0 && old == 0;
-    const unsigned long long fm = __ballot(first);
+    const unsigned long long fm = __ballot(first), nm = __ballot(is_new);
     if (fm) {
         const int fl = __ffsll((long long)fm) - 1;
         int32_t wb = 0;
@@ -136,14 +143,26 @@ __device__ __forceinline__ void hv_bins_push(const HvTable &table, const HvBins 
         wb = __shfl(wb, fl);
         if (first) s_first[wb + __popcll(fm & lt)] = slot;
     }
+    if (nm) {
+        const int fl = __ffsll((long long)nm) - 1;
+        int32_t wb = 0;
+        if (lane == fl) wb = atomicAdd(&s_nn, (int32_t)__popcll(nm));
+        wb = __shfl(wb, fl);
+        if (is_new) {
+            s_new_slot[wb + __popcll(nm & lt)] = slot;
+            s_new_key[wb + __popcll(nm & lt)] = bkey;
+        }
+    }
     __syncthreads();
-    const int32_t nf = s_n;
-    if (nf == 0) return; // (workgroup-uniform)
+    const int32_t nf = s_n, nn = s_nn;
+    if (nf == 0 && nn == 0) return; // (workgroup-uniform)
     const int xcc = hv_xcc_id();
-    if (threadIdx.x == 0) s_base = atomicAdd(&B.len[(B.parity * HV_BIN_LISTS + xcc) * HV_BIN_LEN_STRIDE], nf);
+    if (threadIdx.x == 0 && nf) s_base = atomicAdd(&B.len[(B.parity * HV_BIN_LISTS + xcc) * HV_BIN_LEN_STRIDE], nf);
+    if (threadIdx.x == HV_WAVE && nn) s_nbase = atomicAdd(&table.counters[HV_CNT_BLOCKS], nn); // (another wave: both round trips in flight together)
     __syncthreads();
-    const int32_t at = s_base + (int32_t)threadIdx.x;
-    if ((int32_t)threadIdx.x < nf && at < B.touched_cap) B.touched[(size_t)xcc * B.touched_cap + at] = s_first[threadIdx.x];
+    const int32_t t = (int32_t)threadIdx.x;
+    if (t < nf && s_base + t < B.touched_cap) B.touched[(size_t)xcc * B.touched_cap + s_base + t] = s_first[t];
+    if (t < nn) hv_table_assign(table, s_new_slot[t], s_new_key[t], s_nbase + t);
 }
 
 // Fold side: the call's touched slots as one sequence 0 .. total) over the eight lists.
@@ -173,6 +192,43 @@ __device__ __forceinline__ int32_t hv_bins_touched(const HvBins &B, const HvBinL
     }
     return B.touched[(size_t)x * B.touched_cap + t];
 }
+// The fold's walk over the touched bins: bins first, first + stride, ... of the call, one per call of body(header), by a WAVE (every
+// lane calls; control flow is wave-uniform).  A bin costs its wave a chain of dependent round trips (list entry -> size, block and
+// entries -> records / voxels), and a launch with one wave per bin is as long as the number of bins over the machine's wave slots
+// times that chain.  Here a PERSISTENT wave requests the header of its next bin - size, pool block, the first 64 entries - before
+// it works on the current one, and the list entry of the bin after that: the headers travel while the wave folds.
+struct HvBinHeader {
+    int32_t slot, nb, idx;
+    uint32_t head; // entry [lane] of the bin (places beyond nb hold stale entries)
+};
+__device__ __forceinline__ HvBinHeader hv_bins_header(const HvTable &table, const HvBins &B, int32_t slot) {
+    HvBinHeader h;
+    h.slot = slot;
+    h.head = B.inl[(size_t)slot * HV_BIN_K0 + hv_lane_id()];
+    h.nb = B.cnt[slot];
+    h.idx = table.vals[slot];
+    return h;
+}
+template <typename F>
+__device__ __forceinline__ void hv_bins_for_each(const HvTable &table, const HvBins &B, const HvBinLists &L, int first, int stride, F body) {
+    int t = first;
+    if (t >= L.total) return;
+    HvBinHeader h = hv_bins_header(table, B, hv_bins_touched(B, L, t));
+    int32_t slot_nn = t + stride < L.total ? hv_bins_touched(B, L, t + stride) : 0;
+    while (true) {
+        const HvBinHeader cur = h;
+        const int t1 = t + stride;
+        const bool more = t1 < L.total;
+        if (more) {
+            h = hv_bins_header(table, B, slot_nn);
+            slot_nn = t1 + stride < L.total ? hv_bins_touched(B, L, t1 + stride) : 0;
+        }
+        body(cur);
+        if (!more) break;
+        t = t1;
+    }
+}
+
 // the next call's list lengths (one thread of the fold)
 __device__ __forceinline__ void hv_bins_clear_next(const HvBins &B) {
 #pragma unroll
@@ -204,6 +260,22 @@ __device__ __forceinline__ void hv_vgb_bitonic_wave(uint32_t *s, int m2) { // as
     }
 }
 #endif // __HIPCC__
+
+// Workgroups of a persistent fold launch: as many as are resident at once (registers and LDS of THIS kernel: 4 per CU for the
+// probabilistic semantic fold at 128 registers, 8 for the VOXEL_GRID fold), asked once per kernel.
+template <typename K>
+static unsigned hv_bins_fold_grid(hv_volume *v, K kernel, size_t dyn_lds) {
+    static std::vector<std::pair<const void *, unsigned>> cache; // (one process-wide answer per kernel: the library is gfx950 only)
+    for (const auto &c : cache)
+        if (c.first == (const void *)kernel) return c.second;
+    int per_cu = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, v->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 4;
+    const unsigned grid = (unsigned)(per_cu * cus);
+    cache.emplace_back((const void *)kernel, grid);
+    return grid;
+}
 
 // Host side: the bins of a volume (hv_volume::bins_*), made for the current table and max_points, re-made when the table moves.
 static inline bool hv_bins_usable(const hv_volume *v, int64_t n, int idx_bits) {

@@ -176,6 +176,38 @@ __device__ inline int32_t hv_table_insert(const HvTable &t, uint64_t key) {
     return -1;
 }
 
+// Find-or-claim WITHOUT a pool index: *is_new = this call put the key into the table; the caller gives it its block
+// (hv_table_assign) - the bin pass does that for a whole workgroup's new keys with ONE atomic on the block counter (13 500 new blocks of
+// a 2 mm keyframe, one returning atomic each on that one word, were most of the bin pass: ~10 ns apiece, serialised).
+__device__ inline int32_t hv_table_claim(const HvTable &t, uint64_t key, bool *is_new) {
+    *is_new = false;
+    uint32_t s = hv_slot_hash(key) & t.mask;
+    for (uint32_t probe = 0; probe <= t.mask; ++probe) {
+        unsigned long long k = t.keys[s];
+        if (k == key) return (int32_t)s;
+        if (k == HV_EMPTY_KEY) {
+            k = atomicCAS(&t.keys[s], HV_EMPTY_KEY, (unsigned long long)key);
+            if (k == HV_EMPTY_KEY) {
+                *is_new = true;
+                return (int32_t)s;
+            }
+            if (k == key) return (int32_t)s;
+        }
+        s = (s + 1) & t.mask;
+    }
+    atomicAdd(&t.counters[HV_CNT_OVERFLOW], 1);
+    return -1;
+}
+// ... and the second half of hv_table_insert for a slot claimed that way: pool index idx (from the block counter)
+__device__ inline void hv_table_assign(const HvTable &t, int32_t slot, uint64_t key, int32_t idx) {
+    if (idx >= t.max_blocks) {
+        atomicAdd(&t.counters[HV_CNT_OVERFLOW], 1); // vals[slot] stays -1: consumers skip it
+        return;
+    }
+    t.vals[slot] = idx;
+    t.block_keys[idx] = key;
+}
+
 __device__ inline int hv_lane_id() { return (int)(threadIdx.x & (HV_WAVE - 1)); }
 
 // Wave-aggregated append: every lane with `pred` gets a distinct index from *counter; one atomic

@@ -17,6 +17,7 @@
 #include <array>
 #include <cmath>
 #include <numeric>
+#include <type_traits>
 
 #include "hv_common.h"
 #include "hv_query.h"
@@ -143,6 +144,33 @@ struct HvSemRecs {
     }
 };
 
+// ... and the same records after a wave has fetched its bin's into LDS, one lane per point, all loads in flight together (a run's head
+// lane then adds from LDS instead of chasing two global loads per point, one point after the other); indexed by sorted position
+struct HvSemStaged {
+    const float4 *stage; // LDS
+    const float *lut;    // LDS
+    bool labels, depth;
+    static constexpr bool kColors = true;
+    __device__ __forceinline__ bool has_labels() const { return labels; }
+    __device__ __forceinline__ bool has_depth() const { return depth; }
+    __device__ __forceinline__ HvSemPoint get(int64_t e) const {
+        const float4 a = stage[2 * e], b = stage[2 * e + 1];
+        HvSemPoint q;
+        q.x = (double)a.x;
+        q.y = (double)a.y;
+        q.z = (double)a.z;
+        const uint32_t c = __float_as_uint(a.w);
+        q.c0 = lut[c & 255u];
+        q.c1 = lut[(c >> 8) & 255u];
+        q.c2 = lut[(c >> 16) & 255u];
+        q.cls = (int32_t)__float_as_uint(b.x);
+        q.obj = (int32_t)__float_as_uint(b.y);
+        q.depth = b.z;
+        return q;
+    }
+};
+static constexpr int HV_SEMB_STAGE = 128; // bins up to this size fold from staged records (32 bytes each in the sort's spare windows)
+
 // update_voxel_direct (voxel_block_grid.hpp:524-614) for a SemanticVoxelWithDepth payload: one voxel's points folded in
 // point-index order.  `next(j)` yields the point index of the run's j-th entry, or -1 at its end.  VOX = HvSemVoxel (voting) or
 // HvProbVoxel (probabilistic).
@@ -249,7 +277,7 @@ __device__ __forceinline__ bool sem_point_block(const HvSemParams &G, double px,
 }
 
 template <typename PT>
-__global__ __launch_bounds__(256) void k_semb_bin(HvTable table, HvBins B, const PT *__restrict__ pts, int64_t n, HvSemParams G,
+__global__ __launch_bounds__(HV_BIN_THREADS) void k_semb_bin(HvTable table, HvBins B, const PT *__restrict__ pts, int64_t n, HvSemParams G,
                                                    const uint32_t *__restrict__ valid_mask_keys) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool has = false;
@@ -266,7 +294,7 @@ __global__ __launch_bounds__(256) void k_semb_bin(HvTable table, HvBins B, const
 // The frame entry point's bin pass: the thread unprojects its pixel (depth2pointcloud + world transform, hv_unproject.h), packs
 // position, colour, labels and depth into the pixel's 32-byte record and goes on with the key - the unprojection launch, its 24-byte
 // point / colour rows and the fold's seven scalar gathers per point are gone.
-__global__ __launch_bounds__(256) void k_semb_bin_frame(HvTable table, HvBins B, HvSemParams G, HvUnprojectParams U,
+__global__ __launch_bounds__(HV_BIN_THREADS) void k_semb_bin_frame(HvTable table, HvBins B, HvSemParams G, HvUnprojectParams U,
                                                         const void *__restrict__ depth_raw, const uint8_t *__restrict__ rgb,
                                                         const int32_t *__restrict__ cls_img, const int32_t *__restrict__ obj_img,
                                                         float4 *__restrict__ rec) {
@@ -377,7 +405,7 @@ template <typename VOX, typename SRC>
 __global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_wave(HvTable table, VOX *__restrict__ pool, HvBins B, HvSemParams G, SRC src_in,
                                                          unsigned long long *__restrict__ occ, int64_t n_points, HvStatus *status, int32_t status_seq,
                                                          int32_t *__restrict__ task_count, int4 *__restrict__ tasks, int task_cap, int wcap) {
-    extern __shared__ uint32_t s_dyn[]; // per wave: [wcap src][wcap dst][nvox + 64 offsets]; wcap = the window, a power of two (HV_SEM_WCAP)
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[]; // per wave: [wcap src][wcap dst][nvox + 64 offsets]; wcap = the window, a power of two (HV_SEM_WCAP)
     __shared__ float s_lut[256];
     const SRC src = sem_src_prepare(src_in, s_lut);
     const int idx_bits = B.idx_bits, parity = B.parity;
@@ -401,20 +429,64 @@ __global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_wave(
                               [&](int j) -> int64_t { return (e + j < m && (s[e + j] >> idx_bits) == lidx) ? (int64_t)(s[e + j] & idx_mask) : -1; });
         }
     };
-    for (int t = blockIdx.x * 4 + wave; t < L.total; t += gridDim.x * 4) {
-        const int32_t slot = hv_bins_touched(B, L, t);
-        const int32_t nb = B.cnt[slot];
-        const int32_t idx = table.vals[slot];
+    const bool can_stage = (size_t)(wcap + G.nvox + 64) * sizeof(uint32_t) >= (size_t)HV_SEMB_STAGE * 32;
+    hv_bins_for_each(table, B, L, blockIdx.x * 4 + wave, gridDim.x * 4, [&](const HvBinHeader &h) {
+        const int32_t slot = h.slot, nb = h.nb, idx = h.idx;
         hv_wave_lds_sync(); // the window of the previous bin is no longer read
         if (lane == 0) B.cnt[slot] = 0; // clean for the next call
-        if (idx < 0) continue;          // (the block did not get a pool slot: overflow, reported by the caller)
+        if (idx < 0) return;            // (the block did not get a pool slot: overflow, reported by the caller)
         const int64_t block_base = (int64_t)idx * G.nvox;
         if (nb <= wcap) {
-            for (int e = lane; e < nb; e += HV_WAVE) s[e] = hv_bins_entry(B, slot, e);
+            if (lane < nb) s[lane] = h.head; // (the header brought the bin's first 64 entries)
+            for (int e = HV_WAVE + lane; e < nb; e += HV_WAVE) s[e] = hv_bins_entry(B, slot, e);
             hv_wave_lds_sync();
             semb_sort_window(s, s_dst, off, nb, idx_bits, G.nvox);
+            if constexpr (std::is_same<SRC, HvSemRecs>::value) {
+                if (nb <= HV_SEMB_STAGE && can_stage) {
+                    // every lane fetches the records of ITS sorted entries (all of the bin's in flight at once) into the windows the sort
+                    // no longer needs, and - as the head of a voxel run - asks for the voxel's line, which then arrives with the records
+                    float4 *stage = (float4 *)s_dst;
+                    int32_t warm = 0;
+                    static_assert(HV_SEMB_STAGE == 2 * HV_WAVE, "two sorted entries per lane");
+                    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 ra0 = zero4, rb0 = zero4, ra1 = zero4, rb1 = zero4; // (named registers: an array indexed under a condition went to scratch)
+                    const int e0 = lane, e1 = lane + HV_WAVE;
+                    if (e0 < nb) {
+                        const uint32_t ent = s[e0];
+                        const int64_t p = ent & idx_mask;
+                        ra0 = src.rec[2 * p];
+                        rb0 = src.rec[2 * p + 1];
+                        if (e0 == 0 || (s[e0 - 1] >> idx_bits) != (ent >> idx_bits)) warm += pool[block_base + (ent >> idx_bits)].count;
+                    }
+                    if (e1 < nb) {
+                        const uint32_t ent = s[e1];
+                        const int64_t p = ent & idx_mask;
+                        ra1 = src.rec[2 * p];
+                        rb1 = src.rec[2 * p + 1];
+                        if ((s[e1 - 1] >> idx_bits) != (ent >> idx_bits)) warm += pool[block_base + (ent >> idx_bits)].count;
+                    }
+                    if (e0 < nb) {
+                        stage[2 * e0] = ra0;
+                        stage[2 * e0 + 1] = rb0;
+                    }
+                    if (e1 < nb) {
+                        stage[2 * e1] = ra1;
+                        stage[2 * e1 + 1] = rb1;
+                    }
+                    asm volatile("" ::"v"(warm)); // (the voxel lines have arrived)
+                    hv_wave_lds_sync();
+                    const HvSemStaged staged{stage, src.lut, src.labels, src.depth};
+                    for (int e = lane; e < nb; e += HV_WAVE) {
+                        const uint32_t lidx = s[e] >> idx_bits;
+                        if (e > 0 && (s[e - 1] >> idx_bits) == lidx) continue; // not the head of its voxel's run
+                        sem_fold_run<VOX>(table, pool, block_base + lidx, G, staged, occ,
+                                          [&](int j) -> int64_t { return (e + j < nb && (s[e + j] >> idx_bits) == lidx) ? (int64_t)(e + j) : -1; });
+                    }
+                    return;
+                }
+            }
             fold_sorted(nb, block_base);
-            continue;
+            return;
         }
         if (tasks != nullptr) {
             // A bin beyond the window (a wall at 0.7 m puts ~3 000 points of a 640x480 keyframe into one 8 cm block) would be a
@@ -426,7 +498,7 @@ __global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_wave(
             at = __shfl(at, 0);
             if (at + n_ranges <= task_cap) {
                 if (lane < n_ranges) tasks[at + lane] = make_int4(idx, lane, nb, slot);
-                continue;
+                return;
             }
             if (lane == 0) atomicSub(&task_count[parity], n_ranges); // (no room: this wave does it itself, below)
         }
@@ -467,7 +539,7 @@ __global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_wave(
                 if (w < 0) break;
             }
         }
-    }
+    });
 }
 
 // The deferred big bins: one wave per (block, range of 64 voxel indices).  The range's entries are picked out of the bin
@@ -477,7 +549,7 @@ template <typename VOX, typename SRC>
 __global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_tasks(HvTable table, VOX *__restrict__ pool, HvBins B, const int32_t *__restrict__ task_count,
                                                           const int4 *__restrict__ tasks, int task_cap, HvSemParams G, SRC src_in,
                                                           unsigned long long *__restrict__ occ, int64_t n_points, int wcap) {
-    extern __shared__ uint32_t s_dyn[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     __shared__ float s_lut[256];
     const SRC src = sem_src_prepare(src_in, s_lut);
     const int idx_bits = B.idx_bits;
@@ -679,7 +751,7 @@ static int sem_bins_run(hv_volume *v, int64_t n, bool checked, const SRC &src, B
     }
     v->bins.parity ^= 1;
     const int32_t seq = hv_next_status_seq(v);
-    const unsigned fold_grid = (unsigned)std::min<int64_t>(std::max<int64_t>(n / 128, 256), 16384);
+    const unsigned fold_grid = hv_bins_fold_grid(v, k_semb_fold_wave<VOX, SRC>, lds_bytes); // persistent waves (hv_bins_for_each)
     VOX *bpool = (VOX *)v->pool;
     // task list of the big bins: [2 counters (one per parity)][tasks]; at most n / wcap bins are big
     const int task_cap = (int)std::min<int64_t>((n / wcap + 1) * ((G.nvox + 63) / 64), 1 << 22);
@@ -714,7 +786,7 @@ static int sem_integrate(hv_volume *v, const PT *d_pts, int64_t n, const void *d
     // Per-keyframe bin path (rounds 4-6): needs the point index and the local voxel index in one 32-bit entry.
     if (sem_bins_usable(v, n)) {
         auto bin = [&](const HvBins &B) {
-            hipLaunchKernelGGL(k_semb_bin<PT>, dim3(blocks), dim3(256), 0, v->stream, v->table, B, d_pts, n, G, valid_mask_keys);
+            hipLaunchKernelGGL(k_semb_bin<PT>, dim3((unsigned)((n + HV_BIN_THREADS - 1) / HV_BIN_THREADS)), dim3(HV_BIN_THREADS), 0, v->stream, v->table, B, d_pts, n, G, valid_mask_keys);
         };
         if (color_kind == HV_COLOR_U8)
             return sem_bins_run<VOX>(v, n, checked, HvSemArrays<PT, HV_COLOR_U8>{d_pts, d_cols, d_cls, d_inst, d_depths}, bin);
@@ -987,7 +1059,7 @@ int hv_integrate_rgbd_semantic(hv_volume *v, const float *depth, const uint8_t *
         const HvSemParams G = sem_params(v);
         const HvUnprojectParams U = unproject_params(HV_DEPTH_F32, 1.0, height, width, intr, T_cw, min_depth, max_depth);
         auto bin = [&](const HvBins &B) {
-            hipLaunchKernelGGL(k_semb_bin_frame, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream, v->table, B, G, U, d_depth,
+            hipLaunchKernelGGL(k_semb_bin_frame, dim3((unsigned)((npx + HV_BIN_THREADS - 1) / HV_BIN_THREADS)), dim3(HV_BIN_THREADS), 0, v->stream, v->table, B, G, U, d_depth,
                                (const uint8_t *)d_rgb, d_cls, d_obj, (float4 *)v->bin_rec);
         };
         const HvSemRecs src{(const float4 *)v->bin_rec, nullptr, d_cls != nullptr, use_depths != 0};

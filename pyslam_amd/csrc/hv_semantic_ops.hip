@@ -255,6 +255,27 @@ __global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *_
                                                          int32_t *__restrict__ vcounts, int2 *__restrict__ pending,
                                                          const unsigned long long *__restrict__ occ, int quad) {
     __shared__ HvVoteLocal s_votes;
+    // Voxels waiting for their object id are collected per wave in LDS and get their places in the pending list with ONE returning
+    // atomic per ~200 of them (round 6): a 2 mm keyframe leaves a few hundred thousand such voxels behind, and one atomic per visit
+    // with a pending lane - tens of thousands on a single word, ~10 ns each, serialised - was most of this kernel.
+    constexpr int PEND_BUF = 256;
+    __shared__ int2 s_pend[4][PEND_BUF];
+    int2 *pend = s_pend[threadIdx.x / HV_WAVE];
+    int n_pend = 0; // (wave-uniform)
+    const unsigned long long lane_lt = hv_lane_id() == 0 ? 0ull : (~0ull >> (64 - hv_lane_id()));
+    auto flush_pending = [&]() {
+        if (n_pend == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int32_t base = 0;
+        if (hv_lane_id() == 0) base = atomicAdd(&table.counters[HV_CNT_AUX], n_pend);
+        base = __shfl(base, 0);
+        for (int k = hv_lane_id(); k < n_pend; k += HV_WAVE)
+            if (base + k < A.pending_cap) pending[base + k] = pend[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        n_pend = 0;
+    };
     vote_local_init(s_votes);
     if (n_blocks < 0) n_blocks = min(table.counters[HV_CNT_BLOCKS], table.max_blocks); // (the host does not wait to learn it)
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / HV_WAVE);
@@ -299,8 +320,12 @@ __global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *_
             }
         }
         vote_wave_local(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2], key);
-        const int32_t at = hv_wave_append(&table.counters[HV_CNT_AUX], is_pending);
-        if (is_pending && at < A.pending_cap) pending[at] = make_int2((int32_t)gid, inst);
+        const unsigned long long pm = __ballot(is_pending);
+        if (pm) {
+            if (is_pending) pend[n_pend + __popcll(pm & lane_lt)] = make_int2((int32_t)gid, inst);
+            n_pend += __popcll(pm);
+            if (n_pend > PEND_BUF - HV_WAVE) flush_pending();
+        }
     };
     if (QUAD && quad && sem_occ_words_usable(occ, G.nvox) && (G.nvox >> 6) <= 8) { // (QUAD: an instantiation of its own - the one-block form keeps its registers)
         // four blocks per wave, one per 16-lane group (sem_for_occupied_quad); the next quad's keys and words are requested before this
@@ -347,6 +372,7 @@ __global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *_
                 }
             }
         }
+        flush_pending();
         vote_local_flush(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2]);
         return;
     }
@@ -370,6 +396,7 @@ __global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *_
         if (words) sem_for_occupied_word(word, b, G.nvox, visit);
         else sem_for_occupied(occ, b, G.nvox, false, visit);
     }
+    flush_pending();
     vote_local_flush(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2]);
 }
 

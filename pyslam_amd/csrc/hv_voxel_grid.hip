@@ -269,7 +269,7 @@ __device__ __forceinline__ void hv_rec_lut(float *lut) { // by all 256 threads o
 // FUSED: the points do not exist yet - the thread unprojects its pixel (k_vg_unproject's arithmetic) and goes on with the key: one
 // launch and one pass over the points less per RGB-D frame.
 template <bool FUSED, int REC>
-__global__ __launch_bounds__(256) void k_vgb_bin(HvTable table, HvBins B, const float *__restrict__ pts, const double *__restrict__ pts64,
+__global__ __launch_bounds__(HV_BIN_THREADS) void k_vgb_bin(HvTable table, HvBins B, const float *__restrict__ pts, const double *__restrict__ pts64,
                                                   const void *__restrict__ cols, int64_t n, HvGridParams G,
                                                   const uint32_t *__restrict__ valid_mask_keys, HvUnprojectParams U,
                                                   const void *__restrict__ depth_raw, const uint8_t *__restrict__ rgb, void *__restrict__ rec) {
@@ -401,13 +401,12 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
     }
     const int wave = threadIdx.x >> 6, lane = hv_lane_id();
     uint32_t *s = s_all[wave];
-    for (int t = blockIdx.x * 4 + wave; t < L.total; t += gridDim.x * 4) {
-        const int32_t slot = hv_bins_touched(B, L, t);
-        const int32_t nb = B.cnt[slot];
-        const int32_t idx = table.vals[slot];
+    hv_bins_for_each(table, B, L, blockIdx.x * 4 + wave, gridDim.x * 4, [&](const HvBinHeader &h) {
+        const int32_t slot = h.slot, nb = h.nb, idx = h.idx;
+        const uint32_t head = h.head; // (a bin holds ~24 points: for most bins the header's 64 entries are all of them)
         hv_wave_lds_sync(); // the window of the previous bin is no longer read
         if (lane == 0) B.cnt[slot] = 0; // clean for the next call
-        if (idx < 0) continue;          // (the block did not get a pool slot: overflow, reported by the caller)
+        if (idx < 0) return;            // (the block did not get a pool slot: overflow, reported by the caller)
         HvVoxel *block = pool + (int64_t)idx * G.nvox;
         if (nb <= HV_VGB_RANK) {
             // small bin (the common case: a few dozen points): every lane ranks its <= 4 entries against the whole bin
@@ -417,7 +416,7 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
 #pragma unroll
             for (int q = 0; q < HV_VGB_RANK / HV_WAVE; ++q) {
                 const int e = lane + q * HV_WAVE;
-                mine[q] = e < nb ? B.inl[(size_t)slot * HV_BIN_K0 + e] : 0xFFFFFFFFu; // (HV_VGB_RANK <= HV_BIN_K0: inline entries only)
+                mine[q] = e >= nb ? 0xFFFFFFFFu : q == 0 ? head : B.inl[(size_t)slot * HV_BIN_K0 + e]; // (HV_VGB_RANK <= HV_BIN_K0: inline entries only)
                 rank[q] = 0;
                 if (e < nb) s[e] = mine[q];
             }
@@ -490,11 +489,11 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
                     } while (j < nb && (s[j] >> HV_VGB_IDX_BITS) == lidx);
                     *vx = acc;
                 }
-                continue;
+                return;
             }
             hv_wave_lds_sync();
             hv_vgb_fold_sorted<REC>(s, nb, lane, HV_WAVE, block, rec, s_lut);
-            continue;
+            return;
         }
         if (nb <= HV_VGB_WCAP) {
             int m2 = HV_WAVE;
@@ -503,7 +502,7 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
             hv_wave_lds_sync();
             hv_vgb_bitonic_wave(s, m2);
             hv_vgb_fold_sorted<REC>(s, nb, lane, HV_WAVE, block, rec, s_lut);
-            continue;
+            return;
         }
         for (int64_t w = 0; w < n_points; w += HV_VGB_WCAP) { // point-index windows, ascending: a voxel's points stay in order
             hv_wave_lds_sync();
@@ -526,7 +525,7 @@ __global__ __launch_bounds__(256) void k_vgb_fold_wave(HvTable table, HvVoxel *_
             hv_vgb_bitonic_wave(s, m2);
             hv_vgb_fold_sorted<REC>(s, m, lane, HV_WAVE, block, rec, s_lut);
         }
-    }
+    });
 }
 
 template <int REC>
@@ -875,7 +874,7 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
             if (rc != HV_OK) return rc;
             B = hv_bins_begin(v, HV_VGB_IDX_BITS);
 #define HV_LAUNCH_BIN(FUSED, REC)                                                                                      \
-    hipLaunchKernelGGL((k_vgb_bin<FUSED, REC>), dim3(blocks), dim3(256), 0, v->stream, v->table, B, d_pts, d_pts64, d_cols, n, G, \
+    hipLaunchKernelGGL((k_vgb_bin<FUSED, REC>), dim3((unsigned)((n + HV_BIN_THREADS - 1) / HV_BIN_THREADS)), dim3(HV_BIN_THREADS), 0, v->stream, v->table, B, d_pts, d_pts64, d_cols, n, G, \
                        d_valid, frame ? frame->U : HvUnprojectParams{}, frame ? frame->d_depth : (const void *)nullptr,  \
                        frame ? frame->d_rgb : (const uint8_t *)nullptr, v->bin_rec)
             if (frame) HV_LAUNCH_BIN(true, HV_REC_U8_DIV);
@@ -894,15 +893,16 @@ static int integrate_device_points(hv_volume *v, const float *d_pts, int64_t n, 
         // one wave per bin, or - when the last finished frame had bins beyond a wave's LDS window (coarse voxels, very
         // close surfaces) - one workgroup per bin; both are exact for any bin size
         const bool big = v->h_status->pad > HV_VGB_WCAP;
-        const unsigned fold_grid = (unsigned)std::min<int64_t>(std::max<int64_t>(n / (big ? 32 : 128), 256), 16384);
+        // wave form: persistent waves, one per wave slot of the machine (hv_bins_for_each); workgroup form: one workgroup per bin
+        const unsigned big_grid = (unsigned)std::min<int64_t>(std::max<int64_t>(n / 32, 256), 16384);
 #define HV_LAUNCH_FOLD(REC)                                                                                            \
     do {                                                                                                               \
         if (big)                                                                                                       \
-            hipLaunchKernelGGL(k_vgb_fold<REC>, dim3(fold_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool, B, G, \
+            hipLaunchKernelGGL(k_vgb_fold<REC>, dim3(big_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool, B, G, \
                                (const void *)v->bin_rec, n, v->d_status, seq);                                          \
         else                                                                                                           \
-            hipLaunchKernelGGL(k_vgb_fold_wave<REC>, dim3(fold_grid), dim3(256), 0, v->stream, v->table, (HvVoxel *)v->pool, B, G, \
-                               (const void *)v->bin_rec, n, v->d_status, seq);                                          \
+            hipLaunchKernelGGL(k_vgb_fold_wave<REC>, dim3(hv_bins_fold_grid(v, k_vgb_fold_wave<REC>, 0)), dim3(256), 0, v->stream, v->table, \
+                               (HvVoxel *)v->pool, B, G, (const void *)v->bin_rec, n, v->d_status, seq);                \
     } while (0)
         if (rec_kind == HV_REC_U8_DIV) HV_LAUNCH_FOLD(HV_REC_U8_DIV);
         else if (rec_kind == HV_REC_U8_MUL) HV_LAUNCH_FOLD(HV_REC_U8_MUL);

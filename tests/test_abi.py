@@ -153,10 +153,12 @@ def test_hot_kernels_keep_their_state_in_registers(tmp_path):
         assert hit, parts
         return hit
 
-    # the semantic folds (bucket path and radix path), both payloads: no struct in scratch, 4 waves per SIMD (<= 128 registers)
+    # the semantic folds (bin path and radix path), both payloads: no struct in scratch, 4 waves per SIMD (<= 128 registers).  The
+    # keyframe flow's own instantiations (packed records, HvSemRecs) keep their spills under 32 bytes; the array-source ones of the
+    # binding's generic integrate overloads (float64 points, separate colour / label arrays) may spill a few registers more at the cap
     for parts in (("k_semb_fold_wave",), ("k_semb_fold_tasks",), ("k_sem_reduce",)):
         for name, m in pick(*parts).items():
-            assert m["private_segment_fixed_size"] <= 64, (name, m)
+            assert m["private_segment_fixed_size"] <= (32 if "HvSemRecs" in name else 96), (name, m)
             assert m["vgpr_count"] <= 128, (name, m)
     # the association vote: 4 waves per SIMD (the one-block-per-wave forms without any spill)
     for name, m in pick("k_sem_assoc_vote").items():
