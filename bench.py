@@ -519,10 +519,8 @@ def main():
                          "RCCL accepts a one-rank group, so the N > 1 code path of this file can be executed on a one-GPU box")
     ap.add_argument("--all-on-device0", action="store_true",
                     help="testing only: every rank uses GPU 0 (multi-rank code path on a 1-GPU box, with --backend gloo)")
-    ap.add_argument("--sharding", choices=["owner", "tile", "coherent"], default="owner",
+    ap.add_argument("--sharding", choices=["owner", "tile"], default="owner",
                     help="N > 1: owner = unit-ownership sharding by hash, no collective while fusing (default); "
-                         "coherent = ownership planned per batch on the device (equal work, image-contiguous units per GPU; units may end up "
-                         "on several GPUs: consolidated by merge_halo / gather_to_root); "
                          "tile = image tiles + RCCL merge of the shared units at the end")
     ap.add_argument("--mode", choices=["batch", "online"], default="batch",
                     help="batch: one multi-frame sweep per step (replay/rebuild path); online: one integrate() per frame")
@@ -865,9 +863,7 @@ def main():
                 "sharding": "single spatial tile" if world == 1 else (
                     f"unit ownership: unit -> GPU hash(index) % {world}; every GPU sees every frame, fuses and stores only its "
                     f"units; no collective while fusing" if args.sharding == "owner"
-                    else (f"ownership planned per batch on the device: equal work per GPU, a GPU's units contiguous in the image of the batch's "
-                          f"middle frame; every GPU sees every frame, no collective while fusing" if args.sharding == "coherent"
-                          else f"{world} vertical image tiles + RCCL merge of the shared units (timed)")),
+                    else f"{world} vertical image tiles + RCCL merge of the shared units (timed)"),
                 "units_allocated": units_allocated,
                 "clock_ramp_steps": args.clock_ramp_steps,
                 "build_digest": digest,

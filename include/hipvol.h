@@ -210,6 +210,10 @@ int hv_set_depth_decay_rate(hv_volume *v, float depth_decay_rate);
 /* Label observations the probabilistic payload could not store (a voxel's map past 254 pairs, or the overflow-node pool exhausted):
  * 0 in every test and bench run; never silent. */
 int hv_label_overflows(hv_volume *v, int64_t *n);
+/* Overflow nodes of the probabilistic label maps handed out so far (of the pool's 4 per block; HV_PROB_NODE_CAP overrides).  A voxel
+ * that is reset (carve, remove_low_*, remove_segment) keeps its chain and grows its next map into it, so the count is bounded by the
+ * longest map every voxel ever held - it does not grow with the number of carve / re-observe cycles. */
+int hv_prob_nodes_used(hv_volume *v, int64_t *n);
 /* assign_object_ids_to_instance_ids(camera_frustrum, class_ids_image i32 HxW, semantic_instances_image i32 HxW,
  * depth_image f32 HxW | NULL, depth_threshold, do_carving, min_vote_ratio, min_votes)
  * (voxel_semantic_data_association.h:70-373).  Returns the instance -> object map sorted by instance id in
@@ -301,14 +305,13 @@ int hv_tsdf_integrate_frames(hv_volume *v, const void *const *depth_frames, int3
                              int32_t n_frames, int32_t height, int32_t width, const double *intr, const double *T_cw,
                              double depth_scale, double depth_trunc);
 
-/* How hv_tsdf_set_owner's N GPUs divide the units of a multi-frame call: 0 = owner(unit) = hash(unit index) % N (static; the GPUs'
- * unit sets are disjoint for ever, zero merge), 1 = IMAGE-COHERENT: every hv_tsdf_integrate_batch / _frames call plans its
- * batch on the device - equal work per GPU, a GPU's units contiguous in the image (vertical strips of the batch's middle
- * frame) - so that a GPU touches, packs and gathers only its own part of every frame; all GPUs derive the same plan from the
- * same frames without communication.  Ownership then moves with the camera: a unit's additive numerators may live on several
- * GPUs and are consolidated by hv_merge_halo_* / hv_tsdf_export_numerators like the tile form's.  Single frames
- * (hv_tsdf_integrate) use the hash in both modes. */
-int hv_tsdf_set_sharding(hv_volume *v, int32_t mode);
+/* Undistort / rectify on the device.  The reference remaps every keyframe on the host before it is fused
+ * (estimate_depth_if_needed_and_rectify, volumetric_integrator_base.py:1017-1043: cv2.remap colour INTER_LINEAR, depth INTER_NEAREST,
+ * maps from cv2.initUndistortRectifyMap, :758-786).  With maps set (float32 [H,W], at `loc`; copied), every frame handed to
+ * hv_tsdf_integrate / _batch / _frames goes through them first - one launch per batch, beside the batch's touch + pack launch, the
+ * depth in its own storage type (float32 or uint16: 5 bytes per pixel for a TUM-style keyframe end to end) - and the caller passes
+ * the RECTIFIED intrinsics.  map_x == NULL clears them.  OpenCV's remap semantics restated (hv_remap): unpinned. */
+int hv_tsdf_set_rectify_maps(hv_volume *v, const float *map_x, const float *map_y, int32_t height, int32_t width, int32_t loc);
 
 /* Channel order of the colour frames handed to hv_tsdf_integrate*: 0 = R, G, B (Open3D's RGBDImage, the default), 1 = B, G, R -
  * pySLAM's keyframe.img as OpenCV loads it; the reference converts every keyframe on the host with cv2.cvtColor

@@ -86,3 +86,38 @@ def filter_shadow_points(depth, delta_depth=None, delta_x=2, delta_y=2, fill_val
         mask[:, :-delta_x] |= big
     depth_out[mask] = fill_value
     return depth_out
+
+
+def _cv_round(a):
+    """cvRound: round half to even (float32 maps, as cv2.remap converts them)."""
+    return np.rint(np.asarray(a, dtype=np.float32)).astype(np.int64)
+
+
+def remap_nearest(src, map_x, map_y):
+    """cv2.remap(src, map_x, map_y, cv2.INTER_NEAREST), BORDER_CONSTANT 0 (volumetric_integrator_base.py:1030-1043), restated:
+    dst(y, x) = src(cvRound(map_y), cvRound(map_x)).  OpenCV is not in this image: unpinned (tests/test_prep_undistort.py)."""
+    H, W = src.shape[:2]
+    sx, sy = _cv_round(map_x), _cv_round(map_y)
+    ok = (sx >= 0) & (sx < W) & (sy >= 0) & (sy < H)
+    out = np.zeros(map_x.shape + src.shape[2:], dtype=src.dtype)
+    out[ok] = src[sy[ok], sx[ok]]
+    return out
+
+
+def remap_linear_u8(src, map_x, map_y):
+    """cv2.remap(src uint8 HxWxC, ..., cv2.INTER_LINEAR), BORDER_CONSTANT 0 (volumetric_integrator_base.py:1019-1028), restated:
+    fixed-point bilinear with INTER_BITS = 5 - coordinates quantised to 1/32 pixel, integer weights summing to 2^15,
+    (sum + 2^14) >> 15.  Unpinned, like remap_nearest."""
+    H, W = src.shape[:2]
+    sx = _cv_round(np.asarray(map_x, np.float32) * np.float32(32.0))
+    sy = _cv_round(np.asarray(map_y, np.float32) * np.float32(32.0))
+    ix, iy, fx, fy = sx >> 5, sy >> 5, sx & 31, sy & 31
+    w = [(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32]
+    acc = np.zeros(map_x.shape + src.shape[2:], dtype=np.int64)
+    for (dy, dx), wk in zip(((0, 0), (0, 1), (1, 0), (1, 1)), w):
+        x, y = ix + dx, iy + dy
+        ok = (x >= 0) & (x < W) & (y >= 0) & (y < H)
+        px = np.zeros_like(acc)
+        px[ok] = src[y[ok], x[ok]]
+        acc += px * (wk[..., None] if src.ndim == 3 else wk)
+    return np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)

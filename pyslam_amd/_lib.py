@@ -79,6 +79,7 @@ SIGNATURES = {
     "hv_set_depth_decay_rate": (_i32, [_vp, _f32]),
     "hv_integrate_rgbd_semantic": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _f64, _i32, _i32]),
     "hv_label_overflows": (_i32, [_vp, _pi64]),
+    "hv_prob_nodes_used": (_i32, [_vp, _pi64]),
     "hv_assign_object_ids_to_instance_ids": (_i32, [_vp, _vp, _i32, _i32, _vp, _f32, _f32, _vp, _vp, _vp, _f32, _i32, _f32, _i32,
                                                     _vp, _vp, _i64, _pi64, _i32]),
     "hv_assoc_vote": (_i32, [_vp, _vp, _i32, _i32, _vp, _f32, _f32, _vp, _vp, _vp, _f32, _i32, _i32]),
@@ -103,10 +104,10 @@ SIGNATURES = {
     "hv_tsdf_integrate_batch": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_tsdf_integrate_frames": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64]),
     "hv_tsdf_set_color_order": (_i32, [_vp, _i32]),
-    "hv_tsdf_set_sharding": (_i32, [_vp, _i32]),
     "hv_host_register": (_i32, [_vp, _i64]),
     "hv_host_unregister": (_i32, [_vp]),
     "hv_tsdf_set_tile": (_i32, [_vp, _i32, _i32, _i32, _i32]),
+    "hv_tsdf_set_rectify_maps": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32]),
     "hv_tsdf_set_owner": (_i32, [_vp, _i32, _i32]),
     "hv_tsdf_extract_mesh": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _pi64, _pi64]),
     "hv_tsdf_extract_points": (_i32, [_vp, _vp, _vp, _i64, _pi64]),

@@ -122,17 +122,13 @@ enum {
     HV_CNT_LABEL_OVERFLOW = 8, // probabilistic payload: label observations dropped (the overflow-node pool is exhausted / > 254 labels)
     HV_CNT_PROB_NODES = 9,     // probabilistic payload: overflow nodes handed out
     // TSDF counters that are hammered by atomics while other workgroups of the same launch READ their neighbours live on 128-byte
-    // lines of their own (round 5: with the fused launch's completion counter on the line of the list lengths every workgroup reads
-    // at its start, the line bounced between the XCDs' L2s and the launch took 35 ns per WORKGROUP - 2.4 ms instead of 0.55)
+    // lines of their own
     HV_CNT_TOUCH0 = 32,  // touched-unit list length, scratch set 0 (online path: frame parity 0)
     HV_CNT_TOUCH1 = 64,  // ... set 1 (frame parity 1)
-    HV_CNT_TOUCH2 = 96,  // ... set 2 (the batch pipeline's third set)
-    HV_CNT_SWEEP_DONE = 128,   // k_tsdf_fused: XCDs whose items have all finished (back to 0 with the last one)
-    HV_CNT_SWEEP_DONE_XCD = 160, // + 32 * xcd: items of that XCD that have finished (back to 0 with the XCD's last one)
-    HV_CNT_COUNT = 160 + 32 * 8
+    HV_CNT_COUNT = 96
 };
 #define HV_CNT_TOUCH(set) (HV_CNT_TOUCH0 + 32 * (set))
-static constexpr int HV_TSDF_SETS = 3; // scratch sets of the multi-frame paths (frame records, union list, frame masks, list counter)
+static constexpr int HV_TSDF_SETS = 2; // scratch sets of the multi-frame paths (frame records, union list, frame masks, list counter)
 static constexpr size_t HV_CNT_TOUCH_SPAN_BYTES = sizeof(int32_t) * (32 * (HV_TSDF_SETS - 1) + 1); // one memset clears every list length (nothing lives between them)
 
 #ifdef __HIPCC__
@@ -329,7 +325,6 @@ struct hv_volume {
     int32_t *touched_list = nullptr;  // [2][max_blocks] slots touched this frame / batch (second half: the batch pipeline's other set)
     uint64_t *touched_mask = nullptr; // [2][table_capacity] per-slot frame bitmask of the multi-frame sweep (ditto)
     void *frame_px = nullptr;         // [max_points] uint2 {depth f32 bits, packed rgb}: the gather target
-    int debug_variant = 0;            // env HV_TSDF_DEBUG_VARIANT (roofline ablation only)
     int color_bgr = 0;                // hv_tsdf_set_color_order
     int touch_box_bits = 2048;        // env HV_TSDF_TOUCH_BOX_BITS (0 forces the touch pass's general path; tests)
     int32_t frame_counter = 0;
@@ -342,33 +337,19 @@ struct hv_volume {
     // on `stream`; two sets of scratch (batch_buf / batch_buf2, the halves of touched_list / touched_mask, TOUCH0 / TOUCH1)
     void *batch_buf2 = nullptr;
     size_t batch_buf2_bytes = 0;
-    void *batch_buf3 = nullptr;       // third set (round 5): a batch's touch + pack launch may run TWO sweeps ahead of its own
-    size_t batch_buf3_bytes = 0;
-    hipEvent_t ev_set_prep[3] = {nullptr, nullptr, nullptr}; // the set's touch + pack (+ list sort) launches are done (stream_aux -> stream)
-    hipEvent_t ev_set_free[3] = {nullptr, nullptr, nullptr}; // the batch that last used the set has been swept and finished (stream -> stream_aux)
-    bool ev_set_free_valid[3] = {false, false, false};
     hipStream_t stream_aux = nullptr;
     hipEvent_t ev_prep = nullptr;     // touch + pack of the current batch done (stream_aux -> stream)
     hipEvent_t ev_presweep = nullptr; // everything on `stream` up to the point just before the previous batch's sweep
     int batch_parity = 0;             // scratch set of the next batch
     bool pipe_armed = false;          // ev_presweep is recorded and ...
     uint64_t pipe_version = 0;        // ... content_version has this value iff nothing else touched the volume since that batch
-    // fused form (k_tsdf_fused, round 5): the sweep of the batch a call hands over is launched by the NEXT call, in one launch with
-    // that call's touch + pack pass, or by hv_tsdf_flush, which every other entry point runs first.  One stream, no hand-off events.
-    struct {
-        bool valid = false;
-        int parity = 0, n_frames = 0, ring = 0; // scratch set, frames, slot of the frame-constant ring
-        const void *px = nullptr;               // the batch's frame records
-        const HvFrameParams *params = nullptr;  // its frame constants (device ring)
-    } pending;
-    void *list_sorted = nullptr;      // [2][max_blocks] a batch's union list by decreasing work (k_tsdf_list_by_work; HV_TSDF_LPT)
-    size_t list_sorted_bytes = 0;
-    uint32_t *touch_ticket = nullptr; // touch workgroups of the running touch + pack launch that have finished (back to 0 with the last one)
-    int32_t *sweep_done = nullptr;    // [table_capacity] parts of a unit finished by the running fused launch (zero between launches)
-    void *params_ring = nullptr;      // device: 4 x 64 HvFrameParams, filled a batch ahead by k_upload_words on stream_up
-    hipStream_t stream_up = nullptr;
-    hipEvent_t ev_swept[4] = {nullptr, nullptr, nullptr, nullptr}; // the sweep that read ring slot i has been launched and finished
-    bool ev_swept_valid[4] = {false, false, false, false};
+    // undistort / rectify maps of the camera (hv_tsdf_set_rectify_maps): when set, every frame handed to hv_tsdf_integrate* is remapped
+    // on the device first (colour bilinear, depth nearest: the reference's per-keyframe cv2.remap pair) into rect_buf
+    float *rect_map_x = nullptr, *rect_map_y = nullptr;
+    size_t rect_map_x_bytes = 0, rect_map_y_bytes = 0;
+    int32_t rect_W = 0, rect_H = 0;   // 0: no rectification
+    void *rect_buf = nullptr;         // [B frames depth][B frames rgb] of the batch being prepared
+    size_t rect_buf_bytes = 0;
     float *mult_table = nullptr;      // per-pixel depth-to-distance multiplier of the current intrinsics (multi-frame sweep)
     size_t mult_table_bytes = 0;
     float mult_key[4] = {0.f, 0.f, 0.f, 0.f}; // cx, cy, 1/fx, 1/fy the table was built for
@@ -379,10 +360,6 @@ struct hv_volume {
     int params_idx = 0;
     int32_t tile[4] = {0, 0, 0, 0}; // u0, v0, u1, v1; all zero = whole image
     int32_t owner_rank = 0, owner_world = 1; // hv_tsdf_set_owner
-    int32_t shard_coherent = 0;              // hv_tsdf_set_sharding: 1 = ownership planned per batch in the image of its middle frame
-    void *plan_buf = nullptr;                // [2 sets] batch table + histogram + per-frame pixel boxes (k_tsdf_touch_plan ...)
-    size_t plan_buf_bytes = 0, plan_cap = 0;
-    bool plan_lists_stale = false;           // coherent batches left their list sizes in the TOUCH counters
     float sem_depth_threshold = 10.0f;       // VoxelSemanticDataT::kDepthThreshold (hv_set_depth_threshold)
     float sem_depth_decay_rate = 0.07f;      // VoxelSemanticDataProbabilisticT::kDepthDecayRate (hv_set_depth_decay_rate)
     void *assoc_buf = nullptr;               // association vote table + pending list (hv_semantic_ops.hip)
@@ -473,9 +450,9 @@ static constexpr int HV_RETRY_CLAIM = 1000;
 int32_t hv_next_status_seq(hv_volume *v); // sequence number for the call's publishing kernel
 void hv_launch_publish_status(hv_volume *v); // modes whose last kernel does not publish by itself
 int hv_read_counters(hv_volume *v); // D2H of the counter block (synchronises the stream)
-// TSDF: launch the deferred sweep of the last multi-frame batch, if there is one (see hv_volume::pending).  Every entry point that
-// reads or changes the volume, its stream or its tables runs this first; cheap no-op otherwise.
-int hv_tsdf_flush(hv_volume *v);
+// hv_prep.hip: n_frames device-resident frames through the volume's rectify maps, queued on `s`
+int hv_rectify_frames_device(hv_volume *v, hipStream_t s, const void *d_depth, int32_t depth_dtype, const uint8_t *d_rgb, int n_frames,
+                             int height, int width, void *d_depth_out, uint8_t *d_rgb_out);
 int hv_stage_in(hv_volume *v, const void *src, size_t bytes, int32_t loc, int which, const void **dev);
 // hipMemcpyAsync(H2D) of a caller's array on the volume's stream; waits for the copy when the source is page-locked (the DMA would
 // otherwise read it after the call has returned: the ABI borrows host arrays for the duration of the call only)

@@ -63,7 +63,6 @@ int hv_ensure_buffer(hv_volume *v, void **buf, size_t *cur, size_t want) {
 }
 
 int hv_read_counters(hv_volume *v) {
-    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_HIP(hipMemcpyAsync(v->h_counters, v->table.counters, sizeof(int32_t) * HV_CNT_COUNT,
                           hipMemcpyDeviceToHost, v->stream));
     HV_HIP(hipStreamSynchronize(v->stream));
@@ -202,7 +201,7 @@ __attribute__((target("avx2"))) void hv_stream_copy_avx2(char *dst, const char *
 }
 
 void hv_stream_copy(char *dst, const char *src, size_t n) {
-    static const bool avx2 = __builtin_cpu_supports("avx2") && !(getenv("HV_STAGE_NT") && atoi(getenv("HV_STAGE_NT")) == 0);
+    static const bool avx2 = __builtin_cpu_supports("avx2");
     if (avx2) hv_stream_copy_avx2(dst, src, n);
     else memcpy(dst, src, n);
 }
@@ -293,7 +292,7 @@ int hv_stage_frames(hv_volume *v, const void *const *depth_ptrs, const void *dep
     // DMA engine reads each of them in place.  The call returns when the copies have READ the caller's memory (the contract of
     // hv_tsdf_integrate_frames) - the host waits for the copy stream, not for the sweep that runs beside it.
     {
-        bool pinned = depth_ptrs != nullptr && rgb_ptrs != nullptr && !(getenv("HV_STAGE_DIRECT") && atoi(getenv("HV_STAGE_DIRECT")) == 0);
+        bool pinned = depth_ptrs != nullptr && rgb_ptrs != nullptr;
         for (int f = 0; pinned && f < n_frames; ++f)
             pinned = hv_host_is_registered(depth_ptrs[f], depth_frame_bytes) && hv_host_is_registered(rgb_ptrs[f], rgb_frame_bytes);
         if (pinned) {
@@ -314,7 +313,7 @@ int hv_stage_frames(hv_volume *v, const void *const *depth_ptrs, const void *dep
     // sub-chunks of about 16 MB: long enough for the DMA engine to reach its rate, short enough that the first one is on its
     // way early
     size_t sub_target = 16u << 20; // (4 / 8 / 16 MB measured: 0.53 / 0.72 / 0.76 of the H2D bound)
-    if (const char *e = getenv("HV_STAGE_CHUNK_MB")) sub_target = (size_t)std::max(1, atoi(e)) << 20;
+    if (const char *e = getenv("HV_STAGE_CHUNK_MB")) sub_target = (size_t)std::max(1, atoi(e)) << 20; // (tests: small sub-chunks reuse slots and sets)
     const int per_sub = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, sub_target / std::max<size_t>(1, frame_bytes)));
     HvCopyPool *pool = hv_copy_pool();
     for (int c0 = 0; c0 < n_frames; c0 += per_sub) {
@@ -591,22 +590,7 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
         }                                                                                          \
     } while (0)
 
-    {
-        // HV_TSDF_AUX_CUS=n with HV_TSDF_MAIN_EXCLUDE=1 (experiment): the main stream stays OFF the n CUs the
-        // touch + pack stream gets (hv_tsdf.hip), i.e. the two launches run on disjoint CU sets
-        const int aux_cus = getenv("HV_TSDF_AUX_CUS") ? atoi(getenv("HV_TSDF_AUX_CUS")) : 0;
-        if (cfg->mode == HV_MODE_TSDF && aux_cus > 0 && aux_cus < 256 && getenv("HV_TSDF_MAIN_EXCLUDE") && atoi(getenv("HV_TSDF_MAIN_EXCLUDE")) != 0) {
-            uint32_t mask[8];
-            for (int i = 0; i < 8; ++i) mask[i] = 0xffffffffu;
-            for (int i = 0; i < aux_cus; ++i) {
-                const int bit = (int)((int64_t)i * 256 / aux_cus);
-                mask[bit >> 5] &= ~(1u << (bit & 31));
-            }
-            HV_TRY(hipExtStreamCreateWithCUMask(&v->stream, 8, mask));
-        } else {
-            HV_TRY(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
-        }
-    }
+    HV_TRY(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
     v->own_stream = true;
 
     const int64_t nvox = (int64_t)cfg->block_size * cfg->block_size * cfg->block_size;
@@ -640,9 +624,7 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
         HV_TRY(hipMalloc(&v->touched_stamp, sizeof(int32_t) * v->table_capacity));
         HV_TRY(hipMalloc(&v->touched_list, sizeof(int32_t) * HV_TSDF_SETS * cfg->max_blocks));
         HV_TRY(hipMalloc(&v->touched_mask, sizeof(uint64_t) * HV_TSDF_SETS * v->table_capacity));
-        HV_TRY(hipMalloc((void **)&v->sweep_done, sizeof(int32_t) * v->table_capacity));
         HV_TRY(hipMalloc(&v->frame_px, 8 * (size_t)cfg->max_points));
-        if (const char *dv = getenv("HV_TSDF_DEBUG_VARIANT")) v->debug_variant = atoi(dv);
         if (const char *tb = getenv("HV_TSDF_TOUCH_BOX_BITS")) v->touch_box_bits = std::min(std::max(atoi(tb), 0), 2048);
     } else {
         HV_TRY(hipMalloc(&v->sort_keys_in, sizeof(uint32_t) * cfg->max_points));
@@ -678,9 +660,7 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
 void hv_destroy(hv_volume *v) {
     if (!v) return;
     (void)hipSetDevice(v->device);
-    v->pending.valid = false; // (a deferred sweep dies with the volume)
     if (v->stream_aux) (void)hipStreamSynchronize(v->stream_aux);
-    if (v->stream_up) (void)hipStreamSynchronize(v->stream_up);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     if (v->hs_stream) (void)hipStreamSynchronize(v->hs_stream);
     for (int i = 0; i < 2; ++i) {
@@ -696,7 +676,7 @@ void hv_destroy(hv_volume *v) {
                     v->touched_stamp, v->touched_list, v->touched_mask, v->frame_px,
                     v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                     v->sort_vals_out, v->sort_tmp, v->scratch_points, v->scratch_colors, v->out_a,
-                    v->out_b, v->out_c, v->sweep_done, v->params_ring, v->list_sorted, v->touch_ticket, v->batch_buf, v->assoc_buf, v->mult_table, v->bins.cnt, v->bins.inl, v->bins.touched, v->bins.len, v->bins.pg_keys, v->bins.pg_data, v->bin_rec, v->batch_buf2, v->batch_buf3, v->unit_masks, v->plan_buf, v->occ, v->semb_tasks, v->table.prob_nodes};
+                    v->out_b, v->out_c, v->rect_map_x, v->rect_map_y, v->rect_buf, v->batch_buf, v->assoc_buf, v->mult_table, v->bins.cnt, v->bins.inl, v->bins.touched, v->bins.len, v->bins.pg_keys, v->bins.pg_data, v->bin_rec, v->batch_buf2, v->unit_masks, v->occ, v->semb_tasks, v->table.prob_nodes};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (v->h_counters) (void)hipHostFree(v->h_counters);
@@ -710,13 +690,6 @@ void hv_destroy(hv_volume *v) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);
     }
-    for (int i = 0; i < 4; ++i)
-        if (v->ev_swept[i]) (void)hipEventDestroy(v->ev_swept[i]);
-    if (v->stream_up) (void)hipStreamDestroy(v->stream_up);
-    for (int i = 0; i < HV_TSDF_SETS; ++i) {
-        if (v->ev_set_prep[i]) (void)hipEventDestroy(v->ev_set_prep[i]);
-        if (v->ev_set_free[i]) (void)hipEventDestroy(v->ev_set_free[i]);
-    }
     if (v->ev_prep) (void)hipEventDestroy(v->ev_prep);
     if (v->ev_presweep) (void)hipEventDestroy(v->ev_presweep);
     if (v->stream_aux) (void)hipStreamDestroy(v->stream_aux);
@@ -725,7 +698,6 @@ void hv_destroy(hv_volume *v) {
 }
 
 int hv_reset(hv_volume *v) {
-    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_reset: null volume");
     HV_HIP(hipSetDevice(v->device));
     // zero only the used pool prefix (pool was fully zeroed at creation)
@@ -746,7 +718,6 @@ int hv_reset(hv_volume *v) {
     HV_HIP(hipMemsetAsync(v->table.counters, 0, sizeof(int32_t) * HV_CNT_COUNT, v->stream));
     if (v->touched_stamp) HV_HIP(hipMemsetAsync(v->touched_stamp, 0, sizeof(int32_t) * v->table_capacity, v->stream));
     if (v->touched_mask) HV_HIP(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * HV_TSDF_SETS * v->table_capacity, v->stream));
-    if (v->sweep_done) HV_HIP(hipMemsetAsync(v->sweep_done, 0, sizeof(int32_t) * v->table_capacity, v->stream));
     memset(v->h_counters, 0, sizeof(int32_t) * HV_CNT_COUNT);
     v->content_version += 1;
     v->frame_counter = 0;
@@ -767,14 +738,12 @@ int hv_reset(hv_volume *v) {
 }
 
 int hv_synchronize(hv_volume *v) {
-    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_synchronize: null volume");
     HV_HIP(hipStreamSynchronize(v->stream));
     return HV_OK;
 }
 
 int hv_set_stream(hv_volume *v, void *hip_stream) {
-    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_set_stream: null volume");
     HV_HIP(hipStreamSynchronize(v->stream));
     if (v->own_stream && v->stream) HV_HIP(hipStreamDestroy(v->stream));
@@ -815,7 +784,6 @@ __global__ void k_restamp(HvTable old_t, HvTable new_t, const int32_t *__restric
 static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep);
 
 int hv_reserve_blocks(hv_volume *v, int64_t new_max_blocks) {
-    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_reserve_blocks: null volume");
     if (new_max_blocks <= v->cfg.max_blocks) return HV_OK;
     return hv_rebuild(v, new_max_blocks, -1);
@@ -839,11 +807,11 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
                free_b / 1073741824.0);
     void *pool = nullptr;
     unsigned long long *keys = nullptr, *block_keys = nullptr, *occ = nullptr;
-    int32_t *vals = nullptr, *stamp = nullptr, *list = nullptr, *done = nullptr;
+    int32_t *vals = nullptr, *stamp = nullptr, *list = nullptr;
     uint64_t *mask = nullptr;
     // every allocation is released again if a later step fails (HV_HIP returns from the middle)
     auto release = [&]() {
-        for (void *p : {pool, (void *)keys, (void *)vals, (void *)block_keys, (void *)stamp, (void *)list, (void *)mask, (void *)occ, (void *)done})
+        for (void *p : {pool, (void *)keys, (void *)vals, (void *)block_keys, (void *)stamp, (void *)list, (void *)mask, (void *)occ})
             if (p) (void)hipFree(p);
     };
 #define HV_TRY_GROW(call)                                                                          \
@@ -888,8 +856,6 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
         HV_TRY_GROW(hipMalloc((void **)&mask, sizeof(uint64_t) * HV_TSDF_SETS * new_cap));
         HV_TRY_GROW(hipMemsetAsync(stamp, 0, sizeof(int32_t) * new_cap, v->stream));
         HV_TRY_GROW(hipMemsetAsync(mask, 0, sizeof(uint64_t) * HV_TSDF_SETS * new_cap, v->stream));
-        HV_TRY_GROW(hipMalloc((void **)&done, sizeof(int32_t) * new_cap));
-        HV_TRY_GROW(hipMemsetAsync(done, 0, sizeof(int32_t) * new_cap, v->stream));
         // stamps carry "touched since the last merge": re-stamp the surviving blocks' slots in the new table
         if (used > 0 && v->touched_stamp != nullptr)
             hipLaunchKernelGGL(k_restamp, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, v->stream, v->table, nt,
@@ -913,8 +879,6 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
         v->touched_stamp = stamp;
         v->touched_list = list;
         v->touched_mask = mask;
-        (void)hipFree(v->sweep_done);
-        v->sweep_done = done;
     }
     if (occ) {
         (void)hipFree(v->occ);
@@ -1066,7 +1030,6 @@ int hv_profile_enable(hv_volume *v, int32_t on) {
 }
 
 int hv_profile_read(hv_volume *v, double *kernel_ms_total, int64_t *kernel_launches, int64_t *units_processed) {
-    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_profile_read: null volume");
     HV_HIP(hipStreamSynchronize(v->stream));
     double total = 0.0;
@@ -1084,7 +1047,6 @@ int hv_profile_read(hv_volume *v, double *kernel_ms_total, int64_t *kernel_launc
 }
 
 int hv_profile_read_launches(hv_volume *v, float *launch_ms, int64_t cap, int64_t *n) {
-    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_profile_read_launches: null argument");
     HV_HIP(hipStreamSynchronize(v->stream));
     *n = (int64_t)v->events_used;

@@ -793,7 +793,6 @@ static int mesh_compute(hv_volume *v) {
 
 int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, int64_t cap_vertices,
                          int32_t *triangles, int64_t cap_triangles, int64_t *n_vertices, int64_t *n_triangles) {
-    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr && n_vertices != nullptr && n_triangles != nullptr, HV_ERR_INVALID,
                "hv_tsdf_extract_mesh: null argument");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_extract_mesh: volume is not in TSDF mode");
@@ -865,7 +864,6 @@ static int points_compute(hv_volume *v) {
 }
 
 int hv_tsdf_extract_points(hv_volume *v, double *points, double *colors, int64_t cap, int64_t *n) {
-    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_tsdf_extract_points: null argument");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_extract_points: volume is not in TSDF mode");
     HV_HIP(hipSetDevice(v->device));
@@ -886,7 +884,6 @@ int hv_tsdf_extract_points(hv_volume *v, double *points, double *colors, int64_t
 }
 
 int hv_tsdf_extract_point_normals(hv_volume *v, double *normals, int64_t cap, int64_t *n) {
-    if (const int frc_ = hv_tsdf_flush(v)) return frc_; // the deferred sweep of the last multi-frame batch goes first
     HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_tsdf_extract_point_normals: null argument");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_extract_point_normals: volume is not in TSDF mode");
     HV_HIP(hipSetDevice(v->device));

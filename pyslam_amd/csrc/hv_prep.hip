@@ -57,6 +57,77 @@ __global__ __launch_bounds__(256) void k_remap_linear_f32(const float *__restric
     }
 }
 
+// The reference's per-keyframe pair of remaps (colour INTER_LINEAR, depth INTER_NEAREST: volumetric_integrator_base.py:1017-1043) for
+// a whole batch of device-resident frames in ONE launch: a thread owns an output pixel, reads its map entry once and samples every
+// frame of the batch with it.  Depth keeps its storage type (float32, or the sensor's uint16: the nearest-neighbour pick commutes with
+// the later conversion to metres), so a TUM-style keyframe stays 5 bytes per pixel on its way through the GPU.
+template <typename D>
+__global__ __launch_bounds__(256) void k_rectify_frames(const D *__restrict__ depth, const uint8_t *__restrict__ rgb, int n_frames, int H, int W,
+                                                         const float *__restrict__ mx, const float *__restrict__ my,
+                                                         D *__restrict__ depth_out, uint8_t *__restrict__ rgb_out) {
+    const int64_t npx = (int64_t)H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    const float fxm = mx[i], fym = my[i];
+    const int nx = __float2int_rn(fxm), ny = __float2int_rn(fym);
+    const int sx = __float2int_rn(fxm * 32.0f), sy = __float2int_rn(fym * 32.0f);
+    const int ix = sx >> 5, iy = sy >> 5, fx = sx & 31, fy = sy & 31;
+    const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    for (int f = 0; f < n_frames; ++f) {
+        const D *df = depth + (int64_t)f * npx;
+        const uint8_t *cf = rgb + (int64_t)f * npx * 3;
+        depth_out[(int64_t)f * npx + i] = px_or_zero(df, H, W, 1, ny, nx, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int s = (int)px_or_zero(cf, H, W, 3, iy, ix, c) * w00 + (int)px_or_zero(cf, H, W, 3, iy, ix + 1, c) * w01 +
+                          (int)px_or_zero(cf, H, W, 3, iy + 1, ix, c) * w10 + (int)px_or_zero(cf, H, W, 3, iy + 1, ix + 1, c) * w11;
+            const int r = (s + (1 << 14)) >> 15;
+            rgb_out[((int64_t)f * npx + i) * 3 + c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+    }
+}
+
+// (hv_tsdf.hip: queued on `s`, nothing waits)
+int hv_rectify_frames_device(hv_volume *v, hipStream_t s, const void *d_depth, int32_t depth_dtype, const uint8_t *d_rgb, int n_frames,
+                             int height, int width, void *d_depth_out, uint8_t *d_rgb_out) {
+    const int64_t npx = (int64_t)height * width;
+    const dim3 grid((unsigned)((npx + 255) / 256)), block(256);
+    if (depth_dtype == HV_DEPTH_U16)
+        hipLaunchKernelGGL(k_rectify_frames<uint16_t>, grid, block, 0, s, (const uint16_t *)d_depth, d_rgb, n_frames, height, width,
+                           (const float *)v->rect_map_x, (const float *)v->rect_map_y, (uint16_t *)d_depth_out, d_rgb_out);
+    else
+        hipLaunchKernelGGL(k_rectify_frames<float>, grid, block, 0, s, (const float *)d_depth, d_rgb, n_frames, height, width,
+                           (const float *)v->rect_map_x, (const float *)v->rect_map_y, (float *)d_depth_out, d_rgb_out);
+    HV_HIP(hipGetLastError());
+    return HV_OK;
+}
+
+extern "C" int hv_tsdf_set_rectify_maps(hv_volume *v, const float *map_x, const float *map_y, int32_t height, int32_t width, int32_t loc) {
+    HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_tsdf_set_rectify_maps: null volume");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_set_rectify_maps: volume is not in TSDF mode");
+    HV_HIP(hipSetDevice(v->device));
+    if (v->stream_aux) HV_HIP(hipStreamSynchronize(v->stream_aux));
+    HV_HIP(hipStreamSynchronize(v->stream));
+    if (map_x == nullptr || map_y == nullptr) { // frames are fused as they come again
+        v->rect_W = v->rect_H = 0;
+        return HV_OK;
+    }
+    HV_REQUIRE(height > 0 && width > 0, HV_ERR_INVALID, "hv_tsdf_set_rectify_maps: bad image size");
+    const size_t bytes = sizeof(float) * (size_t)height * width;
+    void *mxb = v->rect_map_x, *myb = v->rect_map_y;
+    int rc = hv_ensure_buffer(v, &mxb, &v->rect_map_x_bytes, bytes);
+    if (rc != HV_OK) return rc;
+    v->rect_map_x = (float *)mxb;
+    rc = hv_ensure_buffer(v, &myb, &v->rect_map_y_bytes, bytes);
+    if (rc != HV_OK) return rc;
+    v->rect_map_y = (float *)myb;
+    HV_HIP(hipMemcpy(v->rect_map_x, map_x, bytes, loc == HV_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    HV_HIP(hipMemcpy(v->rect_map_y, map_y, bytes, loc == HV_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    v->rect_W = width;
+    v->rect_H = height;
+    return HV_OK;
+}
+
 extern "C" int hv_remap(hv_volume *v, const void *src, int32_t src_kind, int32_t channels, int32_t height, int32_t width,
                         const float *map_x, const float *map_y, int32_t linear, void *dst, int32_t loc) {
     HV_REQUIRE(v != nullptr && src != nullptr && map_x != nullptr && map_y != nullptr && dst != nullptr, HV_ERR_INVALID,

@@ -30,8 +30,9 @@ static_assert(sizeof(HvSemVoxel) == 64, "HvSemVoxel must be 64 bytes");
 // from a per-volume node pool (`next` = node index + 1; only the voxel's own fold thread walks or extends its chain).  Rounds 1-3
 // dropped the 8th distinct pair of a voxel (measured: 1-2 % of the occupied voxels under 5 % uniform label noise, largest
 // reference map 23 pairs); now the map is as unbounded as the reference's up to 254 pairs or an exhausted node pool, both counted
-// (HV_CNT_LABEL_OVERFLOW, hv_label_overflows()) - never silent.  A voxel reset leaves its nodes behind (they are only taken back
-// by hv_reset); a collapsed map (set_object_id) keeps its chain for later growth.
+// (HV_CNT_LABEL_OVERFLOW, hv_label_overflows()) - never silent.  A voxel that is reset (carve, remove_*: sem_reset) and a collapsed map
+// (set_object_id) keep their chain and grow the next map into it: carve / re-observe cycles do not drain the pool
+// (tests/test_gpu_semantic_ops.py::test_carve_and_reobserve_cycles_reuse_overflow_nodes); hv_reset takes every node back.
 //   meta = nlab | (best + 1) << 8: best = index of the cached most likely pair (most_likely_pair, voxel_data_semantic.h:266-270;
 //   0 = cache not valid / empty map).  Pair i lives inline for i < HV_PROB_K, else in node (i - K) / NK of the chain.
 static constexpr int HV_PROB_K = 6;
@@ -457,38 +458,6 @@ __device__ __forceinline__ void sem_for_occupied_word(unsigned long long word, i
         const int before = __shfl(incl, wi) - __shfl(cnt, wi);
         const int pos = active ? sem_select_bit(ww, k - before) : 0;
         body(b * nvox + wi * 64 + pos, active);
-    }
-}
-// FOUR blocks per wave (round 5): a block of a 2 mm map holds ~15 occupied voxels, so the one-block-per-wave walk above keeps 15 of 64
-// lanes busy per dependent round trip (record -> image pixels).  Here every 16-lane group owns one block: lane (lane & 15) < W of a group
-// holds word (lane & 15) of ITS block (zero: nothing to visit), the group's k-th set bit goes to its lane k, groups with more than 16
-// occupied voxels take more trips (the trip count is the wave's maximum).  body(gid, active, group's block) is called by every lane of
-// the wave in every trip.  Needs nvox / 64 <= 8 (8^3 blocks).
-template <typename F>
-__device__ __forceinline__ void sem_for_occupied_quad(unsigned long long word, int64_t bg, int nvox, F body) {
-    const int lane = hv_lane_id();
-    const int g16 = lane & ~15, gl = lane & 15;
-    const int W = nvox >> 6;
-    const int cnt = __popcll(word);
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        const int up = __shfl_up(incl, o);
-        if (gl >= o) incl += up;
-    }
-    const int total = __shfl(incl, g16 + 15);
-    int trips = (total + 15) >> 4;
-#pragma unroll
-    for (int o = 32; o >= 16; o >>= 1) trips = max(trips, __shfl_xor(trips, o));
-    for (int it = 0; it < trips; ++it) { // wave-uniform trip count
-        const int k = it * 16 + gl;
-        const bool active = k < total;
-        int wi = 0;
-        for (int w = 0; w < W - 1; ++w) wi += (__shfl(incl, g16 + w) <= k) ? 1 : 0; // word of the group's block that holds its k-th set bit
-        const unsigned long long ww = __shfl(word, g16 + wi);
-        const int before = __shfl(incl, g16 + wi) - __shfl(cnt, g16 + wi);
-        const int pos = active ? sem_select_bit(ww, k - before) : 0;
-        body(bg * nvox + wi * 64 + pos, active, bg);
     }
 }
 __device__ __forceinline__ bool sem_occ_words_usable(const unsigned long long *occ, int nvox) {

@@ -716,12 +716,9 @@ static int sem_sort_bits(const hv_volume *v) {
     return std::min(32, slot_bits + v->local_bits + 1);
 }
 
-// The fold's LDS window per wave (entries): bins beyond it go to the task kernel as voxel ranges.  512 (HV_SEM_WCAP) leaves
-// room for the 16 waves per CU the kernel's registers allow (1024: 12 waves)
-static int sem_wcap() {
-    int wcap = getenv("HV_SEM_WCAP") ? atoi(getenv("HV_SEM_WCAP")) : 512;
-    return (wcap != 256 && wcap != 512 && wcap != 1024) ? 512 : wcap;
-}
+// The fold's LDS window per wave (entries): bins beyond it go to the task kernel as voxel ranges.  512 leaves room for the 16 waves
+// per CU the kernel's registers allow (1024: 12 waves; measured round 4)
+static int sem_wcap() { return 512; }
 static size_t sem_fold_lds(int wcap, int nvox) { return 4 * sizeof(uint32_t) * (size_t)(2 * wcap + nvox + 64); } // two windows + per-voxel offsets per wave
 static bool sem_bins_usable(const hv_volume *v, int64_t n) {
     const char *force = getenv("HV_SEM_PATH"); // HV_SEM_PATH=sort keeps the device-wide radix sort: A/B, tests
@@ -763,7 +760,7 @@ static int sem_bins_run(hv_volume *v, int64_t n, bool checked, const SRC &src, B
     }
     int32_t *task_count = (int32_t *)v->semb_tasks;
     int4 *tasks = (int4 *)((char *)v->semb_tasks + 256);
-    const bool use_tasks = !(getenv("HV_SEM_TASKS") && atoi(getenv("HV_SEM_TASKS")) == 0);
+    const bool use_tasks = true;
     hipLaunchKernelGGL((k_semb_fold_wave<VOX, SRC>), dim3(fold_grid), dim3(256), lds_bytes, v->stream, v->table, bpool, B, G, src, v->occ, n,
                        v->d_status, seq, task_count, use_tasks ? tasks : (int4 *)nullptr, task_cap, wcap);
     if (use_tasks)
@@ -966,6 +963,14 @@ int hv_label_overflows(hv_volume *v, int64_t *n) {
     int rc = hv_read_counters(v);
     if (rc != HV_OK) return rc;
     *n = v->h_counters[HV_CNT_LABEL_OVERFLOW];
+    return HV_OK;
+}
+
+int hv_prob_nodes_used(hv_volume *v, int64_t *n) {
+    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_prob_nodes_used: null argument");
+    int rc = hv_read_counters(v);
+    if (rc != HV_OK) return rc;
+    *n = v->h_counters[HV_CNT_PROB_NODES];
     return HV_OK;
 }
 

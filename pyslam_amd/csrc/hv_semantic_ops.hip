@@ -111,28 +111,6 @@ __device__ __forceinline__ bool sem_block_outside_frustum_key(const HvQuery &Q, 
            (__ballot(out3) & corners) == corners || (__ballot(out4) & corners) == corners || (__ballot(out5) & corners) == corners;
 }
 
-// the same for the block of a 16-lane group (sem_for_occupied_quad): lanes (lane & 15) < 8 of the group test one corner each; the
-// result is uniform inside the group
-__device__ __forceinline__ bool sem_block_outside_frustum_group(const HvQuery &Q, unsigned long long block_key, const HvSemParams &G) {
-    int32_t bk[3];
-    hv_unpack_key(block_key, bk[0], bk[1], bk[2]);
-    const int lane = hv_lane_id();
-    const double vs = 1.0 / (double)G.inv_voxel_size, ext = (double)G.bs * vs;
-    double p[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) p[a] = (double)bk[a] * ext + (((lane >> a) & 1) ? ext + 0.5 * vs : -0.5 * vs);
-    double pc[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) pc[r] = (Q.R[r * 3 + 0] * p[0] + Q.R[r * 3 + 1] * p[1] + Q.R[r * 3 + 2] * p[2]) + Q.t[r];
-    const double fu = (double)Q.fx * pc[0] + (double)Q.cx * pc[2], fv = (double)Q.fy * pc[1] + (double)Q.cy * pc[2];
-    const unsigned long long corners = 0xffull << (lane & ~15);
-    const bool out0 = pc[2] < (double)Q.depth_min, out1 = pc[2] > (double)Q.depth_max;
-    const bool out2 = fu < 0.0, out3 = fu - (double)Q.width * pc[2] >= 0.0;
-    const bool out4 = fv < 0.0, out5 = fv - (double)Q.height * pc[2] >= 0.0;
-    return (__ballot(out0) & corners) == corners || (__ballot(out1) & corners) == corners || (__ballot(out2) & corners) == corners ||
-           (__ballot(out3) & corners) == corners || (__ballot(out4) & corners) == corners || (__ballot(out5) & corners) == corners;
-}
-
 __device__ __forceinline__ bool sem_block_outside_frustum(const HvQuery &Q, const HvTable &table, int64_t b, const HvSemParams &G) {
     return sem_block_outside_frustum_key(Q, table.block_keys[b], G);
 }
@@ -246,14 +224,14 @@ struct HvAssocParams {
 // frustum once, then only the voxels whose occupancy bit is set are visited (a 2 mm ScanNet keyframe faces 120 k blocks = 61 M
 // voxel slots of which 7 % hold a voxel: the thread-per-slot form spent 0.7 - 1.0 ms per keyframe on per-wave overhead - cull,
 // ballots, appends - for 950 k waves of mostly empty slots).
-template <typename VOX, bool QUAD>
+template <typename VOX>
 __global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *__restrict__ pool, int64_t n_blocks,
                                                          HvSemParams G, HvQuery Q, const int32_t *__restrict__ cls_img,
                                                          const int32_t *__restrict__ inst_img,
                                                          const float *__restrict__ depth, HvAssocParams A,
                                                          unsigned long long *__restrict__ vkeys,
                                                          int32_t *__restrict__ vcounts, int2 *__restrict__ pending,
-                                                         const unsigned long long *__restrict__ occ, int quad) {
+                                                         const unsigned long long *__restrict__ occ) {
     __shared__ HvVoteLocal s_votes;
     // Voxels waiting for their object id are collected per wave in LDS and get their places in the pending list with ONE returning
     // atomic per ~200 of them (round 6): a 2 mm keyframe leaves a few hundred thousand such voxels behind, and one atomic per visit
@@ -327,55 +305,6 @@ __global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *_
             if (n_pend > PEND_BUF - HV_WAVE) flush_pending();
         }
     };
-    if (QUAD && quad && sem_occ_words_usable(occ, G.nvox) && (G.nvox >> 6) <= 8) { // (QUAD: an instantiation of its own - the one-block form keeps its registers)
-        // four blocks per wave, one per 16-lane group (sem_for_occupied_quad); the next quad's keys and words are requested before this
-        // one is worked on
-        const int lane = hv_lane_id(), g = lane >> 4, gl = lane & 15, W = G.nvox >> 6;
-        const int64_t n_quads = (n_blocks + 3) >> 2;
-        int64_t q = (int64_t)blockIdx.x * (blockDim.x / HV_WAVE) + threadIdx.x / HV_WAVE;
-        auto fetch = [&](int64_t qq, unsigned long long &key, unsigned long long &word) {
-            const int64_t bb = qq * 4 + g;
-            key = (qq < n_quads && bb < n_blocks) ? table.block_keys[bb] : 0ull;
-            word = (qq < n_quads && bb < n_blocks && gl < W) ? occ[bb * W + gl] : 0ull;
-        };
-        unsigned long long next_key, next_word;
-        fetch(q, next_key, next_word);
-        for (; q < n_quads; q += n_waves) {
-            const unsigned long long bkey = next_key;
-            unsigned long long word = next_word;
-            fetch(q + n_waves, next_key, next_word);
-            const int64_t bg = q * 4 + g;
-            const unsigned long long gmask = 0xffffull << (16 * g);
-            const bool some = (__ballot(word != 0ull) & gmask) != 0ull;
-            const bool outside = sem_block_outside_frustum_group(Q, bkey, G); // (every lane takes part in its ballots)
-            if (bg >= n_blocks || !some || outside) word = 0ull;                // nothing of this group's block is visited
-            if (!__any(word != 0ull)) continue;
-            // four blocks side by side, or one after the other with all 64 lanes each - whichever takes fewer trips (measured: blocks of a
-            // 1 cm map hold ~60 occupied voxels, side by side they cost 6-8 % of a keyframe; blocks of a 2 mm map hold ~15 and gain 4-6 %)
-            int tg = __popcll(word); // (lanes >= W hold 0)
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) tg += __shfl_xor(tg, o);
-            int trips_quad = (tg + 15) >> 4, trips_serial = (gl == 0) ? (tg + 63) >> 6 : 0;
-#pragma unroll
-            for (int o = 32; o >= 16; o >>= 1) trips_quad = max(trips_quad, __shfl_xor(trips_quad, o));
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) trips_serial += __shfl_xor(trips_serial, o);
-            if (trips_quad <= trips_serial) {
-                sem_for_occupied_quad(word, bg, G.nvox, visit_b);
-            } else {
-                for (int gg = 0; gg < 4; ++gg) { // wave-uniform
-                    const unsigned long long wg = __shfl(word, 16 * gg + (lane & 15));
-                    const unsigned long long w64 = lane < W ? wg : 0ull;
-                    if (!__any(w64 != 0ull)) continue;
-                    const int64_t bb = q * 4 + gg;
-                    sem_for_occupied_word(w64, bb, G.nvox, [&](int64_t gid, bool active) { visit_b(gid, active, bb); });
-                }
-            }
-        }
-        flush_pending();
-        vote_local_flush(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2]);
-        return;
-    }
     // the key and the occupancy words of the NEXT block are requested before this block is worked on: a block is a chain of
     // dependent round trips (key -> cull, words -> records -> image pixels) and a wave holds too many registers for the SIMD to
     // hide them with other waves
@@ -1162,17 +1091,14 @@ int hv_assoc_vote(hv_volume *v, const float *intr_f32, int32_t width, int32_t he
         GP.nvox = G.nvox;
         GP.local_bits = G.local_bits;
         fill_key_range(Q, GP);
-        // HV_SEM_VOTE_QUAD=1: four blocks per wave, one per 16-lane group, where that takes fewer trips.  Measured (profiles/r05/README.md):
-        // +2-3 % keyframes/s at 1296x968 / 2 mm (~15 occupied voxels per block), -11 % at 640x480 / 1 cm (~60 per block: the per-quad
-        // decision and the larger kernel cost more than the trips it saves).  Default 0 = one block per wave, as in round 4.
-        const int vote_quad = getenv("HV_SEM_VOTE_QUAD") ? atoi(getenv("HV_SEM_VOTE_QUAD")) : 0;
-        const dim3 grid((unsigned)std::min<int64_t>(((vote_quad ? (nb + 3) / 4 : nb) + 3) / 4, 4096)); // persistent: 16 workgroups per CU
-#define HV_LAUNCH_VOTE(VOX, QUAD)                                                                                                  \
-    hipLaunchKernelGGL((k_sem_assoc_vote<VOX, QUAD>), grid, dim3(256), 0, v->stream, v->table, (VOX *)v->pool, (int64_t)-1, G, Q, d_cls, d_inst, \
-                       d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ, vote_quad)
-        if (prob) { if (vote_quad) HV_LAUNCH_VOTE(HvProbVoxel, true); else HV_LAUNCH_VOTE(HvProbVoxel, false); }
-        else { if (vote_quad) HV_LAUNCH_VOTE(HvSemVoxel, true); else HV_LAUNCH_VOTE(HvSemVoxel, false); }
-#undef HV_LAUNCH_VOTE
+        // (four blocks per wave, one per 16-lane group, was measured in round 5 - profiles/r05/README.md: +2-3 % at 2 mm, -11 % at 1 cm - and dropped)
+        const dim3 grid((unsigned)std::min<int64_t>((nb + 3) / 4, 4096)); // persistent: 16 workgroups per CU
+        if (prob)
+            hipLaunchKernelGGL(k_sem_assoc_vote<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, (int64_t)-1, G, Q, d_cls, d_inst,
+                               d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ);
+        else
+            hipLaunchKernelGGL(k_sem_assoc_vote<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, (int64_t)-1, G, Q, d_cls, d_inst,
+                               d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ);
     }
     hipLaunchKernelGGL(k_sem_assoc_image, dim3((unsigned)std::min<int64_t>((n_px + 255) / 256, 512)), dim3(256), 0, v->stream, v->table, d_cls, d_inst,
                        n_px, S.vkeys, S.vcounts);

@@ -10,16 +10,6 @@ it is free next to the ~0.5 GB of voxel traffic it causes).  Two ways to split t
     simply distributed over the ranks — no collective while fusing.  ``gather_to_root()`` collects
     it on one rank when a mesh is wanted.
 
-``sharding="coherent"`` (round 4, optional: ``bench.py --gpus N --sharding coherent``) — ownership is PLANNED PER BATCH on the
-    device (``hv_tsdf_set_sharding``, kernels ``k_tsdf_touch_plan`` / ``k_tsdf_plan_assign``): every rank enumerates the batch's
-    units into a small replicated table, all ranks derive the same plan from it without talking — equal WORK per rank, a
-    rank's units contiguous in the image (cells of the batch's middle frame) — and a rank then claims, packs and sweeps only
-    its part of every frame: the per-batch replicated pack (206 MB per 32 frames under hash ownership) shrinks with N.  A
-    (unit, frame) pair is fused by exactly one rank; ownership moves with the camera, so a unit's additive numerators may live
-    on several ranks: ``merge_halo()`` / ``gather_to_root()`` consolidate them like the tile form's (no duplicated sweeps,
-    unlike the tile form).  Measured SLOWER than the hash form on one GPU's projection (deciding costs more than the smaller
-    pack saves: DESIGN section 6, profiles/r04/touch_plan_ablation.txt), which is why it is not the default.
-
 ``sharding="tile"`` (north-star form) — rank r fuses only the voxels whose projection falls into its
     vertical image tile (``hv_tsdf_set_tile``); a unit that cannot project into a rank's tile is neither
     allocated nor swept there.  Units on tile borders (and revisits from other viewpoints) then hold
@@ -68,7 +58,7 @@ class ShardedTSDF:
         the ordering of RCCL's stream against the volume's) can be executed on a one-GPU box (they had never run).
         With one rank merge_halo() has no shared unit to find: every dirty unit is then taken through pack -> all-reduce -> unpack
         as its own keeper, which leaves the volume as it was (up to the export / import round trip)."""
-        assert sharding in ("owner", "tile", "coherent")
+        assert sharding in ("owner", "tile")
         self.rank, self.world_size = int(rank), int(world_size)
         self.width, self.height = int(width), int(height)
         self.group = group
@@ -85,8 +75,6 @@ class ShardedTSDF:
         if self.world_size > 1:
             if sharding == "tile":
                 self.volume.set_tile(*self.tile)
-            elif sharding == "coherent":
-                self.volume.set_owner(self.rank, self.world_size, coherent=True)
             else:
                 self.volume.set_owner(self.rank, self.world_size)
 

@@ -5,7 +5,9 @@ depth by analytic ray casting through a pinhole camera; colour is a procedural f
 world hit point quantised to uint8; the camera moves on a closed circle (radius 1.2 m, height
 1.5 m) looking at the room centre.  T_cw (world -> camera) is float64, depth float32 metres.
 Sensor model: optional Gaussian depth noise sigma = 1 mm * z^2 (default_rng(seed)), `invalid_frac`
-random pixels set to 0 (default_rng(seed + 1)), no lens distortion.
+random pixels set to 0 (default_rng(seed + 1)); `distorted=True` renders through the config's lens model (plumb-bob
+coefficients, TUM1's: the ray of sensor pixel (u, v) goes through its UNDISTORTED normalised position), so that the
+frames need the reference's undistort / rectify step before they are fused.
 """
 import numpy as np
 
@@ -19,7 +21,8 @@ CONFIGS = {
     # BASELINE.json configs[1]: synthetic 640x480 @ 30 Hz, 5 mm TSDF
     "synthetic_640x480_5mm": dict(width=640, height=480, fx=525.0, fy=525.0, cx=319.5, cy=239.5, voxel=0.005),
     # TUM fr1-shaped (settings/TUM1.yaml:27-39 intrinsics, DepthMapFactor 5000 -> u16 depth)
-    "tum1_640x480_5mm": dict(width=640, height=480, fx=517.306408, fy=516.469215, cx=318.643040, cy=255.313989, voxel=0.005),
+    "tum1_640x480_5mm": dict(width=640, height=480, fx=517.306408, fy=516.469215, cx=318.643040, cy=255.313989, voxel=0.005,
+                             dist=(0.262383, -0.953104, -0.005358, 0.002628, 1.163314)),  # Camera.k1 k2 p1 p2 k3, TUM1.yaml:32-36
     # Replica-shaped (settings/REPLICA.yaml:27-39)
     "replica_1200x680_4mm": dict(width=1200, height=680, fx=600.0, fy=600.0, cx=599.5, cy=339.5, voxel=0.004),
     # EuRoC-shaped (settings/EuRoC_stereo.yaml:18-35)
@@ -67,10 +70,18 @@ def _colour(p, label):
     return np.clip(np.stack([r, g, b], axis=1), 0, 255).astype(np.uint8)
 
 
-def render(T_wc, width, height, fx, fy, cx, cy):
-    """Analytic ray cast.  Returns depth [H,W] f64 (z-depth, 0 = miss), rgb [H,W,3] u8, label [H,W] i32."""
+def render(T_wc, width, height, fx, fy, cx, cy, dist=None):
+    """Analytic ray cast.  Returns depth [H,W] f64 (z-depth, 0 = miss), rgb [H,W,3] u8, label [H,W] i32.  dist: lens distortion
+    coefficients (k1 k2 p1 p2 k3 ...) of the sensor - pixel (u, v) then looks along its undistorted normalised direction."""
     u, v = np.meshgrid(np.arange(width, dtype=np.float64), np.arange(height, dtype=np.float64))
-    d_cam = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], axis=-1).reshape(-1, 3)
+    if dist is not None:
+        from pyslam_amd.prep import undistort_points_normalized
+
+        K = np.array([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]])
+        xn, yn = undistort_points_normalized(u, v, K, dist, iters=20)
+        d_cam = np.stack([xn, yn, np.ones_like(u)], axis=-1).reshape(-1, 3)
+    else:
+        d_cam = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], axis=-1).reshape(-1, 3)
     R, o = T_wc[:3, :3], T_wc[:3, 3]
     d = d_cam @ R.T  # world direction per unit z-depth
     n = d.shape[0]
@@ -114,8 +125,9 @@ class SyntheticRGBD:
     """Indexable stream: ``depth, rgb, T_cw = stream[i]``."""
 
     def __init__(self, config="synthetic_640x480_5mm", noise=True, invalid_frac=0.02, seed=0, n_poses=600,
-                 depth_dtype="float32", depth_map_factor=5000.0):
+                 depth_dtype="float32", depth_map_factor=5000.0, distorted=False):
         c = CONFIGS[config] if isinstance(config, str) else dict(config)
+        self.dist = tuple(c["dist"]) if distorted and c.get("dist") else None  # lens model of the SENSOR frames (None: pinhole)
         self.width, self.height = c["width"], c["height"]
         self.fx, self.fy, self.cx, self.cy = c["fx"], c["fy"], c["cx"], c["cy"]
         self.voxel = c["voxel"]
@@ -132,7 +144,7 @@ class SyntheticRGBD:
 
     def __getitem__(self, i):
         T_cw, T_wc = trajectory_pose(i, self.n_poses)
-        depth, rgb, _ = render(T_wc, self.width, self.height, self.fx, self.fy, self.cx, self.cy)
+        depth, rgb, _ = render(T_wc, self.width, self.height, self.fx, self.fy, self.cx, self.cy, self.dist)
         if self.noise:
             rng = np.random.default_rng(self.seed + 7919 * i)
             depth = depth + rng.standard_normal(depth.shape) * 1e-3 * depth * depth
@@ -147,11 +159,11 @@ class SyntheticRGBD:
         return depth, np.ascontiguousarray(rgb), T_cw
 
     def labels(self, i):
-        return render(trajectory_pose(i, self.n_poses)[1], self.width, self.height, self.fx, self.fy, self.cx, self.cy)[2]
+        return render(trajectory_pose(i, self.n_poses)[1], self.width, self.height, self.fx, self.fy, self.cx, self.cy, self.dist)[2]
 
     def _args(self):
         return dict(config=dict(width=self.width, height=self.height, fx=self.fx, fy=self.fy, cx=self.cx, cy=self.cy,
-                                voxel=self.voxel), noise=self.noise, invalid_frac=self.invalid_frac, seed=self.seed,
+                                voxel=self.voxel, dist=self.dist), distorted=self.dist is not None, noise=self.noise, invalid_frac=self.invalid_frac, seed=self.seed,
                     n_poses=self.n_poses, depth_dtype=self.depth_dtype, depth_map_factor=self.depth_map_factor)
 
     def frames(self, start, count, workers=None):

@@ -713,11 +713,20 @@ class ScalableTSDFVolume(_Volume):
         """Restrict fusion to the image tile [u0,u1) x [v0,v1) (multi-GPU sharding); zeros = whole image."""
         L.check(self._lib.hv_tsdf_set_tile(self._h, int(u0), int(v0), int(u1), int(v1)))
 
-    def set_owner(self, rank, world_size, coherent=False):
-        """Fuse/store only the units owned by `rank` of `world_size` (multi-GPU unit-ownership sharding).  coherent=True: multi-frame
-        calls plan their batch on the device (equal work, image-contiguous units per GPU: hv_tsdf_set_sharding)."""
+    def set_rectify_maps(self, map_x, map_y):
+        """Undistort / rectify on the device: every frame handed to integrate / integrate_batch / integrate_frames afterwards goes
+        through the maps first (colour bilinear, depth nearest - the reference's per-keyframe cv2.remap pair,
+        volumetric_integrator_base.py:1017-1043), one launch per batch; the caller passes the RECTIFIED intrinsics.  None clears."""
+        if map_x is None or map_y is None:
+            L.check(self._lib.hv_tsdf_set_rectify_maps(self._h, None, None, 0, 0, L.HV_HOST))
+            return
+        mx, my = np.ascontiguousarray(map_x, dtype=np.float32), np.ascontiguousarray(map_y, dtype=np.float32)
+        assert mx.ndim == 2 and mx.shape == my.shape
+        L.check(self._lib.hv_tsdf_set_rectify_maps(self._h, L.ptr(mx), L.ptr(my), int(mx.shape[0]), int(mx.shape[1]), L.HV_HOST))
+
+    def set_owner(self, rank, world_size):
+        """Fuse/store only the units owned by `rank` of `world_size` (multi-GPU unit-ownership sharding)."""
         L.check(self._lib.hv_tsdf_set_owner(self._h, int(rank), int(world_size)))
-        L.check(self._lib.hv_tsdf_set_sharding(self._h, 1 if coherent else 0))
 
     def extract_triangle_mesh(self, device=False):
         """o3d's extract_triangle_mesh().  device=True: vertices / vertex_colors / triangles are torch CUDA tensors on the volume's GPU

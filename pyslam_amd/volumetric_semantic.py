@@ -626,6 +626,12 @@ class _SemanticGridBase(_Volume):
         L.check(self._lib.hv_label_overflows(self._h, ctypes.byref(n)))
         return n.value
 
+    def prob_nodes_used(self):
+        """Overflow nodes of the probabilistic label maps handed out so far (hv_prob_nodes_used)."""
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_prob_nodes_used(self._h, ctypes.byref(n)))
+        return n.value
+
     def clear(self):
         L.check(self._lib.hv_reset(self._h))
 

@@ -43,10 +43,10 @@ FOLD_TSDF_TOL = 5e-6  # fold form of the sweep vs the oracle's per-frame float c
 
 
 def sweep_is_bitwise():
-    """HV_TSDF_SWEEP=1|2 select the forms of the multi-frame sweep that replay the reference's running mean frame by
-    frame (tsdf bit-identical to the oracle); the production forms (4: whole voxel columns, the default; 3: four voxels
-    per lane) fold a batch per voxel (tsdf within FOLD_TSDF_TOL)."""
-    return os.environ.get("HV_TSDF_SWEEP", "4") in ("1", "2")
+    """HV_TSDF_SWEEP=2 selects the form of the multi-frame sweep that replays the reference's running mean frame by
+    frame (tsdf bit-identical to the oracle); the production form (4: whole voxel columns, the default) folds a batch
+    per voxel (tsdf within FOLD_TSDF_TOL)."""
+    return os.environ.get("HV_TSDF_SWEEP", "4") == "2"
 
 
 def assert_tsdf_parity(ta, tb, swept=True):

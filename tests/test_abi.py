@@ -160,16 +160,15 @@ def test_hot_kernels_keep_their_state_in_registers(tmp_path):
         for name, m in pick(*parts).items():
             assert m["private_segment_fixed_size"] <= (32 if "HvSemRecs" in name else 96), (name, m)
             assert m["vgpr_count"] <= 128, (name, m)
-    # the association vote: 4 waves per SIMD (the one-block-per-wave forms without any spill)
+    # the association vote: 4 waves per SIMD, without any spill
     for name, m in pick("k_sem_assoc_vote").items():
         assert m["vgpr_count"] <= 128, (name, m)
-        if "Lb0E" in name:
-            assert m["private_segment_fixed_size"] == 0, (name, m)
+        assert m["private_segment_fixed_size"] == 0, (name, m)
     # the production sweep sits AT the 128-register line with two spilled registers (12 bytes); its z-half form under it with none
-    prod = pick("k_tsdf_sweep_columnILi4ELi4ELi4ELi1ELi2ELi1EE")
+    prod = pick("k_tsdf_sweep_columnILi1EE")
     for name, m in prod.items():
         assert m["vgpr_count"] <= 128 and m["private_segment_fixed_size"] <= 16, (name, m)
-    for name, m in pick("k_tsdf_sweep_columnILi4ELi4ELi4ELi1ELi2ELi2EE").items():
+    for name, m in pick("k_tsdf_sweep_columnILi2EE").items():
         assert m["vgpr_count"] <= 128 and m["private_segment_fixed_size"] == 0, (name, m)
     # no kernel of the library carries more scratch than the capped forms' spills (the A/B instantiations of the sweep are the largest)
     worst = max(meta.items(), key=lambda kv: kv[1].get("private_segment_fixed_size", 0))

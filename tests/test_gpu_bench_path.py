@@ -7,7 +7,7 @@ with those arguments against ``oracle.PortTsdf`` and compare the FULL dump: unit
 <= 1e-4 (north-star tolerance; reference call sites pyslam/dense/volumetric_integrator_tsdf.py:215-223,260), tsdf
 within ``FOLD_TSDF_TOL`` = 5e-6 for the production (fold) form of the sweep - which applies one running-mean step per
 voxel and batch instead of one per frame - and bitwise for the forms that replay the reference's chain frame by
-frame (``HV_TSDF_SWEEP=2`` / ``1``).  Mesh and point-cloud extraction are compared at the
+frame (``HV_TSDF_SWEEP=2``).  Mesh and point-cloud extraction are compared at the
 same configuration and at BASELINE configs[2] (Replica-shaped 1200x680 @ 4 mm).
 """
 import os
@@ -180,38 +180,14 @@ def sweep_case():
 
 
 SWEEP_FORMS = [
-    {"HV_TSDF_SWEEP": "3"},                              # production: batch folded per voxel (tsdf <= FOLD_TSDF_TOL, the rest exact)
-    {"HV_TSDF_SWEEP": "3", "HV_TSDF_PIPELINE": "0"},
-    {"HV_TSDF_SWEEP": "3", "HV_TSDF_SWEEP_XCD": "0"},
-    {"HV_TSDF_SWEEP": "3", "HV_TSDF_SWEEP_WPE": "8"},    # 64 VGPRs
-    {"HV_TSDF_SWEEP": "3", "HV_TSDF_SWEEP_WPE": "4"},
-    {"HV_TSDF_SWEEP": "3", "HV_TSDF_SWEEP_ANYSKIP": "1"},  # fold skipped for voxels no lane of the wave updates
-    {"HV_TSDF_SWEEP": "3", "HV_TSDF_BATCH_SPLIT": "4"},
-    {"HV_TSDF_SWEEP": "3", "HV_TSDF_BATCH_SPLIT": "16"},
-    {"HV_TSDF_SWEEP": "3", "HV_TSDF_SWEEP_ZH": "8"},
-    {"HV_TSDF_SWEEP": "3", "HV_TSDF_BATCH_GENERAL": "1"},  # the fold kernel's rare-regime path everywhere: bitwise again
-    {"HV_TSDF_SWEEP": "3", "HV_TSDF_SWEEP_REC12": "0"},    # 8-byte records + multiplier table (two gathers per visit)
-    {"HV_TSDF_SWEEP": "4"},                                # fold on whole voxel columns (16 z per lane), pipelined gather groups
-    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_WPE": "5"},
-    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_WPE": "3"},
-    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_GV": "2"},
-    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_GV": "1"},
-    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_PIPE": "0"},
-    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_ANYSKIP": "0"},
-    {"HV_TSDF_SWEEP": "4", "HV_TSDF_BATCH_SPLIT": "2"},
-    {"HV_TSDF_SWEEP": "4", "HV_TSDF_BATCH_SPLIT": "1"},
-    {"HV_TSDF_SWEEP": "4", "HV_TSDF_BATCH_GENERAL": "1"},
+    {"HV_TSDF_SWEEP": "4"},                                # production: the batch folded per voxel on whole voxel columns (tsdf <= FOLD_TSDF_TOL, the rest exact)
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_PIPELINE": "0"},     # every launch of a batch on the one stream (no touch / sweep overlap between batches)
+    {"HV_TSDF_SWEEP": "4", "HV_TSDF_BATCH_GENERAL": "1"},  # the column kernel's rare-regime path everywhere: bitwise again
     {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_ZS": "2"},      # z halves: 8 wave tasks per unit (multi-GPU shares; the upper half replays 8 z steps)
-    {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_ZS": "2", "HV_TSDF_SWEEP_WPE": "5"},
     {"HV_TSDF_SWEEP": "4", "HV_TSDF_SWEEP_ZS": "2", "HV_TSDF_BATCH_GENERAL": "1"},
-    {"HV_TSDF_SWEEP": "2"},                              # production: float2 chain, prefetched frame constants, packed colour
-    {"HV_TSDF_SWEEP": "2", "HV_TSDF_PIPELINE": "0"},     # every launch of a batch on the one stream (no touch / sweep overlap between batches)
-    {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_XCD": "0"},    # work items in list order instead of one contiguous list eighth per XCD
-    {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_WPE": "5"},    # the same at 96 VGPRs (5 waves / SIMD)
-    {"HV_TSDF_SWEEP": "2", "HV_TSDF_BATCH_SPLIT": "8"},  # 8 workgroups per unit
-    {"HV_TSDF_SWEEP": "2", "HV_TSDF_SWEEP_ZH": "8"},     # 8 voxels of a column per lane
+    {"HV_TSDF_SWEEP": "2"},                              # bitwise form: the reference's running mean frame by frame
+    {"HV_TSDF_SWEEP": "2", "HV_TSDF_PIPELINE": "0"},
     {"HV_TSDF_SWEEP": "2", "HV_TSDF_BATCH_GENERAL": "1"},  # EXACT evaluation with integer weights everywhere
-    {"HV_TSDF_SWEEP": "1"},                              # first form (round 1)
 ]
 
 
@@ -219,7 +195,7 @@ SWEEP_FORMS = [
 def test_sweep_forms_match_oracle(env, sweep_case, monkeypatch):
     """Every form of the multi-frame sweep (the switches are read per call) against the oracle at the bench
     configuration, two batches of 8 frames: keys and weights exact, colour <= 1e-4, tsdf bitwise for the forms that apply
-    the running mean frame by frame (1, 2, and the fold kernel's rare-regime path) and <= FOLD_TSDF_TOL for the fold."""
+    the running mean frame by frame (2, and the column kernel's rare-regime path) and <= FOLD_TSDF_TOL for the fold."""
     from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
 
     for k, v in env.items():

@@ -261,6 +261,48 @@ def cls_of(gpu, object_id):
     return v.class_ids[v.object_ids == object_id]
 
 
+def test_carve_and_reobserve_cycles_reuse_overflow_nodes():
+    """a long session with carving on must not drain the overflow-node pool.  The same keyframe is fused with
+    up to 24 distinct (object, class) pairs per voxel (> the 6 inline slots: chains of nodes), carved away completely (a depth image
+    pushed back: every voxel in front of it is reset, voxel_grid_carving.h:47-79), and fused again - 50 times.  A reset voxel keeps
+    its chain and grows its next map into it: the nodes handed out stop growing after the first cycle with the same labels and stay
+    bounded when every tenth cycle draws new ones; nothing is dropped; the state is the compiled reference's, which frees and
+    reallocates std::map nodes (voxel_data_semantic.h:249-672)."""
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import CameraFrustrum
+
+    s = SyntheticRGBD(CFG, noise=False, invalid_frac=0.0)
+    intr = s.intrinsics
+    gpu, ref = gpu_grid(PROB, 0.05), RefSemGrid2(PROB, 0.05)
+    depth, rgb, T, cls_img, inst_img = semantic_frame(s, 0)
+    far = np.where(depth > 0, depth + 1.0, 0).astype(np.float32)
+    fr = CameraFrustrum(*intr, s.width, s.height, T, depth_max=DEPTH_MAX, depth_min=DEPTH_MIN)
+
+    def labels(seed):
+        rng = np.random.default_rng(seed)
+        return rng.integers(0, 6, cls_img.shape).astype(np.int32), rng.integers(0, 4, cls_img.shape).astype(np.int32)
+
+    used = []
+    for cycle in range(50):
+        c_img, o_img = labels(5 if cycle % 10 else 100 + cycle)
+        pts, cols, cls, obj, depths = frame_points(depth, rgb, T, c_img, o_img, intr, 4.0)
+        for g in (gpu, ref):
+            g.integrate(pts, cols, cls, obj, depths)
+        used.append(gpu.prob_nodes_used())
+        if cycle == 0:
+            assert gpu.dump2(max_labels=32)[5].max() > 6 and used[0] > 0  # maps beyond the inline slots: chains exist
+        if cycle in (0, 23, 49):
+            assert_state_equal(gpu, ref, PROB)
+        before = gpu.size()
+        gpu.carve(fr, far, 0.01)
+        ref.carve(fr.intr, s.width, s.height, T, fr.depth_max, fr.depth_min, far, 0.01)
+        assert gpu.size() <= 0.02 * before  # (nearly) everything this keyframe put in is carved away again
+    assert gpu.label_overflows() == 0 and gpu.dropped_points() == 0
+    assert used[1:10] == [used[1]] * 9, used[:12]  # the same observation again: not one more node
+    assert used[-1] <= 2 * used[0], (used[0], used[-1])  # new label draws lengthen some chains; 50 cycles do not multiply them
+    assert_state_equal(gpu, ref, PROB)
+
+
 @pytest.mark.parametrize("kind", [VOTE, PROB])
 def test_semantic_carve(kind):
     from pyslam_amd.synthetic import SyntheticRGBD

@@ -23,8 +23,8 @@ def main():
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--window", default="replay", choices=["replay", "sliding"],
                     help="replay: the same frames every step (round 3's curve); sliding: step k fuses frames 32k ... 32k + 31 of the loop "
-                         "(the headline's window: the camera moves, coherent ownership migrates)")
-    ap.add_argument("--sharding", default="owner", choices=["owner", "tile", "coherent"],
+                         "(the headline's window: the camera moves)")
+    ap.add_argument("--sharding", default="owner", choices=["owner", "tile"],
                     help="owner: owner(unit) == rank; tile: vertical image tiles (a unit several tiles see is fused by each of them, "
                          "partial means - what merge_halo() reconciles; not timed here)")
     ap.add_argument("--only-rank", type=int, default=-1, help="run just this rank's share (for a kernel trace)")
