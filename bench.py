@@ -68,7 +68,7 @@ UNIT_BYTES = 4096 * BYTES_PER_VOXEL
 VALU_PEAK_GINSTR_2CYC = 1024 * 2.4 / 2.0  # MI355X_MICROARCH.md lists wave64 v_fma_f32 at 2 cycles: 1228.8 G wave-instr/s
 VECTOR_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector (non-MFMA) fp32
 FLOP_PER_VISIT = 40  # "TSDF ~ 40 flop / voxel visited"
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 PMC_SUMMARY = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_summary.json")
 
 
@@ -93,6 +93,28 @@ def load_frames(config, n_frames, start=0, rank=0, barrier=None):
         barrier()
     z = np.load(cache)
     return s, z["depth"], z["rgb"], z["T"]
+
+
+def d2d_copy_gbs(n_bytes=1 << 30, reps=6):
+    """Device-to-device copy rate of THIS GPU, measured in this run (report against the vendor peak AND a measured copy):
+    a 1 GiB copy kernel, bytes read + bytes written per second."""
+    import torch
+
+    src = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
+    src.fill_(3)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * n_bytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del src, dst
+    return best
 
 
 def pmc_summary(build_digest):
@@ -290,24 +312,24 @@ def voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, frames, steps, cpu_fr
            "blocks": int(g.num_blocks())}
     if k_launches:
         avg_s = k_ms * 1e-3 / k_launches
-        out["roofline"] = {"bound": "hbm", "kernels": "k_vgb_count (fused unprojection + keys + block claim) + k_vgb_offsets + k_vgb_scatter + k_vgb_fold_wave of one integrate_rgbd call (HIP events around the call's launches)",
+        out["roofline"] = {"bound": "hbm", "kernels": "k_vgb_bin (fused unprojection + keys + block claim + bin placement + touched list) + k_vgb_fold_wave of one integrate_rgbd call (HIP events around the call's launches)",
                            "algorithmic_bytes_per_frame": int(b_vox + b_in), "avg_us_per_frame": round(avg_s * 1e6, 2),
                            "achieved": round((b_vox + b_in) / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round((b_vox + b_in) / avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                            "note": "B_vox = 2 x 28 B x distinct voxels touched per frame (oracle keys) + B_in 7 B/px: a ~15 MB/frame "
-                                   "path bounded by four dependent launches; the fold moves whole 128-byte lines for 32-byte voxel "
-                                   "records scattered over the frame's ~13 000 blocks (see traffic)"}
+                                   "path bounded by the dependent memory round trips of two launches; the fold moves whole 128-byte lines for "
+                                   "32-byte voxel records scattered over the frame's ~13 000 blocks (see traffic)"}
         # HBM bytes of the four per-frame kernels from the recorded --pmc passes of tools/bench_voxel_grid.py on this build
         try:
             with open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_voxel_grid.json")) as f:
                 vp = json.load(f)
             if vp.get("build_digest") == current_build_digest():
                 per = {}
-                for name in ("k_vgb_count", "k_vgb_offsets", "k_vgb_scatter", "k_vgb_fold_wave"):
+                for name in ("k_vgb_bin", "k_vgb_fold_wave"):
                     t = hbm_traffic(next((v for k, v in vp.get("kernels", {}).items() if name in k), None))
                     if t is not None:
                         per[name] = t
-                if len(per) == 4:
+                if len(per) == 2:
                     out["roofline"]["traffic"] = int(sum(per.values()))
                     out["roofline"]["traffic_per_kernel"] = per
                     out["roofline"]["traffic_GBs"] = round(sum(per.values()) / avg_s / 1e9, 1)
@@ -815,6 +837,13 @@ def main():
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(n_cov), "frames_per_launch": B,
                         "voxel_visits_per_launch": int(visits / n_cov)}
             roofline["traffic_source"] = traffic_source
+            try:
+                copy_gbs = d2d_copy_gbs()
+                roofline["peak_measured"] = {"value": round(copy_gbs, 1), "unit": "GB/s", "frac": round(alg / t_cov / 1e9 / copy_gbs, 4),
+                                             "what": "device-to-device copy of 1 GiB measured in this run (bytes read + written per second); "
+                                                     "frac = achieved / this figure, beside frac against the vendor's 8 TB/s"}
+            except Exception as e:
+                roofline["peak_measured"] = {"error": f"{type(e).__name__}: {e}"}
             if traffic:
                 roofline["traffic_GBs"] = hbm["traffic_GBs"]
                 roofline["traffic_over_algorithmic"] = hbm["traffic_over_algorithmic"]
@@ -865,6 +894,7 @@ def main():
                     f"units; no collective while fusing" if args.sharding == "owner"
                     else f"{world} vertical image tiles + RCCL merge of the shared units (timed)"),
                 "units_allocated": units_allocated,
+                "parity_pinned": False,  # Open3D (the reference's TSDF arithmetic) is not in the image: the oracle is a restatement (README)
                 "clock_ramp_steps": args.clock_ramp_steps,
                 "build_digest": digest,
             },
@@ -928,6 +958,8 @@ def main():
             del vol, fuser
             for key, leg in (("host_mode", lambda: __import__("tools.bench_host", fromlist=["host_leg"]).host_leg(
                                  s, depth_h, rgb_h, T_h, VOXEL, SDF_TRUNC, DEPTH_TRUNC, B=B, steps=min(6, n_distinct // B))),
+                             ("tum1_640x480_5mm", lambda: __import__("tools.bench_tum", fromlist=["tum_leg"]).tum_leg(
+                                 h2d_gbs=(out.get("host_mode") or {}).get("h2d_pinned_GBs"))),
                              ("configs", config_legs),
                              ("voxel_grid", lambda: voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, min(B, n_distinct), 5, 6)),
                              ("semantic", lambda: __import__("tools.bench_semantic", fromlist=["semantic_leg"]).semantic_leg(10, 2, 0.01)),
@@ -940,6 +972,19 @@ def main():
 
                     traceback.print_exc()
                     out[key] = {"error": f"{type(e).__name__}: {e}"}
+            # the headline the way a consumer meets it: host-fed figures as first-class keys with their own (PCIe) roofline
+            hm = out.get("host_mode") or {}
+            if "staged" in hm:
+                out["host_fed"] = {"what": "the headline's stream handed over as pageable per-keyframe host arrays (PCIe inside the clock, "
+                                           "volume empty when it starts): value = the float32-depth form pySLAM's queue delivers",
+                                   "value": hm["staged"]["value"], "unit": "frames/s"}
+                for k, bpp in (("staged", "float32 depth + uint8 x 3 colour: 7 B / pixel"), ("staged_u16", "uint16 depth (the sensor's format) + uint8 x 3 colour: 5 B / pixel")):
+                    if k in hm and "value" in hm[k]:
+                        fb = hm[k].get("bytes_per_frame", hm.get("bytes_per_frame"))
+                        out["host_fed"][k] = {"value": hm[k]["value"], "unit": "frames/s", "bytes_per_frame": fb,
+                                              "roofline": {"bound": "pcie", "what": bpp, "achieved": round(fb * hm[k]["value"] / 1e9, 2),
+                                                           "peak": hm["h2d_pinned_GBs"], "unit": "GB/s", "peak_what": "pinned-memory H2D rate measured in this run",
+                                                           "frac": round(fb * hm[k]["value"] / 1e9 / hm["h2d_pinned_GBs"], 3), "traffic": None}}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -337,6 +337,7 @@ struct hv_volume {
     // on `stream`; two sets of scratch (batch_buf / batch_buf2, the halves of touched_list / touched_mask, TOUCH0 / TOUCH1)
     void *batch_buf2 = nullptr;
     size_t batch_buf2_bytes = 0;
+    hipEvent_t ev_h2d = nullptr;      // behind the H2D copies of a call whose sources are page-locked (hv_h2d_fence)
     hipStream_t stream_aux = nullptr;
     hipEvent_t ev_prep = nullptr;     // touch + pack of the current batch done (stream_aux -> stream)
     hipEvent_t ev_presweep = nullptr; // everything on `stream` up to the point just before the previous batch's sweep

@@ -113,8 +113,13 @@ int hv_h2d_lazy(hv_volume *v, void *dst, const void *src, size_t bytes, bool *pe
     return HV_OK;
 }
 
+// (an event right behind the copies, not the whole stream: a caller whose keyframes sit in page-locked memory would otherwise wait
+// for every kernel queued before this call as well - ADVICE r05)
 int hv_h2d_fence(hv_volume *v, bool pending) {
-    if (pending) HV_HIP(hipStreamSynchronize(v->stream));
+    if (!pending) return HV_OK;
+    if (v->ev_h2d == nullptr) HV_HIP(hipEventCreateWithFlags(&v->ev_h2d, hipEventDisableTiming));
+    HV_HIP(hipEventRecord(v->ev_h2d, v->stream));
+    HV_HIP(hipEventSynchronize(v->ev_h2d));
     return HV_OK;
 }
 
@@ -440,6 +445,7 @@ int hv_capacity_gate(hv_volume *v, bool *checked) {
     }
     // an earlier association (hv_assoc_vote / _decide in the device flow, which never fetches the map) dropped votes or voxels: say so
     // ONCE, at the first call that can - the volume itself is consistent, the caller decides whether to go on
+    if (overflow != 0) v->overflow_latched = true; // stays set until hv_reserve_blocks / hv_reset repair the pool (a rebuild clears it)
     if (const int32_t af = st->assoc_flags) {
         v->h_status->assoc_flags = 0;
         HV_REQUIRE(false, HV_ERR_CAPACITY,
@@ -447,7 +453,6 @@ int hv_capacity_gate(hv_volume *v, bool *checked) {
                    "the volume is otherwise unchanged",
                    (af & 2) ? "vote table full " : "", (af & 4) ? "pending list full " : "", (af & 1) ? "more than 4096 (instance, object) pairs" : "");
     }
-    if (overflow != 0) v->overflow_latched = true; // stays set until hv_reserve_blocks / hv_reset repair the pool (a rebuild clears it)
     HV_REQUIRE(!v->overflow_latched, HV_ERR_CAPACITY,
                "block pool exhausted during an earlier integrate call (max_blocks=%lld): units that did not fit were not fused; "
                "nothing more is fused until hv_reserve_blocks or hv_reset",
@@ -690,6 +695,7 @@ void hv_destroy(hv_volume *v) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);
     }
+    if (v->ev_h2d) (void)hipEventDestroy(v->ev_h2d);
     if (v->ev_prep) (void)hipEventDestroy(v->ev_prep);
     if (v->ev_presweep) (void)hipEventDestroy(v->ev_presweep);
     if (v->stream_aux) (void)hipStreamDestroy(v->stream_aux);

@@ -624,7 +624,9 @@ class VolumetricIntegratorBase:
             depth = depth.astype(np.float32) * np.float32(factor) if factor != 1.0 else depth.astype(np.float32)
             keyframe_data.depth = depth
         semantic, instances = keyframe_data.semantic_img, keyframe_data.semantic_instances_img
-        if self.calib_map1 is not None:  # base.py:1017-1043: colour bilinear, depth and labels nearest
+        if self.calib_map1 is not None and getattr(self, "volume_rectifies", False):
+            pass  # (TSDF mode: the volume remaps colour and depth of every frame it is handed on the device, hv_tsdf_set_rectify_maps)
+        elif self.calib_map1 is not None:  # base.py:1017-1043: colour bilinear, depth and labels nearest
             m1, m2 = self.calib_map1, self.calib_map2
             color = self.volume.remap(np.ascontiguousarray(color), m1, m2, linear=True)
             depth = self.volume.remap(depth, m1, m2, linear=False)

@@ -46,6 +46,12 @@ class VolumetricIntegratorTsdf(VolumetricIntegratorBase):
         if hasattr(self.volume, "set_color_order"):
             self.volume.set_color_order(bgr=True)
             self.volume_takes_bgr = True
+        # a distorted camera (TUM1's k1..k3): the reference remaps colour and depth of every keyframe on the host with cv2.remap
+        # (base.py:1017-1043); the HIP volume takes the maps once and remaps each batch on the device, beside its touch + pack launch
+        self.volume_rectifies = False
+        if self.calib_map1 is not None and hasattr(self.volume, "set_rectify_maps"):
+            self.volume.set_rectify_maps(self.calib_map1, self.calib_map2)
+            self.volume_rectifies = True
         fx, fy, cx, cy = self.get_camera_intrinsics_for_depth()
         self.o3d_camera = PinholeCameraIntrinsic(width=camera.width, height=camera.height, fx=fx, fy=fy, cx=cx, cy=cy)
 

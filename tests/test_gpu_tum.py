@@ -1,0 +1,155 @@
+"""GPU parity of the TUM-fr1-shaped path (BASELINE configs[0]): uint16 depth with DepthMapFactor 5000, TUM1
+intrinsics with non-zero distortion (settings/TUM1.yaml:27-39,54), undistort / rectify on the device inside the TSDF batch
+(hv_tsdf_set_rectify_maps: colour bilinear, depth nearest - volumetric_integrator_base.py:758-786,1017-1043), host keyframes
+through hv_tsdf_integrate_frames - against oracle.PortTsdf fed with frames rectified on the host by the oracle's numpy remap
+(oracle/host_prep.py: OpenCV's semantics restated, unpinned like hv_remap)."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import host_prep as hp
+from tests.conftest import assert_tsdf_parity, synthetic_frames
+
+pytestmark = pytest.mark.gpu
+
+DEPTH_FACTOR = 5000.0
+
+
+def assert_matches_oracle(da, db):
+    """(keys, tsdf, weight, colour) of the HIP volume against the oracle's: unit keys and weights identical, tsdf bitwise / within the
+    fold tolerance (conftest.assert_tsdf_parity), colour within 1e-4 (the oracle keeps Open3D's running mean in double, the volume
+    exact integer sums: equal to double rounding)."""
+    np.testing.assert_array_equal(da[0], db[0])
+    np.testing.assert_array_equal(da[2], db[2])
+    assert_tsdf_parity(da[1], db[1])
+    assert max(float(np.abs(da[3][lo:lo + 512] - db[3][lo:lo + 512]).max()) for lo in range(0, len(da[0]), 512)) / 255.0 <= 1e-4
+
+
+def tum_case(n_frames, start=0):
+    from pyslam_amd import prep
+
+    s, frames = synthetic_frames("tum1_640x480_5mm", start, n_frames, distorted=True, depth_dtype="uint16")
+    K = np.array([[s.fx, 0.0, s.cx], [0.0, s.fy, s.cy], [0.0, 0.0, 1.0]])
+    new_K = prep.get_optimal_new_camera_matrix(K, s.dist, (s.width, s.height), 0.7, (s.width, s.height))[0]
+    mx, my = prep.init_undistort_rectify_map(K, s.dist, new_K, (s.width, s.height))
+    intr = (float(new_K[0, 0]), float(new_K[1, 1]), float(new_K[0, 2]), float(new_K[1, 2]))
+    return s, frames, mx, my, intr
+
+
+def oracle_volume(frames, mx, my, intr, voxel=0.005, trunc=0.04):
+    cpu = oracle.PortTsdf(voxel, trunc, threads=8)
+    K = np.array(intr, dtype=np.float64)
+    for d16, rgb, T in frames:
+        # the reference converts the keyframe's depth to float32 first and remaps that (base.py:1007-1043); the nearest-neighbour
+        # pick of the uint16 image followed by the conversion inside the fusion gives the same values
+        depth = hp.remap_nearest(d16, mx, my)
+        color = hp.remap_linear_u8(rgb, mx, my)
+        cpu.integrate(depth, color, K, T, DEPTH_FACTOR, 4.0)
+    return cpu
+
+
+def test_rectify_kernel_equals_the_oracle_remap():
+    """The device remap of a batch (what the fusion consumes, read back through hv_remap's single-image twin) against the numpy
+    restatement: depth picks identical, colours identical (integer fixed-point bilinear on both sides)."""
+    from pyslam_amd.volumetric import ScalableTSDFVolume
+
+    s, frames, mx, my, _ = tum_case(2)
+    vol = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 10, max_points=s.width * s.height)
+    for d16, rgb, _T in frames:
+        np.testing.assert_array_equal(vol.remap(rgb, mx, my, linear=True), hp.remap_linear_u8(rgb, mx, my))
+        np.testing.assert_array_equal(vol.remap(d16.astype(np.float32), mx, my, linear=False), hp.remap_nearest(d16, mx, my).astype(np.float32))
+    assert (mx.min() < -1 or my.min() < -1) and hp.remap_nearest(frames[0][0], mx, my).min() == 0  # the border really is sampled
+
+
+def test_tum_keyframes_rectified_on_the_device_match_the_oracle(sweep_form):
+    """The bench leg's own call (tools/bench_tum.py): pageable uint16 / uint8 keyframes -> integrate_frames, rectified on the
+    device, rectified intrinsics, depth_scale 5000 - two calls of 8 keyframes - against the oracle on host-rectified frames:
+    unit keys, weights and colour sums identical, tsdf bitwise (bitwise sweep) / within the fold tolerance (production sweep)."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    s, frames, mx, my, intr = tum_case(16, start=40)
+    K = PinholeCameraIntrinsic(s.width, s.height, *intr)
+    gpu = ScalableTSDFVolume(0.005, 0.04, max_blocks=1 << 15, max_points=s.width * s.height)
+    gpu.set_rectify_maps(mx, my)
+    for lo in (0, 8):
+        part = frames[lo:lo + 8]
+        gpu.integrate_frames([np.array(f[0]) for f in part], [np.array(f[1]) for f in part], K, np.stack([f[2] for f in part]),
+                             depth_scale=DEPTH_FACTOR, depth_trunc=4.0)
+    cpu = oracle_volume(frames, mx, my, intr)
+    assert gpu.num_blocks() == cpu.num_units()
+    assert_matches_oracle(gpu.dump(), cpu.dump())
+    # maps cleared: frames are fused as they come again (and differ from the rectified volume)
+    gpu2 = ScalableTSDFVolume(0.005, 0.04, max_blocks=1 << 15, max_points=s.width * s.height)
+    gpu2.set_rectify_maps(mx, my)
+    gpu2.set_rectify_maps(None, None)
+    part = frames[:4]
+    gpu2.integrate_frames([np.array(f[0]) for f in part], [np.array(f[1]) for f in part], K, np.stack([f[2] for f in part]),
+                          depth_scale=DEPTH_FACTOR, depth_trunc=4.0)
+    raw = oracle.PortTsdf(0.005, 0.04, threads=8)
+    for d16, rgb, T in part:
+        raw.integrate(d16, rgb, np.array(intr), T, DEPTH_FACTOR, 4.0)
+    assert_matches_oracle(gpu2.dump(), raw.dump())
+
+
+def test_online_frames_and_device_batches_are_rectified_too():
+    """hv_tsdf_integrate (one frame, host and device) and hv_tsdf_integrate_batch (device-resident) go through the maps as well."""
+    import torch
+
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+
+    s, frames, mx, my, intr = tum_case(6, start=10)
+    K = PinholeCameraIntrinsic(s.width, s.height, *intr)
+    gpu = ScalableTSDFVolume(0.005, 0.04, max_blocks=1 << 15, max_points=s.width * s.height)
+    gpu.set_rectify_maps(mx, my)
+    d16, rgb, T = frames[0]
+    gpu.integrate(RGBDImage.create_from_color_and_depth(rgb, d16, DEPTH_FACTOR, 4.0, False), K, T)
+    d16, rgb, T = frames[1]  # device-resident: float32 metres (torch has no uint16 arithmetic; the maps pick the same pixels)
+    depth_d = torch.from_numpy(d16.astype(np.float32) / np.float32(DEPTH_FACTOR)).cuda()
+    gpu.integrate(RGBDImage.create_from_color_and_depth(torch.from_numpy(rgb).cuda(), depth_d, 1.0, 4.0, False), K, T)
+    part = frames[2:]
+    gpu.integrate_batch(np.stack([f[0] for f in part]), np.stack([f[1] for f in part]), K, np.stack([f[2] for f in part]),
+                        depth_scale=DEPTH_FACTOR, depth_trunc=4.0)
+    cpu = oracle_volume(frames, mx, my, intr)
+    assert_matches_oracle(gpu.dump(), cpu.dump())
+
+
+def test_tsdf_integrator_front_rectifies_on_the_device(tmp_path):
+    """The drop-in front with a distorted camera (TUM1's coefficients): VolumetricIntegratorTsdf hands its maps to the volume
+    (volume_rectifies) instead of remapping every keyframe on the host; the mesh is the oracle's on host-rectified keyframes."""
+    import time
+
+    from pyslam_amd.dense import VolumetricIntegrationTaskType, VolumetricIntegratorType, volumetric_integrator_factory
+    from pyslam_amd.dense.parameters import Parameters
+    from pyslam_amd.dense.volumetric_integrator_types import DatasetEnvironmentType, SensorType
+    from tests import dense_helpers as dh
+
+    Parameters.kVolumetricIntegrationVoxelLength = 0.02
+    Parameters.kVolumetricIntegrationTSdfTrunc = 0.08
+    s, frames, mx, my, intr = tum_case(3)
+    cam = dh.FakeCamera(s)
+    cam.D = np.array(s.dist)
+    integ = volumetric_integrator_factory(VolumetricIntegratorType.TSDF, cam, DatasetEnvironmentType.INDOOR, SensorType.RGBD)
+    cpu = oracle.PortTsdf(0.02, 0.08)
+    try:
+        t0 = time.time()
+        while not integ.is_ready() and time.time() - t0 < 60:
+            time.sleep(0.02)
+        assert integ.is_ready()
+        last = None
+        for i, (d16, rgb, T) in enumerate(frames):
+            depth_m = d16.astype(np.float32) * np.float32(1.0 / DEPTH_FACTOR)  # Frame's conversion (pyslam/slam/frame.py:429-430)
+            kf = dh.FakeKeyFrame(i, {i: (depth_m, rgb, T)}, cam)
+            integ.add_keyframe(kf, kf.img, None, kf.depth_img)
+            t0 = time.time()
+            out = None
+            while out is None and time.time() - t0 < 60:
+                out = integ.pop_output(timeout=0.2)
+            assert out is not None
+            last = out
+            cpu.integrate(hp.remap_nearest(depth_m, mx, my), hp.remap_linear_u8(rgb, mx, my), np.array(intr), T, 1.0, 4.0)
+        v, t, _c = cpu.extract_triangle_mesh()
+        assert last.task_type == VolumetricIntegrationTaskType.INTEGRATE
+        assert last.mesh.vertices.shape == v.shape and last.mesh.triangles.shape == t.shape
+        np.testing.assert_allclose(np.sort(last.mesh.vertices, axis=0), np.sort(v, axis=0), atol=1e-9)
+    finally:
+        integ.quit()

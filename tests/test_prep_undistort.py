@@ -52,6 +52,49 @@ def _render(Kmat, dist):
     return depth.astype(np.float32), np.clip(np.rint(rgb), 0, 255).astype(np.uint8)
 
 
+def test_oracle_remap_restatement_basics():
+    """oracle/host_prep.py's numpy remaps (the checker of the device rectification, tests/test_gpu_tum.py): identity maps return the
+    image, an integer shift moves it and fills the border with 0, half-pixel maps average neighbours with OpenCV's 1/32-pixel fixed
+    point, nearest rounds half to even (cvRound)."""
+    from oracle import host_prep as hp
+
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (12, 16, 3)).astype(np.uint8)
+    dep = rng.integers(0, 65536, (12, 16)).astype(np.uint16)
+    xx, yy = np.meshgrid(np.arange(16, dtype=np.float32), np.arange(12, dtype=np.float32))
+    np.testing.assert_array_equal(hp.remap_linear_u8(img, xx, yy), img)
+    np.testing.assert_array_equal(hp.remap_nearest(dep, xx, yy), dep)
+    sh = hp.remap_nearest(dep, xx + 3, yy - 2)
+    np.testing.assert_array_equal(sh[2:, :13], dep[:10, 3:])
+    assert (sh[:2] == 0).all() and (sh[:, 13:] == 0).all()
+    half = hp.remap_linear_u8(img, xx + 0.5, yy)[:, :15].astype(np.int32)
+    want = (img[:, :15].astype(np.int32) + img[:, 1:].astype(np.int32) + 1) >> 1
+    assert np.abs(half - want).max() <= 1
+    np.testing.assert_array_equal(hp.remap_nearest(dep, np.full_like(xx, 2.5), yy)[:, 0], dep[:, 2])  # 2.5 -> 2 (half to even)
+    np.testing.assert_array_equal(hp.remap_nearest(dep, np.full_like(xx, 3.5), yy)[:, 0], dep[:, 4])  # 3.5 -> 4
+
+
+def test_distorted_synthetic_stream_is_undone_by_the_maps():
+    """The synthetic stream rendered through TUM1's lens model (SyntheticRGBD(distorted=True)), rectified with the maps of
+    pyslam_amd/prep.py and the oracle's nearest remap, is the pinhole rendering at the NEW camera matrix up to resampling: the
+    depth images agree within a few millimetres away from depth edges."""
+    from oracle import host_prep as hp
+    from pyslam_amd import prep
+    from pyslam_amd.synthetic import SyntheticRGBD, render, trajectory_pose
+
+    s = SyntheticRGBD("tum1_640x480_5mm", distorted=True, noise=False, invalid_frac=0.0)
+    depth, _rgb, _T = s[5]
+    K = np.array([[s.fx, 0.0, s.cx], [0.0, s.fy, s.cy], [0.0, 0.0, 1.0]])
+    new_K = prep.get_optimal_new_camera_matrix(K, s.dist, (s.width, s.height), 0.7, (s.width, s.height))[0]
+    mx, my = prep.init_undistort_rectify_map(K, s.dist, new_K, (s.width, s.height))
+    rect = hp.remap_nearest(depth, mx, my)
+    ideal = render(trajectory_pose(5)[1], s.width, s.height, new_K[0, 0], new_K[1, 1], new_K[0, 2], new_K[1, 2])[0]
+    ok = rect > 0
+    assert ok.mean() > 0.9
+    err = np.abs(rect - ideal)[ok]
+    assert np.median(err) < 2e-3 and (err < 0.02).mean() > 0.97
+
+
 @pytest.mark.gpu
 def test_gpu_remap_undistorts_analytic_scene():
     from pyslam_amd.volumetric import VoxelBlockGrid

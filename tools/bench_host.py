@@ -113,6 +113,33 @@ def host_leg(s, depth_h, rgb_h, T_h, voxel, sdf_trunc, depth_trunc, B=32, steps=
     out["staged"] = {"value": round(fps, 1), "unit": "frames/s", "ms_per_step": round(best / steps * 1e3, 3),
                      "frac_of_h2d_bound": round(fps / (rate * 1e9 / frame_bytes), 3),
                      "call": "ScalableTSDFVolume.integrate_frames (hv_tsdf_integrate_frames), 32 keyframes per call, volume empty when the clock starts"}
+    # the same keyframes with the depth as the SENSOR delivers it: uint16, DepthMapFactor 5000 (settings/TUM1.yaml:54) - 5 bytes per pixel
+    # cross PCIe instead of 7; the conversion to metres happens inside the fusion (Image::ConvertDepthToFloatImage)
+    depths16 = [np.clip(np.rint(d * 5000.0), 0, 65535).astype(np.uint16) for d in depths]
+    fb16 = depths16[0].nbytes + colors[0].nbytes
+
+    def run_staged16():
+        for k in range(steps):
+            lo = k * B
+            vol.integrate_frames(depths16[lo:lo + B], colors[lo:lo + B], K, T_h[lo:lo + B], depth_scale=5000.0, depth_trunc=depth_trunc)
+        vol.synchronize()
+        torch.cuda.synchronize()
+
+    vol.reset()
+    run_staged16()
+    best16 = None
+    for _ in range(3):
+        vol.reset()
+        vol.synchronize()
+        t0 = time.perf_counter()
+        run_staged16()
+        dt = time.perf_counter() - t0
+        best16 = dt if best16 is None else min(best16, dt)
+    fps16 = steps * B / best16
+    out["staged"]["bytes_per_frame"] = int(frame_bytes)
+    out["staged_u16"] = {"value": round(fps16, 1), "unit": "frames/s", "ms_per_step": round(best16 / steps * 1e3, 3), "bytes_per_frame": int(fb16),
+                         "h2d_bound_frames_per_s": round(rate * 1e9 / fb16, 1), "frac_of_h2d_bound": round(fps16 / (rate * 1e9 / fb16), 3),
+                         "call": "integrate_frames with uint16 depth, depth_scale 5000: 5 bytes per pixel over PCIe"}
     # the same through ONE contiguous pageable array per batch (integrate_batch(np.stack(...)), the round-2 call), np.stack inside the clock
     vol.reset()
     vol.synchronize()

@@ -3,7 +3,7 @@ one import of torch, one synthetic stream, many variants).  Every variant times 
 B = 32 posed 640x480 frames resident in HBM, 5 mm - on a volume that is empty when the clock starts, and reports frames/s and
 the sweep kernel's mean launch duration (HIP events on its stream).
 
-usage: python tools/sweep_variants.py [--steps 12] [--warmup 3] 'HV_TSDF_SWEEP=3' 'HV_TSDF_SWEEP=3 HV_TSDF_SWEEP_WPE=8' ...
+usage: python tools/sweep_variants.py [--steps 12] [--warmup 3] 'HV_TSDF_SWEEP=4' 'HV_TSDF_SWEEP=2' ...
 Prints one JSON line per variant (also appended to gpurun_out/sweep_variants.jsonl)."""
 import argparse
 import json
@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--config", default="synthetic_640x480_5mm")
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--owner", default="", help="rank/world: time one rank's share of the unit-ownership sharding (hv_tsdf_set_owner)")
-    ap.add_argument("variants", nargs="*", default=["HV_TSDF_SWEEP=3"])
+    ap.add_argument("variants", nargs="*", default=["HV_TSDF_SWEEP=4"])
     args = ap.parse_args()
     import torch
 
