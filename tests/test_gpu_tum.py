@@ -125,6 +125,8 @@ def test_tsdf_integrator_front_rectifies_on_the_device(tmp_path):
 
     Parameters.kVolumetricIntegrationVoxelLength = 0.02
     Parameters.kVolumetricIntegrationTSdfTrunc = 0.08
+    Parameters.kVolumetricIntegrationOutputTimeInterval = 0.0  # an output after every keyframe
+    Parameters.kVolumetricIntegrationHipMaxBlocks = 1 << 13
     s, frames, mx, my, intr = tum_case(3)
     cam = dh.FakeCamera(s)
     cam.D = np.array(s.dist)
