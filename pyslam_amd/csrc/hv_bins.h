@@ -102,9 +102,10 @@ __device__ __forceinline__ uint32_t hv_bins_entry(const HvBins &B, int32_t slot,
 // The bin pass's common half, called by ALL threads of the workgroup (HV_BIN_THREADS; it synchronises): `has` = this thread holds a
 // point of block `bkey` (packed key, in range, this GPU's), local voxel index lidx, point index i.
 // Two single-word counters are touched ONCE per workgroup, both between the same two barriers: this XCD's touched-list length and
-// the pool's block counter (a workgroup's new blocks take consecutive pool indices).  Workgroups of 1024 threads: 1 225 of them for a
-// 1296x968 keyframe - that many returning atomics per word are ~13 us of serialised time, spread over the launch.
-static constexpr int HV_BIN_THREADS = 1024;
+// the pool's block counter (a workgroup's new blocks take consecutive pool indices).  Workgroups of 512 threads (measured against 256
+// and 1024, round 6: 512 and 256 are level, 1024 is 3-5 % slower at 640x480 - the two barriers hold 16 waves instead of 8 - and
+// 2 450 workgroups' returning atomics per word for a 1296x968 keyframe stay spread over the launch).
+static constexpr int HV_BIN_THREADS = 512;
 __device__ __forceinline__ void hv_bins_push(const HvTable &table, const HvBins &B, bool has, unsigned long long bkey, uint32_t lidx, uint32_t i) {
     __shared__ int32_t s_first[HV_BIN_THREADS];
     __shared__ int32_t s_new_slot[HV_BIN_THREADS];

@@ -74,7 +74,7 @@ def test_product_never_touches_the_oracle():
 
 
 def test_build_digest_covers_every_source_and_header(tmp_path, monkeypatch):
-    """a header-only edit (hv_semantic.h, hv_bucket.h, hv_query.h were not hashed) must change the digest the
+    """a header-only edit (hv_semantic.h, hv_bins.h, hv_query.h were not hashed) must change the digest the
     .so and every profile under profiles/ are keyed by."""
     import shutil
 
@@ -96,7 +96,7 @@ def test_build_digest_covers_every_source_and_header(tmp_path, monkeypatch):
     monkeypatch.setattr(build, "HERE", str(tmp_path / "pkg"))
     same = build._digest()
     # ... and touching one header that only other headers' users include changes it
-    for header in ("hv_semantic.h", "hv_bucket.h", "hv_query.h"):
+    for header in ("hv_semantic.h", "hv_bins.h", "hv_query.h"):
         with open(csrc / header, "a") as f:
             f.write("\n// touched\n")
         after = build._digest()

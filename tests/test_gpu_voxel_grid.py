@@ -271,7 +271,7 @@ def test_batched_replay_is_bit_identical_to_per_frame():
 
 @pytest.mark.parametrize("voxel,bs", [(0.005, 8), (0.05, 8), (0.1, 16)])
 def test_bucket_path_equals_sort_path_and_reference(voxel, bs, monkeypatch):
-    """Single frames take the per-block bucket path (count / offsets / scatter / LDS sort + ordered fold), larger inputs and
+    """Single frames take the per-call bin path (bin pass + LDS sort / ordered fold; hv_bins.h: "bucket" below), larger inputs and
     HV_VG_PATH=sort the device-wide radix sort.  Both fold a voxel's points in point order: identical bits, and identical
     to the compiled reference.  Coarse voxels (5 cm x 8 = 40 cm blocks, 10 cm x 16 = 1.6 m blocks) put far more than the
     4096-entry LDS window into one block: the windowed fold of oversized buckets is covered too."""

@@ -17,8 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-_FLOW_KERNELS = ("k_shadow_", "k_sem_assoc_", "k_remap_instance_ids", "k_vg_unproject", "k_semb_", "k_vgb_offsets", "k_sem_keys",
-                 "k_sem_reduce", "k_sem_carve")
+_FLOW_KERNELS = ("k_shadow_", "k_sem_assoc_", "k_remap_instance_ids", "k_semb_", "k_sem_keys", "k_sem_reduce", "k_sem_carve")
 
 
 def flow_traffic(pmc_file, payload_tag):
