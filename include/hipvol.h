@@ -130,6 +130,13 @@ int hv_remap(hv_volume *v, const void *src, int32_t src_kind, int32_t channels, 
  * call returns without waiting, like the integrate entry points. */
 int hv_filter_shadow_points(hv_volume *v, const float *depth, int32_t height, int32_t width, int32_t delta_x,
                             int32_t delta_y, float fill_value, float *out, int32_t loc);
+/* The same filter on DEVICE images, queued on the caller's HIP stream (`stream` = a hipStream_t) instead of the volume's, with
+ * scratch of its own: the filter reads nothing of the volume, so a front can run it on its upload side - keyframe k + 1's depth is
+ * filtered while keyframe k is fused (pyslam_amd/dense/device_pipeline.py).  The caller orders `out` against its consumers (an
+ * event on `stream`).  Same reference: pyslam/utilities/depth.py filter_shadow_points, as called at
+ * pyslam/dense/volumetric_integrator_voxel_grid.py:235 / volumetric_integrator_voxel_semantic_grid.py:334. */
+int hv_filter_shadow_points_on_stream(hv_volume *v, const float *depth, int32_t height, int32_t width, int32_t delta_x,
+                                      int32_t delta_y, float fill_value, float *out, void *stream);
 
 /* get_voxels(min_count, min_confidence) (voxel_block_grid.hpp:717-819): rows = sum / count.
  * Pass points == NULL to query *n only.  At most `cap` rows are written; *n is the full count. */

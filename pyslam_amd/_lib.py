@@ -61,6 +61,7 @@ SIGNATURES = {
     "hv_integrate_rgbd_points_batch": (_i32, [_vp, _vp, _i32, _f64, _vp, _i32, _i32, _i32, _vp, _vp, _f64, _f64, _i32]),
     "hv_remap": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32]),
     "hv_filter_shadow_points": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _i32]),
+    "hv_filter_shadow_points_on_stream": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "hv_get_voxels": (_i32, [_vp, _i32, _f32, _vp, _vp, _i64, _pi64, _i32]),
     "hv_get_voxels_in_bb": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _i64, _pi64, _i32]),
     "hv_get_voxels_in_frustum": (_i32, [_vp, _vp, _i32, _i32, _vp, _f32, _f32, _i32, _f32, _vp, _vp, _i64, _pi64, _i32]),

@@ -236,11 +236,6 @@ __device__ __forceinline__ void hv_bins_clear_next(const HvBins &B) {
     for (int x = 0; x < HV_BIN_LISTS; ++x) B.len[((B.parity ^ 1) * HV_BIN_LISTS + x) * HV_BIN_LEN_STRIDE] = 0;
 }
 
-// A wave owns its LDS window, lanes synchronise with wave barriers only.
-__device__ __forceinline__ void hv_wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 __device__ __forceinline__ void hv_vgb_bitonic_wave(uint32_t *s, int m2) { // ascending, m2 a power of two >= 64
     const int lane = hv_lane_id();
     for (int k = 2; k <= m2; k <<= 1) {

@@ -205,6 +205,11 @@ __device__ inline void hv_table_assign(const HvTable &t, int32_t slot, uint64_t 
 }
 
 __device__ inline int hv_lane_id() { return (int)(threadIdx.x & (HV_WAVE - 1)); }
+// A wave that owns an LDS window: its lanes synchronise with wave barriers only.
+__device__ __forceinline__ void hv_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // Wave-aggregated append: every lane with `pred` gets a distinct index from *counter; one atomic
 // per wave (ballot + popcount prefix).
@@ -421,15 +426,30 @@ struct hv_volume {
     int64_t mesh_cache_nv = 0, mesh_cache_nt = 0, points_cache_n = 0;
     // per-unit column masks both extractions start from (hv_extract.hip: k_unit_masks), valid for unit_masks_version
     void *unit_masks = nullptr;
-    size_t unit_masks_bytes = 0;
     uint64_t unit_masks_version = 0;
     int unit_masks_units = 0;
+    // Incremental extraction (round 6).  The masks, the marching-cubes classification and the point counts are kept PER UNIT between
+    // extractions (indexed by pool slot, sized for unit_cache_cap units) and recomputed only where something changed: a unit whose
+    // touched_stamp (the id of the last frame that wrote to it: every fuse path stamps its units) is later than the frame_counter of
+    // the previous pass gets new masks and records that pass in mask_stamp[unit]; a unit is classified / counted again when a unit of
+    // its neighbourhood has a mask_stamp later than the previous classification / count.  Writers that do NOT stamp (reset, import,
+    // halo unpack, rebuild, roll-back) bump extract_epoch: a cache of another epoch is recomputed in full.
+    uint64_t extract_epoch = 1;
+    int unit_cache_cap = 0;                          // units the three caches are laid out for
+    uint64_t unit_masks_epoch = 0, mc_epoch = 0, pc_epoch = 0;
+    int32_t unit_masks_stamp = -1, mc_stamp = -1, pc_stamp = -1; // frame_counter at the last pass of each
+    int mc_units = 0, pc_units = 0;
+    void *mc_cache = nullptr; // [edge_mask cap*192 u64][counts cap+1 u64][word_prefix cap*192 u32][cases cap*4096 u8]
+    void *pc_cache = nullptr; // [count cap+1 i32]
 
     // output scratch (grown on demand)
     void *out_a = nullptr;
     void *out_b = nullptr;
     void *out_c = nullptr;
     size_t out_a_bytes = 0, out_b_bytes = 0, out_c_bytes = 0;
+    // histograms + state of hv_filter_shadow_points_on_stream (a caller's stream, beside the volume's: scratch of its own, four sets in turn)
+    void *shadow_ring = nullptr;
+    int shadow_ring_next = 0;
 
     // profiling
     bool profiling = false;

@@ -681,7 +681,7 @@ void hv_destroy(hv_volume *v) {
                     v->touched_stamp, v->touched_list, v->touched_mask, v->frame_px,
                     v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                     v->sort_vals_out, v->sort_tmp, v->scratch_points, v->scratch_colors, v->out_a,
-                    v->out_b, v->out_c, v->rect_map_x, v->rect_map_y, v->rect_buf, v->batch_buf, v->assoc_buf, v->mult_table, v->bins.cnt, v->bins.inl, v->bins.touched, v->bins.len, v->bins.pg_keys, v->bins.pg_data, v->bin_rec, v->batch_buf2, v->unit_masks, v->occ, v->semb_tasks, v->table.prob_nodes};
+                    v->out_b, v->out_c, v->rect_map_x, v->rect_map_y, v->rect_buf, v->batch_buf, v->assoc_buf, v->mult_table, v->bins.cnt, v->bins.inl, v->bins.touched, v->bins.len, v->bins.pg_keys, v->bins.pg_data, v->bin_rec, v->batch_buf2, v->unit_masks, v->occ, v->semb_tasks, v->table.prob_nodes, v->shadow_ring, v->mc_cache, v->pc_cache};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (v->h_counters) (void)hipHostFree(v->h_counters);
@@ -726,6 +726,7 @@ int hv_reset(hv_volume *v) {
     if (v->touched_mask) HV_HIP(hipMemsetAsync(v->touched_mask, 0, sizeof(uint64_t) * HV_TSDF_SETS * v->table_capacity, v->stream));
     memset(v->h_counters, 0, sizeof(int32_t) * HV_CNT_COUNT);
     v->content_version += 1;
+    v->extract_epoch += 1;
     v->frame_counter = 0;
     v->merge_stamp = 0;
     // pool occupancy: known exactly again (the stream is drained first so that no kernel publishes a stale state later)
@@ -802,6 +803,7 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
                "hv_reserve_blocks: %lld blocks are too many for 32-bit (slot, voxel) sort keys", (long long)new_max_blocks);
     HV_HIP(hipSetDevice(v->device));
     HV_HIP(hipStreamSynchronize(v->stream));
+    v->extract_epoch += 1; // (the per-unit extraction caches are recomputed in full after a rebuild: rare, and the stamps move with the table)
     int rc = hv_read_counters(v);
     if (rc != HV_OK) return rc;
     int64_t used = std::min<int64_t>(v->h_counters[HV_CNT_BLOCKS], v->cfg.max_blocks);
@@ -919,6 +921,7 @@ static int hv_rebuild(hv_volume *v, int64_t new_max_blocks, int64_t keep) {
 static int hv_rollback_claims(hv_volume *v, int64_t keep) {
     HV_HIP(hipSetDevice(v->device));
     HV_HIP(hipStreamSynchronize(v->stream));
+    v->extract_epoch += 1;
     const uint64_t cap = v->table_capacity;
     keep = std::max<int64_t>(0, std::min<int64_t>(keep, v->cfg.max_blocks));
     unsigned long long *old_keys = nullptr;

@@ -42,6 +42,11 @@ __constant__ __attribute__((aligned(16))) signed char c_tri_table[256][16];
 __constant__ unsigned char c_tri_count[256];
 
 __device__ __forceinline__ int voxel_word(int x, int y, int z) { return z * RR + x * R + y; }
+// A unit's 192 edge-mask words in z-MAJOR order: word = z * 12 + axis * 4 + quarter (quarter = x >> 2; the word's bit = voxel_word & 63).
+// The vertex ranks of a unit follow the word order, and lane j of the vertex pass builds vertices j, j + 64, ...: with the three
+// axes of a z slice next to each other a wave walks the unit's planes ONCE (round 6).  Axis-major words (rounds 2-5) walked them
+// three times, microseconds apart - longer than a 4 MB L2 holds a line at this fetch rate: 1.35 GB fetched for 152 MB of values.
+__device__ __forceinline__ int mc_word(int axis, int lin) { return (lin >> 8) * 12 + axis * 4 + ((lin >> 6) & 3); }
 
 // pool indices of the 8 units {this, +x, +y, +x+y, +z, ...} (bit0 = x, bit1 = y, bit2 = z), -1 if absent
 __device__ inline void load_neighbours(const HvTable &table, int idx, int *s_nbr) {
@@ -75,13 +80,29 @@ __device__ __forceinline__ void edge_owner(int x, int y, int z, int i, int &n, i
 // (ExtractPointCloud's `f0 * f1 < 0` of two in-range values is "one negative, one positive": the product of two tsdf values
 // cannot underflow to zero - a non-zero tsdf is a ratio of pixel-scale floats, never below 1e-23.)
 //   unit_signs[unit]           bit 0: the unit holds an observed negative voxel, bit 1: an observed non-negative one
-__global__ __launch_bounds__(256) void k_unit_masks(const char *__restrict__ pool, int n_units, uint32_t *__restrict__ m_on,
-                                                     uint32_t *__restrict__ m_ip, uint32_t *__restrict__ unit_signs) {
+//   mask_stamp[unit]           `now` (the volume's frame counter) of the pass that computed the unit's masks last
+// since >= 0: only units written after frame `since` are computed again (touched_stamp of the unit's table slot; the masks of the
+// others are the previous pass's) - a tick of a running reconstruction reads the planes of the units its new keyframes touched,
+// not of the whole map.
+__global__ __launch_bounds__(256) void k_unit_masks(HvTable table, const char *__restrict__ pool, int n_units, uint32_t *__restrict__ m_on,
+                                                     uint32_t *__restrict__ m_ip, uint32_t *__restrict__ unit_signs,
+                                                     int32_t *__restrict__ mask_stamp, const int32_t *__restrict__ touched_stamp,
+                                                     int32_t since, int32_t now) {
     __shared__ uint32_t s_signs;
+    __shared__ int s_skip;
     const int idx = blockIdx.x;
     if (idx >= n_units) return;
-    if (threadIdx.x == 0) s_signs = 0u;
+    if (threadIdx.x == 0) {
+        s_signs = 0u;
+        int skip = 0;
+        if (since >= 0) {
+            const int32_t slot = hv_table_find(table, table.block_keys[idx]);
+            skip = slot >= 0 && touched_stamp[slot] <= since;
+        }
+        s_skip = skip;
+    }
     __syncthreads();
+    if (s_skip) return;
     const char *unit = pool + (int64_t)idx * UNIT_BYTES;
     float t[R];
     uint32_t w[R];
@@ -105,7 +126,10 @@ __global__ __launch_bounds__(256) void k_unit_masks(const char *__restrict__ poo
     const uint32_t wave_signs = (__any(neg != 0u) ? 1u : 0u) | (__any((obs & ~neg) != 0u) ? 2u : 0u);
     if (hv_lane_id() == 0 && wave_signs) atomicOr(&s_signs, wave_signs);
     __syncthreads();
-    if (threadIdx.x == 0) unit_signs[idx] = s_signs;
+    if (threadIdx.x == 0) {
+        unit_signs[idx] = s_signs;
+        mask_stamp[idx] = now;
+    }
 }
 
 // Classification of one unit from per-COLUMN bit masks.  Marching cubes only asks two things of a voxel - observed (weight
@@ -119,7 +143,7 @@ __global__ __launch_bounds__(256) void k_unit_masks(const char *__restrict__ poo
 //   vertex on the +z edge         (neg ^ neg >> 1) & obs-pair & (a valid cube among the four around the edge)
 //   vertex on the +x / +y edge    (neg ^ neg of the next column) & both observed & (a valid cube among the four)
 // which is Open3D's "for every valid cube with a mixed case, every crossing edge gets a vertex".  A unit's 192 mask words are
-// wave ballots (word = z * 4 + wave for each axis) and are all written: no atomics, nothing to clear; the first wave then
+// wave ballots (mc_word: z * 12 + axis * 4 + wave) and are all written: no atomics, nothing to clear; the first wave then
 // scans their popcounts (the rank of a vertex inside the unit; round 2 had a kernel of its own for that).  (First form: a 17^3
 // float slab in LDS, 8 LDS reads per cube, one global atomicOr per crossing edge and cube - 0.45 of its 0.87 ms per 24 k
 // units were those atomics, profiles/r02.)
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32
                                                       const uint32_t *__restrict__ unit_signs, int n_units,
                                                       unsigned long long *__restrict__ edge_mask,
                                                       uint32_t *__restrict__ word_prefix, unsigned long long *__restrict__ counts,
-                                                      uint8_t *__restrict__ cases) {
+                                                      uint8_t *__restrict__ cases, const int32_t *__restrict__ mask_stamp, int32_t since) {
     __shared__ uint32_t s_cnt[MASK_WORDS]; // popcounts of the unit's mask words
     __shared__ uint8_t s_tcnt[256];        // triangles per cube case (a per-lane index into constant memory is a vector load)
     s_tcnt[threadIdx.x] = c_tri_count[threadIdx.x];
@@ -160,9 +184,12 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32
         // (coarse) the signs the 27 units hold between them
         const uint32_t sg = r >= 0 ? unit_signs[r] : 0u;
         const uint32_t all = (__any(sg & 1u) ? 1u : 0u) | (__any(sg & 2u) ? 2u : 0u);
-        if (n == 0) s_coarse = all;
+        // nothing in the neighbourhood has new masks since this unit was classified last: its words, prefixes, cases and counts stand
+        const bool fresh = __any(r >= 0 && mask_stamp[r] > since);
+        if (n == 0) s_coarse = fresh ? all : 0xffu;
     }
     __syncthreads();
+    if (s_coarse == 0xffu) return;
     // A crossing edge and a mixed cube both need an observed negative AND an observed non-negative voxel in the unit's 18 x 18 x 18
     // neighbourhood.  Most allocated units (free space in front of the surface, the far side of the band) see one kind only: no vertex,
     // no triangle, and nothing of their masks / prefixes / cases is ever read (the emit passes return on a zero count; a neighbour asks
@@ -224,7 +251,7 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32
     const uint32_t Ex = (g[1][1] ^ g[2][1]) & o[1][1] & o[2][1] & (Wx | (Wx << 1));
     const uint32_t Ey = (g[1][1] ^ g[1][2]) & o[1][1] & o[1][2] & (Wy | (Wy << 1));
     const uint32_t Ez = (g[1][1] ^ (g[1][1] >> 1)) & pairz(o[1][1]) & (V11 | V01 | V10 | V00);
-    // this unit's mask words: axis * 64 + z * 4 + wave, bit = lane (= voxel_word & 63)
+    // this unit's mask words: mc_word = z * 12 + axis * 4 + wave, bit = lane (= voxel_word & 63)
     const int lane = hv_lane_id(), wave = threadIdx.x >> 6;
     unsigned long long mine = 0ull; // lane k keeps ballot k (k = axis * 16 + z)
 #pragma unroll
@@ -235,7 +262,7 @@ __global__ __launch_bounds__(256) void k_mc_classify(HvTable table, const uint32
         if (lane == 32 + z) mine = bz;
     }
     if (lane < 48) {
-        const int word = (lane >> 4) * (RRR / 64) + (lane & 15) * 4 + wave;
+        const int word = (lane & 15) * 12 + (lane >> 4) * 4 + wave; // mc_word(axis = lane >> 4, z = lane & 15, quarter = wave)
         edge_mask[(int64_t)idx * MASK_WORDS + word] = mine;
         s_cnt[word] = (uint32_t)__popcll(mine);
     }
@@ -329,8 +356,8 @@ __global__ __launch_bounds__(64) void k_mc_vertices(HvTable table, const char *_
             if (s_prefix[mid] <= (uint32_t)r) lo = mid; else hi = mid;
         }
         const int word = lo;
-        const int axis = word / (RRR / 64);
-        const int lin = (word % (RRR / 64)) * 64 + hv_nth_set_bit(s_mask[word], r - (int)s_prefix[word]);
+        const int axis = (word % 12) >> 2;
+        const int lin = ((word / 12) * 4 + (word & 3)) * 64 + hv_nth_set_bit(s_mask[word], r - (int)s_prefix[word]);
         // owner voxel and its +axis neighbour
         const int z = lin / RR, x = (lin / R) % R, y = lin % R;
         int nx = x + (axis == 0), ny = y + (axis == 1), nz = z + (axis == 2);
@@ -452,7 +479,7 @@ __global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, int n_units
         for (int k = 0; k < 3; ++k) {
             int n, axis, lin;
             edge_owner(x, y, z, s_tt[cube * 16 + order[k]], n, axis, lin);
-            const int word = axis * (RRR / 64) + (lin >> 6);
+            const int word = mc_word(axis, lin);
             unsigned long long m;
             uint32_t pre;
             if (n == 0) {
@@ -486,7 +513,7 @@ __global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *_
                                                      const uint32_t *__restrict__ m_ip, int n_units, HvMcParams M,
                                                      double unit_length, int32_t *__restrict__ count,
                                                      const int32_t *__restrict__ base, double *__restrict__ points,
-                                                     double *__restrict__ colors, int64_t cap) {
+                                                     double *__restrict__ colors, int64_t cap, const int32_t *__restrict__ mask_stamp, int32_t since) {
     __shared__ int s_nbr[8];
     __shared__ int s_wave[4];
     const int idx = blockIdx.x;
@@ -494,6 +521,12 @@ __global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *_
     if (FILL && base[idx + 1] == base[idx]) return; // most allocated units hold no surface
     load_neighbours(table, idx, s_nbr);
     __syncthreads();
+    if (!FILL) { // the count of a unit whose own masks and those of its +x / +y / +z units are the previous pass's stands
+        bool fresh = false;
+#pragma unroll
+        for (int n : {0, 1, 2, 4}) fresh = fresh || (s_nbr[n] >= 0 && mask_stamp[s_nbr[n]] > since);
+        if (!fresh) return;
+    }
     const int x = threadIdx.x >> 4, y = threadIdx.x & 15;
     // in-range / negative / positive masks (bit z) of column `col` of neighbour n (bit0 = +x, bit1 = +y, bit2 = +z)
     auto column = [&](int n, int col, uint32_t &inr, uint32_t &neg, uint32_t &pos) {
@@ -668,6 +701,8 @@ __global__ __launch_bounds__(256) void k_pc_normals(HvTable table, const char *_
 
 // ------------------------------------------------------------------------------------------------
 static bool g_tables_uploaded[64] = {false};
+// HV_EXTRACT_INCREMENTAL=0: every extraction recomputes masks, classification and counts of ALL units (rounds 2-5; A/B and tests)
+static bool hv_extract_full() { return getenv("HV_EXTRACT_INCREMENTAL") && atoi(getenv("HV_EXTRACT_INCREMENTAL")) == 0; }
 
 static int upload_tables(int device) {
     if (device < 64 && g_tables_uploaded[device]) return HV_OK;
@@ -712,19 +747,51 @@ extern "C" {
 // no size query preceded it), in which case it recomputes first.
 // k_unit_masks for the volume's current contents (kept under content_version: a tick that extracts the mesh AND the point
 // cloud of the same contents computes them once)
-static int unit_masks_compute(hv_volume *v, int n, const uint32_t **m_on, const uint32_t **m_ip) {
-    const size_t plane = sizeof(uint32_t) * RR * (size_t)n;
-    int rc = hv_ensure_buffer(v, &v->unit_masks, &v->unit_masks_bytes, 2 * plane + sizeof(uint32_t) * (size_t)n);
+// The three per-unit caches (hv_common.h: incremental extraction) are laid out for unit_cache_cap units; a pool that outgrows the
+// layout gets new buffers and one full pass.
+static constexpr size_t MC_UNIT_BYTES = sizeof(uint64_t) * MASK_WORDS + sizeof(uint32_t) * MASK_WORDS + RRR;
+static int unit_caches_ensure(hv_volume *v, int n) {
+    if (n <= v->unit_cache_cap && v->unit_masks != nullptr) return HV_OK;
+    int cap = 1024;
+    while (cap < n) cap <<= 1;
+    HV_HIP(hipStreamSynchronize(v->stream));
+    for (void **p : {&v->unit_masks, &v->mc_cache, &v->pc_cache}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    v->unit_cache_cap = 0;
+    v->unit_masks_version = 0;
+    v->unit_masks_epoch = v->mc_epoch = v->pc_epoch = 0; // (no epoch is 0: everything is computed in full)
+    // masks: [m_on cap*256][m_ip cap*256][unit_signs cap][mask_stamp cap]
+    HV_HIP(hipMalloc(&v->unit_masks, sizeof(uint32_t) * (size_t)cap * (2 * RR + 2)));
+    HV_HIP(hipMalloc(&v->mc_cache, MC_UNIT_BYTES * (size_t)cap + sizeof(uint64_t) * ((size_t)cap + 1) + 256));
+    HV_HIP(hipMalloc(&v->pc_cache, sizeof(int32_t) * ((size_t)cap + 1)));
+    v->unit_cache_cap = cap;
+    return HV_OK;
+}
+struct HvUnitMasks {
+    const uint32_t *m_on, *m_ip, *signs;
+    const int32_t *stamp;
+};
+// k_unit_masks for the volume's current contents (kept under content_version: a tick that extracts the mesh AND the point cloud of
+// the same contents computes them once), over the units written since the previous pass
+static int unit_masks_compute(hv_volume *v, int n, HvUnitMasks *out) {
+    int rc = unit_caches_ensure(v, n);
     if (rc != HV_OK) return rc;
-    uint32_t *on = (uint32_t *)v->unit_masks, *ip = on + (size_t)RR * n; // [m_on n * 256][m_ip n * 256][unit_signs n]
+    const size_t cap = (size_t)v->unit_cache_cap;
+    uint32_t *on = (uint32_t *)v->unit_masks, *ip = on + (size_t)RR * cap, *signs = ip + (size_t)RR * cap;
+    int32_t *stamp = (int32_t *)(signs + cap);
     if (v->unit_masks_version != v->content_version || v->unit_masks_units != n) {
-        hipLaunchKernelGGL(k_unit_masks, dim3(n), dim3(256), 0, v->stream, (const char *)v->pool, n, on, ip, ip + (size_t)RR * n);
+        const bool full = v->unit_masks_epoch != v->extract_epoch || v->touched_stamp == nullptr || n < v->unit_masks_units || hv_extract_full();
+        hipLaunchKernelGGL(k_unit_masks, dim3(n), dim3(256), 0, v->stream, v->table, (const char *)v->pool, n, on, ip, signs, stamp,
+                           (const int32_t *)v->touched_stamp, full ? (int32_t)-1 : v->unit_masks_stamp, v->frame_counter);
         HV_HIP(hipGetLastError());
         v->unit_masks_version = v->content_version;
+        v->unit_masks_epoch = v->extract_epoch;
+        v->unit_masks_stamp = v->frame_counter;
         v->unit_masks_units = n;
     }
-    *m_on = on;
-    *m_ip = ip;
+    *out = HvUnitMasks{on, ip, signs, stamp};
     return HV_OK;
 }
 
@@ -742,26 +809,32 @@ static int mesh_compute(hv_volume *v) {
         return HV_OK;
     }
     const int n = (int)nb;
-    // scratch: [edge_mask nb*192 u64][counts n+1 u64][bases n+1 u64][word_prefix nb*192 u32][cases nb*4096 u8]
-    // counts / bases: vertices in the low 32 bits, triangles in the high 32 bits of one word per unit
-    const size_t mask_bytes = sizeof(uint64_t) * MASK_WORDS * (size_t)n;
-    const size_t cnt_bytes = sizeof(uint64_t) * (size_t)(n + 1);
-    const size_t prefix_bytes = sizeof(uint32_t) * MASK_WORDS * (size_t)n;
-    const size_t cases_off = (mask_bytes + 2 * cnt_bytes + prefix_bytes + 255) & ~(size_t)255;
-    rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, cases_off + (size_t)n * RRR + 64);
+    hv_profile_begin(v); // measurement hook: column masks + classify + scan
+    HvUnitMasks UM;
+    rc = unit_masks_compute(v, n, &UM);
     if (rc != HV_OK) return rc;
-    char *base = (char *)v->out_c;
+    // per-unit cache: [edge_mask cap*192 u64][counts cap+1 u64][word_prefix cap*192 u32][cases cap*4096 u8]; scratch: [bases n+1 u64]
+    // counts / bases: vertices in the low 32 bits, triangles in the high 32 bits of one word per unit
+    const size_t cap = (size_t)v->unit_cache_cap;
+    const size_t mask_bytes = sizeof(uint64_t) * MASK_WORDS * cap;
+    const size_t cnt_bytes = sizeof(uint64_t) * (cap + 1);
+    const size_t prefix_bytes = sizeof(uint32_t) * MASK_WORDS * cap;
+    const size_t cases_off = (mask_bytes + cnt_bytes + prefix_bytes + 255) & ~(size_t)255;
+    rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, sizeof(uint64_t) * (size_t)(n + 1));
+    if (rc != HV_OK) return rc;
+    char *base = (char *)v->mc_cache;
     unsigned long long *edge_mask = (unsigned long long *)base;
     unsigned long long *counts = (unsigned long long *)(base + mask_bytes);
-    unsigned long long *bases = counts + (n + 1);
-    uint32_t *word_prefix = (uint32_t *)(base + mask_bytes + 2 * cnt_bytes);
+    unsigned long long *bases = (unsigned long long *)v->out_c;
+    uint32_t *word_prefix = (uint32_t *)(base + mask_bytes + cnt_bytes);
     uint8_t *cases = (uint8_t *)(base + cases_off);
-    hv_profile_begin(v); // measurement hook: column masks + classify + scan
-    const uint32_t *m_on = nullptr, *m_ip = nullptr;
-    rc = unit_masks_compute(v, n, &m_on, &m_ip);
-    if (rc != HV_OK) return rc;
-    hipLaunchKernelGGL(k_mc_classify, dim3(n), dim3(256), 0, v->stream, v->table, m_on, m_ip + (size_t)RR * n /* unit_signs */, n, edge_mask, word_prefix, counts, cases);
+    const bool mc_full = v->mc_epoch != v->extract_epoch || n < v->mc_units || hv_extract_full();
+    hipLaunchKernelGGL(k_mc_classify, dim3(n), dim3(256), 0, v->stream, v->table, UM.m_on, UM.signs, n, edge_mask, word_prefix, counts, cases,
+                       UM.stamp, mc_full ? (int32_t)-1 : v->mc_stamp);
     HV_HIP(hipGetLastError());
+    v->mc_epoch = v->extract_epoch;
+    v->mc_stamp = v->frame_counter;
+    v->mc_units = n;
     rc = exclusive_scan_u64(v, counts, bases, n + 1);
     if (rc != HV_OK) return rc;
     hv_profile_end(v, n);
@@ -828,19 +901,25 @@ static int points_compute(hv_volume *v) {
     }
     HvMcParams M{v->cfg.voxel_size, v->cfg.voxel_size * 0.5};
     const int nu = (int)nb;
-    // scratch: [count nu+1][base nu+1]
-    rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, sizeof(int32_t) * 2 * (size_t)(nu + 1));
-    if (rc != HV_OK) return rc;
-    int32_t *count = (int32_t *)v->out_c, *base = count + (nu + 1);
-    // pass 1 counts per unit (from the column masks), the scan places the units, pass 2 writes into a buffer of exactly
-    // that size
+    // pass 1 counts per unit (from the column masks; kept per unit between extractions), the scan places the units, pass 2 writes
+    // into a buffer of exactly that size
     hv_profile_begin(v);
-    const uint32_t *m_on = nullptr, *m_ip = nullptr;
-    rc = unit_masks_compute(v, nu, &m_on, &m_ip);
+    HvUnitMasks UM;
+    rc = unit_masks_compute(v, nu, &UM);
     if (rc != HV_OK) return rc;
+    rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, sizeof(int32_t) * (size_t)(nu + 1));
+    if (rc != HV_OK) return rc;
+    int32_t *count = (int32_t *)v->pc_cache, *base = (int32_t *)v->out_c;
+    const uint32_t *m_on = UM.m_on, *m_ip = UM.m_ip;
+    const bool pc_full = v->pc_epoch != v->extract_epoch || nu < v->pc_units || hv_extract_full();
+    HV_HIP(hipMemsetAsync(count + nu, 0, sizeof(int32_t), v->stream)); // the scan's extra element
     hipLaunchKernelGGL(k_pc_extract<false>, dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, m_on, m_ip, nu, M,
-                       v->cfg.voxel_size * (double)R, count, (const int32_t *)nullptr, (double *)nullptr, (double *)nullptr, (int64_t)0);
+                       v->cfg.voxel_size * (double)R, count, (const int32_t *)nullptr, (double *)nullptr, (double *)nullptr, (int64_t)0,
+                       UM.stamp, pc_full ? (int32_t)-1 : v->pc_stamp);
     HV_HIP(hipGetLastError());
+    v->pc_epoch = v->extract_epoch;
+    v->pc_stamp = v->frame_counter;
+    v->pc_units = nu;
     rc = exclusive_scan_i32(v, count, base, nu + 1);
     if (rc != HV_OK) return rc;
     hv_profile_end(v, nb);
@@ -854,7 +933,7 @@ static int points_compute(hv_volume *v) {
         double *d_pts = (double *)v->out_a, *d_cols = d_pts + 3 * n;
         hv_profile_begin(v);
         hipLaunchKernelGGL(k_pc_extract<true>, dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, m_on, m_ip, nu, M,
-                           v->cfg.voxel_size * (double)R, (int32_t *)nullptr, (const int32_t *)base, d_pts, d_cols, n);
+                           v->cfg.voxel_size * (double)R, (int32_t *)nullptr, (const int32_t *)base, d_pts, d_cols, n, UM.stamp, (int32_t)-1);
         hv_profile_end(v, nb);
         HV_HIP(hipGetLastError());
     }

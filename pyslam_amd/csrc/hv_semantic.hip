@@ -437,10 +437,21 @@ __global__ __launch_bounds__(256, HV_SEMB_FOLD_MIN_WAVES) void k_semb_fold_wave(
         if (idx < 0) return;            // (the block did not get a pool slot: overflow, reported by the caller)
         const int64_t block_base = (int64_t)idx * G.nvox;
         if (nb <= wcap) {
-            if (lane < nb) s[lane] = h.head; // (the header brought the bin's first 64 entries)
-            for (int e = HV_WAVE + lane; e < nb; e += HV_WAVE) s[e] = hv_bins_entry(B, slot, e);
-            hv_wave_lds_sync();
-            semb_sort_window(s, s_dst, off, nb, idx_bits, G.nvox);
+            if (nb <= HV_WAVE) {
+                // a bin of one entry per lane (a 2 mm keyframe: 12 points per block on average) is ranked in registers - an entry's
+                // place is the number of smaller entries, one readlane + compare per entry of the bin - instead of the counting sort's
+                // passes over the block's 512 voxel offsets (clear, histogram, prefix, scatter, rank: six wave barriers) (round 6)
+                const uint32_t mine = lane < nb ? h.head : 0xFFFFFFFFu; // (entries are distinct: voxel << idx_bits | point index)
+                int rank = 0;
+                for (int j = 0; j < nb; ++j) rank += ((uint32_t)__builtin_amdgcn_readlane((int)mine, j) < mine) ? 1 : 0;
+                if (lane < nb) s[rank] = mine;
+                hv_wave_lds_sync();
+            } else {
+                if (lane < nb) s[lane] = h.head; // (the header brought the bin's first 64 entries)
+                for (int e = HV_WAVE + lane; e < nb; e += HV_WAVE) s[e] = hv_bins_entry(B, slot, e);
+                hv_wave_lds_sync();
+                semb_sort_window(s, s_dst, off, nb, idx_bits, G.nvox);
+            }
             if constexpr (std::is_same<SRC, HvSemRecs>::value) {
                 if (nb <= HV_SEMB_STAGE && can_stage) {
                     // every lane fetches the records of ITS sorted entries (all of the bin's in flight at once) into the windows the sort

@@ -85,6 +85,77 @@ __device__ __forceinline__ bool sem_visit(const HvQuery &Q, const HvTable &table
     return hv_frustum_contains_d(Q, v->pos[0] / c, v->pos[1] / c, v->pos[2] / c, uvd);
 }
 
+// What the association vote asks of a voxel, read in ONE batch of loads (round 6).  The pointer-based accessors above look at a voxel
+// in global memory field by field behind branches - count, then the label map, then the block key, then the position sums - and the
+// compiler keeps that order: four to five dependent trips to the cache per visit before the image is even looked at.  Here the record
+// (64 / 128 bytes) is loaded whole into registers beside the block key, everything is decided from the copy (the inline label slots
+// through constant indices: hv_semantic.h), and only a map with overflow nodes, an invalid cache or a non-finite log-probability
+// goes back to the pointer-based functions (same answers by construction: they are the fallback).
+struct HvVoteHot {
+    int32_t count, cls, obj;
+    bool conf_ok;
+    double pos[3];
+};
+__device__ __forceinline__ HvVoteHot vote_hot(const HvSemVoxel *v, const void *) {
+    const uint4 a = *(const uint4 *)v; // count, obj1, cls1, counter
+    HvVoteHot h;
+    h.count = (int32_t)a.x;
+    h.obj = (int32_t)a.y - 1;
+    h.cls = (int32_t)a.z - 1;
+    h.pos[0] = v->pos[0];
+    h.pos[1] = v->pos[1];
+    h.pos[2] = v->pos[2];
+    // get_confidence() >= 0 (sem_confidence above): counter / count clamped to 1, 0 for an empty voxel
+    const float r = (float)(int32_t)a.w / (float)h.count;
+    h.conf_ok = h.count == 0 || (r < 1.0f ? r : 1.0f) >= 0.0f;
+    return h;
+}
+__device__ __forceinline__ HvVoteHot vote_hot(const HvProbVoxel *v, const void *nodes_) {
+    const HvProbNode *nodes = (const HvProbNode *)nodes_;
+    const HvProbVoxel r = *v; // eight 16-byte loads in flight together; only constant indices below: the copy stays in registers
+    HvVoteHot h;
+    h.count = r.count;
+    h.pos[0] = r.pos[0];
+    h.pos[1] = r.pos[1];
+    h.pos[2] = r.pos[2];
+    const int nlab = prob_nlab(r.meta), best = prob_best(r.meta);
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < HV_PROB_K; ++k) {
+        const float lp = r.logp[k];
+        finite = finite && (k >= nlab || lp - lp == 0.0f);
+    }
+    if (nlab == 0) {
+        h.cls = h.obj = -1;
+        h.conf_ok = true;
+    } else if (nlab <= HV_PROB_K && best >= 0 && finite) { // the common case: decided from the copy
+        const HvProbPair p = prob_slot_get(&r, best);
+        h.cls = p.cls;
+        h.obj = p.obj;
+        h.conf_ok = true;
+    } else { // overflow nodes / no cached best pair / a NaN or an infinity in the map
+        h.cls = sem_class_id(v, nodes);
+        h.obj = sem_object_id(v, nodes);
+        h.conf_ok = sem_confidence_not_negative(v, nodes);
+    }
+    return h;
+}
+// sem_visit on the copy
+__device__ __forceinline__ bool sem_visit_hot(const HvQuery &Q, unsigned long long block_key, int l, const HvSemParams &G, const HvVoteHot &h, float *uvd) {
+    if (h.count < 1 || !h.conf_ok) return false;
+    int32_t bk[3];
+    hv_unpack_key(block_key, bk[0], bk[1], bk[2]);
+    const int32_t lc[3] = {l % G.bs, (l / G.bs) % G.bs, l / (G.bs * G.bs)};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (bk[a] < Q.bmin[a] || bk[a] > Q.bmax[a]) return false;
+        const int32_t vk = bk[a] * G.bs + lc[a];
+        if (vk < Q.vmin[a] || vk > Q.vmax[a]) return false;
+    }
+    const double c = (double)h.count;
+    return hv_frustum_contains_d(Q, h.pos[0] / c, h.pos[1] / c, h.pos[2] / c, uvd);
+}
+
 // Block-level frustum cull for the per-voxel scans below (a wave = 64 consecutive voxels of ONE block: 64 divides bs^3 for the
 // supported block sizes).  A voxel's averaged position lies in its cell, hence in the block's box; if all eight corners of the
 // box (grown by half a voxel against rounding) are on the outer side of one of the frustum's six planes - depth_min, depth_max,
@@ -224,8 +295,8 @@ struct HvAssocParams {
 // frustum once, then only the voxels whose occupancy bit is set are visited (a 2 mm ScanNet keyframe faces 120 k blocks = 61 M
 // voxel slots of which 7 % hold a voxel: the thread-per-slot form spent 0.7 - 1.0 ms per keyframe on per-wave overhead - cull,
 // ballots, appends - for 950 k waves of mostly empty slots).
-template <typename VOX>
-__global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *__restrict__ pool, int64_t n_blocks,
+template <typename VOX, int MINWG>
+__global__ __launch_bounds__(256, MINWG) void k_sem_assoc_vote(HvTable table, VOX *__restrict__ pool, int64_t n_blocks,
                                                          HvSemParams G, HvQuery Q, const int32_t *__restrict__ cls_img,
                                                          const int32_t *__restrict__ inst_img,
                                                          const float *__restrict__ depth, HvAssocParams A,
@@ -254,6 +325,14 @@ __global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *_
         __builtin_amdgcn_wave_barrier();
         n_pend = 0;
     };
+    // The occupied voxels of the blocks in view are QUEUED per wave in LDS and visited 64 at a time, every lane busy (round 6).  A
+    // 2 mm keyframe faces 160 k blocks holding 15 occupied voxels each on average: visited block by block, a wave went through its
+    // two dependent round trips (record -> image pixels) once per block with a quarter of its lanes, 160 k times per keyframe; from
+    // the queue it does so once per 64 voxels.  Votes and pending voxels are order-free (counts; a list the apply pass scatters).
+    constexpr int Q_CAP = 256;
+    __shared__ int32_t s_queue[4][Q_CAP];
+    int32_t *queue = s_queue[threadIdx.x / HV_WAVE];
+    int n_q = 0; // (wave-uniform)
     vote_local_init(s_votes);
     if (n_blocks < 0) n_blocks = min(table.counters[HV_CNT_BLOCKS], table.max_blocks); // (the host does not wait to learn it)
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / HV_WAVE);
@@ -264,15 +343,18 @@ __global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *_
         int32_t inst = -1;
         if (active) {
             VOX *v = pool + gid;
+            const unsigned long long bkey = table.block_keys[b]; // (requested with the record)
+            const HvVoteHot h = vote_hot(v, table.prob_nodes);
             float uvd[3];
-            if (sem_visit(Q, table, v, b, (int)(gid - b * G.nvox), G, uvd)) {
+            if (sem_visit_hot(Q, bkey, (int)(gid - b * G.nvox), G, h, uvd)) {
+                // the three pixels in one trip as well
                 const int64_t px = (int64_t)(int)uvd[1] * Q.width + (int)uvd[0];
                 const int32_t image_class = cls_img[px];
-                const int32_t point_class = sem_class_id(v, table.prob_nodes);
+                const float image_depth = A.use_depth ? depth[px] : 1.0f;
                 inst = inst_img[px];
+                const int32_t point_class = h.cls;
                 bool go = image_class >= 0 && point_class >= 0 && point_class == image_class && inst >= 0;
                 if (go && A.use_depth) {
-                    const float image_depth = depth[px];
                     if (image_depth <= 0.0f || !isfinite(image_depth)) {
                         go = false;
                     } else if (A.do_carving && uvd[2] < image_depth - A.depth_threshold) {
@@ -283,7 +365,7 @@ __global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *_
                     }
                 }
                 if (go) {
-                    int32_t obj = sem_object_id(v, table.prob_nodes);
+                    int32_t obj = h.obj;
                     if (obj < 0) {
                         if (inst == 0) {
                             obj = 0;
@@ -305,6 +387,27 @@ __global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *_
             if (n_pend > PEND_BUF - HV_WAVE) flush_pending();
         }
     };
+    auto drain_queue = [&](bool all) { // ONE instance of the visit in the kernel
+        hv_wave_lds_sync();
+        const int upto = all ? n_q : (n_q & ~(HV_WAVE - 1));
+        for (int i = 0; i < upto; i += HV_WAVE) {
+            const bool active = i + hv_lane_id() < n_q;
+            const int32_t gid = active ? queue[i + hv_lane_id()] : 0;
+            visit_b((int64_t)gid, active, (int64_t)(gid / G.nvox));
+        }
+        const int rem = n_q - min(upto, n_q); // (< 64) stays queued, moved to the front
+        const int32_t keep = hv_lane_id() < rem ? queue[upto + hv_lane_id()] : 0;
+        hv_wave_lds_sync();
+        if (hv_lane_id() < rem) queue[hv_lane_id()] = keep;
+        n_q = rem;
+        hv_wave_lds_sync();
+    };
+    auto enqueue = [&](int64_t gid, bool active) {
+        const unsigned long long m = __ballot(active);
+        if (active) queue[n_q + (int)__popcll(m & lane_lt)] = (int32_t)gid;
+        n_q += (int)__popcll(m);
+        if (n_q > Q_CAP - HV_WAVE) drain_queue(false);
+    };
     // the key and the occupancy words of the NEXT block are requested before this block is worked on: a block is a chain of
     // dependent round trips (key -> cull, words -> records -> image pixels) and a wave holds too many registers for the SIMD to
     // hide them with other waves
@@ -321,10 +424,10 @@ __global__ __launch_bounds__(256, 4) void k_sem_assoc_vote(HvTable table, VOX *_
         }
         if (words && !__any(word != 0ull)) continue;                                      // nothing ever landed in this block
         if ((G.nvox & 63) == 0 && sem_block_outside_frustum_key(Q, bkey, G)) continue; // wave-uniform
-        auto visit = [&](int64_t gid, bool active) { visit_b(gid, active, b); };
-        if (words) sem_for_occupied_word(word, b, G.nvox, visit);
-        else sem_for_occupied(occ, b, G.nvox, false, visit);
+        if (words) sem_for_occupied_word(word, b, G.nvox, enqueue);
+        else sem_for_occupied(occ, b, G.nvox, false, enqueue);
     }
+    drain_queue(true);
     flush_pending();
     vote_local_flush(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2]);
 }
@@ -1093,11 +1196,13 @@ int hv_assoc_vote(hv_volume *v, const float *intr_f32, int32_t width, int32_t he
         fill_key_range(Q, GP);
         // (four blocks per wave, one per 16-lane group, was measured in round 5 - profiles/r05/README.md: +2-3 % at 2 mm, -11 % at 1 cm - and dropped)
         const dim3 grid((unsigned)std::min<int64_t>((nb + 3) / 4, 4096)); // persistent: 16 workgroups per CU
+        // the probabilistic payload's copy of the record takes 149 registers: three workgroups per CU, nothing spilled (measured
+        // against four with 13 spilled registers: the vote 13 % slower, round 6); the voting payload fits four
         if (prob)
-            hipLaunchKernelGGL(k_sem_assoc_vote<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, (int64_t)-1, G, Q, d_cls, d_inst,
+            hipLaunchKernelGGL((k_sem_assoc_vote<HvProbVoxel, 3>), grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, (int64_t)-1, G, Q, d_cls, d_inst,
                                d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ);
         else
-            hipLaunchKernelGGL(k_sem_assoc_vote<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, (int64_t)-1, G, Q, d_cls, d_inst,
+            hipLaunchKernelGGL((k_sem_assoc_vote<HvSemVoxel, 4>), grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, (int64_t)-1, G, Q, d_cls, d_inst,
                                d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ);
     }
     hipLaunchKernelGGL(k_sem_assoc_image, dim3((unsigned)std::min<int64_t>((n_px + 255) / 256, 512)), dim3(256), 0, v->stream, v->table, d_cls, d_inst,

@@ -2134,6 +2134,7 @@ int hv_tsdf_import_numerators(hv_volume *v, const int32_t *keys, int64_t k, cons
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_import_numerators: not a TSDF volume");
     if (k == 0) return HV_OK;
     v->content_version += 1;
+    v->extract_epoch += 1; // (writes voxels without stamping their units)
     HV_HIP(hipSetDevice(v->device));
     const void *d_keys = nullptr, *d_payload = nullptr;
     int rc = hv_stage_in(v, keys, sizeof(int32_t) * 3 * k, HV_HOST, 0, &d_keys);
@@ -2317,6 +2318,7 @@ int hv_merge_halo_unpack(hv_volume *v, const int32_t *shared_keys, int64_t k, co
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_merge_halo_unpack: not a TSDF volume");
     if (k == 0) return HV_OK;
     v->content_version += 1;
+    v->extract_epoch += 1; // (writes voxels without stamping their units)
     HV_HIP(hipSetDevice(v->device));
     // keys + actions in one staging buffer, payload in the other
     std::vector<char> host((size_t)k * 13);

@@ -689,6 +689,7 @@ __global__ __launch_bounds__(256) void k_vg_probe_keys(const float *__restrict__
 // [5] the threshold (float bits)
 enum { HV_SH_N = 0, HV_SH_RANK0 = 1, HV_SH_RANK1 = 2, HV_SH_PRE0 = 3, HV_SH_PRE1 = 4, HV_SH_THR = 5, HV_SH_TICKET = 8 /* + pass */, HV_SH_WORDS = 16 };
 static constexpr int HV_SH_BINS01 = 4096, HV_SH_BINS2 = 256;
+static constexpr int HV_SH_GRID = 256; // workgroups of a histogram pass
 static constexpr int HV_SH_HIST_WORDS = HV_SH_BINS01 + 2 * HV_SH_BINS01 + 2 * HV_SH_BINS2;
 
 // one workgroup: the bin holding each of the two ranks, the rank inside it.  (Round 5 tried the pick as the tail of the histogram
@@ -1158,6 +1159,26 @@ extern "C" int hv_integrate_rgbd_points(hv_volume *v, const void *depth, int32_t
 
 extern "C" {
 
+// the seven launches of the filter on `st`: head = [histograms][state] (zeroed here), dd -> d_out (device images)
+static int shadow_filter_launch(const float *dd, int32_t height, int32_t width, int32_t delta_x, int32_t delta_y, float fill_value,
+                                float *d_out, uint32_t *head, hipStream_t st) {
+    const int64_t npx = (int64_t)height * width;
+    uint32_t *hist0 = head, *hist1 = hist0 + HV_SH_BINS01, *hist2 = hist1 + 2 * HV_SH_BINS01;
+    uint32_t *state = hist0 + HV_SH_HIST_WORDS;
+    HV_HIP(hipMemsetAsync(hist0, 0, sizeof(uint32_t) * (HV_SH_HIST_WORDS + HV_SH_WORDS), st));
+    // one workgroup per CU (1024 measured the same, round 6: the passes are bound by the LDS atomics of a few dozen hot bins)
+    const unsigned hist_grid = (unsigned)std::min<int64_t>((npx + 255) / 256, HV_SH_GRID);
+    hipLaunchKernelGGL(k_shadow_hist<0>, dim3(hist_grid), dim3(256), 0, st, dd, height, width, delta_x, delta_y, state, hist0);
+    hipLaunchKernelGGL(k_shadow_pick<0>, dim3(1), dim3(256), 0, st, hist0, state);
+    hipLaunchKernelGGL(k_shadow_hist<1>, dim3(hist_grid), dim3(256), 0, st, dd, height, width, delta_x, delta_y, state, hist1);
+    hipLaunchKernelGGL(k_shadow_pick<1>, dim3(1), dim3(256), 0, st, hist1, state);
+    hipLaunchKernelGGL(k_shadow_hist<2>, dim3(hist_grid), dim3(256), 0, st, dd, height, width, delta_x, delta_y, state, hist2);
+    hipLaunchKernelGGL(k_shadow_pick<2>, dim3(1), dim3(256), 0, st, hist2, state);
+    hipLaunchKernelGGL(k_shadow_mask, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, dd, height, width, delta_x, delta_y, state, fill_value, d_out);
+    HV_HIP(hipGetLastError());
+    return HV_OK;
+}
+
 int hv_filter_shadow_points(hv_volume *v, const float *depth, int32_t height, int32_t width, int32_t delta_x,
                             int32_t delta_y, float fill_value, float *out, int32_t loc) {
     HV_REQUIRE(v != nullptr && depth != nullptr && out != nullptr, HV_ERR_INVALID, "hv_filter_shadow_points: null argument");
@@ -1173,27 +1194,32 @@ int hv_filter_shadow_points(hv_volume *v, const float *depth, int32_t height, in
     const size_t head = sizeof(uint32_t) * (HV_SH_HIST_WORDS + HV_SH_WORDS);
     rc = hv_ensure_buffer(v, &v->out_c, &v->out_c_bytes, head + sizeof(float) * npx);
     if (rc != HV_OK) return rc;
-    uint32_t *hist0 = (uint32_t *)v->out_c, *hist1 = hist0 + HV_SH_BINS01, *hist2 = hist1 + 2 * HV_SH_BINS01;
-    uint32_t *state = hist0 + HV_SH_HIST_WORDS;
     float *d_out = loc == HV_DEVICE ? out : (float *)((char *)v->out_c + head);
-    HV_HIP(hipMemsetAsync(hist0, 0, head, v->stream));
-    const unsigned hist_grid = (unsigned)std::min<int64_t>((npx + 255) / 256, 1024);
-    const float *dd = (const float *)d_depth;
-    hipLaunchKernelGGL(k_shadow_hist<0>, dim3(hist_grid), dim3(256), 0, v->stream, dd, height, width, delta_x, delta_y, state, hist0);
-    hipLaunchKernelGGL(k_shadow_pick<0>, dim3(1), dim3(256), 0, v->stream, hist0, state);
-    hipLaunchKernelGGL(k_shadow_hist<1>, dim3(hist_grid), dim3(256), 0, v->stream, dd, height, width, delta_x, delta_y, state, hist1);
-    hipLaunchKernelGGL(k_shadow_pick<1>, dim3(1), dim3(256), 0, v->stream, hist1, state);
-    hipLaunchKernelGGL(k_shadow_hist<2>, dim3(hist_grid), dim3(256), 0, v->stream, dd, height, width, delta_x, delta_y, state, hist2);
-    hipLaunchKernelGGL(k_shadow_pick<2>, dim3(1), dim3(256), 0, v->stream, hist2, state);
-    hipLaunchKernelGGL(k_shadow_mask, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, v->stream,
-                       dd, height, width, delta_x, delta_y, state, fill_value, d_out);
-    HV_HIP(hipGetLastError());
+    rc = shadow_filter_launch((const float *)d_depth, height, width, delta_x, delta_y, fill_value, d_out, (uint32_t *)v->out_c, v->stream);
+    if (rc != HV_OK) return rc;
     // host images: copied back and complete on return; device images: queued on the volume's stream like every other launch
     if (loc == HV_HOST) {
         HV_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * npx, hipMemcpyDeviceToHost, v->stream));
         HV_HIP(hipStreamSynchronize(v->stream));
     }
     return HV_OK;
+}
+
+int hv_filter_shadow_points_on_stream(hv_volume *v, const float *depth, int32_t height, int32_t width, int32_t delta_x,
+                                      int32_t delta_y, float fill_value, float *out, void *stream) {
+    HV_REQUIRE(v != nullptr && depth != nullptr && out != nullptr, HV_ERR_INVALID, "hv_filter_shadow_points_on_stream: null argument");
+    HV_REQUIRE(height > 0 && width > 0 && delta_x >= 0 && delta_y >= 0 && delta_x < width && delta_y < height,
+               HV_ERR_INVALID, "hv_filter_shadow_points_on_stream: bad image size or deltas");
+    HV_REQUIRE((int64_t)height * width < (int64_t)1 << 30, HV_ERR_INVALID, "hv_filter_shadow_points_on_stream: image too large");
+    HV_HIP(hipSetDevice(v->device));
+    // the filter touches nothing of the volume: it may run beside the volume's own launches (a keyframe's depth is filtered on the
+    // upload side while the previous keyframe is fused).  Histograms and state of its own, four sets used in turn.
+    constexpr int SETS = 4;
+    const size_t head = sizeof(uint32_t) * (HV_SH_HIST_WORDS + HV_SH_WORDS);
+    if (v->shadow_ring == nullptr) HV_HIP(hipMalloc(&v->shadow_ring, head * SETS));
+    uint32_t *scratch = (uint32_t *)((char *)v->shadow_ring + head * (size_t)v->shadow_ring_next);
+    v->shadow_ring_next = (v->shadow_ring_next + 1) % SETS;
+    return shadow_filter_launch(depth, height, width, delta_x, delta_y, fill_value, out, scratch, (hipStream_t)stream);
 }
 
 int hv_get_voxels(hv_volume *v, int32_t min_count, float min_confidence, float *points, float *colors,

@@ -215,16 +215,21 @@ class VolumetricIntegratorVoxelSemanticGrid(VolumetricIntegratorBase):
         if getattr(self, "_uploader", None) is None:
             self._uploader = KeyframeUploader(self.volume)
 
+        shadow = bool(Parameters.kVolumetricIntegrationVoxelGridShadowPointsFilter)
+
+        def prep(t, stream):  # upload side: depends on the keyframe's depth alone, runs beside the previous keyframe's kernels
+            t["depth"] = self.volume.filter_shadow_points(t["depth"], stream=stream)
+
         def body(kf, t):
             _, _, pose, _, _ = kf
             self.integrate_2d_instance_ids = t["inst"] is not None
-            self._fuse_device_keyframe(t["color"], t["depth"], pose, t["cls"], t["inst"])
+            self._fuse_device_keyframe(t["color"], t["depth"], pose, t["cls"], t["inst"], depth_filtered=shadow)
 
-        self._uploader.run(keyframes, lambda kf: self._keyframe_arrays(kf[0], kf[1], kf[3], kf[4]), body)
+        self._uploader.run(keyframes, lambda kf: self._keyframe_arrays(kf[0], kf[1], kf[3], kf[4]), body, prep if shadow else None)
 
-    def _fuse_device_keyframe(self, color_d, depth_d, pose, cls_d, inst_d):
+    def _fuse_device_keyframe(self, color_d, depth_d, pose, cls_d, inst_d, depth_filtered=False):
         """The INTEGRATE body on device-resident images (torch CUDA tensors on the volume's stream): nothing waits for the GPU."""
-        if Parameters.kVolumetricIntegrationVoxelGridShadowPointsFilter:
+        if Parameters.kVolumetricIntegrationVoxelGridShadowPointsFilter and not depth_filtered:
             depth_d = self.volume.filter_shadow_points(depth_d)  # stays in HBM
         self.camera_frustrum.set_T_cw(pose)
         object_ids_d = None

@@ -195,8 +195,19 @@ class _Volume:
             L.check(self._lib.hv_profile_read_launches(self._h, L.ptr(out), n.value, ctypes.byref(n)))
         return out
 
-    def filter_shadow_points(self, depth, delta_x=2, delta_y=2, fill_value=-1.0):
-        """pyslam.utilities.depth.filter_shadow_points(depth, delta_depth=None, ...) on the GPU."""
+    def filter_shadow_points(self, depth, delta_x=2, delta_y=2, fill_value=-1.0, stream=None):
+        """pyslam.utilities.depth.filter_shadow_points(depth, delta_depth=None, ...) on the GPU.
+        stream: a torch.cuda.Stream - the launches of a CUDA tensor's filter go to THAT stream (which must be torch's current one:
+        the result is allocated on it) instead of the volume's; the filter reads nothing of the volume, so it may run beside the
+        volume's kernels (device_pipeline.KeyframeUploader: the next keyframe's depth is filtered while this one is fused)."""
+        if stream is not None:
+            import torch
+
+            d = depth.contiguous().float()
+            out = torch.empty_like(d)
+            L.check(self._lib.hv_filter_shadow_points_on_stream(self._h, L.ptr(d), int(d.shape[0]), int(d.shape[1]), int(delta_x),
+                                                                int(delta_y), float(fill_value), L.ptr(out), int(stream.cuda_stream)))
+            return out
         if hasattr(depth, "data_ptr"):
             import torch
 

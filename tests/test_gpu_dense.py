@@ -41,6 +41,67 @@ def test_shadow_filter_bit_exact(config):
     np.testing.assert_array_equal(g.filter_shadow_points(flat), hp.filter_shadow_points(flat))
 
 
+def test_shadow_filter_on_a_side_stream_equals_the_reference():
+    """hv_filter_shadow_points_on_stream: the filter queued on a caller's stream with scratch of its own (the upload side of the
+    keyframe pipeline) - five images in flight on two side streams while the volume integrates on its own, each bit-identical to the
+    reference's depth.py."""
+    import torch
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import VoxelBlockGrid
+
+    s = SyntheticRGBD("synthetic_640x480_5mm")
+    g = VoxelBlockGrid(0.02, 8, max_blocks=1 << 14, max_points=1 << 20)
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
+    depths = [s[i][0] for i in (0, 5, 9, 13, 21)]
+    outs = []
+    for k, depth in enumerate(depths):
+        st = side[k % 2]
+        with torch.cuda.stream(st):
+            d = torch.from_numpy(depth).cuda()
+            outs.append((st, g.filter_shadow_points(d, stream=st)))
+        depth0, rgb0, T0 = s[k]
+        g.integrate_rgbd(depth0, rgb0, *s.intrinsics, T0, max_depth=4.0)  # the volume's own stream is busy meanwhile
+    for (st, out), depth in zip(outs, depths):
+        st.synchronize()
+        np.testing.assert_array_equal(out.cpu().numpy(), hp.filter_shadow_points(depth))
+
+
+def test_semantic_backlog_with_upload_side_filter_equals_keyframe_by_keyframe():
+    """integrate_keyframes_on_device with a backlog (keyframe k + 1 uploaded and shadow-filtered on side streams while keyframe k
+    is fused) leaves the volume of the same keyframes handed over one at a time."""
+    from pyslam_amd.dense.volumetric_integrator_types import DatasetEnvironmentType, SensorType
+    from pyslam_amd.dense.volumetric_integrator_voxel_semantic_grid import VolumetricIntegratorVoxelSemanticGrid
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric_semantic import set_next_object_id
+    from tests.semantic_helpers import CFG, semantic_frame
+    from tests.test_semantic_oracle import srt
+
+    _params(0.02, 0.08)
+    s = SyntheticRGBD(CFG, noise=True)
+    cam = dh.FakeCamera(s)
+    frames = [semantic_frame(s, i) for i in (0, 4, 8, 12, 16)]
+    dumps = []
+    for backlog in (True, False):
+        integ = VolumetricIntegratorVoxelSemanticGrid.__new__(VolumetricIntegratorVoxelSemanticGrid)
+        integ.init(cam, DatasetEnvironmentType.INDOOR, SensorType.RGBD, {}, dict(use_semantic_probabilistic=True))
+        set_next_object_id(1)
+        kfs = [(rgb, depth, T, cls_img, inst_img) for depth, rgb, T, cls_img, inst_img in frames]
+        if backlog:
+            integ.integrate_keyframes_on_device(kfs)
+        else:
+            for kf in kfs:
+                integ.integrate_keyframes_on_device([kf])
+        v = integ.volume.get_voxels(1, 0.0)
+        dumps.append(srt((v.points, v.colors, v.class_ids, v.object_ids, v.confidences)))
+    assert len(dumps[0][0]) > 1000
+    for k, (a, b) in enumerate(zip(*dumps)):
+        if k == 3:  # new object ids may be permuted between instances created in the same call: compare as a partition
+            pairs = set(zip(a.tolist(), b.tolist()))
+            assert len({p[0] for p in pairs}) == len(pairs) == len({p[1] for p in pairs})
+        else:
+            np.testing.assert_array_equal(a, b)
+
+
 def test_shadow_filter_median_select_edge_cases():
     """The exact median comes from a three-pass radix select on the deltas' bit patterns: images built so that the two
     middle ranks sit in one histogram bin, in neighbouring bins, in bins that differ in the top digit, with even and odd

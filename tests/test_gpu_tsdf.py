@@ -159,6 +159,78 @@ def test_mesh_is_watertight_inside_view():
     assert (m.vertex_colors >= 0).all() and (m.vertex_colors <= 1).all()
 
 
+def test_incremental_extraction_equals_a_full_pass_at_every_tick(monkeypatch):
+    """The per-unit extraction caches (hv_common.h: masks, marching-cubes classification, point counts kept between extractions and
+    recomputed only around the units the new frames wrote to) against a full pass over the same volume at every tick of a running
+    reconstruction: single keyframes, batches, mesh-only and points-only ticks, a pool that grows under the caches, numerators
+    imported behind the stamps' back, a reset - and against the oracle at the end."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
+
+    monkeypatch.setenv("HV_TSDF_SWEEP", "2")  # (bitwise form: the oracle comparison at the end is vertex for vertex)
+    s, frames = synthetic_frames("tiny_160x120_2cm", 0, 24)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    inc = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 9)  # (small: the pool is rebuilt on the way)
+    cpu = oracle.PortTsdf(0.02, 0.08)
+
+    def fuse(vol, lo, hi, batch):
+        from pyslam_amd.volumetric import RGBDImage
+
+        if batch:
+            d, c, T = (np.stack([f[k] for f in frames[lo:hi]]) for k in range(3))
+            vol.integrate_batch(d, c, K, T, depth_scale=1.0, depth_trunc=4.0)
+        else:
+            for d, c, T in frames[lo:hi]:
+                vol.integrate(RGBDImage(c, d, 1.0, 4.0), K, T)
+
+    def full_pass(history):
+        """a fresh volume with the same history, extracted once (its first extraction: every unit computed)"""
+        ref = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 13)
+        for step in history:
+            step(ref)
+        return ref
+
+    def same(a, b, mesh=True, points=True):
+        if mesh:
+            ma, mb = a.extract_triangle_mesh(), b.extract_triangle_mesh()
+            assert ma.vertices.shape == mb.vertices.shape and ma.triangles.shape == mb.triangles.shape and len(ma.triangles) > 0
+            for x, y in zip(canonical_mesh(ma.vertices, ma.triangles, ma.vertex_colors), canonical_mesh(mb.vertices, mb.triangles, mb.vertex_colors)):
+                np.testing.assert_array_equal(x, y)
+        if points:
+            pa, pb = a.extract_point_cloud(), b.extract_point_cloud()
+            assert pa.points.shape == pb.points.shape and len(pa.points) > 0
+            for x, y in zip(sort_rows(pa.points, pa.colors), sort_rows(pb.points, pb.colors)):
+                np.testing.assert_array_equal(x, y)
+
+    history = []
+    ticks = [(0, 4, True, True, True), (4, 5, False, True, True), (5, 6, False, False, True), (6, 8, False, True, False),
+             (8, 16, True, True, True), (16, 17, False, True, True), (17, 24, True, True, True)]
+    for lo, hi, batch, mesh, points in ticks:
+        step = (lambda vol, lo=lo, hi=hi, batch=batch: fuse(vol, lo, hi, batch))
+        step(inc)
+        history.append(step)
+        same(inc, full_pass(history), mesh, points)
+    for d, c, T in frames:
+        cpu.integrate(d, c, K.as_array(), T, 1.0, 4.0)
+    m = inc.extract_triangle_mesh()
+    vb, tb, cb = cpu.extract_triangle_mesh()
+    va, ca, ta = canonical_mesh(m.vertices, m.triangles, m.vertex_colors)
+    vb, cb, tb = canonical_mesh(vb, tb, cb)
+    np.testing.assert_allclose(va, vb, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(ta, tb, rtol=0, atol=1e-9)
+    # numerators imported behind the stamps' back (the multi-GPU gather writes voxels without touching a unit's stamp) ...
+    keys = inc.unit_keys()
+    payload = inc.export_numerators(keys)
+    payload[:, :, 0] *= 0.5  # halves every tsdf: the surface moves in every unit
+    inc.import_numerators(keys, payload)
+    other = full_pass(history)
+    other.import_numerators(keys, payload)
+    same(inc, other)
+    # ... and a reset followed by a different stream
+    inc.reset()
+    fuse(inc, 10, 14, True)
+    same(inc, full_pass([lambda vol: fuse(vol, 10, 14, True)]))
+
+
 def test_numerators_roundtrip_and_merge():
     """export -> import reproduces the volume; summing two disjoint-frame volumes' numerators equals
     fusing all frames in one volume (the multi-GPU merge identity)."""

@@ -25,7 +25,7 @@ done
 # semantic flow: kernel table at 1 cm / 640x480 and at the ScanNet shape (1296x968, 2 mm)
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/sem_kt -o sem -- python $R/tools/bench_semantic.py --frames 10 --cpu-frames 0 > $R/gpurun_out/bench_semantic_profiled.json 2>/dev/null
 find $R/gpurun_out/sem_kt -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/sem_kernel_stats.csv \;
-timeout 250 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/sem2_kt -o sem -- python $R/tools/bench_semantic.py --frames 5 --cpu-frames 0 --voxel 0.002 --config scannet_1296x968_2mm --stride 2 > $R/gpurun_out/bench_semantic_scannet_profiled.json 2>/dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/sem2_kt -o sem -- python $R/tools/bench_semantic.py --frames 12 --cpu-frames 0 --voxel 0.002 --config scannet_1296x968_2mm --stride 2 > $R/gpurun_out/bench_semantic_scannet_profiled.json 2>/dev/null
 find $R/gpurun_out/sem2_kt -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/sem_scannet_kernel_stats.csv \;
 cut -c1-120 $R/gpurun_out/sem_scannet_kernel_stats.csv | head -8
 python $R/tools/memset_split.py $R/gpurun_out/sem_kt > $R/gpurun_out/memset_split_semantic.json 2>/dev/null
@@ -33,13 +33,13 @@ python $R/tools/memset_split.py $R/gpurun_out/sem2_kt > $R/gpurun_out/memset_spl
 # semantic flow: HBM traffic per kernel (two --pmc passes each, counters only)
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/sem_pmc_$C -o pmc -- python $R/tools/bench_semantic.py --frames 10 --cpu-frames 0 > /dev/null 2>&1
-  timeout 250 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/sem2_pmc_$C -o pmc -- python $R/tools/bench_semantic.py --frames 5 --cpu-frames 0 --voxel 0.002 --config scannet_1296x968_2mm --stride 2 > /dev/null 2>&1
+  timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/sem2_pmc_$C -o pmc -- python $R/tools/bench_semantic.py --frames 12 --cpu-frames 0 --voxel 0.002 --config scannet_1296x968_2mm --stride 2 > /dev/null 2>&1
 done
 popd > /dev/null
 python tools/pmc_summary.py --json gpurun_out/pmc_voxel_grid.json --command-key "tools/bench_voxel_grid.py --steps 3" gpurun_out/vg_pmc_FETCH_SIZE gpurun_out/vg_pmc_WRITE_SIZE > gpurun_out/vg_pmc_summary.txt 2>&1; grep -E "vgb|vg_" gpurun_out/vg_pmc_summary.txt | cut -c1-200
 cp gpurun_out/pmc_voxel_grid.json profiles/$ROUND/pmc_voxel_grid.json
 python tools/pmc_summary.py --json gpurun_out/pmc_semantic.json --command-key "tools/bench_semantic.py --frames 10 --cpu-frames 0" gpurun_out/sem_pmc_FETCH_SIZE gpurun_out/sem_pmc_WRITE_SIZE > gpurun_out/sem_pmc_summary.txt 2>&1
-python tools/pmc_summary.py --json gpurun_out/pmc_semantic_scannet_2mm.json --command-key "tools/bench_semantic.py --frames 5 --cpu-frames 0 --voxel 0.002 --config scannet_1296x968_2mm --stride 2" gpurun_out/sem2_pmc_FETCH_SIZE gpurun_out/sem2_pmc_WRITE_SIZE > gpurun_out/sem2_pmc_summary.txt 2>&1
+python tools/pmc_summary.py --json gpurun_out/pmc_semantic_scannet_2mm.json --command-key "tools/bench_semantic.py --frames 12 --cpu-frames 0 --voxel 0.002 --config scannet_1296x968_2mm --stride 2" gpurun_out/sem2_pmc_FETCH_SIZE gpurun_out/sem2_pmc_WRITE_SIZE > gpurun_out/sem2_pmc_summary.txt 2>&1
 cp gpurun_out/pmc_semantic.json gpurun_out/pmc_semantic_scannet_2mm.json profiles/$ROUND/
 grep -E "sem|shadow" gpurun_out/sem2_pmc_summary.txt | cut -c1-200 | head -8
 timeout 200 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log

@@ -97,16 +97,19 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
         v_touched.append(len(np.unique(oracle.keys(p, args.voxel, 8, which="port")[0], axis=0)))
     b_in = s.width * s.height * 15
     host_flow = os.environ.get("PYSLAM_AMD_SEMANTIC_DEVICE_FLOW", "1") == "0"  # A/B: every call stages its own host inputs (round 2)
-    out["flow"] = "host images staged by every call" if host_flow else "one upload per image, steps on device tensors (the integrator's flow)"
+    out["flow"] = "host images staged by every call" if host_flow else ("one upload per image, steps on device tensors, the next keyframe's shadow filter beside this keyframe's kernels "
+                                                                           "(the integrator's flow)")
     out["host_images"] = "page-locked (as in the front's registered ring), asynchronous uploads" if out_pinned else "pageable"
     for name, cls, kind in (("voting", VoxelBlockSemanticGrid, 0), ("probabilistic", VoxelBlockSemanticProbabilisticGrid, 1)):
         g = cls(args.voxel, 8, max_blocks=1 << (19 if args.voxel < 0.004 else 17), max_points=max(1 << 20, s.width * s.height))  # (a pool that does not have to grow inside the timed keyframes)
         fr = CameraFrustrum(*intr, s.width, s.height, np.eye(4), depth_max=8.0, depth_min=0.01)
         set_next_object_id(1)
 
+        prep_side = not host_flow and os.environ.get("PYSLAM_AMD_SEMANTIC_PREP", "1") != "0"  # A/B: 0 = the filter in front of every keyframe's own kernels (rounds 4-5)
+
         def fuse(frame, t):
             depth, rgb, T, cls_img, inst_img = frame
-            d = g.filter_shadow_points(t["depth"] if t is not None else depth)
+            d = t["depth"] if prep_side else g.filter_shadow_points(t["depth"] if t is not None else depth)
             c, cl, ins = (t["color"], t["cls"], t["inst"]) if t is not None else (rgb, cls_img, inst_img)
             fr.set_T_cw(T)
             m = g.assign_object_ids_to_instance_ids(fr, cl, ins, d, depth_threshold=0.03, do_carving=False, min_vote_ratio=0.5, min_votes=3)
@@ -123,8 +126,11 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
                 for f in frames_:
                     fuse(f, None)
                 return
+            def prep(t, stream):  # the shadow filter on the upload side (integrate_keyframes_on_device does the same)
+                t["depth"] = g.filter_shadow_points(t["depth"], stream=stream)
+
             uploader.run(frames_, lambda f: {"depth": (f[0], np.float32), "color": (f[1], np.uint8), "cls": (f[3], np.int32),
-                                             "inst": (f[4], np.int32)}, fuse)
+                                             "inst": (f[4], np.int32)}, fuse, prep if prep_side else None)
 
         run(frames[:2])
         g.synchronize()
