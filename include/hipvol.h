@@ -255,6 +255,18 @@ int hv_assoc_pairs_import(hv_volume *v, const int64_t *d_msgs, int32_t world, in
 int hv_assoc_decide(hv_volume *v, float min_vote_ratio, int32_t min_votes);
 int hv_assoc_map_fetch(hv_volume *v, int32_t *map_inst, int32_t *map_obj, int64_t cap, int64_t *n_map);
 int hv_remap_instance_ids_last(hv_volume *v, const int32_t *instance_ids, int32_t height, int32_t width, int32_t *out, int32_t loc);
+/* One semantic keyframe in one call, on DEVICE images, queued on the volume's stream (nothing waits): the per-keyframe body of
+ * VolumetricIntegratorVoxelSemanticGrid (pyslam/dense/volumetric_integrator_voxel_semantic_grid.py:326-461) - filter_shadow_points
+ * (:334, when filter_shadow_points != 0) -> assign_object_ids_to_instance_ids + remap_instance_ids (:340-372, when use_instance_ids
+ * != 0 and instance_ids_image != NULL; a NULL class image gives the reference's empty map: every object id -1) or carve (:373-380,
+ * when do_carving != 0) -> depth2pointcloud + world transform + integrate (:402-461).  The stages are the entry points above, in that
+ * order; the filtered depth and the object-id image live in scratch of the volume.  frustum_*: the CameraFrustrum of the
+ * association / carve (float32 intrinsics, camera_frustrum.h:37-130); intr: the float64 intrinsics of depth2pointcloud. */
+int hv_semantic_fuse_keyframe(hv_volume *v, const float *depth, const uint8_t *rgb, const int32_t *class_ids_image,
+                              const int32_t *instance_ids_image, int32_t height, int32_t width, const float *frustum_intr_f32,
+                              float frustum_depth_max, float frustum_depth_min, const double *intr, const double *T_cw,
+                              int32_t filter_shadow_points, int32_t use_instance_ids, float assoc_depth_threshold, int32_t do_carving,
+                              float min_vote_ratio, int32_t min_votes, double min_depth, double max_depth, int32_t use_depths);
 int32_t hv_peek_next_object_id(void); /* VoxelSemanticSharedData::next_object_id, voxel_semantic_shared_data.h:26-34 */
 void hv_set_next_object_id(int32_t id);
 /* remap_instance_ids(instance_ids i32 HxW, map) (image_utils.h:69-163): ids absent from the map (or an empty map)

@@ -91,6 +91,8 @@ SIGNATURES = {
     "hv_assoc_decide": (_i32, [_vp, _f32, _i32]),
     "hv_assoc_map_fetch": (_i32, [_vp, _vp, _vp, _i64, _pi64]),
     "hv_remap_instance_ids_last": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32]),
+    "hv_semantic_fuse_keyframe": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _f32, _f32, _vp, _vp, _i32, _i32, _f32, _i32, _f32, _i32,
+                                         _f64, _f64, _i32]),
     "hv_peek_next_object_id": (_i32, []),
     "hv_set_next_object_id": (None, [_i32]),
     "hv_remap_instance_ids": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _i32]),

@@ -450,6 +450,9 @@ struct hv_volume {
     // histograms + state of hv_filter_shadow_points_on_stream (a caller's stream, beside the volume's: scratch of its own, four sets in turn)
     void *shadow_ring = nullptr;
     int shadow_ring_next = 0;
+    // hv_semantic_fuse_keyframe: the keyframe's filtered depth and object-id image ([npx f32][npx i32])
+    void *kf_buf = nullptr;
+    size_t kf_buf_bytes = 0;
 
     // profiling
     bool profiling = false;

@@ -1378,6 +1378,51 @@ int hv_remap_instance_ids_last(hv_volume *v, const int32_t *instance_ids, int32_
     return HV_OK;
 }
 
+// One semantic keyframe in ONE host call (round 6): the stages above in the integrator's order, on device-resident images.  At
+// 640x480 / 1 cm the device needs ~150 us for a keyframe and the Python front spent ~200 us issuing its five calls (tensor wrappers,
+// stream bookkeeping, argument marshalling) - the flow was bound by the host.
+int hv_semantic_fuse_keyframe(hv_volume *v, const float *depth, const uint8_t *rgb, const int32_t *class_ids_image,
+                              const int32_t *instance_ids_image, int32_t height, int32_t width, const float *frustum_intr_f32,
+                              float frustum_depth_max, float frustum_depth_min, const double *intr, const double *T_cw,
+                              int32_t filter_shadow_points, int32_t use_instance_ids, float assoc_depth_threshold, int32_t do_carving,
+                              float min_vote_ratio, int32_t min_votes, double min_depth, double max_depth, int32_t use_depths) {
+    HV_REQUIRE(v != nullptr && depth != nullptr && rgb != nullptr && intr != nullptr && T_cw != nullptr && frustum_intr_f32 != nullptr,
+               HV_ERR_INVALID, "hv_semantic_fuse_keyframe: null argument");
+    HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_semantic_fuse_keyframe: not a semantic volume");
+    HV_REQUIRE(height > 0 && width > 0, HV_ERR_INVALID, "hv_semantic_fuse_keyframe: bad image size");
+    HV_HIP(hipSetDevice(v->device));
+    const size_t npx = (size_t)height * width;
+    int rc = hv_ensure_buffer(v, &v->kf_buf, &v->kf_buf_bytes, npx * (sizeof(float) + sizeof(int32_t)));
+    if (rc != HV_OK) return rc;
+    float *d_filtered = (float *)v->kf_buf;
+    int32_t *d_obj = (int32_t *)(d_filtered + npx);
+    const float *d_depth = depth;
+    if (filter_shadow_points) { // kVolumetricIntegrationVoxelGridShadowPointsFilter, volumetric_integrator_voxel_semantic_grid.py:334
+        rc = hv_filter_shadow_points(v, depth, height, width, 2, 2, -1.0f, d_filtered, HV_DEVICE);
+        if (rc != HV_OK) return rc;
+        d_depth = d_filtered;
+    }
+    const int32_t *d_obj_in = nullptr;
+    if (use_instance_ids && instance_ids_image != nullptr) { // :340-372 (no class image: empty map, every id -> -1)
+        if (class_ids_image != nullptr) {
+            rc = hv_assoc_vote(v, frustum_intr_f32, width, height, T_cw, frustum_depth_max, frustum_depth_min, class_ids_image, instance_ids_image,
+                               d_depth, assoc_depth_threshold, do_carving, HV_DEVICE);
+            if (rc != HV_OK) return rc;
+            rc = hv_assoc_decide(v, min_vote_ratio, min_votes);
+            if (rc != HV_OK) return rc;
+            rc = hv_remap_instance_ids_last(v, instance_ids_image, height, width, d_obj, HV_DEVICE);
+            if (rc != HV_OK) return rc;
+        } else {
+            HV_HIP(hipMemsetAsync(d_obj, 0xFF, sizeof(int32_t) * npx, v->stream));
+        }
+        d_obj_in = d_obj;
+    } else if (do_carving) { // :373-380
+        rc = hv_carve(v, frustum_intr_f32, width, height, T_cw, frustum_depth_max, frustum_depth_min, d_depth, assoc_depth_threshold, HV_DEVICE);
+        if (rc != HV_OK) return rc;
+    }
+    return hv_integrate_rgbd_semantic(v, d_depth, rgb, class_ids_image, d_obj_in, height, width, intr, T_cw, min_depth, max_depth, use_depths, HV_DEVICE);
+}
+
 // The reference's one call = vote + decide + fetch.
 int hv_assign_object_ids_to_instance_ids(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw,
                                          float depth_max, float depth_min, const int32_t *class_ids_image,

@@ -229,6 +229,20 @@ class VolumetricIntegratorVoxelSemanticGrid(VolumetricIntegratorBase):
 
     def _fuse_device_keyframe(self, color_d, depth_d, pose, cls_d, inst_d, depth_filtered=False):
         """The INTEGRATE body on device-resident images (torch CUDA tensors on the volume's stream): nothing waits for the GPU."""
+        vol = self.volume
+        if hasattr(vol, "fuse_keyframe") and getattr(vol, "_pair_exchange", None) is None and getattr(vol, "_pair_exchange_device", None) is None:
+            # one call into the library for the whole body (hv_semantic_fuse_keyframe: the same stages in the same order)
+            fx, fy, cx, cy = self.get_camera_intrinsics_for_depth()
+            vol.fuse_keyframe(self.camera_frustrum, depth_d, color_d, cls_d, inst_d, fx, fy, cx, cy, pose,
+                              filter_shadow_points=bool(Parameters.kVolumetricIntegrationVoxelGridShadowPointsFilter),
+                              use_instance_ids=inst_d is not None,
+                              depth_threshold=Parameters.kVolumetricIntegrationVoxelGridCarvingDepthThreshold,
+                              do_carving=Parameters.kVolumetricIntegrationVoxelGridUseCarving,
+                              min_vote_ratio=Parameters.kVolumetricSemanticIntegrationMinVoteRatio,
+                              min_votes=Parameters.kVolumetricSemanticIntegrationMinVotes,
+                              max_depth=self.volumetric_integration_depth_trunc,
+                              use_depths=Parameters.kVolumetricSemanticProbabilisticIntegrationUseDepth, depth_is_filtered=depth_filtered)
+            return
         if Parameters.kVolumetricIntegrationVoxelGridShadowPointsFilter and not depth_filtered:
             depth_d = self.volume.filter_shadow_points(depth_d)  # stays in HBM
         self.camera_frustrum.set_T_cw(pose)

@@ -405,6 +405,44 @@ class _SemanticGridBase(_Volume):
         if loc == L.HV_DEVICE:
             self._torch_out(ts, depth.device)
 
+    def fuse_keyframe(self, camera_frustrum, depth, rgb, class_ids_image, instance_ids_image, fx, fy, cx, cy, T_cw, filter_shadow_points=True,
+                      use_instance_ids=True, depth_threshold=0.1, do_carving=False, min_vote_ratio=0.5, min_votes=3, max_depth=np.inf,
+                      min_depth=0.0, use_depths=True, depth_is_filtered=False):
+        """One keyframe of the integrator's flow - filter_shadow_points -> assign_object_ids_to_instance_ids -> remap_instance_ids (or
+        carve) -> integrate_rgbd - in ONE call into the library (hv_semantic_fuse_keyframe) on device-resident images (torch CUDA
+        tensors: depth f32, rgb u8, labels i32 or None); queued on the volume's stream, nothing waits.  The same kernels in the same
+        order as the separate calls; what goes away is the host time of five calls.  Multi-GPU grids (a pair exchange between vote and
+        decide) keep the staged calls."""
+        import torch
+
+        if self._pair_exchange is not None or self._pair_exchange_device is not None:
+            raise RuntimeError("fuse_keyframe: a sharded grid exchanges its pair lists between vote and decide - use the staged calls")
+        (depth, rgb, cls, inst), _ = _device_images(depth, rgb, class_ids_image, instance_ids_image, device=self._cfg.device)
+        if depth.dtype != torch.float32 or rgb.dtype != torch.uint8 or any(a is not None and a.dtype != torch.int32 for a in (cls, inst)):
+            raise RuntimeError("device images must be float32 depth, uint8 colour, int32 labels")
+        H, W = int(depth.shape[0]), int(depth.shape[1])
+        f = camera_frustrum
+        if tuple(rgb.shape[:2]) != (H, W) or any(a is not None and tuple(a.shape) != (H, W) for a in (cls, inst)) or (f.height, f.width) != (H, W):
+            raise RuntimeError("fuse_keyframe: image sizes differ")
+        use_inst = bool(use_instance_ids) and inst is not None
+        if use_inst and cls is not None:
+            prev = getattr(self, "_last_map_ref", None)
+            prev = prev() if prev is not None else None
+            if prev is not None and prev._d is None:
+                prev._get()  # somebody still holds the previous association's map and has not read it: fetch it before it is replaced
+        ts = self._torch_in(depth, rgb, cls, inst)
+        intr = np.array([fx, fy, cx, cy], np.float64)
+        T = np.ascontiguousarray(T_cw, dtype=np.float64)
+        f.set_T_cw(T)
+        big = float(np.finfo(np.float32).max)
+        L.check(self._lib.hv_semantic_fuse_keyframe(
+            self._h, L.ptr(depth), L.ptr(rgb), L.ptr(cls), L.ptr(inst), H, W, L.ptr(f.intr), f.depth_max, f.depth_min, L.ptr(intr), L.ptr(T),
+            int(bool(filter_shadow_points) and not depth_is_filtered), int(use_inst), float(depth_threshold), int(bool(do_carving)),
+            float(min_vote_ratio), int(min_votes), float(min_depth), float(min(max_depth, big)), int(bool(use_depths))))
+        if use_inst and cls is not None:
+            self._assoc_serial = getattr(self, "_assoc_serial", 0) + 1  # (a LazyIdMap of an earlier association is stale now)
+        self._torch_out(ts, depth.device)
+
     def get_voxels(self, min_count=1, min_confidence=0.0):
         n = ctypes.c_int64()
         L.check(self._lib.hv_get_voxels_semantic(self._h, int(min_count), float(min_confidence), None, None, None, None, None, 0,

@@ -479,6 +479,59 @@ def test_device_resident_keyframe_flow_equals_host_flow(kind):
 
 
 @pytest.mark.parametrize("kind", [VOTE, PROB])
+def test_fuse_keyframe_is_the_staged_calls_in_one(kind):
+    """hv_semantic_fuse_keyframe (one call into the library per keyframe: what the integrator's device flow and the bench issue) against
+    the staged calls it is made of - filter_shadow_points -> assign_object_ids_to_instance_ids -> remap_instance_ids -> integrate_rgbd -
+    on the same keyframes, carving on in two of them, one keyframe without instance ids (the carve branch):
+    the same voxel records (object ids up to the permutation of ids created in the same call)."""
+    import torch
+
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import CameraFrustrum
+    from pyslam_amd.volumetric_semantic import remap_instance_ids, set_next_object_id
+    from tests.semantic_flow import canonical_ids
+
+    s = SyntheticRGBD(CFG, noise=True, invalid_frac=0.02)
+    dumps = []
+    for fused in (False, True):
+        g = gpu_grid(kind, CFG["voxel"])
+        g.set_depth_threshold(2.0)
+        g.set_depth_decay_rate(0.07)
+        fr = CameraFrustrum(*s.intrinsics, s.width, s.height, np.eye(4), depth_max=DEPTH_MAX, depth_min=DEPTH_MIN)
+        set_next_object_id(1)
+        for k, i in enumerate((0, 6, 12, 18, 24)):
+            depth, rgb, T, cls_img, inst_img = semantic_frame(s, i, shuffle=k)
+            depth, rgb, cls_img, inst_img = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (depth, rgb, cls_img, inst_img))
+            carving = k == 2 or k == 3
+            use_inst = k != 3  # keyframe 3: no instance ids -> the carve branch
+            if fused:
+                g.fuse_keyframe(fr, depth, rgb, cls_img, inst_img if use_inst else None, *s.intrinsics, T, filter_shadow_points=True,
+                                use_instance_ids=use_inst, depth_threshold=0.05, do_carving=carving, min_vote_ratio=0.5, min_votes=3,
+                                max_depth=4.0, use_depths=True)
+            else:
+                d = g.filter_shadow_points(depth)
+                fr.set_T_cw(T)
+                obj = None
+                if use_inst:
+                    m = g.assign_object_ids_to_instance_ids(fr, cls_img, inst_img, d, depth_threshold=0.05, do_carving=carving, min_vote_ratio=0.5,
+                                                            min_votes=3)
+                    obj = remap_instance_ids(inst_img, m, volume=g)
+                elif carving:
+                    g.carve(fr, d, 0.05)
+                g.integrate_rgbd(d, rgb, *s.intrinsics, T, class_ids_image=cls_img, object_ids_image=obj, max_depth=4.0, use_depths=True)
+            torch.cuda.synchronize()
+        dumps.append(g.dump2()[:5])
+    (ka, inta, posa, cola, confa), (kb, intb, posb, colb, confb) = dumps
+    assert len(ka) > 100
+    np.testing.assert_array_equal(ka, kb)
+    np.testing.assert_array_equal(inta[..., (0, 2, 3)], intb[..., (0, 2, 3)])
+    np.testing.assert_array_equal(canonical_ids(inta[..., 1]), canonical_ids(intb[..., 1]))
+    np.testing.assert_array_equal(posa, posb)
+    np.testing.assert_array_equal(cola, colb)
+    np.testing.assert_array_equal(confa, confb)
+
+
+@pytest.mark.parametrize("kind", [VOTE, PROB])
 @pytest.mark.parametrize("world", [2, 3])
 def test_block_ownership_sharding_with_exchanged_votes_equals_the_single_grid(kind, world):
     """Semantic grids on `world` GPUs (here: `world` grids in one process play the ranks): hv_set_owner splits the blocks, every rank

@@ -107,8 +107,15 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
 
         prep_side = not host_flow and os.environ.get("PYSLAM_AMD_SEMANTIC_PREP", "1") != "0"  # A/B: 0 = the filter in front of every keyframe's own kernels (rounds 4-5)
 
+        one_call = not host_flow and os.environ.get("PYSLAM_AMD_SEMANTIC_ONE_CALL", "1") != "0"  # A/B: 0 = the staged calls (rounds 4-5)
+
         def fuse(frame, t):
             depth, rgb, T, cls_img, inst_img = frame
+            if one_call:  # what _fuse_device_keyframe does: the whole body in one call into the library
+                g.fuse_keyframe(fr, t["depth"], t["color"], t["cls"], t["inst"], *intr, T, filter_shadow_points=True, use_instance_ids=True,
+                                depth_threshold=0.03, do_carving=False, min_vote_ratio=0.5, min_votes=3, max_depth=4.0, use_depths=True,
+                                depth_is_filtered=prep_side)
+                return
             d = t["depth"] if prep_side else g.filter_shadow_points(t["depth"] if t is not None else depth)
             c, cl, ins = (t["color"], t["cls"], t["inst"]) if t is not None else (rgb, cls_img, inst_img)
             fr.set_T_cw(T)
