@@ -142,8 +142,9 @@ def pmc_kernel(pmc, name, command_key):
     different command."""
     if not pmc or pmc.get("stale") or pmc.get("command_key") != command_key:
         return None
+    base, _, suffix = name.partition("@")  # "<kernel>@full": the second entry tools/pmc_summary.py --also writes for a kernel
     for k, v in pmc.get("kernels", {}).items():
-        if name in k:
+        if base in k and k.endswith("@" + suffix) == bool(suffix) and ("@" in k) == bool(suffix):
             return v
     return None
 
@@ -736,6 +737,20 @@ def main():
             torch.cuda.synchronize()
             t_mesh_dev = time.perf_counter() - t1
             assert mesh.vertices.is_cuda and len(mesh.vertices) > 0
+            # ... and a FULL pass (HV_EXTRACT_INCREMENTAL=0: masks, classification and counts of every unit again - what every tick cost
+            # before round 6 and what the first extraction of a volume still costs), after one more keyframe
+            del mesh
+            vol.integrate(RGBDImage(rgb_d[3], depth_d[3], 1.0, DEPTH_TRUNC), Kcam, T_res[3])
+            fence()
+            os.environ["HV_EXTRACT_INCREMENTAL"] = "0"
+            try:
+                vol.profile_enable(True)
+                mesh = vol.extract_triangle_mesh(device=True)
+                torch.cuda.synchronize()
+                k_mesh_full = vol.profile_read()[0]
+                vol.profile_enable(False)
+            finally:
+                del os.environ["HV_EXTRACT_INCREMENTAL"]
             b_mc_in = units_allocated * 4096 * 8
             b_mesh_out = nv * 48 + nt * 12
             b_pc_out = npts * 48
@@ -744,14 +759,25 @@ def main():
                         "(host-visible results: size query = all device work, fetch = D2H into page-locked numpy arrays; *_wall_ms = a tick of a "
                         "running reconstruction, *_first_call_ms = the first tick, which also page-locks the result arrays)",
                 "units": units_allocated, "vertices": nv, "triangles": nt, "points": npts,
-                "mesh_wall_ms": round(t_mesh * 1e3, 2), "mesh_kernel_ms": round(k_mesh, 3), "mesh_fetch_only_ms": round(t_mesh_fetch * 1e3, 2),
+                "mesh_wall_ms": round(t_mesh * 1e3, 2), "mesh_kernel_ms": round(k_mesh, 3), "mesh_full_pass_kernel_ms": round(k_mesh_full, 3),
+                "mesh_kernel_what": "mesh_kernel_ms / points_kernel_ms: a TICK - one keyframe fused since the previous extraction, so column masks, "
+                                    "marching-cubes classification and point counts are recomputed only around the units that keyframe wrote to "
+                                    "(per-unit caches, DESIGN section 4), vertices / triangles / points emitted in full; "
+                                    "mesh_full_pass_kernel_ms: every unit recomputed (HV_EXTRACT_INCREMENTAL=0; rounds 2-5 paid this on every tick)",
+                "mesh_fetch_only_ms": round(t_mesh_fetch * 1e3, 2),
                 "mesh_device_resident_wall_ms": round(t_mesh_dev * 1e3, 2),
                 "mesh_first_call_ms": round(t_mesh_cold * 1e3, 2), "points_first_call_ms": round(t_pc_cold * 1e3, 2),
                 "points_wall_ms": round(t_pc * 1e3, 2), "points_kernel_ms": round(k_pc, 3),
-                "roofline": {"bound": "hbm", "kernel": "k_unit_masks + k_mc_classify + scans + k_mc_vertices + k_mc_triangles (once: the size query computes, the fetch copies)",
-                             "algorithmic_bytes": int(b_mc_in + b_mesh_out), "achieved": round((b_mc_in + b_mesh_out) / (k_mesh * 1e-3) / 1e9, 1),
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((b_mc_in + b_mesh_out) / (k_mesh * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             "traffic": None, "note": "B_mc = U_alloc x 4096 x 8 B (tsdf + weight read once) + output bytes (SURVEY 8d)"},
+                "roofline": {"bound": "hbm", "kernel": "FULL pass: k_unit_masks + k_mc_classify over every unit + scans + k_mc_vertices + k_mc_triangles",
+                             "algorithmic_bytes": int(b_mc_in + b_mesh_out), "achieved": round((b_mc_in + b_mesh_out) / (k_mesh_full * 1e-3) / 1e9, 1),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((b_mc_in + b_mesh_out) / (k_mesh_full * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "traffic": None, "kernel_ms": round(k_mesh_full, 3),
+                             "note": "B_mc = U_alloc x 4096 x 8 B (tsdf + weight read once) + output bytes (SURVEY 8d)"},
+                "tick_roofline": {"bound": "hbm", "kernel": "a tick: masks + classification of the units written since the previous extraction, scans, k_mc_vertices + k_mc_triangles in full",
+                                  "algorithmic_bytes": int(nv * 40 + b_mesh_out), "achieved": round((nv * 40 + b_mesh_out) / (k_mesh * 1e-3) / 1e9, 1),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((nv * 40 + b_mesh_out) / (k_mesh * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "traffic": None, "kernel_ms": round(k_mesh, 3),
+                                  "note": "lower bound: 2 voxels x 20 B gathered per vertex + output bytes (the planes of the few units one keyframe wrote to are not counted)"},
                 "points_roofline": {"bound": "hbm", "kernel": "k_unit_masks + k_pc_extract x2 (count pass + fill pass inside the size query)", "algorithmic_bytes": int(b_mc_in + b_pc_out),
                                     "achieved": round((b_mc_in + b_pc_out) / (k_pc * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round((b_mc_in + b_pc_out) / (k_pc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
@@ -933,7 +959,12 @@ def main():
                     tot += t
                 return int(tot)
 
-            extraction["roofline"]["traffic"] = kernels_traffic(("k_unit_masks", "k_mc_classify", "k_mc_vertices", "k_mc_triangles"))
+            extraction["roofline"]["traffic"] = kernels_traffic(("k_unit_masks@full", "k_mc_classify@full", "k_mc_vertices", "k_mc_triangles"))
+            extraction["tick_roofline"]["traffic"] = kernels_traffic(("k_unit_masks", "k_mc_classify", "k_mc_vertices", "k_mc_triangles"))
+            for key in ("roofline", "tick_roofline"):
+                r = extraction[key]
+                if r["traffic"]:
+                    r["traffic_over_algorithmic"] = round(r["traffic"] / r["algorithmic_bytes"], 2)
             extraction["points_roofline"]["traffic"] = kernels_traffic(("k_unit_masks", "k_pc_extract<false>", "k_pc_extract<true>"))
         if online is not None:
             om = {"value": round(online["fps"], 2), "unit": "frames/s",
