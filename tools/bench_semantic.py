@@ -153,17 +153,28 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
         t_seg = time.perf_counter() - t0
         rec = 64 if kind == 0 else 128
         alg = 2 * rec * float(np.mean(v_touched)) + b_in
+        # ... and what the association reads: every voxel in the last keyframe's view (count >= 1) is looked at once by
+        # assign_object_ids_to_instance_ids - in the reference as well (iterate_voxels_in_camera_frustrum); one record each
+        fr.set_T_cw(frames[-1][2])
+        n_view = int(len(g.get_voxels_in_camera_frustrum(fr, 1, 0.0).points))
         res = {"value": round(fps, 1),
                "roofline": {"bound": "hbm", "what": "the WHOLE per-keyframe flow (shadow filter, association, remap, integrate), not one kernel: "
                             f"algorithmic bytes = 2 x {rec} B x distinct voxels touched (oracle keys) + 15 B / pixel of inputs",
                             "algorithmic_bytes_per_keyframe": int(alg), "achieved": round(alg * fps / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                            "frac": round(alg * fps / 1e9 / 8000.0, 5), "traffic": None},
+                            "frac": round(alg * fps / 1e9 / 8000.0, 5), "traffic": None,
+                            "association": {"voxels_in_view_last_keyframe": n_view, "bytes": int(rec * n_view),
+                                            "algorithmic_bytes_with_association": int(alg + rec * n_view),
+                                            "what": "assign_object_ids_to_instance_ids looks at every voxel in the keyframe's view once (the reference "
+                                                    "does too): one record each, counted at the LAST keyframe of the stream (the view fills up as the "
+                                                    "map grows); not part of algorithmic_bytes_per_keyframe"}},
                "get_voxels_ms": round(t_get * 1e3, 2), "voxels_out": int(len(v.points)),
                "get_object_segments_ms": round(t_seg * 1e3, 2), "objects": len(segs.object_vector), "blocks": int(g.num_blocks()),
                "label_overflows": g.label_overflows()}
         traffic, per = flow_traffic("pmc_semantic_scannet_2mm.json" if args.voxel < 0.004 else "pmc_semantic.json", "HvSemVoxel" if kind == 0 else "HvProbVoxel")
         if traffic is not None:
             res["roofline"]["traffic"] = traffic
+            res["roofline"]["traffic_over_algorithmic"] = round(traffic / alg, 2)
+            res["roofline"]["traffic_over_algorithmic_with_association"] = round(traffic / (alg + rec * n_view), 2)
             res["roofline"]["traffic_per_kernel"] = per
             res["roofline"]["traffic_source"] = "recorded rocprofv3 --pmc passes of tools/bench_semantic.py on this build (profiles/, build digest checked)"
         if oracle.ref_available() and args.cpu_frames > 0:
