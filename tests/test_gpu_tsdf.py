@@ -169,7 +169,7 @@ def test_incremental_extraction_equals_a_full_pass_at_every_tick(monkeypatch):
     monkeypatch.setenv("HV_TSDF_SWEEP", "2")  # (bitwise form: the oracle comparison at the end is vertex for vertex)
     s, frames = synthetic_frames("tiny_160x120_2cm", 0, 24)
     K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
-    inc = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 9)  # (small: the pool is rebuilt on the way)
+    inc = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 6)  # (small: the pool is rebuilt on the way)
     cpu = oracle.PortTsdf(0.02, 0.08)
 
     def fuse(vol, lo, hi, batch):
