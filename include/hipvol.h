@@ -427,6 +427,27 @@ int hv_merge_halo_plan_held(const int32_t *dirty_keys, const int64_t *dirty_coun
 int hv_merge_halo_pack(hv_volume *v, const int32_t *shared_keys, int64_t k, float *payload, int32_t loc);
 int hv_merge_halo_unpack(hv_volume *v, const int32_t *shared_keys, int64_t k, const float *payload, const uint8_t *action,
                          int32_t loc);
+/* The same merge with the key lists and the plan staying in DEVICE memory (round 6: the transport is RCCL, which gathers device
+ * buffers; rounds 3-5 took the lists through the host twice per merge).  Keys are packed 64-bit words (the library's block key) in
+ * int64 device buffers of the caller (torch tensors):
+ *   1. hv_merge_halo_lists_device   this rank's dirty list and held list into d_dirty_keys / d_held_keys (NULL buffers: *n_held = an
+ *                                   upper bound of both lengths, to size them); the two lengths come back to the host (they size the
+ *                                   all-gather)
+ *   2. (caller) all-gather of the counts and of the padded lists -> [world][stride] device buffers
+ *   3. hv_merge_halo_plan_device    radix sort of (key, rank, held) + two small kernels: the plan of hv_merge_halo_plan_held, in
+ *                                   packed-key order, left IN THE VOLUME; *n_shared comes back to the host (it sizes the payload).
+ *                                   all_dirty_kept != 0: one rank takes every dirty unit through the path as its own keeper.
+ *   4. hv_merge_halo_pack_planned / 6. _unpack_planned   units [first, first + count) of the stored plan, device payload, queued on the
+ *                                   volume's stream (the caller orders its all-reduce against that stream)
+ *   hv_merge_halo_plan_fetch        the stored plan as host arrays (inspection, tests). */
+int hv_merge_halo_lists_device(hv_volume *v, int64_t *d_dirty_keys, int64_t dirty_cap, int64_t *d_held_keys, int64_t held_cap,
+                               int64_t *n_dirty, int64_t *n_held);
+int hv_merge_halo_plan_device(hv_volume *v, const int64_t *d_dirty_all, const int64_t *dirty_counts /* host [world] */, int64_t dirty_stride,
+                              const int64_t *d_held_all, const int64_t *held_counts /* host [world] */, int64_t held_stride,
+                              int32_t world_size, int32_t rank, int32_t all_dirty_kept, int64_t *n_shared);
+int hv_merge_halo_plan_fetch(hv_volume *v, int32_t *shared_keys, uint8_t *action, int64_t cap, int64_t *n_shared);
+int hv_merge_halo_pack_planned(hv_volume *v, int64_t first, int64_t count, float *d_payload);
+int hv_merge_halo_unpack_planned(hv_volume *v, int64_t first, int64_t count, const float *d_payload);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------
  * When enabled, the dominant kernel of each integrate call is bracketed by HIP events on the

@@ -128,6 +128,11 @@ SIGNATURES = {
     "hv_merge_halo_plan_held": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _pi64]),
     "hv_merge_halo_pack": (_i32, [_vp, _vp, _i64, _vp, _i32]),
     "hv_merge_halo_unpack": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32]),
+    "hv_merge_halo_lists_device": (_i32, [_vp, _vp, _i64, _vp, _i64, _pi64, _pi64]),
+    "hv_merge_halo_plan_device": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _pi64]),
+    "hv_merge_halo_plan_fetch": (_i32, [_vp, _vp, _vp, _i64, _pi64]),
+    "hv_merge_halo_pack_planned": (_i32, [_vp, _i64, _i64, _vp]),
+    "hv_merge_halo_unpack_planned": (_i32, [_vp, _i64, _i64, _vp]),
     "hv_profile_enable": (_i32, [_vp, _i32]),
     "hv_profile_read": (_i32, [_vp, _c.POINTER(_f64), _pi64, _pi64]),
     "hv_profile_read_launches": (_i32, [_vp, _vp, _i64, _pi64]),

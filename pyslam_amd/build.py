@@ -18,7 +18,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpyslam_hipvol.so")
-SOURCES = ["hv_core.hip", "hv_tsdf.hip", "hv_voxel_grid.hip", "hv_semantic.hip", "hv_semantic_ops.hip", "hv_extract.hip", "hv_prep.hip"]
+SOURCES = ["hv_core.hip", "hv_tsdf.hip", "hv_voxel_grid.hip", "hv_semantic.hip", "hv_semantic_ops.hip", "hv_extract.hip", "hv_prep.hip", "hv_halo.hip"]
 INCLUDE = os.path.join(ROOT, "include")
 
 

@@ -450,6 +450,10 @@ struct hv_volume {
     // histograms + state of hv_filter_shadow_points_on_stream (a caller's stream, beside the volume's: scratch of its own, four sets in turn)
     void *shadow_ring = nullptr;
     int shadow_ring_next = 0;
+    // the halo merge's plan of hv_merge_halo_plan_device (hv_halo.hip): [shared keys n*3 i32][action n u8], device memory
+    void *halo_plan = nullptr;
+    size_t halo_plan_bytes = 0;
+    int64_t halo_plan_n = 0;
     // hv_semantic_fuse_keyframe: the keyframe's filtered depth and object-id image ([npx f32][npx i32])
     void *kf_buf = nullptr;
     size_t kf_buf_bytes = 0;

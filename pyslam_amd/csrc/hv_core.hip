@@ -681,7 +681,7 @@ void hv_destroy(hv_volume *v) {
                     v->touched_stamp, v->touched_list, v->touched_mask, v->frame_px,
                     v->stage_a, v->stage_b, v->sort_keys_in, v->sort_keys_out, v->sort_vals_in,
                     v->sort_vals_out, v->sort_tmp, v->scratch_points, v->scratch_colors, v->out_a,
-                    v->out_b, v->out_c, v->rect_map_x, v->rect_map_y, v->rect_buf, v->batch_buf, v->assoc_buf, v->mult_table, v->bins.cnt, v->bins.inl, v->bins.touched, v->bins.len, v->bins.pg_keys, v->bins.pg_data, v->bin_rec, v->batch_buf2, v->unit_masks, v->occ, v->semb_tasks, v->table.prob_nodes, v->shadow_ring, v->mc_cache, v->pc_cache, v->kf_buf};
+                    v->out_b, v->out_c, v->rect_map_x, v->rect_map_y, v->rect_buf, v->batch_buf, v->assoc_buf, v->mult_table, v->bins.cnt, v->bins.inl, v->bins.touched, v->bins.len, v->bins.pg_keys, v->bins.pg_data, v->bin_rec, v->batch_buf2, v->unit_masks, v->occ, v->semb_tasks, v->table.prob_nodes, v->shadow_ring, v->mc_cache, v->pc_cache, v->kf_buf, v->halo_plan};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (v->h_counters) (void)hipHostFree(v->h_counters);

@@ -2338,4 +2338,35 @@ int hv_merge_halo_unpack(hv_volume *v, const int32_t *shared_keys, int64_t k, co
     return HV_OK;
 }
 
+// ... with the plan hv_merge_halo_plan_device left in the volume (hv_halo.hip): units [first, first + count) of it, device payload,
+// nothing staged, nothing waited for - the caller orders its collective against the volume's stream
+int hv_merge_halo_pack_planned(hv_volume *v, int64_t first, int64_t count, float *d_payload) {
+    HV_REQUIRE(v != nullptr && (count == 0 || d_payload != nullptr), HV_ERR_INVALID, "hv_merge_halo_pack_planned: null argument");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_merge_halo_pack_planned: not a TSDF volume");
+    HV_REQUIRE(first >= 0 && count >= 0 && first + count <= v->halo_plan_n, HV_ERR_INVALID, "hv_merge_halo_pack_planned: range outside the plan");
+    if (count == 0) return HV_OK;
+    HV_HIP(hipSetDevice(v->device));
+    const int64_t total = count * RRR;
+    hipLaunchKernelGGL(k_tsdf_export, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, v->table, (const char *)v->pool,
+                       (const int32_t *)v->halo_plan + 3 * first, count, d_payload);
+    HV_HIP(hipGetLastError());
+    return HV_OK;
+}
+
+int hv_merge_halo_unpack_planned(hv_volume *v, int64_t first, int64_t count, const float *d_payload) {
+    HV_REQUIRE(v != nullptr && (count == 0 || d_payload != nullptr), HV_ERR_INVALID, "hv_merge_halo_unpack_planned: null argument");
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_merge_halo_unpack_planned: not a TSDF volume");
+    HV_REQUIRE(first >= 0 && count >= 0 && first + count <= v->halo_plan_n, HV_ERR_INVALID, "hv_merge_halo_unpack_planned: range outside the plan");
+    if (count == 0) return HV_OK;
+    v->content_version += 1;
+    v->extract_epoch += 1; // (writes voxels without stamping their units)
+    HV_HIP(hipSetDevice(v->device));
+    const int64_t total = count * RRR;
+    hipLaunchKernelGGL(k_tsdf_halo_unpack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, v->table, (char *)v->pool,
+                       (const int32_t *)v->halo_plan + 3 * first, count, d_payload,
+                       (const uint8_t *)v->halo_plan + (size_t)v->halo_plan_n * 12 + first);
+    HV_HIP(hipGetLastError());
+    return HV_OK;
+}
+
 } // extern "C"

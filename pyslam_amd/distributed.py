@@ -159,6 +159,8 @@ class ShardedTSDF:
         lib = L.load()
         on_gpu = dist.get_backend(self.group) == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+        if on_gpu and hasattr(self.volume, "halo_lists_device"):
+            return self._merge_halo_device(dist, torch, dev)
         mine = np.ascontiguousarray(self.volume.dirty_keys(), dtype=np.int32).reshape(-1, 3)
         held = np.ascontiguousarray(self.volume.unit_keys(), dtype=np.int32).reshape(-1, 3)
 
@@ -197,6 +199,65 @@ class ShardedTSDF:
             del payload
         self.volume.mark_merged()
         return k, len(mine)
+
+
+    def _merge_halo_device(self, dist, torch, dev):
+        """merge_halo over RCCL with the key lists and the plan in device memory (hv_halo.hip): the lists are written into torch
+        tensors, gathered where they lie, sorted and planned by the library on the device; the shared keys never exist on the host
+        (``last_halo`` fetches them on demand).  Three integers cross to the host per merge: the two list lengths (they size the
+        gather) and the number of shared units (it sizes the payload)."""
+        vol = self.volume
+        cap = max(int(vol.num_blocks()), 1)
+        dirty = torch.empty(cap, dtype=torch.int64, device=dev)
+        held = torch.empty(cap, dtype=torch.int64, device=dev)
+        n_dirty, n_held = vol.halo_lists_device(dirty, held)
+        counts = torch.tensor([n_dirty, n_held], dtype=torch.int64, device=dev)
+        all_counts = torch.zeros((self.world_size, 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(all_counts.view(-1), counts, group=self.group)
+        all_counts = all_counts.cpu().numpy()  # (2 x world integers: the gather below is sized by them)
+        sd, sh = max(int(all_counts[:, 0].max()), 1), max(int(all_counts[:, 1].max()), 1)
+        dirty_all = torch.empty((self.world_size, sd), dtype=torch.int64, device=dev)
+        held_all = torch.empty((self.world_size, sh), dtype=torch.int64, device=dev)
+        pad_d, pad_h = torch.zeros(sd, dtype=torch.int64, device=dev), torch.zeros(sh, dtype=torch.int64, device=dev)
+        pad_d[:n_dirty].copy_(dirty[:n_dirty])
+        pad_h[:n_held].copy_(held[:n_held])
+        dist.all_gather_into_tensor(dirty_all.view(-1), pad_d, group=self.group)
+        dist.all_gather_into_tensor(held_all.view(-1), pad_h, group=self.group)
+        torch.cuda.current_stream().synchronize()  # RCCL results visible before the plan kernels (the volume's stream) read them
+        own_all = self.force_collectives and self.world_size == 1  # one rank: its dirty units through the path as their own keeper
+        k = vol.halo_plan_device(dirty_all, np.ascontiguousarray(all_counts[:, 0]), held_all, np.ascontiguousarray(all_counts[:, 1]),
+                                 self.world_size, self.rank, all_dirty_kept=own_all)
+        self.last_halo = _LazyHalo(vol, n_dirty)
+        res3 = vol.res ** 3
+        units_per_bucket = max(1, self.BUCKET_BYTES // (res3 * 5 * 4))
+        for b0 in range(0, k, units_per_bucket):
+            cnt = min(units_per_bucket, k - b0)
+            payload = torch.empty((cnt, res3, 5), dtype=torch.float32, device=dev)
+            vol.halo_pack_planned(b0, cnt, payload)
+            vol.synchronize()  # the pack (volume's stream) before the all-reduce (torch's stream)
+            dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=self.group)
+            torch.cuda.current_stream().synchronize()  # RCCL result visible before the unpack kernel reads it
+            self.last_halo["payload_bytes"] += payload.numel() * 4
+            vol.halo_unpack_planned(b0, cnt, payload)
+            vol.synchronize()  # (the payload is dropped below)
+            del payload
+        vol.mark_merged()
+        return k, n_dirty
+
+
+class _LazyHalo(dict):
+    """``last_halo`` of a device-planned merge: counters at once, the shared keys / actions fetched from the volume when asked for."""
+
+    def __init__(self, volume, n_dirty):
+        super().__init__(dirty=n_dirty, payload_bytes=0)
+        self._volume = volume
+
+    def __missing__(self, key):
+        if key in ("shared_keys", "action"):
+            keys, action = self._volume.halo_plan_fetch()
+            self["shared_keys"], self["action"] = keys, action
+            return self[key]
+        raise KeyError(key)
 
 
 class TileShardedTSDF(ShardedTSDF):

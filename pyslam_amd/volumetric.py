@@ -831,6 +831,39 @@ class ScalableTSDFVolume(_Volume):
     def mark_merged(self):
         L.check(self._lib.hv_tsdf_mark_merged(self._h))
 
+    # -- the halo merge with lists and plan in device memory (hv_halo.hip; distributed.ShardedTSDF._merge_halo_device) ------------
+    def halo_lists_device(self, dirty, held):
+        """This volume's dirty and held unit keys (packed 64-bit words) into the torch CUDA int64 tensors `dirty` / `held`
+        (each at least num_blocks() long).  -> (n_dirty, n_held)."""
+        nd, nh = ctypes.c_int64(), ctypes.c_int64()
+        L.check(self._lib.hv_merge_halo_lists_device(self._h, L.ptr(dirty), int(dirty.numel()), L.ptr(held), int(held.numel()),
+                                                     ctypes.byref(nd), ctypes.byref(nh)))
+        return nd.value, nh.value
+
+    def halo_plan_device(self, dirty_all, dirty_counts, held_all, held_counts, world_size, rank, all_dirty_kept=False):
+        """The gathered lists ([world, stride] CUDA int64 tensors; counts: host int64 [world]) -> the merge plan, left in the volume.
+        -> number of shared units."""
+        n = ctypes.c_int64()
+        dc, hc = np.ascontiguousarray(dirty_counts, dtype=np.int64), np.ascontiguousarray(held_counts, dtype=np.int64)
+        L.check(self._lib.hv_merge_halo_plan_device(self._h, L.ptr(dirty_all), L.ptr(dc), int(dirty_all.shape[1]), L.ptr(held_all), L.ptr(hc),
+                                                    int(held_all.shape[1]), int(world_size), int(rank), int(bool(all_dirty_kept)), ctypes.byref(n)))
+        return n.value
+
+    def halo_plan_fetch(self):
+        """-> (shared_keys [K,3] int32, action [K] uint8) of the stored plan (host arrays; inspection and tests)."""
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_merge_halo_plan_fetch(self._h, None, None, 0, ctypes.byref(n)))
+        keys, action = np.zeros((n.value, 3), np.int32), np.zeros(n.value, np.uint8)
+        if n.value:
+            L.check(self._lib.hv_merge_halo_plan_fetch(self._h, L.ptr(keys), L.ptr(action), n.value, ctypes.byref(n)))
+        return keys, action
+
+    def halo_pack_planned(self, first, count, payload):
+        L.check(self._lib.hv_merge_halo_pack_planned(self._h, int(first), int(count), L.ptr(payload)))
+
+    def halo_unpack_planned(self, first, count, payload):
+        L.check(self._lib.hv_merge_halo_unpack_planned(self._h, int(first), int(count), L.ptr(payload)))
+
     def halo_unpack(self, keys, payload, action):
         """hv_merge_halo_unpack: action[k] 0 = not held here, 1 = keep (state := payload), 2 = zero the unit."""
         keys = np.ascontiguousarray(keys, dtype=np.int32)

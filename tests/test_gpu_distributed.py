@@ -4,6 +4,8 @@ logic are exactly what the N-GPU RCCL run executes (only the transport differs).
 import os
 import sys
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -165,6 +167,101 @@ def _bench_case():
                             np.stack([f[2] for f in fs])))
         _BENCH.update(s=s, K=K, batches=batches, dump=cpu.dump())
     return _BENCH
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_device_halo_lists_and_plan_equal_the_host_plan_and_merge(world):
+    """The halo merge with key lists and plan in device memory (hv_halo.hip: what ShardedTSDF.merge_halo runs over RCCL) against the host
+    path (hv_tsdf_dirty_keys / hv_tsdf_unit_keys -> hv_merge_halo_plan_held -> hv_merge_halo_pack / _unpack): `world` tile-sharded
+    volumes in one process play the ranks; two merge windows (the second with units that were merged before and units only one rank
+    wrote to).  Per rank: same dirty and held key sets, same shared keys with the same action; and after pack -> sum over the ranks
+    -> unpack through the planned entry points every rank's volume equals the one the host path leaves."""
+    import torch
+
+    from pyslam_amd import _lib as L
+    from pyslam_amd.distributed import tile_bounds
+    from pyslam_amd.synthetic import SyntheticRGBD
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+
+    s = SyntheticRGBD("tiny_160x120_2cm")
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    lib = L.load()
+
+    def make():
+        vols = [ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 12) for _ in range(world)]
+        for r, v in enumerate(vols):
+            v.set_tile(*tile_bounds(r, world, s.width, s.height))
+        return vols
+
+    dev_ranks, host_ranks = make(), make()
+    for window, frame_ids in enumerate(((0, 3, 6), (9, 12))):
+        for vols in (dev_ranks, host_ranks):
+            for i in frame_ids:
+                d, c, T = s[i]
+                for v in vols:
+                    v.integrate(RGBDImage(c, d, 1.0, 4.0), K, T)
+        # ---- host path (the reference of this test)
+        mine = [np.ascontiguousarray(v.dirty_keys(), dtype=np.int32).reshape(-1, 3) for v in host_ranks]
+        held = [np.ascontiguousarray(v.unit_keys(), dtype=np.int32).reshape(-1, 3) for v in host_ranks]
+        dk, dc = np.ascontiguousarray(np.concatenate(mine)), np.array([len(x) for x in mine], np.int64)
+        hk, hc = np.ascontiguousarray(np.concatenate(held)), np.array([len(x) for x in held], np.int64)
+        host_plans = []
+        for r in range(world):
+            n = ctypes.c_int64()
+            L.check(lib.hv_merge_halo_plan_held(L.ptr(dk), L.ptr(dc), L.ptr(hk), L.ptr(hc), world, r, None, None, 0, ctypes.byref(n)))
+            shared, action = np.zeros((n.value, 3), np.int32), np.zeros(n.value, np.uint8)
+            if n.value:
+                L.check(lib.hv_merge_halo_plan_held(L.ptr(dk), L.ptr(dc), L.ptr(hk), L.ptr(hc), world, r, L.ptr(shared), L.ptr(action), n.value, ctypes.byref(n)))
+            host_plans.append((shared, action))
+        assert len(host_plans[0][0]) > 0 and any((a == 1).any() for _, a in host_plans) and any((a == 2).any() for _, a in host_plans)
+        # ---- device path: lists, "all-gather" (a concatenation here), plan
+        lists = []
+        for v in dev_ranks:
+            cap = max(v.num_blocks(), 1)
+            d_t, h_t = torch.empty(cap, dtype=torch.int64, device="cuda"), torch.empty(cap, dtype=torch.int64, device="cuda")
+            nd, nh = v.halo_lists_device(d_t, h_t)
+            lists.append((d_t[:nd].clone(), h_t[:nh].clone()))
+        for r in range(world):
+            assert len(lists[r][0]) == len(mine[r]) and len(lists[r][1]) == len(held[r])
+        sd, sh = max(max(len(a) for a, _ in lists), 1), max(max(len(b) for _, b in lists), 1)
+        dirty_all, held_all = torch.zeros((world, sd), dtype=torch.int64, device="cuda"), torch.zeros((world, sh), dtype=torch.int64, device="cuda")
+        for r, (a, b) in enumerate(lists):
+            dirty_all[r, :len(a)] = a
+            held_all[r, :len(b)] = b
+        torch.cuda.synchronize()
+        for r, v in enumerate(dev_ranks):
+            k = v.halo_plan_device(dirty_all, dc, held_all, hc, world, r)
+            keys, action = v.halo_plan_fetch()
+            assert k == len(keys) == len(host_plans[r][0])
+            got = sorted(map(tuple, np.concatenate([keys, action[:, None].astype(np.int32)], axis=1).tolist()))
+            want = sorted(map(tuple, np.concatenate([host_plans[r][0], host_plans[r][1][:, None].astype(np.int32)], axis=1).tolist()))
+            assert got == want
+        # ---- the merge itself through both paths: pack, sum over the ranks (the all-reduce), unpack
+        k = len(host_plans[0][0])
+        total = sum(v.export_numerators(host_plans[0][0]) for v in host_ranks)
+        for r, v in enumerate(host_ranks):
+            v.halo_unpack(host_plans[r][0], total, host_plans[r][1])
+            v.mark_merged()
+        payloads = []
+        for v in dev_ranks:
+            p = torch.empty((k, v.res ** 3, 5), dtype=torch.float32, device="cuda")
+            v.halo_pack_planned(0, k, p)
+            v.synchronize()
+            payloads.append(p)
+        total_d = payloads[0].clone()
+        for p in payloads[1:]:
+            total_d += p  # (the same order of additions as the host path's sum)
+        torch.cuda.synchronize()
+        for v in dev_ranks:
+            half = k // 2  # (two buckets: the range arguments)
+            v.halo_unpack_planned(0, half, total_d[:half].contiguous())
+            v.halo_unpack_planned(half, k - half, total_d[half:].contiguous())
+            v.synchronize()
+            v.mark_merged()
+        for a, b in zip(dev_ranks, host_ranks):
+            for x, y in zip(a.dump(), b.dump()):
+                np.testing.assert_array_equal(x, y)
+            assert len(a.dirty_keys()) == 0
 
 
 @pytest.mark.parametrize("world", [2, 8])
