@@ -42,3 +42,30 @@ def test_memset_split_separates_setup_fills_from_keyframe_fills(tmp_path):
     assert r["fills_outside_keyframes"] == 2 + 3  # set-up + the one after every keyframe
     assert r["fills_outside_max_us"] == 5000.0
     assert r["launches_per_keyframe_incl_fills"] == 5.0
+
+
+def test_pmc_summary_ranges_and_second_entries(tmp_path):
+    """tools/pmc_summary.py: --range keeps a kernel's launches LO .. HI-1 (bench.py's incremental extraction ticks), --also adds a second
+    entry "<kernel><suffix>" over another range (its forced full pass); bench.pmc_kernel tells the two apart."""
+    d = tmp_path / "pmc_FETCH_SIZE"
+    d.mkdir()
+    with open(d / "pmc_counter_collection.csv", "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_ALL)
+        w.writerow(["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+        values = [1000.0, 10.0, 20.0, 30.0, 1200.0]  # full (cold), three ticks, forced full
+        for i, v in enumerate(values):
+            w.writerow([i * 2 + 1, "k_unit_masks(HvTable, char const*)", "FETCH_SIZE", v])
+            w.writerow([i * 2 + 2, "k_mc_vertices(HvTable)", "FETCH_SIZE", 500.0])
+    out = tmp_path / "pmc.json"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "--json", str(out), "--command-key", "K", "--also", "k_unit_masks:4:5:@full",
+                    "--range", "k_unit_masks:1:4", str(d)], capture_output=True, text=True, check=True)
+    z = json.load(open(out))
+    assert z["kernels"]["k_unit_masks"]["FETCH_SIZE"] == 20.0 and z["kernels"]["k_unit_masks"]["launches"] == 3
+    assert z["kernels"]["k_unit_masks@full"]["FETCH_SIZE"] == 1200.0 and z["kernels"]["k_unit_masks@full"]["launches"] == 1
+    assert z["kernels"]["k_mc_vertices"]["launches"] == 5
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.pmc_kernel(z, "k_unit_masks", "K")["FETCH_SIZE"] == 20.0
+    assert bench.pmc_kernel(z, "k_unit_masks@full", "K")["FETCH_SIZE"] == 1200.0
+    assert bench.pmc_kernel(z, "k_mc_vertices@full", "K") is None
