@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, MINWG) void k_sem_assoc_vote(HvTable table, VO
                                                          const float *__restrict__ depth, HvAssocParams A,
                                                          unsigned long long *__restrict__ vkeys,
                                                          int32_t *__restrict__ vcounts, int2 *__restrict__ pending,
-                                                         const unsigned long long *__restrict__ occ) {
+                                                         const unsigned long long *__restrict__ occ, int64_t n_px) {
     __shared__ HvVoteLocal s_votes;
     // Voxels waiting for their object id are collected per wave in LDS and get their places in the pending list with ONE returning
     // atomic per ~200 of them (round 6): a 2 mm keyframe leaves a few hundred thousand such voxels behind, and one atomic per visit
@@ -429,22 +429,15 @@ __global__ __launch_bounds__(256, MINWG) void k_sem_assoc_vote(HvTable table, VO
     }
     drain_queue(true);
     flush_pending();
-    vote_local_flush(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2]);
-}
-
-// the image scan of voxel_semantic_data_association.h:316-331: every instance id with a valid class
-__global__ __launch_bounds__(256) void k_sem_assoc_image(HvTable table, const int32_t *__restrict__ cls_img,
-                                                          const int32_t *__restrict__ inst_img, int64_t n_px,
-                                                          unsigned long long *__restrict__ vkeys,
-                                                          int32_t *__restrict__ vcounts) {
-    __shared__ HvVoteLocal s_votes;
-    vote_local_init(s_votes);
+    // the image scan of voxel_semantic_data_association.h:316-331 - every instance id with a valid class - into the same workgroup table:
+    // a launch of its own until round 6 (18 us at 1296x968, 10 us at 640x480 for a pass over two images); here it fills the tail of this
+    // kernel, where most waves have run out of blocks (the table takes the markers in any order)
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n_px; base += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = base + threadIdx.x;
         uint64_t key = HV_VOTE_EMPTY;
         if (i < n_px) {
-            const int32_t inst = inst_img[i];
-            if (inst >= 0 && cls_img[i] >= 0) key = vote_key(inst, HV_OBJ_SEEN);
+            const int32_t inst_px = inst_img[i];
+            if (inst_px >= 0 && cls_img[i] >= 0) key = vote_key(inst_px, HV_OBJ_SEEN);
         }
         vote_wave_local(s_votes, vkeys, vcounts, &table.counters[HV_CNT_OUT2], key);
     }
@@ -1182,7 +1175,7 @@ int hv_assoc_vote(hv_volume *v, const float *intr_f32, int32_t width, int32_t he
     A.pending_cap = (int32_t)std::min<int64_t>(S.pending_cap, INT32_MAX);
     v->assoc_pending_cap = A.pending_cap;
     const bool prob = is_prob(v);
-    if (nb > 0) {
+    { // (always: nb >= 1, and the kernel scans the image as well)
         HvQuery Q;
         memset(&Q, 0, sizeof(Q));
         Q.kind = 2;
@@ -1200,13 +1193,11 @@ int hv_assoc_vote(hv_volume *v, const float *intr_f32, int32_t width, int32_t he
         // against four with 13 spilled registers: the vote 13 % slower, round 6); the voting payload fits four
         if (prob)
             hipLaunchKernelGGL((k_sem_assoc_vote<HvProbVoxel, 3>), grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, (int64_t)-1, G, Q, d_cls, d_inst,
-                               d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ);
+                               d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ, n_px);
         else
             hipLaunchKernelGGL((k_sem_assoc_vote<HvSemVoxel, 4>), grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, (int64_t)-1, G, Q, d_cls, d_inst,
-                               d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ);
+                               d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ, n_px);
     }
-    hipLaunchKernelGGL(k_sem_assoc_image, dim3((unsigned)std::min<int64_t>((n_px + 255) / 256, 512)), dim3(256), 0, v->stream, v->table, d_cls, d_inst,
-                       n_px, S.vkeys, S.vcounts);
     hipLaunchKernelGGL(k_sem_assoc_compact, dim3(HV_VOTE_CAP / 256), dim3(256), 0, v->stream, v->table, S.vkeys, S.vcounts, S.ckeys,
                        S.ccounts);
     HV_HIP(hipGetLastError());

@@ -61,6 +61,8 @@ def test_depth_gate_and_default_object_id():
 @pytest.mark.parametrize("use_inst,use_depth", [(True, True), (True, False), (False, True), (False, False)])
 def test_port_matches_compiled_reference(pos_dtype, use_inst, use_depth):
     p, r = PortSemGrid(0.05, 8), RefSemGrid(0.05, 8)
+    for g in (p, r):  # the threshold is a static of the payload class: whatever ran before in this process must not leak in
+        g.set_depth_threshold(10.0)
     for it in range(3):
         pts, cols, cls, inst, dep = stream(100 + it, 20000, pos_dtype)
         c = cols if it != 1 else (cols / 255.0).astype(np.float32)
