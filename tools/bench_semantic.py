@@ -101,7 +101,8 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
                                                                            "(the integrator's flow)")
     out["host_images"] = "page-locked (as in the front's registered ring), asynchronous uploads" if out_pinned else "pageable"
     for name, cls, kind in (("voting", VoxelBlockSemanticGrid, 0), ("probabilistic", VoxelBlockSemanticProbabilisticGrid, 1)):
-        g = cls(args.voxel, 8, max_blocks=1 << (19 if args.voxel < 0.004 else 17), max_points=max(1 << 20, s.width * s.height))  # (a pool that does not have to grow inside the timed keyframes)
+        mb_log2 = int(os.environ.get("PYSLAM_AMD_SEMANTIC_MAX_BLOCKS_LOG2", "19" if args.voxel < 0.004 else "17"))  # A/B: the hash table has 4 slots per block of this
+        g = cls(args.voxel, 8, max_blocks=1 << mb_log2, max_points=max(1 << 20, s.width * s.height))  # (a pool that does not have to grow inside the timed keyframes)
         fr = CameraFrustrum(*intr, s.width, s.height, np.eye(4), depth_max=8.0, depth_min=0.01)
         set_next_object_id(1)
 
