@@ -46,7 +46,11 @@ typedef enum hv_mode {
     HV_MODE_VOXEL_GRID = 0,
     HV_MODE_VOXEL_SEMANTIC_GRID = 1,               /* voting payload */
     HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID = 2, /* log-probability payload */
-    HV_MODE_TSDF = 3
+    HV_MODE_TSDF = 3,
+    /* the two "*2" payload variants the reference's module also binds (volumetric_grid_module.h:1014-1032,
+     * voxel_block_semantic_grid.h:120-123); pySLAM's VolumetricIntegratorType has no entry for them (4 is GAUSSIAN_SPLATTING) */
+    HV_MODE_VOXEL_SEMANTIC_GRID2 = 11,               /* separate object / class counters, voxel_data_semantic2.h:46-196 */
+    HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID2 = 12  /* marginal object / class label maps, voxel_data_semantic2.h:256-787 */
 } hv_mode;
 typedef enum hv_loc { HV_HOST = 0, HV_DEVICE = 1 } hv_loc;
 typedef enum hv_color_dtype { HV_COLOR_NONE = 0, HV_COLOR_U8 = 1, HV_COLOR_F32 = 2 } hv_color_dtype;
@@ -173,7 +177,14 @@ int hv_keys_from_points(hv_volume *v, const float *points, int64_t n, int32_t *v
  *                                              VoxelSemanticData, voxel_data_semantic.h:106-202)
  * HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID == volumetric.VoxelBlockSemanticProbabilisticGrid (log-probability
  *                                              payload, VoxelSemanticDataProbabilistic, voxel_data_semantic.h:249-672)
- * (bindings: cpp/volumetric/volumetric_grid_module.h:939-1033; class: voxel_block_semantic_grid.h:57-121).
+ * HV_MODE_VOXEL_SEMANTIC_GRID2               == volumetric.VoxelBlockSemanticGrid2 (VoxelSemanticData2: one confidence counter
+ *                                              for the object id and one for the class id, voxel_data_semantic2.h:46-196)
+ * HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID2 == volumetric.VoxelBlockSemanticProbabilisticGrid2 (VoxelSemanticDataProbabilistic2:
+ *                                              one log-probability map per object id and one per class id, half of every
+ *                                              observation's log-probability to each, voxel_data_semantic2.h:256-787)
+ * (bindings: cpp/volumetric/volumetric_grid_module.h:939-1033; class: voxel_block_semantic_grid.h:57-123).  Every entry point of
+ * this section takes the four modes; the reference itself documents the two *2 payloads as the inferior variants
+ * (voxel_data_semantic.h:52-100) and nothing under pyslam/dense instantiates them.
  *
  * hv_integrate_points_semantic == .integrate(points f32|f64 [N,3], colors u8|f32, class_ids i32 [N] | None,
  *   instance_ids i32 [N] | None, depths f32 [N] | None)
@@ -299,6 +310,11 @@ int hv_dump_blocks_semantic(hv_volume *v, int32_t *keys, int32_t *ints, double *
 int hv_dump_blocks_semantic2(hv_volume *v, int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums,
                              int32_t *label_counts, int32_t *labels, float *log_probs, int32_t max_labels,
                              int64_t *n_blocks);
+/* The marginal confidences of the two "*2" payloads, [B,bs^3] f32 each in the dumps' order: get_object_confidence() /
+ * get_class_confidence() (voxel_data_semantic2.h:60-76, 528-560); -1 everywhere for the other two payloads, which have none.
+ * For HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID2 the labels of hv_dump_blocks_semantic2 are the entries of the voxel's two maps,
+ * {id, which map (0 object, 1 class)}, in insertion order. */
+int hv_dump_marginals_semantic(hv_volume *v, float *object_confidences, float *class_confidences, int64_t *n_blocks);
 
 /* ---- TSDF mode ---------------------------------------------------------------------------------
  * hv_tsdf_integrate == RGBDImage.create_from_color_and_depth(color, depth, depth_scale,

@@ -5,7 +5,9 @@
 //
 //   VoxelBlockSemanticGrid              = VoxelBlockSemanticGridT<VoxelSemanticData>               (kind 0, voting)
 //   VoxelBlockSemanticProbabilisticGrid = VoxelBlockSemanticGridT<VoxelSemanticDataProbabilistic>  (kind 1, log-prob)
-//   (cpp/volumetric/voxel_block_semantic_grid.h:57-121, voxel_data_semantic.h:106-202, 249-672)
+//   VoxelBlockSemanticGrid2              = VoxelBlockSemanticGridT<VoxelSemanticData2>              (kind 2, two counters)
+//   VoxelBlockSemanticProbabilisticGrid2 = VoxelBlockSemanticGridT<VoxelSemanticDataProbabilistic2> (kind 3, marginal maps)
+//   (cpp/volumetric/voxel_block_semantic_grid.h:57-123, voxel_data_semantic.h:106-202, 249-672, voxel_data_semantic2.h:46-196, 256-787)
 //
 // Wrapped beyond the container part: assign_object_ids_to_instance_ids
 // (voxel_semantic_data_association.h:70-373), remap_instance_ids (image_utils.h:69-163), carve
@@ -38,11 +40,15 @@ template <typename Base> class Dumpable : public Base {
 };
 using VoteGrid = Dumpable<volumetric::VoxelBlockSemanticGrid>;
 using ProbGrid = Dumpable<volumetric::VoxelBlockSemanticProbabilisticGrid>;
+using Vote2Grid = Dumpable<volumetric::VoxelBlockSemanticGrid2>;
+using Prob2Grid = Dumpable<volumetric::VoxelBlockSemanticProbabilisticGrid2>;
 
 struct Handle {
     int kind;
     VoteGrid *vote = nullptr;
     ProbGrid *prob = nullptr;
+    Vote2Grid *vote2 = nullptr;
+    Prob2Grid *prob2 = nullptr;
 };
 
 CameraFrustrum make_frustum(const float *intr, int width, int height, const double *T_cw_rowmajor, float depth_max,
@@ -116,6 +122,23 @@ int64_t dump_g(const G *g, int32_t *keys, int32_t *ints, float *conf, double *po
             if (col_sums) for (int k = 0; k < 3; ++k) col_sums[(b * nv + i) * 3 + k] = v.color_sum[k];
         }
     }
+    return (int64_t)order.size();
+}
+
+template <typename G> int64_t marginals_g(const G *g, float *obj_conf, float *cls_conf) {
+    const auto order = sorted_blocks(g);
+    const int bs = g->get_block_size();
+    const size_t nv = size_t(bs) * bs * bs;
+    for (size_t b = 0; b < order.size(); ++b)
+        for (size_t i = 0; i < nv; ++i) {
+            const auto &v = order[b]->second.data[i];
+            if constexpr (requires { v.get_object_confidence(); }) {
+                obj_conf[b * nv + i] = v.get_object_confidence();
+                cls_conf[b * nv + i] = v.get_class_confidence();
+            } else {
+                obj_conf[b * nv + i] = cls_conf[b * nv + i] = -1.0f;
+            }
+        }
     return (int64_t)order.size();
 }
 
@@ -204,71 +227,85 @@ template <typename G> int64_t get_ids_g(const G *g, int32_t *class_ids, int32_t 
 
 } // namespace
 
-#define DISPATCH(h, expr_vote, expr_prob) (static_cast<Handle *>(h)->kind == 0 ? (expr_vote) : (expr_prob))
 #define H(h) static_cast<Handle *>(h)
+// f(grid) on the grid the handle holds (every lambda below returns the same type for the four grids)
+template <typename F> auto visit(void *h, F &&f) {
+    Handle *x = H(h);
+    switch (x->kind) {
+    case 0: return f(x->vote);
+    case 1: return f(x->prob);
+    case 2: return f(x->vote2);
+    default: return f(x->prob2);
+    }
+}
 
 extern "C" {
 
-// kind 0: VoxelBlockSemanticGrid (voting); kind 1: VoxelBlockSemanticProbabilisticGrid
+// kind 0: VoxelBlockSemanticGrid (voting); kind 1: VoxelBlockSemanticProbabilisticGrid; kind 2: VoxelBlockSemanticGrid2 (separate
+// object / class counters, voxel_data_semantic2.h:46-196); kind 3: VoxelBlockSemanticProbabilisticGrid2 (marginal label maps, :256-787)
 void *ref_sem2_create(int kind, double voxel_size, int block_size) {
     auto *h = new Handle{kind};
     if (kind == 0) h->vote = new VoteGrid(voxel_size, block_size);
-    else h->prob = new ProbGrid(voxel_size, block_size);
+    else if (kind == 1) h->prob = new ProbGrid(voxel_size, block_size);
+    else if (kind == 2) h->vote2 = new Vote2Grid(voxel_size, block_size);
+    else h->prob2 = new Prob2Grid(voxel_size, block_size);
     return h;
 }
 void ref_sem2_destroy(void *h) {
     delete H(h)->vote;
     delete H(h)->prob;
+    delete H(h)->vote2;
+    delete H(h)->prob2;
     delete H(h);
 }
-void ref_sem2_clear(void *h) { if (H(h)->kind == 0) H(h)->vote->clear(); else H(h)->prob->clear(); }
-int64_t ref_sem2_num_blocks(void *h) { return (int64_t)DISPATCH(h, H(h)->vote->num_blocks(), H(h)->prob->num_blocks()); }
+void ref_sem2_clear(void *h) { visit(h, [](auto *g) { g->clear(); }); }
+int64_t ref_sem2_num_blocks(void *h) { return visit(h, [](auto *g) { return (int64_t)g->num_blocks(); }); }
 // the thresholds are static members of the payload types (process-wide), exactly as in the reference
-void ref_sem2_set_depth_threshold(void *h, float t) { if (H(h)->kind == 0) H(h)->vote->set_depth_threshold(t); else H(h)->prob->set_depth_threshold(t); }
-void ref_sem2_set_depth_decay_rate(void *h, float r) { if (H(h)->kind == 0) H(h)->vote->set_depth_decay_rate(r); else H(h)->prob->set_depth_decay_rate(r); }
+void ref_sem2_set_depth_threshold(void *h, float t) { visit(h, [&](auto *g) { g->set_depth_threshold(t); }); }
+void ref_sem2_set_depth_decay_rate(void *h, float r) { visit(h, [&](auto *g) { g->set_depth_decay_rate(r); }); }
 int32_t ref_sem2_peek_next_object_id() { return volumetric::VoxelSemanticSharedData::next_object_id.load(); }
 void ref_sem2_set_next_object_id(int32_t v) { volumetric::VoxelSemanticSharedData::next_object_id.store(v); }
 
 void ref_sem2_integrate(void *h, const void *pts, int pos_kind, int64_t n, const void *cols, int color_kind,
                         const int32_t *class_ids, const int32_t *instance_ids, const float *depths) {
-    if (H(h)->kind == 0) integrate_g(H(h)->vote, pts, pos_kind, (size_t)n, cols, color_kind, class_ids, instance_ids, depths);
-    else integrate_g(H(h)->prob, pts, pos_kind, (size_t)n, cols, color_kind, class_ids, instance_ids, depths);
+    visit(h, [&](auto *g) { integrate_g(g, pts, pos_kind, (size_t)n, cols, color_kind, class_ids, instance_ids, depths); });
 }
 int64_t ref_sem2_dump(void *h, int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums) {
-    return DISPATCH(h, dump_g(H(h)->vote, keys, ints, conf, pos_sums, col_sums), dump_g(H(h)->prob, keys, ints, conf, pos_sums, col_sums));
+    return visit(h, [&](auto *g) { return dump_g(g, keys, ints, conf, pos_sums, col_sums); });
+}
+// the marginal confidences of the two *2 payloads (get_object_confidence / get_class_confidence, voxel_data_semantic2.h:60-76, 528-560),
+// blocks and voxels in ref_sem2_dump's order; -1 for the payloads that have none
+int64_t ref_sem2_dump_marginals(void *h, float *obj_conf, float *cls_conf) {
+    return visit(h, [&](auto *g) { return marginals_g(g, obj_conf, cls_conf); });
 }
 int64_t ref_sem2_get_voxels(void *h, int min_count, float min_confidence, double *pts, float *cols, int32_t *class_ids,
                             int32_t *object_ids, float *confidences, int64_t cap) {
-    return DISPATCH(h, get_voxels_g(H(h)->vote, min_count, min_confidence, pts, cols, class_ids, object_ids, confidences, cap),
-                    get_voxels_g(H(h)->prob, min_count, min_confidence, pts, cols, class_ids, object_ids, confidences, cap));
+    return visit(h, [&](auto *g) { return get_voxels_g(g, min_count, min_confidence, pts, cols, class_ids, object_ids, confidences, cap); });
 }
 int64_t ref_sem2_assign_object_ids(void *h, const float *intr, int width, int height, const double *T_cw, float depth_max,
                                    float depth_min, const int32_t *class_img, const int32_t *inst_img, const float *depth,
                                    float depth_threshold, int do_carving, float min_vote_ratio, int min_votes, int32_t *map_inst,
                                    int32_t *map_obj, int64_t cap) {
-    return DISPATCH(h,
-                    assign_g(H(h)->vote, intr, width, height, T_cw, depth_max, depth_min, class_img, inst_img, depth,
-                             depth_threshold, do_carving, min_vote_ratio, min_votes, map_inst, map_obj, cap),
-                    assign_g(H(h)->prob, intr, width, height, T_cw, depth_max, depth_min, class_img, inst_img, depth,
-                             depth_threshold, do_carving, min_vote_ratio, min_votes, map_inst, map_obj, cap));
+    return visit(h, [&](auto *g) {
+        return assign_g(g, intr, width, height, T_cw, depth_max, depth_min, class_img, inst_img, depth, depth_threshold, do_carving,
+                        min_vote_ratio, min_votes, map_inst, map_obj, cap);
+    });
 }
 void ref_sem2_carve(void *h, const float *intr, int width, int height, const double *T_cw, float depth_max, float depth_min,
                     const float *depth, float depth_threshold) {
-    if (H(h)->kind == 0) carve_g(H(h)->vote, intr, width, height, T_cw, depth_max, depth_min, depth, depth_threshold);
-    else carve_g(H(h)->prob, intr, width, height, T_cw, depth_max, depth_min, depth, depth_threshold);
+    visit(h, [&](auto *g) { carve_g(g, intr, width, height, T_cw, depth_max, depth_min, depth, depth_threshold); });
 }
 int64_t ref_sem2_get_object_segments(void *h, int min_count, float min_confidence, int32_t *ids, float *conf, double *obb,
                                      double *pts, float *cols, int64_t cap_objects, int64_t cap_points, int64_t *n_points) {
-    return DISPATCH(h, segments_g(H(h)->vote, min_count, min_confidence, ids, conf, obb, pts, cols, cap_objects, cap_points, n_points),
-                    segments_g(H(h)->prob, min_count, min_confidence, ids, conf, obb, pts, cols, cap_objects, cap_points, n_points));
+    return visit(h, [&](auto *g) { return segments_g(g, min_count, min_confidence, ids, conf, obb, pts, cols, cap_objects, cap_points, n_points); });
 }
-void ref_sem2_merge_segments(void *h, int id1, int id2) { if (H(h)->kind == 0) H(h)->vote->merge_segments(id1, id2); else H(h)->prob->merge_segments(id1, id2); }
-void ref_sem2_remove_segment(void *h, int id) { if (H(h)->kind == 0) H(h)->vote->remove_segment(id); else H(h)->prob->remove_segment(id); }
+void ref_sem2_merge_segments(void *h, int id1, int id2) { visit(h, [&](auto *g) { g->merge_segments(id1, id2); }); }
+void ref_sem2_remove_segment(void *h, int id) { visit(h, [&](auto *g) { g->remove_segment(id); }); }
 void ref_sem2_remove_low_confidence_segments(void *h, int min_confidence) {
-    if (H(h)->kind == 0) H(h)->vote->remove_low_confidence_segments(min_confidence); else H(h)->prob->remove_low_confidence_segments(min_confidence);
+    visit(h, [&](auto *g) { g->remove_low_confidence_segments(min_confidence); });
 }
 int64_t ref_sem2_get_ids(void *h, int32_t *class_ids, int32_t *object_ids, int64_t cap) {
-    return DISPATCH(h, get_ids_g(H(h)->vote, class_ids, object_ids, cap), get_ids_g(H(h)->prob, class_ids, object_ids, cap));
+    return visit(h, [&](auto *g) { return get_ids_g(g, class_ids, object_ids, cap); });
 }
 
 // remap_instance_ids<MapInstanceIdToObjectId, int32_t>, image_utils.h:69-163
@@ -346,23 +383,19 @@ extern "C" {
 int64_t ref_sem2_get_voxels_in_bb(void *h, const double *bb, int min_count, float min_confidence, double *pts, float *cols,
                                   int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap) {
     volumetric::BoundingBox3D bbox(bb[0], bb[1], bb[2], bb[3], bb[4], bb[5]);
-    if (H(h)->kind == 0) return copy_sem(H(h)->vote->get_voxels_in_bb<true>(bbox, min_count, min_confidence), pts, cols, class_ids, object_ids, confidences, cap);
-    return copy_sem(H(h)->prob->get_voxels_in_bb<true>(bbox, min_count, min_confidence), pts, cols, class_ids, object_ids, confidences, cap);
+    return visit(h, [&](auto *g) { return copy_sem(g->template get_voxels_in_bb<true>(bbox, min_count, min_confidence), pts, cols, class_ids, object_ids, confidences, cap); });
 }
 int64_t ref_sem2_get_voxels_in_frustum(void *h, const float *intr, int width, int height, const double *T_cw, float depth_max,
                                        float depth_min, int min_count, float min_confidence, double *pts, float *cols,
                                        int32_t *class_ids, int32_t *object_ids, float *confidences, int64_t cap) {
     const CameraFrustrum fr = make_frustum(intr, width, height, T_cw, depth_max, depth_min);
-    if (H(h)->kind == 0) return copy_sem(H(h)->vote->get_voxels_in_camera_frustrum<true>(fr, min_count, min_confidence), pts, cols, class_ids, object_ids, confidences, cap);
-    return copy_sem(H(h)->prob->get_voxels_in_camera_frustrum<true>(fr, min_count, min_confidence), pts, cols, class_ids, object_ids, confidences, cap);
+    return visit(h, [&](auto *g) { return copy_sem(g->template get_voxels_in_camera_frustrum<true>(fr, min_count, min_confidence), pts, cols, class_ids, object_ids, confidences, cap); });
 }
 void ref_sem2_integrate_segment(void *h, const double *pts, int64_t n, const float *cols, int object_id, int class_id) {
-    if (H(h)->kind == 0) H(h)->vote->integrate_segment_raw<double, float, int, int>(pts, (size_t)n, cols, class_id, object_id);
-    else H(h)->prob->integrate_segment_raw<double, float, int, int>(pts, (size_t)n, cols, class_id, object_id);
+    visit(h, [&](auto *g) { g->template integrate_segment_raw<double, float, int, int>(pts, (size_t)n, cols, class_id, object_id); });
 }
 int64_t ref_sem2_get_class_segments(void *h, int min_count, float min_confidence, int32_t *ids, float *conf, int64_t cap) {
-    return DISPATCH(h, class_segments_g(H(h)->vote, min_count, min_confidence, ids, conf, cap),
-                    class_segments_g(H(h)->prob, min_count, min_confidence, ids, conf, cap));
+    return visit(h, [&](auto *g) { return class_segments_g(g, min_count, min_confidence, ids, conf, cap); });
 }
 
 } // extern "C"

@@ -272,10 +272,23 @@ class _Sem2Base:
 
 
 class RefSemGrid2(_Sem2Base):
-    """The compiled reference's VoxelBlockSemanticGrid (kind 0) / VoxelBlockSemanticProbabilisticGrid (kind 1)."""
+    """The compiled reference's VoxelBlockSemanticGrid (kind 0) / VoxelBlockSemanticProbabilisticGrid (kind 1) /
+    VoxelBlockSemanticGrid2 (kind 2: separate object and class counters) / VoxelBlockSemanticProbabilisticGrid2 (kind 3: marginal
+    label maps) - voxel_block_semantic_grid.h:118-123."""
 
     def __init__(self, kind, voxel_size, block_size=8):
         super().__init__(ref_lib(), "ref_sem2_", kind, voxel_size, block_size)
+
+    def dump_marginals(self):
+        """-> (object confidence, class confidence) [B,bs^3] f32 in dump()'s order: get_object_confidence / get_class_confidence of the
+        two *2 payloads (voxel_data_semantic2.h:60-76, 528-560); -1 everywhere for kinds 0 and 1."""
+        fn = self._lib.ref_sem2_dump_marginals
+        fn.restype = _i64
+        fn.argtypes = [_vp, _vp, _vp]
+        nb, nv = self.num_blocks(), self.block_size ** 3
+        oc, cc = np.zeros((nb, nv), np.float32), np.zeros((nb, nv), np.float32)
+        fn(self._h, _ptr(oc), _ptr(cc))
+        return oc, cc
 
 
 class PortSemGrid2(_Sem2Base):

@@ -4,10 +4,13 @@
  *
  *   kind 0  VoxelBlockSemanticGrid              = VoxelBlockSemanticGridT<VoxelSemanticData>
  *   kind 1  VoxelBlockSemanticProbabilisticGrid = VoxelBlockSemanticGridT<VoxelSemanticDataProbabilistic>
- *   (cpp/volumetric/voxel_block_semantic_grid.h:57-121)
+ *   kind 2  VoxelBlockSemanticGrid2              = VoxelBlockSemanticGridT<VoxelSemanticData2>
+ *   kind 3  VoxelBlockSemanticProbabilisticGrid2 = VoxelBlockSemanticGridT<VoxelSemanticDataProbabilistic2>
+ *   (cpp/volumetric/voxel_block_semantic_grid.h:57-123)
  *
  * Restated, function by function:
- *   payloads                                voxel_data_semantic.h:106-202 (voting), :249-672 (log-probability)
+ *   payloads                                voxel_data_semantic.h:106-202 (voting), :249-672 (log-probability);
+ *                                           voxel_data_semantic2.h:46-196 (two counters), :256-787 (marginal label maps)
  *   integrate_raw -> update_voxel_direct    voxel_block_grid.hpp:221-287, 466-497, 524-614 (sequential branch)
  *   get_voxels                              voxel_block_grid.hpp:785-817
  *   iterate_voxels_in_camera_frustrum       voxel_block_grid.hpp:1335-1349, 1445-1537; CameraFrustrum::contains
@@ -49,6 +52,14 @@ typedef struct {
     int32_t ml_obj, ml_cls; /* most_likely_pair */
     float ml_logp;          /* most_likely_log_prob */
     int cache_valid;
+    /* kind 2 (VoxelSemanticData2): confidence_counter above is object_confidence_counter_, this is class_confidence_counter_ */
+    int32_t class_counter;
+    /* kind 3 (VoxelSemanticDataProbabilistic2): `labels` holds BOTH maps, keyed (which map, id) - obj field = 0 for
+     * object_log_probabilities / 1 for class_log_probabilities, cls field = the id - so that each map is contiguous and in id
+     * order; the two caches of voxel_data_semantic2.h:281-287 */
+    int32_t ml2_id[2];
+    float ml2_logp[2];
+    int ml2_valid[2];
 } s2_voxel;
 
 typedef struct {
@@ -70,6 +81,9 @@ typedef struct {
 static float s2_vote_depth_threshold = 10.0f; /* voxel_data_semantic.h:107-108 */
 static float s2_prob_depth_threshold = 5.0f;  /* :251-252 */
 static float s2_prob_depth_decay = 0.07f;     /* :253-254 */
+static float s2_vote2_depth_threshold = 10.0f; /* voxel_data_semantic2.h:47-48 */
+static float s2_prob2_depth_threshold = 5.0f;  /* :258-259 */
+static float s2_prob2_depth_decay = 0.07f;     /* :260-261 */
 static int32_t s2_next_object_id = 1;         /* voxel_semantic_shared_data.h:26-34 */
 
 int32_t so2_peek_next_object_id(void) { return s2_next_object_id; }
@@ -170,14 +184,82 @@ static float s2_observation_log_prob(int has_depth, float depth) { /* :419-447 *
     return confidence * S2_BASE_LOG_PROB;
 }
 
+/* ---- payload: marginal label maps (kind 3, voxel_data_semantic2.h:256-787) --------------------------------- */
+static void s2_m_update_cache(s2_voxel *v, int which) { /* update_object_cache / update_class_cache, :601-645 */
+    v->ml2_id[which] = -1;
+    v->ml2_logp[which] = -INFINITY;
+    for (int i = 0; i < v->n_labels; ++i) /* (this map's entries in id order) */
+        if (v->labels[i].obj == which && v->labels[i].logp > v->ml2_logp[which]) {
+            v->ml2_logp[which] = v->labels[i].logp;
+            v->ml2_id[which] = v->labels[i].cls;
+        }
+    v->ml2_valid[which] = 1;
+}
+static int s2_m_size(const s2_voxel *v, int which) {
+    int n = 0;
+    for (int i = 0; i < v->n_labels; ++i) n += v->labels[i].obj == which;
+    return n;
+}
+static float s2_m_log_normalization(const s2_voxel *v, int which) { /* :647-691: two passes, sum in id order */
+    if (s2_m_size(v, which) == 0) return 0.0f;
+    float mx = -INFINITY;
+    for (int i = 0; i < v->n_labels; ++i)
+        if (v->labels[i].obj == which && v->labels[i].logp > mx) mx = v->labels[i].logp;
+    float sum = 0.0f;
+    for (int i = 0; i < v->n_labels; ++i)
+        if (v->labels[i].obj == which) sum += expf(v->labels[i].logp - mx);
+    return mx + logf(sum);
+}
+static void s2_m_add(s2_voxel *v, int which, int32_t id, float half, int assign) {
+    const int i = s2_find(v, which, id);
+    if (i < 0) s2_insert(v, which, id, half);
+    else v->labels[i].logp = assign ? half : v->labels[i].logp + half;
+}
+static void s2_m_initialize(s2_voxel *v, int32_t obj, int32_t cls, float lp) { /* initialize_semantics_log_prob, :311-326 */
+    const float half = lp * 0.5f;
+    s2_m_add(v, 0, obj, half, 1);
+    s2_m_add(v, 1, cls, half, 1);
+    v->ml2_id[0] = obj;
+    v->ml2_id[1] = cls;
+    v->ml2_logp[0] = v->ml2_logp[1] = half;
+    v->ml2_valid[0] = v->ml2_valid[1] = 1;
+}
+static void s2_m_update(s2_voxel *v, int32_t obj, int32_t cls, float lp) { /* update_semantics_log_prob, :339-369 */
+    const float half = lp * 0.5f;
+    s2_m_add(v, 0, obj, half, 0);
+    s2_m_add(v, 1, cls, half, 0);
+    v->ml2_valid[0] = v->ml2_valid[1] = 0;
+}
+static float s2_m_observation_log_prob(int has_depth, float depth) { /* :371-388 (no base log-probability here) */
+    if (!has_depth) return logf(1.0f);
+    return depth <= s2_prob2_depth_threshold ? 0.0f : -(depth - s2_prob2_depth_threshold) * s2_prob2_depth_decay;
+}
+static float s2_m_confidence(s2_voxel *v) { /* ensure_cache_updated + compute_confidence, :562-598 */
+    for (int w = 0; w < 2; ++w)
+        if (!v->ml2_valid[w]) s2_m_update_cache(v, w);
+    if (v->ml2_id[0] == -1 || v->ml2_id[1] == -1) return 0.0f;
+    if (s2_m_size(v, 0) == 0 || s2_m_size(v, 1) == 0) return 0.0f;
+    const float joint = v->ml2_logp[0] + v->ml2_logp[1];
+    return expf(joint - (s2_m_log_normalization(v, 0) + s2_m_log_normalization(v, 1)));
+}
+static float s2_min1(float r) { return r < 1.0f ? r : 1.0f; } /* std::min(1.0f, r) */
+
 /* ---- payload-independent accessors ----------------------------------------------------------------- */
 static int32_t s2_object_id(const s2_grid *g, s2_voxel *v) {
-    if (g->kind == 0) return v->object_id;
+    if (g->kind == 0 || g->kind == 2) return v->object_id;
+    if (g->kind == 3) {
+        if (!v->ml2_valid[0]) s2_m_update_cache(v, 0);
+        return v->ml2_id[0];
+    }
     if (!v->cache_valid) s2_update_cache(v);
     return v->ml_obj;
 }
 static int32_t s2_class_id(const s2_grid *g, s2_voxel *v) {
-    if (g->kind == 0) return v->class_id;
+    if (g->kind == 0 || g->kind == 2) return v->class_id;
+    if (g->kind == 3) {
+        if (!v->ml2_valid[1]) s2_m_update_cache(v, 1);
+        return v->ml2_id[1];
+    }
     if (!v->cache_valid) s2_update_cache(v);
     return v->ml_cls;
 }
@@ -187,6 +269,12 @@ static float s2_confidence(const s2_grid *g, s2_voxel *v) {
         const float r = (float)v->confidence_counter / (float)v->count;
         return r < 1.0f ? r : 1.0f;
     }
+    if (g->kind == 2) { /* voxel_data_semantic2.h:60-85: the smaller of the two clamped counter / count ratios */
+        if (v->count == 0) return 0.0f;
+        const float o = s2_min1((float)v->confidence_counter / (float)v->count), c = s2_min1((float)v->class_counter / (float)v->count);
+        return c < o ? c : o;
+    }
+    if (g->kind == 3) return s2_m_confidence(v);
     if (!v->cache_valid) s2_update_cache(v);
     if (v->ml_obj == -1 || v->ml_cls == -1) return 0.0f; /* compute_confidence, :562-572 */
     if (v->n_labels == 0) return 0.0f;
@@ -194,11 +282,23 @@ static float s2_confidence(const s2_grid *g, s2_voxel *v) {
 }
 static int32_t s2_confidence_counter(const s2_grid *g, s2_voxel *v) {
     if (g->kind == 0) return v->confidence_counter;
-    return (int32_t)(s2_confidence(g, v) * (float)v->count); /* :505-511 */
+    if (g->kind == 2) return v->class_counter < v->confidence_counter ? v->class_counter : v->confidence_counter; /* semantic2.h:55-57 */
+    return (int32_t)(s2_confidence(g, v) * (float)v->count); /* :505-511; voxel_data_semantic2.h:506-511 */
 }
 static void s2_set_object_id(const s2_grid *g, s2_voxel *v, int32_t id) {
-    if (g->kind == 0) {
+    if (g->kind == 0 || g->kind == 2) {
         v->object_id = id;
+        return;
+    }
+    if (g->kind == 3) { /* voxel_data_semantic2.h:424-452 */
+        if (!v->ml2_valid[0]) s2_m_update_cache(v, 0);
+        const float target = (s2_m_size(v, 0) > 0 && v->ml2_id[0] != -1 && v->ml2_logp[0] != -INFINITY) ? v->ml2_logp[0] : 0.0f;
+        s2_m_add(v, 0, id, target, 1);
+        v->ml2_id[0] = id;
+        v->ml2_logp[0] = target;
+        v->ml2_valid[0] = 1;
+        v->ml2_valid[1] = 0;
+        (void)s2_m_confidence(v); /* ensure_cache_updated */
         return;
     }
     /* set_object_id -> force_label_distribution, :476-481, 603-618 */
@@ -223,6 +323,8 @@ static void s2_reset(s2_voxel *v) {
     v->object_id = v->class_id = -1;
     v->ml_obj = v->ml_cls = -1;
     v->ml_logp = -INFINITY;
+    v->ml2_id[0] = v->ml2_id[1] = -1;
+    v->ml2_logp[0] = v->ml2_logp[1] = -INFINITY;
 }
 
 /* ---- container -------------------------------------------------------------------------------------- */
@@ -287,10 +389,13 @@ int32_t so2_label_histogram(const s2_grid *g, int64_t *hist, int32_t cap) {
 }
 void so2_set_depth_threshold(s2_grid *g, float t) {
     if (g->kind == 0) s2_vote_depth_threshold = t;
-    else s2_prob_depth_threshold = t;
+    else if (g->kind == 1) s2_prob_depth_threshold = t;
+    else if (g->kind == 2) s2_vote2_depth_threshold = t;
+    else s2_prob2_depth_threshold = t;
 }
 void so2_set_depth_decay_rate(s2_grid *g, float r) {
-    if (g->kind == 1) s2_prob_depth_decay = r; /* only the probabilistic payload, voxel_block_semantic_grid.hpp:32-37 */
+    if (g->kind == 1) s2_prob_depth_decay = r; /* only the probabilistic payloads, voxel_block_semantic_grid.hpp:32-37 */
+    else if (g->kind == 3) s2_prob2_depth_decay = r;
 }
 
 static s2_block *s2_find_or_create(s2_grid *g, int32_t bx, int32_t by, int32_t bz) {
@@ -365,6 +470,20 @@ void so2_integrate(s2_grid *g, const void *pts, int pos_kind, int64_t n, const v
                         if (v->confidence_counter <= 0) { v->object_id = obj; v->class_id = cls; v->confidence_counter = 1; }
                     }
                 }
+            } else if (g->kind == 2) { /* voxel_data_semantic2.h:120-195: the object id and the class id vote on their own */
+                const int gate = depths ? (depths[i] < s2_vote2_depth_threshold) : 1;
+                if (v->count == 0) {
+                    if (gate) { v->object_id = obj; v->class_id = cls; v->confidence_counter = 1; v->class_counter = 1; }
+                } else if (gate) {
+                    if (v->object_id == obj) v->confidence_counter++;
+                    else if (--v->confidence_counter <= 0) { v->object_id = obj; v->confidence_counter = 1; }
+                    if (v->class_id == cls) v->class_counter++;
+                    else if (--v->class_counter <= 0) { v->class_id = cls; v->class_counter = 1; }
+                }
+            } else if (g->kind == 3) {
+                const float lp = s2_m_observation_log_prob(depths != NULL, depths ? depths[i] : 0.0f);
+                if (v->count == 0) s2_m_initialize(v, obj, cls, lp);
+                else s2_m_update(v, obj, cls, lp);
             } else {
                 const float lp = s2_observation_log_prob(depths != NULL, depths ? depths[i] : 0.0f);
                 if (v->count == 0) s2_prob_initialize(v, obj, cls, lp);

@@ -20,6 +20,8 @@ HV_MODE_VOXEL_GRID = 0
 HV_MODE_VOXEL_SEMANTIC_GRID = 1
 HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID = 2
 HV_MODE_TSDF = 3
+HV_MODE_VOXEL_SEMANTIC_GRID2 = 11
+HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID2 = 12
 HV_HOST, HV_DEVICE = 0, 1
 HV_COLOR_NONE, HV_COLOR_U8, HV_COLOR_F32 = 0, 1, 2
 HV_DEPTH_F32, HV_DEPTH_U16 = 0, 1
@@ -77,6 +79,7 @@ SIGNATURES = {
     "hv_set_depth_threshold": (_i32, [_vp, _f32]),
     "hv_dump_blocks_semantic": (_i32, [_vp, _vp, _vp, _vp, _vp, _pi64]),
     "hv_dump_blocks_semantic2": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _pi64]),
+    "hv_dump_marginals_semantic": (_i32, [_vp, _vp, _vp, _pi64]),
     "hv_set_depth_decay_rate": (_i32, [_vp, _f32]),
     "hv_integrate_rgbd_semantic": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _f64, _i32, _i32]),
     "hv_label_overflows": (_i32, [_vp, _pi64]),

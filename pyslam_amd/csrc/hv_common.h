@@ -304,6 +304,15 @@ struct HvEventPair {
     hipEvent_t start, stop;
 };
 
+// the four semantic block grids (include/hipvol.h: hv_mode); the two probabilistic ones keep per-voxel label maps with overflow nodes
+static inline bool hv_mode_is_semantic(int32_t mode) {
+    return mode == HV_MODE_VOXEL_SEMANTIC_GRID || mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID || mode == HV_MODE_VOXEL_SEMANTIC_GRID2 ||
+           mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID2;
+}
+static inline bool hv_mode_has_label_maps(int32_t mode) {
+    return mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID || mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID2;
+}
+
 struct hv_volume {
     hv_config cfg;
     int device = 0;

@@ -551,7 +551,7 @@ void hv_default_config(int32_t mode, hv_config *cfg) {
 
 int hv_create(const hv_config *cfg, hv_volume **out) {
     HV_REQUIRE(cfg != nullptr && out != nullptr, HV_ERR_INVALID, "hv_create: null argument");
-    HV_REQUIRE(cfg->mode == HV_MODE_VOXEL_GRID || cfg->mode == HV_MODE_VOXEL_SEMANTIC_GRID || cfg->mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID || cfg->mode == HV_MODE_TSDF, HV_ERR_INVALID,
+    HV_REQUIRE(cfg->mode == HV_MODE_VOXEL_GRID || hv_mode_is_semantic(cfg->mode) || cfg->mode == HV_MODE_TSDF, HV_ERR_INVALID,
                "hv_create: unsupported mode %d", cfg->mode);
     HV_REQUIRE(cfg->voxel_size > 0.0, HV_ERR_INVALID, "hv_create: voxel_size must be > 0");
     HV_REQUIRE(cfg->max_blocks > 0 && cfg->max_blocks < (1ll << 30), HV_ERR_INVALID,
@@ -600,9 +600,10 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
 
     const int64_t nvox = (int64_t)cfg->block_size * cfg->block_size * cfg->block_size;
     v->bytes_per_block = cfg->mode == HV_MODE_TSDF ? nvox * 4 * HV_TSDF_PLANES
-                         : cfg->mode == HV_MODE_VOXEL_SEMANTIC_GRID ? nvox * 64 /* HvSemVoxel */
-                         : cfg->mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID ? nvox * 128 /* HvProbVoxel */ : nvox * (int64_t)sizeof(HvVoxel);
-    if (cfg->mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID) v->sem_depth_threshold = 5.0f; // voxel_data_semantic.h:251-254
+                         : hv_mode_has_label_maps(cfg->mode) ? nvox * 128 /* HvProbVoxel, HvProb2Voxel */
+                         : hv_mode_is_semantic(cfg->mode)    ? nvox * 64  /* HvSemVoxel, HvSem2Voxel */
+                                                             : nvox * (int64_t)sizeof(HvVoxel);
+    if (hv_mode_has_label_maps(cfg->mode)) v->sem_depth_threshold = 5.0f; // voxel_data_semantic.h:251-254, voxel_data_semantic2.h:258-261
     v->local_bits = 0;
     while ((1ll << v->local_bits) < nvox) v->local_bits++;
 
@@ -643,7 +644,7 @@ int hv_create(const hv_config *cfg, hv_volume **out) {
             HV_TRY(hipMalloc((void **)&v->occ, sizeof(unsigned long long) * occ_words));
             HV_TRY(hipMemsetAsync(v->occ, 0, sizeof(unsigned long long) * occ_words, v->stream));
         }
-        if (cfg->mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID) {
+        if (hv_mode_has_label_maps(cfg->mode)) {
             // overflow nodes of the per-voxel label maps (hv_semantic.h): 4 per block of the pool - measured need under 5 % uniform
             // label noise: about one node per 100 occupied voxels.  HV_PROB_NODE_CAP overrides (tests of the exhausted pool).
             int64_t cap = std::max<int64_t>(1 << 16, (int64_t)cfg->max_blocks * 4);

@@ -2,6 +2,8 @@
 //
 //   HvSemVoxel   voting payload        VoxelSemanticData              voxel_data_semantic.h:106-202
 //   HvProbVoxel  log-probability one   VoxelSemanticDataProbabilistic voxel_data_semantic.h:249-672
+//   HvSem2Voxel  two counters          VoxelSemanticData2             voxel_data_semantic2.h:46-196
+//   HvProb2Voxel marginal label maps   VoxelSemanticDataProbabilistic2 voxel_data_semantic2.h:256-787
 //
 // Both keep `count`, float64 position sums and float32 colour sums; they differ in how the
 // (object_id, class_id) label is fused.  The accessors below are the payload-independent interface the
@@ -86,7 +88,7 @@ __host__ __device__ inline float sem_confidence(const HvSemVoxel *v, const void 
     return r < 1.0f ? r : 1.0f;
 }
 __host__ __device__ inline int32_t sem_confidence_counter(const HvSemVoxel *v, const void * = nullptr) { return v->counter; }
-__host__ __device__ inline void sem_set_object_id(HvSemVoxel *v, const void *, int32_t id) { v->obj1 = id + 1; }
+__host__ __device__ inline void sem_set_object_id(HvSemVoxel *v, const HvTable &, int32_t id) { v->obj1 = id + 1; }
 
 // ---- probabilistic accessors -----------------------------------------------------------------------
 // `nodes` = the volume's overflow-node pool (HvTable::prob_nodes); the voting payload's accessors take and ignore it so that the
@@ -217,8 +219,8 @@ __host__ __device__ inline int32_t sem_confidence_counter(const HvProbVoxel *v, 
 }
 // set_object_id() -> force_label_distribution(), voxel_data_semantic.h:476-481, 603-618: the label
 // distribution collapses to the single pair (id, current class) with log-probability 0.
-__host__ __device__ inline void sem_set_object_id(HvProbVoxel *v, const void *nodes, int32_t id) {
-    const int32_t cls = sem_class_id(v, nodes);
+__host__ __device__ inline void sem_set_object_id(HvProbVoxel *v, const HvTable &table, int32_t id) {
+    const int32_t cls = sem_class_id(v, table.prob_nodes);
     if (id >= 0 && cls >= 0) {
         v->obj[0] = id;
         v->cls[0] = cls;
@@ -394,6 +396,314 @@ __device__ inline bool prob_fold(HvProbVoxel *v, const HvTable &table, bool firs
 }
 #endif
 
+// =====================================================================================================================
+// The "*2" payloads of voxel_data_semantic2.h (bound by the reference's module as VoxelBlockSemanticGrid2 /
+// VoxelBlockSemanticProbabilisticGrid2, volumetric_grid_module.h:1014-1032; documented there as the inferior variants).
+// =====================================================================================================================
+
+// ---- VoxelSemanticData2 (voxel_data_semantic2.h:46-196): one confidence counter for the object id, one for the class id; 64 B ------
+struct __attribute__((aligned(16))) HvSem2Voxel {
+    int32_t count;
+    int32_t obj1;        // object_id + 1
+    int32_t cls1;        // class_id + 1
+    int32_t obj_counter; // object_confidence_counter_
+    double pos[3];
+    float col[3];
+    int32_t cls_counter; // class_confidence_counter_
+    float pad[2];
+};
+static_assert(sizeof(HvSem2Voxel) == 64, "HvSem2Voxel must be 64 bytes");
+
+__host__ __device__ inline int32_t sem_object_id(const HvSem2Voxel *v, const void * = nullptr) { return v->obj1 - 1; }
+__host__ __device__ inline int32_t sem_class_id(const HvSem2Voxel *v, const void * = nullptr) { return v->cls1 - 1; }
+// std::min(1.0f, counter / count), voxel_data_semantic2.h:60-76
+__host__ __device__ inline float sem2_ratio(int32_t counter, int32_t count) {
+    const float r = (float)counter / (float)count;
+    return r < 1.0f ? r : 1.0f;
+}
+__host__ __device__ inline float sem_object_confidence(const HvSem2Voxel *v, const void * = nullptr) {
+    return v->count == 0 ? 0.0f : sem2_ratio(v->obj_counter, v->count);
+}
+__host__ __device__ inline float sem_class_confidence(const HvSem2Voxel *v, const void * = nullptr) {
+    return v->count == 0 ? 0.0f : sem2_ratio(v->cls_counter, v->count);
+}
+// get_confidence(): std::min(object confidence, class confidence), :79-83
+__host__ __device__ inline float sem_confidence(const HvSem2Voxel *v, const void * = nullptr) {
+    if (v->count == 0) return 0.0f;
+    const float o = sem2_ratio(v->obj_counter, v->count), c = sem2_ratio(v->cls_counter, v->count);
+    return c < o ? c : o;
+}
+__host__ __device__ inline bool sem_confidence_not_negative(const HvSem2Voxel *v, const void * = nullptr) { return sem_confidence(v) >= 0.0f; }
+// get_confidence_counter(): std::min of the two counters, :55-57
+__host__ __device__ inline int32_t sem_confidence_counter(const HvSem2Voxel *v, const void * = nullptr) {
+    return v->cls_counter < v->obj_counter ? v->cls_counter : v->obj_counter;
+}
+__host__ __device__ inline void sem_set_object_id(HvSem2Voxel *v, const HvTable &, int32_t id) { v->obj1 = id + 1; }
+// one labelled observation: initialize_semantics[_with_depth] (count == 0) / update_semantics[_with_depth], :120-195
+__host__ __device__ inline void sem2_fold(HvSem2Voxel *v, bool first, bool gate, int32_t obj, int32_t cls) {
+    if (!gate) return; // (*_with_depth: depth >= kDepthThreshold leaves the label state alone)
+    if (first) {
+        v->obj1 = obj + 1;
+        v->cls1 = cls + 1;
+        v->obj_counter = 1;
+        v->cls_counter = 1;
+        return;
+    }
+    if (v->obj1 == obj + 1) {
+        v->obj_counter++;
+    } else if (--v->obj_counter <= 0) {
+        v->obj1 = obj + 1;
+        v->obj_counter = 1;
+    }
+    if (v->cls1 == cls + 1) {
+        v->cls_counter++;
+    } else if (--v->cls_counter <= 0) {
+        v->cls1 = cls + 1;
+        v->cls_counter = 1;
+    }
+}
+
+// ---- VoxelSemanticDataProbabilistic2 (voxel_data_semantic2.h:256-787): two std::map<int, float> per voxel, object id -> log-probability
+// and class id -> log-probability; every observation adds HALF its log-probability to its object's entry and half to its class's.
+// Storage: the record, the inline slots and the overflow-node chain of HvProbVoxel, as ONE list of entries
+//     obj[i] = the id, cls[i] = which map the entry belongs to (0: object_log_probabilities, 1: class_log_probabilities), logp[i]
+// (a voxel that saw one object and one class holds two entries; 6 inline, 254 in all, both limits counted like HvProbVoxel's).
+//   meta = n entries | (cached most likely OBJECT entry + 1) << 8 | (cached most likely CLASS entry + 1) << 16; 0 = that cache is not valid:
+//   the reference's object_cache_valid / class_cache_valid (:281-287).  They are valid after the first observation (:311-326) and
+//   after set_object_id (:424-452, which may name an entry that an argmax in key order would not pick among equal log-probabilities),
+//   every update clears both (:366-368); a cache that is not valid is the argmax, a pure function of the map - computed where it is asked
+//   for, never stored.
+struct __attribute__((aligned(16))) HvProb2Voxel : HvProbVoxel {};
+static_assert(sizeof(HvProb2Voxel) == 128, "HvProb2Voxel must be 128 bytes");
+__host__ __device__ inline int prob2_best_obj(uint32_t meta) { return (int)((meta >> 8) & 0xffu) - 1; }
+__host__ __device__ inline int prob2_best_cls(uint32_t meta) { return (int)((meta >> 16) & 0xffu) - 1; }
+__host__ __device__ inline uint32_t prob2_meta(int n, int best_obj, int best_cls) {
+    return (uint32_t)n | ((uint32_t)(best_obj + 1) << 8) | ((uint32_t)(best_cls + 1) << 16);
+}
+struct HvProb2Best {
+    int32_t id; // most_likely_object_id / most_likely_class_id (-1: no entry wins)
+    float lp;   // most_likely_*_log_prob (-inf then)
+    bool any;   // the map has entries at all
+};
+// update_object_cache / update_class_cache, :601-645: the first entry in KEY order whose log-probability is greater than every one before
+// it, starting from -inf (an entry at -inf or NaN never wins) = the largest log-probability, the smallest id among equals
+__host__ __device__ inline HvProb2Best prob2_argmax(const HvProbVoxel *v, const HvProbNode *nodes, int n, int which) {
+    HvProb2Best b{-1, -INFINITY, false};
+    bool won = false;
+    for (int i = 0; i < n; ++i) {
+        const HvProbPair p = prob_get(v, nodes, i);
+        if (p.cls != which) continue;
+        b.any = true;
+        if (p.logp > b.lp) {
+            b.id = p.obj;
+            b.lp = p.logp;
+            won = true;
+        } else if (won && p.logp == b.lp && p.obj < b.id) {
+            b.id = p.obj;
+        }
+    }
+    return b;
+}
+// the cached most likely entry of map `which`, or the argmax when the cache is not valid
+__host__ __device__ inline HvProb2Best prob2_most_likely(const HvProbVoxel *v, const HvProbNode *nodes, int which) {
+    const int n = prob_nlab(v->meta);
+    const int c = which == 0 ? prob2_best_obj(v->meta) : prob2_best_cls(v->meta);
+    if (c >= 0) {
+        const HvProbPair p = prob_get(v, nodes, c);
+        return {p.obj, p.logp, true};
+    }
+    return prob2_argmax(v, nodes, n, which);
+}
+// get_object_log_normalization / get_class_log_normalization, :647-691: max, then sum of exp(lp - max) in key order, max + log(sum)
+__host__ __device__ inline float prob2_log_normalization(const HvProbVoxel *v, const HvProbNode *nodes, int n, int which) {
+    float mx = -INFINITY;
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const HvProbPair p = prob_get(v, nodes, i);
+        if (p.cls != which) continue;
+        ++m;
+        if (p.logp > mx) mx = p.logp;
+    }
+    if (m == 0) return 0.0f;
+    float sum = 0.0f;
+    int32_t last = 0;
+    for (int step = 0; step < m; ++step) { // entries of this map in ascending id order
+        int pick = -1;
+        int32_t pid = 0;
+        float plp = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const HvProbPair p = prob_get(v, nodes, i);
+            if (p.cls != which || (step > 0 && p.obj <= last)) continue;
+            if (pick < 0 || p.obj < pid) {
+                pick = i;
+                pid = p.obj;
+                plp = p.logp;
+            }
+        }
+        if (pick < 0) break;
+        sum += hv_expf_cr(plp - mx);
+        last = pid;
+    }
+    return mx + hv_logf_cr(sum);
+}
+__host__ __device__ inline int32_t sem_object_id(const HvProb2Voxel *v, const void *nodes) { return prob2_most_likely(v, (const HvProbNode *)nodes, 0).id; }
+__host__ __device__ inline int32_t sem_class_id(const HvProb2Voxel *v, const void *nodes) { return prob2_most_likely(v, (const HvProbNode *)nodes, 1).id; }
+// compute_confidence(), :579-598: the normalised joint probability of (most likely object, most likely class)
+__host__ __device__ inline float sem_confidence(const HvProb2Voxel *v, const void *nodes_) {
+    const HvProbNode *nodes = (const HvProbNode *)nodes_;
+    const int n = prob_nlab(v->meta);
+    const HvProb2Best o = prob2_most_likely(v, nodes, 0), c = prob2_most_likely(v, nodes, 1);
+    if (o.id == -1 || c.id == -1) return 0.0f;
+    if (!o.any || !c.any) return 0.0f;
+    const float joint = o.lp + c.lp;
+    const float norm = prob2_log_normalization(v, nodes, n, 0) + prob2_log_normalization(v, nodes, n, 1);
+    return hv_expf_cr(joint - norm);
+}
+// get_object_confidence / get_class_confidence, :528-560: the marginal probability of the most likely id
+__host__ __device__ inline float prob2_marginal_confidence(const HvProb2Voxel *v, const void *nodes_, int which) {
+    const HvProbNode *nodes = (const HvProbNode *)nodes_;
+    const HvProb2Best b = prob2_most_likely(v, nodes, which);
+    if (!b.any || b.id == -1) return 0.0f;
+    return hv_expf_cr(b.lp - prob2_log_normalization(v, nodes, prob_nlab(v->meta), which));
+}
+__host__ __device__ inline float sem_object_confidence(const HvProb2Voxel *v, const void *nodes) { return prob2_marginal_confidence(v, nodes, 0); }
+__host__ __device__ inline float sem_class_confidence(const HvProb2Voxel *v, const void *nodes) { return prob2_marginal_confidence(v, nodes, 1); }
+// (the two payloads without marginals answer -1: hv_dump_marginals_semantic)
+__host__ __device__ inline float sem_object_confidence(const HvSemVoxel *, const void * = nullptr) { return -1.0f; }
+__host__ __device__ inline float sem_class_confidence(const HvSemVoxel *, const void * = nullptr) { return -1.0f; }
+__host__ __device__ inline float sem_object_confidence(const HvProbVoxel *, const void * = nullptr) { return -1.0f; }
+__host__ __device__ inline float sem_class_confidence(const HvProbVoxel *, const void * = nullptr) { return -1.0f; }
+__host__ __device__ inline bool sem_confidence_not_negative(const HvProb2Voxel *v, const void *nodes_) {
+    const HvProbNode *nodes = (const HvProbNode *)nodes_;
+    const int n = prob_nlab(v->meta);
+    bool finite = true;
+    for (int i = 0; i < n; ++i) {
+        const float lp = prob_get(v, nodes, i).logp;
+        finite = finite && (lp - lp == 0.0f);
+    }
+    return finite ? true : sem_confidence(v, nodes_) >= 0.0f; // (all finite: exp(finite) or the 0 of an unlabelled voxel)
+}
+// get_confidence_counter(), :506-511
+__host__ __device__ inline int32_t sem_confidence_counter(const HvProb2Voxel *v, const void *nodes) {
+    return (int32_t)(sem_confidence(v, nodes) * (float)v->count);
+}
+
+#ifdef __HIPCC__
+// entry `n` (the next free index) of a label list gets (obj, cls, lp): inline, or in the chain's node (n - K) / NK, which may have to be
+// linked in first (a chain left behind by a reset or collapsed map is taken up again).  false: 254 entries, or the node pool is exhausted.
+// (the node pool comes as three scalars, not as `const HvTable &`: where one of these functions is not inlined, the address of the
+// kernel's by-value table would escape into the call and the whole struct would be spilled to scratch memory at the kernel's entry)
+struct HvNodePool {
+    HvProbNode *nodes;
+    int32_t *counters;
+    int32_t cap;
+};
+__device__ __forceinline__ HvNodePool hv_node_pool(const HvTable &table) { return {(HvProbNode *)table.prob_nodes, table.counters, table.prob_node_cap}; }
+template <bool CHAIN>
+__device__ inline bool prob_append_t(HvProbVoxel *v, HvNodePool pool, int n, int32_t obj, int32_t cls, float lp) {
+    HvProbNode *nodes = pool.nodes;
+    if (n >= HV_PROB_MAX) return false;
+    if (!CHAIN || n < HV_PROB_K) {
+        prob_slot_set(v, n, obj, cls, lp);
+        return true;
+    }
+    if ((n - HV_PROB_K) % HV_PROB_NK == 0) {
+        const int hops = (n - HV_PROB_K) / HV_PROB_NK;
+        HvProbNode *tail = nullptr;
+        if (hops > 0) {
+            uint32_t k = v->next;
+            for (int hop = hops - 1; hop > 0; --hop) k = nodes[k - 1].next;
+            tail = &nodes[k - 1];
+        }
+        const uint32_t own_next = v->next;
+        if ((tail ? tail->next : own_next) == 0u) {
+            if (nodes == nullptr) return false;
+            const int32_t id = atomicAdd(&pool.counters[HV_CNT_PROB_NODES], 1);
+            if (id >= pool.cap) {
+                atomicSub(&pool.counters[HV_CNT_PROB_NODES], 1);
+                return false;
+            }
+            nodes[id].next = 0u;
+            if (tail) tail->next = (uint32_t)id + 1u;
+            v->next = tail ? own_next : (uint32_t)id + 1u;
+        }
+    }
+    int j = n;
+    HvProbNode *nd = (HvProbNode *)prob_node_of(v, nodes, j);
+    nd->obj[j] = obj;
+    nd->cls[j] = cls;
+    nd->logp[j] = lp;
+    return true;
+}
+// entry (id, which) of the list, -1 if there is none
+template <bool CHAIN>
+__device__ __forceinline__ int prob2_find(const HvProbVoxel *v, const HvProbNode *nodes, int n, int32_t id, int32_t which) {
+    int idx = -1;
+#pragma unroll
+    for (int i = 0; i < HV_PROB_K; ++i) {
+        const bool hit = (int)(v->obj[i] == id) & (int)(v->cls[i] == which) & (int)(i < n);
+        idx = hit ? i : idx;
+    }
+    if (CHAIN)
+        for (int i = HV_PROB_K; i < n; ++i) {
+            int j = i;
+            const HvProbNode *nd = prob_node_of(v, nodes, j);
+            if (nd->obj[j] == id && nd->cls[j] == which) idx = i;
+        }
+    return idx;
+}
+// initialize_semantics_log_prob (first: the entries are ASSIGNED half the log-probability and become the cached most likely ones,
+// :311-326) / update_semantics_log_prob (found: += half, new: = half; both caches dropped, :339-369).  Returns the number of entries that
+// could not be stored (0-2).
+template <bool CHAIN>
+__device__ inline int prob2_fold_t(HvProbVoxel *v, HvNodePool table, bool first, int32_t obj, int32_t cls, float lp) {
+    HvProbNode *nodes = table.nodes;
+    int n = prob_nlab(v->meta);
+    const float half = lp * 0.5f;
+    int lost = 0;
+    int io = prob2_find<CHAIN>(v, nodes, n, obj, 0);
+    if (io < 0) {
+        if (prob_append_t<CHAIN>(v, table, n, obj, 0, half)) io = n++;
+        else ++lost;
+    } else {
+        prob_set_logp_r<CHAIN>(v, nodes, io, first ? half : prob_get_r<CHAIN>(v, nodes, io).logp + half);
+    }
+    int ic = prob2_find<CHAIN>(v, nodes, n, cls, 1);
+    if (ic < 0) {
+        if (prob_append_t<CHAIN>(v, table, n, cls, 1, half)) ic = n++;
+        else ++lost;
+    } else {
+        prob_set_logp_r<CHAIN>(v, nodes, ic, first ? half : prob_get_r<CHAIN>(v, nodes, ic).logp + half);
+    }
+    v->meta = first ? prob2_meta(n, io, ic) : prob2_meta(n, -1, -1);
+    return lost;
+}
+__device__ __forceinline__ int prob2_fold(HvProbVoxel *v, const HvTable &table, bool first, int32_t obj, int32_t cls, float lp) {
+    const HvNodePool pool = hv_node_pool(table);
+    return prob_nlab(v->meta) + 2 <= HV_PROB_K ? prob2_fold_t<false>(v, pool, first, obj, cls, lp) : prob2_fold_t<true>(v, pool, first, obj, cls, lp);
+}
+// set_object_id(), :424-452 (merge_segments, the association's deferred assignment): the id's entry takes the log-probability of the
+// current most likely object (0 when there is none) and becomes the cached most likely one; the class cache is recomputed.
+__device__ inline void prob2_set_object_id(HvProb2Voxel *v, HvNodePool table, int32_t id) {
+    HvProbNode *nodes = table.nodes;
+    int n = prob_nlab(v->meta);
+    const HvProb2Best b = prob2_most_likely(v, nodes, 0);
+    const float target = (b.any && b.id != -1 && b.lp != -INFINITY) ? b.lp : 0.0f;
+    int io = prob2_find<true>(v, nodes, n, id, 0);
+    if (io < 0) {
+        if (prob_append_t<true>(v, table, n, id, 0, target)) {
+            io = n++;
+        } else {
+            atomicAdd(&table.counters[HV_CNT_LABEL_OVERFLOW], 1);
+        }
+    } else {
+        prob_set_logp<true>(v, nodes, io, target);
+    }
+    v->meta = prob2_meta(n, io, -1);
+}
+__device__ __forceinline__ void sem_set_object_id(HvProb2Voxel *v, const HvTable &table, int32_t id) { prob2_set_object_id(v, hv_node_pool(table), id); }
+#endif
+
 // log evidence of one observation: update_semantics / update_semantics_with_depth,
 // voxel_data_semantic.h:419-447
 __host__ __device__ inline float prob_observation_log_prob(bool has_depth, float depth, const HvSemParams &G) {
@@ -401,6 +711,19 @@ __host__ __device__ inline float prob_observation_log_prob(bool has_depth, float
     const float confidence = hv_expf_cr(-(depth - G.depth_threshold) * G.depth_decay_rate);
     return confidence * HV_BASE_LOG_PROB;
 }
+// the "*2" probabilistic payload: update_semantics (confidence 1: log 1 = 0) / update_semantics_with_depth, voxel_data_semantic2.h:371-388
+// (no BASE_LOG_PROB_PER_OBSERVATION there)
+__host__ __device__ inline float prob2_observation_log_prob(bool has_depth, float depth, const HvSemParams &G) {
+    if (!has_depth) return hv_logf_cr(1.0f);
+    return depth <= G.depth_threshold ? 0.0f : -(depth - G.depth_threshold) * G.depth_decay_rate;
+}
+
+// which payload a voxel type is (the kernels are templates over the four; `maps`: the record is HvProbVoxel's, with an overflow chain)
+template <typename VOX> struct HvPay;
+template <> struct HvPay<HvSemVoxel> { static constexpr int kind = 0; static constexpr bool maps = false; };
+template <> struct HvPay<HvProbVoxel> { static constexpr int kind = 1; static constexpr bool maps = true; };
+template <> struct HvPay<HvSem2Voxel> { static constexpr int kind = 2; static constexpr bool maps = false; };
+template <> struct HvPay<HvProb2Voxel> { static constexpr int kind = 3; static constexpr bool maps = true; };
 
 // The occupancy bit of voxel `gid` (pool order): false = the voxel never took a point, its record need not be read.  The lanes
 // of a wave ask for 64 consecutive voxels: one 8-byte word.
@@ -493,5 +816,13 @@ static inline HvSemParams sem_params(const hv_volume *v) {
     return G;
 }
 static inline bool hv_is_semantic(const hv_volume *v) {
-    return v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID || v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID;
+    return hv_mode_is_semantic(v->cfg.mode);
 }
+// the statement(s) given, with VOX = the voxel type of the volume's mode
+#define HV_SEM_DISPATCH(v, ...)                                                                                                            \
+    switch ((v)->cfg.mode) {                                                                                                               \
+    case HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID: { using VOX = HvProbVoxel; __VA_ARGS__; } break;                                       \
+    case HV_MODE_VOXEL_SEMANTIC_GRID2: { using VOX = HvSem2Voxel; __VA_ARGS__; } break;                                                    \
+    case HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID2: { using VOX = HvProb2Voxel; __VA_ARGS__; } break;                                     \
+    default: { using VOX = HvSemVoxel; __VA_ARGS__; } break;                                                                               \
+    }

@@ -172,8 +172,8 @@ struct HvSemStaged {
 static constexpr int HV_SEMB_STAGE = 128; // bins up to this size fold from staged records (32 bytes each in the sort's spare windows)
 
 // update_voxel_direct (voxel_block_grid.hpp:524-614) for a SemanticVoxelWithDepth payload: one voxel's points folded in
-// point-index order.  `next(j)` yields the point index of the run's j-th entry, or -1 at its end.  VOX = HvSemVoxel (voting) or
-// HvProbVoxel (probabilistic).
+// point-index order.  `next(j)` yields the point index of the run's j-th entry, or -1 at its end.  VOX = HvSemVoxel (voting),
+// HvProbVoxel (probabilistic) or one of the two "*2" payloads (hv_semantic.h).
 template <typename VOX, typename SRC, typename Next>
 __device__ __forceinline__ void sem_fold_run(const HvTable &table, VOX *__restrict__ pool, int64_t vid, const HvSemParams &G,
                                              const SRC &src, unsigned long long *__restrict__ occ, Next next) {
@@ -198,7 +198,7 @@ __device__ __forceinline__ void sem_fold_run(const HvTable &table, VOX *__restri
         }
         if (labels) {
             const int32_t obj = q.obj, cls = q.cls;
-            if constexpr (sizeof(VOX) == sizeof(HvSemVoxel)) {
+            if constexpr (HvPay<VOX>::kind == 0) {
                 HvSemVoxel *sv = (HvSemVoxel *)&acc;
                 const bool gate = with_depth ? (q.depth < G.depth_threshold) : true; // *_with_depth, voxel_data_semantic.h:168-198
                 if (count == 0) {
@@ -219,9 +219,13 @@ __device__ __forceinline__ void sem_fold_run(const HvTable &table, VOX *__restri
                         }
                     }
                 }
+            } else if constexpr (HvPay<VOX>::kind == 2) {
+                sem2_fold(&acc, count == 0, with_depth ? (q.depth < G.depth_threshold) : true, obj, cls);
+            } else if constexpr (HvPay<VOX>::kind == 3) {
+                overflowed += prob2_fold(&acc, table, count == 0, obj, cls, prob2_observation_log_prob(with_depth, q.depth, G));
             } else {
                 const float lp = prob_observation_log_prob(with_depth, q.depth, G);
-                if (!prob_fold((HvProbVoxel *)&acc, table, count == 0, obj, cls, lp)) ++overflowed;
+                if (!prob_fold(&acc, table, count == 0, obj, cls, lp)) ++overflowed;
             }
         }
         count = count == 0 ? 1 : count + 1;
@@ -859,7 +863,7 @@ static int sem_stage(hv_volume *v, const void *src, size_t bytes, int32_t loc, c
 template <typename VOX>
 static int sem_dump(hv_volume *v, int64_t nb, const std::vector<int64_t> &order, const std::vector<std::array<int32_t, 3>> &xyz,
                     int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums, int32_t *label_counts,
-                    int32_t *labels, float *log_probs, int32_t max_labels) {
+                    int32_t *labels, float *log_probs, int32_t max_labels, float *obj_conf, float *cls_conf) {
     const int nvox = sem_params(v).nvox;
     std::vector<VOX> host((size_t)nb * nvox);
     HV_HIP(hipMemcpy(host.data(), v->pool, sizeof(VOX) * host.size(), hipMemcpyDeviceToHost));
@@ -882,9 +886,11 @@ static int sem_dump(hv_volume *v, int64_t nb, const std::vector<int64_t> &order,
                 d[0] = x->count; d[1] = sem_object_id(x, nodes); d[2] = sem_class_id(x, nodes); d[3] = sem_confidence_counter(x, nodes);
             }
             if (conf) conf[at] = sem_confidence(x, nodes);
+            if (obj_conf) obj_conf[at] = sem_object_confidence(x, nodes);
+            if (cls_conf) cls_conf[at] = sem_class_confidence(x, nodes);
             if (pos_sums) memcpy(pos_sums + at * 3, x->pos, 24);
             if (col_sums) memcpy(col_sums + at * 3, x->col, 12);
-            if constexpr (sizeof(VOX) == sizeof(HvProbVoxel)) {
+            if constexpr (HvPay<VOX>::maps) { // (the "*2" payload: entries (id, which map) of its two marginal maps)
                 const HvProbVoxel *p = (const HvProbVoxel *)x;
                 const int nlab = prob_nlab(p->meta);
                 if (label_counts) label_counts[at] = nlab;
@@ -931,12 +937,8 @@ static int sem_run_collect(hv_volume *v, const HvQuery &Q, int32_t min_count, fl
     const dim3 grid((unsigned)std::min<int64_t>((nb + 3) / 4, 8192)); // a wave per block, grid-stride
     // (min_count <= 0 asks for voxels that never took a point as well: the occupancy bits cannot be used then)
     const unsigned long long *occ = min_count >= 1 ? v->occ : nullptr;
-    if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID)
-        hipLaunchKernelGGL(k_sem_collect<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvProbVoxel *)v->pool,
-                           nb, sem_params(v), Q, min_count, min_confidence, d_pts, d_cols, d_cls, d_obj, d_conf, want ? cap : 0, occ);
-    else
-        hipLaunchKernelGGL(k_sem_collect<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvSemVoxel *)v->pool,
-                           nb, sem_params(v), Q, min_count, min_confidence, d_pts, d_cols, d_cls, d_obj, d_conf, want ? cap : 0, occ);
+    HV_SEM_DISPATCH(v, hipLaunchKernelGGL(k_sem_collect<VOX>, grid, dim3(256), 0, v->stream, v->table, (const VOX *)v->pool, nb, sem_params(v), Q, min_count,
+                                          min_confidence, d_pts, d_cols, d_cls, d_obj, d_conf, want ? cap : 0, occ));
     HV_HIP(hipGetLastError());
     rc = hv_read_counters(v);
     if (rc != HV_OK) return rc;
@@ -1015,19 +1017,13 @@ int hv_integrate_points_semantic(hv_volume *v, const void *points, int32_t point
     if (rc == HV_OK) rc = sem_stage(v, instance_ids, 4 * (size_t)n, loc, cursor, &d_inst);
     if (rc == HV_OK) rc = sem_stage(v, depths, 4 * (size_t)n, loc, cursor, &d_dep);
     if (rc != HV_OK) return rc;
-    const bool prob = v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID;
     if (point_dtype == 1) {
-        if (prob)
-            return sem_integrate<HvProbVoxel, double>(v, (const double *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
-                                                      (const int32_t *)d_inst, (const float *)d_dep);
-        return sem_integrate<HvSemVoxel, double>(v, (const double *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
-                                                 (const int32_t *)d_inst, (const float *)d_dep);
+        HV_SEM_DISPATCH(v, return sem_integrate<VOX, double>(v, (const double *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls, (const int32_t *)d_inst,
+                                                             (const float *)d_dep));
     }
-    if (prob)
-        return sem_integrate<HvProbVoxel, float>(v, (const float *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
-                                                 (const int32_t *)d_inst, (const float *)d_dep);
-    return sem_integrate<HvSemVoxel, float>(v, (const float *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls,
-                                            (const int32_t *)d_inst, (const float *)d_dep);
+    HV_SEM_DISPATCH(v, return sem_integrate<VOX, float>(v, (const float *)d_pts, n, d_cols, color_dtype, (const int32_t *)d_cls, (const int32_t *)d_inst,
+                                                        (const float *)d_dep));
+    return HV_OK; // (not reached)
 }
 
 int hv_integrate_rgbd_semantic(hv_volume *v, const float *depth, const uint8_t *rgb, const int32_t *class_ids_image,
@@ -1064,7 +1060,6 @@ int hv_integrate_rgbd_semantic(hv_volume *v, const float *depth, const uint8_t *
         }
         if ((rc = hv_h2d_fence(v, pinned_src)) != HV_OK) return rc;
     }
-    const bool prob = v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID;
     if (sem_bins_usable(v, npx)) {
         // production: the bin pass unprojects the pixel itself and leaves a 32-byte record per point for the fold
         bool checked = false;
@@ -1079,18 +1074,15 @@ int hv_integrate_rgbd_semantic(hv_volume *v, const float *depth, const uint8_t *
                                (const uint8_t *)d_rgb, d_cls, d_obj, (float4 *)v->bin_rec);
         };
         const HvSemRecs src{(const float4 *)v->bin_rec, nullptr, d_cls != nullptr, use_depths != 0};
-        return prob ? sem_bins_run<HvProbVoxel>(v, npx, checked, src, bin) : sem_bins_run<HvSemVoxel>(v, npx, checked, src, bin);
+        HV_SEM_DISPATCH(v, return sem_bins_run<VOX>(v, npx, checked, src, bin));
     }
     // (inputs beyond the bin path's limits: unprojected rows, then the radix path)
     rc = hv_unproject_frame(v, d_depth, HV_DEPTH_F32, 1.0, (const uint8_t *)d_rgb, height, width, intr, T_cw, min_depth, max_depth, HV_DEVICE, nullptr);
     if (rc != HV_OK) return rc;
     // depths = camera z of the point = the pixel's depth (…voxel_semantic_grid.py:418-424)
     const float *d_depths = use_depths ? (const float *)d_depth : nullptr;
-    if (prob)
-        return sem_integrate<HvProbVoxel, float>(v, v->scratch_points, npx, v->scratch_colors, HV_COLOR_F32, d_cls, d_obj, d_depths,
-                                                 v->sort_keys_out);
-    return sem_integrate<HvSemVoxel, float>(v, v->scratch_points, npx, v->scratch_colors, HV_COLOR_F32, d_cls, d_obj, d_depths,
-                                            v->sort_keys_out);
+    HV_SEM_DISPATCH(v, return sem_integrate<VOX, float>(v, v->scratch_points, npx, v->scratch_colors, HV_COLOR_F32, d_cls, d_obj, d_depths, v->sort_keys_out));
+    return HV_OK; // (not reached)
 }
 
 int hv_get_voxels_semantic(hv_volume *v, int32_t min_count, float min_confidence, double *points, float *colors,
@@ -1129,15 +1121,15 @@ int hv_get_voxels_semantic_in_frustum(hv_volume *v, const float *intr_f32, int32
     return sem_run_collect(v, Q, min_count, min_confidence, points, colors, class_ids, object_ids, confidences, cap, n);
 }
 
-int hv_dump_blocks_semantic2(hv_volume *v, int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums,
-                             int32_t *label_counts, int32_t *labels, float *log_probs, int32_t max_labels, int64_t *n_blocks) {
+static int sem_dump_blocks(hv_volume *v, int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums, int32_t *label_counts,
+                           int32_t *labels, float *log_probs, int32_t max_labels, float *obj_conf, float *cls_conf, int64_t *n_blocks) {
     HV_REQUIRE(v != nullptr && n_blocks != nullptr && max_labels >= 0, HV_ERR_INVALID, "hv_dump_blocks_semantic: null argument");
     HV_REQUIRE(hv_is_semantic(v), HV_ERR_MODE, "hv_dump_blocks_semantic: wrong mode");
     int64_t nb = 0;
     int rc = hv_num_blocks(v, &nb);
     if (rc != HV_OK) return rc;
     *n_blocks = nb;
-    if (nb == 0 || (!keys && !ints && !conf && !pos_sums && !col_sums && !label_counts && !labels && !log_probs)) return HV_OK;
+    if (nb == 0 || (!keys && !ints && !conf && !pos_sums && !col_sums && !label_counts && !labels && !log_probs && !obj_conf && !cls_conf)) return HV_OK;
     std::vector<uint64_t> bkeys((size_t)nb);
     HV_HIP(hipMemcpy(bkeys.data(), v->table.block_keys, sizeof(uint64_t) * nb, hipMemcpyDeviceToHost));
     std::vector<std::array<int32_t, 3>> xyz((size_t)nb);
@@ -1145,9 +1137,17 @@ int hv_dump_blocks_semantic2(hv_volume *v, int32_t *keys, int32_t *ints, float *
     std::vector<int64_t> order((size_t)nb);
     std::iota(order.begin(), order.end(), 0);
     std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return xyz[a] < xyz[b]; });
-    if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID)
-        return sem_dump<HvProbVoxel>(v, nb, order, xyz, keys, ints, conf, pos_sums, col_sums, label_counts, labels, log_probs, max_labels);
-    return sem_dump<HvSemVoxel>(v, nb, order, xyz, keys, ints, conf, pos_sums, col_sums, label_counts, labels, log_probs, max_labels);
+    HV_SEM_DISPATCH(v, return sem_dump<VOX>(v, nb, order, xyz, keys, ints, conf, pos_sums, col_sums, label_counts, labels, log_probs, max_labels, obj_conf, cls_conf));
+    return HV_OK; // (not reached)
+}
+
+int hv_dump_blocks_semantic2(hv_volume *v, int32_t *keys, int32_t *ints, float *conf, double *pos_sums, float *col_sums,
+                             int32_t *label_counts, int32_t *labels, float *log_probs, int32_t max_labels, int64_t *n_blocks) {
+    return sem_dump_blocks(v, keys, ints, conf, pos_sums, col_sums, label_counts, labels, log_probs, max_labels, nullptr, nullptr, n_blocks);
+}
+
+int hv_dump_marginals_semantic(hv_volume *v, float *object_confidences, float *class_confidences, int64_t *n_blocks) {
+    return sem_dump_blocks(v, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, object_confidences, class_confidences, n_blocks);
 }
 
 int hv_dump_blocks_semantic(hv_volume *v, int32_t *keys, int32_t *ints, double *pos_sums, float *col_sums,

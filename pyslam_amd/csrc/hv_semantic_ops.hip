@@ -57,10 +57,10 @@ static int hv_dev_next_id(int device, int32_t **out) {
 template <typename VOX> __device__ __forceinline__ void sem_reset(VOX *v) {
     uint4 *q = (uint4 *)v;
     uint32_t chain = 0u; // a probabilistic voxel keeps its overflow nodes for the label map it grows next
-    if constexpr (sizeof(VOX) == sizeof(HvProbVoxel)) chain = ((const HvProbVoxel *)v)->next;
+    if constexpr (HvPay<VOX>::maps) chain = ((const HvProbVoxel *)v)->next;
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(VOX) / 16); ++i) q[i] = make_uint4(0u, 0u, 0u, 0u);
-    if constexpr (sizeof(VOX) == sizeof(HvProbVoxel)) {
+    if constexpr (HvPay<VOX>::maps) {
         if (chain != 0u) ((HvProbVoxel *)v)->next = chain;
     }
 }
@@ -134,6 +134,63 @@ __device__ __forceinline__ HvVoteHot vote_hot(const HvProbVoxel *v, const void *
         h.obj = p.obj;
         h.conf_ok = true;
     } else { // overflow nodes / no cached best pair / a NaN or an infinity in the map
+        h.cls = sem_class_id(v, nodes);
+        h.obj = sem_object_id(v, nodes);
+        h.conf_ok = sem_confidence_not_negative(v, nodes);
+    }
+    return h;
+}
+__device__ __forceinline__ HvVoteHot vote_hot(const HvSem2Voxel *v, const void *) {
+    const uint4 a = *(const uint4 *)v; // count, obj1, cls1, obj_counter
+    HvVoteHot h;
+    h.count = (int32_t)a.x;
+    h.obj = (int32_t)a.y - 1;
+    h.cls = (int32_t)a.z - 1;
+    h.pos[0] = v->pos[0];
+    h.pos[1] = v->pos[1];
+    h.pos[2] = v->pos[2];
+    // get_confidence() >= 0: the smaller of the two counter / count ratios, each clamped to 1 (0 for an empty voxel)
+    const float o = sem2_ratio((int32_t)a.w, h.count), c = sem2_ratio(v->cls_counter, h.count);
+    h.conf_ok = h.count == 0 || (c < o ? c : o) >= 0.0f;
+    return h;
+}
+__device__ __forceinline__ HvVoteHot vote_hot(const HvProb2Voxel *v, const void *nodes_) {
+    const HvProbNode *nodes = (const HvProbNode *)nodes_;
+    const HvProbVoxel r = *v;
+    HvVoteHot h;
+    h.count = r.count;
+    h.pos[0] = r.pos[0];
+    h.pos[1] = r.pos[1];
+    h.pos[2] = r.pos[2];
+    const int n = prob_nlab(r.meta);
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < HV_PROB_K; ++k) {
+        const float lp = r.logp[k];
+        finite = finite && (k >= n || lp - lp == 0.0f);
+    }
+    if (n == 0) {
+        h.cls = h.obj = -1;
+        h.conf_ok = true;
+    } else if (n <= HV_PROB_K && finite) { // the common case: both most likely ids from the copy (cached entry, else the argmax of its map)
+        auto most_likely = [&](int which, int c) { // (scalars only: nothing of the copy may be reached through a run-time index)
+            int32_t id = -1;
+            float lp = -INFINITY;
+            bool won = false;
+#pragma unroll
+            for (int k = 0; k < HV_PROB_K; ++k) {
+                const bool mine = k < n && r.cls[k] == which;
+                const bool take = mine && (c >= 0 ? k == c : (r.logp[k] > lp || (won && r.logp[k] == lp && r.obj[k] < id)));
+                id = take ? r.obj[k] : id;
+                lp = take ? r.logp[k] : lp;
+                won = won || take;
+            }
+            return id;
+        };
+        h.obj = most_likely(0, prob2_best_obj(r.meta));
+        h.cls = most_likely(1, prob2_best_cls(r.meta));
+        h.conf_ok = true;
+    } else { // overflow nodes / a NaN or an infinity in the maps
         h.cls = sem_class_id(v, nodes);
         h.obj = sem_object_id(v, nodes);
         h.conf_ok = sem_confidence_not_negative(v, nodes);
@@ -369,7 +426,7 @@ __global__ __launch_bounds__(256, MINWG) void k_sem_assoc_vote(HvTable table, VO
                     if (obj < 0) {
                         if (inst == 0) {
                             obj = 0;
-                            sem_set_object_id(v, table.prob_nodes, 0);
+                            sem_set_object_id(v, table, 0);
                         } else {
                             obj = HV_OBJ_PENDING;
                             is_pending = true;
@@ -656,7 +713,7 @@ __global__ __launch_bounds__(256) void k_sem_assoc_apply(HvTable table, VOX *__r
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pending; i += gridDim.x * blockDim.x) {
         const int2 p = pending[i];
         const int32_t final_id = map_lookup(map_inst, map_obj, n_map, p.y, -1);
-        if (final_id >= 0) sem_set_object_id(pool + p.x, table.prob_nodes, final_id);
+        if (final_id >= 0) sem_set_object_id(pool + p.x, table, final_id);
     }
 }
 
@@ -751,14 +808,15 @@ __global__ __launch_bounds__(256) void k_seg_rows(const VOX *__restrict__ pool, 
 // op 0 merge_segments(a <- b), 1 remove_segment(a), 2 remove_low_confidence_segments(int a),
 // 3 remove_low_count_voxels(a), 4 remove_low_confidence_voxels(fa)
 template <typename VOX>
-__global__ __launch_bounds__(256) void k_sem_segment_op(VOX *__restrict__ pool, int64_t n_voxels, int op, int32_t a, int32_t b,
-                                                         float fa, const unsigned long long *__restrict__ occ, const void *__restrict__ nodes) {
+__global__ __launch_bounds__(256) void k_sem_segment_op(HvTable table, VOX *__restrict__ pool, int64_t n_voxels, int op, int32_t a, int32_t b,
+                                                         float fa, const unsigned long long *__restrict__ occ) {
+    const void *nodes = table.prob_nodes;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_voxels) return;
     if (!sem_maybe_occupied(occ, gid)) return; // a voxel that never took a point: every op leaves its zero record as it is
     VOX *v = pool + gid;
     if (op == 0) {
-        if (sem_object_id(v, nodes) == b) sem_set_object_id(v, nodes, a);
+        if (sem_object_id(v, nodes) == b) sem_set_object_id(v, table, a);
     } else if (op == 1) {
         if (sem_object_id(v, nodes) == a) sem_reset(v);
     } else if (op == 2) {
@@ -963,13 +1021,11 @@ template <typename VOX> int sem_launch_segment_op(hv_volume *v, int op, int32_t 
     if (rc != HV_OK) return rc;
     if (nb == 0) return HV_OK;
     const int64_t total = nb * sem_params(v).nvox;
-    hipLaunchKernelGGL(k_sem_segment_op<VOX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, (VOX *)v->pool,
-                       total, op, a, b, fa, (op == 0 && b < 0) ? nullptr : v->occ, (const void *)v->table.prob_nodes); // (merging INTO the voxels without an object id reaches empty ones too)
+    hipLaunchKernelGGL(k_sem_segment_op<VOX>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, v->stream, v->table, (VOX *)v->pool,
+                       total, op, a, b, fa, (op == 0 && b < 0) ? nullptr : v->occ); // (merging INTO the voxels without an object id reaches empty ones too)
     HV_HIP(hipGetLastError());
     return HV_OK;
 }
-
-bool is_prob(const hv_volume *v) { return v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID; }
 
 } // namespace
 
@@ -978,16 +1034,14 @@ void hv_segments_cache_free(void *cache) { delete static_cast<HvSegmentsCache *>
 int hv_sem_carve(hv_volume *v, const HvQuery &Q, const float *d_depth, int64_t nb) {
     const HvSemParams G = sem_params(v);
     const dim3 grid((unsigned)std::min<int64_t>((nb + 3) / 4, 8192)); // a wave per block, grid-stride
-    if (is_prob(v))
-        hipLaunchKernelGGL(k_sem_carve<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, nb, G, Q, d_depth, v->occ);
-    else
-        hipLaunchKernelGGL(k_sem_carve<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, nb, G, Q, d_depth, v->occ);
+    HV_SEM_DISPATCH(v, hipLaunchKernelGGL(k_sem_carve<VOX>, grid, dim3(256), 0, v->stream, v->table, (VOX *)v->pool, nb, G, Q, d_depth, v->occ));
     HV_HIP(hipGetLastError());
     return HV_OK;
 }
 
 int hv_sem_segment_op(hv_volume *v, int op, int32_t a, int32_t b, float fa) {
-    return is_prob(v) ? sem_launch_segment_op<HvProbVoxel>(v, op, a, b, fa) : sem_launch_segment_op<HvSemVoxel>(v, op, a, b, fa);
+    HV_SEM_DISPATCH(v, return sem_launch_segment_op<VOX>(v, op, a, b, fa));
+    return HV_OK; // (not reached)
 }
 
 int hv_sem_size(hv_volume *v, int64_t *n) {
@@ -1000,10 +1054,7 @@ int hv_sem_size(hv_volume *v, int64_t *n) {
     const int nvox = sem_params(v).nvox;
     HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
     const dim3 grid((unsigned)std::min<int64_t>((nb + 3) / 4, 8192));
-    if (is_prob(v))
-        hipLaunchKernelGGL(k_sem_count_nonempty<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvProbVoxel *)v->pool, nb, nvox, v->occ);
-    else
-        hipLaunchKernelGGL(k_sem_count_nonempty<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvSemVoxel *)v->pool, nb, nvox, v->occ);
+    HV_SEM_DISPATCH(v, hipLaunchKernelGGL(k_sem_count_nonempty<VOX>, grid, dim3(256), 0, v->stream, v->table, (const VOX *)v->pool, nb, nvox, v->occ));
     HV_HIP(hipGetLastError());
     rc = hv_read_counters(v);
     if (rc != HV_OK) return rc;
@@ -1174,7 +1225,6 @@ int hv_assoc_vote(hv_volume *v, const float *intr_f32, int32_t width, int32_t he
     A.depth_threshold = depth_threshold;
     A.pending_cap = (int32_t)std::min<int64_t>(S.pending_cap, INT32_MAX);
     v->assoc_pending_cap = A.pending_cap;
-    const bool prob = is_prob(v);
     { // (always: nb >= 1, and the kernel scans the image as well)
         HvQuery Q;
         memset(&Q, 0, sizeof(Q));
@@ -1191,12 +1241,9 @@ int hv_assoc_vote(hv_volume *v, const float *intr_f32, int32_t width, int32_t he
         const dim3 grid((unsigned)std::min<int64_t>((nb + 3) / 4, 4096)); // persistent: 16 workgroups per CU
         // the probabilistic payload's copy of the record takes 149 registers: three workgroups per CU, nothing spilled (measured
         // against four with 13 spilled registers: the vote 13 % slower, round 6); the voting payload fits four
-        if (prob)
-            hipLaunchKernelGGL((k_sem_assoc_vote<HvProbVoxel, 3>), grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, (int64_t)-1, G, Q, d_cls, d_inst,
-                               d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ, n_px);
-        else
-            hipLaunchKernelGGL((k_sem_assoc_vote<HvSemVoxel, 4>), grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, (int64_t)-1, G, Q, d_cls, d_inst,
-                               d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ, n_px);
+        // (the 128-byte records - HvPay<VOX>::maps - take three, the 64-byte ones four)
+        HV_SEM_DISPATCH(v, hipLaunchKernelGGL((k_sem_assoc_vote<VOX, HvPay<VOX>::maps ? 3 : 4>), grid, dim3(256), 0, v->stream, v->table, (VOX *)v->pool, (int64_t)-1, G, Q,
+                                              d_cls, d_inst, d_depth, A, S.vkeys, S.vcounts, S.pending, v->occ, n_px));
     }
     hipLaunchKernelGGL(k_sem_assoc_compact, dim3(HV_VOTE_CAP / 256), dim3(256), 0, v->stream, v->table, S.vkeys, S.vcounts, S.ckeys,
                        S.ccounts);
@@ -1296,12 +1343,8 @@ int hv_assoc_decide(hv_volume *v, float min_vote_ratio, int32_t min_votes) {
     hipLaunchKernelGGL(k_sem_assoc_rules, dim3(1), dim3(1024), 0, v->stream, v->table, S.ckeys, S.ccounts, min_vote_ratio, min_votes, d_next,
                        S.map_inst, S.map_obj, S.n_map, S.flags);
     const dim3 grid(256);
-    if (is_prob(v))
-        hipLaunchKernelGGL(k_sem_assoc_apply<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvProbVoxel *)v->pool, S.pending,
-                           v->assoc_pending_cap, S.map_inst, S.map_obj, S.n_map, S.flags, v->d_status);
-    else
-        hipLaunchKernelGGL(k_sem_assoc_apply<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (HvSemVoxel *)v->pool, S.pending,
-                           v->assoc_pending_cap, S.map_inst, S.map_obj, S.n_map, S.flags, v->d_status);
+    HV_SEM_DISPATCH(v, hipLaunchKernelGGL(k_sem_assoc_apply<VOX>, grid, dim3(256), 0, v->stream, v->table, (VOX *)v->pool, S.pending, v->assoc_pending_cap, S.map_inst,
+                                          S.map_obj, S.n_map, S.flags, v->d_status));
     HV_HIP(hipGetLastError());
     v->assoc_state = 2;
     return HV_OK;
@@ -1447,7 +1490,6 @@ int hv_object_segments_compute(hv_volume *v, int32_t min_count, float min_confid
     int rc = hv_num_blocks(v, &nb);
     if (rc != HV_OK) return rc;
     if (nb == 0) return HV_OK;
-    const bool prob = is_prob(v);
     const int nvox = sem_params(v).nvox;
     const dim3 grid((unsigned)std::min<int64_t>((nb + 3) / 4, 8192));
     // pass 1: count; pass 2: emit (object id, voxel index) keys
@@ -1461,12 +1503,8 @@ int hv_object_segments_compute(hv_volume *v, int32_t min_count, float min_confid
         }
         HV_HIP(hipMemsetAsync(&v->table.counters[HV_CNT_OUT], 0, sizeof(int32_t), v->stream));
         // (min_count < 0 would admit voxels that never took a point: no occupancy bits then)
-        if (prob)
-            hipLaunchKernelGGL(k_seg_collect<HvProbVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvProbVoxel *)v->pool, nb, nvox,
-                               min_count, min_confidence, d_keys, m, min_count >= 0 ? v->occ : nullptr);
-        else
-            hipLaunchKernelGGL(k_seg_collect<HvSemVoxel>, grid, dim3(256), 0, v->stream, v->table, (const HvSemVoxel *)v->pool, nb, nvox,
-                               min_count, min_confidence, d_keys, m, min_count >= 0 ? v->occ : nullptr);
+        HV_SEM_DISPATCH(v, hipLaunchKernelGGL(k_seg_collect<VOX>, grid, dim3(256), 0, v->stream, v->table, (const VOX *)v->pool, nb, nvox, min_count, min_confidence, d_keys, m,
+                                              min_count >= 0 ? v->occ : nullptr));
         HV_HIP(hipGetLastError());
         rc = hv_read_counters(v);
         if (rc != HV_OK) return rc;
@@ -1488,12 +1526,8 @@ int hv_object_segments_compute(hv_volume *v, int32_t min_count, float min_confid
     int32_t *d_cls = d_obj + m;
     float *d_conf = (float *)(d_cls + m);
     const dim3 rgrid((unsigned)((m + 255) / 256));
-    if (prob)
-        hipLaunchKernelGGL(k_seg_rows<HvProbVoxel>, rgrid, dim3(256), 0, v->stream, (const HvProbVoxel *)v->pool, d_sorted, m, d_pts,
-                           d_cols, d_obj, d_cls, d_conf, (const void *)v->table.prob_nodes);
-    else
-        hipLaunchKernelGGL(k_seg_rows<HvSemVoxel>, rgrid, dim3(256), 0, v->stream, (const HvSemVoxel *)v->pool, d_sorted, m, d_pts,
-                           d_cols, d_obj, d_cls, d_conf, (const void *)nullptr);
+    HV_SEM_DISPATCH(v, hipLaunchKernelGGL(k_seg_rows<VOX>, rgrid, dim3(256), 0, v->stream, (const VOX *)v->pool, d_sorted, m, d_pts, d_cols, d_obj, d_cls, d_conf,
+                                          (const void *)v->table.prob_nodes));
     HV_HIP(hipGetLastError());
     C.pts.resize((size_t)m * 3);
     C.cols.resize((size_t)m * 3);

@@ -1264,7 +1264,7 @@ int hv_get_voxels_in_frustum(hv_volume *v, const float *intr_f32, int32_t width,
 int hv_carve(hv_volume *v, const float *intr_f32, int32_t width, int32_t height, const double *T_cw, float depth_max,
              float depth_min, const float *depth, float depth_threshold, int32_t loc) {
     HV_REQUIRE(v != nullptr && intr_f32 != nullptr && T_cw != nullptr, HV_ERR_INVALID, "hv_carve: null argument");
-    const bool semantic = v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID || v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID;
+    const bool semantic = hv_mode_is_semantic(v->cfg.mode);
     HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_GRID || semantic, HV_ERR_MODE, "hv_carve: volume is not a voxel grid");
     if (depth == nullptr || width <= 0 || height <= 0) return HV_OK; // "Depth image is empty": reference returns
     HV_HIP(hipSetDevice(v->device));
@@ -1293,7 +1293,7 @@ int hv_carve(hv_volume *v, const float *intr_f32, int32_t width, int32_t height,
 
 int hv_remove_low_count_voxels(hv_volume *v, int32_t min_count) {
     HV_REQUIRE(v != nullptr, HV_ERR_INVALID, "hv_remove_low_count_voxels: null volume");
-    if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID || v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID)
+    if (hv_mode_is_semantic(v->cfg.mode))
         return hv_sem_segment_op(v, 3, min_count, 0, 0.f);
     HV_REQUIRE(v->cfg.mode == HV_MODE_VOXEL_GRID, HV_ERR_MODE, "hv_remove_low_count_voxels: not a voxel grid");
     HV_HIP(hipSetDevice(v->device));
@@ -1310,7 +1310,7 @@ int hv_remove_low_count_voxels(hv_volume *v, int32_t min_count) {
 
 int hv_size(hv_volume *v, int64_t *n) {
     HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_size: null argument");
-    if (v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_GRID || v->cfg.mode == HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID) return hv_sem_size(v, n);
+    if (hv_mode_is_semantic(v->cfg.mode)) return hv_sem_size(v, n);
     return hv_get_voxels(v, 1, 0.0f, nullptr, nullptr, 0, n, HV_HOST);
 }
 

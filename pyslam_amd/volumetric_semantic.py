@@ -710,6 +710,15 @@ class _SemanticGridBase(_Volume):
                                                    L.ptr(labels), L.ptr(logp), int(max_labels), ctypes.byref(n)))
         return keys, ints, pos, col, conf, nlab, labels, logp
 
+    def dump_marginals(self):
+        """-> (object confidence, class confidence) [B,bs^3] f32 in dump()'s order: ``get_object_confidence()`` /
+        ``get_class_confidence()`` of the two ``*2`` payloads (voxel_data_semantic2.h:60-76, 528-560); -1 for the other two."""
+        nb, nv = self.num_blocks(), self.block_size ** 3
+        oc, cc = np.zeros((nb, nv), np.float32), np.zeros((nb, nv), np.float32)
+        n = ctypes.c_int64()
+        L.check(self._lib.hv_dump_marginals_semantic(self._h, L.ptr(oc), L.ptr(cc), ctypes.byref(n)))
+        return oc, cc
+
 
 class VoxelBlockSemanticGrid(_SemanticGridBase):
     _MODE = L.HV_MODE_VOXEL_SEMANTIC_GRID
@@ -717,6 +726,18 @@ class VoxelBlockSemanticGrid(_SemanticGridBase):
 
 class VoxelBlockSemanticProbabilisticGrid(_SemanticGridBase):
     _MODE = L.HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID
+
+
+class VoxelBlockSemanticGrid2(_SemanticGridBase):
+    """``volumetric.VoxelBlockSemanticGrid2`` (volumetric_grid_module.h:1014-1018): the voting payload with one confidence counter
+    for the object id and one for the class id (VoxelSemanticData2, voxel_data_semantic2.h:46-196)."""
+    _MODE = L.HV_MODE_VOXEL_SEMANTIC_GRID2
+
+
+class VoxelBlockSemanticProbabilisticGrid2(_SemanticGridBase):
+    """``volumetric.VoxelBlockSemanticProbabilisticGrid2`` (volumetric_grid_module.h:1028-1032): one log-probability map per object
+    id and one per class id (VoxelSemanticDataProbabilistic2, voxel_data_semantic2.h:256-787)."""
+    _MODE = L.HV_MODE_VOXEL_SEMANTIC_PROBABILISTIC_GRID2
 
 
 class VoxelSemanticGrid(VoxelBlockSemanticGrid):
@@ -729,6 +750,20 @@ class VoxelSemanticGrid(VoxelBlockSemanticGrid):
 
 class VoxelSemanticGridProbabilistic(VoxelBlockSemanticProbabilisticGrid):
     """``volumetric.VoxelSemanticGridProbabilistic(voxel_size)`` (direct-hash variant, same payload)."""
+
+    def __init__(self, voxel_size=0.05, device=0, max_blocks=None, max_points=None):
+        super().__init__(voxel_size, 8, device=device, max_blocks=max_blocks, max_points=max_points)
+
+
+class VoxelSemanticGrid2(VoxelBlockSemanticGrid2):
+    """``volumetric.VoxelSemanticGrid2(voxel_size)`` (direct-hash variant, same payload; volumetric_grid_module.h:987-990)."""
+
+    def __init__(self, voxel_size=0.05, device=0, max_blocks=None, max_points=None):
+        super().__init__(voxel_size, 8, device=device, max_blocks=max_blocks, max_points=max_points)
+
+
+class VoxelSemanticGridProbabilistic2(VoxelBlockSemanticProbabilisticGrid2):
+    """``volumetric.VoxelSemanticGridProbabilistic2(voxel_size)`` (direct-hash variant, same payload; :1000-1004)."""
 
     def __init__(self, voxel_size=0.05, device=0, max_blocks=None, max_points=None):
         super().__init__(voxel_size, 8, device=device, max_blocks=max_blocks, max_points=max_points)

@@ -13,22 +13,27 @@ from tests.test_semantic_oracle import srt, stream
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not oracle.ref_available(), reason="compiled reference not available")]
 
 VOTE, PROB = 0, 1
+VOTE2, PROB2 = 2, 3  # the "*2" payloads (voxel_data_semantic2.h): separate object / class counters; marginal label maps
+EXACT = (VOTE, VOTE2)  # integer label state: compared bit for bit (the log-probability payloads: confidences within 2e-6)
+ALL_KINDS = [VOTE, PROB, VOTE2, PROB2]
 
 
 @pytest.fixture(autouse=True)
 def restore_reference_statics():
     """The reference keeps the depth threshold / decay rate as process-wide statics of the payload types."""
     yield
-    RefSemGrid2(VOTE, 0.05).set_depth_threshold(10.0)
-    g = RefSemGrid2(PROB, 0.05)
-    g.set_depth_threshold(5.0)
-    g.set_depth_decay_rate(0.07)
+    for kind in (VOTE, VOTE2):
+        RefSemGrid2(kind, 0.05).set_depth_threshold(10.0)
+    for kind in (PROB, PROB2):
+        g = RefSemGrid2(kind, 0.05)
+        g.set_depth_threshold(5.0)
+        g.set_depth_decay_rate(0.07)
 
 
 def gpu_grid(kind, voxel, **kw):
-    from pyslam_amd.volumetric_semantic import VoxelBlockSemanticGrid, VoxelBlockSemanticProbabilisticGrid
+    from pyslam_amd import volumetric_semantic as vs
 
-    cls = VoxelBlockSemanticProbabilisticGrid if kind == PROB else VoxelBlockSemanticGrid
+    cls = (vs.VoxelBlockSemanticGrid, vs.VoxelBlockSemanticProbabilisticGrid, vs.VoxelBlockSemanticGrid2, vs.VoxelBlockSemanticProbabilisticGrid2)[kind]
     return cls(voxel, 8, max_blocks=kw.get("max_blocks", 1 << 14), max_points=kw.get("max_points", 1 << 18))
 
 
@@ -42,7 +47,7 @@ def assert_state_equal(gpu, ref, kind, obj_map=None):
     np.testing.assert_array_equal(ig[..., :3], ir[..., :3])  # count, object id, class id
     np.testing.assert_array_equal(pg, pr)
     np.testing.assert_array_equal(cg, cr)
-    if kind == VOTE:
+    if kind in EXACT:
         np.testing.assert_array_equal(ig[..., 3], ir[..., 3])
         np.testing.assert_array_equal(confg, confr)
     elif ig.size:
@@ -162,7 +167,7 @@ def test_probabilistic_label_overflow_is_counted(monkeypatch):
     assert g.label_overflows() == 30 - 16 and g.dump2()[5].max() == 16  # 6 inline + the pool's only node
 
 
-@pytest.mark.parametrize("kind", [VOTE, PROB])
+@pytest.mark.parametrize("kind", ALL_KINDS)
 @pytest.mark.parametrize("do_carving", [False, True])
 def test_pyslam_semantic_flow(kind, do_carving):
     """assign_object_ids_to_instance_ids -> remap_instance_ids -> integrate, 4 frames, per-frame instance ids
@@ -222,7 +227,7 @@ def test_pyslam_semantic_flow(kind, do_carving):
         np.testing.assert_array_equal(a[1], b[1])
         if len(np.unique(cls_of(gpu, og_.object_id))) == 1:
             assert og_.class_id == o["class_id"]
-        if kind == VOTE:
+        if kind in EXACT:
             assert (og_.confidence_min, og_.confidence_max) == (o["conf_min"], o["conf_max"])
         else:
             assert abs(og_.confidence_min - o["conf_min"]) < 2e-6 and abs(og_.confidence_max - o["conf_max"]) < 2e-6
@@ -303,7 +308,7 @@ def test_carve_and_reobserve_cycles_reuse_overflow_nodes():
     assert_state_equal(gpu, ref, PROB)
 
 
-@pytest.mark.parametrize("kind", [VOTE, PROB])
+@pytest.mark.parametrize("kind", ALL_KINDS)
 def test_semantic_carve(kind):
     from pyslam_amd.synthetic import SyntheticRGBD
     from pyslam_amd.volumetric import CameraFrustrum
@@ -379,7 +384,7 @@ def test_flow_matches_committed_golden(kind, name):
     check_flow_against_golden(r, name, 0.0 if kind == VOTE else 2e-6)
 
 
-@pytest.mark.parametrize("kind", [VOTE, PROB])
+@pytest.mark.parametrize("kind", ALL_KINDS)
 def test_semantic_queries_segments_by_class_and_integrate_segment(kind):
     """get_voxels_in_bb / get_voxels_in_camera_frustrum with semantics, get_class_segments, integrate_segment
     against the compiled reference."""
@@ -402,7 +407,7 @@ def test_semantic_queries_segments_by_class_and_integrate_segment(kind):
     gpu.integrate_segment(seg_pts, seg_cols, -1, 5)  # negative ids: ignored
     ref_integrate_segment(ref, seg_pts, seg_cols, -1, 5)
     assert_state_equal(gpu, ref, kind)
-    tol = 0 if kind == VOTE else 2e-6
+    tol = 0 if kind in EXACT else 2e-6
 
     def same(v, r):
         a = srt((v.points, v.colors, v.class_ids, v.object_ids, v.confidences))
@@ -425,7 +430,7 @@ def test_semantic_queries_segments_by_class_and_integrate_segment(kind):
     np.testing.assert_allclose([[c.confidence_min, c.confidence_max] for c in got], conf, rtol=0, atol=tol)
 
 
-@pytest.mark.parametrize("kind", [VOTE, PROB])
+@pytest.mark.parametrize("kind", ALL_KINDS)
 def test_device_resident_keyframe_flow_equals_host_flow(kind):
     """filter_shadow_points -> assign_object_ids_to_instance_ids -> remap_instance_ids -> integrate_rgbd on torch CUDA tensors (one
     upload per image, what the semantic integrator does) against the same calls on numpy arrays: same id maps, id images and
@@ -478,7 +483,7 @@ def test_device_resident_keyframe_flow_equals_host_flow(kind):
     np.testing.assert_allclose(confa, confb, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("kind", [VOTE, PROB])
+@pytest.mark.parametrize("kind", ALL_KINDS)
 def test_fuse_keyframe_is_the_staged_calls_in_one(kind):
     """hv_semantic_fuse_keyframe (one call into the library per keyframe: what the integrator's device flow and the bench issue) against
     the staged calls it is made of - filter_shadow_points -> assign_object_ids_to_instance_ids -> remap_instance_ids -> integrate_rgbd -
@@ -531,7 +536,7 @@ def test_fuse_keyframe_is_the_staged_calls_in_one(kind):
     np.testing.assert_array_equal(confa, confb)
 
 
-@pytest.mark.parametrize("kind", [VOTE, PROB])
+@pytest.mark.parametrize("kind", ALL_KINDS)
 @pytest.mark.parametrize("world", [2, 3])
 def test_block_ownership_sharding_with_exchanged_votes_equals_the_single_grid(kind, world):
     """Semantic grids on `world` GPUs (here: `world` grids in one process play the ranks): hv_set_owner splits the blocks, every rank

@@ -23,14 +23,24 @@ need_ref = pytest.mark.skipif(not oracle.ref_available(), reason="compiled refer
 def restore_statics():
     yield
     for mk in (PortSemGrid2,) + ((RefSemGrid2,) if oracle.ref_available() else ()):
-        mk(0, 0.05).set_depth_threshold(10.0)
-        g = mk(1, 0.05)
-        g.set_depth_threshold(5.0)
-        g.set_depth_decay_rate(0.07)
+        for kind in (0, 2):
+            mk(kind, 0.05).set_depth_threshold(10.0)
+        for kind in (1, 3):
+            g = mk(kind, 0.05)
+            g.set_depth_threshold(5.0)
+            g.set_depth_decay_rate(0.07)
 
 
 def test_reference_kats_on_the_port():
     run_reference_kats(lambda kind, voxel: PortSemGrid2(kind, voxel))
+
+
+def test_hand_derived_answers_of_the_star2_payloads_on_the_port():
+    """tests/semantic2_kats.py (derived by hand from voxel_data_semantic2.h; held on the compiled reference in
+    tests/test_semantic2_payloads_reference.py) on the C restatement's kinds 2 and 3."""
+    from tests.semantic2_kats import run_semantic2_kats
+
+    run_semantic2_kats(lambda kind, voxel: PortSemGrid2(kind, voxel))
 
 
 @need_ref
@@ -57,7 +67,7 @@ def test_port_flow_matches_golden(kind, name):
 
 
 @need_ref
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])  # 2, 3: the "*2" payloads of voxel_data_semantic2.h
 @pytest.mark.parametrize("pos_dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("use_inst,use_depth", [(True, True), (True, False), (False, True), (False, False)])
 def test_port_vs_reference_streams(kind, pos_dtype, use_inst, use_depth):
@@ -78,7 +88,7 @@ def test_port_vs_reference_streams(kind, pos_dtype, use_inst, use_depth):
 
 
 @need_ref
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
 def test_port_vs_reference_flow_and_segment_ops(kind):
     a, b = PortSemGrid2(kind, FLOW_CFG["voxel"]), RefSemGrid2(kind, FLOW_CFG["voxel"])
     ra = run_flow(a, port_remap_instance_ids, kind)
