@@ -360,14 +360,36 @@ class CameraFrustrum:
 
 
 class VoxelGridData:
-    """cpp/volumetric/voxel_grid_data.h:36-50: .points/.colors (+ empty semantic fields)."""
+    """cpp/volumetric/voxel_grid_data.h:36-50: .points/.colors (+ empty semantic fields); default-constructible like the binding's."""
 
-    def __init__(self, points, colors):
-        self.points = points
-        self.colors = colors
+    def __init__(self, points=None, colors=None):
+        self.points = np.zeros((0, 3), np.float32) if points is None else points
+        self.colors = np.zeros((0, 3), np.float32) if colors is None else colors
         self.class_ids = np.zeros((0,), np.int32)
         self.object_ids = np.zeros((0,), np.int32)
         self.confidences = np.zeros((0,), np.float32)
+
+
+class VoxelData:
+    """``volumetric.VoxelData`` (volumetric_grid_module.h:943-947; cpp/volumetric/voxel_data.h:118-139): the value type of one voxel as
+    the module hands it to Python - ``count`` (read / write), ``get_position()``, ``get_color()`` = sum / count in float32 (0 / 0 = nan for
+    an empty voxel: the release build has no zero-count check, voxel_data.h:31-37).  A host-side value class as in the reference; the
+    grids keep their voxels in HBM (HvVoxel) and return rows, not objects."""
+
+    _pos_dtype = np.float32
+
+    def __init__(self):
+        self.count = 0
+        self.position_sum = np.zeros(3, self._pos_dtype)
+        self.color_sum = np.zeros(3, np.float32)
+
+    def get_position(self):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return list(self.position_sum / self._pos_dtype(self.count))
+
+    def get_color(self):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return list(self.color_sum / np.float32(self.count))
 
 
 class VoxelBlockGrid(_Volume):
@@ -582,9 +604,22 @@ class TBBUtils:
     """`volumetric.TBBUtils` exists only so callers' thread-cap call keeps working; the GPU path has
     no CPU worker threads (cpp/volumetric/tbb_utils.h:29-58)."""
 
+    _max_threads = None  # what the caller set last (nothing on the GPU path depends on it)
+
     @staticmethod
     def set_max_threads(num_threads):
-        return None
+        """-> the number of threads set (tbb_utils.h:37-48: a value <= 0 asks for the default, all hardware threads)."""
+        import os
+
+        TBBUtils._max_threads = int(num_threads) if int(num_threads) > 0 else (os.cpu_count() or 1)
+        return TBBUtils._max_threads
+
+    @staticmethod
+    def get_max_threads():
+        """tbb_utils.h:51-53: the cap in force (the host's hardware threads until one is set)."""
+        import os
+
+        return TBBUtils._max_threads if TBBUtils._max_threads is not None else (os.cpu_count() or 1)
 
 
 # ================================================================================================

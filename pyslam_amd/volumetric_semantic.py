@@ -19,7 +19,7 @@ from collections.abc import Mapping
 import numpy as np
 
 from . import _lib as L
-from .volumetric import VoxelGridData, _Volume
+from .volumetric import VoxelData, VoxelGridData, _Volume
 
 
 class OBBComputationMethod:
@@ -305,6 +305,32 @@ def _scratch_volume():
     if _scratch is None:
         _scratch = VoxelBlockSemanticGrid(0.05, 8, max_blocks=64, max_points=1 << 12)
     return _scratch
+
+
+class VoxelSemanticData(VoxelData):
+    """``volumetric.VoxelSemanticData`` (volumetric_grid_module.h:952-966; voxel_data_semantic.h:106-202): VoxelData with float64
+    position sums plus the voting label state - ``get_object_id()`` / ``get_class_id()`` (-1 when unlabelled), ``get_confidence()`` =
+    min(1, counter / count) (0 for an empty voxel), ``get_confidence_counter()``.  A host-side value class as in the reference."""
+
+    _pos_dtype = np.float64
+
+    def __init__(self):
+        super().__init__()
+        self.object_id, self.class_id, self.confidence_counter = -1, -1, 0
+
+    def get_object_id(self):
+        return self.object_id
+
+    def get_class_id(self):
+        return self.class_id
+
+    def get_confidence(self):
+        if self.count == 0:
+            return 0.0
+        return float(min(np.float32(1.0), np.float32(self.confidence_counter) / np.float32(self.count)))
+
+    def get_confidence_counter(self):
+        return self.confidence_counter
 
 
 class _SemanticGridBase(_Volume):

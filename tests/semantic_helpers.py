@@ -57,22 +57,23 @@ def compare_keyframe_flow(kind, config, voxel, frame_ids, max_blocks, max_points
     configuration.  Asserts after every keyframe: filtered depth bit-equal, id maps equal (new object ids up to the permutation
     between instances that need one in the same call, voxel_semantic_data_association.h:284-361), remapped id images equal; after
     the last: same block count, every occupied voxel's averaged position / colour / class / object id equal, confidences exact
-    (voting) or <= 2e-6 (probabilistic), the count distribution through get_voxels(min_count = 2, 3, 5), segments per object; with
+    (voting payloads) or <= 2e-6 (log-probability payloads), the count distribution through get_voxels(min_count = 2, 3, 5), segments per object; with
     full_dump also every voxel record (counts, sums, counters).  -> dict of sizes (for the bench line)."""
     import torch
 
     from oracle import host_prep as hp
     from oracle.semantic import RefSemGrid2, ref_remap_instance_ids
     from pyslam_amd.volumetric import CameraFrustrum
-    from pyslam_amd.volumetric_semantic import (VoxelBlockSemanticGrid, VoxelBlockSemanticProbabilisticGrid, remap_instance_ids,
-                                                set_next_object_id)
+    from pyslam_amd import volumetric_semantic as vs
+    from pyslam_amd.volumetric_semantic import remap_instance_ids, set_next_object_id
 
     s = SyntheticRGBD(config)
     intr = s.intrinsics
     intr32 = np.array(intr, np.float32)
     if gpu is None:
-        gpu = (VoxelBlockSemanticProbabilisticGrid if kind == 1 else VoxelBlockSemanticGrid)(voxel, 8, max_blocks=max_blocks,
-                                                                                              max_points=max_points)
+        # kind 0 voting, 1 probabilistic, 2 / 3 the "*2" payloads of voxel_data_semantic2.h (RefSemGrid2's kinds)
+        gpu = (vs.VoxelBlockSemanticGrid, vs.VoxelBlockSemanticProbabilisticGrid, vs.VoxelBlockSemanticGrid2,
+               vs.VoxelBlockSemanticProbabilisticGrid2)[kind](voxel, 8, max_blocks=max_blocks, max_points=max_points)
     ref = RefSemGrid2(kind, voxel, 8)
     for g in (gpu, ref):
         g.set_depth_threshold(5.0)
@@ -126,7 +127,7 @@ def compare_keyframe_flow(kind, config, voxel, frame_ids, max_blocks, max_points
         ref_seconds.append(t_ref + time.perf_counter() - t0)
     assert gpu.dropped_points() == 0 and gpu.label_overflows() == 0
     assert gpu.num_blocks() == ref.num_blocks()
-    tol = 0.0 if kind == 0 else 2e-6
+    tol = 0.0 if kind in (0, 2) else 2e-6  # integer label state: exact; log-probability payloads: confidences within 2e-6
     vg = gpu.get_voxels(1, -1.0)
     a = sorted_rows((vg.points, vg.colors, vg.class_ids, vg.object_ids, vg.confidences))
     b = sorted_rows(ref.get_voxels(1, -1.0))
@@ -151,7 +152,7 @@ def compare_keyframe_flow(kind, config, voxel, frame_ids, max_blocks, max_points
         np.testing.assert_array_equal(ig[..., :3], ir[..., :3])
         np.testing.assert_array_equal(pg, pr)
         np.testing.assert_array_equal(cg, cr)
-        if kind == 0:
+        if kind in (0, 2):
             np.testing.assert_array_equal(ig[..., 3], ir[..., 3])
             np.testing.assert_array_equal(confg, confr)
         else:

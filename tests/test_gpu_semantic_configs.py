@@ -17,19 +17,21 @@ def restore_reference_statics():
     from oracle.semantic import RefSemGrid2
 
     yield
-    RefSemGrid2(0, 0.05).set_depth_threshold(10.0)
-    g = RefSemGrid2(1, 0.05)
-    g.set_depth_threshold(5.0)
-    g.set_depth_decay_rate(0.07)
+    for kind in (0, 2):
+        RefSemGrid2(kind, 0.05).set_depth_threshold(10.0)
+    for kind in (1, 3):
+        g = RefSemGrid2(kind, 0.05)
+        g.set_depth_threshold(5.0)
+        g.set_depth_decay_rate(0.07)
 
 
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])  # 2, 3: the "*2" payloads (voxel_data_semantic2.h)
 def test_keyframe_flow_at_the_640x480_1cm_bench_configuration(kind):
     r = compare_keyframe_flow(kind, "synthetic_640x480_5mm", 0.01, (0, 3, 6), max_blocks=1 << 17, max_points=1 << 20, full_dump=True)
     assert r["occupied_voxels"] > 100_000 and r["new_object_ids"] >= 1
 
 
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
 def test_keyframe_flow_at_the_scannet_1296x968_2mm_bench_configuration(kind):
     r = compare_keyframe_flow(kind, "scannet_1296x968_2mm", 0.002, (0, 3, 6), max_blocks=1 << 17, max_points=1296 * 968)
     assert r["blocks"] > 50_000 and r["occupied_voxels"] > 1_000_000 and r["new_object_ids"] >= 1

@@ -57,7 +57,7 @@ def flow_traffic(pmc_file, payload_tag):
     return (int(sum(per.values())), per) if per else (None, None)
 
 
-def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x480_5mm", stride=3):
+def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x480_5mm", stride=3, star2=False):
     """-> dict (bench.py's `semantic` key / this tool's JSON line).  config="scannet_1296x968_2mm", voxel=0.002 is BASELINE
     configs[4]'s shape (1.25 M points per keyframe, 1.6 cm blocks)."""
     import types
@@ -67,8 +67,8 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
     from oracle import host_prep as hp
     from pyslam_amd.synthetic import SyntheticRGBD
     from pyslam_amd.volumetric import CameraFrustrum
-    from pyslam_amd.volumetric_semantic import (VoxelBlockSemanticGrid, VoxelBlockSemanticProbabilisticGrid,
-                                                remap_instance_ids, set_next_object_id)
+    from pyslam_amd.volumetric_semantic import (VoxelBlockSemanticGrid, VoxelBlockSemanticGrid2, VoxelBlockSemanticProbabilisticGrid,
+                                                VoxelBlockSemanticProbabilisticGrid2, remap_instance_ids, set_next_object_id)
     from pyslam_amd.dense.device_pipeline import KeyframeUploader
     from tests.semantic_helpers import frame_points, semantic_frame
 
@@ -100,7 +100,10 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
     out["flow"] = "host images staged by every call" if host_flow else ("one upload per image, steps on device tensors, the next keyframe's shadow filter beside this keyframe's kernels "
                                                                            "(the integrator's flow)")
     out["host_images"] = "page-locked (as in the front's registered ring), asynchronous uploads" if out_pinned else "pageable"
-    for name, cls, kind in (("voting", VoxelBlockSemanticGrid, 0), ("probabilistic", VoxelBlockSemanticProbabilisticGrid, 1)):
+    payloads = [("voting", VoxelBlockSemanticGrid, 0), ("probabilistic", VoxelBlockSemanticProbabilisticGrid, 1)]
+    if star2:  # the module's other two payloads (voxel_data_semantic2.h), on request: same flow, same checks
+        payloads += [("voting2", VoxelBlockSemanticGrid2, 2), ("probabilistic2", VoxelBlockSemanticProbabilisticGrid2, 3)]
+    for name, cls, kind in payloads:
         mb_log2 = int(os.environ.get("PYSLAM_AMD_SEMANTIC_MAX_BLOCKS_LOG2", "19" if args.voxel < 0.004 else "17"))  # A/B: the hash table has 4 slots per block of this
         g = cls(args.voxel, 8, max_blocks=1 << mb_log2, max_points=max(1 << 20, s.width * s.height))  # (a pool that does not have to grow inside the timed keyframes)
         fr = CameraFrustrum(*intr, s.width, s.height, np.eye(4), depth_max=8.0, depth_min=0.01)
@@ -152,7 +155,7 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
         t0 = time.perf_counter()
         segs = g.get_object_segments(3, 0.6)
         t_seg = time.perf_counter() - t0
-        rec = 64 if kind == 0 else 128
+        rec = 64 if kind in (0, 2) else 128
         alg = 2 * rec * float(np.mean(v_touched)) + b_in
         # ... and what the association reads: every voxel in the last keyframe's view (count >= 1) is looked at once by
         # assign_object_ids_to_instance_ids - in the reference as well (iterate_voxels_in_camera_frustrum); one record each
@@ -171,7 +174,8 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
                "get_voxels_ms": round(t_get * 1e3, 2), "voxels_out": int(len(v.points)),
                "get_object_segments_ms": round(t_seg * 1e3, 2), "objects": len(segs.object_vector), "blocks": int(g.num_blocks()),
                "label_overflows": g.label_overflows()}
-        traffic, per = flow_traffic("pmc_semantic_scannet_2mm.json" if args.voxel < 0.004 else "pmc_semantic.json", "HvSemVoxel" if kind == 0 else "HvProbVoxel")
+        # (the recorded counter passes ran the first two payloads only)
+        traffic, per = flow_traffic("pmc_semantic_scannet_2mm.json" if args.voxel < 0.004 else "pmc_semantic.json", "HvSemVoxel" if kind == 0 else "HvProbVoxel") if kind < 2 else (None, None)
         if traffic is not None:
             res["roofline"]["traffic"] = traffic
             res["roofline"]["traffic_over_algorithmic"] = round(traffic / alg, 2)
@@ -207,8 +211,9 @@ def main():
     ap.add_argument("--voxel", type=float, default=0.01)
     ap.add_argument("--config", default="synthetic_640x480_5mm")
     ap.add_argument("--stride", type=int, default=3)
+    ap.add_argument("--star2", action="store_true", help="also time VoxelBlockSemanticGrid2 / VoxelBlockSemanticProbabilisticGrid2 (voxel_data_semantic2.h)")
     args = ap.parse_args()
-    print(json.dumps(semantic_leg(args.frames, args.cpu_frames, args.voxel, args.config, args.stride)))
+    print(json.dumps(semantic_leg(args.frames, args.cpu_frames, args.voxel, args.config, args.stride, args.star2)))
 
 
 if __name__ == "__main__":
