@@ -280,8 +280,8 @@ int hv_semantic_fuse_keyframe(hv_volume *v, const float *depth, const uint8_t *r
                               float min_vote_ratio, int32_t min_votes, double min_depth, double max_depth, int32_t use_depths);
 int32_t hv_peek_next_object_id(void); /* VoxelSemanticSharedData::next_object_id, voxel_semantic_shared_data.h:26-34 */
 void hv_set_next_object_id(int32_t id);
-/* remap_instance_ids(instance_ids i32 HxW, map) (image_utils.h:69-163): ids absent from the map (or an empty map)
- * become -1. */
+/* volumetric.remap_instance_ids(instance_ids i32 HxW, map) (binding image_utils_module.h:49-94 over image_utils.h:69-163): ids
+ * absent from the map become -1; an EMPTY map returns the image unchanged (the binding's early return, :52-58). */
 int hv_remap_instance_ids(hv_volume *v, const int32_t *instance_ids, int32_t height, int32_t width, const int32_t *map_inst,
                           const int32_t *map_obj, int64_t n_map, int32_t *out, int32_t loc);
 /* get_object_segments(min_count, min_confidence) (voxel_block_semantic_grid.hpp:217-267): voxels with

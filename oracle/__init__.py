@@ -338,6 +338,27 @@ def frustum_contains(intr, width, height, T_cw, depth_max, depth_min, p_w, which
     return bool(ok), out
 
 
+def ref_frustum_surface(intr, width, height, T_cw, depth_max, depth_min, points, orientation=None, translation=None):
+    """The compiled reference's CameraFrustrum (oracle/ref_shim.cpp: ref_frustum_surface) -> dict: corners [8,3], obb [10], K [3,3],
+    R_cw [3,3], t_cw [3], orientation_cw wxyz [4], and for the float64 points [N,3]: in_bbox, in_obb, inside, uvd [N,3] f32."""
+    lib = ref_lib()
+    fn = lib.ref_frustum_surface
+    fn.restype = None
+    fn.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]
+    intr = np.ascontiguousarray(intr, dtype=np.float32)
+    T = np.ascontiguousarray(np.eye(4) if T_cw is None else T_cw, dtype=np.float64)
+    q = None if orientation is None else np.ascontiguousarray(orientation, dtype=np.float64)
+    t = None if translation is None else np.ascontiguousarray(translation, dtype=np.float64)
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    n = len(pts)
+    out = dict(corners=np.zeros((8, 3)), obb=np.zeros(10), K=np.zeros((3, 3)), R_cw=np.zeros((3, 3)), t_cw=np.zeros(3), orientation_cw=np.zeros(4),
+               in_bbox=np.zeros(n, np.uint8), in_obb=np.zeros(n, np.uint8), inside=np.zeros(n, np.uint8), uvd=np.zeros((n, 3), np.float32))
+    fn(_ptr(intr), int(width), int(height), _ptr(T), _ptr(q), _ptr(t), float(depth_max), float(depth_min), _ptr(out["corners"]), _ptr(out["obb"]),
+       _ptr(out["K"]), _ptr(out["R_cw"]), _ptr(out["t_cw"]), _ptr(out["orientation_cw"]), _ptr(pts), n, _ptr(out["in_bbox"]), _ptr(out["in_obb"]),
+       _ptr(out["inside"]), _ptr(out["uvd"]))
+    return out
+
+
 def frustum_bbox(intr, width, height, T_cw, depth_max, depth_min, which="port"):
     intr = np.ascontiguousarray(intr, dtype=np.float32)
     T = np.ascontiguousarray(T_cw, dtype=np.float64)

@@ -220,6 +220,42 @@ void ref_frustum_bbox(const float *intr, int width, int height, const double *T_
     bb[3] = b.max_x; bb[4] = b.max_y; bb[5] = b.max_z;
 }
 
+// The rest of CameraFrustrum's bound surface (camera_frustrum_module.h:50-130) for one frustum: corners [8,3] (near / far per image
+// corner, camera_frustrum.cpp:209-245), obb {center xyz, quaternion wxyz, size xyz} (:266-301), K [9], R_cw [9], t_cw [3],
+// orientation_cw wxyz [4]; then for n float64 points (the binding's Eigen::Vector3d overloads): is_in_bbox, is_in_obb, contains and
+// its ImagePoint {u, v, depth}.  quat != nullptr builds the frustum through the (orientation, translation) constructor instead.
+void ref_frustum_surface(const float *intr, int width, int height, const double *T_cw, const double *quat_wxyz, const double *trans,
+                         float depth_max, float depth_min, double *corners24, double *obb10, double *K9, double *R9, double *t3,
+                         double *q4, const double *pts, int64_t n, uint8_t *in_bbox, uint8_t *in_obb, uint8_t *inside, float *uvd) {
+    CameraFrustrum fr = quat_wxyz != nullptr
+                            ? CameraFrustrum(intr[0], intr[1], intr[2], intr[3], width, height,
+                                             Eigen::Quaterniond(quat_wxyz[0], quat_wxyz[1], quat_wxyz[2], quat_wxyz[3]),
+                                             Eigen::Vector3d(trans[0], trans[1], trans[2]), depth_max, depth_min)
+                            : make_frustum(intr, width, height, T_cw, depth_max, depth_min);
+    const auto &cs = fr.get_corners();
+    for (int i = 0; i < 8; ++i)
+        for (int k = 0; k < 3; ++k) corners24[i * 3 + k] = cs[i][k];
+    const auto &b = fr.get_obb();
+    obb10[0] = b.center.x(); obb10[1] = b.center.y(); obb10[2] = b.center.z();
+    obb10[3] = b.orientation.w(); obb10[4] = b.orientation.x(); obb10[5] = b.orientation.y(); obb10[6] = b.orientation.z();
+    obb10[7] = b.size.x(); obb10[8] = b.size.y(); obb10[9] = b.size.z();
+    const Eigen::Matrix3d K = fr.get_K(), R = fr.get_R_cw();
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) { K9[r * 3 + c] = K(r, c); R9[r * 3 + c] = R(r, c); }
+    const Eigen::Vector3d t = fr.get_t_cw();
+    const Eigen::Quaterniond q = fr.get_orientation_cw();
+    for (int k = 0; k < 3; ++k) t3[k] = t[k];
+    q4[0] = q.w(); q4[1] = q.x(); q4[2] = q.y(); q4[3] = q.z();
+    for (int64_t i = 0; i < n; ++i) {
+        const Eigen::Vector3d p(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
+        in_bbox[i] = fr.is_in_bbox(p) ? 1 : 0;
+        in_obb[i] = fr.is_in_obb(p) ? 1 : 0;
+        const auto res = fr.contains(p);
+        inside[i] = res.first ? 1 : 0;
+        uvd[i * 3] = res.second.u; uvd[i * 3 + 1] = res.second.v; uvd[i * 3 + 2] = res.second.depth;
+    }
+}
+
 // Key arithmetic straight from voxel_hashing.h for n float32 points.
 void ref_keys(float voxel_size, int block_size, const float *pts, int64_t n, int32_t *voxel_keys,
               int32_t *block_keys, int32_t *local_keys, uint64_t *block_hashes) {

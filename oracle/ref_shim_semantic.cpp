@@ -308,12 +308,16 @@ int64_t ref_sem2_get_ids(void *h, int32_t *class_ids, int32_t *object_ids, int64
     return visit(h, [&](auto *g) { return get_ids_g(g, class_ids, object_ids, cap); });
 }
 
-// remap_instance_ids<MapInstanceIdToObjectId, int32_t>, image_utils.h:69-163
+// volumetric.remap_instance_ids as bound (image_utils_module.h:49-94): remap_instance_ids<MapInstanceIdToObjectId, int32_t>, image_utils.h:69-163
 void ref_remap_instance_ids(const int32_t *inst_img, int height, int width, const int32_t *map_inst, const int32_t *map_obj,
                             int64_t n_map, int32_t *out) {
     cv::Mat im(height, width, CV_32S, const_cast<int32_t *>(inst_img));
     std::unordered_map<int, int> m;
     for (int64_t i = 0; i < n_map; ++i) m[map_inst[i]] = map_obj[i];
+    if (m.empty()) { // what Python sees: the binding's lambda returns the image itself for an empty map (image_utils_module.h:52-58)
+        for (int i = 0; i < height; ++i) std::memcpy(out + (size_t)i * width, im.ptr<int32_t>(i), sizeof(int32_t) * width);
+        return;
+    }
     const cv::Mat r = volumetric::remap_instance_ids<std::unordered_map<int, int>, int32_t>(im, m);
     for (int i = 0; i < height; ++i) std::memcpy(out + (size_t)i * width, r.ptr<int32_t>(i), sizeof(int32_t) * width);
 }

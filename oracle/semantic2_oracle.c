@@ -795,6 +795,10 @@ int64_t so2_assign_object_ids(s2_grid *g, const float *intr, int width, int heig
 void so2_remap_instance_ids(const int32_t *inst_img, int height, int width, const int32_t *map_inst, const int32_t *map_obj,
                             int64_t n_map, int32_t *out) {
     for (int64_t p = 0; p < (int64_t)height * width; ++p) {
+        if (n_map == 0) { /* the binding hands the image back for an empty map, image_utils_module.h:52-58 */
+            out[p] = inst_img[p];
+            continue;
+        }
         int32_t r = -1;
         for (int64_t k = 0; k < n_map; ++k)
             if (map_inst[k] == inst_img[p]) { r = map_obj[k]; break; }

@@ -725,7 +725,9 @@ __global__ __launch_bounds__(256) void k_remap_instance_ids(const int32_t *__res
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (n_map_p != nullptr) n_map = *n_map_p;
-    out[i] = n_map > 0 ? map_lookup(map_inst, map_obj, n_map, in[i], -1) : -1;
+    // an EMPTY map hands the image back as it is - the early return of the module's binding, image_utils_module.h:52-58, which is what
+    // pySLAM calls (the C++ template behind it would set every id to -1, image_utils.h:108-141)
+    out[i] = n_map > 0 ? map_lookup(map_inst, map_obj, n_map, in[i], -1) : in[i];
 }
 
 // ---- segments ------------------------------------------------------------------------------------

@@ -328,35 +328,277 @@ class BoundingBox3D:
         return BoundingBox3D(p.min(axis=0), p.max(axis=0))
 
 
+class ImagePoint:
+    """``volumetric.ImagePoint`` (camera_frustrum.h:31-35, camera_frustrum_module.h:41-47): pixel coordinates and depth as float32."""
+
+    def __init__(self, u=0.0, v=0.0, depth=0.0):
+        self.u, self.v, self.depth = float(np.float32(u)), float(np.float32(v)), float(np.float32(depth))
+
+    def __repr__(self):
+        return f"ImagePoint(u={self.u}, v={self.v}, depth={self.depth})"
+
+
+class Quaterniond:
+    """``volumetric.Quaterniond`` (eigen_module.h:36-96): Eigen::Quaterniond as the module exposes it - Quaterniond() identity,
+    Quaterniond(w, x, y, z), Quaterniond([w, x, y, z]); w() x() y() z(), coeffs() -> [w, x, y, z], normalized(), normalize(),
+    conjugate(), inverse(), toRotationMatrix(); picklable."""
+
+    def __init__(self, *args):
+        if len(args) == 0:
+            c = (1.0, 0.0, 0.0, 0.0)
+        elif len(args) == 4:
+            c = args
+        elif len(args) == 1 and np.size(args[0]) == 4:
+            c = np.asarray(args[0], np.float64).reshape(4)
+        else:
+            raise RuntimeError("Quaternion array must have exactly 4 elements [w, x, y, z]")
+        self._c = np.array([float(v) for v in c], np.float64)  # w, x, y, z
+
+    def w(self):
+        return float(self._c[0])
+
+    def x(self):
+        return float(self._c[1])
+
+    def y(self):
+        return float(self._c[2])
+
+    def z(self):
+        return float(self._c[3])
+
+    def coeffs(self):
+        return self._c.copy()
+
+    def normalized(self):
+        return Quaterniond(self._c / np.sqrt(np.sum(self._c * self._c)))
+
+    def normalize(self):
+        self._c = self._c / np.sqrt(np.sum(self._c * self._c))
+
+    def conjugate(self):
+        return Quaterniond(self._c[0], -self._c[1], -self._c[2], -self._c[3])
+
+    def inverse(self):
+        n2 = float(np.sum(self._c * self._c))
+        return Quaterniond(self.conjugate()._c / n2) if n2 > 0.0 else Quaterniond(0.0, 0.0, 0.0, 0.0)
+
+    def toRotationMatrix(self):
+        w, x, y, z = self._c  # (Eigen does not normalise here)
+        tx, ty, tz = 2.0 * x, 2.0 * y, 2.0 * z
+        twx, twy, twz = tx * w, ty * w, tz * w
+        txx, txy, txz = tx * x, ty * x, tz * x
+        tyy, tyz, tzz = ty * y, tz * y, tz * z
+        return np.array([[1.0 - (tyy + tzz), txy - twz, txz + twy], [txy + twz, 1.0 - (txx + tzz), tyz - twx], [txz - twy, tyz + twx, 1.0 - (txx + tyy)]])
+
+    def __repr__(self):
+        return "Quaterniond(w=%f, x=%f, y=%f, z=%f)" % tuple(self._c)
+
+    def __reduce__(self):
+        return (Quaterniond, tuple(float(v) for v in self._c))
+
+
+def _quat_from_matrix(m):
+    """Eigen::Quaterniond(Matrix3d) (Eigen/src/Geometry/Quaternion.h, quaternionbase_assign_impl<Other, 3, 3>) -> (w, x, y, z)."""
+    t = m[0, 0] + m[1, 1] + m[2, 2]
+    q = np.zeros(4, np.float64)  # x, y, z, w
+    if t > 0.0:
+        t = np.sqrt(t + 1.0)
+        q[3] = 0.5 * t
+        t = 0.5 / t
+        q[0], q[1], q[2] = (m[2, 1] - m[1, 2]) * t, (m[0, 2] - m[2, 0]) * t, (m[1, 0] - m[0, 1]) * t
+    else:
+        i = 0
+        if m[1, 1] > m[0, 0]:
+            i = 1
+        if m[2, 2] > m[i, i]:
+            i = 2
+        j, k = (i + 1) % 3, (i + 2) % 3
+        t = np.sqrt(m[i, i] - m[j, j] - m[k, k] + 1.0)
+        q[i] = 0.5 * t
+        t = 0.5 / t
+        q[3] = (m[k, j] - m[j, k]) * t
+        q[j] = (m[j, i] + m[i, j]) * t
+        q[k] = (m[k, i] + m[i, k]) * t
+    return np.array([q[3], q[0], q[1], q[2]])
+
+
+def _matrix_from_quat(wxyz):
+    """Eigen::Quaterniond::normalized().toRotationMatrix()."""
+    w, x, y, z = np.asarray(wxyz, np.float64) / np.sqrt(np.sum(np.asarray(wxyz, np.float64) ** 2))
+    tx, ty, tz = 2.0 * x, 2.0 * y, 2.0 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([[1.0 - (tyy + tzz), txy - twz, txz + twy], [txy + twz, 1.0 - (txx + tzz), tyz - twx], [txz - twy, tyz + twx, 1.0 - (txx + tyy)]])
+
+
+def _mat3_vec(R, v):
+    """R v in Eigen's coefficient order ((r0 v0 + r1 v1) + r2 v2 per row): the same float64 bits as the reference's products."""
+    return R[:, 0] * v[0] + R[:, 1] * v[1] + R[:, 2] * v[2]
+
+
 class CameraFrustrum:
-    """cpp/volumetric/camera_frustrum.h:37-130: CameraFrustrum(fx, fy, cx, cy, width, height, T_cw,
-    depth_max=10.0, depth_min=1e-2); intrinsics and depth limits are float32 there."""
+    """``volumetric.CameraFrustrum`` (cpp/volumetric/camera_frustrum.h:37-130, camera_frustrum.cpp, bindings camera_frustrum_module.h:50-130).
+    The binding's three constructors: ``CameraFrustrum(fx, fy, cx, cy, width, height, T_cw, depth_max, depth_min)``,
+    ``CameraFrustrum(K, width, height, T_cw, depth_max, depth_min)`` and ``CameraFrustrum(fx, fy, cx, cy, width, height, orientation,
+    translation, depth_max, depth_min)`` (orientation: quaternion (w, x, y, z) or an object with .w() .. .z()); keywords as there.
+    Intrinsics and depth limits are float32 members, the pose float64.  Corners, boxes and the point tests are the host-side
+    geometry of the reference class; the grids take the frustum as a query (hv_query.h)."""
 
-    def __init__(self, fx, fy, cx, cy, width, height, T_cw=None, depth_max=10.0, depth_min=1e-2):
-        self.intr = np.array([fx, fy, cx, cy], dtype=np.float32)
-        self.width = int(width)
-        self.height = int(height)
-        self.depth_max = float(np.float32(depth_max))
-        self.depth_min = float(np.float32(depth_min))
-        self.T_cw = _as_f64_4x4(np.eye(4) if T_cw is None else T_cw)
+    def __init__(self, *args, **kw):
+        names9 = ("fx", "fy", "cx", "cy", "width", "height", "T_cw", "depth_max", "depth_min")
+        names6 = ("K", "width", "height", "T_cw", "depth_max", "depth_min")
+        names10 = ("fx", "fy", "cx", "cy", "width", "height", "orientation", "translation", "depth_max", "depth_min")
+        if "K" in kw or (args and np.ndim(args[0]) == 2):
+            a = dict(zip(names6, args), **kw)
+            K = np.asarray(a["K"], np.float64)
+            a.update(fx=K[0, 0], fy=K[1, 1], cx=K[0, 2], cy=K[1, 2])
+        elif "orientation" in kw or len(args) == 10:
+            a = dict(zip(names10, args), **kw)
+        else:
+            a = dict(zip(names9, args), **kw)
+        self.intr = np.array([a["fx"], a["fy"], a["cx"], a["cy"]], dtype=np.float32)
+        self.width = int(a["width"])
+        self.height = int(a["height"])
+        self.depth_max = float(np.float32(a.get("depth_max", 10.0)))
+        self.depth_min = float(np.float32(a.get("depth_min", 1e-2)))
+        self._cache = None
+        if "orientation" in a:
+            self.set_T_cw(a["orientation"], a["translation"])
+        else:
+            self.set_T_cw(np.eye(4) if a.get("T_cw") is None else a["T_cw"])
 
-    def set_T_cw(self, T_cw):
+    # ---- setters (each drops the cached corners / boxes, camera_frustrum.cpp:64-121) ----
+    def set_T_cw(self, T_cw, translation=None):
+        """set_T_cw(T_cw 4x4) or set_T_cw(orientation, translation)."""
+        if translation is not None:
+            q = T_cw
+            wxyz = np.array([q.w(), q.x(), q.y(), q.z()], np.float64) if hasattr(q, "w") and callable(q.w) else np.asarray(q, np.float64)
+            T = np.eye(4)
+            T[:3, :3] = _matrix_from_quat(wxyz)
+            T[:3, 3] = np.asarray(translation, np.float64)
+            T_cw = T
         self.T_cw = _as_f64_4x4(T_cw)
+        self._cache = None
 
-    def get_T_cw(self):
-        return self.T_cw.copy()
+    def set_width(self, width):
+        self.width = int(width)
+        self._cache = None
+
+    def set_height(self, height):
+        self.height = int(height)
+        self._cache = None
 
     def set_depth_max(self, depth_max):
         self.depth_max = float(np.float32(depth_max))
+        self._cache = None
 
     def set_depth_min(self, depth_min):
         self.depth_min = float(np.float32(depth_min))
+        self._cache = None
 
+    def set_intrinsics(self, *args, **kw):
+        """set_intrinsics(K) or set_intrinsics(fx, fy, cx, cy)."""
+        if "K" in kw or len(args) == 1:
+            K = np.asarray(kw.get("K", args[0] if args else None), np.float64)
+            vals = (K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        else:
+            vals = tuple(dict(zip(("fx", "fy", "cx", "cy"), args), **kw)[k] for k in ("fx", "fy", "cx", "cy"))
+        self.intr = np.array(vals, dtype=np.float32)
+        self._cache = None
+
+    # ---- getters ----
     def get_width(self):
         return self.width
 
     def get_height(self):
         return self.height
+
+    def get_fx(self):
+        return float(self.intr[0])
+
+    def get_fy(self):
+        return float(self.intr[1])
+
+    def get_cx(self):
+        return float(self.intr[2])
+
+    def get_cy(self):
+        return float(self.intr[3])
+
+    def get_K(self):
+        fx, fy, cx, cy = (float(x) for x in self.intr)
+        return np.array([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]])
+
+    def get_T_cw(self):
+        T = np.eye(4)
+        T[:3, :] = self.T_cw[:3, :]
+        return T
+
+    def get_R_cw(self):
+        return self.T_cw[:3, :3].copy()
+
+    def get_t_cw(self):
+        return self.T_cw[:3, 3].copy()
+
+    def get_orientation_cw(self):
+        """-> Quaterniond of R_cw (Eigen::Quaterniond(R_cw_), camera_frustrum.cpp:152-154)."""
+        return Quaterniond(_quat_from_matrix(self.T_cw[:3, :3]))
+
+    def is_cache_valid(self):
+        return self._cache is not None
+
+    def _update_cache(self):
+        if self._cache is not None:
+            return self._cache
+        fx, fy, cx, cy = (float(x) for x in self.intr)
+        R_cw, t_cw = self.T_cw[:3, :3], self.T_cw[:3, 3]
+        R_wc = R_cw.T
+        t_wc = _mat3_vec(-R_wc, t_cw)
+        corners = []  # camera_frustrum.cpp:209-245: near and far point of top-left, top-right, bottom-right, bottom-left
+        for u, v in ((0.0, 0.0), (float(self.width), 0.0), (float(self.width), float(self.height)), (0.0, float(self.height))):
+            xn, yn = (u - cx) / fx, (v - cy) / fy
+            for d in (self.depth_min, self.depth_max):
+                corners.append(_mat3_vec(R_wc, np.array([xn * d, yn * d, d])) + t_wc)
+        corners = np.array(corners)
+        bbox = BoundingBox3D(corners.min(axis=0), corners.max(axis=0))  # :247-264
+        cam = np.array([_mat3_vec(R_cw, c) + t_cw for c in corners])  # :266-301: the box of the corners in the camera frame
+        lo, hi = cam.min(axis=0), cam.max(axis=0)
+        center_w = _mat3_vec(R_wc, (lo + hi) / 2.0) + t_wc
+        self._cache = (corners, bbox, (center_w, _quat_from_matrix(R_wc), hi - lo))
+        return self._cache
+
+    def get_corners(self):
+        return [c.copy() for c in self._update_cache()[0]]
+
+    def get_bbox(self):
+        return self._update_cache()[1]
+
+    def get_obb(self):
+        from .volumetric_semantic import OrientedBoundingBox3D
+
+        return OrientedBoundingBox3D(*self._update_cache()[2])
+
+    def is_in_bbox(self, point_w):
+        return self.get_bbox().contains(np.asarray(point_w, np.float64))
+
+    def is_in_obb(self, point_w):
+        return self.get_obb().contains(np.asarray(point_w, np.float64))
+
+    def contains(self, point_w):
+        """-> (inside, ImagePoint): camera_frustrum.cpp:175-196 (the depth test first - ImagePoint(-1, -1, -1) when it fails -, then
+        the projection in float64 narrowed to float32 pixel coordinates, then the image bounds)."""
+        p = np.asarray(point_w, np.float64)
+        pc = _mat3_vec(self.T_cw[:3, :3], p) + self.T_cw[:3, 3]
+        depth = np.float32(pc[2])
+        if not (depth >= np.float32(self.depth_min) and depth <= np.float32(self.depth_max)):
+            return False, ImagePoint(-1.0, -1.0, -1.0)
+        fx, fy, cx, cy = (float(x) for x in self.intr)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = np.float32(fx * (pc[0] / pc[2]) + cx)
+            v = np.float32(fy * (pc[1] / pc[2]) + cy)
+        inside = bool(u >= np.float32(0.0) and u < np.float32(self.width) and v >= np.float32(0.0) and v < np.float32(self.height))
+        return inside, ImagePoint(u, v, depth)
 
 
 class VoxelGridData:

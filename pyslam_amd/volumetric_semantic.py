@@ -11,7 +11,7 @@ set_depth_threshold, set_depth_decay_rate, clear/reset, size, num_blocks; module
 ``remap_instance_ids`` (image_utils.h:69-163) and the ``ObjectData`` / ``ObjectDataGroup`` /
 ``OrientedBoundingBox3D`` result types (voxel_grid_data.h:58-99, bounding_boxes_3d.h:82-131).
 Also: get_voxels_in_bb / get_voxels_in_camera_frustrum (include_semantics), integrate_segment, get_class_segments.
-Not provided: the *2 payload variants (voxel_data_semantic2.h)."""
+The module's "*2" payloads (voxel_data_semantic2.h) are the *Grid2 classes at the end."""
 import ctypes
 import weakref
 from collections.abc import Mapping
@@ -155,6 +155,58 @@ class ObjectDataGroup:
         self.object_ids = np.array([o.object_id for o in self.object_vector], np.int32)
 
 
+class ClassDataGroup:
+    """voxel_grid_data.h:131-139: class_vector + the redundant class_ids list (what get_class_segments returns).  Iterates, indexes and
+    measures like its class_vector (rounds 3-5 returned the bare list)."""
+
+    def __init__(self, class_vector=()):
+        self.class_vector = list(class_vector)
+        self.class_ids = np.array([c.class_id for c in self.class_vector], np.int32)
+
+    def __iter__(self):
+        return iter(self.class_vector)
+
+    def __len__(self):
+        return len(self.class_vector)
+
+    def __getitem__(self, i):
+        return self.class_vector[i]
+
+
+def check_image_size(image, height, width, image_name="image"):
+    """``volumetric.check_image_size`` (image_utils.h:30-41): False - with the reference's message - for an empty image or one whose
+    rows x cols differ from the expected size."""
+    a = np.asarray(image) if not hasattr(image, "shape") else image
+    rows, cols = (int(a.shape[0]), int(a.shape[1])) if len(a.shape) >= 2 else (0, 0)
+    if rows == 0 or cols == 0 or rows != int(height) or cols != int(width):
+        print(f"check_image_size: {image_name} size: {rows}x{cols}\n\tExpected height: {height}\n\tExpected width: {width}\n"
+              "\tImage size does not match expected size")
+        return False
+    return True
+
+
+# OpenCV's depth codes (CV_8U .. CV_64F), the `expected_type` of convert_image_type_if_needed for single-channel images
+_CV_DEPTH_DTYPES = {0: np.uint8, 1: np.int8, 2: np.uint16, 3: np.int16, 4: np.int32, 5: np.float32, 6: np.float64}
+
+
+def convert_image_type_if_needed(image, expected_type, image_name="image"):
+    """``volumetric.convert_image_type_if_needed`` (image_utils.h:43-59): the image itself when it is empty or already of the expected
+    type, else a converted copy (cv::Mat::convertTo: saturating, round-to-nearest-even for float -> integer).  expected_type: a numpy
+    dtype or one of OpenCV's single-channel type codes (CV_32S = 4 ...)."""
+    a = np.asarray(image)
+    if a.size == 0:
+        return image
+    dt = np.dtype(_CV_DEPTH_DTYPES[int(expected_type) & 7] if isinstance(expected_type, (int, np.integer)) else expected_type)
+    if a.dtype == dt:
+        return image
+    print(f"check_image_type: {image_name} type: {a.dtype}\n\tConverting image to {dt}")
+    if np.issubdtype(dt, np.integer):
+        info = np.iinfo(dt)
+        src = np.rint(a) if np.issubdtype(a.dtype, np.floating) else a
+        return np.clip(src, info.min, info.max).astype(dt)
+    return a.astype(dt)
+
+
 def _i32_image(img, name):
     a = np.ascontiguousarray(img)
     if a.ndim != 2:
@@ -248,8 +300,14 @@ def _remap_with_last_map(instance_ids, id_map, volume):
         return img
     if img.ndim != 2:
         raise RuntimeError("Instance ids must be single-channel")
+    if img.dtype in (np.int8, np.uint8, np.int16, np.uint16):
+        # the binding's narrower instantiations (image_utils_module.h:66-88): looked up as int, written back in the image's own type
+        # (an object id, and the invalid id -1, narrowed the way the C++ assignment does: modulo 2^bits)
+        if len(instance_id_to_object_id) == 0:
+            return img
+        return remap_instance_ids(img.astype(np.int32), instance_id_to_object_id, volume).astype(img.dtype)
     if img.dtype != np.int32:
-        raise RuntimeError("Instance ids must be int32")
+        raise RuntimeError("Unsupported instance id type")
     out = np.empty_like(img)
     L.check(v._lib.hv_remap_instance_ids_last(v._h, L.ptr(img), img.shape[0], img.shape[1], L.ptr(out), L.HV_HOST))
     return out
@@ -257,7 +315,8 @@ def _remap_with_last_map(instance_ids, id_map, volume):
 
 def remap_instance_ids(instance_ids, instance_id_to_object_id, volume=None):
     """volumetric.remap_instance_ids(image int32 HxW, map) (image_utils.h:69-163, binding image_utils_module.h):
-    ids absent from the map (or an empty map) become -1.  Runs on the GPU of ``volume`` (any volume).  A torch CUDA int32
+    ids absent from the map become -1; an EMPTY map returns the image as it is (the binding's early return, image_utils_module.h:52-58 -
+    the C++ template behind it would set every id to -1).  Runs on the GPU of ``volume`` (any volume).  A torch CUDA int32
     image stays on the device (the result is a CUDA tensor).  The map an association on ``volume`` just returned is used where it
     lies, in device memory."""
     if isinstance(instance_id_to_object_id, LazyIdMap) and volume is not None and instance_id_to_object_id.on_device_of(volume):
@@ -285,8 +344,14 @@ def remap_instance_ids(instance_ids, instance_id_to_object_id, volume=None):
         return img
     if img.ndim != 2:
         raise RuntimeError("Instance ids must be single-channel")
+    if img.dtype in (np.int8, np.uint8, np.int16, np.uint16):
+        # the binding's narrower instantiations (image_utils_module.h:66-88): looked up as int, written back in the image's own type
+        # (an object id, and the invalid id -1, narrowed the way the C++ assignment does: modulo 2^bits)
+        if len(instance_id_to_object_id) == 0:
+            return img
+        return remap_instance_ids(img.astype(np.int32), instance_id_to_object_id, volume).astype(img.dtype)
     if img.dtype != np.int32:
-        raise RuntimeError("Instance ids must be int32")
+        raise RuntimeError("Unsupported instance id type")
     if volume is None:
         volume = _scratch_volume()
     keys = np.fromiter(instance_id_to_object_id.keys(), np.int32, len(instance_id_to_object_id))
@@ -522,7 +587,7 @@ class _SemanticGridBase(_Volume):
         self.integrate(points, colors, np.full(n, class_id, np.int32), np.full(n, object_id, np.int32))
 
     def get_class_segments(self, min_count=1, min_confidence=0.0):
-        """-> list of ClassData-like objects (voxel_block_semantic_grid.hpp:269-313): voxels with count > min_count,
+        """-> ClassDataGroup (.class_vector of ClassData, .class_ids; voxel_block_semantic_grid.hpp:269-313): voxels with count > min_count,
         confidence >= min_confidence and class id >= 0 grouped by class (ascending)."""
         v = self.get_voxels(int(min_count) + 1, min_confidence)  # strict '>' on the count, like get_object_segments
         keep = v.class_ids >= 0
@@ -530,7 +595,7 @@ class _SemanticGridBase(_Volume):
         for c in np.unique(v.class_ids[keep]):
             m = keep & (v.class_ids == c)
             out.append(ClassData(v.points[m], v.colors[m], int(c), float(v.confidences[m].min()), float(v.confidences[m].max())))
-        return out
+        return ClassDataGroup(out)
 
     def get_points(self):
         return self.get_voxels(1, -1.0).points

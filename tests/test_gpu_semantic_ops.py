@@ -425,7 +425,8 @@ def test_semantic_queries_segments_by_class_and_integrate_segment(kind):
          ref_get_voxels_in_frustum(ref, fr.intr, s.width, s.height, T, fr.depth_max, fr.depth_min, 1, 0.0))
     assert len(gpu.get_voxels_in_bb(BoundingBox3D(bb[:3], bb[3:]), 2, 0.0).class_ids) == 0  # include_semantics=False
     ids, conf = ref_get_class_segments(ref, 1, 0.0)
-    got = gpu.get_class_segments(1, 0.0)
+    got = gpu.get_class_segments(1, 0.0)  # a ClassDataGroup (voxel_grid_data.h:131-139)
+    assert list(got.class_ids) == [c.class_id for c in got.class_vector] and len(got) == len(got.class_vector)
     assert [(c.class_id, len(c.points)) for c in got] == [tuple(r) for r in ids.tolist()]
     np.testing.assert_allclose([[c.confidence_min, c.confidence_max] for c in got], conf, rtol=0, atol=tol)
 
@@ -589,3 +590,32 @@ def test_block_ownership_sharding_with_exchanged_votes_equals_the_single_grid(ki
     for x, y in zip(got, exp):
         np.testing.assert_array_equal(x, y)
     assert sum(g.num_blocks() for g in ranks) == single.num_blocks()
+
+
+def test_remap_instance_ids_as_the_module_binds_it():
+    """volumetric.remap_instance_ids (image_utils_module.h:49-94): ids absent from the map become -1, an EMPTY map hands the image back
+    unchanged (the binding's early return; the C++ template behind it would set everything to -1) - host arrays and CUDA tensors, against
+    the compiled reference through the same two early returns."""
+    import torch
+
+    from pyslam_amd.volumetric_semantic import remap_instance_ids
+
+    rng = np.random.default_rng(8)
+    img = rng.integers(-2, 9, (120, 160)).astype(np.int32)
+    for m in ({}, {0: 0, 3: 41, 7: -1, 100: 5}):
+        exp = ref_remap_instance_ids(img, m)
+        np.testing.assert_array_equal(remap_instance_ids(img, m), exp)
+        np.testing.assert_array_equal(remap_instance_ids(torch.from_numpy(img).cuda(), m).cpu().numpy(), exp)
+    np.testing.assert_array_equal(ref_remap_instance_ids(img, {}), img)
+    assert (ref_remap_instance_ids(img, {3: 41}) == np.where(img == 3, 41, -1)).all()
+    # the narrower image types of the binding (int8 / uint8 / int16 / uint16): same lookup, results narrowed like the C++ assignment
+    for dt in (np.int8, np.uint8, np.int16, np.uint16):
+        small = rng.integers(0, 9, (40, 50)).astype(dt)
+        m = {0: 0, 3: 300, 7: -1}
+        exp = np.vectorize(lambda x: m.get(int(x), -1))(small).astype(np.int64).astype(dt)
+        got = remap_instance_ids(small, m)
+        assert got.dtype == dt
+        np.testing.assert_array_equal(got, exp)
+        assert remap_instance_ids(small, {}) is not None and (remap_instance_ids(small, {}) == small).all()
+    with pytest.raises(RuntimeError, match="Unsupported instance id type"):
+        remap_instance_ids(img.astype(np.float32), {1: 2})

@@ -160,3 +160,12 @@ def test_label_map_sizes_the_reference_builds():
     most, hist = result[0.05]
     over = hist[8:].sum() / hist.sum()
     assert most > 7 and 0.005 < over < 0.05  # 1-2 % of the occupied voxels need an overflow node
+
+
+@need_ref
+def test_remap_instance_ids_port_vs_reference_including_the_empty_map():
+    rng = np.random.default_rng(8)
+    img = rng.integers(-2, 9, (60, 80)).astype(np.int32)
+    for m in ({}, {0: 0, 3: 41, 7: -1, 100: 5}):
+        np.testing.assert_array_equal(port_remap_instance_ids(img, m), ref_remap_instance_ids(img, m))
+    np.testing.assert_array_equal(ref_remap_instance_ids(img, {}), img)  # the binding's early return (image_utils_module.h:52-58)
