@@ -459,3 +459,50 @@ void ref_obb3_from_points(const double *pts, int64_t n, double *out10) {
     put_obb(volumetric::OrientedBoundingBox3D::compute_from_points<double>(v, volumetric::OBBComputationMethod::PCA), out10);
 }
 }
+
+// ---- 2D bounding boxes (cpp/volumetric/bounding_boxes_2d.h/.cpp, bindings bounding_boxes_module.h:165-258): the same thin exports.
+// aabb = {min xy, max xy} (4 doubles); obb = {center xy, angle, size xy} (5 doubles).
+#include "bounding_boxes_2d.h"
+namespace {
+volumetric::BoundingBox2D mk_aabb2(const double *b) { return volumetric::BoundingBox2D(b[0], b[1], b[2], b[3]); }
+volumetric::OrientedBoundingBox2D mk_obb2(const double *o) {
+    return volumetric::OrientedBoundingBox2D(Eigen::Vector2d(o[0], o[1]), o[2], Eigen::Vector2d(o[3], o[4]));
+}
+} // namespace
+extern "C" {
+void ref_aabb2_scalars(const double *b, double *out7) { // center 2, size 2, area, perimeter, diagonal
+    const auto a = mk_aabb2(b);
+    const auto c = a.get_center(), s = a.get_size();
+    out7[0] = c.x(); out7[1] = c.y(); out7[2] = s.x(); out7[3] = s.y();
+    out7[4] = a.get_area(); out7[5] = a.get_perimeter(); out7[6] = a.get_diagonal_length();
+}
+void ref_aabb2_contains(const double *b, const double *pts, int64_t n, uint8_t *out) {
+    const auto a = mk_aabb2(b);
+    for (int64_t i = 0; i < n; ++i) out[i] = a.contains<double>(pts[2 * i], pts[2 * i + 1]) ? 1 : 0;
+}
+int ref_aabb2_intersects(const double *a, const double *b) { return mk_aabb2(a).intersects(mk_aabb2(b)) ? 1 : 0; }
+void ref_aabb2_from_points(const double *pts, int64_t n, double *out4) {
+    std::vector<Eigen::Vector2d> v((size_t)n);
+    for (int64_t i = 0; i < n; ++i) v[i] = Eigen::Vector2d(pts[2 * i], pts[2 * i + 1]);
+    const auto a = volumetric::BoundingBox2D::compute_from_points<double>(v);
+    out4[0] = a.min_x; out4[1] = a.min_y; out4[2] = a.max_x; out4[3] = a.max_y;
+}
+void ref_obb2_scalars(const double *o, double *out4, double *corners8) { // volume, area, perimeter, diagonal; corners [4,2]
+    const auto b = mk_obb2(o);
+    out4[0] = b.get_volume(); out4[1] = b.get_area(); out4[2] = b.get_perimeter(); out4[3] = b.get_diagonal_length();
+    const auto cs = b.get_corners();
+    for (int i = 0; i < 4; ++i) { corners8[2 * i] = cs[i].x(); corners8[2 * i + 1] = cs[i].y(); }
+}
+void ref_obb2_contains(const double *o, const double *pts, int64_t n, uint8_t *out) {
+    const auto b = mk_obb2(o);
+    for (int64_t i = 0; i < n; ++i) out[i] = b.contains<double>(pts[2 * i], pts[2 * i + 1]) ? 1 : 0;
+}
+int ref_obb2_intersects_obb(const double *a, const double *b) { return mk_obb2(a).intersects(mk_obb2(b)) ? 1 : 0; }
+int ref_obb2_intersects_aabb(const double *a, const double *b) { return mk_obb2(a).intersects(mk_aabb2(b)) ? 1 : 0; }
+void ref_obb2_from_points(const double *pts, int64_t n, double *out5) {
+    std::vector<Eigen::Vector2d> v((size_t)n);
+    for (int64_t i = 0; i < n; ++i) v[i] = Eigen::Vector2d(pts[2 * i], pts[2 * i + 1]);
+    const auto b = volumetric::OrientedBoundingBox2D::compute_from_points<double>(v, volumetric::OBBComputationMethod::PCA);
+    out5[0] = b.center.x(); out5[1] = b.center.y(); out5[2] = b.angle_rad; out5[3] = b.size.x(); out5[4] = b.size.y();
+}
+}

@@ -1,9 +1,9 @@
 """One namespace with the names of the reference's ``volumetric`` extension module (cpp/volumetric/volumetric_module.cpp:33-62 and the
 bind_* functions it calls): code written against ``import volumetric`` runs against ``import pyslam_amd.volumetric_module as volumetric``.
 
-Not provided: ``BoundingBox2D`` / ``OrientedBoundingBox2D`` (bounding_boxes_module.h:165-258 - image-plane boxes that nothing on the
-dense path touches).  The ``F`` twins of the result classes (float32 positions, voxel_grid_data_module.h:179-188) are the same
+Every bound name is here (tests/test_volumetric_module_names_cpu.py).  The ``F`` twins of the result classes (float32 positions, voxel_grid_data_module.h:179-188) are the same
 Python classes: the arrays carry their dtype."""
+from .bounding_boxes_2d import BoundingBox2D, OrientedBoundingBox2D  # noqa: F401
 from .volumetric import (BoundingBox3D, CameraFrustrum, ImagePoint, Quaterniond, TBBUtils, VoxelBlockGrid, VoxelData, VoxelGrid,  # noqa: F401
                          VoxelGridData)
 from .volumetric_semantic import (ClassData, ClassDataGroup, OBBComputationMethod, ObjectData, ObjectDataGroup, OrientedBoundingBox3D,  # noqa: F401

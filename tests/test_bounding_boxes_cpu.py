@@ -4,7 +4,7 @@ pyslam_amd.volumetric_semantic.OrientedBoundingBox3D: what get_voxels_in_bb take
 * the COMPILED reference classes (cpp/volumetric/bounding_boxes_3d.h/.cpp through oracle/_ref: getters, contains, the
   separating-axis intersects of box pairs, corners, matrices, PCA compute_from_points) on seeded random inputs, and
 * the scenarios and expected values of the reference's own unit tests for these classes
-  (cpp/test_volumetric_bounding_boxes.py:67-543, 865-1250: the 3D / PCA cases; its 2D boxes and the Qhull method are outside
+  (cpp/test_volumetric_bounding_boxes.py:67-543, 865-1250: the 3D / PCA cases; its 2D boxes: tests/test_bounding_boxes_2d_cpu.py; the Qhull method is outside
   the path).
 Host code only - the PCA entry point hv_compute_obb_pca is a host function of the C ABI."""
 import ctypes as C

@@ -1,6 +1,5 @@
 """CPU: pyslam_amd.volumetric_module offers every name the reference's `volumetric` extension module binds (fixture
-tests/golden/volumetric_module_names.json, read from the binding sources by tools/make_golden_module_names.py) except the two
-image-plane boxes it declares as not provided; plus the small host helpers of that namespace against their C++ definitions."""
+tests/golden/volumetric_module_names.json, read from the binding sources by tools/make_golden_module_names.py); plus the small host helpers of that namespace against their C++ definitions."""
 import json
 import os
 import pickle
@@ -8,7 +7,6 @@ import pickle
 import numpy as np
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "volumetric_module_names.json")
-NOT_PROVIDED = {"BoundingBox2D", "OrientedBoundingBox2D"}
 
 
 def test_every_bound_name_exists():
@@ -17,7 +15,7 @@ def test_every_bound_name_exists():
     names = json.load(open(GOLD))
     assert len(names) >= 34
     missing = [n for n in names if not hasattr(volumetric, n)]
-    assert set(missing) == NOT_PROVIDED, missing
+    assert missing == [], missing
 
 
 def test_quaterniond_like_eigen():
