@@ -739,6 +739,21 @@ def main():
             torch.cuda.synchronize()
             t_mesh_dev = time.perf_counter() - t1
             assert mesh.vertices.is_cuda and len(mesh.vertices) > 0
+            # ... and a tick handed over as float32 (dtype=np.float32: hv_tsdf_extract_mesh_f32 - the float64 values rounded once on the
+            # device, what pySLAM's viewer casts the arrays to; opt-in, Open3D's arrays are float64)
+            del mesh
+            vol.integrate(RGBDImage(rgb_d[4], depth_d[4], 1.0, DEPTH_TRUNC), Kcam, T_res[4])
+            fence()
+            vol.extract_triangle_mesh(dtype=np.float32)  # (its page-locked result arrays exist from here on)
+            vol.integrate(RGBDImage(rgb_d[5], depth_d[5], 1.0, DEPTH_TRUNC), Kcam, T_res[5])
+            fence()
+            vol.profile_enable(True)
+            t1 = time.perf_counter()
+            mesh = vol.extract_triangle_mesh(dtype=np.float32)
+            t_mesh_f32 = time.perf_counter() - t1
+            k_mesh_f32 = vol.profile_read()[0]
+            vol.profile_enable(False)
+            assert mesh.vertices.dtype == np.float32 and len(mesh.vertices) > 0
             # ... and a FULL pass (HV_EXTRACT_INCREMENTAL=0: masks, classification and counts of every unit again - what every tick cost
             # before round 6 and what the first extraction of a volume still costs), after one more keyframe
             del mesh
@@ -768,6 +783,9 @@ def main():
                                     "mesh_full_pass_kernel_ms: every unit recomputed (HV_EXTRACT_INCREMENTAL=0; rounds 2-5 paid this on every tick)",
                 "mesh_fetch_only_ms": round(t_mesh_fetch * 1e3, 2),
                 "mesh_device_resident_wall_ms": round(t_mesh_dev * 1e3, 2),
+                "mesh_f32_wall_ms": round(t_mesh_f32 * 1e3, 2), "mesh_f32_kernel_ms": round(k_mesh_f32, 3),
+                "mesh_f32_what": "the same tick with float32 vertices / colours (extract_triangle_mesh(dtype=np.float32): 24 instead of 48 bytes per vertex "
+                                 "written and copied to the host; opt-in - Open3D's and the reference's arrays are float64)",
                 "mesh_first_call_ms": round(t_mesh_cold * 1e3, 2), "points_first_call_ms": round(t_pc_cold * 1e3, 2),
                 "points_wall_ms": round(t_pc * 1e3, 2), "points_kernel_ms": round(k_pc, 3),
                 "roofline": {"bound": "hbm", "kernel": "FULL pass: k_unit_masks + k_mc_classify over every unit + scans + k_mc_vertices + k_mc_triangles",
@@ -961,13 +979,13 @@ def main():
                     tot += t
                 return int(tot)
 
-            extraction["roofline"]["traffic"] = kernels_traffic(("k_unit_masks@full", "k_mc_classify@full", "k_mc_vertices", "k_mc_triangles"))
-            extraction["tick_roofline"]["traffic"] = kernels_traffic(("k_unit_masks", "k_mc_classify", "k_mc_vertices", "k_mc_triangles"))
+            extraction["roofline"]["traffic"] = kernels_traffic(("k_unit_masks@full", "k_mc_classify@full", "k_mc_vertices<double>", "k_mc_triangles"))
+            extraction["tick_roofline"]["traffic"] = kernels_traffic(("k_unit_masks", "k_mc_classify", "k_mc_vertices<double>", "k_mc_triangles"))
             for key in ("roofline", "tick_roofline"):
                 r = extraction[key]
                 if r["traffic"]:
                     r["traffic_over_algorithmic"] = round(r["traffic"] / r["algorithmic_bytes"], 2)
-            extraction["points_roofline"]["traffic"] = kernels_traffic(("k_unit_masks", "k_pc_extract<false>", "k_pc_extract<true>"))
+            extraction["points_roofline"]["traffic"] = kernels_traffic(("k_unit_masks", "k_pc_extract<false", "k_pc_extract<true"))
         if online is not None:
             om = {"value": round(online["fps"], 2), "unit": "frames/s",
                   "what": "one hv_tsdf_integrate per frame (pySLAM's online flow), same sliding stream, fresh volume", "roofline": None}

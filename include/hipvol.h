@@ -388,8 +388,18 @@ int hv_tsdf_set_owner(hv_volume *v, int32_t rank, int32_t world_size);
 int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, int64_t cap_vertices,
                          int32_t *triangles, int64_t cap_triangles, int64_t *n_vertices,
                          int64_t *n_triangles);
+/* The same mesh with float32 vertices / vertex_colors: the float64 values of hv_tsdf_extract_mesh rounded once on the device
+ * (numpy's astype(float32) of its arrays, bit for bit).  pySLAM's viewer and dense-map consumers take float32
+ * (Parameters.kDenseMappingDtypeVertices / kDenseMappingDtypeColors, pyslam/config_parameters.py:290-291; the viewer casts,
+ * pyslam/viz/viewer3D.py:1335-1342): a third fewer bytes across PCIe per output tick and half the vertex bytes written.
+ * Opt-in: Open3D's arrays (and the reference's VolumetricIntegrationMesh, volumetric_integrator_base.py:209-214) are float64. */
+int hv_tsdf_extract_mesh_f32(hv_volume *v, float *vertices, float *vertex_colors, int64_t cap_vertices,
+                             int32_t *triangles, int64_t cap_triangles, int64_t *n_vertices,
+                             int64_t *n_triangles);
 /* extract_point_cloud() (volumetric_integrator_tsdf.py:246,267): points/colors f64 [N,3]. */
 int hv_tsdf_extract_points(hv_volume *v, double *points, double *colors, int64_t cap, int64_t *n);
+/* ... with float32 points / colors (the float64 rows rounded once, as hv_tsdf_extract_mesh_f32). */
+int hv_tsdf_extract_points_f32(hv_volume *v, float *points, float *colors, int64_t cap, int64_t *n);
 /* The normals Open3D's extract_point_cloud() attaches to those points (ScalableTSDFVolume::GetNormalAt: central differences of
  * the trilinearly interpolated tsdf at +/- 0.99 voxel, normalised); o3d.io.write_point_cloud stores them in dense_map.ply
  * (volumetric_integrator_tsdf.py:246-247).  normals f64 [N,3] in the order of hv_tsdf_extract_points; NULL to query *n. */

@@ -116,7 +116,9 @@ SIGNATURES = {
     "hv_tsdf_set_rectify_maps": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32]),
     "hv_tsdf_set_owner": (_i32, [_vp, _i32, _i32]),
     "hv_tsdf_extract_mesh": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _pi64, _pi64]),
+    "hv_tsdf_extract_mesh_f32": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _pi64, _pi64]),
     "hv_tsdf_extract_points": (_i32, [_vp, _vp, _vp, _i64, _pi64]),
+    "hv_tsdf_extract_points_f32": (_i32, [_vp, _vp, _vp, _i64, _pi64]),
     "hv_tsdf_extract_point_normals": (_i32, [_vp, _vp, _i64, _pi64]),
     "hv_tsdf_dump": (_i32, [_vp, _vp, _vp, _vp, _vp, _pi64]),
     "hv_tsdf_touched": (_i32, [_vp, _vp, _i64, _pi64]),

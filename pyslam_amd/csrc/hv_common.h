@@ -433,6 +433,7 @@ struct hv_volume {
     uint64_t content_version = 1;
     uint64_t mesh_cache_version = 0, points_cache_version = 0; // content_version the cached results belong to (0: none)
     int64_t mesh_cache_nv = 0, mesh_cache_nt = 0, points_cache_n = 0;
+    bool mesh_cache_f32 = false, points_cache_f32 = false; // out_a holds float32 rows (hv_tsdf_extract_mesh_f32 / _points_f32)
     // per-unit column masks both extractions start from (hv_extract.hip: k_unit_masks), valid for unit_masks_version
     void *unit_masks = nullptr;
     uint64_t unit_masks_version = 0;

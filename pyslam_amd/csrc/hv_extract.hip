@@ -322,11 +322,14 @@ __device__ __forceinline__ int hv_nth_set_bit(unsigned long long m, int n) { // 
     return pos;
 }
 
+// OUT = double: Open3D's arrays; OUT = float: the same float64 values rounded once on the way out (hv_tsdf_extract_mesh_f32 - what
+// pySLAM's viewer casts them to, config_parameters.py:290-291; half the bytes written here and half the bytes across PCIe).
+template <typename OUT>
 __global__ __launch_bounds__(64) void k_mc_vertices(HvTable table, const char *__restrict__ pool, int n_units,
                                                      const unsigned long long *__restrict__ edge_mask,
                                                      const uint32_t *__restrict__ word_prefix,
                                                      const unsigned long long *__restrict__ bases, HvMcParams M,
-                                                     double *__restrict__ vertices, double *__restrict__ colors,
+                                                     OUT *__restrict__ vertices, OUT *__restrict__ colors,
                                                      int64_t cap) {
     __shared__ unsigned long long s_mask[MASK_WORDS];
     __shared__ uint32_t s_prefix[MASK_WORDS + 1];
@@ -387,8 +390,8 @@ __global__ __launch_bounds__(64) void k_mc_vertices(HvTable table, const char *_
         pt[axis] += f0 * M.voxel_length / (f0 + f1);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            vertices[vi * 3 + k] = pt[k];
-            colors[vi * 3 + k] = (f1 * c0[k] + f0 * c1[k]) / (f0 + f1);
+            vertices[vi * 3 + k] = (OUT)pt[k];
+            colors[vi * 3 + k] = (OUT)((f1 * c0[k] + f0 * c1[k]) / (f0 + f1));
         }
     }
 }
@@ -508,12 +511,12 @@ __global__ __launch_bounds__(256) void k_mc_triangles(HvTable table, int n_units
 // of a crossing only - no atomics, and the output order is deterministic (unit, column, axis, z).  (Second form: both passes
 // staged a 17^3 float slab of the planes, 0.38 + 0.53 ms and 5.6 GB of traffic per 32 k units, profiles/r03 before this
 // form.  First form: one thread per voxel, a workgroup-aggregated append - 1.43 ms per pass, profiles/r02.)
-template <bool FILL>
+template <bool FILL, typename OUT = double>
 __global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *__restrict__ pool, const uint32_t *__restrict__ m_on,
                                                      const uint32_t *__restrict__ m_ip, int n_units, HvMcParams M,
                                                      double unit_length, int32_t *__restrict__ count,
-                                                     const int32_t *__restrict__ base, double *__restrict__ points,
-                                                     double *__restrict__ colors, int64_t cap, const int32_t *__restrict__ mask_stamp, int32_t since) {
+                                                     const int32_t *__restrict__ base, OUT *__restrict__ points,
+                                                     OUT *__restrict__ colors, int64_t cap, const int32_t *__restrict__ mask_stamp, int32_t since) {
     __shared__ int s_nbr[8];
     __shared__ int s_wave[4];
     const int idx = blockIdx.x;
@@ -619,8 +622,8 @@ __global__ __launch_bounds__(256) void k_pc_extract(HvTable table, const char *_
         p[i] = (p0[i] * (double)r1 + p1i * (double)r0) / (double)(r0 + r1);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            points[at * 3 + k] = p[k];
-            colors[at * 3 + k] = (double)((c0[k] * r1 + c1[k] * r0) / (r0 + r1) / 255.0f);
+            points[at * 3 + k] = (OUT)p[k];
+            colors[at * 3 + k] = (OUT)(double)((c0[k] * r1 + c1[k] * r0) / (r0 + r1) / 255.0f);
         }
     }
 }
@@ -795,7 +798,7 @@ static int unit_masks_compute(hv_volume *v, int n, HvUnitMasks *out) {
     return HV_OK;
 }
 
-static int mesh_compute(hv_volume *v) {
+static int mesh_compute(hv_volume *v, bool f32) {
     int rc = upload_tables(v->device);
     if (rc != HV_OK) return rc;
     int64_t nb = 0;
@@ -844,15 +847,21 @@ static int mesh_compute(hv_volume *v) {
     const int64_t totals[2] = {(int64_t)(uint32_t)total64, (int64_t)(total64 >> 32)};
     const int64_t nv = totals[0], nt = totals[1];
     if (nv > 0 || nt > 0) {
-        rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, sizeof(double) * 6 * (size_t)std::max<int64_t>(nv, 1));
+        rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, (f32 ? sizeof(float) : sizeof(double)) * 6 * (size_t)std::max<int64_t>(nv, 1));
         if (rc != HV_OK) return rc;
         rc = hv_ensure_buffer(v, &v->out_b, &v->out_b_bytes, sizeof(int32_t) * 3 * (size_t)std::max<int64_t>(nt, 1));
         if (rc != HV_OK) return rc;
-        double *d_vert = (double *)v->out_a, *d_col = d_vert + 3 * nv;
         HvMcParams M{v->cfg.voxel_size, v->cfg.voxel_size * 0.5};
         hv_profile_begin(v); // vertices + triangles (D2H of the results is outside the bracket)
-        hipLaunchKernelGGL(k_mc_vertices, dim3(n), dim3(64), 0, v->stream, v->table,
-                           (const char *)v->pool, n, edge_mask, word_prefix, bases, M, d_vert, d_col, nv);
+        if (f32) {
+            float *d_vert = (float *)v->out_a, *d_col = d_vert + 3 * nv;
+            hipLaunchKernelGGL(k_mc_vertices<float>, dim3(n), dim3(64), 0, v->stream, v->table,
+                               (const char *)v->pool, n, edge_mask, word_prefix, bases, M, d_vert, d_col, nv);
+        } else {
+            double *d_vert = (double *)v->out_a, *d_col = d_vert + 3 * nv;
+            hipLaunchKernelGGL(k_mc_vertices<double>, dim3(n), dim3(64), 0, v->stream, v->table,
+                               (const char *)v->pool, n, edge_mask, word_prefix, bases, M, d_vert, d_col, nv);
+        }
         hipLaunchKernelGGL(k_mc_triangles, dim3(n), dim3(256), 0, v->stream, v->table, n, (const uint8_t *)cases, edge_mask,
                            word_prefix, bases, (int32_t *)v->out_b, nt);
         hv_profile_end(v, n);
@@ -860,35 +869,51 @@ static int mesh_compute(hv_volume *v) {
     }
     v->mesh_cache_nv = nv;
     v->mesh_cache_nt = nt;
+    v->mesh_cache_f32 = f32;
     v->mesh_cache_version = v->content_version;
     return HV_OK;
 }
 
-int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, int64_t cap_vertices,
-                         int32_t *triangles, int64_t cap_triangles, int64_t *n_vertices, int64_t *n_triangles) {
-    HV_REQUIRE(v != nullptr && n_vertices != nullptr && n_triangles != nullptr, HV_ERR_INVALID,
-               "hv_tsdf_extract_mesh: null argument");
-    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_extract_mesh: volume is not in TSDF mode");
+// OUT = double: hv_tsdf_extract_mesh; OUT = float: hv_tsdf_extract_mesh_f32.  A result cached in the other type is computed again
+// (the per-unit caches stand: only the vertex and triangle passes run).
+} // extern "C"
+template <typename OUT>
+static int extract_mesh_as(hv_volume *v, OUT *vertices, OUT *vertex_colors, int64_t cap_vertices, int32_t *triangles, int64_t cap_triangles,
+                           int64_t *n_vertices, int64_t *n_triangles, const char *who) {
+    HV_REQUIRE(v != nullptr && n_vertices != nullptr && n_triangles != nullptr, HV_ERR_INVALID, "%s: null argument", who);
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "%s: volume is not in TSDF mode", who);
     HV_HIP(hipSetDevice(v->device));
-    if (v->mesh_cache_version != v->content_version) {
-        const int rc = mesh_compute(v);
+    constexpr bool f32 = sizeof(OUT) == sizeof(float);
+    if (v->mesh_cache_version != v->content_version || v->mesh_cache_f32 != f32) {
+        const int rc = mesh_compute(v, f32);
         if (rc != HV_OK) return rc;
     }
     *n_vertices = v->mesh_cache_nv;
     *n_triangles = v->mesh_cache_nt;
     if (vertices == nullptr || vertex_colors == nullptr || triangles == nullptr) return HV_OK;
     const int64_t nv = std::min<int64_t>(v->mesh_cache_nv, cap_vertices), nt = std::min<int64_t>(v->mesh_cache_nt, cap_triangles);
-    const double *d_vert = (const double *)v->out_a, *d_col = d_vert + 3 * v->mesh_cache_nv;
+    const OUT *d_vert = (const OUT *)v->out_a, *d_col = d_vert + 3 * v->mesh_cache_nv;
     if (nv > 0) {
-        HV_HIP(hipMemcpyAsync(vertices, d_vert, sizeof(double) * 3 * nv, hipMemcpyDefault /* the destination may be host or device memory (a GPU consumer) */, v->stream));
-        HV_HIP(hipMemcpyAsync(vertex_colors, d_col, sizeof(double) * 3 * nv, hipMemcpyDefault, v->stream));
+        HV_HIP(hipMemcpyAsync(vertices, d_vert, sizeof(OUT) * 3 * nv, hipMemcpyDefault /* the destination may be host or device memory (a GPU consumer) */, v->stream));
+        HV_HIP(hipMemcpyAsync(vertex_colors, d_col, sizeof(OUT) * 3 * nv, hipMemcpyDefault, v->stream));
     }
     if (nt > 0) HV_HIP(hipMemcpyAsync(triangles, v->out_b, sizeof(int32_t) * 3 * nt, hipMemcpyDefault, v->stream));
     HV_HIP(hipStreamSynchronize(v->stream));
     return HV_OK;
 }
 
-static int points_compute(hv_volume *v) {
+extern "C" {
+int hv_tsdf_extract_mesh(hv_volume *v, double *vertices, double *vertex_colors, int64_t cap_vertices,
+                         int32_t *triangles, int64_t cap_triangles, int64_t *n_vertices, int64_t *n_triangles) {
+    return extract_mesh_as<double>(v, vertices, vertex_colors, cap_vertices, triangles, cap_triangles, n_vertices, n_triangles, "hv_tsdf_extract_mesh");
+}
+
+int hv_tsdf_extract_mesh_f32(hv_volume *v, float *vertices, float *vertex_colors, int64_t cap_vertices,
+                             int32_t *triangles, int64_t cap_triangles, int64_t *n_vertices, int64_t *n_triangles) {
+    return extract_mesh_as<float>(v, vertices, vertex_colors, cap_vertices, triangles, cap_triangles, n_vertices, n_triangles, "hv_tsdf_extract_mesh_f32");
+}
+
+static int points_compute(hv_volume *v, bool f32) {
     int64_t nb = 0;
     int rc = hv_num_blocks(v, &nb);
     if (rc != HV_OK) return rc;
@@ -913,7 +938,7 @@ static int points_compute(hv_volume *v) {
     const uint32_t *m_on = UM.m_on, *m_ip = UM.m_ip;
     const bool pc_full = v->pc_epoch != v->extract_epoch || nu < v->pc_units || hv_extract_full();
     HV_HIP(hipMemsetAsync(count + nu, 0, sizeof(int32_t), v->stream)); // the scan's extra element
-    hipLaunchKernelGGL(k_pc_extract<false>, dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, m_on, m_ip, nu, M,
+    hipLaunchKernelGGL((k_pc_extract<false, double>), dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, m_on, m_ip, nu, M,
                        v->cfg.voxel_size * (double)R, count, (const int32_t *)nullptr, (double *)nullptr, (double *)nullptr, (int64_t)0,
                        UM.stamp, pc_full ? (int32_t)-1 : v->pc_stamp);
     HV_HIP(hipGetLastError());
@@ -928,46 +953,65 @@ static int points_compute(hv_volume *v) {
     HV_HIP(hipStreamSynchronize(v->stream));
     const int64_t n = total;
     if (n > 0) {
-        rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, sizeof(double) * 6 * (size_t)n);
+        rc = hv_ensure_buffer(v, &v->out_a, &v->out_a_bytes, (f32 ? sizeof(float) : sizeof(double)) * 6 * (size_t)n);
         if (rc != HV_OK) return rc;
-        double *d_pts = (double *)v->out_a, *d_cols = d_pts + 3 * n;
         hv_profile_begin(v);
-        hipLaunchKernelGGL(k_pc_extract<true>, dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, m_on, m_ip, nu, M,
-                           v->cfg.voxel_size * (double)R, (int32_t *)nullptr, (const int32_t *)base, d_pts, d_cols, n, UM.stamp, (int32_t)-1);
+        if (f32) {
+            float *d_pts = (float *)v->out_a, *d_cols = d_pts + 3 * n;
+            hipLaunchKernelGGL((k_pc_extract<true, float>), dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, m_on, m_ip, nu, M,
+                               v->cfg.voxel_size * (double)R, (int32_t *)nullptr, (const int32_t *)base, d_pts, d_cols, n, UM.stamp, (int32_t)-1);
+        } else {
+            double *d_pts = (double *)v->out_a, *d_cols = d_pts + 3 * n;
+            hipLaunchKernelGGL((k_pc_extract<true, double>), dim3(nu), dim3(256), 0, v->stream, v->table, (const char *)v->pool, m_on, m_ip, nu, M,
+                               v->cfg.voxel_size * (double)R, (int32_t *)nullptr, (const int32_t *)base, d_pts, d_cols, n, UM.stamp, (int32_t)-1);
+        }
         hv_profile_end(v, nb);
         HV_HIP(hipGetLastError());
     }
     v->points_cache_n = n;
+    v->points_cache_f32 = f32;
     v->points_cache_version = v->content_version;
     return HV_OK;
 }
 
-int hv_tsdf_extract_points(hv_volume *v, double *points, double *colors, int64_t cap, int64_t *n) {
-    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_tsdf_extract_points: null argument");
-    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_extract_points: volume is not in TSDF mode");
+} // extern "C"
+template <typename OUT>
+static int extract_points_as(hv_volume *v, OUT *points, OUT *colors, int64_t cap, int64_t *n, const char *who) {
+    HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "%s: null argument", who);
+    HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "%s: volume is not in TSDF mode", who);
     HV_HIP(hipSetDevice(v->device));
-    if (v->points_cache_version != v->content_version) {
-        const int rc = points_compute(v);
+    constexpr bool f32 = sizeof(OUT) == sizeof(float);
+    if (v->points_cache_version != v->content_version || v->points_cache_f32 != f32) {
+        const int rc = points_compute(v, f32);
         if (rc != HV_OK) return rc;
     }
     *n = v->points_cache_n;
     if (points == nullptr || colors == nullptr || cap <= 0) return HV_OK;
     const int64_t m = std::min<int64_t>(v->points_cache_n, cap);
     if (m > 0) {
-        const double *d_pts = (const double *)v->out_a, *d_cols = d_pts + 3 * v->points_cache_n;
-        HV_HIP(hipMemcpyAsync(points, d_pts, sizeof(double) * 3 * m, hipMemcpyDefault, v->stream));
-        HV_HIP(hipMemcpyAsync(colors, d_cols, sizeof(double) * 3 * m, hipMemcpyDefault, v->stream));
+        const OUT *d_pts = (const OUT *)v->out_a, *d_cols = d_pts + 3 * v->points_cache_n;
+        HV_HIP(hipMemcpyAsync(points, d_pts, sizeof(OUT) * 3 * m, hipMemcpyDefault, v->stream));
+        HV_HIP(hipMemcpyAsync(colors, d_cols, sizeof(OUT) * 3 * m, hipMemcpyDefault, v->stream));
         HV_HIP(hipStreamSynchronize(v->stream));
     }
     return HV_OK;
+}
+
+extern "C" {
+int hv_tsdf_extract_points(hv_volume *v, double *points, double *colors, int64_t cap, int64_t *n) {
+    return extract_points_as<double>(v, points, colors, cap, n, "hv_tsdf_extract_points");
+}
+
+int hv_tsdf_extract_points_f32(hv_volume *v, float *points, float *colors, int64_t cap, int64_t *n) {
+    return extract_points_as<float>(v, points, colors, cap, n, "hv_tsdf_extract_points_f32");
 }
 
 int hv_tsdf_extract_point_normals(hv_volume *v, double *normals, int64_t cap, int64_t *n) {
     HV_REQUIRE(v != nullptr && n != nullptr, HV_ERR_INVALID, "hv_tsdf_extract_point_normals: null argument");
     HV_REQUIRE(v->cfg.mode == HV_MODE_TSDF, HV_ERR_MODE, "hv_tsdf_extract_point_normals: volume is not in TSDF mode");
     HV_HIP(hipSetDevice(v->device));
-    if (v->points_cache_version != v->content_version) {
-        const int rc = points_compute(v);
+    if (v->points_cache_version != v->content_version || v->points_cache_f32) { // (the gradient is taken at the float64 points)
+        const int rc = points_compute(v, false);
         if (rc != HV_OK) return rc;
     }
     *n = v->points_cache_n;

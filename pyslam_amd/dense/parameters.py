@@ -61,6 +61,10 @@ class Parameters:
     kVolumetricIntegrationHipMaxBlocks = None  # None: library default pool size
     kVolumetricIntegrationUseSharedMemory = True  # keyframe images / output arrays through shared memory, queues carry control only
     kVolumetricIntegrationSharedMemorySlots = 96  # ring slots (one keyframe each; 5.5 MB at 640x480)
+    # TSDF output ticks: False = Open3D's float64 vertices / colours, as the reference hands them on (base.py:209-214); True = extract
+    # them in kDenseMappingDtypeVertices / kDenseMappingDtypeColors (float32: what the viewer casts them to) - the float64 values
+    # rounded once on the device (hv_tsdf_extract_mesh_f32), a third fewer bytes per tick.  Saved files always come from float64.
+    kVolumetricIntegrationTsdfOutputInDenseMappingDtype = False
 
 
 def get_parameters():

@@ -128,10 +128,14 @@ class VolumetricIntegratorTsdf(VolumetricIntegratorBase):
                         do_output = True
                     if do_output:
                         mesh_out, pc_out = None, None
+                        kw = {}
+                        if (getattr(Parameters, "kVolumetricIntegrationTsdfOutputInDenseMappingDtype", False)
+                                and self.dtype_vertices == np.float32 and self.dtype_colors == np.float32):
+                            kw["dtype"] = np.float32  # (opt-in: float64 rounded once on the device instead of by the consumer)
                         if Parameters.kVolumetricIntegrationTsdfExtractMesh:
-                            mesh_out = VolumetricIntegrationMesh(self.volume.extract_triangle_mesh())
+                            mesh_out = VolumetricIntegrationMesh(self.volume.extract_triangle_mesh(**kw))
                         else:
-                            pc_out = VolumetricIntegrationPointCloud(self.volume.extract_point_cloud())
+                            pc_out = VolumetricIntegrationPointCloud(self.volume.extract_point_cloud(**kw))
                         last_output = VolumetricIntegrationOutput(ttype, self.last_integrated_id, pc_out, mesh_out)
                         self.last_output = last_output
                     self._publish(last_output, q_out, q_out_condition, is_running, save_request_completed, save_request_condition)

@@ -1016,50 +1016,63 @@ class ScalableTSDFVolume(_Volume):
         """Fuse/store only the units owned by `rank` of `world_size` (multi-GPU unit-ownership sharding)."""
         L.check(self._lib.hv_tsdf_set_owner(self._h, int(rank), int(world_size)))
 
-    def extract_triangle_mesh(self, device=False):
+    @staticmethod
+    def _out_dtype(dtype):
+        dt = np.dtype(np.float64 if dtype is None else dtype)
+        if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise TypeError(f"extraction dtype must be float64 (Open3D's) or float32, got {dt}")
+        return dt
+
+    def extract_triangle_mesh(self, device=False, dtype=None):
         """o3d's extract_triangle_mesh().  device=True: vertices / vertex_colors / triangles are torch CUDA tensors on the volume's GPU
-        (nothing crosses PCIe: for consumers that render or post-process on the GPU); default: host arrays like Open3D's."""
+        (nothing crosses PCIe: for consumers that render or post-process on the GPU); default: host arrays like Open3D's.
+        dtype=np.float32: vertices / vertex_colors as float32 - Open3D's float64 values rounded once on the device (what
+        Parameters.kDenseMappingDtypeVertices / Colors name and pySLAM's viewer casts to, config_parameters.py:290-291): a third fewer
+        bytes per output tick.  Default float64 = Open3D's arrays."""
+        dt = self._out_dtype(dtype)
+        fn = self._lib.hv_tsdf_extract_mesh if dt == np.float64 else self._lib.hv_tsdf_extract_mesh_f32
         nv, nt = ctypes.c_int64(), ctypes.c_int64()
-        L.check(self._lib.hv_tsdf_extract_mesh(self._h, None, None, 0, None, 0, ctypes.byref(nv), ctypes.byref(nt)))
+        L.check(fn(self._h, None, None, 0, None, 0, ctypes.byref(nv), ctypes.byref(nt)))
         if device:
             import torch
 
             dev = torch.device("cuda", int(self._cfg.device))
-            verts = torch.empty((nv.value, 3), dtype=torch.float64, device=dev)
-            cols = torch.empty((nv.value, 3), dtype=torch.float64, device=dev)
+            tdt = torch.float64 if dt == np.float64 else torch.float32
+            verts = torch.empty((nv.value, 3), dtype=tdt, device=dev)
+            cols = torch.empty((nv.value, 3), dtype=tdt, device=dev)
             tris = torch.empty((nt.value, 3), dtype=torch.int32, device=dev)
             torch.cuda.current_stream(dev).synchronize()  # (the allocator may hand out blocks with work pending on torch's stream)
         else:
-            verts = _result_array((nv.value, 3), np.float64)
-            cols = _result_array((nv.value, 3), np.float64)
+            verts = _result_array((nv.value, 3), dt)
+            cols = _result_array((nv.value, 3), dt)
             tris = _result_array((nt.value, 3), np.int32)
         if nv.value or nt.value:
-            L.check(
-                self._lib.hv_tsdf_extract_mesh(
-                    self._h, L.ptr(verts), L.ptr(cols), nv.value, L.ptr(tris), nt.value, ctypes.byref(nv), ctypes.byref(nt)
-                )
-            )
+            L.check(fn(self._h, L.ptr(verts), L.ptr(cols), nv.value, L.ptr(tris), nt.value, ctypes.byref(nv), ctypes.byref(nt)))
         return TriangleMesh(verts, tris, cols)
 
-    def extract_point_cloud(self, normals=False, device=False):
+    def extract_point_cloud(self, normals=False, device=False, dtype=None):
         """o3d's extract_point_cloud().  normals=True also computes the per-point normals Open3D attaches (GetNormalAt: the
         gradient of the trilinearly interpolated tsdf) - pySLAM's viewer path does not read them, its save path writes them.
-        device=True: torch CUDA tensors on the volume's GPU instead of host arrays."""
+        device=True: torch CUDA tensors on the volume's GPU instead of host arrays.  dtype=np.float32: points / colors as float32
+        (see extract_triangle_mesh; the normals stay float64, taken at the float64 points)."""
+        dt = self._out_dtype(dtype)
+        fn = self._lib.hv_tsdf_extract_points if dt == np.float64 else self._lib.hv_tsdf_extract_points_f32
         n = ctypes.c_int64()
-        L.check(self._lib.hv_tsdf_extract_points(self._h, None, None, 0, ctypes.byref(n)))
+        L.check(fn(self._h, None, None, 0, ctypes.byref(n)))
         if device:
             import torch
 
             dev = torch.device("cuda", int(self._cfg.device))
-            pts = torch.empty((n.value, 3), dtype=torch.float64, device=dev)
-            cols = torch.empty((n.value, 3), dtype=torch.float64, device=dev)
+            tdt = torch.float64 if dt == np.float64 else torch.float32
+            pts = torch.empty((n.value, 3), dtype=tdt, device=dev)
+            cols = torch.empty((n.value, 3), dtype=tdt, device=dev)
             torch.cuda.current_stream(dev).synchronize()
         else:
-            pts = _result_array((n.value, 3), np.float64)
-            cols = _result_array((n.value, 3), np.float64)
+            pts = _result_array((n.value, 3), dt)
+            cols = _result_array((n.value, 3), dt)
         nrm = None
         if n.value:
-            L.check(self._lib.hv_tsdf_extract_points(self._h, L.ptr(pts), L.ptr(cols), n.value, ctypes.byref(n)))
+            L.check(fn(self._h, L.ptr(pts), L.ptr(cols), n.value, ctypes.byref(n)))
         if normals:
             nrm = torch.zeros((n.value, 3), dtype=torch.float64, device=dev) if device else np.zeros((n.value, 3), np.float64)
             if n.value:

@@ -175,13 +175,16 @@ def test_voxel_grid_integrator_matches_reference_flow():
         integ.quit()
 
 
-def test_tsdf_integrator_end_to_end(tmp_path):
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_tsdf_integrator_end_to_end(tmp_path, out_f32, monkeypatch):
+    """out_f32: kVolumetricIntegrationTsdfOutputInDenseMappingDtype - the output ticks carry float32 vertices / colours (the float64
+    ones rounded once on the device); the saved dense_map.ply still comes from float64."""
     from pyslam_amd.dense import VolumetricIntegrationTaskType, VolumetricIntegratorType, volumetric_integrator_factory
     from pyslam_amd.dense.ply_io import read_ply
     from pyslam_amd.dense.volumetric_integrator_types import DatasetEnvironmentType, SensorType
     from pyslam_amd.synthetic import SyntheticRGBD
 
-    _params(0.02, 0.08)
+    monkeypatch.setattr(_params(0.02, 0.08), "kVolumetricIntegrationTsdfOutputInDenseMappingDtype", out_f32)
     s = SyntheticRGBD("tiny_160x120_2cm")
     cam = dh.FakeCamera(s)
     integ = volumetric_integrator_factory(VolumetricIntegratorType.TSDF, cam, DatasetEnvironmentType.INDOOR, SensorType.RGBD)
@@ -201,7 +204,11 @@ def test_tsdf_integrator_end_to_end(tmp_path):
         v, t, c = cpu.extract_triangle_mesh()
         assert last.task_type == VolumetricIntegrationTaskType.INTEGRATE and last.id == 2
         assert last.mesh.vertices.shape == v.shape and last.mesh.triangles.shape == t.shape
-        np.testing.assert_allclose(np.sort(last.mesh.vertices, axis=0), np.sort(v, axis=0), atol=1e-9)
+        assert last.mesh.vertices.dtype == last.mesh.vertex_colors.dtype == (np.float32 if out_f32 else np.float64)
+        if out_f32:
+            np.testing.assert_allclose(np.sort(last.mesh.vertices, axis=0), np.sort(v, axis=0).astype(np.float32), atol=5e-7, rtol=0)
+        else:
+            np.testing.assert_allclose(np.sort(last.mesh.vertices, axis=0), np.sort(v, axis=0), atol=1e-9)
         integ.save(str(tmp_path))
         pts, cols, faces = read_ply(str(tmp_path / "dense_map.ply"))
         assert pts.shape == v.shape and faces.shape == t.shape

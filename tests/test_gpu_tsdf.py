@@ -572,6 +572,46 @@ def test_device_resident_extraction_equals_host_extraction():
     np.testing.assert_array_equal(pd.normals.cpu().numpy(), ph.normals)
 
 
+def test_float32_extraction_is_the_float64_result_rounded_once():
+    """extract_triangle_mesh / extract_point_cloud(dtype=np.float32) (hv_tsdf_extract_mesh_f32 / _points_f32): Open3D's float64 rows
+    cast to float32 - numpy's astype, bit for bit - with the same triangles, in any order of the calls (a result cached in the
+    other type is computed again), on host arrays and on device tensors, and after further keyframes (incremental extraction)."""
+    from pyslam_amd.volumetric import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+
+    s, frames = synthetic_frames("tiny_160x120_2cm", 0, 6)
+    K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
+    vol = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 12)
+    for k, (d, c, T) in enumerate(frames):
+        vol.integrate(RGBDImage.create_from_color_and_depth(c, d, 1.0, 4.0, False), K, T)
+        if k < 3:
+            continue
+        m32 = vol.extract_triangle_mesh(dtype=np.float32)  # float32 first on a changed volume ...
+        m64 = vol.extract_triangle_mesh()  # ... then float64 of the same contents
+        again = vol.extract_triangle_mesh(dtype="float32")
+        assert m32.vertices.dtype == np.float32 and m32.vertex_colors.dtype == np.float32 and len(m64.vertices) > 100
+        np.testing.assert_array_equal(m32.vertices, m64.vertices.astype(np.float32))
+        np.testing.assert_array_equal(m32.vertex_colors, m64.vertex_colors.astype(np.float32))
+        np.testing.assert_array_equal(m32.triangles, m64.triangles)
+        np.testing.assert_array_equal(again.vertices, m32.vertices)
+        p64 = vol.extract_point_cloud(normals=True)
+        p32 = vol.extract_point_cloud(normals=True, dtype=np.float32)  # the normals are taken at the float64 points
+        assert p32.points.dtype == np.float32 and p32.normals.dtype == np.float64 and len(p64.points) > 100
+        np.testing.assert_array_equal(p32.points, p64.points.astype(np.float32))
+        np.testing.assert_array_equal(p32.colors, p64.colors.astype(np.float32))
+        np.testing.assert_array_equal(p32.normals, p64.normals)
+        np.testing.assert_array_equal(vol.extract_point_cloud().points, p64.points)  # (float64 again after a float32 result)
+    dev = vol.extract_triangle_mesh(device=True, dtype=np.float32)
+    assert dev.vertices.is_cuda and str(dev.vertices.dtype) == "torch.float32"
+    np.testing.assert_array_equal(dev.vertices.cpu().numpy(), m32.vertices)
+    np.testing.assert_array_equal(dev.vertex_colors.cpu().numpy(), m32.vertex_colors)
+    pdev = vol.extract_point_cloud(device=True, dtype=np.float32)
+    np.testing.assert_array_equal(pdev.points.cpu().numpy(), p32.points)
+    with pytest.raises(TypeError):
+        vol.extract_triangle_mesh(dtype=np.float16)
+    empty = ScalableTSDFVolume(0.02, 0.08, max_blocks=1 << 10).extract_triangle_mesh(dtype=np.float32)
+    assert empty.vertices.shape == (0, 3) and empty.vertices.dtype == np.float32 and empty.triangles.shape == (0, 3)
+
+
 @pytest.mark.parametrize("path", ["online", "batch"])
 def test_hip_volume_equals_the_closed_form_evaluator_on_full_frames(path):
     """the HIP volume held to tests/tsdf_closed_form.py - a float64, closed-form, whole-frame evaluator that
