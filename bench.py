@@ -388,7 +388,7 @@ def config_legs():
         depth_d, rgb_d = torch.from_numpy(depth_h).cuda(), torch.from_numpy(rgb_h).cuda()
         vol = ScalableTSDFVolume(voxel, SDF_TRUNC, max_blocks=max_blocks, max_points=s.width * s.height)
 
-        def run(extract):
+        def run(extract, dtype=None):
             vol.reset()
             vol.synchronize()
             t0 = time.perf_counter()
@@ -396,7 +396,7 @@ def config_legs():
             for lo in range(0, n_frames, B):
                 vol.integrate_batch(depth_d[lo:lo + B], rgb_d[lo:lo + B], K, T_h[lo:lo + B], depth_scale=1.0, depth_trunc=DEPTH_TRUNC)
                 if extract and mesh_every and (lo + B) % mesh_every == 0:
-                    tri = len(vol.extract_triangle_mesh().triangles)
+                    tri = len(vol.extract_triangle_mesh(dtype=dtype).triangles)
             vol.synchronize()
             torch.cuda.synchronize()
             return time.perf_counter() - t0, tri
@@ -409,6 +409,9 @@ def config_legs():
             t_all, tri = run(True)
             leg["with_mesh_every_%d_frames" % mesh_every] = {"value": round(n_frames / t_all, 1), "unit": "frames/s", "triangles_last": int(tri),
                                                               "what": "extract_triangle_mesh (host-visible result, D2H included) after every 10th frame"}
+            run(True, np.float32)  # (page-locks the float32 result arrays)
+            leg["with_float32_mesh_every_%d_frames" % mesh_every] = {"value": round(n_frames / run(True, np.float32)[0], 1), "unit": "frames/s",
+                                                                      "what": "the same with extract_triangle_mesh(dtype=np.float32) (opt-in: Open3D's arrays are float64)"}
         out[key] = leg
         del vol, depth_d, rgb_d
     try:
