@@ -25,5 +25,5 @@ pmc_pass FETCH_SIZE FETCH_SIZE
 pmc_pass WRITE_SIZE WRITE_SIZE
 pmc_pass sq SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM GRBM_GUI_ACTIVE
 pmc_pass tcp TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum
-python $R/tools/pmc_summary.py --json $O/pmc_summary.json --command-key "$KEY" --range k_tsdf_sweep:$LO:$HI --range k_tsdf_prep_touch_batch:$LO:$HI --range k_tsdf_batch_finish:$LO:$HI --also k_unit_masks:4:5:@full --also k_mc_classify:3:4:@full --range k_unit_masks:1:4 --range k_mc_classify:1:3 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq $O/pmc_tcp > $O/pmc_summary.txt
+python $R/tools/pmc_summary.py --json $O/pmc_summary.json --command-key "$KEY" --range k_tsdf_sweep:$LO:$HI --range k_tsdf_prep_touch_batch:$LO:$HI --range k_tsdf_batch_finish:$LO:$HI --also k_unit_masks:6:7:@full --also k_mc_classify:5:6:@full --range k_unit_masks:1:6 --range k_mc_classify:1:5 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq $O/pmc_tcp > $O/pmc_summary.txt
 cat $O/pmc_summary.txt
