@@ -534,15 +534,15 @@ class VolumetricIntegratorBase:
     def pop_output(self, timeout=Parameters.kLoopDetectingTimeoutPopKeyframe):  # base.py:1320-1342
         if self.is_running.value == 0:
             return None
-        with self.q_out_condition:
-            while self.q_out.empty() and self.is_running.value == 1:
-                if not self.q_out_condition.wait(timeout=timeout):
-                    break
-        if self.q_out.empty():
-            return None
+        # The reference waits on q_out_condition while q_out.empty() and then get()s (same outcome: the next output, or None after
+        # `timeout`).  Its q_out is a manager queue, where an item is visible the moment put() returns; q_out here is an mp.Queue (a
+        # second pickle of a mesh through the manager is what the shared segment avoids), whose feeder thread delivers AFTER put()
+        # returns: a consumer woken by the worker's notify_all could find empty() still true, wait again and sleep out the whole
+        # timeout with the output already on its way (seen as sporadic +0.5 s ticks in bench.py's front leg).  get(timeout) blocks on
+        # the queue's pipe itself and wakes when the item is there.
         try:
             return st.import_arrays(self.q_out.get(timeout=timeout))
-        except Exception:
+        except Exception:  # queue.Empty after `timeout`, or the queue closed by quit()
             return None
 
     def _drop_task(self, task):
