@@ -6,12 +6,14 @@ For N > 1 the driver launches it with torch.distributed.run (one rank per GPU, R
 
 Workload (BASELINE.json configs[1]): synthetic 640x480 RGB-D stream (30 Hz camera on a 600-pose loop), 5 mm
 voxels, sdf_trunc 0.04 m, depth_trunc 4 m, Open3D ScalableTSDFVolume semantics.  A *step* fuses one batch of
-``--frames-per-step`` consecutive posed frames that are already resident in HBM; value = frames/s of the whole job.
+``--frames-per-step`` consecutive posed frames that are already resident in HBM (default 64: the width of the sweep's frame
+mask and what the drop-in front drains per call; rounds 1-5 and the first lines of round 6 used 32 - reported beside the headline
+as ``batch32``); value = frames/s of the whole job.
 
-``--window sliding`` (default, the headline): step k fuses frames 32k .. 32k+31 of the stream into ONE volume that
+``--window sliding`` (default, the headline): step k fuses frames Bk .. Bk+B-1 of the stream into ONE volume that
 is empty when the timed region starts (the warm-up steps run on the same frames and the volume is reset after
 them) — first-touch allocation of every unit and the frame-to-frame overlap of a moving camera are inside the
-timing.  ``--window replay``: every step re-fuses the same 32 frames (the round-1 figure; reported as the secondary
+timing.  ``--window replay``: every step re-fuses the same B frames (the round-1 figure; reported as the secondary
 key ``replay_mode`` at N = 1).
 
 N > 1 ("strong" scaling: total work is fixed): every rank sees every frame; --sharding owner (default): a unit is
@@ -199,7 +201,7 @@ def live_pmc(args, B, kernel_substr="k_tsdf_sweep"):
     return out
 
 
-def cpu_baseline_and_counts(s, depth, rgb, T, B, max_steps, budget_s, threads, window):
+def cpu_baseline_and_counts(s, depth, rgb, T, B, max_steps, budget_s, threads, window, extras=True):
     """Time the CPU restatement over the same stream step by step (bounded by budget_s) and collect the oracle
     counts the roofline figures need: per frame (touched units, updated voxels) and per batch (distinct units
     touched, distinct voxels updated)."""
@@ -215,7 +217,7 @@ def cpu_baseline_and_counts(s, depth, rgb, T, B, max_steps, budget_s, threads, w
         # code on ONE core (`single_core`) and on EVERY hardware thread (`all_hw_threads`) beside it, so that no choice is hidden
         threads = min(os.cpu_count() or 1, 32)
     single = every = None
-    if budget_s > 0 and (os.cpu_count() or 1) > threads:
+    if extras and budget_s > 0 and (os.cpu_count() or 1) > threads:
         allc = oracle.PortTsdf(VOXEL, SDF_TRUNC, threads=os.cpu_count())
         allc.integrate(depth[0], rgb[0], K, T[0], 1.0, DEPTH_TRUNC)
         t0 = time.perf_counter()
@@ -226,7 +228,7 @@ def cpu_baseline_and_counts(s, depth, rgb, T, B, max_steps, budget_s, threads, w
             na += 1
         every = {"value": round(na / (time.perf_counter() - t0), 3), "unit": "frames/s", "cores": os.cpu_count(), "frames": na}
         del allc
-    if budget_s > 0:
+    if extras and budget_s > 0:
         one = oracle.PortTsdf(VOXEL, SDF_TRUNC, threads=1)
         one.integrate(depth[0], rgb[0], K, T[0], 1.0, DEPTH_TRUNC)
         t0 = time.perf_counter()
@@ -531,7 +533,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-step", type=int, default=32)
+    ap.add_argument("--frames-per-step", type=int, default=64, help="posed frames per integrate_batch call (<= 64: the sweep's frame mask; 64 is what the drop-in front drains per call)")
     ap.add_argument("--clock-ramp-steps", type=int, default=60, help="untimed steps before the warm-up steps (device clock ramp, ~40 ms)")
     ap.add_argument("--config", default="synthetic_640x480_5mm")
     ap.add_argument("--window", choices=["sliding", "replay"], default="sliding")
@@ -695,7 +697,7 @@ def main():
     secondary = world == 1 and args.mode == "batch" and not args.no_secondary
 
     # ---- secondary legs (single GPU): extraction of the volume just built, replay figure, online mode ----
-    extraction = replay = online = None
+    extraction = replay = online = batch32 = None
     secondary_error = None
     try:
         if secondary:
@@ -822,7 +824,7 @@ def main():
             vol.profile_enable(False)
             replay = {"value": round(n_rep * B / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / n_rep * 1e3, 4),
                       "sweep_avg_launch_us": round(rep_ms / max(rep_launches, 1) * 1e3, 2),
-                      "what": "every step re-fuses frames 0..31 (maximum frustum overlap, nothing allocated in the timed region)"}
+                      "what": f"every step re-fuses frames 0..{B - 1} (maximum frustum overlap, nothing allocated in the timed region)"}
             # online mode on the sliding stream, fresh volume
             vol.reset()
             fence()
@@ -837,6 +839,32 @@ def main():
             vol.profile_read()
             vol.profile_enable(False)
             online = {"fps": n_on * B / dt, "launch_ms": on_launch_ms, "steps": n_on}
+            # the headline's stream in calls of 32 frames (the batch size of rounds 1-5 and of round 6's earlier lines): same frames, same
+            # clock procedure (warm-up, reset, timed steps on an empty volume), twice the launches
+            if B > 32:
+                B32 = 32
+                n32 = args.steps * B // B32
+
+                def step32(k):
+                    lo = (k * B32) % n_distinct
+                    vol.integrate_batch(depth_d[lo:lo + B32], rgb_d[lo:lo + B32], Kcam, T_res[lo:lo + B32], depth_scale=1.0, depth_trunc=DEPTH_TRUNC)
+
+                vol.reset()
+                for k in range(args.warmup):
+                    step32(k)
+                fence()
+                vol.reset()
+                fence()
+                vol.profile_enable(True)
+                t1 = time.perf_counter()
+                for k in range(n32):
+                    step32(k)
+                fence()
+                dt = time.perf_counter() - t1
+                b32_launch_ms = vol.profile_launches()
+                vol.profile_read()
+                vol.profile_enable(False)
+                batch32 = {"fps": n32 * B32 / dt, "ms_per_step": dt / n32 * 1e3, "launch_ms": b32_launch_ms, "steps": n32}
 
 
     except Exception as e:  # a secondary leg must never cost the headline line
@@ -886,6 +914,15 @@ def main():
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": int(n_cov), "frames_per_launch": B,
                         "voxel_visits_per_launch": int(visits / n_cov)}
             roofline["traffic_source"] = traffic_source
+            # SURVEY 8d's PER-FRAME byte model beside it (what B successive one-frame integrations of the same frames would move): the
+            # batch reads and writes a unit once per launch instead of once per frame - reuse, not bandwidth, is why frames/s exceed what
+            # the per-frame model allows at 8 TB/s
+            per_frame = sum((t * UNIT_BYTES + u * BYTES_PER_VOXEL) for st in cpu["steps"][:n_cov] for t, u in zip(st["touched"], st["updated"])) / world
+            roofline["per_frame_model"] = {"algorithmic_bytes_per_frame": int(per_frame / (n_cov * B)), "equivalent_GBs": round(per_frame / t_cov / 1e9, 1),
+                                           "batch_bytes_over_per_frame_bytes": round(alg / per_frame, 4),
+                                           "what": "SURVEY 8d: touched units x 81 920 B + updated voxels x 20 B PER FRAME, summed over the launch's frames, / the "
+                                                   "launch duration: the rate B one-frame integrations would need for the same frames/s (above the HBM peak: a "
+                                                   "launch moves each unit once for all its frames)"}
             try:
                 copy_gbs = d2d_copy_gbs()
                 roofline["peak_measured"] = {"value": round(copy_gbs, 1), "unit": "GB/s", "frac": round(alg / t_cov / 1e9 / copy_gbs, 4),
@@ -935,8 +972,8 @@ def main():
                 "workload": f"{args.config}: synthetic 640x480 RGB-D @ 30 Hz stream, 5 mm TSDF (sdf_trunc 0.04 m, depth_trunc 4 m), "
                             f"{B} posed frames per step resident in HBM, Open3D ScalableTSDFVolume semantics",
                 "frames_per_step": B,
-                "window": ("sliding: step k fuses frames 32k..32k+31 of the 600-pose loop into one volume that is empty when the timed region starts"
-                           if args.window == "sliding" else "replay: every step re-fuses frames 0..31"),
+                "window": (f"sliding: step k fuses frames {B}k..{B}k+{B - 1} of the 600-pose loop into one volume that is empty when the timed region starts"
+                           if args.window == "sliding" else f"replay: every step re-fuses frames 0..{B - 1}"),
                 "mode": "multi-frame sweep (hv_tsdf_integrate_batch)" if args.mode == "batch" else "one hv_tsdf_integrate per frame",
                 "sharding": "single spatial tile" if world == 1 else (
                     f"unit ownership: unit -> GPU hash(index) % {world}; every GPU sees every frame, fuses and stores only its "
@@ -1002,6 +1039,24 @@ def main():
                                   "algorithmic_bytes_per_launch": int(alg / n_l), "avg_launch_us": round(t_l / n_l * 1e6, 2), "launches": int(n_l),
                                   "frames_per_launch": 1}
             out["online_mode"] = om
+        if batch32 is not None:
+            b32 = {"value": round(batch32["fps"], 2), "unit": "frames/s", "frames_per_step": 32, "steps": batch32["steps"],
+                   "ms_per_step": round(batch32["ms_per_step"], 4),
+                   "what": "the same stream in calls of 32 frames (the headline's batch size of rounds 1-5): twice the launches, each unit's slab "
+                           "read and written twice as often per frame - a shorter launch moves more algorithmic bytes per second (higher roofline "
+                           "fraction) and fuses fewer frames per second", "roofline": None}
+            if cpu is not None:
+                try:  # the oracle's batch-level counts for 32-frame batches (a counts-only pass over the first 640 frames of the stream)
+                    c32 = cpu_baseline_and_counts(s, depth_h, rgb_h, T_h, 32, min(batch32["steps"], 20), 60.0, cpu["threads"], args.window, extras=False)
+                    n_cov = min(len(c32["steps"]), len(batch32["launch_ms"]))
+                    t_cov = float(np.sum(batch32["launch_ms"][:n_cov])) * 1e-3
+                    alg = sum(st["union_units"] * UNIT_BYTES + st["union_voxels"] * BYTES_PER_VOXEL for st in c32["steps"][:n_cov])
+                    b32["roofline"] = {"bound": "hbm", "kernel": "k_tsdf_sweep_column", "achieved": round(alg / t_cov / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(alg / t_cov / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(alg / n_cov),
+                                       "avg_launch_us": round(t_cov / n_cov * 1e6, 2), "launches": int(n_cov), "frames_per_launch": 32}
+                except Exception as e:
+                    b32["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+            out["batch32"] = b32
         if replay is not None:
             out["replay_mode"] = replay
         if extraction is not None:
@@ -1015,7 +1070,7 @@ def main():
                              ("tum1_640x480_5mm", lambda: __import__("tools.bench_tum", fromlist=["tum_leg"]).tum_leg(
                                  h2d_gbs=(out.get("host_mode") or {}).get("h2d_pinned_GBs"))),
                              ("configs", config_legs),
-                             ("voxel_grid", lambda: voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, min(B, n_distinct), 5, 6)),
+                             ("voxel_grid", lambda: voxel_grid_leg(s, depth_h, rgb_h, T_h, depth_d, rgb_d, min(32, n_distinct), 5, 6)),  # (32 frames: the leg of rounds 3-6, whatever the headline's batch)
                              ("semantic", lambda: __import__("tools.bench_semantic", fromlist=["semantic_leg"]).semantic_leg(26, 2, 0.01)),  # (24 timed keyframes: with 8 - rounds 3-6a - the timed region was 1.6 ms and one hiccup 10 % of it)
                              # 12 keyframes, 10 inside the clock: with 3 (rounds 4-5) the first keyframe's 19 MB upload - 0.33 ms that
                              # nothing can hide - was a sixth of the measurement; a backlog's steady state is what the figure is for

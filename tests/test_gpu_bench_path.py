@@ -1,8 +1,8 @@
 """GPU parity of the EXACT code path and configuration bench.py times.
 
-bench.py's step = ``ScalableTSDFVolume.integrate_batch`` with B = 32 posed frames of
+bench.py's step = ``ScalableTSDFVolume.integrate_batch`` with B = 64 posed frames (32 in rounds 1-5 and in the ``batch32`` leg) of
 ``synthetic_640x480_5mm`` at voxel 0.005 m / sdf_trunc 0.04 m / depth_trunc 4 m, batches taken as a sliding
-window over the stream (step k fuses frames 32k .. 32k+31 into the same volume).  These tests run that call
+window over the stream (step k fuses frames Bk .. Bk+B-1 into the same volume).  These tests run that call
 with those arguments against ``oracle.PortTsdf`` and compare the FULL dump: unit keys and weights exact, colour
 <= 1e-4 (north-star tolerance; reference call sites pyslam/dense/volumetric_integrator_tsdf.py:215-223,260), tsdf
 within ``FOLD_TSDF_TOL`` = 5e-6 for the production (fold) form of the sweep - which applies one running-mean step per
@@ -22,7 +22,7 @@ from tests.conftest import (FOLD_TSDF_TOL, assert_dumps_match, assert_tsdf_parit
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-VOXEL, SDF_TRUNC, DEPTH_TRUNC, B = 0.005, 0.04, 4.0, 32  # == bench.py VOXEL / SDF_TRUNC / DEPTH_TRUNC / --frames-per-step
+VOXEL, SDF_TRUNC, DEPTH_TRUNC, B = 0.005, 0.04, 4.0, 32  # == bench.py VOXEL / SDF_TRUNC / DEPTH_TRUNC; B: the batch32 leg (the default step of 64 frames: test_bench_step_sliding_window_matches_oracle[*-64])
 THREADS = min(32, os.cpu_count() or 1)
 
 
@@ -44,25 +44,27 @@ def batch_arrays(frames):
     return np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), np.stack([f[2] for f in frames])
 
 
-def test_bench_step_b32_sliding_window_matches_oracle(sweep_form):
-    """Two consecutive bench steps (frames 0..31, then 32..63) through integrate_batch, device-resident inputs as in
-    bench.py, against the oracle fusing the same 64 frames one by one."""
+@pytest.mark.parametrize("batch", [32, 64])
+def test_bench_step_sliding_window_matches_oracle(sweep_form, batch):
+    """The bench's steps over frames 0..63 through integrate_batch, device-resident inputs as in bench.py - two consecutive steps of
+    32 frames (the batch size of rounds 1-5, bench.py's ``batch32`` leg) or ONE step of 64 (bench.py's default since round 6: the width
+    of the sweep's frame mask) - against the oracle fusing the same 64 frames one by one."""
     import torch
     from pyslam_amd.volumetric import PinholeCameraIntrinsic, ScalableTSDFVolume
 
-    s, frames = synthetic_frames("synthetic_640x480_5mm", 0, 2 * B)
+    s, frames = synthetic_frames("synthetic_640x480_5mm", 0, 64)
     K = PinholeCameraIntrinsic(s.width, s.height, *s.intrinsics)
     gpu = ScalableTSDFVolume(VOXEL, SDF_TRUNC, max_blocks=1 << 15)
     cpu = oracle.PortTsdf(VOXEL, SDF_TRUNC, threads=THREADS)
-    for step in range(2):
-        depth, rgb, T = batch_arrays(frames[step * B:(step + 1) * B])
+    for step in range(64 // batch):
+        depth, rgb, T = batch_arrays(frames[step * batch:(step + 1) * batch])
         gpu.integrate_batch(torch.from_numpy(depth).cuda(), torch.from_numpy(rgb).cuda(), K, T, depth_scale=1.0,
                             depth_trunc=DEPTH_TRUNC)
-        for f in frames[step * B:(step + 1) * B]:
+        for f in frames[step * batch:(step + 1) * batch]:
             cpu.integrate(f[0], f[1], K.as_array(), f[2], 1.0, DEPTH_TRUNC)
         assert gpu.num_blocks() == cpu.num_units()
     n_units, w_max = assert_same_volume_chunked(gpu, cpu)
-    assert n_units > 6000 and w_max >= 2 * B - 8  # revisits really happened across the two batches
+    assert n_units > 6000 and w_max >= 64 - 8  # revisits really happened across the 64 frames
     assert gpu.dropped_points() == 0
 
 

@@ -11,7 +11,7 @@ mkdir -p gpurun_out profiles/$ROUND
 ( time timeout 1200 python -m pytest tests -m gpu -q --durations=5 ) > gpurun_out/pytest_gpu.log 2>&1
 tail -12 gpurun_out/pytest_gpu.log
 # frame caches first: the generator's worker processes must not start under the profiler
-timeout 400 python -c "import bench; bench.load_frames('synthetic_640x480_5mm', 600); bench.load_frames('synthetic_640x480_5mm', 32); bench.load_frames('synthetic_640x480_5mm', 192); from tools import bench_tum; bench_tum.tum_frames(192)" > /dev/null 2>&1
+timeout 400 python -c "import bench; bench.load_frames('synthetic_640x480_5mm', 600); bench.load_frames('synthetic_640x480_5mm', 32); bench.load_frames('synthetic_640x480_5mm', 64); bench.load_frames('synthetic_640x480_5mm', 192); from tools import bench_tum; bench_tum.tum_frames(192)" > /dev/null 2>&1
 bash tools/profile_round.sh > gpurun_out/profile_round.log 2>&1
 tail -5 gpurun_out/profile_round.log | cut -c1-300
 cp gpurun_out/prof_round/pmc_summary.json profiles/$ROUND/pmc_summary.json
@@ -45,7 +45,7 @@ grep -E "sem|shadow" gpurun_out/sem2_pmc_summary.txt | cut -c1-200 | head -8
 timeout 200 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; tail -1 gpurun_out/smoke.log
 timeout 900 python bench.py > gpurun_out/bench_n1.log 2>&1
 grep '^{"metric"' gpurun_out/bench_n1.log > gpurun_out/bench_n1.json; cut -c1-1500 gpurun_out/bench_n1.json
-timeout 250 python tools/sweep_variants.py --steps 18 --warmup 3 --repeat 3 "HV_TSDF_SWEEP=4" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_ZS=2" "HV_TSDF_SWEEP=4 HV_TSDF_PIPELINE=0" "HV_TSDF_SWEEP=2" 2>/dev/null | tail -4 > gpurun_out/sweep_forms.jsonl; cut -c1-200 gpurun_out/sweep_forms.jsonl
+timeout 250 python tools/sweep_variants.py --steps 9 --warmup 3 --repeat 3 "HV_TSDF_SWEEP=4" "HV_TSDF_SWEEP=4 HV_TSDF_SWEEP_ZS=2" "HV_TSDF_SWEEP=4 HV_TSDF_PIPELINE=0" "HV_TSDF_SWEEP=2" 2>/dev/null | tail -4 > gpurun_out/sweep_forms.jsonl; cut -c1-200 gpurun_out/sweep_forms.jsonl
 for SH in owner tile; do
   BENCH_LIVE_PMC=0 timeout 300 python bench.py --force-dist --sharding $SH --steps 6 --warmup 2 --clock-ramp-steps 4 --no-secondary --no-cpu-baseline > gpurun_out/bench_nccl1_$SH.log 2>&1
   grep '^{"metric"' gpurun_out/bench_nccl1_$SH.log > gpurun_out/bench_nccl1_$SH.json; python -c "

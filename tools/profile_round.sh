@@ -11,8 +11,9 @@ O=$R/gpurun_out/prof_round
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-20}; WARM=${WARM:-5}; RAMP=${RAMP:-60}   # bench.py runs RAMP clock-ramp steps, then WARM warm-up steps, then the timed STEPS
-KEY="steps=$STEPS warmup=$WARM B=32 window=sliding config=synthetic_640x480_5mm"
-BENCH="python $R/bench.py --steps $STEPS --warmup $WARM --clock-ramp-steps $RAMP --no-cpu-baseline"
+FB=${FB:-64}   # frames per step (bench.py --frames-per-step)
+KEY="steps=$STEPS warmup=$WARM B=$FB window=sliding config=synthetic_640x480_5mm"
+BENCH="python $R/bench.py --steps $STEPS --warmup $WARM --frames-per-step $FB --clock-ramp-steps $RAMP --no-cpu-baseline"
 LO=$((WARM+STEPS+RAMP+WARM)); HI=$((LO+STEPS))   # bench.py: cold pass (WARM + STEPS), ramp, warm-up, then the timed steps
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- $BENCH > $O/kt.log 2>&1
 cp $O/kt/bench_kernel_stats.csv $O/rocprofv3_kernel_stats.csv 2>/dev/null || find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_kernel_stats.csv \;

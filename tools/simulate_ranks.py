@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--frames-per-step", type=int, default=32)
+    ap.add_argument("--frames-per-step", type=int, default=64)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--mode", default="batch")
     ap.add_argument("--worlds", default="1,2,4,8")

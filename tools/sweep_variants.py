@@ -1,6 +1,6 @@
 """A/B of the multi-frame sweep's switches inside ONE process (a gpurun call is charged for the box, not only for the run:
 one import of torch, one synthetic stream, many variants).  Every variant times bench.py's headline step - sliding window,
-B = 32 posed 640x480 frames resident in HBM, 5 mm - on a volume that is empty when the clock starts, and reports frames/s and
+B = 64 posed 640x480 frames (--frames-per-step) resident in HBM, 5 mm - on a volume that is empty when the clock starts, and reports frames/s and
 the sweep kernel's mean launch duration (HIP events on its stream).
 
 usage: python tools/sweep_variants.py [--steps 12] [--warmup 3] 'HV_TSDF_SWEEP=4' 'HV_TSDF_SWEEP=2' ...
@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=32)
+    ap.add_argument("--frames-per-step", type=int, default=64)
     ap.add_argument("--config", default="synthetic_640x480_5mm")
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--owner", default="", help="rank/world: time one rank's share of the unit-ownership sharding (hv_tsdf_set_owner)")
