@@ -933,6 +933,11 @@ def main():
             if traffic:
                 roofline["traffic_GBs"] = hbm["traffic_GBs"]
                 roofline["traffic_over_algorithmic"] = hbm["traffic_over_algorithmic"]
+                rec_bytes = B * s.width * s.height * 12
+                roofline["traffic_note"] = (f"beyond the algorithmic bytes the counters see the launch's frame records - {B} frames x {s.width * s.height} pixels x 12 B = "
+                                            f"{rec_bytes / 1e6:.0f} MB, gathered once per voxel visit - arriving in each of the 8 XCDs' L2s: up to 8 x {rec_bytes / 1e6:.0f} MB "
+                                            f"= {8 * rec_bytes / 1e9:.2f} GB of fabric requests, served by the 256 MB Infinity Cache, which FETCH_SIZE counts "
+                                            f"(MI355X_MICROARCH.md, HBM section); the planes themselves move once per launch")
             tf = FLOP_PER_VISIT * visits / t_cov / 1e12
             roofline["flops"] = {"achieved": round(tf, 2), "peak": VECTOR_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / VECTOR_F32_PEAK_TFLOPS, 4),
                                  "what": f"{FLOP_PER_VISIT} flop per voxel visit (SURVEY 8d) x the oracle's visits (touched units x 4096, per frame) vs the vector fp32 peak"}
