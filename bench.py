@@ -541,6 +541,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline; 0 = min(os.cpu_count(), 32) (the stated policy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the replay / online / extraction / voxel-grid legs (profiling runs)")
+    ap.add_argument("--no-batch32", action="store_true", help="skip the 32-frames-per-call leg (profiling runs: every sweep launch of the command is then a --frames-per-step one)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group (and run every barrier / all-reduce / all-gather of the N > 1 line) with ONE rank: "
@@ -841,7 +842,7 @@ def main():
             online = {"fps": n_on * B / dt, "launch_ms": on_launch_ms, "steps": n_on}
             # the headline's stream in calls of 32 frames (the batch size of rounds 1-5 and of round 6's earlier lines): same frames, same
             # clock procedure (warm-up, reset, timed steps on an empty volume), twice the launches
-            if B > 32:
+            if B > 32 and not args.no_batch32:
                 B32 = 32
                 n32 = args.steps * B // B32
 

@@ -10,6 +10,7 @@ for f in bench_n1.json bench_n8_owner.json bench_n8_tile.json bench_nccl1_owner.
 done
 cp gpurun_out/prof_round/pmc_summary.json $P/pmc_summary.json
 cp gpurun_out/prof_round/pmc_summary.txt $P/pmc_summary.txt 2>/dev/null
+cp gpurun_out/prof_round/sweep_timed_launches.txt $P/sweep_timed_launches.txt 2>/dev/null
 find gpurun_out/prof_round -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $P/rocprofv3_kernel_stats.csv
 cp gpurun_out/vg_kernel_stats.csv $P/kernel_stats_voxel_grid.csv
 cp gpurun_out/sem_kernel_stats.csv $P/kernel_stats_semantic.csv

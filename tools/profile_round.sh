@@ -13,11 +13,21 @@ cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-20}; WARM=${WARM:-5}; RAMP=${RAMP:-60}   # bench.py runs RAMP clock-ramp steps, then WARM warm-up steps, then the timed STEPS
 FB=${FB:-64}   # frames per step (bench.py --frames-per-step)
 KEY="steps=$STEPS warmup=$WARM B=$FB window=sliding config=synthetic_640x480_5mm"
-BENCH="python $R/bench.py --steps $STEPS --warmup $WARM --frames-per-step $FB --clock-ramp-steps $RAMP --no-cpu-baseline"
+BENCH="python $R/bench.py --steps $STEPS --warmup $WARM --frames-per-step $FB --clock-ramp-steps $RAMP --no-cpu-baseline --no-batch32"
 LO=$((WARM+STEPS+RAMP+WARM)); HI=$((LO+STEPS))   # bench.py: cold pass (WARM + STEPS), ramp, warm-up, then the timed steps
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- $BENCH > $O/kt.log 2>&1
 cp $O/kt/bench_kernel_stats.csv $O/rocprofv3_kernel_stats.csv 2>/dev/null || find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/rocprofv3_kernel_stats.csv \;
 cut -c1-200 $O/rocprofv3_kernel_stats.csv
+# the sweep launches of the TIMED steps alone (the stats table above averages every launch of the process: cold pass, ramp, warm-up, replay leg)
+python - "$O" $LO $HI <<'PY' > $O/sweep_timed_launches.txt
+import csv, glob, sys
+o, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+rows = sorted(csv.DictReader(open(glob.glob(o + "/kt/**/*kernel_trace.csv", recursive=True)[0])), key=lambda r: int(r["Start_Timestamp"]))
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "k_tsdf_sweep_column" in r["Kernel_Name"]]
+t = d[lo:hi]
+print(f"k_tsdf_sweep_column: {len(d)} launches in the process, mean {sum(d) / len(d):.1f} us; launches {lo}..{hi - 1} (the timed steps): mean {sum(t) / len(t):.1f} us, min {min(t):.1f}, max {max(t):.1f}")
+PY
+cat $O/sweep_timed_launches.txt
 pmc_pass() { # name, counters...
   local name=$1; shift
   timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$name -o pmc -- $BENCH > $O/pmc_$name.log 2>&1
