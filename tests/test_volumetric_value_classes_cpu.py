@@ -41,3 +41,17 @@ def test_tbb_utils_like_the_reference_script():
     assert TBBUtils.set_max_threads(4) == 4 and TBBUtils.get_max_threads() == 4
     assert TBBUtils.set_max_threads(before) == before and TBBUtils.get_max_threads() == before
     assert TBBUtils.set_max_threads(0) >= 1  # <= 0: the default
+
+
+def test_extraction_dtype_argument_is_float64_or_float32():
+    """extract_triangle_mesh / extract_point_cloud(dtype=...): Open3D's float64 (default) or float32 (hv_tsdf_extract_mesh_f32 /
+    _points_f32); anything else is refused before the library is called."""
+    import pytest
+
+    from pyslam_amd.volumetric import ScalableTSDFVolume
+
+    assert ScalableTSDFVolume._out_dtype(None) == np.float64 and ScalableTSDFVolume._out_dtype("float32") == np.float32
+    assert ScalableTSDFVolume._out_dtype(np.float64) == np.float64 and ScalableTSDFVolume._out_dtype(np.dtype("f4")) == np.float32
+    for bad in (np.float16, np.int32, "uint8"):
+        with pytest.raises(TypeError):
+            ScalableTSDFVolume._out_dtype(bad)
