@@ -161,6 +161,19 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
         # assign_object_ids_to_instance_ids - in the reference as well (iterate_voxels_in_camera_frustrum); one record each
         fr.set_T_cw(frames[-1][2])
         n_view = int(len(g.get_voxels_in_camera_frustrum(fr, 1, 0.0).points))
+        # ... and at EVERY timed keyframe (an untimed second pass over the same stream on the cleared grid: the voxels in view of
+        # keyframe k BEFORE it is fused - what its association looks at; the view fills up as the map grows)
+        views = []
+        if not host_flow and args.cpu_frames > 0:  # (like the parity check below: not in the profiled commands, --cpu-frames 0, whose launches are counted per keyframe)
+            g.clear()
+            set_next_object_id(1)
+            for k, frame in enumerate(frames):
+                if k >= 2:
+                    fr.set_T_cw(frame[2])
+                    views.append(int(len(g.get_voxels_in_camera_frustrum(fr, 1, 0.0).points)))
+                run([frame])
+                g.synchronize()
+        n_view_mean = float(np.mean(views)) if views else float(n_view)
         res = {"value": round(fps, 1),
                "roofline": {"bound": "hbm", "what": "the WHOLE per-keyframe flow (shadow filter, association, remap, integrate), not one kernel: "
                             f"algorithmic bytes = 2 x {rec} B x distinct voxels touched (oracle keys) + 15 B / pixel of inputs",
@@ -168,9 +181,14 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
                             "frac": round(alg * fps / 1e9 / 8000.0, 5), "traffic": None,
                             "association": {"voxels_in_view_last_keyframe": n_view, "bytes": int(rec * n_view),
                                             "algorithmic_bytes_with_association": int(alg + rec * n_view),
+                                            "voxels_in_view_mean_over_timed_keyframes": int(n_view_mean),
+                                            "algorithmic_bytes_with_association_mean": int(alg + rec * n_view_mean),
+                                            "frac_with_association": round((alg + rec * n_view_mean) * fps / 1e9 / 8000.0, 5),
                                             "what": "assign_object_ids_to_instance_ids looks at every voxel in the keyframe's view once (the reference "
                                                     "does too): one record each, counted at the LAST keyframe of the stream (the view fills up as the "
-                                                    "map grows); not part of algorithmic_bytes_per_keyframe"}},
+                                                    "map grows) and - *_mean - before every timed keyframe in an untimed second pass; not part of "
+                                                    "algorithmic_bytes_per_keyframe; frac_with_association = (integrate bytes + mean association bytes) x "
+                                                    "keyframes/s / 8 TB/s"}},
                "get_voxels_ms": round(t_get * 1e3, 2), "voxels_out": int(len(v.points)),
                "get_object_segments_ms": round(t_seg * 1e3, 2), "objects": len(segs.object_vector), "blocks": int(g.num_blocks()),
                "label_overflows": g.label_overflows()}
@@ -180,6 +198,7 @@ def semantic_leg(n_frames=24, cpu_frames=4, voxel=0.01, config="synthetic_640x48
             res["roofline"]["traffic"] = traffic
             res["roofline"]["traffic_over_algorithmic"] = round(traffic / alg, 2)
             res["roofline"]["traffic_over_algorithmic_with_association"] = round(traffic / (alg + rec * n_view), 2)
+            res["roofline"]["traffic_over_algorithmic_with_association_mean"] = round(traffic / (alg + rec * n_view_mean), 2)
             res["roofline"]["traffic_per_kernel"] = per
             res["roofline"]["traffic_source"] = "recorded rocprofv3 --pmc passes of tools/bench_semantic.py on this build (profiles/, build digest checked)"
         if oracle.ref_available() and args.cpu_frames > 0:
